@@ -1,0 +1,194 @@
+/*
+ * gcsa2_hip.h -- C ABI of the MI355X batched backward-search engine for GCSA2 indexes.
+ *
+ * This is the drop-in boundary for the query hot path of jltsiren/gcsa2: every entry point
+ * below replaces a method of `gcsa::GCSA` / `gcsa::LCPArray` that the reference implements as
+ * header-inline C++ over SDSL bitvectors (citations are relative to the reference tree).
+ * The reference has no FFI of its own -- its boundary is a C++ class API -- so this header is
+ * what a C++ facade (include/gcsa2_hip/gcsa.hpp), a cgo/JNI stub or the ctypes binding in
+ * gcsa2_amd/binding.py binds.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - All index data are described by plain LSB-first bit arrays (bit i of a vector lives in
+ *     word i >> 6 at position i & 63, as in SDSL) and plain integer arrays.  The engine builds
+ *     its own device image from them; nothing is kept by reference after create() returns.
+ *   - Every bit array must be readable for ceil(bits / 64) whole words.
+ *   - Ranges are closed [sp, ep] pairs of uint64 as in `gcsa::range_type`
+ *     (include/gcsa/utils.h:84); a range is empty iff sp + 1 > ep + 1 (utils.h:93-96).
+ *   - `*_batch` entry points take HOST pointers, copy in, run the kernels, copy out and
+ *     synchronise.  `*_device` entry points take DEVICE pointers on the handle's device, only
+ *     enqueue work on `stream` (a hipStream_t passed as void*, NULL = default stream) and do
+ *     not synchronise -- they are what the benchmark and the multi-GPU driver use.
+ *   - Return value: GCSA2_OK (0) or a negative gcsa2_status.  Query entry points do not
+ *     validate ranges or comps, exactly like the reference's low-level interface
+ *     (include/gcsa/gcsa.h:133-135); count/locate apply the reference's `ep >= size()` guard.
+ *   - A handle is immutable after creation and may be used from several host threads.
+ */
+#ifndef GCSA2_HIP_H
+#define GCSA2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gcsa2_status {
+  GCSA2_OK = 0,
+  GCSA2_ERR_INVALID_ARGUMENT = -1,
+  GCSA2_ERR_NO_DEVICE = -2,     /* no HIP device / runtime failure at init */
+  GCSA2_ERR_OUT_OF_MEMORY = -3,
+  GCSA2_ERR_HIP = -4,           /* any other HIP runtime error; see gcsa2_last_error() */
+  GCSA2_ERR_MISSING_COMPONENT = -5, /* e.g. count() without counters, parent() without LCP */
+  GCSA2_ERR_BUFFER_TOO_SMALL = -6
+} gcsa2_status;
+
+/*
+ * Host-side description of one index = the data members of gcsa::GCSA
+ * (include/gcsa/gcsa.h:214-240) and gcsa::LCPArray (include/gcsa/lcp.h:188-190) as plain arrays.
+ */
+typedef struct gcsa2_host_view {
+  /* GCSAHeader (include/gcsa/files.h:135-156) */
+  uint64_t path_nodes;            /* header.path_nodes = size() */
+  uint64_t edges;                 /* header.edges */
+  uint64_t order;                 /* header.order */
+
+  /* Alphabet (include/gcsa/support.h:93-155) */
+  uint64_t sigma;                 /* alpha.sigma, 1..GCSA2_MAX_SIGMA */
+  uint64_t fast_chars;            /* alpha.fast_chars (informational: every comp is stored densely) */
+  const uint8_t*  char2comp;      /* alpha.char2comp, 256 entries */
+  const uint64_t* C;              /* alpha.C, sigma + 1 entries */
+
+  /* fast_bwt[1..fast_chars] / sparse_bwt[0, fast_chars+1..] as plain bits: bwt[c], path_nodes bits */
+  const uint64_t* const* bwt;     /* sigma pointers */
+  const uint64_t* edge_bits;      /* edges, `edges` bits */
+  const uint64_t* sampled_path_bits; /* sampled_paths, path_nodes bits; NULL = no locate support */
+
+  /* stored_samples (sdsl::int_vector<0>) and samples (bit_vector) */
+  uint64_t sample_count;          /* stored_samples.size() */
+  uint64_t sample_width;          /* stored_samples.width(), 1..64 */
+  const uint64_t* stored_samples; /* packed: element i = bits [i*w, (i+1)*w) */
+  const uint64_t* sample_bits;    /* samples, sample_count bits */
+
+  /* extra_pointers (SadaSparse, include/gcsa/support.h:298-364); NULL filter = no count support */
+  const uint64_t* extra_filter_bits; /* filter, path_nodes bits */
+  uint64_t extra_values_len;         /* values.size() */
+  const uint64_t* extra_values_bits; /* values as plain bits */
+  /* redundant_pointers (SadaCount, include/gcsa/support.h:231-279) */
+  uint64_t redundant_len;            /* data.size() */
+  const uint64_t* redundant_bits;    /* data */
+
+  /* LCPArray (include/gcsa/lcp.h:182-190); lcp_data NULL = no parent/depth support */
+  uint64_t lcp_size;              /* header.size = number of leaves */
+  uint64_t lcp_branching;         /* header.branching */
+  uint64_t lcp_levels;            /* offsets.size() - 1 */
+  const uint64_t* lcp_offsets;    /* lcp_levels + 1 entries */
+  const uint8_t*  lcp_data;       /* data widened to bytes, lcp_offsets[lcp_levels] entries */
+} gcsa2_host_view;
+
+#define GCSA2_MAX_SIGMA 16
+
+typedef struct gcsa2_index gcsa2_index;   /* opaque; owns the device image */
+
+/* Suffix-tree node, field for field gcsa::STNode (include/gcsa/lcp.h:40-79). */
+typedef struct gcsa2_stnode {
+  uint64_t sp, ep;
+  uint64_t left_lcp, right_lcp;
+  uint64_t node_lcp;              /* GCSA2_UNKNOWN = STNode::UNKNOWN */
+} gcsa2_stnode;
+
+#define GCSA2_UNKNOWN (~(uint64_t)0)
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+
+/* Number of visible HIP devices, or a negative status. */
+int gcsa2_device_count(void);
+
+/* Build the device image of `view` on HIP device `device`.  Replaces GCSA::load + LCPArray::load
+ * followed by nothing: the reference queries host RAM in place (benchmark/query_gcsa.cpp:55,63). */
+int gcsa2_index_create(const gcsa2_host_view* view, int device, gcsa2_index** out);
+void gcsa2_index_destroy(gcsa2_index* index);
+
+/* Thread-local description of the last failing call. */
+const char* gcsa2_last_error(void);
+
+/* GCSAHeader accessors (include/gcsa/gcsa.h:137-148). */
+uint64_t gcsa2_size(const gcsa2_index* index);
+uint64_t gcsa2_edge_count(const gcsa2_index* index);
+uint64_t gcsa2_order(const gcsa2_index* index);
+uint64_t gcsa2_sample_count(const gcsa2_index* index);
+uint64_t gcsa2_sample_bits(const gcsa2_index* index);
+int      gcsa2_device(const gcsa2_index* index);
+/* Bytes of HBM held by the image. */
+uint64_t gcsa2_device_bytes(const gcsa2_index* index);
+/* Payload bits per rank block of the device layout (the unit of the roofline model). */
+uint64_t gcsa2_block_bits(const gcsa2_index* index);
+
+/* ---- find: GCSA::find(begin, end)  (include/gcsa/gcsa.h:96-122) ---------------------------- */
+
+/* patterns = concatenated pattern bytes, pattern q = patterns[offsets[q] .. offsets[q+1]).
+ * ranges[2q], ranges[2q+1] = (sp, ep), including the edge-space integers the reference returns
+ * for a range that empties inside LF (gcsa.h:160).  */
+int gcsa2_find_batch(const gcsa2_index* index, const uint8_t* patterns, const uint64_t* offsets,
+                     uint64_t n_queries, uint64_t* ranges);
+int gcsa2_find_device(const gcsa2_index* index, const uint8_t* d_patterns,
+                      const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
+                      void* stream);
+
+/* ---- LF: GCSA::LF(range, comp) (gcsa.h:155-162), GCSA::LF(path_node) (gcsa.h:165-183),
+ *      GCSA::charRange(comp) (gcsa.h:150-153) ------------------------------------------------- */
+int gcsa2_lf_batch(const gcsa2_index* index, const uint64_t* ranges_in, const uint8_t* comps,
+                   uint64_t n_queries, uint64_t* ranges_out);
+int gcsa2_lf_device(const gcsa2_index* index, const uint64_t* d_ranges_in, const uint8_t* d_comps,
+                    uint64_t n_queries, uint64_t* d_ranges_out, void* stream);
+int gcsa2_lf_node_batch(const gcsa2_index* index, const uint64_t* nodes_in, uint64_t n_queries,
+                        uint64_t* nodes_out);
+int gcsa2_char_range(const gcsa2_index* index, uint8_t comp, uint64_t* sp, uint64_t* ep);
+/* GCSA::LF_fast / LF_all (src/gcsa.cpp:742-798): ranges_out holds sigma ranges per query,
+ * entries the reference leaves untouched are written as the empty range (1, 0).
+ * all = 0: comps 1..fast_chars; all = 1: comps 1..sigma-2. */
+int gcsa2_lf_all_batch(const gcsa2_index* index, const uint64_t* ranges_in, uint64_t n_queries,
+                       int all, uint64_t* ranges_out);
+
+/* ---- count: GCSA::count(range) (src/gcsa.cpp:802-809) -------------------------------------- */
+int gcsa2_count_batch(const gcsa2_index* index, const uint64_t* ranges, uint64_t n_queries,
+                      uint64_t* counts);
+int gcsa2_count_device(const gcsa2_index* index, const uint64_t* d_ranges, uint64_t n_queries,
+                       uint64_t* d_counts, void* stream);
+
+/* ---- locate: GCSA::locate(range, results, append=false, sort=true) (src/gcsa.cpp:827-842) --
+ * Two calls, CSR output.  locate_sizes runs the whole query (walk, sort, unique) and keeps the
+ * result on the device inside `*job`; offsets[q+1] - offsets[q] = number of distinct values of
+ * query q.  locate_fetch copies the values (offsets[n_queries] of them) and frees the job. */
+typedef struct gcsa2_locate_job gcsa2_locate_job;
+int gcsa2_locate_run(const gcsa2_index* index, const uint64_t* ranges, uint64_t n_queries,
+                     uint64_t* offsets /* n_queries + 1 */, gcsa2_locate_job** job);
+int gcsa2_locate_fetch(gcsa2_locate_job* job, uint64_t* values, uint64_t capacity);
+void gcsa2_locate_discard(gcsa2_locate_job* job);
+/* Device-resident form for pipelines and the benchmark: d_ranges in HBM; on return
+ * *d_offsets / *d_values point into memory owned by the job (valid until discard). */
+int gcsa2_locate_device(const gcsa2_index* index, const uint64_t* d_ranges, uint64_t n_queries,
+                        gcsa2_locate_job** job, const uint64_t** d_offsets,
+                        const uint64_t** d_values, uint64_t* total_values, void* stream);
+
+/* ---- suffix-tree operations: LCPArray::parent / depth / psv / psev / nsv / nsev / rmq
+ *      (include/gcsa/lcp.h:137-178, src/lcp.cpp:276-519) -------------------------------------- */
+int gcsa2_parent_batch(const gcsa2_index* index, const uint64_t* ranges, uint64_t n_queries,
+                       gcsa2_stnode* nodes);
+int gcsa2_parent_device(const gcsa2_index* index, const uint64_t* d_ranges, uint64_t n_queries,
+                        gcsa2_stnode* d_nodes, void* stream);
+int gcsa2_depth_batch(const gcsa2_index* index, const uint64_t* ranges, uint64_t n_queries,
+                      uint64_t* depths);
+/* op: 0 psv, 1 psev, 2 nsv, 3 nsev.  results[2q], results[2q+1] = (position, LCP value) or
+ * notFound() = (values(), values()). */
+int gcsa2_sv_batch(const gcsa2_index* index, int op, const uint64_t* positions,
+                   uint64_t n_queries, uint64_t* results);
+/* rmq(sp, ep): leftmost minimum of LCP[sp..ep] as (position, value), or notFound(). */
+int gcsa2_rmq_batch(const gcsa2_index* index, const uint64_t* ranges, uint64_t n_queries,
+                    uint64_t* results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCSA2_HIP_H */

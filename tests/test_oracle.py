@@ -1,0 +1,263 @@
+"""CPU tests pinning the oracle (oracle/gcsa_oracle.c).
+
+1. the paper's worked example (the only known-answer material in the reference tree),
+2. differential tests against tests/naive.py (array-level and input-graph-level brute force)
+   on seeded random graphs incl. bubbles, cycles, `N`s and repeated labels,
+3. the invariants `verifyIndex` asserts (reference src/algorithms.cpp:131-275).
+"""
+import numpy as np
+import pytest
+
+from workload import graphs
+from workload.brute_builder import build, node_table
+from workload.index_arrays import unpack_bits
+from workload.rng import SplitMix64
+from oracle.oracle import OracleIndex
+from gcsa2_amd.hostview import concat_patterns
+from naive import NaiveIndex, GraphBrute
+
+COMP2CHAR = "$ACGTN#"
+UNKNOWN = (1 << 64) - 1
+
+
+def bits_str(words, n):
+    return "".join("1" if b else "0" for b in unpack_bits(words, n))
+
+
+# ---------------------------------------------------------------------------------------------
+# 1. paper example
+
+def test_builder_reproduces_paper_figure(paper):
+    g = graphs.paper_graph()
+    ix = build(g, paper["order"], sample_period=1 << 40)
+    t = ix.table
+    assert ix.n == len(paper["nodes"]) == 16 and ix.e == 20
+    for i, node in enumerate(paper["nodes"]):
+        key = "".join(COMP2CHAR[c] for c in t.keys[i])
+        # the figure keeps the sink as `$$$`; maximal pruning names it `$`
+        assert key == node["key"] or (node["key"] == "$$$" and key == "$")
+        vals = [int(v) for v in t.vals[int(t.val_off[i]):int(t.val_off[i + 1])]]
+        assert vals == node["values"]
+        bwt = "".join(COMP2CHAR[c] for c in range(7) if (int(t.pred_mask[i]) >> c) & 1)
+        assert sorted(bwt) == sorted(node["bwt"])
+        assert int(t.outdeg[i]) == node["outdegree"]
+    assert [int(x) for x in ix.C] == paper["C"]
+    assert bits_str(ix.edges, ix.e) == paper["OUT"]
+    assert bits_str(ix.sampled_paths, ix.n) == paper["B_S"]
+    assert bits_str(ix.samples, ix.sample_count) == paper["B_V"]
+    assert [int(v) for v in ix.stored_samples_plain] == paper["V_S"]
+
+
+def test_oracle_on_paper_example(paper):
+    ix = build(graphs.paper_graph(), paper["order"], sample_period=1 << 40)
+    o = OracleIndex(ix)
+    for q in paper["find"]:
+        assert list(o.find(q["pattern"].encode())) == q["range"], q
+    for q in paper["locate"]:
+        rng = tuple(q["range"])
+        assert list(o.locate(rng)) == q["values"]
+        assert o.count(rng) == q["count"]
+    # the red arrows of Figure 3: one LF step with A from find("T") gives find("AT")
+    assert o.LF((9, 12), 1) == (2, 4)
+    assert o.find(b"") == (0, 15)
+
+
+# ---------------------------------------------------------------------------------------------
+# 2. differential tests
+
+def small_cases():
+    cases = [("paper", graphs.paper_graph(), 3)]
+    for seed, n, K, pb, back in [(1, 30, 4, 0.25, 0.0), (2, 40, 5, 0.3, 0.0), (3, 25, 3, 0.2, 0.1),
+                                 (4, 60, 6, 0.15, 0.0), (5, 35, 8, 0.2, 0.05), (6, 50, 2, 0.3, 0.0),
+                                 (7, 12, 16, 0.3, 0.0)]:
+        cases.append((f"rand{seed}", graphs.random_graph(n, 0xABC0 + seed, p_branch=pb, p_back=back,
+                                                         alphabet=2 + seed % 3), K))
+    cases.append(("linear", graphs.linear_graph(200, 0x51, node_len=8), 6))
+    cases.append(("snp", graphs.snp_graph(150, 0x52, 0x53, snp_period=8, node_len=8), 6))
+    return cases
+
+
+CASES = small_cases()
+
+
+@pytest.fixture(scope="module", params=range(len(CASES)), ids=[c[0] for c in CASES])
+def case(request):
+    name, g, K = CASES[request.param]
+    ix = build(g, K, sample_period=8, branching=4)
+    return name, g, K, ix, OracleIndex(ix), NaiveIndex(ix), GraphBrute(g)
+
+
+def random_patterns(g, K, seed, count):
+    """Half walks through the graph (hits), half random strings; lengths 1..K+2."""
+    rng = SplitMix64(seed)
+    pats = []
+    for i in range(count):
+        L = 1 + rng.below(K + 2)
+        if i % 2 == 0:
+            v = rng.below(g.size)
+            s = []
+            for _ in range(L):
+                s.append(COMP2CHAR[int(g.comp[v])])
+                succ = g.successors(v)
+                v = int(succ[rng.below(len(succ))])
+            pats.append("".join(s).encode())
+        else:
+            pats.append("".join("ACGTN"[rng.below(5)] for _ in range(L)).encode())
+    return pats
+
+
+def truncate_at_sink(p):
+    """verifyIndex ends a k-mer at its first `$` (reference src/algorithms.cpp:127-129)."""
+    k = p.find(b"$")
+    return p if k < 0 else p[:k + 1]
+
+
+def test_find_lf_vs_naive(case):
+    name, g, K, ix, o, nv, gb = case
+    pats = [truncate_at_sink(p) for p in random_patterns(g, K, 0x77, 300)] + [b"", b"A", b"N", b"#", b"$"]
+    for p in pats:
+        assert o.find(p) == nv.find(p), (name, p)
+    # batched driver, serial and OpenMP
+    data, off = concat_patterns(pats)
+    r1 = o.find_batch(data, off, threads=1)
+    r4 = o.find_batch(data, off, threads=4)
+    assert np.array_equal(r1, r4)
+    for i, p in enumerate(pats):
+        assert tuple(int(x) for x in r1[i]) == nv.find(p)
+    # single LF steps on all non-empty char ranges and comps
+    for c in range(ix.sigma):
+        rng = nv.charRange(c) if ix.C[c + 1] > 0 else None
+        if rng is None:
+            continue
+        assert o.charRange(c) == rng
+        if nv.empty(*rng):
+            continue
+        for c2 in range(ix.sigma):
+            assert o.LF(rng, c2) == nv.LF(rng, c2)
+    for i in range(ix.n):
+        assert o.LF(i) == nv.LF1(i)
+
+
+def test_find_vs_input_graph(case):
+    """No false negatives / no short false positives (paper.tex:270-283): for |X| <= K,
+    locate(find(X)) is exactly the set of start positions of paths labelled X."""
+    name, g, K, ix, o, nv, gb = case
+    c2c = ix.char2comp
+    for p in random_patterns(g, K, 0x99, 200):
+        p = truncate_at_sink(p)[:K]
+        comps = [int(c2c[b]) for b in p]
+        rng = o.find(p)
+        expected = gb.occurrences(comps)
+        got = [int(v) for v in o.locate(rng)]
+        assert got == expected, (name, p, rng)
+        assert o.count(rng) == len(expected), (name, p, rng)
+        # the range is the set of nodes whose key prefix-matches X (Lemma "context length")
+        if expected:
+            keys = ix.table.keys
+            match = [i for i, k in enumerate(keys)
+                     if tuple(comps[:len(k)]) == k[:len(comps)]]
+            assert match == list(range(rng[0], rng[1] + 1)), (name, p)
+        else:
+            assert nv.empty(*rng)
+
+
+def test_locate_count_vs_naive(case):
+    name, g, K, ix, o, nv, gb = case
+    rng = SplitMix64(0x1234)
+    ranges = [(i, i) for i in range(ix.n)]
+    for _ in range(100):
+        a = rng.below(ix.n)
+        b = min(ix.n - 1, a + rng.below(6))
+        ranges.append((a, b))
+    ranges += [(0, ix.n - 1), (1, 0), (3, 2), (0, ix.n), (ix.n, ix.n + 3)]
+    for r in ranges:
+        assert [int(v) for v in o.locate(r)] == nv.locate(r), (name, r)
+        assert [int(v) for v in o.locate(r, sort=False)] == nv.locate(r, sort=False)
+        assert o.count(r) == nv.count(r), (name, r)
+    arr = np.array(ranges, dtype=np.uint64)
+    offs, vals = o.locate_batch(arr, threads=3)
+    for i, r in enumerate(ranges):
+        assert [int(v) for v in vals[int(offs[i]):int(offs[i + 1])]] == nv.locate(r)
+    assert [int(c) for c in o.count_batch(arr, threads=2)] == [nv.count(r) for r in ranges]
+    for i in range(ix.n):
+        assert o.sampled(i) == bool(nv.SP[i])
+    for j in range(ix.sample_count):
+        assert o.sample(j) == nv.VS[j] and o.lastSample(j) == bool(nv.SM[j])
+
+
+def test_suffix_tree_ops_vs_naive(case):
+    name, g, K, ix, o, nv, gb = case
+    for pos in range(ix.n + 2):
+        assert o.psv(pos) == nv.psv(pos), (name, pos)
+        assert o.psev(pos) == nv.psv(pos, equal=True)
+        assert o.nsv(pos) == nv.nsv(pos)
+        assert o.nsev(pos) == nv.nsv(pos, equal=True)
+    rng = SplitMix64(0x4321)
+    ranges = [(i, i) for i in range(ix.n)] + [(0, ix.n - 1)]
+    for _ in range(200):
+        a = rng.below(ix.n)
+        b = min(ix.n - 1, a + rng.below(ix.n))
+        ranges.append((a, b))
+    for r in ranges:
+        assert o.rmq(*r) == nv.rmq(*r), (name, r)
+        assert o.parent(r) == nv.parent(r), (name, r)
+        assert o.depth(r) == nv.depth(r), (name, r)
+    assert o.rmq(3, 2) == nv.rmq(3, 2)
+    arr = np.array(ranges, dtype=np.uint64)
+    pb = o.parent_batch(arr, threads=2)
+    db = o.depth_batch(arr, threads=2)
+    for i, r in enumerate(ranges):
+        assert tuple(int(x) for x in pb[i]) == nv.parent(r)
+        assert int(db[i]) == nv.depth(r)
+
+
+def test_lf_fast_all(case):
+    name, g, K, ix, o, nv, gb = case
+    rng = SplitMix64(0x55)
+    ranges = [(i, i) for i in range(ix.n)] + [(0, ix.n - 1), (1, 0)]
+    for _ in range(50):
+        a = rng.below(ix.n)
+        ranges.append((a, min(ix.n - 1, a + 1 + rng.below(5))))
+    for r in ranges:
+        for all_, limit in ((0, ix.fast_chars), (1, ix.sigma - 2)):
+            got = o.LF_all(r) if all_ else o.LF_fast(r)
+            for c in range(ix.sigma):
+                if c < 1 or c > limit or nv.empty(*r):
+                    assert got[c] == (1, 0)
+                elif r[0] == r[1]:
+                    exp = nv.LF(r, c) if nv.B[c][r[0]] else (1, 0)
+                    assert got[c] == exp
+                else:
+                    assert got[c] == nv.LF(r, c)
+
+
+# ---------------------------------------------------------------------------------------------
+# 3. verifyIndex invariants (reference src/algorithms.cpp:131-275)
+
+def test_verify_index_invariants(case):
+    name, g, K, ix, o, nv, gb = case
+    c2c = ix.char2comp
+    seen = set()
+    for p in random_patterns(g, K, 0x31, 200):
+        p = truncate_at_sink(p)[:K]
+        if p in seen:
+            continue
+        seen.add(p)
+        rng = o.find(p)
+        if nv.empty(*rng):
+            continue
+        # parent() == re-searching successively shorter prefixes until the range changes
+        par = o.parent(rng)
+        end = len(p)
+        q = rng
+        while q == rng:
+            end -= 1
+            q = o.find(p[:end])
+        assert (par[0], par[1]) == q, (name, p)
+        assert par[4] == end, (name, p)
+        assert o.depth((par[0], par[1])) == par[4]
+        # count == |locate| == distinct start nodes; locate(range, 10) is a sorted subset
+        occ = [int(v) for v in o.locate(rng)]
+        assert o.count(rng) == len(occ)
+        sub = [int(v) for v in o.locate(rng, max_positions=3)]
+        assert len(sub) == min(3, len(occ)) and sub == sorted(sub) and set(sub) <= set(occ)
