@@ -1,0 +1,400 @@
+"""ctypes binding of the C ABI (include/gcsa2_hip.h) + a host-side mirror of the reference's
+query interface.
+
+`GCSA` / `LCPArray` keep the reference's method names and argument meaning
+(`include/gcsa/gcsa.h:96-210`, `include/gcsa/lcp.h:137-178`) so that parity tests read like the
+reference's own checks; every method runs on the GPU through `libgcsa2_hip.so`.  There is no CPU
+fallback: if the library or a device is missing, construction raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from .hostview import (HostView, STNode, STNODE_DTYPE, UNKNOWN, make_host_view, concat_patterns,
+                       u64p, u8p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgcsa2_hip.so")
+
+STATUS = {0: "OK", -1: "INVALID_ARGUMENT", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY", -4: "HIP",
+          -5: "MISSING_COMPONENT", -6: "BUFFER_TOO_SMALL"}
+
+EXPORTS = [
+    "gcsa2_device_count", "gcsa2_index_create", "gcsa2_index_destroy", "gcsa2_last_error",
+    "gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count", "gcsa2_sample_bits",
+    "gcsa2_device", "gcsa2_device_bytes", "gcsa2_block_bits",
+    "gcsa2_find_batch", "gcsa2_find_device", "gcsa2_lf_batch", "gcsa2_lf_device",
+    "gcsa2_lf_node_batch", "gcsa2_char_range", "gcsa2_lf_all_batch",
+    "gcsa2_count_batch", "gcsa2_count_device",
+    "gcsa2_locate_run", "gcsa2_locate_fetch", "gcsa2_locate_discard", "gcsa2_locate_device",
+    "gcsa2_parent_batch", "gcsa2_parent_device", "gcsa2_depth_batch", "gcsa2_sv_batch",
+    "gcsa2_rmq_batch",
+]
+
+
+class Gcsa2Error(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"gcsa2_hip: {STATUS.get(code, code)}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libgcsa2_hip.so.  When torch is installed it is imported first so that both share
+    the one HIP runtime already mapped into the process (same soname, libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Gcsa2Error(-2, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    try:
+        import torch  # noqa: F401  (plumbing only: one HIP runtime per process)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.gcsa2_last_error.restype = C.c_char_p
+    L.gcsa2_index_create.argtypes = [C.POINTER(HostView), i32, C.POINTER(vp)]
+    L.gcsa2_index_destroy.argtypes = [vp]
+    L.gcsa2_index_destroy.restype = None
+    for name in ("gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count",
+                 "gcsa2_sample_bits", "gcsa2_device_bytes", "gcsa2_block_bits"):
+        getattr(L, name).restype = u64
+        getattr(L, name).argtypes = [vp]
+    L.gcsa2_device.argtypes = [vp]
+    L.gcsa2_find_batch.argtypes = [vp, u8p, u64p, u64, u64p]
+    L.gcsa2_find_device.argtypes = [vp, vp, vp, u64, vp, vp]
+    L.gcsa2_lf_batch.argtypes = [vp, u64p, u8p, u64, u64p]
+    L.gcsa2_lf_device.argtypes = [vp, vp, vp, u64, vp, vp]
+    L.gcsa2_lf_node_batch.argtypes = [vp, u64p, u64, u64p]
+    L.gcsa2_char_range.argtypes = [vp, C.c_uint8, u64p, u64p]
+    L.gcsa2_lf_all_batch.argtypes = [vp, u64p, u64, i32, u64p]
+    L.gcsa2_count_batch.argtypes = [vp, u64p, u64, u64p]
+    L.gcsa2_count_device.argtypes = [vp, vp, u64, vp, vp]
+    L.gcsa2_locate_run.argtypes = [vp, u64p, u64, u64p, C.POINTER(vp)]
+    L.gcsa2_locate_fetch.argtypes = [vp, u64p, u64]
+    L.gcsa2_locate_discard.argtypes = [vp]
+    L.gcsa2_locate_discard.restype = None
+    L.gcsa2_locate_device.argtypes = [vp, vp, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                      u64p, vp]
+    L.gcsa2_parent_batch.argtypes = [vp, u64p, u64, vp]
+    L.gcsa2_parent_device.argtypes = [vp, vp, u64, vp, vp]
+    L.gcsa2_depth_batch.argtypes = [vp, u64p, u64, u64p]
+    L.gcsa2_sv_batch.argtypes = [vp, i32, u64p, u64, u64p]
+    L.gcsa2_rmq_batch.argtypes = [vp, u64p, u64, u64p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise Gcsa2Error(rc, load_library().gcsa2_last_error().decode(errors="replace"))
+
+
+def device_count():
+    rc = load_library().gcsa2_device_count()
+    if rc < 0:
+        _check(rc)
+    return rc
+
+
+def _p64(a):
+    return a.ctypes.data_as(u64p)
+
+
+def _p8(a):
+    return a.ctypes.data_as(u8p)
+
+
+def _ranges(r):
+    r = np.ascontiguousarray(r, dtype=np.uint64)
+    if r.ndim == 1:
+        r = r.reshape(-1, 2)
+    return r
+
+
+class Range:
+    """`gcsa::Range` (reference include/gcsa/utils.h:84-117)."""
+
+    @staticmethod
+    def length(r):
+        return (int(r[1]) + 1 - int(r[0])) & UNKNOWN
+
+    @staticmethod
+    def empty(r):
+        return ((int(r[0]) + 1) & UNKNOWN) > ((int(r[1]) + 1) & UNKNOWN)
+
+    @staticmethod
+    def empty_range():
+        return (1, 0)
+
+
+class Node:
+    """`gcsa::Node` (reference include/gcsa/support.h:443-471): id << 11 | rc << 10 | offset."""
+    OFFSET_BITS = 10
+    ID_OFFSET = 11
+
+    @staticmethod
+    def encode(node_id, offset=0, rc=False):
+        return (node_id << 11) | (int(bool(rc)) << 10) | offset
+
+    @staticmethod
+    def id(node):
+        return int(node) >> 11
+
+    @staticmethod
+    def rc(node):
+        return bool((int(node) >> 10) & 1)
+
+    @staticmethod
+    def offset(node):
+        return int(node) & 1023
+
+
+class GCSA:
+    """Device-resident index with the reference's query methods.
+
+    Scalar methods (`find`, `LF`, `count`, `locate`, ...) are one-element batches of the batched
+    ones; the batched ones take / return numpy arrays.  `*_device` methods take raw device
+    pointers (ints) and a stream pointer and only enqueue work."""
+
+    def __init__(self, index_arrays, device=0, **view_kwargs):
+        L = load_library()
+        holder = make_host_view(index_arrays, **view_kwargs)
+        h = C.c_void_p()
+        _check(L.gcsa2_index_create(holder.ref(), device, C.byref(h)))
+        self._h = h
+        self._L = L
+        self.char2comp = np.asarray(index_arrays.char2comp, dtype=np.uint8).copy()
+        self.sigma = int(index_arrays.sigma)
+        self.fast_chars = int(index_arrays.fast_chars)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gcsa2_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # header accessors (gcsa.h:137-148)
+    def size(self):
+        return int(self._L.gcsa2_size(self._h))
+
+    def empty(self):
+        return self.size() == 0
+
+    def edgeCount(self):
+        return int(self._L.gcsa2_edge_count(self._h))
+
+    def order(self):
+        return int(self._L.gcsa2_order(self._h))
+
+    def sampleCount(self):
+        return int(self._L.gcsa2_sample_count(self._h))
+
+    def sampleBits(self):
+        return int(self._L.gcsa2_sample_bits(self._h))
+
+    def device_bytes(self):
+        return int(self._L.gcsa2_device_bytes(self._h))
+
+    def block_bits(self):
+        return int(self._L.gcsa2_block_bits(self._h))
+
+    # ---- find ---------------------------------------------------------------------------
+    def find_batch(self, patterns, offsets):
+        patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nq = offsets.shape[0] - 1
+        out = np.zeros((nq, 2), dtype=np.uint64)
+        _check(self._L.gcsa2_find_batch(self._h, _p8(patterns), _p64(offsets), nq, _p64(out)))
+        return out
+
+    def find(self, pattern):
+        data, off = concat_patterns([pattern])
+        r = self.find_batch(data, off)[0]
+        return (int(r[0]), int(r[1]))
+
+    def find_device(self, d_patterns, d_offsets, nq, d_ranges, stream=0):
+        _check(self._L.gcsa2_find_device(self._h, d_patterns, d_offsets, nq, d_ranges, stream))
+
+    # ---- LF -----------------------------------------------------------------------------
+    def lf_batch(self, ranges, comps):
+        ranges = _ranges(ranges)
+        comps = np.ascontiguousarray(comps, dtype=np.uint8)
+        out = np.zeros_like(ranges)
+        _check(self._L.gcsa2_lf_batch(self._h, _p64(ranges), _p8(comps), ranges.shape[0], _p64(out)))
+        return out
+
+    def lf_node_batch(self, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+        out = np.zeros_like(nodes)
+        _check(self._L.gcsa2_lf_node_batch(self._h, _p64(nodes), nodes.shape[0], _p64(out)))
+        return out
+
+    def LF(self, arg, comp=None):
+        if comp is None:
+            return int(self.lf_node_batch(np.array([arg], dtype=np.uint64))[0])
+        r = self.lf_batch(np.array([arg], dtype=np.uint64), np.array([comp], dtype=np.uint8))[0]
+        return (int(r[0]), int(r[1]))
+
+    def charRange(self, comp):
+        sp, ep = C.c_uint64(), C.c_uint64()
+        _check(self._L.gcsa2_char_range(self._h, comp, C.byref(sp), C.byref(ep)))
+        return (sp.value, ep.value)
+
+    def lf_all_batch(self, ranges, all_comps):
+        ranges = _ranges(ranges)
+        out = np.zeros((ranges.shape[0], self.sigma, 2), dtype=np.uint64)
+        _check(self._L.gcsa2_lf_all_batch(self._h, _p64(ranges), ranges.shape[0], int(all_comps), _p64(out)))
+        return out
+
+    def LF_fast(self, rng):
+        return [(int(a), int(b)) for a, b in self.lf_all_batch(np.array([rng], dtype=np.uint64), 0)[0]]
+
+    def LF_all(self, rng):
+        return [(int(a), int(b)) for a, b in self.lf_all_batch(np.array([rng], dtype=np.uint64), 1)[0]]
+
+    # ---- count --------------------------------------------------------------------------
+    def count_batch(self, ranges):
+        ranges = _ranges(ranges)
+        out = np.zeros(ranges.shape[0], dtype=np.uint64)
+        _check(self._L.gcsa2_count_batch(self._h, _p64(ranges), ranges.shape[0], _p64(out)))
+        return out
+
+    def count(self, rng):
+        return int(self.count_batch(np.array([rng], dtype=np.uint64))[0])
+
+    # ---- locate -------------------------------------------------------------------------
+    def locate_batch(self, ranges):
+        """CSR (offsets[nq+1], values): sorted distinct node_type values per range."""
+        ranges = _ranges(ranges)
+        nq = ranges.shape[0]
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        job = C.c_void_p()
+        _check(self._L.gcsa2_locate_run(self._h, _p64(ranges), nq, _p64(offsets), C.byref(job)))
+        values = np.zeros(max(int(offsets[nq]), 1), dtype=np.uint64)
+        _check(self._L.gcsa2_locate_fetch(job, _p64(values), values.shape[0]))
+        return offsets, values[: int(offsets[nq])]
+
+    def locate(self, rng):
+        if isinstance(rng, (int, np.integer)):
+            rng = (int(rng), int(rng))
+        return self.locate_batch(np.array([rng], dtype=np.uint64))[1]
+
+    def locate_device(self, d_ranges, nq, stream=0):
+        """Returns (job, d_offsets, d_values, total); free with locate_discard(job)."""
+        job, d_off, d_val = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        total = C.c_uint64()
+        _check(self._L.gcsa2_locate_device(self._h, d_ranges, nq, C.byref(job), C.byref(d_off),
+                                           C.byref(d_val), C.byref(total), stream))
+        return job, d_off.value, d_val.value, total.value
+
+    def locate_discard(self, job):
+        self._L.gcsa2_locate_discard(job)
+
+    def count_device(self, d_ranges, nq, d_counts, stream=0):
+        _check(self._L.gcsa2_count_device(self._h, d_ranges, nq, d_counts, stream))
+
+    def lf_device(self, d_in, d_comps, nq, d_out, stream=0):
+        _check(self._L.gcsa2_lf_device(self._h, d_in, d_comps, nq, d_out, stream))
+
+    def parent_device(self, d_ranges, nq, d_nodes, stream=0):
+        _check(self._L.gcsa2_parent_device(self._h, d_ranges, nq, d_nodes, stream))
+
+
+class LCPArray:
+    """`gcsa::LCPArray` queries (reference include/gcsa/lcp.h:137-178) over the LCP part of the
+    same device image as a `GCSA`."""
+
+    def __init__(self, gcsa: GCSA, lcp_values: int, lcp_size: int):
+        self._g = gcsa
+        self._L = gcsa._L
+        self._values = int(lcp_values)
+        self._size = int(lcp_size)
+
+    def size(self):
+        return self._size
+
+    def values(self):
+        return self._values
+
+    def notFound(self):
+        return (self._values, self._values)
+
+    def root(self):
+        return (0, self._size - 1, 0, 0, 0)
+
+    def parent_batch(self, ranges):
+        ranges = _ranges(ranges)
+        out = np.zeros(ranges.shape[0], dtype=STNODE_DTYPE)
+        _check(self._L.gcsa2_parent_batch(self._g.handle, _p64(ranges), ranges.shape[0], out.ctypes.data))
+        return out
+
+    def parent(self, rng):
+        return tuple(int(x) for x in self.parent_batch(np.array([rng], dtype=np.uint64))[0])
+
+    def depth_batch(self, ranges):
+        ranges = _ranges(ranges)
+        out = np.zeros(ranges.shape[0], dtype=np.uint64)
+        _check(self._L.gcsa2_depth_batch(self._g.handle, _p64(ranges), ranges.shape[0], _p64(out)))
+        return out
+
+    def depth(self, rng):
+        return int(self.depth_batch(np.array([rng], dtype=np.uint64))[0])
+
+    def _sv_batch(self, op, positions):
+        positions = np.ascontiguousarray(positions, dtype=np.uint64)
+        out = np.zeros((positions.shape[0], 2), dtype=np.uint64)
+        _check(self._L.gcsa2_sv_batch(self._g.handle, op, _p64(positions), positions.shape[0], _p64(out)))
+        return out
+
+    def psv_batch(self, positions):
+        return self._sv_batch(0, positions)
+
+    def psev_batch(self, positions):
+        return self._sv_batch(1, positions)
+
+    def nsv_batch(self, positions):
+        return self._sv_batch(2, positions)
+
+    def nsev_batch(self, positions):
+        return self._sv_batch(3, positions)
+
+    def psv(self, pos):
+        return tuple(int(x) for x in self._sv_batch(0, [pos])[0])
+
+    def psev(self, pos):
+        return tuple(int(x) for x in self._sv_batch(1, [pos])[0])
+
+    def nsv(self, pos):
+        return tuple(int(x) for x in self._sv_batch(2, [pos])[0])
+
+    def nsev(self, pos):
+        return tuple(int(x) for x in self._sv_batch(3, [pos])[0])
+
+    def rmq_batch(self, ranges):
+        ranges = _ranges(ranges)
+        out = np.zeros((ranges.shape[0], 2), dtype=np.uint64)
+        _check(self._L.gcsa2_rmq_batch(self._g.handle, _p64(ranges), ranges.shape[0], _p64(out)))
+        return out
+
+    def rmq(self, sp, ep):
+        return tuple(int(x) for x in self.rmq_batch(np.array([[sp, ep]], dtype=np.uint64))[0])
+
+
+def open_index(index_arrays, device=0):
+    """(GCSA, LCPArray) over one device image."""
+    g = GCSA(index_arrays, device=device)
+    lcp = LCPArray(g, int(index_arrays.lcp_offsets[-1]), int(index_arrays.lcp_size))
+    return g, lcp

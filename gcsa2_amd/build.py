@@ -1,0 +1,28 @@
+"""Compile the HIP engine for gfx950 into gcsa2_amd/lib/libgcsa2_hip.so (in-tree, so that it
+travels to the GPU box with the snapshot).  hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "gcsa2_hip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "layout.hpp"),
+        os.path.join(os.path.dirname(HERE), "include", "gcsa2_hip.h")]
+OUT = os.path.join(HERE, "lib", "libgcsa2_hip.so")
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+         "-Wno-unused-result", "-Wno-unused-function"]
+
+
+def build(force=False, verbose=False):
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    cmd = ["hipcc"] + FLAGS + ["-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

@@ -1,0 +1,1100 @@
+// gcsa2_hip.hip -- MI355X (gfx950) batched backward-search engine for GCSA2 indexes:
+// kernels + the C ABI of include/gcsa2_hip.h.  Written for CDNA4 only (wave64, no CUDA paths).
+//
+// Kernel <-> reference map (paths relative to the reference tree):
+//   k_find        GCSA::find                         include/gcsa/gcsa.h:96-110
+//   k_lf          GCSA::LF(range, comp)              include/gcsa/gcsa.h:155-162, 262-274
+//   k_lf_node     GCSA::LF(path_node)                include/gcsa/gcsa.h:165-183
+//   k_lf_all      GCSA::LF_fast / LF_all             src/gcsa.cpp:742-798
+//   k_count       GCSA::count, Sada*::count          src/gcsa.cpp:802-809, support.h:255-258,329-335
+//   k_locate_*    GCSA::locate(range), locateInternal, removeDuplicates
+//                                                    src/gcsa.cpp:827-842, 880-896, utils.h:350-357
+//   k_parent/...  LCPArray::parent/depth/psv/nsv/rmq include/gcsa/lcp.h:137-178, src/lcp.cpp:276-519
+#include "layout.hpp"
+#include "../../include/gcsa2_hip.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace g2;
+
+// ==========================================================================================
+// device code
+
+namespace {
+
+constexpr int TPB = 256;   // 4 waves per workgroup
+
+struct Tables   // small per-workgroup lookup tables staged into LDS
+{
+  u64 C[MAX_SIGMA + 1];
+  u8 c2c[256];
+};
+
+__device__ __forceinline__ void stage_tables(const DevImage& img, Tables& t)
+{
+  // DevImage lives in the kernarg segment; a lane-indexed read of it is a plain global load.
+  if(threadIdx.x <= MAX_SIGMA) { t.C[threadIdx.x] = img.C[threadIdx.x]; }
+  t.c2c[threadIdx.x & 255] = img.char2comp[threadIdx.x & 255];
+  __syncthreads();
+}
+
+__device__ __forceinline__ u64 clampu(u64 x, u64 hi) { return x < hi ? x : hi; }
+
+// pathNodeRange (gcsa.h:253-258)
+__device__ __forceinline__ void path_node_range(const DevImage& img, u64& sp, u64& ep)
+{
+  u64 a, b;
+  bv_rank2(img.edges, clampu(sp, img.e), clampu(ep, img.e), a, b);
+  sp = a; ep = b;
+}
+
+// The per-comp descriptors sit in the kernarg segment; selecting one by a lane-varying comp is a
+// global load of the descriptor.  All B_c have the same geometry, so only the base pointer varies.
+__device__ __forceinline__ DevBV bwt_of(const DevImage& img, u32 comp)
+{
+  DevBV bv = img.bwt[0];
+  bv.blocks = img.bwt[0].blocks + u64(comp) * (img.bwt[0].nblocks * BLOCK_WORDS);
+  return bv;
+}
+
+__global__ __launch_bounds__(TPB) void k_find(DevImage img, const u8* __restrict__ patterns,
+                                              const u64* __restrict__ offsets, u64 nq,
+                                              u64* __restrict__ out)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  u64 begin = offsets[q], len = offsets[q + 1] - begin;
+  u64 sp = 0, ep = img.n - 1;
+  if(len > 0 && img.n > 0)                                  // gcsa.h:99
+  {
+    const u8* p = patterns + begin;
+    u64 i = len - 1;
+    u32 comp = t.c2c[p[i]];
+    sp = t.C[comp]; ep = t.C[comp + 1] - 1;                 // charRange, utils.h:414-419
+    path_node_range(img, sp, ep);                           // gcsa.h:150-153 (no emptiness check)
+    while(!range_empty(sp, ep) && i > 0)                    // gcsa.h:103
+    {
+      i--;
+      comp = t.c2c[p[i]];
+      DevBV bv = bwt_of(img, comp);
+      u64 ra, rb;
+      bv_rank2(bv, sp, ep + 1, ra, rb);                     // gcsa.h:271-272
+      sp = t.C[comp] + ra; ep = t.C[comp] + rb - 1;
+      if(range_empty(sp, ep)) { break; }                    // gcsa.h:160: edge-space integers
+      path_node_range(img, sp, ep);                         // gcsa.h:161
+    }
+  }
+  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep);
+}
+
+__global__ __launch_bounds__(TPB) void k_lf(DevImage img, const u64* __restrict__ in,
+                                            const u8* __restrict__ comps, u64 nq, u64* __restrict__ out)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  ulonglong2 r = reinterpret_cast<const ulonglong2*>(in)[q];
+  u32 comp = comps[q];
+  if(comp >= img.sigma) { comp = u32(img.sigma - 1); }     // memory safety only
+  u64 sp = r.x, ep = r.y;
+  DevBV bv = bwt_of(img, comp);
+  u64 ra, rb;
+  bv_rank2(bv, clampu(sp, img.n), clampu(ep + 1, img.n), ra, rb);
+  sp = t.C[comp] + ra; ep = t.C[comp] + rb - 1;
+  if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
+  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep);
+}
+
+// LF(path_node): first incoming edge, comps 1..fast_chars, then fast_chars+1..sigma-1, else 0
+__device__ __forceinline__ u64 lf_node(const DevImage& img, const u64* C, u64 node)
+{
+  u32 sigma = u32(img.sigma);
+  u32 comp = 0; u64 rank = 0; bool hit = false;
+  for(u32 c = 1; c < sigma && !hit; c++)
+  {
+    u64 r;
+    if(bv_get_rank(bwt_of(img, c), node, r)) { comp = c; rank = r; hit = true; }
+  }
+  if(!hit) { rank = bv_rank(bwt_of(img, 0), node); }
+  return bv_rank(img.edges, clampu(C[comp] + rank, img.e));
+}
+
+__global__ __launch_bounds__(TPB) void k_lf_node(DevImage img, const u64* __restrict__ in, u64 nq,
+                                                 u64* __restrict__ out)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  u64 node = in[q];
+  out[q] = (node < img.n ? lf_node(img, t.C, node) : 0);
+}
+
+// LF_fast (all = 0, comps 1..fast_chars) / LF_all (all = 1, comps 1..sigma-2); src/gcsa.cpp:742-798
+__global__ __launch_bounds__(TPB) void k_lf_all(DevImage img, const u64* __restrict__ in, u64 nq, int all,
+                                                u64* __restrict__ out)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  ulonglong2 r = reinterpret_cast<const ulonglong2*>(in)[q];
+  u32 sigma = u32(img.sigma);
+  ulonglong2* dst = reinterpret_cast<ulonglong2*>(out) + q * sigma;
+  for(u32 c = 0; c < sigma; c++) { dst[c] = make_ulonglong2(1, 0); }
+  if(range_empty(r.x, r.y)) { return; }
+  u32 limit = (all ? sigma - 2 : u32(img.fast_chars));
+  u64 sp0 = clampu(r.x, img.n), ep0 = clampu(r.y, img.n);
+  for(u32 c = 1; c <= limit; c++)
+  {
+    DevBV bv = bwt_of(img, c);
+    if(r.x == r.y)     // single path node: bit probe (gcsa.cpp:748-757)
+    {
+      u64 rk;
+      if(sp0 < img.n && bv_get_rank(bv, sp0, rk))
+      {
+        u64 v = bv_rank(img.edges, clampu(t.C[c] + rk, img.e));
+        dst[c] = make_ulonglong2(v, v);
+      }
+    }
+    else               // general case (gcsa.cpp:758-765)
+    {
+      u64 ra, rb;
+      bv_rank2(bv, sp0, clampu(ep0 + 1, img.n), ra, rb);
+      u64 sp = t.C[c] + ra, ep = t.C[c] + rb - 1;
+      if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
+      dst[c] = make_ulonglong2(sp, ep);
+    }
+  }
+}
+
+// ---- counting ----------------------------------------------------------------------------
+
+// SadaSparse::count (support.h:329-335)
+__device__ __forceinline__ u64 sada_sparse_count(const DevImage& img, u64 sp, u64 ep)
+{
+  u64 a, b;
+  bv_rank2(img.xfilter, sp, ep + 1, a, b);
+  if(b <= a) { return 0; }
+  return (bv_select(img.xvalues, b) + 1) - (a > 0 ? bv_select(img.xvalues, a) + 1 : 0);
+}
+
+// SadaCount::count (support.h:255-258)
+__device__ __forceinline__ u64 sada_count(const DevImage& img, u64 sp, u64 ep)
+{
+  return (bv_select(img.redundant, ep + 1) - ep) - (sp > 0 ? bv_select(img.redundant, sp) + 1 - sp : 0);
+}
+
+__device__ __forceinline__ u64 count_range(const DevImage& img, u64 sp, u64 ep)
+{
+  if(range_empty(sp, ep) || ep >= img.n) { return 0; }                  // gcsa.cpp:805
+  u64 res = sada_sparse_count(img, sp, ep) + (ep + 1 - sp);            // gcsa.cpp:806
+  if(ep > sp) { res -= sada_count(img, sp, ep - 1); }                  // gcsa.cpp:807
+  return res;
+}
+
+__global__ __launch_bounds__(TPB) void k_count(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                               u64* __restrict__ out)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
+  out[q] = count_range(img, r.x, r.y);
+}
+
+// ---- locate ------------------------------------------------------------------------------
+
+// per query: number of path nodes to walk and number of values before deduplication
+__global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                                      u64* __restrict__ node_counts, u64* __restrict__ raw_counts)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
+  u64 nodes = 0, raw = 0;
+  if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831
+  {
+    nodes = r.y + 1 - r.x;
+    raw = nodes + sada_sparse_count(img, r.x, r.y);         // sum of |values(i)| = sum of (A[i] + 1)
+  }
+  node_counts[q] = nodes; raw_counts[q] = raw;
+}
+
+// one lane per (query, path node): locateInternal (gcsa.cpp:880-896)
+__global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                                     const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
+                                                     u64 total_nodes, u64* __restrict__ values)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(g >= total_nodes) { return; }
+  // query owning flattened node g: last q with node_off[q] <= g
+  u64 lo = 0, hi = nq - 1;
+  while(lo < hi)
+  {
+    u64 mid = (lo + hi + 1) >> 1;
+    if(node_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
+  }
+  u64 sp = ranges[2 * lo];
+  u64 node = sp + (g - node_off[lo]);
+  u64 dest = raw_off[lo] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0);
+
+  u64 steps = 0, srank;
+  while(!bv_get_rank(img.sampled, node, srank))             // gcsa.cpp:883-887
+  {
+    node = lf_node(img, t.C, node); steps++;
+  }
+  u64 s = (srank > 0 ? bv_select(img.samples, srank) + 1 : 0);   // firstSample, gcsa.h:202-206
+  do
+  {
+    values[dest++] = packed_get(img.stored, img.sample_width, s) + steps;   // gcsa.cpp:893
+    s++;
+  }
+  while(!bv_get(img.samples, s - 1));                        // lastSample, gcsa.h:208
+}
+
+// flag the first occurrence of every value inside its (sorted) segment
+__global__ __launch_bounds__(TPB) void k_mark_unique(const u64* __restrict__ sorted, const u64* __restrict__ raw_off,
+                                                     u64 nq, u64 total, u32* __restrict__ flags)
+{
+  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(g >= total) { return; }
+  u64 lo = 0, hi = nq - 1;
+  while(lo < hi)
+  {
+    u64 mid = (lo + hi + 1) >> 1;
+    if(raw_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
+  }
+  // segments of empty queries share their start with the next one; lo is the last of them,
+  // which is the only one that can contain g.
+  flags[g] = (g == raw_off[lo] || sorted[g] != sorted[g - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted, const u32* __restrict__ flags,
+                                                 const u64* __restrict__ flag_scan, u64 total, u64* __restrict__ out)
+{
+  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(g >= total) { return; }
+  if(flags[g]) { out[flag_scan[g]] = sorted[g]; }
+}
+
+__global__ __launch_bounds__(TPB) void k_final_offsets(const u64* __restrict__ raw_off, const u64* __restrict__ flag_scan,
+                                                       u64 nq, u64 total, u64 total_unique, u64* __restrict__ offsets)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q > nq) { return; }
+  u64 r = (q < nq ? raw_off[q] : total);
+  offsets[q] = (r < total ? flag_scan[r] : total_unique);
+}
+
+// ---- suffix-tree operations over the LCP range-minimum tree ------------------------------
+
+struct Lcp
+{
+  const DevImage& img;
+  __device__ __forceinline__ u64 at(u64 i) const { return img.lcp[i]; }
+  __device__ __forceinline__ u64 root() const { return img.lcp_values - 1; }
+  __device__ __forceinline__ u64 parent(u64 node, u64 level) const
+  { return img.lcp_offsets[level + 1] + (node - img.lcp_offsets[level]) / img.lcp_branching; }
+  __device__ __forceinline__ u64 first_sibling(u64 node, u64 level) const
+  { return node - (node - img.lcp_offsets[level]) % img.lcp_branching; }
+  __device__ __forceinline__ u64 last_sibling(u64 first_child, u64 level) const
+  {
+    u64 a = img.lcp_offsets[level + 1], b = first_child + img.lcp_branching;
+    return (a < b ? a : b) - 1;
+  }
+  __device__ __forceinline__ u64 first_child(u64 node, u64 level) const
+  { return img.lcp_offsets[level - 1] + (node - img.lcp_offsets[level]) * img.lcp_branching; }
+  __device__ __forceinline__ u64 last_child(u64 node, u64 level) const
+  { return last_sibling(first_child(node, level), level - 1); }
+  __device__ __forceinline__ u64 level_of(u64 node) const
+  { u64 level = 0; while(img.lcp_offsets[level + 1] <= node) { level++; } return level; }
+};
+
+__device__ __forceinline__ bool sv_cmp(bool equal, u64 a, u64 b) { return equal ? (a <= b) : (a < b); }
+
+// psv / psev (src/lcp.cpp:345-382)
+__device__ void lcp_psv(const DevImage& img, u64 to, bool equal, u64& rpos, u64& rval)
+{
+  Lcp L{img};
+  rpos = rval = img.lcp_values;                     // notFound()
+  if(to == 0 || to >= img.lcp_size) { return; }
+  u64 level = 0, val = L.at(to);
+  bool found = false;
+  while(to != L.root())
+  {
+    u64 from = L.first_sibling(to, level);
+    for(u64 i = to; i > from; )
+    {
+      i--;
+      u64 v = L.at(i);
+      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; found = true; break; }
+    }
+    if(found) { break; }
+    to = L.parent(to, level); level++;
+  }
+  if(!found) { return; }
+  while(level > 0)
+  {
+    u64 from = L.first_child(rpos, level); level--;
+    for(u64 i = L.last_sibling(from, level) + 1; i > from; )
+    {
+      i--;
+      u64 v = L.at(i);
+      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; break; }
+    }
+  }
+}
+
+// nsv / nsev (src/lcp.cpp:401-438)
+__device__ void lcp_nsv(const DevImage& img, u64 from, bool equal, u64& rpos, u64& rval)
+{
+  Lcp L{img};
+  rpos = rval = img.lcp_values;
+  if(from + 1 >= img.lcp_size) { return; }
+  u64 level = 0, val = L.at(from);
+  bool found = false;
+  while(from != L.root())
+  {
+    u64 last = L.last_sibling(L.first_sibling(from, level), level);
+    for(u64 i = from + 1; i <= last; i++)
+    {
+      u64 v = L.at(i);
+      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; found = true; break; }
+    }
+    if(found) { break; }
+    from = L.parent(from, level); level++;
+  }
+  if(!found) { return; }
+  while(level > 0)
+  {
+    from = L.first_child(rpos, level); level--;
+    u64 last = L.last_sibling(from, level);
+    for(u64 i = from; i <= last; i++)
+    {
+      u64 v = L.at(i);
+      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; break; }
+    }
+  }
+}
+
+// rmq (src/lcp.cpp:448-513): leftmost minimum of LCP[sp..ep].  Same tree walk as the reference;
+// its explicit stack of right-hand tails is replaced by one accumulator that prefers the later
+// (= more leftward) candidate on ties, which yields the same leftmost minimum.
+__device__ void lcp_rmq(const DevImage& img, u64 sp, u64 ep, u64& rpos, u64& rval)
+{
+  Lcp L{img};
+  if(sp > ep || ep >= img.lcp_size) { rpos = rval = img.lcp_values; return; }
+  if(sp == ep) { rpos = sp; rval = L.at(sp); return; }
+  const u64 INF = ~u64(0);
+  u64 lpos = img.lcp_values, lval = INF, tpos = img.lcp_values, tval = INF;
+  u64 level = 0, left = sp, right = ep;
+  while(true)
+  {
+    u64 left_par = L.parent(left, level), right_par = L.parent(right, level);
+    if(left_par == right_par)
+    {
+      for(u64 i = left; i <= right; i++) { u64 v = L.at(i); if(v < lval) { lpos = i; lval = v; } }
+      break;
+    }
+    u64 left_child = L.first_child(left_par, level + 1);
+    if(left != left_child)
+    {
+      u64 last = L.last_sibling(left_child, level);
+      for(u64 i = left; i <= last; i++) { u64 v = L.at(i); if(v < lval) { lpos = i; lval = v; } }
+      left_par++;
+    }
+    u64 right_child = L.last_child(right_par, level + 1);
+    if(right != right_child)
+    {
+      u64 first = L.first_sibling(right_child, level);
+      u64 gpos = img.lcp_values, gval = INF;
+      for(u64 i = first; i <= right; i++) { u64 v = L.at(i); if(v < gval) { gpos = i; gval = v; } }
+      if(gval <= tval) { tpos = gpos; tval = gval; }      // this group lies left of earlier tails
+      right_par--;
+    }
+    if(left_par >= right_par)
+    {
+      if(left_par == right_par) { u64 v = L.at(left_par); if(v < lval) { lpos = left_par; lval = v; } }
+      break;
+    }
+    left = left_par; right = right_par; level++;
+  }
+  if(lval <= tval) { rpos = lpos; rval = lval; } else { rpos = tpos; rval = tval; }
+  level = L.level_of(rpos);
+  while(level > 0)
+  {
+    rpos = L.first_child(rpos, level); level--;
+    while(L.at(rpos) != rval) { rpos++; }
+  }
+}
+
+// nodeFor (lcp.h:163-175) + parent (src/lcp.cpp:276-301)
+__device__ void lcp_parent(const DevImage& img, u64 sp, u64 ep, gcsa2_stnode& out)
+{
+  if(sp == 0 && ep == img.lcp_size - 1) { out = gcsa2_stnode{0, img.lcp_size - 1, 0, 0, 0}; return; }
+  u64 sp_safe = clampu(sp, img.lcp_size - 1);
+  u64 left_lcp = img.lcp[sp_safe];
+  u64 right_lcp = (ep + 1 < img.lcp_size ? img.lcp[ep + 1] : 0);
+  u64 node_lcp = (left_lcp > right_lcp ? left_lcp : right_lcp);
+  u64 lpos = sp, lval = left_lcp, rpos = ep + 1, rval = right_lcp;
+  if(left_lcp == node_lcp)
+  {
+    lcp_psv(img, sp, false, lpos, lval);
+    if(lpos == img.lcp_values && lval == img.lcp_values) { lpos = 0; lval = 0; }
+  }
+  if(right_lcp == node_lcp)
+  {
+    lcp_nsv(img, ep + 1, false, rpos, rval);
+    if(rpos == img.lcp_values && rval == img.lcp_values) { rpos = img.lcp_size; rval = 0; }
+  }
+  out = gcsa2_stnode{lpos, rpos - 1, lval, rval, node_lcp};
+}
+
+__global__ __launch_bounds__(TPB) void k_parent(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                                gcsa2_stnode* __restrict__ out)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
+  gcsa2_stnode node;
+  lcp_parent(img, r.x, r.y, node);
+  out[q] = node;
+}
+
+// depth(range) (src/lcp.cpp:319-325)
+__global__ __launch_bounds__(TPB) void k_depth(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                               u64* __restrict__ out)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
+  u64 res = GCSA2_UNKNOWN;
+  if(r.y + 1 - r.x > 1)
+  {
+    u64 pos, val;
+    lcp_rmq(img, r.x + 1, r.y, pos, val);
+    if(!(pos == img.lcp_values && val == img.lcp_values)) { res = val; }
+  }
+  out[q] = res;
+}
+
+__global__ __launch_bounds__(TPB) void k_sv(DevImage img, int op, const u64* __restrict__ positions, u64 nq,
+                                            u64* __restrict__ out)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  u64 pos, val;
+  if(op < 2) { lcp_psv(img, positions[q], op & 1, pos, val); }
+  else { lcp_nsv(img, positions[q], op & 1, pos, val); }
+  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(pos, val);
+}
+
+__global__ __launch_bounds__(TPB) void k_rmq(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                             u64* __restrict__ out)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
+  u64 pos, val;
+  lcp_rmq(img, r.x, r.y, pos, val);
+  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(pos, val);
+}
+
+}  // namespace
+
+// ==========================================================================================
+// host code
+
+struct gcsa2_index
+{
+  int device = 0;
+  DevImage img;
+  void* d_base = nullptr;
+  u64 bytes = 0;
+  u64 order = 0;
+};
+
+struct gcsa2_locate_job
+{
+  int device = 0;
+  u64 nq = 0, total = 0;
+  u64* d_offsets = nullptr;   // nq + 1
+  u64* d_values = nullptr;    // total
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) { \
+  return fail(e_ == hipErrorOutOfMemory ? GCSA2_ERR_OUT_OF_MEMORY : GCSA2_ERR_HIP, \
+              std::string(#expr) + ": " + hipGetErrorString(e_)); } } while(0)
+
+inline unsigned grid_for(u64 n) { return unsigned((n + TPB - 1) / TPB); }
+
+// host-side staging of the device image --------------------------------------------------
+
+struct Stager
+{
+  std::vector<u64> words;      // image, in u64 units; every piece starts on a 64-byte boundary
+  u64 reserve(u64 nwords)
+  {
+    u64 off = (words.size() + 7) & ~u64(7);
+    words.resize(off + nwords, 0);
+    return off;
+  }
+};
+
+struct BVPlan { u64 blocks_off = 0, hints_off = 0, size = 0, nblocks = 0, ones = 0; bool hints = false; };
+
+BVPlan stage_bv(Stager& st, const u64* plain, u64 size, bool with_select)
+{
+  BVPlan p;
+  p.size = size; p.nblocks = size / BLOCK_BITS + 1; p.hints = with_select;
+  p.blocks_off = st.reserve(p.nblocks * BLOCK_WORDS);
+  u64 total_words = (size + 63) / 64, cumul = 0;
+  for(u64 b = 0; b < p.nblocks; b++)
+  {
+    u64* dst = st.words.data() + p.blocks_off + b * BLOCK_WORDS;
+    dst[0] = cumul;
+    for(u64 j = 0; j < PAYLOAD_WORDS; j++)
+    {
+      u64 w = b * PAYLOAD_WORDS + j, val = 0;
+      if(w < total_words)
+      {
+        val = plain[w];
+        if(w == (size >> 6) && (size & 63)) { val &= (u64(1) << (size & 63)) - 1; }
+      }
+      dst[1 + j] = val; cumul += u64(__builtin_popcountll(val));
+    }
+  }
+  p.ones = cumul;
+  if(with_select)
+  {
+    u64 nh = p.ones / SELECT_SAMPLE + 2;
+    p.hints_off = st.reserve((nh + 1) / 2);
+    u32* h = reinterpret_cast<u32*>(st.words.data() + p.hints_off);
+    const u64* blk = st.words.data() + p.blocks_off;
+    for(u64 j = 0, b = 0; j < nh; j++)
+    {
+      u64 target = j * SELECT_SAMPLE + 1;    // largest block whose counter is < target
+      while(b + 1 < p.nblocks && blk[(b + 1) * BLOCK_WORDS] < target) { b++; }
+      h[j] = u32(b);
+    }
+  }
+  return p;
+}
+
+DevBV resolve(const BVPlan& p, const u64* d_base)
+{
+  DevBV bv;
+  bv.blocks = d_base + p.blocks_off;
+  bv.hints = p.hints ? reinterpret_cast<const u32*>(d_base + p.hints_off) : nullptr;
+  bv.size = p.size; bv.nblocks = p.nblocks; bv.ones = p.ones;
+  return bv;
+}
+
+struct DeviceGuard
+{
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev)
+  {
+    if(hipGetDevice(&prev) != hipSuccess) { prev = -1; }
+    ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() { if(prev >= 0) { (void)hipSetDevice(prev); } }
+};
+
+// RAII device buffer for the host-pointer entry points
+template<class T> struct DBuf
+{
+  T* p = nullptr;
+  hipError_t alloc(u64 count) { return hipMalloc(reinterpret_cast<void**>(&p), (count > 0 ? count : 1) * sizeof(T)); }
+  ~DBuf() { if(p) { (void)hipFree(p); } }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* gcsa2_last_error(void) { return g_error.c_str(); }
+
+int gcsa2_device_count(void)
+{
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if(e != hipSuccess) { return fail(GCSA2_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+  return count;
+}
+
+int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
+{
+  if(v == nullptr || out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null argument"); }
+  *out = nullptr;
+  if(v->sigma == 0 || v->sigma > GCSA2_MAX_SIGMA || v->char2comp == nullptr || v->C == nullptr ||
+     v->bwt == nullptr || v->edge_bits == nullptr)
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "host view lacks alphabet / bwt / edges or sigma out of range");
+  }
+  if(v->lcp_data != nullptr && v->lcp_levels > u64(MAX_LCP_LEVELS)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "too many LCP levels"); }
+  int count = gcsa2_device_count();
+  if(count <= 0) { return fail(GCSA2_ERR_NO_DEVICE, "no HIP device visible: " + g_error); }
+  if(device < 0 || device >= count) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "device index out of range"); }
+
+  gcsa2_index* ix = new(std::nothrow) gcsa2_index();
+  if(ix == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+  ix->device = device; ix->order = v->order;
+  std::memset(&ix->img, 0, sizeof(DevImage));
+  DevImage& img = ix->img;
+  img.n = v->path_nodes; img.e = v->edges; img.sigma = v->sigma; img.fast_chars = v->fast_chars;
+  for(u64 c = 0; c <= v->sigma; c++) { img.C[c] = v->C[c]; }
+  std::memcpy(img.char2comp, v->char2comp, 256);
+
+  Stager st;
+  try
+  {
+    // all B_c back to back with identical geometry (k_find selects by base + comp * stride)
+    std::vector<BVPlan> bwt(v->sigma);
+    for(u64 c = 0; c < v->sigma; c++)
+    {
+      bwt[c] = stage_bv(st, v->bwt[c], img.n, false);
+      if(c > 0 && bwt[c].blocks_off != bwt[0].blocks_off + c * (bwt[0].nblocks * BLOCK_WORDS))
+      {
+        delete ix; return fail(GCSA2_ERR_INVALID_ARGUMENT, "internal: B_c stride mismatch");
+      }
+    }
+    BVPlan edges = stage_bv(st, v->edge_bits, img.e, false);
+    BVPlan sampled, samples, xfilter, xvalues, redundant;
+    u64 stored_off = 0, lcp_off = 0;
+    img.has_samples = (v->sampled_path_bits != nullptr);
+    if(img.has_samples)
+    {
+      sampled = stage_bv(st, v->sampled_path_bits, img.n, false);
+      samples = stage_bv(st, v->sample_bits, v->sample_count, true);
+      u64 nw = (v->sample_count * v->sample_width + 63) / 64;
+      stored_off = st.reserve(nw + 2);
+      std::memcpy(st.words.data() + stored_off, v->stored_samples, nw * sizeof(u64));
+      img.sample_count = v->sample_count; img.sample_width = v->sample_width;
+    }
+    img.has_counters = (v->extra_filter_bits != nullptr);
+    if(img.has_counters)
+    {
+      xfilter = stage_bv(st, v->extra_filter_bits, img.n, false);
+      xvalues = stage_bv(st, v->extra_values_bits, v->extra_values_len, true);
+      redundant = stage_bv(st, v->redundant_bits, v->redundant_len, true);
+    }
+    img.has_lcp = (v->lcp_data != nullptr);
+    if(img.has_lcp)
+    {
+      img.lcp_size = v->lcp_size; img.lcp_branching = v->lcp_branching; img.lcp_levels = v->lcp_levels;
+      for(u64 l = 0; l <= v->lcp_levels; l++) { img.lcp_offsets[l] = v->lcp_offsets[l]; }
+      img.lcp_values = v->lcp_offsets[v->lcp_levels];
+      lcp_off = st.reserve((img.lcp_values + 7) / 8 + 1);
+      std::memcpy(st.words.data() + lcp_off, v->lcp_data, img.lcp_values);
+    }
+
+    DeviceGuard guard(device);
+    if(!guard.ok) { delete ix; return fail(GCSA2_ERR_HIP, "hipSetDevice failed"); }
+    ix->bytes = st.words.size() * sizeof(u64);
+    hipError_t e = hipMalloc(&ix->d_base, ix->bytes > 0 ? ix->bytes : 8);
+    if(e != hipSuccess) { delete ix; return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(image): ") + hipGetErrorString(e)); }
+    e = hipMemcpy(ix->d_base, st.words.data(), ix->bytes, hipMemcpyHostToDevice);
+    if(e != hipSuccess) { (void)hipFree(ix->d_base); delete ix; return fail(GCSA2_ERR_HIP, std::string("hipMemcpy(image): ") + hipGetErrorString(e)); }
+
+    const u64* base = static_cast<const u64*>(ix->d_base);
+    for(u64 c = 0; c < v->sigma; c++) { img.bwt[c] = resolve(bwt[c], base); }
+    img.edges = resolve(edges, base);
+    if(img.has_samples)
+    {
+      img.sampled = resolve(sampled, base); img.samples = resolve(samples, base);
+      img.stored = base + stored_off;
+    }
+    if(img.has_counters)
+    {
+      img.xfilter = resolve(xfilter, base); img.xvalues = resolve(xvalues, base); img.redundant = resolve(redundant, base);
+    }
+    if(img.has_lcp) { img.lcp = reinterpret_cast<const u8*>(base + lcp_off); }
+  }
+  catch(const std::bad_alloc&)
+  {
+    delete ix; return fail(GCSA2_ERR_OUT_OF_MEMORY, "host staging allocation failed");
+  }
+  *out = ix;
+  return GCSA2_OK;
+}
+
+void gcsa2_index_destroy(gcsa2_index* ix)
+{
+  if(ix == nullptr) { return; }
+  DeviceGuard guard(ix->device);
+  if(ix->d_base) { (void)hipFree(ix->d_base); }
+  delete ix;
+}
+
+uint64_t gcsa2_size(const gcsa2_index* ix) { return ix->img.n; }
+uint64_t gcsa2_edge_count(const gcsa2_index* ix) { return ix->img.e; }
+uint64_t gcsa2_order(const gcsa2_index* ix) { return ix->order; }
+uint64_t gcsa2_sample_count(const gcsa2_index* ix) { return ix->img.sample_count; }
+uint64_t gcsa2_sample_bits(const gcsa2_index* ix) { return ix->img.sample_width; }
+int gcsa2_device(const gcsa2_index* ix) { return ix->device; }
+uint64_t gcsa2_device_bytes(const gcsa2_index* ix) { return ix->bytes; }
+uint64_t gcsa2_block_bits(const gcsa2_index*) { return BLOCK_BITS; }
+
+// ---- device-pointer entry points: enqueue only -------------------------------------------
+
+#define CHECK_INDEX(ix) do { if((ix) == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null index"); } } while(0)
+#define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if(e_ != hipSuccess) { \
+  return fail(GCSA2_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); } } while(0)
+
+int gcsa2_find_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets,
+                      uint64_t nq, uint64_t* d_ranges, void* stream)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_find, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+                     ix->img, d_patterns, d_offsets, nq, d_ranges);
+  LAUNCH_CHECK("k_find");
+  return GCSA2_OK;
+}
+
+int gcsa2_lf_device(const gcsa2_index* ix, const uint64_t* d_in, const uint8_t* d_comps, uint64_t nq,
+                    uint64_t* d_out, void* stream)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_lf, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+                     ix->img, d_in, d_comps, nq, d_out);
+  LAUNCH_CHECK("k_lf");
+  return GCSA2_OK;
+}
+
+int gcsa2_count_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t nq, uint64_t* d_counts, void* stream)
+{
+  CHECK_INDEX(ix);
+  if(!ix->img.has_counters) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without counters"); }
+  if(nq == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_count, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+                     ix->img, d_ranges, nq, d_counts);
+  LAUNCH_CHECK("k_count");
+  return GCSA2_OK;
+}
+
+int gcsa2_parent_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t nq, gcsa2_stnode* d_nodes, void* stream)
+{
+  CHECK_INDEX(ix);
+  if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
+  if(nq == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_parent, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+                     ix->img, d_ranges, nq, d_nodes);
+  LAUNCH_CHECK("k_parent");
+  return GCSA2_OK;
+}
+
+void gcsa2_locate_discard(gcsa2_locate_job* job)
+{
+  if(job == nullptr) { return; }
+  DeviceGuard guard(job->device);
+  if(job->d_offsets) { (void)hipFree(job->d_offsets); }
+  if(job->d_values) { (void)hipFree(job->d_values); }
+  delete job;
+}
+
+int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t nq, gcsa2_locate_job** job_out,
+                        const uint64_t** d_offsets, const uint64_t** d_values, uint64_t* total_values, void* stream_)
+{
+  CHECK_INDEX(ix);
+  if(job_out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null job pointer"); }
+  *job_out = nullptr;
+  if(!ix->img.has_samples || !ix->img.has_counters)
+  {
+    return fail(GCSA2_ERR_MISSING_COMPONENT, "locate needs samples and counters (extra_pointers sizes the output)");
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(ix->device);
+  gcsa2_locate_job* job = new(std::nothrow) gcsa2_locate_job();
+  if(job == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+  job->device = ix->device; job->nq = nq;
+  struct Cleanup { gcsa2_locate_job*& j; bool armed = true; ~Cleanup() { if(armed) { gcsa2_locate_discard(j); j = nullptr; } } };
+  Cleanup cleanup{job};
+
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_offsets), (nq + 1) * sizeof(u64)));
+  if(nq == 0)
+  {
+    HIP_TRY(hipMemsetAsync(job->d_offsets, 0, sizeof(u64), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    cleanup.armed = false; *job_out = job;
+    if(d_offsets) { *d_offsets = job->d_offsets; }
+    if(d_values) { *d_values = nullptr; }
+    if(total_values) { *total_values = 0; }
+    return GCSA2_OK;
+  }
+
+  DBuf<u64> node_counts, raw_counts, node_off, raw_off;
+  HIP_TRY(node_counts.alloc(nq + 1)); HIP_TRY(raw_counts.alloc(nq + 1));
+  HIP_TRY(node_off.alloc(nq + 1)); HIP_TRY(raw_off.alloc(nq + 1));
+  HIP_TRY(hipMemsetAsync(node_counts.p + nq, 0, sizeof(u64), stream));
+  HIP_TRY(hipMemsetAsync(raw_counts.p + nq, 0, sizeof(u64), stream));
+  hipLaunchKernelGGL(k_locate_sizes, dim3(grid_for(nq)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_counts.p, raw_counts.p);
+  LAUNCH_CHECK("k_locate_sizes");
+
+  // exclusive scans over nq + 1 entries: entry nq becomes the total
+  size_t tmp_bytes = 0, need = 0;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, node_counts.p, node_off.p, int(nq + 1), stream));
+  tmp_bytes = need;
+  DBuf<char> tmp;
+  HIP_TRY(tmp.alloc(tmp_bytes));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, node_counts.p, node_off.p, int(nq + 1), stream));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, raw_counts.p, raw_off.p, int(nq + 1), stream));
+  u64 totals[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(&totals[0], node_off.p + nq, sizeof(u64), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(&totals[1], raw_off.p + nq, sizeof(u64), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  u64 total_nodes = totals[0], total_raw = totals[1];
+  if(total_raw >= (u64(1) << 31)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate batch produces >= 2^31 values; split the batch"); }
+
+  if(total_raw == 0)
+  {
+    HIP_TRY(hipMemsetAsync(job->d_offsets, 0, (nq + 1) * sizeof(u64), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+  else
+  {
+    DBuf<u64> raw, sorted, flag_scan;
+    DBuf<u32> flags;
+    HIP_TRY(raw.alloc(total_raw)); HIP_TRY(sorted.alloc(total_raw));
+    HIP_TRY(flags.alloc(total_raw + 1)); HIP_TRY(flag_scan.alloc(total_raw + 1));
+    hipLaunchKernelGGL(k_locate_walk, dim3(grid_for(total_nodes)), dim3(TPB), 0, stream,
+                       ix->img, d_ranges, nq, node_off.p, raw_off.p, total_nodes, raw.p);
+    LAUNCH_CHECK("k_locate_walk");
+
+    // removeDuplicates: segmented sort, then flag + scan + compact
+    size_t sort_bytes = 0;
+    HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw.p, sorted.p, int(total_raw), int(nq),
+                                                       raw_off.p, raw_off.p + 1, 0, 64, stream));
+    DBuf<char> sort_tmp;
+    HIP_TRY(sort_tmp.alloc(sort_bytes));
+    HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp.p, sort_bytes, raw.p, sorted.p, int(total_raw), int(nq),
+                                                       raw_off.p, raw_off.p + 1, 0, 64, stream));
+    hipLaunchKernelGGL(k_mark_unique, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted.p, raw_off.p, nq, total_raw, flags.p);
+    LAUNCH_CHECK("k_mark_unique");
+    HIP_TRY(hipMemsetAsync(flags.p + total_raw, 0, sizeof(u32), stream));
+    size_t scan_bytes = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.p, flag_scan.p, int(total_raw + 1), stream));
+    DBuf<char> scan_tmp;
+    HIP_TRY(scan_tmp.alloc(scan_bytes));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, flags.p, flag_scan.p, int(total_raw + 1), stream));
+    u64 total_unique = 0;
+    HIP_TRY(hipMemcpyAsync(&total_unique, flag_scan.p + total_raw, sizeof(u64), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    job->total = total_unique;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_values), (total_unique > 0 ? total_unique : 1) * sizeof(u64)));
+    hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted.p, flags.p, flag_scan.p, total_raw, job->d_values);
+    LAUNCH_CHECK("k_compact");
+    hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, raw_off.p, flag_scan.p, nq, total_raw, total_unique, job->d_offsets);
+    LAUNCH_CHECK("k_final_offsets");
+    HIP_TRY(hipStreamSynchronize(stream));   // temporaries die at scope exit
+  }
+
+  cleanup.armed = false; *job_out = job;
+  if(d_offsets) { *d_offsets = job->d_offsets; }
+  if(d_values) { *d_values = job->d_values; }
+  if(total_values) { *total_values = job->total; }
+  return GCSA2_OK;
+}
+
+// ---- host-pointer entry points: copy in, run, copy out, synchronise ----------------------
+
+int gcsa2_find_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t* ranges)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  if(offsets == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  DeviceGuard guard(ix->device);
+  u64 total = offsets[nq];
+  DBuf<u8> d_pat; DBuf<u64> d_off, d_out;
+  HIP_TRY(d_pat.alloc(total + 1)); HIP_TRY(d_off.alloc(nq + 1)); HIP_TRY(d_out.alloc(2 * nq));
+  if(total > 0) { HIP_TRY(hipMemcpy(d_pat.p, patterns, total, hipMemcpyHostToDevice)); }
+  HIP_TRY(hipMemcpy(d_off.p, offsets, (nq + 1) * sizeof(u64), hipMemcpyHostToDevice));
+  int rc = gcsa2_find_device(ix, d_pat.p, d_off.p, nq, d_out.p, nullptr);
+  if(rc != GCSA2_OK) { return rc; }
+  HIP_TRY(hipMemcpy(ranges, d_out.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_lf_batch(const gcsa2_index* ix, const uint64_t* in, const uint8_t* comps, uint64_t nq, uint64_t* out)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in, d_out; DBuf<u8> d_c;
+  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(2 * nq)); HIP_TRY(d_c.alloc(nq));
+  HIP_TRY(hipMemcpy(d_in.p, in, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_c.p, comps, nq, hipMemcpyHostToDevice));
+  int rc = gcsa2_lf_device(ix, d_in.p, d_c.p, nq, d_out.p, nullptr);
+  if(rc != GCSA2_OK) { return rc; }
+  HIP_TRY(hipMemcpy(out, d_out.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_lf_node_batch(const gcsa2_index* ix, const uint64_t* in, uint64_t nq, uint64_t* out)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in, d_out;
+  HIP_TRY(d_in.alloc(nq)); HIP_TRY(d_out.alloc(nq));
+  HIP_TRY(hipMemcpy(d_in.p, in, nq * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_lf_node, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
+  LAUNCH_CHECK("k_lf_node");
+  HIP_TRY(hipMemcpy(out, d_out.p, nq * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_char_range(const gcsa2_index* ix, uint8_t comp, uint64_t* sp, uint64_t* ep)
+{
+  CHECK_INDEX(ix);
+  if(comp >= ix->img.sigma) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "comp >= sigma"); }
+  // charRange(comp) = find() of a one-character pattern whose byte maps to comp
+  int byte = -1;
+  for(int b = 0; b < 256; b++) { if(ix->img.char2comp[b] == comp) { byte = b; break; } }
+  if(byte < 0) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "no byte maps to this comp"); }
+  uint8_t pat = uint8_t(byte);
+  uint64_t off[2] = {0, 1}, rng[2];
+  int rc = gcsa2_find_batch(ix, &pat, off, 1, rng);
+  if(rc != GCSA2_OK) { return rc; }
+  *sp = rng[0]; *ep = rng[1];
+  return GCSA2_OK;
+}
+
+int gcsa2_lf_all_batch(const gcsa2_index* ix, const uint64_t* in, uint64_t nq, int all, uint64_t* out)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  u64 sigma = ix->img.sigma;
+  DBuf<u64> d_in, d_out;
+  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(2 * nq * sigma));
+  HIP_TRY(hipMemcpy(d_in.p, in, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_lf_all, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, all, d_out.p);
+  LAUNCH_CHECK("k_lf_all");
+  HIP_TRY(hipMemcpy(out, d_out.p, 2 * nq * sigma * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_count_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, uint64_t* counts)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in, d_out;
+  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(nq));
+  HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
+  int rc = gcsa2_count_device(ix, d_in.p, nq, d_out.p, nullptr);
+  if(rc != GCSA2_OK) { return rc; }
+  HIP_TRY(hipMemcpy(counts, d_out.p, nq * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_locate_run(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, uint64_t* offsets, gcsa2_locate_job** job)
+{
+  CHECK_INDEX(ix);
+  if(offsets == nullptr || job == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in;
+  HIP_TRY(d_in.alloc(2 * nq));
+  if(nq > 0) { HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice)); }
+  const u64* d_off = nullptr;
+  int rc = gcsa2_locate_device(ix, d_in.p, nq, job, &d_off, nullptr, nullptr, nullptr);
+  if(rc != GCSA2_OK) { return rc; }
+  HIP_TRY(hipMemcpy(offsets, d_off, (nq + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_locate_fetch(gcsa2_locate_job* job, uint64_t* values, uint64_t capacity)
+{
+  if(job == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null job"); }
+  if(capacity < job->total) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer smaller than offsets[n_queries]"); }
+  {
+    DeviceGuard guard(job->device);
+    if(job->total > 0) { HIP_TRY(hipMemcpy(values, job->d_values, job->total * sizeof(u64), hipMemcpyDeviceToHost)); }
+  }
+  gcsa2_locate_discard(job);
+  return GCSA2_OK;
+}
+
+int gcsa2_parent_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, gcsa2_stnode* nodes)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in; DBuf<gcsa2_stnode> d_out;
+  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(nq));
+  HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
+  int rc = gcsa2_parent_device(ix, d_in.p, nq, d_out.p, nullptr);
+  if(rc != GCSA2_OK) { return rc; }
+  HIP_TRY(hipMemcpy(nodes, d_out.p, nq * sizeof(gcsa2_stnode), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_depth_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, uint64_t* depths)
+{
+  CHECK_INDEX(ix);
+  if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in, d_out;
+  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(nq));
+  HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_depth, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
+  LAUNCH_CHECK("k_depth");
+  HIP_TRY(hipMemcpy(depths, d_out.p, nq * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_sv_batch(const gcsa2_index* ix, int op, const uint64_t* positions, uint64_t nq, uint64_t* results)
+{
+  CHECK_INDEX(ix);
+  if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
+  if(op < 0 || op > 3) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "op must be 0..3"); }
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in, d_out;
+  HIP_TRY(d_in.alloc(nq)); HIP_TRY(d_out.alloc(2 * nq));
+  HIP_TRY(hipMemcpy(d_in.p, positions, nq * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_sv, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, op, d_in.p, nq, d_out.p);
+  LAUNCH_CHECK("k_sv");
+  HIP_TRY(hipMemcpy(results, d_out.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_rmq_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, uint64_t* results)
+{
+  CHECK_INDEX(ix);
+  if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in, d_out;
+  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(2 * nq));
+  HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_rmq, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
+  LAUNCH_CHECK("k_rmq");
+  HIP_TRY(hipMemcpy(results, d_out.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// layout.hpp -- HBM image of a GCSA2 index and the device-side succinct primitives.
+//
+// Every bitvector of the reference (fast_bwt / sparse_bwt / edges / sampled_paths / samples /
+// the Sadakane vectors; include/gcsa/gcsa.h:214-240) is stored in ONE format, "RB64":
+//
+//   block b = 8 x u64 = 64 bytes, 64-byte aligned
+//     word 0      number of 1-bits in [0, 448 b)
+//     words 1..7  payload bits [448 b, 448 (b + 1)), LSB first
+//
+// so rank(i) is exactly one aligned 64-byte fetch (the "rank probe" of SURVEY.md 8(d)), and
+// because 448 = 7 x 64 payload word j of block b is plain word 7 b + j (no bit shifting on
+// upload).  A vector of `size` bits gets size / 448 + 1 blocks so that rank(size) is legal
+// (it occurs for ep = n - 1, include/gcsa/gcsa.h:272).  The sparse vectors of the reference
+// (sd_vector for $, N, # and for the Sadakane counters) are stored densely in the same format:
+// rank / select / access are integer functions of the bit sequence, so results are identical
+// and the fast/sparse branch of gcsa.h:157-158 disappears.
+//
+// select_1 uses one u32 hint per 448 ones (block holding the (448 j + 1)-th one) followed by a
+// short binary search over block counters and an in-block scan.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace g2 {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t  u8;
+
+constexpr u64 BLOCK_WORDS   = 8;
+constexpr u64 PAYLOAD_WORDS = 7;
+constexpr u64 BLOCK_BITS    = 448;
+constexpr u64 BLOCK_BYTES   = 64;
+constexpr u64 SELECT_SAMPLE = 448;
+constexpr int MAX_SIGMA     = 16;
+constexpr int MAX_LCP_LEVELS = 16;
+
+struct DevBV
+{
+  const u64* blocks;   // nblocks * 8 words
+  const u32* hints;    // select hints or nullptr
+  u64 size, nblocks, ones;
+};
+
+// Passed to kernels by value (kernarg segment, scalar loads).
+struct DevImage
+{
+  u64 n, e, sigma, fast_chars;
+  u64 C[MAX_SIGMA + 1];
+  DevBV bwt[MAX_SIGMA];
+  DevBV edges;
+  DevBV sampled;        // sampled_paths
+  DevBV samples;        // + select
+  const u64* stored;    // packed stored_samples
+  u64 sample_count, sample_width;
+  DevBV xfilter;        // extra_pointers.filter
+  DevBV xvalues;        // extra_pointers.values, + select
+  DevBV redundant;      // redundant_pointers.data, + select
+  const u8* lcp;        // LCP bytes + range-minimum tree levels
+  u64 lcp_size, lcp_branching, lcp_levels, lcp_values;
+  u64 lcp_offsets[MAX_LCP_LEVELS + 1];
+  int has_samples, has_counters, has_lcp;
+  u8 char2comp[256];
+};
+
+// ------------------------------------------------------------------------------------------
+// device primitives
+
+struct Block { u64 w[8]; };
+
+__device__ __forceinline__ Block load_block(const u64* p)
+{
+  // 64-byte aligned: four 16-byte vector loads
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+  ulonglong2 a = q[0], b = q[1], c = q[2], d = q[3];
+  Block r;
+  r.w[0] = a.x; r.w[1] = a.y; r.w[2] = b.x; r.w[3] = b.y;
+  r.w[4] = c.x; r.w[5] = c.y; r.w[6] = d.x; r.w[7] = d.y;
+  return r;
+}
+
+// rank inside a loaded block; r = bit offset in the block, 0 <= r < 448
+__device__ __forceinline__ u64 rank_in_block(const Block& b, u32 r)
+{
+  u64 res = b.w[0];
+  u32 wq = r >> 6, rb = r & 63;
+  u64 part = (u64(1) << rb) - 1;
+#pragma unroll
+  for(u32 j = 0; j < 7; j++)
+  {
+    u64 m = (j < wq ? ~u64(0) : (j == wq ? part : u64(0)));
+    res += __popcll(b.w[j + 1] & m);
+  }
+  return res;
+}
+
+__device__ __forceinline__ u64 block_of(u64 i) { return i / BLOCK_BITS; }
+
+// number of 1-bits in [0, i), 0 <= i <= size
+__device__ __forceinline__ u64 bv_rank(const DevBV& bv, u64 i)
+{
+  u64 blk = block_of(i);
+  Block b = load_block(bv.blocks + blk * BLOCK_WORDS);
+  return rank_in_block(b, u32(i - blk * BLOCK_BITS));
+}
+
+// rank at two positions; one fetch when both fall into the same block
+__device__ __forceinline__ void bv_rank2(const DevBV& bv, u64 i, u64 j, u64& ri, u64& rj)
+{
+  u64 bi = block_of(i), bj = block_of(j);
+  Block a = load_block(bv.blocks + bi * BLOCK_WORDS);
+  ri = rank_in_block(a, u32(i - bi * BLOCK_BITS));
+  if(bj == bi) { rj = rank_in_block(a, u32(j - bj * BLOCK_BITS)); }
+  else
+  {
+    Block b = load_block(bv.blocks + bj * BLOCK_WORDS);
+    rj = rank_in_block(b, u32(j - bj * BLOCK_BITS));
+  }
+}
+
+__device__ __forceinline__ bool bv_get(const DevBV& bv, u64 i)
+{
+  u64 blk = block_of(i);
+  u32 r = u32(i - blk * BLOCK_BITS);
+  return (bv.blocks[blk * BLOCK_WORDS + 1 + (r >> 6)] >> (r & 63)) & 1;
+}
+
+// access + rank with one block fetch
+__device__ __forceinline__ bool bv_get_rank(const DevBV& bv, u64 i, u64& rank)
+{
+  u64 blk = block_of(i);
+  u32 r = u32(i - blk * BLOCK_BITS);
+  Block b = load_block(bv.blocks + blk * BLOCK_WORDS);
+  rank = rank_in_block(b, r);
+  return (b.w[1 + (r >> 6)] >> (r & 63)) & 1;
+}
+
+// position (0..63) of the k-th (k >= 1) set bit of w
+__device__ __forceinline__ u32 select_in_word(u64 w, u32 k)
+{
+  u32 pos = 0;
+#pragma unroll
+  for(u32 s = 32; s >= 1; s >>= 1)
+  {
+    u32 c = __popcll((w >> pos) & ((u64(1) << s) - 1));
+    if(c < k) { k -= c; pos += s; }
+  }
+  return pos;
+}
+
+// position of the r-th 1-bit, 1 <= r <= ones
+__device__ __forceinline__ u64 bv_select(const DevBV& bv, u64 r)
+{
+  u64 k = (r - 1) / SELECT_SAMPLE;
+  u64 lo = bv.hints[k], hi = bv.hints[k + 1];
+  while(lo < hi)   // largest block whose counter is < r
+  {
+    u64 mid = (lo + hi + 1) >> 1;
+    if(bv.blocks[mid * BLOCK_WORDS] < r) { lo = mid; } else { hi = mid - 1; }
+  }
+  Block b = load_block(bv.blocks + lo * BLOCK_WORDS);
+  u32 rem = u32(r - b.w[0]);
+  u64 pos = lo * BLOCK_BITS;
+  u32 word = 0, found = 0;
+#pragma unroll
+  for(u32 j = 0; j < 7; j++)
+  {
+    u32 c = __popcll(b.w[j + 1]);
+    if(!found)
+    {
+      if(c >= rem) { word = j; found = 1; } else { rem -= c; }
+    }
+  }
+  u64 w = b.w[1];
+#pragma unroll
+  for(u32 j = 1; j < 7; j++) { if(word == j) { w = b.w[j + 1]; } }
+  return pos + (u64(word) << 6) + select_in_word(w, rem);
+}
+
+__device__ __forceinline__ u64 packed_get(const u64* words, u64 width, u64 i)
+{
+  u64 pos = i * width, word = pos >> 6, shift = pos & 63;
+  u64 val = words[word] >> shift;
+  if(shift + width > 64) { val |= words[word + 1] << (64 - shift); }
+  return (width >= 64 ? val : val & ((u64(1) << width) - 1));
+}
+
+__device__ __forceinline__ bool range_empty(u64 sp, u64 ep) { return sp + 1 > ep + 1; }
+
+}  // namespace g2

@@ -1,0 +1,141 @@
+"""GPU parity tests: the HIP engine, called through the C ABI (gcsa2_amd/binding.py -> ctypes ->
+libgcsa2_hip.so), must equal the CPU oracle bit for bit on the same seeded inputs.
+
+Small definitional indexes (bubbles, cycles, N, repeats) exercise every edge case the oracle is
+pinned on; larger cases live in test_gpu_scale.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from workload import graphs
+from workload.brute_builder import build
+from workload.rng import SplitMix64
+from gcsa2_amd.hostview import concat_patterns
+from test_oracle import CASES, random_patterns, truncate_at_sink
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from gcsa2_amd import binding
+    assert binding.device_count() >= 1, "no MI355X visible"
+    return binding
+
+
+@pytest.fixture(scope="module", params=range(len(CASES)), ids=[c[0] for c in CASES])
+def case(request, engine):
+    from oracle.oracle import OracleIndex
+    name, g, K = CASES[request.param]
+    ix = build(g, K, sample_period=8, branching=4)
+    gpu, lcp = engine.open_index(ix, device=0)
+    return name, g, K, ix, gpu, lcp, OracleIndex(ix)
+
+
+def all_ranges(ix, seed, extra=200):
+    rng = SplitMix64(seed)
+    ranges = [(i, i) for i in range(ix.n)] + [(0, ix.n - 1)]
+    for _ in range(extra):
+        a = rng.below(ix.n)
+        ranges.append((a, min(ix.n - 1, a + rng.below(8))))
+    return ranges
+
+
+def test_paper_example_on_gpu(engine, paper):
+    ix = build(graphs.paper_graph(), paper["order"], sample_period=1 << 40)
+    gpu, lcp = engine.open_index(ix)
+    for q in paper["find"]:
+        assert list(gpu.find(q["pattern"].encode())) == q["range"], q
+    for q in paper["locate"]:
+        assert list(gpu.locate(tuple(q["range"]))) == q["values"]
+        assert gpu.count(tuple(q["range"])) == q["count"]
+    assert gpu.LF((9, 12), 1) == (2, 4)
+    assert gpu.find(b"") == (0, 15)
+    assert gpu.size() == 16 and gpu.edgeCount() == 20 and gpu.order() == 3
+
+
+def test_find(case):
+    name, g, K, ix, gpu, lcp, cpu = case
+    pats = [truncate_at_sink(p) for p in random_patterns(g, K, 0x77, 600)]
+    pats += [b"", b"A", b"N", b"#", b"$", b"x", b"acgt", b"\x00", bytes([200, 65])]
+    data, off = concat_patterns(pats)
+    got = gpu.find_batch(data, off)
+    want = cpu.find_batch(data, off)
+    assert np.array_equal(got, want), name
+    for p in pats[:20]:
+        assert gpu.find(p) == cpu.find(p)
+
+
+def test_lf(case):
+    name, g, K, ix, gpu, lcp, cpu = case
+    ranges, comps = [], []
+    for r in all_ranges(ix, 0x11):
+        for c in range(ix.sigma):
+            ranges.append(r); comps.append(c)
+    ranges = np.array(ranges, dtype=np.uint64)
+    comps = np.array(comps, dtype=np.uint8)
+    assert np.array_equal(gpu.lf_batch(ranges, comps), cpu.lf_batch(ranges, comps)), name
+    nodes = np.arange(ix.n, dtype=np.uint64)
+    want = np.array([cpu.LF(int(i)) for i in nodes], dtype=np.uint64)
+    assert np.array_equal(gpu.lf_node_batch(nodes), want), name
+    for c in range(ix.sigma):
+        if ix.C[c + 1] > 0:
+            assert gpu.charRange(c) == cpu.charRange(c)
+    rr = np.array(all_ranges(ix, 0x12, 50) + [(1, 0)], dtype=np.uint64)
+    for all_ in (0, 1):
+        got = gpu.lf_all_batch(rr, all_)
+        for i, r in enumerate(rr):
+            want = cpu.LF_all(tuple(int(x) for x in r)) if all_ else cpu.LF_fast(tuple(int(x) for x in r))
+            assert [tuple(int(x) for x in t) for t in got[i]] == want, (name, r, all_)
+
+
+def test_count_locate(case):
+    name, g, K, ix, gpu, lcp, cpu = case
+    ranges = all_ranges(ix, 0x13) + [(1, 0), (3, 2), (0, ix.n), (ix.n, ix.n + 3)]
+    arr = np.array(ranges, dtype=np.uint64)
+    assert np.array_equal(gpu.count_batch(arr), cpu.count_batch(arr)), name
+    go, gv = gpu.locate_batch(arr)
+    co, cv = cpu.locate_batch(arr)
+    assert np.array_equal(go, co), name
+    assert np.array_equal(gv, cv), name
+    # count() == |locate()| on ranges produced by find (the query_gcsa consistency check,
+    # reference benchmark/query_gcsa.cpp:171-179)
+    pats = [truncate_at_sink(p)[:K] for p in random_patterns(g, K, 0x78, 300)]
+    data, off = concat_patterns(pats)
+    found = gpu.find_batch(data, off)
+    offs, vals = gpu.locate_batch(found)
+    assert np.array_equal(np.diff(offs), gpu.count_batch(found)), name
+    # empty batch
+    eo, ev = gpu.locate_batch(np.zeros((0, 2), dtype=np.uint64))
+    assert eo.tolist() == [0] and ev.shape[0] == 0
+
+
+def test_suffix_tree_ops(case):
+    name, g, K, ix, gpu, lcp, cpu = case
+    pos = np.arange(ix.n + 2, dtype=np.uint64)
+    for op, fn in ((0, cpu.psv), (1, cpu.psev), (2, cpu.nsv), (3, cpu.nsev)):
+        want = np.array([fn(int(p)) for p in pos], dtype=np.uint64)
+        assert np.array_equal(lcp._sv_batch(op, pos), want), (name, op)
+    ranges = all_ranges(ix, 0x14)
+    rng = SplitMix64(0x15)
+    for _ in range(200):
+        a = rng.below(ix.n)
+        ranges.append((a, min(ix.n - 1, a + rng.below(ix.n))))
+    arr = np.array(ranges, dtype=np.uint64)
+    assert np.array_equal(lcp.parent_batch(arr), cpu.parent_batch(arr)), name
+    assert np.array_equal(lcp.depth_batch(arr), cpu.depth_batch(arr)), name
+    want = np.array([cpu.rmq(int(a), int(b)) for a, b in arr] , dtype=np.uint64)
+    assert np.array_equal(lcp.rmq_batch(arr), want), name
+    assert lcp.rmq(3, 2) == cpu.rmq(3, 2)
+
+
+def test_errors(engine):
+    ix = build(graphs.paper_graph(), 3)
+    g = engine.GCSA(ix, with_counters=False, with_lcp=False)
+    with pytest.raises(engine.Gcsa2Error) as e:
+        g.count((0, 1))
+    assert e.value.code == -5
+    with pytest.raises(engine.Gcsa2Error):
+        engine.GCSA(ix, device=99)
