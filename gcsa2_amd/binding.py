@@ -23,7 +23,7 @@ EXPORTS = [
     "gcsa2_device_count", "gcsa2_index_create", "gcsa2_index_destroy", "gcsa2_last_error",
     "gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count", "gcsa2_sample_bits",
     "gcsa2_device", "gcsa2_device_bytes", "gcsa2_block_bits",
-    "gcsa2_find_batch", "gcsa2_find_device", "gcsa2_lf_batch", "gcsa2_lf_device",
+    "gcsa2_find_batch", "gcsa2_find_device", "gcsa2_find_stats_device", "gcsa2_lf_batch", "gcsa2_lf_device",
     "gcsa2_lf_node_batch", "gcsa2_char_range", "gcsa2_lf_all_batch",
     "gcsa2_count_batch", "gcsa2_count_device",
     "gcsa2_locate_run", "gcsa2_locate_fetch", "gcsa2_locate_discard", "gcsa2_locate_device",
@@ -66,6 +66,7 @@ def load_library():
     L.gcsa2_device.argtypes = [vp]
     L.gcsa2_find_batch.argtypes = [vp, u8p, u64p, u64, u64p]
     L.gcsa2_find_device.argtypes = [vp, vp, vp, u64, vp, vp]
+    L.gcsa2_find_stats_device.argtypes = [vp, vp, vp, u64, vp, vp, vp]
     L.gcsa2_lf_batch.argtypes = [vp, u64p, u8p, u64, u64p]
     L.gcsa2_lf_device.argtypes = [vp, vp, vp, u64, vp, vp]
     L.gcsa2_lf_node_batch.argtypes = [vp, u64p, u64, u64p]
@@ -227,6 +228,9 @@ class GCSA:
 
     def find_device(self, d_patterns, d_offsets, nq, d_ranges, stream=0):
         _check(self._L.gcsa2_find_device(self._h, d_patterns, d_offsets, nq, d_ranges, stream))
+
+    def find_stats_device(self, d_patterns, d_offsets, nq, d_ranges, d_stats, stream=0):
+        _check(self._L.gcsa2_find_stats_device(self._h, d_patterns, d_offsets, nq, d_ranges, d_stats, stream))
 
     # ---- LF -----------------------------------------------------------------------------
     def lf_batch(self, ranges, comps):

@@ -64,36 +64,52 @@ __device__ __forceinline__ DevBV bwt_of(const DevImage& img, u32 comp)
   return bv;
 }
 
+// STATS = true additionally counts, per launch, the distinct rank blocks fetched and the LF steps
+// executed (the "algorithmic bytes" of the roofline model): stats[0] += blocks,
+// stats[1] += steps.  The timed path is the STATS = false instantiation.
+template<bool STATS>
 __global__ __launch_bounds__(TPB) void k_find(DevImage img, const u8* __restrict__ patterns,
                                               const u64* __restrict__ offsets, u64 nq,
-                                              u64* __restrict__ out)
+                                              u64* __restrict__ out, unsigned long long* __restrict__ stats)
 {
   __shared__ Tables t;
   stage_tables(img, t);
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  u64 begin = offsets[q], len = offsets[q + 1] - begin;
-  u64 sp = 0, ep = img.n - 1;
-  if(len > 0 && img.n > 0)                                  // gcsa.h:99
+  u64 blocks = 0, steps = 0;
+  if(q < nq)
   {
-    const u8* p = patterns + begin;
-    u64 i = len - 1;
-    u32 comp = t.c2c[p[i]];
-    sp = t.C[comp]; ep = t.C[comp + 1] - 1;                 // charRange, utils.h:414-419
-    path_node_range(img, sp, ep);                           // gcsa.h:150-153 (no emptiness check)
-    while(!range_empty(sp, ep) && i > 0)                    // gcsa.h:103
+    u64 begin = offsets[q], len = offsets[q + 1] - begin;
+    u64 sp = 0, ep = img.n - 1;
+    if(len > 0 && img.n > 0)                                  // gcsa.h:99
     {
-      i--;
-      comp = t.c2c[p[i]];
-      DevBV bv = bwt_of(img, comp);
-      u64 ra, rb;
-      bv_rank2(bv, sp, ep + 1, ra, rb);                     // gcsa.h:271-272
-      sp = t.C[comp] + ra; ep = t.C[comp] + rb - 1;
-      if(range_empty(sp, ep)) { break; }                    // gcsa.h:160: edge-space integers
-      path_node_range(img, sp, ep);                         // gcsa.h:161
+      const u8* p = patterns + begin;
+      u64 i = len - 1;
+      u32 comp = t.c2c[p[i]];
+      sp = t.C[comp]; ep = t.C[comp + 1] - 1;                 // charRange, utils.h:414-419
+      if(STATS) { blocks += 1 + (block_of(clampu(sp, img.e)) != block_of(clampu(ep, img.e))); }
+      path_node_range(img, sp, ep);                           // gcsa.h:150-153 (no emptiness check)
+      while(!range_empty(sp, ep) && i > 0)                    // gcsa.h:103
+      {
+        i--;
+        comp = t.c2c[p[i]];
+        DevBV bv = bwt_of(img, comp);
+        u64 ra, rb;
+        if(STATS) { steps++; blocks += 1 + (block_of(sp) != block_of(ep + 1)); }
+        bv_rank2(bv, sp, ep + 1, ra, rb);                     // gcsa.h:271-272
+        sp = t.C[comp] + ra; ep = t.C[comp] + rb - 1;
+        if(range_empty(sp, ep)) { break; }                    // gcsa.h:160: edge-space integers
+        if(STATS) { blocks += 1 + (block_of(sp) != block_of(ep)); }
+        path_node_range(img, sp, ep);                         // gcsa.h:161
+      }
     }
+    reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep);
   }
-  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep);
+  if(STATS)
+  {
+    // wave reduction, one atomic per wave
+    for(int o = 32; o > 0; o >>= 1) { blocks += __shfl_down(blocks, o, 64); steps += __shfl_down(steps, o, 64); }
+    if((threadIdx.x & 63) == 0) { atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps); }
+  }
 }
 
 __global__ __launch_bounds__(TPB) void k_lf(DevImage img, const u64* __restrict__ in,
@@ -766,9 +782,22 @@ int gcsa2_find_device(const gcsa2_index* ix, const uint8_t* d_patterns, const ui
 {
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
-  hipLaunchKernelGGL(k_find, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
-                     ix->img, d_patterns, d_offsets, nq, d_ranges);
+  hipLaunchKernelGGL(k_find<false>, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+                     ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr);
   LAUNCH_CHECK("k_find");
+  return GCSA2_OK;
+}
+
+int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets,
+                            uint64_t nq, uint64_t* d_ranges, uint64_t* d_stats, void* stream)
+{
+  CHECK_INDEX(ix);
+  if(d_stats == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null stats buffer"); }
+  if(nq == 0) { return GCSA2_OK; }
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64 atomics");
+  hipLaunchKernelGGL(k_find<true>, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+                     ix->img, d_patterns, d_offsets, nq, d_ranges, reinterpret_cast<unsigned long long*>(d_stats));
+  LAUNCH_CHECK("k_find<stats>");
   return GCSA2_OK;
 }
 

@@ -136,6 +136,14 @@ int gcsa2_find_device(const gcsa2_index* index, const uint8_t* d_patterns,
                       const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
                       void* stream);
 
+/* Instrumented find for the roofline model (not the timed path): same results in d_ranges, and
+ * d_stats[0] += number of distinct 64-byte rank blocks fetched, d_stats[1] += LF steps executed
+ * (a step whose two probes fall into one block counts once).  The caller zeroes
+ * d_stats. */
+int gcsa2_find_stats_device(const gcsa2_index* index, const uint8_t* d_patterns,
+                            const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
+                            uint64_t* d_stats, void* stream);
+
 /* ---- LF: GCSA::LF(range, comp) (gcsa.h:155-162), GCSA::LF(path_node) (gcsa.h:165-183),
  *      GCSA::charRange(comp) (gcsa.h:150-153) ------------------------------------------------- */
 int gcsa2_lf_batch(const gcsa2_index* index, const uint64_t* ranges_in, const uint8_t* comps,
