@@ -1,0 +1,110 @@
+"""CPU tests of the host side: C-ABI surface, loud failure without a device, query sharding +
+gather over gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as entry
+    entry.build()
+    from gcsa2_amd import binding
+    return binding
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "gcsa2_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gcsa2_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    names = declared_functions()
+    assert len(names) >= 30
+    lib = ctypes.CDLL(built.LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/gcsa2_hip.h but not exported"
+    assert sorted(built.EXPORTS) == names, "binding.EXPORTS out of sync with the header"
+
+
+def test_fails_loudly_without_device(built):
+    from workload import graphs
+    from workload.brute_builder import build
+    if built.load_library().gcsa2_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    ix = build(graphs.paper_graph(), 3)
+    with pytest.raises(built.Gcsa2Error) as e:
+        built.GCSA(ix)
+    assert e.value.code == -2   # GCSA2_ERR_NO_DEVICE: no silent CPU path
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gcsa2_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower().replace("no cpu fallback", ""), f"{f} mentions the oracle"
+
+
+def test_shard_bounds():
+    from gcsa2_amd.shard import shard_bounds, slice_batch
+    assert shard_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert shard_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    flat = np.frombuffer(b"AACCCGT", dtype=np.uint8)
+    off = np.array([0, 2, 5, 6, 7], dtype=np.uint64)
+    f, o = slice_batch(flat, off, 1, 3)
+    assert f.tobytes() == b"CCCG" and o.tolist() == [0, 3, 4]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, nq, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from workload import graphs
+    from workload.brute_builder import build
+    from workload.rng import SplitMix64
+    from gcsa2_amd.hostview import concat_patterns
+    from gcsa2_amd.shard import find_sharded
+    from oracle.oracle import OracleIndex
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ix = build(graphs.snp_graph(120, 0x52, 0x53, snp_period=8, node_len=8), 6, sample_period=8, branching=4)
+    cpu = OracleIndex(ix)   # stands in for the GPU engine: this test covers sharding + gather only
+    rng = SplitMix64(7)
+    pats = ["".join("ACGT"[rng.below(4)] for _ in range(1 + rng.below(7))).encode() for _ in range(nq)]
+    flat, off = concat_patterns(pats)
+
+    def compute(sub_flat, sub_off):
+        return torch.from_numpy(cpu.find_batch(sub_flat, sub_off).view(np.int64))
+
+    res = find_sharded(compute, flat, off)
+    if rank == 0:
+        want = cpu.find_batch(flat, off)
+        assert np.array_equal(res.numpy().view(np.uint64), want)
+        open(out_path, "w").write("ok")
+    else:
+        assert res is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nq", [101, 1])
+def test_sharded_find_gloo_world2(tmp_path, nq):
+    import torch.multiprocessing as mp
+    out = tmp_path / "ok.txt"
+    mp.spawn(_worker, args=(2, _free_port(), nq, str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
