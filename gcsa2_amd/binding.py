@@ -28,7 +28,10 @@ EXPORTS = [
     "gcsa2_count_batch", "gcsa2_count_device",
     "gcsa2_locate_run", "gcsa2_locate_fetch", "gcsa2_locate_discard", "gcsa2_locate_device",
     "gcsa2_parent_batch", "gcsa2_parent_device", "gcsa2_depth_batch", "gcsa2_sv_batch",
-    "gcsa2_rmq_batch",
+    "gcsa2_rmq_batch", "gcsa2_locate_max", "gcsa2_sample_range_batch", "gcsa2_sample_batch",
+    "gcsa2_sampled_positions", "gcsa2_sigma", "gcsa2_fast_chars", "gcsa2_alphabet",
+    "gcsa2_lcp_size", "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching",
+    "gcsa2_lcp_access_batch",
 ]
 
 
@@ -60,7 +63,9 @@ def load_library():
     L.gcsa2_index_destroy.argtypes = [vp]
     L.gcsa2_index_destroy.restype = None
     for name in ("gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count",
-                 "gcsa2_sample_bits", "gcsa2_device_bytes", "gcsa2_block_bits"):
+                 "gcsa2_sample_bits", "gcsa2_device_bytes", "gcsa2_block_bits",
+                 "gcsa2_sampled_positions", "gcsa2_sigma", "gcsa2_fast_chars", "gcsa2_lcp_size",
+                 "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching"):
         getattr(L, name).restype = u64
         getattr(L, name).argtypes = [vp]
     L.gcsa2_device.argtypes = [vp]
@@ -74,17 +79,23 @@ def load_library():
     L.gcsa2_lf_all_batch.argtypes = [vp, u64p, u64, i32, u64p]
     L.gcsa2_count_batch.argtypes = [vp, u64p, u64, u64p]
     L.gcsa2_count_device.argtypes = [vp, vp, u64, vp, vp]
-    L.gcsa2_locate_run.argtypes = [vp, u64p, u64, u64p, C.POINTER(vp)]
+    L.gcsa2_locate_run.argtypes = [vp, u64p, u64, i32, u64p, C.POINTER(vp)]
     L.gcsa2_locate_fetch.argtypes = [vp, u64p, u64]
     L.gcsa2_locate_discard.argtypes = [vp]
     L.gcsa2_locate_discard.restype = None
-    L.gcsa2_locate_device.argtypes = [vp, vp, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+    L.gcsa2_locate_device.argtypes = [vp, vp, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                       u64p, vp]
     L.gcsa2_parent_batch.argtypes = [vp, u64p, u64, vp]
     L.gcsa2_parent_device.argtypes = [vp, vp, u64, vp, vp]
     L.gcsa2_depth_batch.argtypes = [vp, u64p, u64, u64p]
     L.gcsa2_sv_batch.argtypes = [vp, i32, u64p, u64, u64p]
     L.gcsa2_rmq_batch.argtypes = [vp, u64p, u64, u64p]
+    L.gcsa2_locate_max.argtypes = [vp, u64, u64, u64, u64p, u64, u64p]
+    L.gcsa2_sample_range_batch.argtypes = [vp, u64p, u64, u64p]
+    L.gcsa2_sample_batch.argtypes = [vp, u64p, u64, u64p, u8p]
+    L.gcsa2_alphabet.argtypes = [vp, u8p, u64p]
+    L.gcsa2_alphabet.restype = None
+    L.gcsa2_lcp_access_batch.argtypes = [vp, u64p, u64, u64p]
     _lib = L
     return L
 
@@ -280,27 +291,68 @@ class GCSA:
         return int(self.count_batch(np.array([rng], dtype=np.uint64))[0])
 
     # ---- locate -------------------------------------------------------------------------
-    def locate_batch(self, ranges):
-        """CSR (offsets[nq+1], values): sorted distinct node_type values per range."""
+    def locate_batch(self, ranges, sort=True):
+        """CSR (offsets[nq+1], values): sorted distinct node_type values per range
+        (sort=False: path order with duplicates, as the reference's sort == false)."""
         ranges = _ranges(ranges)
         nq = ranges.shape[0]
         offsets = np.zeros(nq + 1, dtype=np.uint64)
         job = C.c_void_p()
-        _check(self._L.gcsa2_locate_run(self._h, _p64(ranges), nq, _p64(offsets), C.byref(job)))
+        _check(self._L.gcsa2_locate_run(self._h, _p64(ranges), nq, int(sort), _p64(offsets), C.byref(job)))
         values = np.zeros(max(int(offsets[nq]), 1), dtype=np.uint64)
         _check(self._L.gcsa2_locate_fetch(job, _p64(values), values.shape[0]))
         return offsets, values[: int(offsets[nq])]
 
-    def locate(self, rng):
+    def locate(self, rng, sort=True, max_positions=None):
+        """locate(path_node) / locate(range) / locate(range, max_positions) (gcsa.h:126-128)."""
         if isinstance(rng, (int, np.integer)):
             rng = (int(rng), int(rng))
-        return self.locate_batch(np.array([rng], dtype=np.uint64))[1]
+        if max_positions is None:
+            return self.locate_batch(np.array([rng], dtype=np.uint64), sort)[1]
+        cap = max(1, min(int(max_positions), self.count(rng)))
+        values = np.zeros(cap, dtype=np.uint64)
+        cnt = C.c_uint64()
+        _check(self._L.gcsa2_locate_max(self._h, rng[0], rng[1], max_positions, _p64(values), cap, C.byref(cnt)))
+        return values[: cnt.value]
 
-    def locate_device(self, d_ranges, nq, stream=0):
+    # ---- samples (gcsa.h:191-210) ---------------------------------------------------------
+    def sample_range_batch(self, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+        out = np.zeros((nodes.shape[0], 3), dtype=np.uint64)
+        _check(self._L.gcsa2_sample_range_batch(self._h, _p64(nodes), nodes.shape[0], _p64(out)))
+        return out
+
+    def sampled(self, node):
+        return bool(self.sample_range_batch([node])[0, 0])
+
+    def sampleRange(self, node):
+        r = self.sample_range_batch([node])[0]
+        return (int(r[1]), int(r[2]))
+
+    def firstSample(self, node):
+        return int(self.sample_range_batch([node])[0, 1])
+
+    def sample_batch(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        values = np.zeros(idx.shape[0], dtype=np.uint64)
+        last = np.zeros(idx.shape[0], dtype=np.uint8)
+        _check(self._L.gcsa2_sample_batch(self._h, _p64(idx), idx.shape[0], _p64(values), _p8(last)))
+        return values, last.astype(bool)
+
+    def sample(self, i):
+        return int(self.sample_batch([i])[0][0])
+
+    def lastSample(self, i):
+        return bool(self.sample_batch([i])[1][0])
+
+    def sampledPositions(self):
+        return int(self._L.gcsa2_sampled_positions(self._h))
+
+    def locate_device(self, d_ranges, nq, stream=0, sort=True):
         """Returns (job, d_offsets, d_values, total); free with locate_discard(job)."""
         job, d_off, d_val = C.c_void_p(), C.c_void_p(), C.c_void_p()
         total = C.c_uint64()
-        _check(self._L.gcsa2_locate_device(self._h, d_ranges, nq, C.byref(job), C.byref(d_off),
+        _check(self._L.gcsa2_locate_device(self._h, d_ranges, nq, int(sort), C.byref(job), C.byref(d_off),
                                            C.byref(d_val), C.byref(total), stream))
         return job, d_off.value, d_val.value, total.value
 
@@ -395,6 +447,27 @@ class LCPArray:
 
     def rmq(self, sp, ep):
         return tuple(int(x) for x in self.rmq_batch(np.array([[sp, ep]], dtype=np.uint64))[0])
+
+    def levels(self):
+        return int(self._L.gcsa2_lcp_levels(self._g.handle))
+
+    def branching(self):
+        return int(self._L.gcsa2_lcp_branching(self._g.handle))
+
+    def access_batch(self, positions):
+        positions = np.ascontiguousarray(positions, dtype=np.uint64)
+        out = np.zeros(positions.shape[0], dtype=np.uint64)
+        _check(self._L.gcsa2_lcp_access_batch(self._g.handle, _p64(positions), positions.shape[0], _p64(out)))
+        return out
+
+    def __getitem__(self, i):
+        return int(self.access_batch([i])[0])
+
+    def nodeFor(self, rng):
+        """LCPArray::nodeFor (lcp.h:163-175)."""
+        sp, ep = int(rng[0]), int(rng[1])
+        right = self[ep + 1] if ep + 1 < self._size else 0
+        return (sp, ep, self[sp], right, UNKNOWN)
 
 
 def open_index(index_arrays, device=0):

@@ -18,7 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -528,6 +530,40 @@ __global__ __launch_bounds__(TPB) void k_rmq(DevImage img, const u64* __restrict
   reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(pos, val);
 }
 
+// sampled / sampleRange / firstSample (gcsa.h:191-206): out[3q] = sampled(node),
+// out[3q+1] = sampleRange(node).first = firstSample(node), out[3q+2] = sampleRange(node).second
+__global__ __launch_bounds__(TPB) void k_sample_range(DevImage img, const u64* __restrict__ nodes, u64 nq,
+                                                      u64* __restrict__ out)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  u64 node = clampu(nodes[q], img.n), r;
+  bool s = (node < img.n ? bv_get_rank(img.sampled, node, r) : (r = bv_rank(img.sampled, node), false));
+  u64 first = (r > 0 ? bv_select(img.samples, r) + 1 : 0);
+  u64 second = (r + 1 <= img.samples.ones ? bv_select(img.samples, r + 1) : img.sample_count);
+  out[3 * q] = s ? 1 : 0; out[3 * q + 1] = first; out[3 * q + 2] = second;
+}
+
+// sample(i), lastSample(i) (gcsa.h:208-210)
+__global__ __launch_bounds__(TPB) void k_sample(DevImage img, const u64* __restrict__ idx, u64 nq,
+                                                u64* __restrict__ values, u8* __restrict__ last)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  u64 i = idx[q];
+  bool ok = (i < img.sample_count);
+  values[q] = ok ? packed_get(img.stored, img.sample_width, i) : 0;
+  last[q] = (ok && bv_get(img.samples, i)) ? 1 : 0;
+}
+
+// LCPArray::operator[] (lcp.h:129)
+__global__ __launch_bounds__(TPB) void k_lcp_access(DevImage img, const u64* __restrict__ pos, u64 nq, u64* __restrict__ out)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  out[q] = (pos[q] < img.lcp_values ? img.lcp[pos[q]] : 0);
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -843,7 +879,7 @@ void gcsa2_locate_discard(gcsa2_locate_job* job)
   delete job;
 }
 
-int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t nq, gcsa2_locate_job** job_out,
+int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t nq, int sort, gcsa2_locate_job** job_out,
                         const uint64_t** d_offsets, const uint64_t** d_values, uint64_t* total_values, void* stream_)
 {
   CHECK_INDEX(ix);
@@ -900,6 +936,18 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
   {
     HIP_TRY(hipMemsetAsync(job->d_offsets, 0, (nq + 1) * sizeof(u64), stream));
     HIP_TRY(hipStreamSynchronize(stream));
+  }
+  else if(!sort)
+  {
+    // sort == false (gcsa.cpp:827-842 without removeDuplicates): values in path order, the
+    // values of one path node in sample order, duplicates kept -- exactly the walk's output.
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_values), total_raw * sizeof(u64)));
+    hipLaunchKernelGGL(k_locate_walk, dim3(grid_for(total_nodes)), dim3(TPB), 0, stream,
+                       ix->img, d_ranges, nq, node_off.p, raw_off.p, total_nodes, job->d_values);
+    LAUNCH_CHECK("k_locate_walk");
+    HIP_TRY(hipMemcpyAsync(job->d_offsets, raw_off.p, (nq + 1) * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    job->total = total_raw;
   }
   else
   {
@@ -1039,7 +1087,7 @@ int gcsa2_count_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq
   return GCSA2_OK;
 }
 
-int gcsa2_locate_run(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, uint64_t* offsets, gcsa2_locate_job** job)
+int gcsa2_locate_run(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, int sort, uint64_t* offsets, gcsa2_locate_job** job)
 {
   CHECK_INDEX(ix);
   if(offsets == nullptr || job == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
@@ -1048,7 +1096,7 @@ int gcsa2_locate_run(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq,
   HIP_TRY(d_in.alloc(2 * nq));
   if(nq > 0) { HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice)); }
   const u64* d_off = nullptr;
-  int rc = gcsa2_locate_device(ix, d_in.p, nq, job, &d_off, nullptr, nullptr, nullptr);
+  int rc = gcsa2_locate_device(ix, d_in.p, nq, sort, job, &d_off, nullptr, nullptr, nullptr);
   if(rc != GCSA2_OK) { return rc; }
   HIP_TRY(hipMemcpy(offsets, d_off, (nq + 1) * sizeof(u64), hipMemcpyDeviceToHost));
   return GCSA2_OK;
@@ -1123,6 +1171,124 @@ int gcsa2_rmq_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, 
   hipLaunchKernelGGL(k_rmq, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
   LAUNCH_CHECK("k_rmq");
   HIP_TRY(hipMemcpy(results, d_out.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_sample_range_batch(const gcsa2_index* ix, const uint64_t* nodes, uint64_t nq, uint64_t* out)
+{
+  CHECK_INDEX(ix);
+  if(!ix->img.has_samples) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without samples"); }
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in, d_out;
+  HIP_TRY(d_in.alloc(nq)); HIP_TRY(d_out.alloc(3 * nq));
+  HIP_TRY(hipMemcpy(d_in.p, nodes, nq * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_sample_range, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
+  LAUNCH_CHECK("k_sample_range");
+  HIP_TRY(hipMemcpy(out, d_out.p, 3 * nq * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+int gcsa2_sample_batch(const gcsa2_index* ix, const uint64_t* idx, uint64_t nq, uint64_t* values, uint8_t* last)
+{
+  CHECK_INDEX(ix);
+  if(!ix->img.has_samples) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without samples"); }
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in, d_val; DBuf<u8> d_last;
+  HIP_TRY(d_in.alloc(nq)); HIP_TRY(d_val.alloc(nq)); HIP_TRY(d_last.alloc(nq));
+  HIP_TRY(hipMemcpy(d_in.p, idx, nq * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_sample, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_val.p, d_last.p);
+  LAUNCH_CHECK("k_sample");
+  HIP_TRY(hipMemcpy(values, d_val.p, nq * sizeof(u64), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(last, d_last.p, nq, hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+uint64_t gcsa2_sampled_positions(const gcsa2_index* ix) { return ix->img.has_samples ? ix->img.sampled.ones : 0; }
+uint64_t gcsa2_lcp_size(const gcsa2_index* ix) { return ix->img.lcp_size; }
+uint64_t gcsa2_lcp_values(const gcsa2_index* ix) { return ix->img.lcp_values; }
+uint64_t gcsa2_lcp_levels(const gcsa2_index* ix) { return ix->img.lcp_levels; }
+uint64_t gcsa2_lcp_branching(const gcsa2_index* ix) { return ix->img.lcp_branching; }
+uint64_t gcsa2_sigma(const gcsa2_index* ix) { return ix->img.sigma; }
+uint64_t gcsa2_fast_chars(const gcsa2_index* ix) { return ix->img.fast_chars; }
+void gcsa2_alphabet(const gcsa2_index* ix, uint8_t* char2comp, uint64_t* C)
+{
+  if(char2comp) { std::memcpy(char2comp, ix->img.char2comp, 256); }
+  if(C) { for(u64 c = 0; c <= ix->img.sigma; c++) { C[c] = ix->img.C[c]; } }
+}
+
+int gcsa2_lcp_access_batch(const gcsa2_index* ix, const uint64_t* positions, uint64_t nq, uint64_t* out)
+{
+  CHECK_INDEX(ix);
+  if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
+  if(nq == 0) { return GCSA2_OK; }
+  DeviceGuard guard(ix->device);
+  DBuf<u64> d_in, d_out;
+  HIP_TRY(d_in.alloc(nq)); HIP_TRY(d_out.alloc(nq));
+  HIP_TRY(hipMemcpy(d_in.p, positions, nq * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_lcp_access, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
+  LAUNCH_CHECK("k_lcp_access");
+  HIP_TRY(hipMemcpy(out, d_out.p, nq * sizeof(u64), hipMemcpyDeviceToHost));
+  return GCSA2_OK;
+}
+
+// GCSA::locate(range, max_positions, results) (src/gcsa.cpp:844-878): host control flow with the
+// reference's std::mt19937_64 draws; every locateInternal() runs on the device.  The reference's
+// unordered_set is replaced by a sorted unique vector: its iteration order never reaches the
+// output, because deterministicShuffle sorts first (utils.h:359-370) and the result is sorted last.
+int gcsa2_locate_max(const gcsa2_index* ix, uint64_t sp, uint64_t ep, uint64_t max_positions,
+                     uint64_t* values, uint64_t capacity, uint64_t* count_out)
+{
+  CHECK_INDEX(ix);
+  if(count_out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null count pointer"); }
+  *count_out = 0;
+  uint64_t range[2] = {sp, ep}, total = 0;
+  int rc = gcsa2_count_batch(ix, range, 1, &total);
+  if(rc != GCSA2_OK) { return rc; }
+  if(total == 0) { return GCSA2_OK; }
+  if(max_positions > total) { max_positions = total; }
+  std::mt19937_64 rng(sp ^ ep);
+  std::vector<u64> results;
+  auto locate_ranges = [&](const std::vector<u64>& rr, std::vector<u64>& dst) -> int
+  {
+    u64 nq = rr.size() / 2;
+    std::vector<u64> offs(nq + 1);
+    gcsa2_locate_job* job = nullptr;
+    int r = gcsa2_locate_run(ix, rr.data(), nq, 1, offs.data(), &job);
+    if(r != GCSA2_OK) { return r; }
+    dst.resize(offs[nq]);
+    return gcsa2_locate_fetch(job, dst.data(), dst.size());
+  };
+  if(max_positions >= total / 2)   // just locate everything (gcsa.cpp:855-858)
+  {
+    rc = locate_ranges({sp, ep}, results);
+    if(rc != GCSA2_OK) { return rc; }
+  }
+  else                             // random positions until enough distinct values (gcsa.cpp:859-871)
+  {
+    std::vector<u64> found, tmp;
+    while(found.size() < max_positions)
+    {
+      u64 pos = sp + rng() % (ep + 1 - sp);
+      rc = locate_ranges({pos, pos}, tmp);
+      if(rc != GCSA2_OK) { return rc; }
+      found.insert(found.end(), tmp.begin(), tmp.end());
+      std::sort(found.begin(), found.end());
+      found.erase(std::unique(found.begin(), found.end()), found.end());
+    }
+    results.swap(found);
+  }
+  if(results.size() > max_positions)   // deterministicShuffle + truncate (gcsa.cpp:873-877)
+  {
+    std::sort(results.begin(), results.end());
+    for(u64 i = results.size(); i > 0; i--) { std::swap(results[i - 1], results[rng() % i]); }
+    results.resize(max_positions);
+  }
+  std::sort(results.begin(), results.end());
+  if(results.size() > capacity) { *count_out = results.size(); return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small"); }
+  std::memcpy(values, results.data(), results.size() * sizeof(u64));
+  *count_out = results.size();
   return GCSA2_OK;
 }
 

@@ -165,20 +165,41 @@ int gcsa2_count_batch(const gcsa2_index* index, const uint64_t* ranges, uint64_t
 int gcsa2_count_device(const gcsa2_index* index, const uint64_t* d_ranges, uint64_t n_queries,
                        uint64_t* d_counts, void* stream);
 
-/* ---- locate: GCSA::locate(range, results, append=false, sort=true) (src/gcsa.cpp:827-842) --
- * Two calls, CSR output.  locate_sizes runs the whole query (walk, sort, unique) and keeps the
- * result on the device inside `*job`; offsets[q+1] - offsets[q] = number of distinct values of
- * query q.  locate_fetch copies the values (offsets[n_queries] of them) and frees the job. */
+/* ---- locate: GCSA::locate(range, results, append=false, sort) (src/gcsa.cpp:827-842) -------
+ * Two calls, CSR output.  locate_run runs the whole query and keeps the result on the device
+ * inside `*job`; locate_fetch copies the values (offsets[n_queries] of them) and frees the job.
+ * sort != 0: sorted distinct values per query (removeDuplicates, utils.h:350-357), so
+ *            offsets[q+1] - offsets[q] == count(range q).
+ * sort == 0: values in path order, duplicates kept, exactly as the reference pushes them. */
 typedef struct gcsa2_locate_job gcsa2_locate_job;
 int gcsa2_locate_run(const gcsa2_index* index, const uint64_t* ranges, uint64_t n_queries,
-                     uint64_t* offsets /* n_queries + 1 */, gcsa2_locate_job** job);
+                     int sort, uint64_t* offsets /* n_queries + 1 */, gcsa2_locate_job** job);
 int gcsa2_locate_fetch(gcsa2_locate_job* job, uint64_t* values, uint64_t capacity);
 void gcsa2_locate_discard(gcsa2_locate_job* job);
 /* Device-resident form for pipelines and the benchmark: d_ranges in HBM; on return
  * *d_offsets / *d_values point into memory owned by the job (valid until discard). */
 int gcsa2_locate_device(const gcsa2_index* index, const uint64_t* d_ranges, uint64_t n_queries,
-                        gcsa2_locate_job** job, const uint64_t** d_offsets,
+                        int sort, gcsa2_locate_job** job, const uint64_t** d_offsets,
                         const uint64_t** d_values, uint64_t* total_values, void* stream);
+
+/* GCSA::locate(range, max_positions, results) (src/gcsa.cpp:844-878): at most max_positions
+ * distinct values, chosen with the reference's std::mt19937_64(sp ^ ep) draws, sorted.
+ * *count = number of values written (or needed, with GCSA2_ERR_BUFFER_TOO_SMALL). */
+int gcsa2_locate_max(const gcsa2_index* index, uint64_t sp, uint64_t ep, uint64_t max_positions,
+                     uint64_t* values, uint64_t capacity, uint64_t* count);
+
+/* sampled / sampleRange / firstSample (gcsa.h:191-206): out[3q] = sampled(node),
+ * out[3q+1] = sampleRange(node).first (= firstSample(node)), out[3q+2] = sampleRange(node).second. */
+int gcsa2_sample_range_batch(const gcsa2_index* index, const uint64_t* nodes, uint64_t n_queries,
+                             uint64_t* out);
+/* sample(i) and lastSample(i) (gcsa.h:208-210). */
+int gcsa2_sample_batch(const gcsa2_index* index, const uint64_t* sample_indexes, uint64_t n_queries,
+                       uint64_t* values, uint8_t* last_flags);
+/* sampledPositions() (gcsa.h:143-148) and the Alphabet members callers read (support.h:150-151). */
+uint64_t gcsa2_sampled_positions(const gcsa2_index* index);
+uint64_t gcsa2_sigma(const gcsa2_index* index);
+uint64_t gcsa2_fast_chars(const gcsa2_index* index);
+void gcsa2_alphabet(const gcsa2_index* index, uint8_t* char2comp /* 256 */, uint64_t* C /* sigma + 1 */);
 
 /* ---- suffix-tree operations: LCPArray::parent / depth / psv / psev / nsv / nsev / rmq
  *      (include/gcsa/lcp.h:137-178, src/lcp.cpp:276-519) -------------------------------------- */
@@ -195,6 +216,14 @@ int gcsa2_sv_batch(const gcsa2_index* index, int op, const uint64_t* positions,
 /* rmq(sp, ep): leftmost minimum of LCP[sp..ep] as (position, value), or notFound(). */
 int gcsa2_rmq_batch(const gcsa2_index* index, const uint64_t* ranges, uint64_t n_queries,
                     uint64_t* results);
+
+/* LCPArray::size / values / levels / branching / operator[] (lcp.h:124-129). */
+uint64_t gcsa2_lcp_size(const gcsa2_index* index);
+uint64_t gcsa2_lcp_values(const gcsa2_index* index);
+uint64_t gcsa2_lcp_levels(const gcsa2_index* index);
+uint64_t gcsa2_lcp_branching(const gcsa2_index* index);
+int gcsa2_lcp_access_batch(const gcsa2_index* index, const uint64_t* positions, uint64_t n_queries,
+                           uint64_t* out);
 
 #ifdef __cplusplus
 }

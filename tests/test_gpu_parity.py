@@ -139,3 +139,28 @@ def test_errors(engine):
     assert e.value.code == -5
     with pytest.raises(engine.Gcsa2Error):
         engine.GCSA(ix, device=99)
+
+
+def test_locate_modes_and_samples(case):
+    name, g, K, ix, gpu, lcp, cpu = case
+    ranges = all_ranges(ix, 0x16, 60)
+    arr = np.array(ranges, dtype=np.uint64)
+    # sort == false: path order with duplicates (reference src/gcsa.cpp:827-842)
+    go, gv = gpu.locate_batch(arr, sort=False)
+    for i, r in enumerate(ranges):
+        assert gv[int(go[i]):int(go[i + 1])].tolist() == cpu.locate(r, sort=False).tolist(), (name, r)
+    # locate(range, max_positions): same mt19937_64 draws as the reference (src/gcsa.cpp:844-878)
+    for r in ranges[:: 7]:
+        for mx in (1, 2, 5, 1000):
+            assert gpu.locate(r, max_positions=mx).tolist() == cpu.locate(r, max_positions=mx).tolist(), (name, r, mx)
+    # sampled / firstSample / sampleRange / sample / lastSample (reference gcsa.h:191-210)
+    info = gpu.sample_range_batch(np.arange(ix.n, dtype=np.uint64))
+    for i in range(ix.n):
+        assert bool(info[i, 0]) == cpu.sampled(i)
+        assert int(info[i, 1]) == cpu.firstSample(i)
+    vals, last = gpu.sample_batch(np.arange(ix.sample_count, dtype=np.uint64))
+    assert vals.tolist() == [cpu.sample(j) for j in range(ix.sample_count)]
+    assert last.tolist() == [cpu.lastSample(j) for j in range(ix.sample_count)]
+    assert gpu.sampledPositions() == sum(cpu.sampled(i) for i in range(ix.n))
+    assert lcp.access_batch(np.arange(ix.n, dtype=np.uint64)).tolist() == ix.lcp_data[: ix.n].tolist()
+    assert lcp.levels() == ix.lcp_offsets.shape[0] - 1 and lcp.branching() == ix.lcp_branching
