@@ -35,29 +35,45 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2-bases", type=int, default=25, help="backbone length of the SNP graph")
+    ap.add_argument("--workload", choices=["snp", "linear"], default="snp",
+                    help="snp: chr22-like SNP-bubble graph (config 2, fits the Infinity Cache); "
+                         "linear: footprint-scale linear graph = FM-index built on the GPU (HBM-bound)")
+    ap.add_argument("--log2-bases", type=int, default=25, help="backbone length")
     ap.add_argument("--order", type=int, default=256)
     ap.add_argument("--queries", type=int, default=10_000_000, help="patterns per GPU per step")
     ap.add_argument("--pattern-len", type=int, default=32)
     ap.add_argument("--set", choices=["S", "U"], default="S")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--variant", type=int, default=2, help="find kernel generation (1 = k_find, 2 = k_find2)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
+
+
+LINEAR_SEED = 0x6C5A0040
 
 
 def get_index_and_graph(args, rank, barrier):
     """Rank 0 builds the index once per node and caches it; the others load it."""
     from workload import graphs, builder, cache
-    key = f"snp_{args.log2_bases}_{args.order}_v1"
+    key = f"{args.workload}_{args.log2_bases}_{args.order}_v2"
     path = os.path.join(args.cache_dir, key + ".npz")
     t = time.time()
-    graph = graphs.snp_graph(1 << args.log2_bases, 0x6C5A0010, 0x6C5A0011)
-    log(f"graph: {graph.size} positions ({time.time() - t:.1f} s)")
+    graph = None
+    if args.workload == "snp":
+        graph = graphs.snp_graph(1 << args.log2_bases, 0x6C5A0010, 0x6C5A0011)
+        log(f"graph: {graph.size} positions ({time.time() - t:.1f} s)")
     if rank == 0 and not os.path.exists(path):
         os.makedirs(args.cache_dir, exist_ok=True)
         t = time.time()
-        ix = builder.build(graph, args.order, keep_table=False)
+        if args.workload == "snp":
+            ix = builder.build(graph, args.order, keep_table=False)
+        else:
+            from workload import linear_torch
+            ix = linear_torch.build_linear(1 << args.log2_bases, LINEAR_SEED, order=args.order,
+                                           with_lcp=False, with_samples=False, verbose=log)
+            import torch
+            torch.cuda.empty_cache()
         log(f"index built: n={ix.n} e={ix.e} samples={ix.sample_count} ({time.time() - t:.1f} s)")
         cache.save(path + ".tmp.npz", ix)
         os.replace(path + ".tmp.npz", path)
@@ -95,13 +111,21 @@ def main():
 
     ix, graph = get_index_and_graph(args, rank, barrier)
     t = time.time()
-    gpu = GCSA(ix, device=local_rank)
+    full = args.workload == "snp"
+    gpu = GCSA(ix, device=local_rank, with_samples=full, with_counters=full, with_lcp=full)
     log(f"device image: {gpu.device_bytes() / 1e6:.1f} MB in HBM, block = {gpu.block_bits()} payload bits ({time.time() - t:.1f} s)")
 
     nq, m = args.queries, args.pattern_len
     t = time.time()
     seed = 0x6C5A0012 + 0x1000 * rank
-    pats = patterns.walk_patterns(graph, nq, m, seed) if args.set == "S" else patterns.uniform_patterns(nq, m, seed)
+    if args.set == "U":
+        pats = patterns.uniform_patterns(nq, m, seed)
+    elif args.workload == "snp":
+        pats = patterns.walk_patterns(graph, nq, m, seed)
+    else:
+        from workload import linear_torch
+        pats = linear_torch.substring_patterns_torch(1 << args.log2_bases, LINEAR_SEED, nq, m, seed, dev)
+        torch.cuda.empty_cache()
     flat, offsets = patterns.as_batch(pats)
     log(f"patterns: {nq} x {m} set {args.set} ({time.time() - t:.1f} s)")
     d_pat = torch.from_numpy(flat).to(dev)
@@ -113,7 +137,7 @@ def main():
     def step(record=None):
         if record is not None:
             record[0].record(stream)
-        gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), stream.cuda_stream)
+        gpu.find_device_variant(args.variant, d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), stream.cuda_stream)
         if record is not None:
             record[1].record(stream)
         if world > 1:   # the single gather of hit ranges over xGMI (16 B per query)
@@ -144,7 +168,7 @@ def main():
     torch.cuda.synchronize()
     assert torch.equal(d_out, d_out2), "instrumented and timed kernels disagree"
     blocks, lf_steps = (int(x) for x in d_stats.cpu())
-    algo_bytes = blocks * 64 + nq * (m + 16)
+    algo_bytes = blocks * gpu.find_block_bytes() + nq * (m + 16)
     found = int(((d_out[:, 0] <= d_out[:, 1])).sum().item())
 
     result = None
@@ -155,13 +179,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"chr22-like SNP graph 2^{args.log2_bases} bases, order-{args.order} GCSA, "
-                                   f"{nq} x {m}-mer find() per GPU, pattern set {args.set}",
+            "config": {"workload": (f"chr22-like SNP graph 2^{args.log2_bases} bases" if args.workload == "snp"
+                                    else f"linear graph 2^{args.log2_bases} bases (FM-index shaped GCSA)")
+                                   + f", order-{args.order} GCSA, {nq} x {m}-mer find() per GPU, pattern set {args.set}",
                        "path_nodes": int(ix.n), "edges": int(ix.e), "queries_per_gpu": nq,
                        "pattern_len": m, "pattern_set": args.set, "index_bytes_hbm": gpu.device_bytes(),
                        "found": found, "lf_steps_per_query": lf_steps / nq,
-                       "blocks_per_query": blocks / nq, "parallelism": f"replicated index, query shards x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_find", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "blocks_per_query": blocks / nq, "block_bytes": gpu.find_block_bytes(), "parallelism": f"replicated index, query shards x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_find2" if args.variant == 2 else "k_find", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms},
         }

@@ -23,7 +23,8 @@ EXPORTS = [
     "gcsa2_device_count", "gcsa2_index_create", "gcsa2_index_destroy", "gcsa2_last_error",
     "gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count", "gcsa2_sample_bits",
     "gcsa2_device", "gcsa2_device_bytes", "gcsa2_block_bits",
-    "gcsa2_find_batch", "gcsa2_find_device", "gcsa2_find_stats_device", "gcsa2_lf_batch", "gcsa2_lf_device",
+    "gcsa2_find_batch", "gcsa2_find_device", "gcsa2_find_stats_device", "gcsa2_find_device_variant",
+    "gcsa2_find_block_bytes", "gcsa2_lf_batch", "gcsa2_lf_device",
     "gcsa2_lf_node_batch", "gcsa2_char_range", "gcsa2_lf_all_batch",
     "gcsa2_count_batch", "gcsa2_count_device",
     "gcsa2_locate_run", "gcsa2_locate_fetch", "gcsa2_locate_discard", "gcsa2_locate_device",
@@ -63,7 +64,7 @@ def load_library():
     L.gcsa2_index_destroy.argtypes = [vp]
     L.gcsa2_index_destroy.restype = None
     for name in ("gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count",
-                 "gcsa2_sample_bits", "gcsa2_device_bytes", "gcsa2_block_bits",
+                 "gcsa2_sample_bits", "gcsa2_device_bytes", "gcsa2_block_bits", "gcsa2_find_block_bytes",
                  "gcsa2_sampled_positions", "gcsa2_sigma", "gcsa2_fast_chars", "gcsa2_lcp_size",
                  "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching"):
         getattr(L, name).restype = u64
@@ -72,6 +73,7 @@ def load_library():
     L.gcsa2_find_batch.argtypes = [vp, u8p, u64p, u64, u64p]
     L.gcsa2_find_device.argtypes = [vp, vp, vp, u64, vp, vp]
     L.gcsa2_find_stats_device.argtypes = [vp, vp, vp, u64, vp, vp, vp]
+    L.gcsa2_find_device_variant.argtypes = [vp, i32, vp, vp, u64, vp, vp]
     L.gcsa2_lf_batch.argtypes = [vp, u64p, u8p, u64, u64p]
     L.gcsa2_lf_device.argtypes = [vp, vp, vp, u64, vp, vp]
     L.gcsa2_lf_node_batch.argtypes = [vp, u64p, u64, u64p]
@@ -239,6 +241,12 @@ class GCSA:
 
     def find_device(self, d_patterns, d_offsets, nq, d_ranges, stream=0):
         _check(self._L.gcsa2_find_device(self._h, d_patterns, d_offsets, nq, d_ranges, stream))
+
+    def find_device_variant(self, variant, d_patterns, d_offsets, nq, d_ranges, stream=0):
+        _check(self._L.gcsa2_find_device_variant(self._h, variant, d_patterns, d_offsets, nq, d_ranges, stream))
+
+    def find_block_bytes(self):
+        return int(self._L.gcsa2_find_block_bytes(self._h))
 
     def find_stats_device(self, d_patterns, d_offsets, nq, d_ranges, d_stats, stream=0):
         _check(self._L.gcsa2_find_stats_device(self._h, d_patterns, d_offsets, nq, d_ranges, d_stats, stream))

@@ -114,6 +114,165 @@ __global__ __launch_bounds__(TPB) void k_find(DevImage img, const u8* __restrict
   }
 }
 
+// ---- find, version 2: fused 128-byte LF blocks, wave-cooperative fetch through LDS -----------
+//
+// One lane = one pattern, 64 patterns per wave walk their LF chains in lockstep.  Per step the
+// wave fetches the 64 fused blocks its lanes need with 8 line-coalesced instructions (8 adjacent
+// lanes x 16 bytes = one 128-byte block per request), stages them in LDS (XOR-swizzled so that the
+// ds_read_b128 read-back is conflict free) and every lane then evaluates its own
+// C[c] + rank(B_c, .) and rank(edges, .) from the staged block.  A second fetch round runs only
+// for lanes whose sp and ep + 1 fall into different blocks.
+constexpr int TPB2 = 128;          // 2 waves: 16 KB of staging + tables -> 9 workgroups / CU
+
+struct Tables2
+{
+  u64 crange[2 * MAX_SIGMA];
+  u8 c2c[256];
+};
+
+struct Endpoint { u64 edge; u64 node; u32 ones; };
+
+// lane-private evaluation of one LF endpoint from a staged fused block
+//   blk = 8 x ulonglong2 (w0..w15), r = bit offset inside the block
+//   edge = C[c] + rank(B_c, i);  node = rank(edges, edge - back) with back = 0 (sp) or 1 (ep)
+__device__ __forceinline__ void eval_endpoint(const ulonglong2 (&blk)[8], u32 r, u32 back, u64& edge, u64& node)
+{
+  const u64 w[16] = { blk[0].x, blk[0].y, blk[1].x, blk[1].y, blk[2].x, blk[2].y, blk[3].x, blk[3].y,
+                      blk[4].x, blk[4].y, blk[5].x, blk[5].y, blk[6].x, blk[6].y, blk[7].x, blk[7].y };
+  u32 wq = r >> 6;
+  u64 part = (u64(1) << (r & 63)) - 1;
+  u32 ones = 0;
+#pragma unroll
+  for(u32 j = 0; j < 7; j++)
+  {
+    u64 m = (j < wq ? ~u64(0) : (j == wq ? part : u64(0)));
+    ones += __popcll(w[2 + j] & m);
+  }
+  edge = w[0] + ones;
+  u64 ncnt = w[1] & ~PREV_BIT;
+  if(back > ones) { node = ncnt - (w[1] >> 63); return; }    // rank(edges, ecnt - 1)
+  u32 k = ones - back, kq = k >> 6;
+  u64 kpart = (u64(1) << (k & 63)) - 1;
+  u32 cnt = 0;
+#pragma unroll
+  for(u32 j = 0; j < 7; j++)
+  {
+    u64 m = (j < kq ? ~u64(0) : (j == kq ? kpart : u64(0)));
+    cnt += __popcll(w[9 + j] & m);
+  }
+  node = ncnt + cnt;
+}
+
+// wave-cooperative fetch: every lane with need != 0 gets flb block `idx` staged at its slot
+__device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane)
+{
+  u32 sub = lane & 7;
+#pragma unroll
+  for(u32 j = 0; j < 8; j++)
+  {
+    u32 owner = 8 * j + (lane >> 3);
+    u32 oidx = __shfl(idx, owner, 64);
+    bool oneed = __shfl(int(need), owner, 64) != 0;
+    if(oneed)
+    {
+      ulonglong2 a = reinterpret_cast<const ulonglong2*>(flb + u64(oidx) * FLB_WORDS)[sub];
+      wave_stage[owner * 8 + (sub ^ (owner & 7))] = a;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void read_block(const ulonglong2* wave_stage, u32 lane, ulonglong2 (&blk)[8])
+{
+#pragma unroll
+  for(u32 k = 0; k < 8; k++) { blk[k] = wave_stage[lane * 8 + (k ^ (lane & 7))]; }
+}
+
+template<bool STATS>
+__global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restrict__ patterns,
+                                               const u64* __restrict__ offsets, u64 nq,
+                                               u64* __restrict__ out, unsigned long long* __restrict__ stats)
+{
+  __shared__ ulonglong2 stage[TPB2 * 8];
+  __shared__ Tables2 t;
+  if(threadIdx.x < 2 * MAX_SIGMA) { t.crange[threadIdx.x] = img.crange[threadIdx.x]; }
+  t.c2c[threadIdx.x] = img.char2comp[threadIdx.x];
+  t.c2c[threadIdx.x + TPB2] = img.char2comp[threadIdx.x + TPB2];
+  __syncthreads();
+
+  const u32 lane = threadIdx.x & 63;
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  const u64 q = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  u64 blocks = 0, steps = 0;
+
+  u64 sp = 0, ep = img.n - 1, i = 0;
+  const u8* p = patterns;
+  bool done = true;
+  if(q < nq)
+  {
+    u64 begin = offsets[q], len = offsets[q + 1] - begin;
+    if(len > 0 && img.n > 0)                                   // gcsa.h:99
+    {
+      p = patterns + begin;
+      i = len - 1;
+      u32 comp = t.c2c[p[i]];
+      sp = t.crange[2 * comp]; ep = t.crange[2 * comp + 1];    // charRange, gcsa.h:101-102, 150-153
+      done = range_empty(sp, ep) || i == 0;                    // gcsa.h:103
+    }
+  }
+
+  // pattern bytes are consumed back to front from aligned 8-byte words
+  u64 word = 0; u64 word_addr = ~u64(0);
+  while(__any(!done))
+  {
+    u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
+    if(!done)
+    {
+      i--;
+      u64 addr = reinterpret_cast<u64>(p) + i, aligned = addr & ~u64(7);
+      if(aligned != word_addr) { word = *reinterpret_cast<const u64*>(aligned); word_addr = aligned; }
+      comp = t.c2c[(word >> ((addr & 7) * 8)) & 0xFF];
+      u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
+      r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
+      idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
+    }
+    ulonglong2 blk[8];
+    u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
+    fetch_blocks(img.flb, idx_sp, !done, wave_stage, lane);
+    if(!done)
+    {
+      read_block(wave_stage, lane, blk);
+      eval_endpoint(blk, r_sp, 0, e_sp, n_sp);                 // gcsa.h:271, then rank(edges, sp')
+      if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
+    }
+    bool need2 = !done && idx_ep != idx_sp;
+    if(STATS && !done) { steps++; blocks += 1 + (need2 ? 1 : 0); }
+    if(__any(need2))
+    {
+      __builtin_amdgcn_wave_barrier();
+      fetch_blocks(img.flb, idx_ep, need2, wave_stage, lane);
+      if(need2)
+      {
+        read_block(wave_stage, lane, blk);
+        eval_endpoint(blk, r_ep, 1, e_ep, n_ep);               // gcsa.h:272: LF(ep + 1) - 1
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if(!done)
+    {
+      u64 a = e_sp, b = e_ep - 1;                              // edge space
+      if(range_empty(a, b)) { sp = a; ep = b; done = true; }   // gcsa.h:160
+      else { sp = n_sp; ep = n_ep; done = (i == 0); }          // gcsa.h:161, 103
+    }
+  }
+  if(q < nq) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); }
+  if(STATS)
+  {
+    for(int o = 32; o > 0; o >>= 1) { blocks += __shfl_down(blocks, o, 64); steps += __shfl_down(steps, o, 64); }
+    if(lane == 0) { atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps); }
+  }
+}
+
 __global__ __launch_bounds__(TPB) void k_lf(DevImage img, const u64* __restrict__ in,
                                             const u8* __restrict__ comps, u64 nq, u64* __restrict__ out)
 {
@@ -603,9 +762,9 @@ inline unsigned grid_for(u64 n) { return unsigned((n + TPB - 1) / TPB); }
 struct Stager
 {
   std::vector<u64> words;      // image, in u64 units; every piece starts on a 64-byte boundary
-  u64 reserve(u64 nwords)
+  u64 reserve(u64 nwords, u64 align_words = 8)
   {
-    u64 off = (words.size() + 7) & ~u64(7);
+    u64 off = (words.size() + align_words - 1) / align_words * align_words;
     words.resize(off + nwords, 0);
     return off;
   }
@@ -649,6 +808,69 @@ BVPlan stage_bv(Stager& st, const u64* plain, u64 size, bool with_select)
     }
   }
   return p;
+}
+
+// Fused LF blocks (layout.hpp "FLB128") and the charRange table, built on the host from the plain
+// B_c and edges bits.
+u64 stage_flb(Stager& st, const gcsa2_host_view* v, DevImage& img)
+{
+  const u64 n = v->path_nodes, e = v->edges, sigma = v->sigma;
+  const u64 ewords = (e + 63) / 64;
+  std::vector<u64> ew(ewords + 9, 0), ecum(ewords + 10, 0);
+  for(u64 w = 0; w < ewords; w++)
+  {
+    u64 val = v->edge_bits[w];
+    if(w == (e >> 6) && (e & 63)) { val &= (u64(1) << (e & 63)) - 1; }
+    ew[w] = val;
+  }
+  for(u64 w = 0; w < ewords + 9; w++) { ecum[w + 1] = ecum[w] + u64(__builtin_popcountll(ew[w])); }
+  auto erank = [&](u64 x) -> u64   // ones in edges[0, x), x clamped to e
+  {
+    if(x > e) { x = e; }
+    u64 w = x >> 6, r = x & 63;
+    return ecum[w] + (r ? u64(__builtin_popcountll(ew[w] & ((u64(1) << r) - 1))) : 0);
+  };
+  auto ebits = [&](u64 pos) -> u64  // 64 edges bits starting at bit pos (zero past the end)
+  {
+    if(pos >= e) { return 0; }
+    u64 w = pos >> 6, r = pos & 63;
+    return r ? ((ew[w] >> r) | (ew[w + 1] << (64 - r))) : ew[w];
+  };
+
+  for(u64 c = 0; c < sigma; c++)   // charRange(c): pathNodeRange of (C[c], C[c+1] - 1), gcsa.h:150-153
+  {
+    img.crange[2 * c] = erank(v->C[c]);
+    img.crange[2 * c + 1] = erank(v->C[c + 1] - 1);
+  }
+
+  const u64 nblocks = n / BLOCK_BITS + 1, nwords = (n + 63) / 64;
+  img.flb_nblocks = nblocks;
+  u64 off = st.reserve(sigma * nblocks * FLB_WORDS, FLB_WORDS);
+  for(u64 c = 0; c < sigma; c++)
+  {
+    const u64* plain = v->bwt[c];
+    u64 cumul = 0;
+    for(u64 b = 0; b < nblocks; b++)
+    {
+      u64* dst = st.words.data() + off + (c * nblocks + b) * FLB_WORDS;
+      u64 ecnt = v->C[c] + cumul;
+      u64 prev = (ecnt > 0 && ecnt - 1 < e) ? ((ew[(ecnt - 1) >> 6] >> ((ecnt - 1) & 63)) & 1) : 0;
+      dst[0] = ecnt;
+      dst[1] = erank(ecnt) | (prev << 63);
+      for(u64 j = 0; j < PAYLOAD_WORDS; j++)
+      {
+        u64 w = b * PAYLOAD_WORDS + j, val = 0;
+        if(w < nwords)
+        {
+          val = plain[w];
+          if(w == (n >> 6) && (n & 63)) { val &= (u64(1) << (n & 63)) - 1; }
+        }
+        dst[2 + j] = val; cumul += u64(__builtin_popcountll(val));
+        dst[9 + j] = ebits(ecnt + 64 * j);
+      }
+    }
+  }
+  return off;
 }
 
 DevBV resolve(const BVPlan& p, const u64* d_base)
@@ -731,6 +953,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       }
     }
     BVPlan edges = stage_bv(st, v->edge_bits, img.e, false);
+    u64 flb_off = stage_flb(st, v, img);
     BVPlan sampled, samples, xfilter, xvalues, redundant;
     u64 stored_off = 0, lcp_off = 0;
     img.has_samples = (v->sampled_path_bits != nullptr);
@@ -771,6 +994,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     const u64* base = static_cast<const u64*>(ix->d_base);
     for(u64 c = 0; c < v->sigma; c++) { img.bwt[c] = resolve(bwt[c], base); }
     img.edges = resolve(edges, base);
+    img.flb = base + flb_off;
     if(img.has_samples)
     {
       img.sampled = resolve(sampled, base); img.samples = resolve(samples, base);
@@ -818,6 +1042,19 @@ int gcsa2_find_device(const gcsa2_index* ix, const uint8_t* d_patterns, const ui
 {
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_find2<false>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
+                     ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr);
+  LAUNCH_CHECK("k_find2");
+  return GCSA2_OK;
+}
+
+int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets,
+                              uint64_t nq, uint64_t* d_ranges, void* stream)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  if(variant == 2) { return gcsa2_find_device(ix, d_patterns, d_offsets, nq, d_ranges, stream); }
+  if(variant != 1) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown find variant"); }
   hipLaunchKernelGGL(k_find<false>, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
                      ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr);
   LAUNCH_CHECK("k_find");
@@ -831,11 +1068,13 @@ int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, co
   if(d_stats == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null stats buffer"); }
   if(nq == 0) { return GCSA2_OK; }
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64 atomics");
-  hipLaunchKernelGGL(k_find<true>, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(k_find2<true>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
                      ix->img, d_patterns, d_offsets, nq, d_ranges, reinterpret_cast<unsigned long long*>(d_stats));
-  LAUNCH_CHECK("k_find<stats>");
+  LAUNCH_CHECK("k_find2<stats>");
   return GCSA2_OK;
 }
+
+uint64_t gcsa2_find_block_bytes(const gcsa2_index*) { return FLB_BYTES; }
 
 int gcsa2_lf_device(const gcsa2_index* ix, const uint64_t* d_in, const uint8_t* d_comps, uint64_t nq,
                     uint64_t* d_out, void* stream)

@@ -15,6 +15,20 @@
 // rank / select / access are integer functions of the bit sequence, so results are identical
 // and the fast/sparse branch of gcsa.h:157-158 disappears.
 //
+// For find() / LF(range) every B_c is ALSO stored in a fused 128-byte form, "FLB128":
+//
+//   block b of comp c (16 x u64 = 128 bytes, 128-byte aligned)
+//     word 0       ecnt = C[c] + rank(B_c, 448 b)                  edge-space position of the block
+//     word 1       ncnt = rank(edges, ecnt), bit 63 = edges[ecnt - 1]
+//     words 2..8   B_c payload bits [448 b, 448 (b + 1))
+//     words 9..15  edges bits [ecnt, ecnt + 448)                   the slice those ones map into
+//
+// so one LF endpoint, C[c] + rank(B_c, i) followed by rank(edges, .) (gcsa.h:262-274, 253-258), is
+// ONE 128-byte fetch instead of two dependent 64-byte fetches: beyond L2 the memory system is
+// bound by requests per second, not bytes (profiles/r01_gather_bench.md), and a 128-byte request
+// costs the same as a 64-byte one.  Blocks are fetched cooperatively: 8 adjacent lanes load the
+// 8 x 16 bytes of one block in a single line-coalesced instruction and stage it in LDS.
+//
 // select_1 uses one u32 hint per 448 ones (block holding the (448 j + 1)-th one) followed by a
 // short binary search over block counters and an in-block scan.
 #pragma once
@@ -33,6 +47,9 @@ constexpr u64 PAYLOAD_WORDS = 7;
 constexpr u64 BLOCK_BITS    = 448;
 constexpr u64 BLOCK_BYTES   = 64;
 constexpr u64 SELECT_SAMPLE = 448;
+constexpr u64 FLB_WORDS     = 16;
+constexpr u64 FLB_BYTES     = 128;
+constexpr u64 PREV_BIT      = u64(1) << 63;
 constexpr int MAX_SIGMA     = 16;
 constexpr int MAX_LCP_LEVELS = 16;
 
@@ -50,6 +67,9 @@ struct DevImage
   u64 C[MAX_SIGMA + 1];
   DevBV bwt[MAX_SIGMA];
   DevBV edges;
+  const u64* flb;       // fused LF blocks: comp c, block b at flb + (c * flb_nblocks + b) * 16
+  u64 flb_nblocks;      // per comp = n / 448 + 1
+  u64 crange[2 * MAX_SIGMA];   // charRange(c) in node space, precomputed (gcsa.h:150-153)
   DevBV sampled;        // sampled_paths
   DevBV samples;        // + select
   const u64* stored;    // packed stored_samples

@@ -136,10 +136,17 @@ int gcsa2_find_device(const gcsa2_index* index, const uint8_t* d_patterns,
                       const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
                       void* stream);
 
+/* A/B access to older kernel generations (benchmarking only): variant 1 = one lane per query over
+ * 64-byte rank blocks (k_find), variant 2 = the current default (k_find2, fused 128-byte blocks). */
+int gcsa2_find_device_variant(const gcsa2_index* index, int variant, const uint8_t* d_patterns,
+                              const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
+                              void* stream);
+
 /* Instrumented find for the roofline model (not the timed path): same results in d_ranges, and
- * d_stats[0] += number of distinct 64-byte rank blocks fetched, d_stats[1] += LF steps executed
- * (a step whose two probes fall into one block counts once).  The caller zeroes
- * d_stats. */
+ * d_stats[0] += number of distinct fused LF blocks fetched (gcsa2_find_block_bytes() each),
+ * d_stats[1] += LF steps executed.  A step whose two endpoints fall into one block counts once
+ * (SURVEY.md 8(d)).  The caller zeroes d_stats. */
+uint64_t gcsa2_find_block_bytes(const gcsa2_index* index);
 int gcsa2_find_stats_device(const gcsa2_index* index, const uint8_t* d_patterns,
                             const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
                             uint64_t* d_stats, void* stream);

@@ -101,6 +101,18 @@ def test_config2_full_size_properties():
     seg = np.repeat(np.arange(sub.shape[0]), np.diff(loff).astype(np.int64))
     same = seg[1:] == seg[:-1]
     assert bool(np.all(lval[1:][same] > lval[:-1][same]))
+    # 4b. both kernel generations agree on the whole batch (device-resident entry points)
+    dev = torch.device("cuda", 0)
+    d_pat = torch.from_numpy(flat).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    outs = []
+    for variant in (1, 2):
+        d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+        gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(d_out.cpu().numpy().view(np.uint64))
+    assert np.array_equal(outs[0], ranges) and np.array_equal(outs[1], ranges)
     # 5. oracle on a sample + order-independent checksum of the whole batch vs the oracle's
     cpu = OracleIndex(ix, with_samples=False, with_counters=False, with_lcp=False)
     want = cpu.find_batch(flat, off, threads=64)

@@ -1,0 +1,49 @@
+"""Workload generators agree with each other: the scalable C++ builder with the definitional
+builder, and the torch (GPU-capable) linear-graph generator with the C++ builder."""
+import numpy as np
+import pytest
+
+from workload import graphs, builder, brute_builder
+from workload.rng import SplitMix64, splitmix64_array
+from test_oracle import CASES
+
+FIELDS = ("pred_mask", "outdeg", "lcp", "val_off", "vals", "redundant", "key_len")
+
+
+@pytest.mark.parametrize("case", range(len(CASES)), ids=[c[0] for c in CASES])
+def test_cpp_builder_matches_definition(case):
+    name, g, K = CASES[case]
+    a = brute_builder.node_table(g, K)
+    b = builder.node_table(g, K, threads=2)
+    for f in FIELDS:
+        assert np.array_equal(getattr(a, f).astype(np.uint64), getattr(b, f).astype(np.uint64)), (name, f)
+
+
+def test_rng_vectorised_matches_scalar():
+    r = SplitMix64(0x1234)
+    assert [r.next() for _ in range(50)] == [int(x) for x in splitmix64_array(0x1234, 50)]
+
+
+@pytest.mark.parametrize("n,seed", [(5000, 0x6C5A0040), (777, 3)])
+def test_linear_torch_matches_general_builder(n, seed):
+    import torch
+    from workload import linear_torch
+    assert np.array_equal(linear_torch.random_bases_torch(n, seed, torch.device("cpu")).numpy(),
+                          graphs.random_bases(n, seed))
+    a = builder.build(graphs.linear_graph(n, seed), 32)
+    b = linear_torch.build_linear(n, seed, order=32, device=torch.device("cpu"))
+    assert (a.n, a.e, a.sample_count, a.sample_width) == (b.n, b.e, b.sample_count, b.sample_width)
+    assert np.array_equal(a.C, b.C)
+    w = (a.n + 63) // 64
+    for c in range(a.sigma):
+        assert np.array_equal(a.bwt[c][:w], b.bwt[c][:w]), c
+    assert np.array_equal(a.edges[:w], b.edges[:w])
+    assert np.array_equal(a.sampled_paths[:w], b.sampled_paths[:w])
+    assert np.array_equal(a.stored_samples_plain, b.stored_samples_plain)
+    sw = (a.sample_count * a.sample_width + 63) // 64
+    assert np.array_equal(a.stored_samples[:sw], b.stored_samples[:sw])
+    assert np.array_equal(a.samples[: (a.sample_count + 63) // 64], b.samples[: (a.sample_count + 63) // 64])
+    assert np.array_equal(a.lcp_data, b.lcp_data) and np.array_equal(a.lcp_offsets, b.lcp_offsets)
+    assert a.extra_values_len == b.extra_values_len == 0 and a.redundant_len == b.redundant_len
+    assert np.array_equal(a.redundant[: (a.redundant_len + 63) // 64], b.redundant[: (a.redundant_len + 63) // 64])
+    assert not a.extra_filter[:w].any() and not b.extra_filter[:w].any()
