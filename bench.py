@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """Benchmark of the GCSA2 query hot path on MI355X: batched k-mer find().
 
-One step = one pass of the hot path (`gcsa2_find_device`, kernel k_find) over one batch of
+One step = one pass of the hot path (`gcsa2_find_device`, kernel k_find2) over one batch of
 synthetic patterns that already sit in HBM; with N > 1 every rank holds a replica of the index,
 searches its own shard (weak scaling) and the hit ranges are gathered on rank 0 with one RCCL
-gather per step.  Prints ONE JSON line on rank 0 (contract: see the task statement / DESIGN.md).
+gather per step.  Prints ONE JSON line on rank 0 (contract: task statement / DESIGN.md section 5).
 
-Workload (default): "chr22-like" = seeded SNP-bubble graph, 2^25 backbone bases, one SNP per 32 bp,
-order-256 maximally pruned de Bruijn graph, 10 M 32-mers per GPU drawn
-as random walks through the graph (set S: full-depth matches).
+Primary workload (BASELINE.json configs[1]): "chr22-like" seeded
+SNP-bubble graph, 2^25 backbone bases, one SNP per 32 bp, order-256 maximally pruned de Bruijn graph
+(51 M path nodes), 10 M 32-mers per GPU drawn as random walks through the graph (set S: full-depth
+matches).  Its fused blocks (102 MB) fit the 256 MiB Infinity Cache, so at N = 1 the run also
+measures an HBM-resident index (linear graph, 2^30 bases, 2.1 GB of fused blocks) and reports it
+under "hbm_resident" -- that is where the HBM roofline fraction is meaningful.
 """
 import argparse
-import hashlib
 import json
 import os
 import sys
@@ -23,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+LINEAR_SEED = 0x6C5A0040
 
 
 def log(msg):
@@ -36,102 +39,95 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["snp", "linear"], default="snp",
-                    help="snp: chr22-like SNP-bubble graph (config 2, fits the Infinity Cache); "
-                         "linear: footprint-scale linear graph = FM-index built on the GPU (HBM-bound)")
-    ap.add_argument("--log2-bases", type=int, default=25, help="backbone length")
+                    help="snp: chr22-like SNP-bubble graph (config 2, Infinity-Cache resident); "
+                         "linear: footprint-scale linear graph = FM-index built on the GPU (HBM resident)")
+    ap.add_argument("--log2-bases", type=int, default=0, help="backbone length (default 25 for snp, 30 for linear)")
     ap.add_argument("--order", type=int, default=256)
     ap.add_argument("--queries", type=int, default=10_000_000, help="patterns per GPU per step")
     ap.add_argument("--pattern-len", type=int, default=32)
     ap.add_argument("--set", choices=["S", "U"], default="S")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-hbm-resident", action="store_true", help="skip the secondary HBM-resident measurement")
     ap.add_argument("--variant", type=int, default=2, help="find kernel generation (1 = k_find, 2 = k_find2)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
 
 
-LINEAR_SEED = 0x6C5A0040
+class Dist:
+    """torch.distributed plumbing; a no-op when not launched by torch.distributed.run."""
+
+    def __init__(self, dev):
+        import torch.distributed as dist
+        self.dist = dist
+        self.active = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.active:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=dev)
+
+    def barrier(self):
+        if self.active:
+            self.dist.barrier()
+
+    def gather(self, tensor, parts):
+        if self.active:
+            self.dist.gather(tensor, parts if self.rank == 0 else None, dst=0)
+
+    def max(self, value, dev):
+        import torch
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        if self.active:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.active:
+            self.dist.destroy_process_group()
 
 
-def get_index_and_graph(args, rank, barrier):
+def build_snp_index(args, log2_bases, rank, barrier):
     """Rank 0 builds the index once per node and caches it; the others load it."""
     from workload import graphs, builder, cache
-    key = f"{args.workload}_{args.log2_bases}_{args.order}_v2"
-    path = os.path.join(args.cache_dir, key + ".npz")
+    path = os.path.join(args.cache_dir, f"snp_{log2_bases}_{args.order}_v2.npz")
     t = time.time()
-    graph = None
-    if args.workload == "snp":
-        graph = graphs.snp_graph(1 << args.log2_bases, 0x6C5A0010, 0x6C5A0011)
-        log(f"graph: {graph.size} positions ({time.time() - t:.1f} s)")
+    graph = graphs.snp_graph(1 << log2_bases, 0x6C5A0010, 0x6C5A0011)
+    log(f"graph: {graph.size} positions ({time.time() - t:.1f} s)")
+    ix = None
     if rank == 0 and not os.path.exists(path):
         os.makedirs(args.cache_dir, exist_ok=True)
         t = time.time()
-        if args.workload == "snp":
-            ix = builder.build(graph, args.order, keep_table=False)
-        else:
-            from workload import linear_torch
-            ix = linear_torch.build_linear(1 << args.log2_bases, LINEAR_SEED, order=args.order,
-                                           with_lcp=False, with_samples=False, verbose=log)
-            import torch
-            torch.cuda.empty_cache()
+        ix = builder.build(graph, args.order, keep_table=False)
         log(f"index built: n={ix.n} e={ix.e} samples={ix.sample_count} ({time.time() - t:.1f} s)")
         cache.save(path + ".tmp.npz", ix)
         os.replace(path + ".tmp.npz", path)
-    else:
-        ix = None
     barrier()
     if ix is None:
         ix = cache.load(path)
     return ix, graph
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
-
+def build_linear_index(args, log2_bases):
+    """Every rank builds its own replica on its own GPU (a few seconds, deterministic)."""
     import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    from workload import patterns
-    from gcsa2_amd.binding import GCSA
-
-    ix, graph = get_index_and_graph(args, rank, barrier)
+    from workload import linear_torch
     t = time.time()
-    full = args.workload == "snp"
-    gpu = GCSA(ix, device=local_rank, with_samples=full, with_counters=full, with_lcp=full)
-    log(f"device image: {gpu.device_bytes() / 1e6:.1f} MB in HBM, block = {gpu.block_bits()} payload bits ({time.time() - t:.1f} s)")
+    ix = linear_torch.build_linear(1 << log2_bases, LINEAR_SEED, order=args.order, with_lcp=False,
+                                   with_samples=False, verbose=log)
+    torch.cuda.empty_cache()
+    log(f"linear index built on the GPU: n={ix.n} ({time.time() - t:.1f} s)")
+    return ix
 
-    nq, m = args.queries, args.pattern_len
-    t = time.time()
-    seed = 0x6C5A0012 + 0x1000 * rank
-    if args.set == "U":
-        pats = patterns.uniform_patterns(nq, m, seed)
-    elif args.workload == "snp":
-        pats = patterns.walk_patterns(graph, nq, m, seed)
-    else:
-        from workload import linear_torch
-        pats = linear_torch.substring_patterns_torch(1 << args.log2_bases, LINEAR_SEED, nq, m, seed, dev)
-        torch.cuda.empty_cache()
-    flat, offsets = patterns.as_batch(pats)
-    log(f"patterns: {nq} x {m} set {args.set} ({time.time() - t:.1f} s)")
+
+def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup):
+    """Warm-up, then `steps` timed find() launches (+ gather when distributed).  Returns timings,
+    the device result tensor and the algorithmic traffic of one launch."""
+    import torch
     d_pat = torch.from_numpy(flat).to(dev)
     d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
     d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
-    gathered = [torch.zeros_like(d_out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    parts = [torch.zeros_like(d_out) for _ in range(D.world)] if (D.active and D.rank == 0) else None
     stream = torch.cuda.current_stream()
 
     def step(record=None):
@@ -140,62 +136,125 @@ def main():
         gpu.find_device_variant(args.variant, d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), stream.cuda_stream)
         if record is not None:
             record[1].record(stream)
-        if world > 1:   # the single gather of hit ranges over xGMI (16 B per query)
-            dist.gather(d_out, gathered, dst=0)
+        D.gather(d_out, parts)   # the single gather of hit ranges over xGMI (16 B per query)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         step(events[k])
     torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    D.barrier()
+    elapsed = D.max(time.perf_counter() - t0, dev)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-
     # algorithmic traffic of one launch (instrumented kernel, outside the timed region)
-    d_stats = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_stats = torch.zeros(3, dtype=torch.int64, device=dev)
     d_out2 = torch.zeros_like(d_out)
     gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out2.data_ptr(), d_stats.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(d_out, d_out2), "instrumented and timed kernels disagree"
-    blocks, lf_steps = (int(x) for x in d_stats.cpu())
-    algo_bytes = blocks * gpu.find_block_bytes() + nq * (m + 16)
-    found = int(((d_out[:, 0] <= d_out[:, 1])).sum().item())
+    blocks, lf_steps, lookups = (int(x) for x in d_stats.cpu())
+    algo_bytes = blocks * gpu.find_block_bytes() + lookups * 16 + nq * (m + 16)
+    found = int((d_out[:, 0] <= d_out[:, 1]).sum().item())
+    return dict(elapsed=elapsed, kernel_ms=kernel_ms, blocks=blocks, lf_steps=lf_steps, algo_bytes=algo_bytes,
+                found=found, d_out=d_out)
+
+
+def roofline(args, r):
+    achieved = r["algo_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_find2" if args.variant == 2 else "k_find", "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"]}
+
+
+def main():
+    args = parse()
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D = Dist(dev)
+    rank, world = D.rank, D.world
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
+
+    from workload import patterns, linear_torch
+    from gcsa2_amd.binding import GCSA
+
+    nq, m = args.queries, args.pattern_len
+    seed = 0x6C5A0012 + 0x1000 * rank
+    log2_bases = args.log2_bases or (25 if args.workload == "snp" else 30)
+    if args.workload == "snp":
+        ix, graph = build_snp_index(args, log2_bases, rank, D.barrier)
+        label = f"chr22-like SNP graph 2^{log2_bases} bases"
+    else:
+        ix, graph = build_linear_index(args, log2_bases), None
+        label = f"linear graph 2^{log2_bases} bases (FM-index shaped GCSA)"
+    t = time.time()
+    full = args.workload == "snp"
+    gpu = GCSA(ix, device=local_rank, with_samples=full, with_counters=full, with_lcp=full)
+    log(f"device image: {gpu.device_bytes() / 1e6:.1f} MB in HBM ({time.time() - t:.1f} s)")
+    t = time.time()
+    if args.set == "U":
+        pats = patterns.uniform_patterns(nq, m, seed)
+    elif args.workload == "snp":
+        pats = patterns.walk_patterns(graph, nq, m, seed)
+    else:
+        pats = linear_torch.substring_patterns_torch(1 << log2_bases, LINEAR_SEED, nq, m, seed, dev)
+    flat, offsets = patterns.as_batch(pats)
+    log(f"patterns: {nq} x {m} set {args.set} ({time.time() - t:.1f} s)")
+
+    r = measure(args, D, dev, gpu, flat, offsets, nq, m, args.steps, args.warmup)
 
     result = None
     if rank == 0:
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         result = {
-            "metric": "kmer_find_queries_per_sec", "value": world * nq * args.steps / elapsed, "unit": "queries/s",
+            "metric": "kmer_find_queries_per_sec", "value": world * nq * args.steps / r["elapsed"], "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": r["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": (f"chr22-like SNP graph 2^{args.log2_bases} bases" if args.workload == "snp"
-                                    else f"linear graph 2^{args.log2_bases} bases (FM-index shaped GCSA)")
-                                   + f", order-{args.order} GCSA, {nq} x {m}-mer find() per GPU, pattern set {args.set}",
-                       "path_nodes": int(ix.n), "edges": int(ix.e), "queries_per_gpu": nq,
-                       "pattern_len": m, "pattern_set": args.set, "index_bytes_hbm": gpu.device_bytes(),
-                       "found": found, "lf_steps_per_query": lf_steps / nq,
-                       "blocks_per_query": blocks / nq, "block_bytes": gpu.find_block_bytes(), "parallelism": f"replicated index, query shards x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_find2" if args.variant == 2 else "k_find", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms},
+            "config": {"workload": f"{label}, order-{args.order} GCSA, {nq} x {m}-mer find() per GPU, pattern set {args.set}",
+                       "path_nodes": int(ix.n), "edges": int(ix.e), "queries_per_gpu": nq, "pattern_len": m,
+                       "pattern_set": args.set, "index_bytes_hbm": gpu.device_bytes(),
+                       "find_bytes_hbm": int(ix.sigma) * (int(ix.n) // 448 + 1) * 128,
+                       "found": r["found"], "lf_steps_per_query": r["lf_steps"] / nq,
+                       "blocks_per_query": r["blocks"] / nq, "block_bytes": gpu.find_block_bytes(),
+                       "kmer_table_k": gpu.kmer_table_k(),
+                       "parallelism": f"replicated index, query shards x{world}, one RCCL gather of ranges per step"},
+            "roofline": roofline(args, r),
         }
+        if args.workload == "snp":
+            result["roofline"]["note"] = ("fused blocks of this index fit the 256 MiB Infinity Cache: achieved = algorithmic bytes / "
+                                          "kernel time, served mostly on-die; see hbm_resident for the HBM-bound figure")
         if not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(args, ix, flat, offsets, d_out, m)
+            result["cpu_baseline"] = cpu_baseline(args, ix, flat, offsets, r["d_out"], m)
+    del r
+
+    # secondary measurement: the same kernel on an index far larger than the Infinity Cache
+    if args.workload == "snp" and world == 1 and not args.no_hbm_resident:
+        del gpu, ix, graph
+        torch.cuda.empty_cache()
+        lb = 30
+        ix2 = build_linear_index(args, lb)
+        gpu2 = GCSA(ix2, device=local_rank, with_samples=False, with_counters=False, with_lcp=False)
+        pats2 = linear_torch.substring_patterns_torch(1 << lb, LINEAR_SEED, nq, m, seed, dev)
+        flat2, off2 = patterns.as_batch(pats2)
+        r2 = measure(args, D, dev, gpu2, flat2, off2, nq, m, max(5, args.steps // 2), 2)
+        result["hbm_resident"] = {
+            "workload": f"linear graph 2^{lb} bases (FM-index shaped GCSA, built on the GPU), {nq} x {m}-mer find(), substrings of the text",
+            "path_nodes": int(ix2.n), "find_bytes_hbm": int(ix2.sigma) * (int(ix2.n) // 448 + 1) * 128,
+            "value": nq / (r2["kernel_ms"] * 1e-3), "unit": "queries/s", "blocks_per_query": r2["blocks"] / nq,
+            "roofline": roofline(args, r2)}
+    if rank == 0:
         print(json.dumps(result), flush=True)
-    barrier()
-    if world > 1:
-        dist.destroy_process_group()
+    D.barrier()
+    D.close()
 
 
 def cpu_baseline(args, ix, flat, offsets, d_out, m):

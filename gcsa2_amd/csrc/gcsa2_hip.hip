@@ -114,6 +114,30 @@ __global__ __launch_bounds__(TPB) void k_find(DevImage img, const u8* __restrict
   }
 }
 
+// ---- k-mer seed table ----------------------------------------------------------------------
+// table[t] = find() of the k-mer whose j-th character FROM THE END has comp 1 + ((t >> 2j) & 3):
+// the exact (sp, ep) the backward search returns, including edge-space empty ranges, so that
+// k_find2 can start a pattern whose last k characters are all fast characters at step k.
+// Pure memoisation of gcsa.h:96-110; results are unchanged.
+__global__ __launch_bounds__(TPB) void k_build_kmer_table(DevImage img, u32 k, u64 entries, u64* __restrict__ table)
+{
+  u64 tix = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(tix >= entries) { return; }
+  u32 comp = 1 + u32(tix & 3);                               // last character
+  u64 sp = img.crange[2 * comp], ep = img.crange[2 * comp + 1];
+  for(u32 j = 1; j < k && !range_empty(sp, ep); j++)
+  {
+    comp = 1 + u32((tix >> (2 * j)) & 3);
+    DevBV bv = bwt_of(img, comp);
+    u64 ra, rb;
+    bv_rank2(bv, sp, ep + 1, ra, rb);
+    sp = img.C[comp] + ra; ep = img.C[comp] + rb - 1;
+    if(range_empty(sp, ep)) { break; }
+    path_node_range(img, sp, ep);
+  }
+  reinterpret_cast<ulonglong2*>(table)[tix] = make_ulonglong2(sp, ep);
+}
+
 // ---- find, version 2: fused 128-byte LF blocks, wave-cooperative fetch through LDS -----------
 //
 // One lane = one pattern, 64 patterns per wave walk their LF chains in lockstep.  Per step the
@@ -203,35 +227,60 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
   const u64 q = u64(blockIdx.x) * TPB2 + threadIdx.x;
-  u64 blocks = 0, steps = 0;
+  u64 blocks = 0, steps = 0, lookups = 0;
 
   u64 sp = 0, ep = img.n - 1, i = 0;
   const u8* p = patterns;
   bool done = true;
+  u64 word = 0, word_addr = ~u64(0);        // pattern bytes are consumed back to front from aligned 8-byte words
+  auto byte_at = [&](u64 pos) -> u32
+  {
+    u64 addr = reinterpret_cast<u64>(p) + pos, aligned = addr & ~u64(7);
+    if(aligned != word_addr) { word = *reinterpret_cast<const u64*>(aligned); word_addr = aligned; }
+    return u32(word >> ((addr & 7) * 8)) & 0xFF;
+  };
   if(q < nq)
   {
     u64 begin = offsets[q], len = offsets[q + 1] - begin;
     if(len > 0 && img.n > 0)                                   // gcsa.h:99
     {
       p = patterns + begin;
-      i = len - 1;
-      u32 comp = t.c2c[p[i]];
-      sp = t.crange[2 * comp]; ep = t.crange[2 * comp + 1];    // charRange, gcsa.h:101-102, 150-153
+      const u32 k = img.kmer_k;
+      bool seeded = false;
+      if(k > 0 && len >= k)
+      {
+        u64 tix = 0;
+        bool fast = true;
+        for(u32 j = 0; j < k; j++)                             // j-th character from the end
+        {
+          u32 comp = t.c2c[byte_at(len - 1 - j)];
+          fast = fast && (comp - 1 < 4);
+          tix |= u64((comp - 1) & 3) << (2 * j);
+        }
+        if(fast)
+        {
+          ulonglong2 r = reinterpret_cast<const ulonglong2*>(img.kmer_table)[tix];
+          sp = r.x; ep = r.y; i = len - k; seeded = true;
+          if(STATS) { lookups++; }
+        }
+      }
+      if(!seeded)
+      {
+        i = len - 1;
+        u32 comp = t.c2c[byte_at(i)];
+        sp = t.crange[2 * comp]; ep = t.crange[2 * comp + 1];  // charRange, gcsa.h:101-102, 150-153
+      }
       done = range_empty(sp, ep) || i == 0;                    // gcsa.h:103
     }
   }
 
-  // pattern bytes are consumed back to front from aligned 8-byte words
-  u64 word = 0; u64 word_addr = ~u64(0);
   while(__any(!done))
   {
     u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
     if(!done)
     {
       i--;
-      u64 addr = reinterpret_cast<u64>(p) + i, aligned = addr & ~u64(7);
-      if(aligned != word_addr) { word = *reinterpret_cast<const u64*>(aligned); word_addr = aligned; }
-      comp = t.c2c[(word >> ((addr & 7) * 8)) & 0xFF];
+      comp = t.c2c[byte_at(i)];
       u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
       r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
       idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
@@ -268,8 +317,15 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
   if(q < nq) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); }
   if(STATS)
   {
-    for(int o = 32; o > 0; o >>= 1) { blocks += __shfl_down(blocks, o, 64); steps += __shfl_down(steps, o, 64); }
-    if(lane == 0) { atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps); }
+    for(int o = 32; o > 0; o >>= 1)
+    {
+      blocks += __shfl_down(blocks, o, 64); steps += __shfl_down(steps, o, 64); lookups += __shfl_down(lookups, o, 64);
+    }
+    if(lane == 0)
+    {
+      atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps);
+      atomicAdd(stats + 2, (unsigned long long)lookups);
+    }
   }
 }
 
@@ -733,6 +789,7 @@ struct gcsa2_index
   int device = 0;
   DevImage img;
   void* d_base = nullptr;
+  void* d_kmer = nullptr;
   u64 bytes = 0;
   u64 order = 0;
 };
@@ -1005,6 +1062,33 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       img.xfilter = resolve(xfilter, base); img.xvalues = resolve(xvalues, base); img.redundant = resolve(redundant, base);
     }
     if(img.has_lcp) { img.lcp = reinterpret_cast<const u8*>(base + lcp_off); }
+
+    // k-mer seed table: largest k <= 12 with 4^k <= n / 4, and only if comps 1..4 exist
+    u32 k = 0;
+    const char* env = std::getenv("GCSA2_KMER_TABLE");
+    u32 kmax = (env != nullptr ? u32(std::atoi(env)) : 12);
+    if(kmax > 12) { kmax = 12; }
+    while(k < kmax && (u64(1) << (2 * (k + 1))) <= img.n / 4) { k++; }
+    if(img.sigma < 5) { k = 0; }
+    img.kmer_k = 0; img.kmer_table = nullptr;
+    if(k > 0)
+    {
+      u64 entries = u64(1) << (2 * k);
+      e = hipMalloc(&ix->d_kmer, entries * 2 * sizeof(u64));
+      if(e == hipSuccess)
+      {
+        hipLaunchKernelGGL(k_build_kmer_table, dim3(grid_for(entries)), dim3(TPB), 0, nullptr, img, k, entries, static_cast<u64*>(ix->d_kmer));
+        e = hipDeviceSynchronize();
+      }
+      if(e != hipSuccess)
+      {
+        if(ix->d_kmer) { (void)hipFree(ix->d_kmer); }
+        (void)hipFree(ix->d_base); delete ix;
+        return fail(GCSA2_ERR_HIP, std::string("k-mer table: ") + hipGetErrorString(e));
+      }
+      img.kmer_table = static_cast<const u64*>(ix->d_kmer); img.kmer_k = k;
+      ix->bytes += entries * 2 * sizeof(u64);
+    }
   }
   catch(const std::bad_alloc&)
   {
@@ -1019,6 +1103,7 @@ void gcsa2_index_destroy(gcsa2_index* ix)
   if(ix == nullptr) { return; }
   DeviceGuard guard(ix->device);
   if(ix->d_base) { (void)hipFree(ix->d_base); }
+  if(ix->d_kmer) { (void)hipFree(ix->d_kmer); }
   delete ix;
 }
 
@@ -1075,6 +1160,7 @@ int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, co
 }
 
 uint64_t gcsa2_find_block_bytes(const gcsa2_index*) { return FLB_BYTES; }
+uint64_t gcsa2_kmer_table_k(const gcsa2_index* ix) { return ix->img.kmer_k; }
 
 int gcsa2_lf_device(const gcsa2_index* ix, const uint64_t* d_in, const uint8_t* d_comps, uint64_t nq,
                     uint64_t* d_out, void* stream)

@@ -144,9 +144,14 @@ int gcsa2_find_device_variant(const gcsa2_index* index, int variant, const uint8
 
 /* Instrumented find for the roofline model (not the timed path): same results in d_ranges, and
  * d_stats[0] += number of distinct fused LF blocks fetched (gcsa2_find_block_bytes() each),
- * d_stats[1] += LF steps executed.  A step whose two endpoints fall into one block counts once
- * (SURVEY.md 8(d)).  The caller zeroes d_stats. */
+ * d_stats[1] += LF steps executed, d_stats[2] += seed-table lookups (16 bytes each).  A step whose
+ * two endpoints fall into one block counts once.  The caller zeroes the three
+ * counters of d_stats. */
 uint64_t gcsa2_find_block_bytes(const gcsa2_index* index);
+/* Length k of the k-mer seed table built at create time (find() of every k-mer over comps 1..4,
+ * memoised: a pattern whose last k characters are fast characters starts at step k).  0 = none.
+ * Environment variable GCSA2_KMER_TABLE caps k (0 disables). */
+uint64_t gcsa2_kmer_table_k(const gcsa2_index* index);
 int gcsa2_find_stats_device(const gcsa2_index* index, const uint8_t* d_patterns,
                             const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
                             uint64_t* d_stats, void* stream);
