@@ -72,8 +72,10 @@ class Dist:
             self.dist.barrier()
 
     def gather(self, tensor, parts):
+        """Asynchronous gather on rank 0; returns the work handle (None when not distributed)."""
         if self.active:
-            self.dist.gather(tensor, parts if self.rank == 0 else None, dst=0)
+            return self.dist.gather(tensor, parts if self.rank == 0 else None, dst=0, async_op=True)
+        return None
 
     def max(self, value, dev):
         import torch
@@ -126,28 +128,44 @@ def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup):
     import torch
     d_pat = torch.from_numpy(flat).to(dev)
     d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
-    d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
-    parts = [torch.zeros_like(d_out) for _ in range(D.world)] if (D.active and D.rank == 0) else None
+    # two result buffers: the RCCL gather of step k (async, on RCCL's own stream) overlaps the
+    # find() launch of step k + 1; a buffer is reused only after its gather has completed.
+    outs = [torch.zeros((nq, 2), dtype=torch.int64, device=dev) for _ in range(2 if D.active else 1)]
+    parts = [[torch.zeros_like(outs[0]) for _ in range(D.world)] for _ in outs] if (D.active and D.rank == 0) else [None, None]
+    pending = [None, None]
     stream = torch.cuda.current_stream()
 
-    def step(record=None):
+    def step(k, record=None):
+        b = k % len(outs)
+        if pending[b] is not None:
+            pending[b].wait()          # stream-level wait, no host sync
+            pending[b] = None
         if record is not None:
             record[0].record(stream)
-        gpu.find_device_variant(args.variant, d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), stream.cuda_stream)
+        gpu.find_device_variant(args.variant, d_pat.data_ptr(), d_off.data_ptr(), nq, outs[b].data_ptr(), stream.cuda_stream)
         if record is not None:
             record[1].record(stream)
-        D.gather(d_out, parts)   # the single gather of hit ranges over xGMI (16 B per query)
+        pending[b] = D.gather(outs[b], parts[b])   # the single gather of hit ranges over xGMI (16 B per query)
 
-    for _ in range(warmup):
-        step()
+    def drain():
+        for b in range(len(pending)):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    for k in range(warmup):
+        step(k)
+    drain()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
-        step(events[k])
+        step(k, events[k])
+    drain()
     torch.cuda.synchronize()
     D.barrier()
+    d_out = outs[(steps - 1) % len(outs)] if steps > 0 else outs[0]
     elapsed = D.max(time.perf_counter() - t0, dev)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
