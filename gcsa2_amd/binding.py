@@ -33,6 +33,8 @@ EXPORTS = [
     "gcsa2_sampled_positions", "gcsa2_sigma", "gcsa2_fast_chars", "gcsa2_alphabet",
     "gcsa2_lcp_size", "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching",
     "gcsa2_lcp_access_batch",
+    "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
+    "gcsa2_group_find_batch",
 ]
 
 
@@ -98,6 +100,13 @@ def load_library():
     L.gcsa2_alphabet.argtypes = [vp, u8p, u64p]
     L.gcsa2_alphabet.restype = None
     L.gcsa2_lcp_access_batch.argtypes = [vp, u64p, u64, u64p]
+    L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
+    L.gcsa2_group_destroy.argtypes = [vp]
+    L.gcsa2_group_destroy.restype = None
+    L.gcsa2_group_size.argtypes = [vp]
+    L.gcsa2_group_index.argtypes = [vp, i32]
+    L.gcsa2_group_index.restype = vp
+    L.gcsa2_group_find_batch.argtypes = [vp, u8p, u64p, u64, u64p]
     _lib = L
     return L
 
@@ -479,6 +488,41 @@ class LCPArray:
         sp, ep = int(rng[0]), int(rng[1])
         right = self[ep + 1] if ep + 1 < self._size else 0
         return (sp, ep, self[sp], right, UNKNOWN)
+
+
+class GCSAGroup:
+    """One replica per device; `find_batch` shards the batch contiguously over the replicas
+    (single-process multi-GPU, `gcsa2_group_*`)."""
+
+    def __init__(self, index_arrays, devices):
+        L = load_library()
+        holder = make_host_view(index_arrays)
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(L.gcsa2_group_create(holder.ref(), devs, len(devices), C.byref(h)))
+        self._h, self._L = h, L
+
+    def size(self):
+        return int(self._L.gcsa2_group_size(self._h))
+
+    def find_batch(self, patterns, offsets):
+        patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nq = offsets.shape[0] - 1
+        out = np.zeros((nq, 2), dtype=np.uint64)
+        _check(self._L.gcsa2_group_find_batch(self._h, _p8(patterns), _p64(offsets), nq, _p64(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gcsa2_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def open_index(index_arrays, device=0):

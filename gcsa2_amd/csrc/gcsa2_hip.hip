@@ -22,6 +22,7 @@
 #include <new>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace g2;
@@ -445,6 +446,123 @@ __global__ __launch_bounds__(TPB) void k_count(DevImage img, const u64* __restri
   out[q] = count_range(img, r.x, r.y);
 }
 
+// ---- pred4: first-predecessor code + sampled flag, 4 bits per path node ------------------------
+// One thread per 64 nodes: reads the payload word of every B_c and of sampled_paths and writes
+// four u64 (16 nibbles each).  Derived data: LF(path_node) probes comps 1..sigma-1 in order and
+// falls back to comp 0 (gcsa.h:165-183); the nibble records which probe hits first.
+__global__ __launch_bounds__(TPB) void k_build_pred4(DevImage img, u64 nwords, u64* __restrict__ out)
+{
+  u64 w = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(w >= nwords) { return; }
+  u64 blk = w / PAYLOAD_WORDS, j = w - blk * PAYLOAD_WORDS;
+  u64 remaining = ~u64(0), p0 = 0, p1 = 0, p2 = 0;
+  for(u32 c = 1; c < u32(img.sigma); c++)
+  {
+    u64 bits = bwt_of(img, c).blocks[blk * BLOCK_WORDS + 1 + j] & remaining;
+    if(c & 1) { p0 |= bits; }
+    if(c & 2) { p1 |= bits; }
+    if(c & 4) { p2 |= bits; }
+    remaining &= ~bits;
+  }
+  u64 smp = (img.has_samples ? img.sampled.blocks[blk * BLOCK_WORDS + 1 + j] : 0);
+  for(u32 part = 0; part < 4; part++)
+  {
+    u64 v = 0;
+    for(u32 k = 0; k < 16; k++)
+    {
+      u32 bit = part * 16 + k;
+      u64 nib = ((p0 >> bit) & 1) | (((p1 >> bit) & 1) << 1) | (((p2 >> bit) & 1) << 2) | (((smp >> bit) & 1) << 3);
+      v |= nib << (4 * k);
+    }
+    out[w * 4 + part] = v;
+  }
+}
+
+__device__ __forceinline__ u32 pred4_get(const u64* pred4, u64 node)
+{
+  return u32(pred4[node >> 4] >> ((node & 15) * 4)) & 15;
+}
+
+// one lane per (query, path node): locateInternal (gcsa.cpp:880-896), wave-cooperative.
+// The LF(path_node) walk uses the pred4 nibble (which comp, already sampled?) and then ONE fused
+// block per step for C[c] + rank(B_c, node) and rank(edges, .), fetched like in k_find2.
+__global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                                      const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
+                                                      u64 total_nodes, u64* __restrict__ values)
+{
+  __shared__ ulonglong2 stage[TPB2 * 8];
+  const u32 lane = threadIdx.x & 63;
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  u64 g = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  bool live = g < total_nodes;
+  u64 node = 0, dest = 0, steps = 0;
+  if(live)
+  {
+    u64 lo = 0, hi = nq - 1;            // query owning flattened node g: last q with node_off[q] <= g
+    while(lo < hi)
+    {
+      u64 mid = (lo + hi + 1) >> 1;
+      if(node_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
+    }
+    u64 sp = ranges[2 * lo];
+    node = sp + (g - node_off[lo]);
+    dest = raw_off[lo] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0);
+  }
+  bool walking = live;
+  while(__any(walking))
+  {
+    u32 idx = 0, r = 0;
+    if(walking)
+    {
+      u32 nib = pred4_get(img.pred4, node);
+      if(nib & 8) { walking = false; }                       // sampled(node), gcsa.cpp:883
+      else
+      {
+        u64 b = node / BLOCK_BITS;
+        r = u32(node - b * BLOCK_BITS);
+        idx = u32(u64(nib & 7) * img.flb_nblocks + b);
+      }
+    }
+    if(!__any(walking)) { break; }
+    fetch_blocks(img.flb, idx, walking, wave_stage, lane);
+    if(walking)
+    {
+      ulonglong2 blk[8];
+      read_block(wave_stage, lane, blk);
+      u64 edge, next;
+      eval_endpoint(blk, r, 0, edge, next);                  // LF(path_node), gcsa.h:165-183
+      node = next; steps++;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if(live)
+  {
+    u64 srank = bv_rank(img.sampled, node);
+    u64 s = (srank > 0 ? bv_select(img.samples, srank) + 1 : 0);   // firstSample, gcsa.h:202-206
+    do
+    {
+      values[dest++] = packed_get(img.stored, img.sample_width, s) + steps;   // gcsa.cpp:893
+      s++;
+    }
+    while(!bv_get(img.samples, s - 1));                      // lastSample, gcsa.h:208
+  }
+}
+
+// segments with more than one raw value (the only ones removeDuplicates has to sort)
+__global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ raw_off, u64 nq,
+                                                       unsigned long long* __restrict__ counter,
+                                                       u64* __restrict__ seg_begin, u64* __restrict__ seg_end)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  u64 b = raw_off[q], e = raw_off[q + 1];
+  if(e - b >= 2)
+  {
+    unsigned long long slot = atomicAdd(counter, 1ull);
+    seg_begin[slot] = b; seg_end[slot] = e;
+  }
+}
+
 // ---- locate ------------------------------------------------------------------------------
 
 // per query: number of path nodes to walk and number of values before deduplication
@@ -790,6 +908,7 @@ struct gcsa2_index
   DevImage img;
   void* d_base = nullptr;
   void* d_kmer = nullptr;
+  void* d_pred4 = nullptr;
   u64 bytes = 0;
   u64 order = 0;
 };
@@ -813,6 +932,9 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
               std::string(#expr) + ": " + hipGetErrorString(e_)); } } while(0)
 
 inline unsigned grid_for(u64 n) { return unsigned((n + TPB - 1) / TPB); }
+
+inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
+                        u64 total_nodes, u64* values, hipStream_t stream);
 
 // host-side staging of the device image --------------------------------------------------
 
@@ -961,6 +1083,23 @@ template<class T> struct DBuf
 
 }  // namespace
 
+namespace {
+inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
+                        u64 total_nodes, u64* values, hipStream_t stream)
+{
+  if(ix->img.pred4 != nullptr)
+  {
+    hipLaunchKernelGGL(k_locate_walk2, dim3(unsigned((total_nodes + TPB2 - 1) / TPB2)), dim3(TPB2), 0, stream,
+                       ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values);
+  }
+  else
+  {
+    hipLaunchKernelGGL(k_locate_walk, dim3(grid_for(total_nodes)), dim3(TPB), 0, stream,
+                       ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values);
+  }
+}
+}  // namespace
+
 extern "C" {
 
 const char* gcsa2_last_error(void) { return g_error.c_str(); }
@@ -1063,6 +1202,27 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     }
     if(img.has_lcp) { img.lcp = reinterpret_cast<const u8*>(base + lcp_off); }
 
+    // pred4 nibbles (first predecessor comp + sampled flag), built on the device
+    img.pred4 = nullptr;
+    if(img.sigma <= 8 && img.n > 0)
+    {
+      u64 nwords = (img.n / BLOCK_BITS + 1) * PAYLOAD_WORDS;
+      e = hipMalloc(&ix->d_pred4, nwords * 4 * sizeof(u64));
+      if(e == hipSuccess)
+      {
+        hipLaunchKernelGGL(k_build_pred4, dim3(grid_for(nwords)), dim3(TPB), 0, nullptr, img, nwords, static_cast<u64*>(ix->d_pred4));
+        e = hipDeviceSynchronize();
+      }
+      if(e != hipSuccess)
+      {
+        if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
+        (void)hipFree(ix->d_base); delete ix;
+        return fail(GCSA2_ERR_HIP, std::string("pred4: ") + hipGetErrorString(e));
+      }
+      img.pred4 = static_cast<const u64*>(ix->d_pred4);
+      ix->bytes += nwords * 4 * sizeof(u64);
+    }
+
     // k-mer seed table: largest k <= 12 with 4^k <= n / 4, and only if comps 1..4 exist
     u32 k = 0;
     const char* env = std::getenv("GCSA2_KMER_TABLE");
@@ -1083,6 +1243,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       if(e != hipSuccess)
       {
         if(ix->d_kmer) { (void)hipFree(ix->d_kmer); }
+        if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
         (void)hipFree(ix->d_base); delete ix;
         return fail(GCSA2_ERR_HIP, std::string("k-mer table: ") + hipGetErrorString(e));
       }
@@ -1104,6 +1265,7 @@ void gcsa2_index_destroy(gcsa2_index* ix)
   DeviceGuard guard(ix->device);
   if(ix->d_base) { (void)hipFree(ix->d_base); }
   if(ix->d_kmer) { (void)hipFree(ix->d_kmer); }
+  if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
   delete ix;
 }
 
@@ -1267,8 +1429,7 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
     // sort == false (gcsa.cpp:827-842 without removeDuplicates): values in path order, the
     // values of one path node in sample order, duplicates kept -- exactly the walk's output.
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_values), total_raw * sizeof(u64)));
-    hipLaunchKernelGGL(k_locate_walk, dim3(grid_for(total_nodes)), dim3(TPB), 0, stream,
-                       ix->img, d_ranges, nq, node_off.p, raw_off.p, total_nodes, job->d_values);
+    launch_walk(ix, d_ranges, nq, node_off.p, raw_off.p, total_nodes, job->d_values, stream);
     LAUNCH_CHECK("k_locate_walk");
     HIP_TRY(hipMemcpyAsync(job->d_offsets, raw_off.p, (nq + 1) * sizeof(u64), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -1280,18 +1441,31 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
     DBuf<u32> flags;
     HIP_TRY(raw.alloc(total_raw)); HIP_TRY(sorted.alloc(total_raw));
     HIP_TRY(flags.alloc(total_raw + 1)); HIP_TRY(flag_scan.alloc(total_raw + 1));
-    hipLaunchKernelGGL(k_locate_walk, dim3(grid_for(total_nodes)), dim3(TPB), 0, stream,
-                       ix->img, d_ranges, nq, node_off.p, raw_off.p, total_nodes, raw.p);
+    launch_walk(ix, d_ranges, nq, node_off.p, raw_off.p, total_nodes, raw.p, stream);
     LAUNCH_CHECK("k_locate_walk");
 
-    // removeDuplicates: segmented sort, then flag + scan + compact
-    size_t sort_bytes = 0;
-    HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw.p, sorted.p, int(total_raw), int(nq),
-                                                       raw_off.p, raw_off.p + 1, 0, 64, stream));
+    // removeDuplicates: sort only the segments that hold more than one value (single-value
+    // segments are copied through), then flag + scan + compact
+    DBuf<u64> seg_begin, seg_end;
+    DBuf<unsigned long long> seg_count;
+    HIP_TRY(seg_begin.alloc(nq)); HIP_TRY(seg_end.alloc(nq)); HIP_TRY(seg_count.alloc(1));
+    HIP_TRY(hipMemsetAsync(seg_count.p, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off.p, nq, seg_count.p, seg_begin.p, seg_end.p);
+    LAUNCH_CHECK("k_collect_multi");
+    HIP_TRY(hipMemcpyAsync(sorted.p, raw.p, total_raw * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    unsigned long long multi = 0;
+    HIP_TRY(hipMemcpyAsync(&multi, seg_count.p, sizeof(multi), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     DBuf<char> sort_tmp;
-    HIP_TRY(sort_tmp.alloc(sort_bytes));
-    HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp.p, sort_bytes, raw.p, sorted.p, int(total_raw), int(nq),
-                                                       raw_off.p, raw_off.p + 1, 0, 64, stream));
+    if(multi > 0)
+    {
+      size_t sort_bytes = 0;
+      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw.p, sorted.p, int(total_raw), int(multi),
+                                                         seg_begin.p, seg_end.p, 0, 64, stream));
+      HIP_TRY(sort_tmp.alloc(sort_bytes));
+      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp.p, sort_bytes, raw.p, sorted.p, int(total_raw), int(multi),
+                                                         seg_begin.p, seg_end.p, 0, 64, stream));
+    }
     hipLaunchKernelGGL(k_mark_unique, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted.p, raw_off.p, nq, total_raw, flags.p);
     LAUNCH_CHECK("k_mark_unique");
     HIP_TRY(hipMemsetAsync(flags.p + total_raw, 0, sizeof(u32), stream));
@@ -1614,6 +1788,81 @@ int gcsa2_locate_max(const gcsa2_index* ix, uint64_t sp, uint64_t ep, uint64_t m
   if(results.size() > capacity) { *count_out = results.size(); return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small"); }
   std::memcpy(values, results.data(), results.size() * sizeof(u64));
   *count_out = results.size();
+  return GCSA2_OK;
+}
+
+// ---- single-process multi-GPU: replicated index, contiguous query shards ---------------------
+// Queries are independent and the index is read-only (the reference's only data-parallel query
+// path is the static split of verifyIndex, src/algorithms.cpp:106-114), so every device gets a
+// replica and a contiguous shard; one host thread per device stages its shard, runs k_find2 and
+// copies its ranges straight into the caller's buffer.  No device-to-device traffic.
+
+struct gcsa2_group
+{
+  std::vector<gcsa2_index*> replicas;
+};
+
+int gcsa2_group_create(const gcsa2_host_view* view, const int* devices, int n_devices, gcsa2_group** out)
+{
+  if(view == nullptr || devices == nullptr || out == nullptr || n_devices <= 0) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad group arguments"); }
+  *out = nullptr;
+  gcsa2_group* g = new(std::nothrow) gcsa2_group();
+  if(g == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+  for(int i = 0; i < n_devices; i++)
+  {
+    gcsa2_index* ix = nullptr;
+    int rc = gcsa2_index_create(view, devices[i], &ix);
+    if(rc != GCSA2_OK)
+    {
+      for(gcsa2_index* r : g->replicas) { gcsa2_index_destroy(r); }
+      delete g;
+      return rc;
+    }
+    g->replicas.push_back(ix);
+  }
+  *out = g;
+  return GCSA2_OK;
+}
+
+void gcsa2_group_destroy(gcsa2_group* g)
+{
+  if(g == nullptr) { return; }
+  for(gcsa2_index* r : g->replicas) { gcsa2_index_destroy(r); }
+  delete g;
+}
+
+int gcsa2_group_size(const gcsa2_group* g) { return g == nullptr ? 0 : int(g->replicas.size()); }
+
+const gcsa2_index* gcsa2_group_index(const gcsa2_group* g, int i)
+{
+  return (g == nullptr || i < 0 || i >= int(g->replicas.size())) ? nullptr : g->replicas[size_t(i)];
+}
+
+int gcsa2_group_find_batch(const gcsa2_group* g, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t* ranges)
+{
+  if(g == nullptr || g->replicas.empty()) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null or empty group"); }
+  if(nq == 0) { return GCSA2_OK; }
+  if(offsets == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  const u64 G = g->replicas.size(), base = nq / G, rem = nq % G;
+  std::vector<int> status(G, GCSA2_OK);
+  std::vector<std::string> messages(G);
+  std::vector<std::thread> workers;
+  u64 begin = 0;
+  for(u64 r = 0; r < G; r++)
+  {
+    u64 count = base + (r < rem ? 1 : 0), b = begin;
+    begin += count;
+    if(count == 0) { continue; }
+    workers.emplace_back([&, r, b, count]()
+    {
+      std::vector<u64> local(count + 1);
+      for(u64 i = 0; i <= count; i++) { local[i] = offsets[b + i] - offsets[b]; }
+      status[r] = gcsa2_find_batch(g->replicas[r], patterns + offsets[b], local.data(), count, ranges + 2 * b);
+      if(status[r] != GCSA2_OK) { messages[r] = g_error; }     // g_error is thread-local
+    });
+  }
+  for(std::thread& t : workers) { t.join(); }
+  for(u64 r = 0; r < G; r++) { if(status[r] != GCSA2_OK) { return fail(status[r], "shard " + std::to_string(r) + ": " + messages[r]); } }
   return GCSA2_OK;
 }
 

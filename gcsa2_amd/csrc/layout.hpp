@@ -70,6 +70,8 @@ struct DevImage
   const u64* flb;       // fused LF blocks: comp c, block b at flb + (c * flb_nblocks + b) * 16
   u64 flb_nblocks;      // per comp = n / 448 + 1
   u64 crange[2 * MAX_SIGMA];   // charRange(c) in node space, precomputed (gcsa.h:150-153)
+  const u64* pred4;            // 4 bits per path node: bits 0-2 = comp of the first incoming edge
+                               // (gcsa.h:165-183 probe order), bit 3 = sampled(node); nullptr if sigma > 8
   const u64* kmer_table;       // find() of every k-mer over comps 1..4: (sp, ep) pairs, 4^kmer_k entries
   u32 kmer_k;                  // 0 = no table
   DevBV sampled;        // sampled_paths

@@ -237,6 +237,20 @@ uint64_t gcsa2_lcp_branching(const gcsa2_index* index);
 int gcsa2_lcp_access_batch(const gcsa2_index* index, const uint64_t* positions, uint64_t n_queries,
                            uint64_t* out);
 
+/* ---- single-process multi-GPU -------------------------------------------------------------
+ * A group holds one replica of the index per listed device (a device may be listed more than
+ * once).  group_find_batch splits the batch into contiguous shards (sizes differ by at most one,
+ * the static split of verifyIndex, src/algorithms.cpp:106-114), runs every shard on its device
+ * from its own host thread and writes the ranges in query order.  Multi-process deployments
+ * (one rank per GPU + one RCCL gather) use gcsa2_find_device from each rank instead. */
+typedef struct gcsa2_group gcsa2_group;
+int gcsa2_group_create(const gcsa2_host_view* view, const int* devices, int n_devices, gcsa2_group** out);
+void gcsa2_group_destroy(gcsa2_group* group);
+int gcsa2_group_size(const gcsa2_group* group);
+const gcsa2_index* gcsa2_group_index(const gcsa2_group* group, int i);
+int gcsa2_group_find_batch(const gcsa2_group* group, const uint8_t* patterns, const uint64_t* offsets,
+                           uint64_t n_queries, uint64_t* ranges);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,3 +164,23 @@ def test_locate_modes_and_samples(case):
     assert gpu.sampledPositions() == sum(cpu.sampled(i) for i in range(ix.n))
     assert lcp.access_batch(np.arange(ix.n, dtype=np.uint64)).tolist() == ix.lcp_data[: ix.n].tolist()
     assert lcp.levels() == ix.lcp_offsets.shape[0] - 1 and lcp.branching() == ix.lcp_branching
+
+
+def test_group_find_shards(engine):
+    """Single-process multi-GPU API; on a 1-GPU box the replicas share device 0."""
+    from oracle.oracle import OracleIndex
+    name, g, K = CASES[-1]
+    ix = build(g, K, sample_period=8, branching=4)
+    cpu = OracleIndex(ix)
+    pats = [truncate_at_sink(p) for p in random_patterns(g, K, 0x79, 101)] + [b"", b"N"]
+    data, off = concat_patterns(pats)
+    want = cpu.find_batch(data, off)
+    for devices in ([0], [0, 0, 0], [0] * 7):
+        grp = engine.GCSAGroup(ix, devices)
+        assert grp.size() == len(devices)
+        assert np.array_equal(grp.find_batch(data, off), want), devices
+        one = concat_patterns(pats[:1])
+        assert np.array_equal(grp.find_batch(*one), want[:1])
+        grp.close()
+    with pytest.raises(engine.Gcsa2Error):
+        engine.GCSAGroup(ix, [0, 99])
