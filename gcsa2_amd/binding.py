@@ -34,7 +34,7 @@ EXPORTS = [
     "gcsa2_lcp_size", "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching",
     "gcsa2_lcp_access_batch",
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
-    "gcsa2_group_find_batch",
+    "gcsa2_group_find_batch", "gcsa2_count_kmers",
 ]
 
 
@@ -100,6 +100,7 @@ def load_library():
     L.gcsa2_alphabet.argtypes = [vp, u8p, u64p]
     L.gcsa2_alphabet.restype = None
     L.gcsa2_lcp_access_batch.argtypes = [vp, u64p, u64, u64p]
+    L.gcsa2_count_kmers.argtypes = [vp, u64, i32, i32, u64p]
     L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
     L.gcsa2_group_destroy.argtypes = [vp]
     L.gcsa2_group_destroy.restype = None
@@ -334,6 +335,12 @@ class GCSA:
         cnt = C.c_uint64()
         _check(self._L.gcsa2_locate_max(self._h, rng[0], rng[1], max_positions, _p64(values), cap, C.byref(cnt)))
         return values[: cnt.value]
+
+    def count_kmers(self, k, include_Ns=False, force=False):
+        """`countKMers` (reference src/algorithms.cpp:387-421)."""
+        res = C.c_uint64()
+        _check(self._L.gcsa2_count_kmers(self._h, k, int(include_Ns), int(force), C.byref(res)))
+        return res.value
 
     # ---- samples (gcsa.h:191-210) ---------------------------------------------------------
     def sample_range_batch(self, nodes):

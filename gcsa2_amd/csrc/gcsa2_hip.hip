@@ -563,6 +563,55 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ r
   }
 }
 
+// ---- countKMers frontier expansion (src/algorithms.cpp:364-421) -------------------------------
+// One lane per search state (a non-empty range at depth d): its children are LF_fast / LF_all of
+// the range (src/gcsa.cpp:742-798) for comps 1..limit; non-empty children are appended to `out`
+// (wave-aggregated atomic slot allocation) or, when out == nullptr, only counted.
+__global__ __launch_bounds__(TPB) void k_kmer_expand(DevImage img, const u64* __restrict__ in, u64 n_in, u32 limit,
+                                                     u64* __restrict__ out, unsigned long long* __restrict__ counter)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  const u32 lane = threadIdx.x & 63;
+  bool live = q < n_in;
+  ulonglong2 r = live ? reinterpret_cast<const ulonglong2*>(in)[q] : make_ulonglong2(1, 0);
+  for(u32 c = 1; c <= limit; c++)
+  {
+    u64 sp = 1, ep = 0;
+    if(live)
+    {
+      DevBV bv = bwt_of(img, c);
+      if(r.x == r.y)      // single path node: bit probe (gcsa.cpp:748-757)
+      {
+        u64 rk;
+        if(bv_get_rank(bv, r.x, rk)) { sp = ep = bv_rank(img.edges, t.C[c] + rk); }
+      }
+      else
+      {
+        u64 ra, rb;
+        bv_rank2(bv, r.x, r.y + 1, ra, rb);
+        sp = t.C[c] + ra; ep = t.C[c] + rb - 1;
+        if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
+      }
+    }
+    bool has = live && !range_empty(sp, ep);
+    u64 mask = __ballot(has);
+    if(mask != 0)
+    {
+      u32 leader = u32(__ffsll((long long)mask)) - 1;
+      unsigned long long base = 0;
+      if(lane == leader) { base = atomicAdd(counter, (unsigned long long)__popcll(mask)); }
+      base = __shfl(base, leader, 64);
+      if(has && out != nullptr)
+      {
+        u64 slot = base + __popcll(mask & ((u64(1) << lane) - 1));
+        reinterpret_cast<ulonglong2*>(out)[slot] = make_ulonglong2(sp, ep);
+      }
+    }
+  }
+}
+
 // ---- locate ------------------------------------------------------------------------------
 
 // per query: number of path nodes to walk and number of values before deduplication
@@ -1867,3 +1916,82 @@ int gcsa2_group_find_batch(const gcsa2_group* g, const uint8_t* patterns, const 
 }
 
 }  // extern "C"
+
+// countKMers(index, k, parameters) (src/algorithms.cpp:387-421): level-synchronous frontier
+// expansion on the device instead of the reference's seed DFS + OpenMP; the count is the number of
+// non-empty states at depth k either way.
+namespace {
+int kmer_level(const gcsa2_index* ix, const u64* d_in, u64 n_in, u32 limit, u64* d_out, unsigned long long* d_counter, u64& produced)
+{
+  HIP_TRY(hipMemset(d_counter, 0, sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_kmer_expand, dim3(grid_for(n_in)), dim3(TPB), 0, nullptr, ix->img, d_in, n_in, limit, d_out, d_counter);
+  LAUNCH_CHECK("k_kmer_expand");
+  unsigned long long c = 0;
+  HIP_TRY(hipMemcpy(&c, d_counter, sizeof(c), hipMemcpyDeviceToHost));
+  produced = c;
+  return GCSA2_OK;
+}
+
+// takes ownership of d_frontier
+int kmer_run(const gcsa2_index* ix, u64* d_frontier, u64 n, u64 depth, u64 k, u32 limit, unsigned long long* d_counter, u64& total)
+{
+  const u64 MAX_FRONTIER = u64(1) << 26;   // 64 M states = 1 GB
+  struct Free { u64*& p; ~Free() { if(p) { (void)hipFree(p); p = nullptr; } } } guard{d_frontier};
+  while(depth < k && n > 0)
+  {
+    if(n > MAX_FRONTIER)    // split: each half continues on its own copy
+    {
+      u64 half = n / 2, parts[2][2] = {{0, half}, {half, n - half}};
+      for(auto& part : parts)
+      {
+        u64* copy = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&copy), part[1] * 2 * sizeof(u64)));
+        hipError_t e = hipMemcpy(copy, d_frontier + 2 * part[0], part[1] * 2 * sizeof(u64), hipMemcpyDeviceToDevice);
+        if(e != hipSuccess) { (void)hipFree(copy); return fail(GCSA2_ERR_HIP, hipGetErrorString(e)); }
+        int rc = kmer_run(ix, copy, part[1], depth, k, limit, d_counter, total);
+        if(rc != GCSA2_OK) { return rc; }
+      }
+      return GCSA2_OK;
+    }
+    u64 produced = 0;
+    int rc = kmer_level(ix, d_frontier, n, limit, nullptr, d_counter, produced);     // count pass
+    if(rc != GCSA2_OK) { return rc; }
+    if(depth + 1 == k) { total += produced; return GCSA2_OK; }
+    if(produced == 0) { return GCSA2_OK; }
+    u64* next = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&next), produced * 2 * sizeof(u64)));
+    u64 again = 0;
+    rc = kmer_level(ix, d_frontier, n, limit, next, d_counter, again);               // fill pass
+    if(rc != GCSA2_OK || again != produced) { (void)hipFree(next); return rc != GCSA2_OK ? rc : fail(GCSA2_ERR_HIP, "k-mer frontier changed between passes"); }
+    (void)hipFree(d_frontier);
+    d_frontier = next; n = produced; depth++;
+  }
+  if(depth == k) { total += n; }
+  return GCSA2_OK;
+}
+}  // namespace
+
+extern "C" int gcsa2_count_kmers(const gcsa2_index* ix, uint64_t k, int include_ns, int force, uint64_t* result)
+{
+  CHECK_INDEX(ix);
+  if(result == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null result"); }
+  *result = 0;
+  if(k == 0) { *result = 1; return GCSA2_OK; }                       // algorithms.cpp:390
+  if(k > ix->order && !force) { return GCSA2_OK; }                   // algorithms.cpp:391-395 (returns 0)
+  if(ix->img.n == 0) { return GCSA2_OK; }
+  if(ix->img.sigma < 3) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "alphabet too small for countKMers"); }
+  u32 limit = u32(include_ns ? ix->img.sigma - 2 : ix->img.fast_chars);   // comps 1..limit (algorithms.cpp:369, 379)
+  DeviceGuard guard(ix->device);
+  DBuf<unsigned long long> counter;
+  HIP_TRY(counter.alloc(1));
+  u64* frontier = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&frontier), 2 * sizeof(u64)));
+  u64 root[2] = {0, ix->img.n - 1};
+  hipError_t e = hipMemcpy(frontier, root, sizeof(root), hipMemcpyHostToDevice);
+  if(e != hipSuccess) { (void)hipFree(frontier); return fail(GCSA2_ERR_HIP, hipGetErrorString(e)); }
+  u64 total = 0;
+  int rc = kmer_run(ix, frontier, 1, 0, k, limit, counter.p, total);
+  if(rc != GCSA2_OK) { return rc; }
+  *result = total;
+  return GCSA2_OK;
+}

@@ -237,6 +237,12 @@ uint64_t gcsa2_lcp_branching(const gcsa2_index* index);
 int gcsa2_lcp_access_batch(const gcsa2_index* index, const uint64_t* positions, uint64_t n_queries,
                            uint64_t* out);
 
+/* ---- countKMers(index, k, parameters) (include/gcsa/algorithms.h:73-84, src/algorithms.cpp:387-421):
+ * number of distinct k-mers in the index = non-empty states at depth k of the search tree,
+ * expanding with LF_fast (bases only) or, include_ns != 0, LF_all.  k > order() yields 0 unless
+ * force != 0, k == 0 yields 1, as in the reference. */
+int gcsa2_count_kmers(const gcsa2_index* index, uint64_t k, int include_ns, int force, uint64_t* result);
+
 /* ---- single-process multi-GPU -------------------------------------------------------------
  * A group holds one replica of the index per listed device (a device may be listed more than
  * once).  group_find_batch splits the batch into contiguous shards (sizes differ by at most one,

@@ -933,3 +933,59 @@ void oracle_find_traffic(const oracle_index* ix, const uint8_t* patterns, const 
   }
   *blocks_touched = blocks; *lf_steps = steps;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* countKMers (src/algorithms.cpp:364-421): number of distinct k-mers = non-empty states at     */
+/* depth k of the search tree rooted at (0, n - 1), expanding with LF_fast (bases only) or       */
+/* LF_all (include_Ns).  Restated as an explicit-stack DFS per seed, OpenMP over seeds.          */
+
+typedef struct { u64 sp, ep, k; } kstate;
+
+static u64 count_subtree(const oracle_index* ix, kstate root, u64 k, int include_ns, kstate** seeds, u64* nseeds, u64* cap)
+{
+  u64 limit = (include_ns ? ix->sigma : ix->fast_chars + 2), count = 0;          /* algorithms.cpp:369 */
+  u64 stack_cap = 64, top = 0;
+  kstate* stack = (kstate*)malloc(stack_cap * sizeof(kstate));
+  u64* pred = (u64*)malloc(2 * ix->sigma * sizeof(u64));
+  stack[top++] = root;
+  while(top > 0)
+  {
+    kstate cur = stack[--top];
+    if(range_empty(cur.sp, cur.ep)) { continue; }                                   /* :373 */
+    if(cur.k == k)                                                                  /* report */
+    {
+      if(seeds != NULL)
+      {
+        if(*nseeds == *cap) { *cap = (*cap == 0 ? 64 : 2 * *cap); *seeds = (kstate*)realloc(*seeds, *cap * sizeof(kstate)); }
+        (*seeds)[(*nseeds)++] = cur;
+      }
+      count++;
+    }
+    if(cur.k < k)                                                                   /* expand */
+    {
+      oracle_lf_all(ix, cur.sp, cur.ep, include_ns, pred);                          /* :377-378 */
+      for(u64 comp = 1; comp + 1 < limit; comp++)
+      {
+        if(top == stack_cap) { stack_cap *= 2; stack = (kstate*)realloc(stack, stack_cap * sizeof(kstate)); }
+        kstate next = { pred[2 * comp], pred[2 * comp + 1], cur.k + 1 };
+        stack[top++] = next;
+      }
+    }
+  }
+  free(stack); free(pred);
+  return count;
+}
+
+uint64_t oracle_count_kmers(const oracle_index* ix, uint64_t k, int include_ns, int force, uint64_t seed_length, int threads)
+{
+  if(k == 0) { return 1; }                                                          /* :390 */
+  if(k > ix->order && !force) { return 0; }                                         /* :391-395 */
+  kstate* seeds = NULL; u64 nseeds = 0, cap = 0;
+  kstate root = { 0, ix->n - 1, 0 };
+  count_subtree(ix, root, (k < seed_length ? k : seed_length), include_ns, &seeds, &nseeds, &cap);   /* :398-405 */
+  u64 result = 0;
+  #pragma omp parallel for schedule(dynamic, 1) reduction(+:result) num_threads(threads > 0 ? threads : 1)
+  for(u64 i = 0; i < nseeds; i++) { result += count_subtree(ix, seeds[i], k, include_ns, NULL, NULL, NULL); }   /* :408-418 */
+  free(seeds);
+  return result;
+}

@@ -91,6 +91,9 @@ void oracle_find_traffic(const oracle_index* ix, const uint8_t* patterns, const 
                          uint64_t nq, uint64_t block_bits, uint64_t* blocks_touched,
                          uint64_t* lf_steps);
 
+/* countKMers (src/algorithms.cpp:387-421); seed_length = KMerSearchParameters::SEED_LENGTH = 5. */
+uint64_t oracle_count_kmers(const oracle_index* ix, uint64_t k, int include_ns, int force, uint64_t seed_length, int threads);
+
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -74,6 +74,8 @@ def lib():
         L.oracle_locate_batch.restype = dbl
         L.oracle_locate_batch.argtypes = [vp, u64p, u64, u64p, C.POINTER(vp), i32]
         L.oracle_find_traffic.argtypes = [vp, u8p, u64p, u64, u64, u64p, u64p]
+        L.oracle_count_kmers.restype = u64
+        L.oracle_count_kmers.argtypes = [vp, u64, i32, i32, u64, i32]
         L.oracle_max_threads.restype = i32
         _lib = L
     return _lib
@@ -252,6 +254,10 @@ class OracleIndex:
                                                       C.byref(ptr), threads)
         values = self._take(ptr.value, int(offsets[nq]))
         return offsets, values
+
+    def count_kmers(self, k, include_Ns=False, force=False, threads=1):
+        """`countKMers` (reference src/algorithms.cpp:387-421)."""
+        return int(lib().oracle_count_kmers(self._h, k, int(include_Ns), int(force), 5, threads))
 
     def find_traffic(self, patterns, offsets, block_bits):
         blocks, steps = C.c_uint64(), C.c_uint64()

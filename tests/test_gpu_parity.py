@@ -184,3 +184,12 @@ def test_group_find_shards(engine):
         grp.close()
     with pytest.raises(engine.Gcsa2Error):
         engine.GCSAGroup(ix, [0, 99])
+
+
+def test_count_kmers(case):
+    """countKMers (reference src/algorithms.cpp:387-421) as a device frontier expansion."""
+    name, g, K, ix, gpu, lcp, cpu = case
+    for k in range(0, K + 2):
+        for ns in (False, True):
+            assert gpu.count_kmers(k, include_Ns=ns) == cpu.count_kmers(k, include_Ns=ns, threads=2), (name, k, ns)
+    assert gpu.count_kmers(K + 3, force=True) == cpu.count_kmers(K + 3, force=True)

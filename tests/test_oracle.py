@@ -261,3 +261,14 @@ def test_verify_index_invariants(case):
         assert o.count(rng) == len(occ)
         sub = [int(v) for v in o.locate(rng, max_positions=3)]
         assert len(sub) == min(3, len(occ)) and sub == sorted(sub) and set(sub) <= set(occ)
+
+
+def test_count_kmers_vs_input_graph(case):
+    """countKMers == number of distinct base-only k-mers spelled by paths of the input graph."""
+    import itertools
+    name, g, K, ix, o, nv, gb = case
+    for k in range(0, min(K, 5) + 1):
+        want = 1 if k == 0 else sum(1 for t in itertools.product([1, 2, 3, 4], repeat=k) if gb.starts(list(t)))
+        assert o.count_kmers(k) == want, (name, k)
+        assert o.count_kmers(k, threads=3) == want
+    assert o.count_kmers(K + 1) == 0
