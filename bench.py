@@ -182,11 +182,31 @@ def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup):
                 found=found, d_out=d_out)
 
 
-def roofline(args, r):
+def pmc_traffic(args, key, nq, m):
+    """Memory-side read bytes of one launch from the committed rocprofv3 --pmc pass of this exact
+    workload (profiles/traffic.json, derivation in profiles/r01_v3_pmc.md).  PMC counters cannot
+    be read from inside the timed process, so this is looked up, never estimated: any mismatch in
+    workload, batch shape or kernel generation yields None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            entry = json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+    if not entry or args.variant != 2 or args.set != "S" or entry["queries"] != nq or entry["pattern_len"] != m:
+        return None
+    return entry["read_bytes_per_launch"]
+
+
+def roofline(args, r, key, nq, m):
     achieved = r["algo_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_find2" if args.variant == 2 else "k_find", "achieved": achieved,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"]}
+    traffic = pmc_traffic(args, key, nq, m)
+    out = {"bound": "hbm", "kernel": "k_find2" if args.variant == 2 else "k_find", "achieved": achieved,
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+           "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"]}
+    if traffic is not None:
+        out["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_*_sum pass of this workload; 128 B x RDREQ_128B + 64 B x RDREQ_64B)"
+        out["traffic_GBps"] = traffic / (r["kernel_ms"] * 1e-3) / 1e9
+    return out
 
 
 def main():
@@ -245,7 +265,7 @@ def main():
                        "blocks_per_query": r["blocks"] / nq, "block_bytes": gpu.find_block_bytes(),
                        "kmer_table_k": gpu.kmer_table_k(),
                        "parallelism": f"replicated index, query shards x{world}, one RCCL gather of ranges per step"},
-            "roofline": roofline(args, r),
+            "roofline": roofline(args, r, f"{args.workload}_{log2_bases}", nq, m),
         }
         if args.workload == "snp":
             result["roofline"]["note"] = ("fused blocks of this index fit the 256 MiB Infinity Cache: achieved = algorithmic bytes / "
@@ -268,7 +288,7 @@ def main():
             "workload": f"linear graph 2^{lb} bases (FM-index shaped GCSA, built on the GPU), {nq} x {m}-mer find(), substrings of the text",
             "path_nodes": int(ix2.n), "find_bytes_hbm": int(ix2.sigma) * (int(ix2.n) // 448 + 1) * 128,
             "value": nq / (r2["kernel_ms"] * 1e-3), "unit": "queries/s", "blocks_per_query": r2["blocks"] / nq,
-            "roofline": roofline(args, r2)}
+            "roofline": roofline(args, r2, f"linear_{lb}", nq, m)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     D.barrier()

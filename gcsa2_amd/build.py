@@ -5,8 +5,9 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "gcsa2_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "layout.hpp"),
-        os.path.join(os.path.dirname(HERE), "include", "gcsa2_hip.h")]
+DEPS = [SRC, os.path.join(os.path.dirname(HERE), "include", "gcsa2_hip.h")] + \
+       [os.path.join(HERE, "csrc", f) for f in ("layout.hpp", "kernels_common.hpp", "kernels_find.hpp",
+                                                 "kernels_locate.hpp", "kernels_lcp.hpp")]
 OUT = os.path.join(HERE, "lib", "libgcsa2_hip.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",

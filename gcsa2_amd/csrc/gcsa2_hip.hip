@@ -1,15 +1,19 @@
 // gcsa2_hip.hip -- MI355X (gfx950) batched backward-search engine for GCSA2 indexes:
 // kernels + the C ABI of include/gcsa2_hip.h.  Written for CDNA4 only (wave64, no CUDA paths).
 //
+// One translation unit: the device code lives in kernels_*.hpp, this file holds the host side
+// (device image staging, handles, launches, the extern "C" entry points).
+//
 // Kernel <-> reference map (paths relative to the reference tree):
-//   k_find        GCSA::find                         include/gcsa/gcsa.h:96-110
-//   k_lf          GCSA::LF(range, comp)              include/gcsa/gcsa.h:155-162, 262-274
-//   k_lf_node     GCSA::LF(path_node)                include/gcsa/gcsa.h:165-183
-//   k_lf_all      GCSA::LF_fast / LF_all             src/gcsa.cpp:742-798
-//   k_count       GCSA::count, Sada*::count          src/gcsa.cpp:802-809, support.h:255-258,329-335
-//   k_locate_*    GCSA::locate(range), locateInternal, removeDuplicates
-//                                                    src/gcsa.cpp:827-842, 880-896, utils.h:350-357
-//   k_parent/...  LCPArray::parent/depth/psv/nsv/rmq include/gcsa/lcp.h:137-178, src/lcp.cpp:276-519
+//   kernels_find.hpp    k_find2 / k_find      GCSA::find                 include/gcsa/gcsa.h:96-110
+//                       k_lf2                 GCSA::LF(range, comp)      include/gcsa/gcsa.h:155-162, 262-274
+//                       k_lf_node             GCSA::LF(path_node)        include/gcsa/gcsa.h:165-183
+//                       k_lf_all              GCSA::LF_fast / LF_all     src/gcsa.cpp:742-798
+//   kernels_locate.hpp  k_count               GCSA::count, Sada*::count  src/gcsa.cpp:802-809, support.h:255-258,329-335
+//                       k_locate_*            GCSA::locate(range), locateInternal, removeDuplicates
+//                                                                        src/gcsa.cpp:827-842, 880-896, utils.h:350-357
+//                       k_kmer_expand         countKMers                 src/algorithms.cpp:364-421
+//   kernels_lcp.hpp     k_parent / k_depth / k_sv / k_rmq   LCPArray     include/gcsa/lcp.h:137-178, src/lcp.cpp:276-519
 #include "layout.hpp"
 #include "../../include/gcsa2_hip.h"
 
@@ -27,926 +31,10 @@
 
 using namespace g2;
 
-// ==========================================================================================
-// device code
-
-namespace {
-
-constexpr int TPB = 256;   // 4 waves per workgroup
-
-struct Tables   // small per-workgroup lookup tables staged into LDS
-{
-  u64 C[MAX_SIGMA + 1];
-  u8 c2c[256];
-};
-
-__device__ __forceinline__ void stage_tables(const DevImage& img, Tables& t)
-{
-  // DevImage lives in the kernarg segment; a lane-indexed read of it is a plain global load.
-  if(threadIdx.x <= MAX_SIGMA) { t.C[threadIdx.x] = img.C[threadIdx.x]; }
-  t.c2c[threadIdx.x & 255] = img.char2comp[threadIdx.x & 255];
-  __syncthreads();
-}
-
-__device__ __forceinline__ u64 clampu(u64 x, u64 hi) { return x < hi ? x : hi; }
-
-// pathNodeRange (gcsa.h:253-258)
-__device__ __forceinline__ void path_node_range(const DevImage& img, u64& sp, u64& ep)
-{
-  u64 a, b;
-  bv_rank2(img.edges, clampu(sp, img.e), clampu(ep, img.e), a, b);
-  sp = a; ep = b;
-}
-
-// The per-comp descriptors sit in the kernarg segment; selecting one by a lane-varying comp is a
-// global load of the descriptor.  All B_c have the same geometry, so only the base pointer varies.
-__device__ __forceinline__ DevBV bwt_of(const DevImage& img, u32 comp)
-{
-  DevBV bv = img.bwt[0];
-  bv.blocks = img.bwt[0].blocks + u64(comp) * (img.bwt[0].nblocks * BLOCK_WORDS);
-  return bv;
-}
-
-// STATS = true additionally counts, per launch, the distinct rank blocks fetched and the LF steps
-// executed (the "algorithmic bytes" of the roofline model): stats[0] += blocks,
-// stats[1] += steps.  The timed path is the STATS = false instantiation.
-template<bool STATS>
-__global__ __launch_bounds__(TPB) void k_find(DevImage img, const u8* __restrict__ patterns,
-                                              const u64* __restrict__ offsets, u64 nq,
-                                              u64* __restrict__ out, unsigned long long* __restrict__ stats)
-{
-  __shared__ Tables t;
-  stage_tables(img, t);
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  u64 blocks = 0, steps = 0;
-  if(q < nq)
-  {
-    u64 begin = offsets[q], len = offsets[q + 1] - begin;
-    u64 sp = 0, ep = img.n - 1;
-    if(len > 0 && img.n > 0)                                  // gcsa.h:99
-    {
-      const u8* p = patterns + begin;
-      u64 i = len - 1;
-      u32 comp = t.c2c[p[i]];
-      sp = t.C[comp]; ep = t.C[comp + 1] - 1;                 // charRange, utils.h:414-419
-      if(STATS) { blocks += 1 + (block_of(clampu(sp, img.e)) != block_of(clampu(ep, img.e))); }
-      path_node_range(img, sp, ep);                           // gcsa.h:150-153 (no emptiness check)
-      while(!range_empty(sp, ep) && i > 0)                    // gcsa.h:103
-      {
-        i--;
-        comp = t.c2c[p[i]];
-        DevBV bv = bwt_of(img, comp);
-        u64 ra, rb;
-        if(STATS) { steps++; blocks += 1 + (block_of(sp) != block_of(ep + 1)); }
-        bv_rank2(bv, sp, ep + 1, ra, rb);                     // gcsa.h:271-272
-        sp = t.C[comp] + ra; ep = t.C[comp] + rb - 1;
-        if(range_empty(sp, ep)) { break; }                    // gcsa.h:160: edge-space integers
-        if(STATS) { blocks += 1 + (block_of(sp) != block_of(ep)); }
-        path_node_range(img, sp, ep);                         // gcsa.h:161
-      }
-    }
-    reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep);
-  }
-  if(STATS)
-  {
-    // wave reduction, one atomic per wave
-    for(int o = 32; o > 0; o >>= 1) { blocks += __shfl_down(blocks, o, 64); steps += __shfl_down(steps, o, 64); }
-    if((threadIdx.x & 63) == 0) { atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps); }
-  }
-}
-
-// ---- k-mer seed table ----------------------------------------------------------------------
-// table[t] = find() of the k-mer whose j-th character FROM THE END has comp 1 + ((t >> 2j) & 3):
-// the exact (sp, ep) the backward search returns, including edge-space empty ranges, so that
-// k_find2 can start a pattern whose last k characters are all fast characters at step k.
-// Pure memoisation of gcsa.h:96-110; results are unchanged.
-__global__ __launch_bounds__(TPB) void k_build_kmer_table(DevImage img, u32 k, u64 entries, u64* __restrict__ table)
-{
-  u64 tix = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(tix >= entries) { return; }
-  u32 comp = 1 + u32(tix & 3);                               // last character
-  u64 sp = img.crange[2 * comp], ep = img.crange[2 * comp + 1];
-  for(u32 j = 1; j < k && !range_empty(sp, ep); j++)
-  {
-    comp = 1 + u32((tix >> (2 * j)) & 3);
-    DevBV bv = bwt_of(img, comp);
-    u64 ra, rb;
-    bv_rank2(bv, sp, ep + 1, ra, rb);
-    sp = img.C[comp] + ra; ep = img.C[comp] + rb - 1;
-    if(range_empty(sp, ep)) { break; }
-    path_node_range(img, sp, ep);
-  }
-  reinterpret_cast<ulonglong2*>(table)[tix] = make_ulonglong2(sp, ep);
-}
-
-// ---- find, version 2: fused 128-byte LF blocks, wave-cooperative fetch through LDS -----------
-//
-// One lane = one pattern, 64 patterns per wave walk their LF chains in lockstep.  Per step the
-// wave fetches the 64 fused blocks its lanes need with 8 line-coalesced instructions (8 adjacent
-// lanes x 16 bytes = one 128-byte block per request), stages them in LDS (XOR-swizzled so that the
-// ds_read_b128 read-back is conflict free) and every lane then evaluates its own
-// C[c] + rank(B_c, .) and rank(edges, .) from the staged block.  A second fetch round runs only
-// for lanes whose sp and ep + 1 fall into different blocks.
-constexpr int TPB2 = 128;          // 2 waves: 16 KB of staging + tables -> 9 workgroups / CU
-
-struct Tables2
-{
-  u64 crange[2 * MAX_SIGMA];
-  u8 c2c[256];
-};
-
-struct Endpoint { u64 edge; u64 node; u32 ones; };
-
-// lane-private evaluation of one LF endpoint from a staged fused block
-//   blk = 8 x ulonglong2 (w0..w15), r = bit offset inside the block
-//   edge = C[c] + rank(B_c, i);  node = rank(edges, edge - back) with back = 0 (sp) or 1 (ep)
-__device__ __forceinline__ void eval_endpoint(const ulonglong2 (&blk)[8], u32 r, u32 back, u64& edge, u64& node)
-{
-  const u64 w[16] = { blk[0].x, blk[0].y, blk[1].x, blk[1].y, blk[2].x, blk[2].y, blk[3].x, blk[3].y,
-                      blk[4].x, blk[4].y, blk[5].x, blk[5].y, blk[6].x, blk[6].y, blk[7].x, blk[7].y };
-  u32 wq = r >> 6;
-  u64 part = (u64(1) << (r & 63)) - 1;
-  u32 ones = 0;
-#pragma unroll
-  for(u32 j = 0; j < 7; j++)
-  {
-    u64 m = (j < wq ? ~u64(0) : (j == wq ? part : u64(0)));
-    ones += __popcll(w[2 + j] & m);
-  }
-  edge = w[0] + ones;
-  u64 ncnt = w[1] & ~PREV_BIT;
-  if(back > ones) { node = ncnt - (w[1] >> 63); return; }    // rank(edges, ecnt - 1)
-  u32 k = ones - back, kq = k >> 6;
-  u64 kpart = (u64(1) << (k & 63)) - 1;
-  u32 cnt = 0;
-#pragma unroll
-  for(u32 j = 0; j < 7; j++)
-  {
-    u64 m = (j < kq ? ~u64(0) : (j == kq ? kpart : u64(0)));
-    cnt += __popcll(w[9 + j] & m);
-  }
-  node = ncnt + cnt;
-}
-
-// wave-cooperative fetch: every lane with need != 0 gets flb block `idx` staged at its slot
-__device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane)
-{
-  u32 sub = lane & 7;
-#pragma unroll
-  for(u32 j = 0; j < 8; j++)
-  {
-    u32 owner = 8 * j + (lane >> 3);
-    u32 oidx = __shfl(idx, owner, 64);
-    bool oneed = __shfl(int(need), owner, 64) != 0;
-    if(oneed)
-    {
-      ulonglong2 a = reinterpret_cast<const ulonglong2*>(flb + u64(oidx) * FLB_WORDS)[sub];
-      wave_stage[owner * 8 + (sub ^ (owner & 7))] = a;
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ void read_block(const ulonglong2* wave_stage, u32 lane, ulonglong2 (&blk)[8])
-{
-#pragma unroll
-  for(u32 k = 0; k < 8; k++) { blk[k] = wave_stage[lane * 8 + (k ^ (lane & 7))]; }
-}
-
-template<bool STATS>
-__global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restrict__ patterns,
-                                               const u64* __restrict__ offsets, u64 nq,
-                                               u64* __restrict__ out, unsigned long long* __restrict__ stats)
-{
-  __shared__ ulonglong2 stage[TPB2 * 8];
-  __shared__ Tables2 t;
-  if(threadIdx.x < 2 * MAX_SIGMA) { t.crange[threadIdx.x] = img.crange[threadIdx.x]; }
-  t.c2c[threadIdx.x] = img.char2comp[threadIdx.x];
-  t.c2c[threadIdx.x + TPB2] = img.char2comp[threadIdx.x + TPB2];
-  __syncthreads();
-
-  const u32 lane = threadIdx.x & 63;
-  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  const u64 q = u64(blockIdx.x) * TPB2 + threadIdx.x;
-  u64 blocks = 0, steps = 0, lookups = 0;
-
-  u64 sp = 0, ep = img.n - 1, i = 0;
-  const u8* p = patterns;
-  bool done = true;
-  u64 word = 0, word_addr = ~u64(0);        // pattern bytes are consumed back to front from aligned 8-byte words
-  auto byte_at = [&](u64 pos) -> u32
-  {
-    u64 addr = reinterpret_cast<u64>(p) + pos, aligned = addr & ~u64(7);
-    if(aligned != word_addr) { word = *reinterpret_cast<const u64*>(aligned); word_addr = aligned; }
-    return u32(word >> ((addr & 7) * 8)) & 0xFF;
-  };
-  if(q < nq)
-  {
-    u64 begin = offsets[q], len = offsets[q + 1] - begin;
-    if(len > 0 && img.n > 0)                                   // gcsa.h:99
-    {
-      p = patterns + begin;
-      const u32 k = img.kmer_k;
-      bool seeded = false;
-      if(k > 0 && len >= k)
-      {
-        u64 tix = 0;
-        bool fast = true;
-        for(u32 j = 0; j < k; j++)                             // j-th character from the end
-        {
-          u32 comp = t.c2c[byte_at(len - 1 - j)];
-          fast = fast && (comp - 1 < 4);
-          tix |= u64((comp - 1) & 3) << (2 * j);
-        }
-        if(fast)
-        {
-          ulonglong2 r = reinterpret_cast<const ulonglong2*>(img.kmer_table)[tix];
-          sp = r.x; ep = r.y; i = len - k; seeded = true;
-          if(STATS) { lookups++; }
-        }
-      }
-      if(!seeded)
-      {
-        i = len - 1;
-        u32 comp = t.c2c[byte_at(i)];
-        sp = t.crange[2 * comp]; ep = t.crange[2 * comp + 1];  // charRange, gcsa.h:101-102, 150-153
-      }
-      done = range_empty(sp, ep) || i == 0;                    // gcsa.h:103
-    }
-  }
-
-  while(__any(!done))
-  {
-    u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
-    if(!done)
-    {
-      i--;
-      comp = t.c2c[byte_at(i)];
-      u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
-      r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
-      idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
-    }
-    ulonglong2 blk[8];
-    u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
-    fetch_blocks(img.flb, idx_sp, !done, wave_stage, lane);
-    if(!done)
-    {
-      read_block(wave_stage, lane, blk);
-      eval_endpoint(blk, r_sp, 0, e_sp, n_sp);                 // gcsa.h:271, then rank(edges, sp')
-      if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
-    }
-    bool need2 = !done && idx_ep != idx_sp;
-    if(STATS && !done) { steps++; blocks += 1 + (need2 ? 1 : 0); }
-    if(__any(need2))
-    {
-      __builtin_amdgcn_wave_barrier();
-      fetch_blocks(img.flb, idx_ep, need2, wave_stage, lane);
-      if(need2)
-      {
-        read_block(wave_stage, lane, blk);
-        eval_endpoint(blk, r_ep, 1, e_ep, n_ep);               // gcsa.h:272: LF(ep + 1) - 1
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if(!done)
-    {
-      u64 a = e_sp, b = e_ep - 1;                              // edge space
-      if(range_empty(a, b)) { sp = a; ep = b; done = true; }   // gcsa.h:160
-      else { sp = n_sp; ep = n_ep; done = (i == 0); }          // gcsa.h:161, 103
-    }
-  }
-  if(q < nq) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); }
-  if(STATS)
-  {
-    for(int o = 32; o > 0; o >>= 1)
-    {
-      blocks += __shfl_down(blocks, o, 64); steps += __shfl_down(steps, o, 64); lookups += __shfl_down(lookups, o, 64);
-    }
-    if(lane == 0)
-    {
-      atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps);
-      atomicAdd(stats + 2, (unsigned long long)lookups);
-    }
-  }
-}
-
-__global__ __launch_bounds__(TPB) void k_lf(DevImage img, const u64* __restrict__ in,
-                                            const u8* __restrict__ comps, u64 nq, u64* __restrict__ out)
-{
-  __shared__ Tables t;
-  stage_tables(img, t);
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  ulonglong2 r = reinterpret_cast<const ulonglong2*>(in)[q];
-  u32 comp = comps[q];
-  if(comp >= img.sigma) { comp = u32(img.sigma - 1); }     // memory safety only
-  u64 sp = r.x, ep = r.y;
-  DevBV bv = bwt_of(img, comp);
-  u64 ra, rb;
-  bv_rank2(bv, clampu(sp, img.n), clampu(ep + 1, img.n), ra, rb);
-  sp = t.C[comp] + ra; ep = t.C[comp] + rb - 1;
-  if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
-  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep);
-}
-
-// LF(path_node): first incoming edge, comps 1..fast_chars, then fast_chars+1..sigma-1, else 0
-__device__ __forceinline__ u64 lf_node(const DevImage& img, const u64* C, u64 node)
-{
-  u32 sigma = u32(img.sigma);
-  u32 comp = 0; u64 rank = 0; bool hit = false;
-  for(u32 c = 1; c < sigma && !hit; c++)
-  {
-    u64 r;
-    if(bv_get_rank(bwt_of(img, c), node, r)) { comp = c; rank = r; hit = true; }
-  }
-  if(!hit) { rank = bv_rank(bwt_of(img, 0), node); }
-  return bv_rank(img.edges, clampu(C[comp] + rank, img.e));
-}
-
-__global__ __launch_bounds__(TPB) void k_lf_node(DevImage img, const u64* __restrict__ in, u64 nq,
-                                                 u64* __restrict__ out)
-{
-  __shared__ Tables t;
-  stage_tables(img, t);
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  u64 node = in[q];
-  out[q] = (node < img.n ? lf_node(img, t.C, node) : 0);
-}
-
-// LF_fast (all = 0, comps 1..fast_chars) / LF_all (all = 1, comps 1..sigma-2); src/gcsa.cpp:742-798
-__global__ __launch_bounds__(TPB) void k_lf_all(DevImage img, const u64* __restrict__ in, u64 nq, int all,
-                                                u64* __restrict__ out)
-{
-  __shared__ Tables t;
-  stage_tables(img, t);
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  ulonglong2 r = reinterpret_cast<const ulonglong2*>(in)[q];
-  u32 sigma = u32(img.sigma);
-  ulonglong2* dst = reinterpret_cast<ulonglong2*>(out) + q * sigma;
-  for(u32 c = 0; c < sigma; c++) { dst[c] = make_ulonglong2(1, 0); }
-  if(range_empty(r.x, r.y)) { return; }
-  u32 limit = (all ? sigma - 2 : u32(img.fast_chars));
-  u64 sp0 = clampu(r.x, img.n), ep0 = clampu(r.y, img.n);
-  for(u32 c = 1; c <= limit; c++)
-  {
-    DevBV bv = bwt_of(img, c);
-    if(r.x == r.y)     // single path node: bit probe (gcsa.cpp:748-757)
-    {
-      u64 rk;
-      if(sp0 < img.n && bv_get_rank(bv, sp0, rk))
-      {
-        u64 v = bv_rank(img.edges, clampu(t.C[c] + rk, img.e));
-        dst[c] = make_ulonglong2(v, v);
-      }
-    }
-    else               // general case (gcsa.cpp:758-765)
-    {
-      u64 ra, rb;
-      bv_rank2(bv, sp0, clampu(ep0 + 1, img.n), ra, rb);
-      u64 sp = t.C[c] + ra, ep = t.C[c] + rb - 1;
-      if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
-      dst[c] = make_ulonglong2(sp, ep);
-    }
-  }
-}
-
-// ---- counting ----------------------------------------------------------------------------
-
-// SadaSparse::count (support.h:329-335)
-__device__ __forceinline__ u64 sada_sparse_count(const DevImage& img, u64 sp, u64 ep)
-{
-  u64 a, b;
-  bv_rank2(img.xfilter, sp, ep + 1, a, b);
-  if(b <= a) { return 0; }
-  return (bv_select(img.xvalues, b) + 1) - (a > 0 ? bv_select(img.xvalues, a) + 1 : 0);
-}
-
-// SadaCount::count (support.h:255-258)
-__device__ __forceinline__ u64 sada_count(const DevImage& img, u64 sp, u64 ep)
-{
-  return (bv_select(img.redundant, ep + 1) - ep) - (sp > 0 ? bv_select(img.redundant, sp) + 1 - sp : 0);
-}
-
-__device__ __forceinline__ u64 count_range(const DevImage& img, u64 sp, u64 ep)
-{
-  if(range_empty(sp, ep) || ep >= img.n) { return 0; }                  // gcsa.cpp:805
-  u64 res = sada_sparse_count(img, sp, ep) + (ep + 1 - sp);            // gcsa.cpp:806
-  if(ep > sp) { res -= sada_count(img, sp, ep - 1); }                  // gcsa.cpp:807
-  return res;
-}
-
-__global__ __launch_bounds__(TPB) void k_count(DevImage img, const u64* __restrict__ ranges, u64 nq,
-                                               u64* __restrict__ out)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
-  out[q] = count_range(img, r.x, r.y);
-}
-
-// ---- pred4: first-predecessor code + sampled flag, 4 bits per path node ------------------------
-// One thread per 64 nodes: reads the payload word of every B_c and of sampled_paths and writes
-// four u64 (16 nibbles each).  Derived data: LF(path_node) probes comps 1..sigma-1 in order and
-// falls back to comp 0 (gcsa.h:165-183); the nibble records which probe hits first.
-__global__ __launch_bounds__(TPB) void k_build_pred4(DevImage img, u64 nwords, u64* __restrict__ out)
-{
-  u64 w = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(w >= nwords) { return; }
-  u64 blk = w / PAYLOAD_WORDS, j = w - blk * PAYLOAD_WORDS;
-  u64 remaining = ~u64(0), p0 = 0, p1 = 0, p2 = 0;
-  for(u32 c = 1; c < u32(img.sigma); c++)
-  {
-    u64 bits = bwt_of(img, c).blocks[blk * BLOCK_WORDS + 1 + j] & remaining;
-    if(c & 1) { p0 |= bits; }
-    if(c & 2) { p1 |= bits; }
-    if(c & 4) { p2 |= bits; }
-    remaining &= ~bits;
-  }
-  u64 smp = (img.has_samples ? img.sampled.blocks[blk * BLOCK_WORDS + 1 + j] : 0);
-  for(u32 part = 0; part < 4; part++)
-  {
-    u64 v = 0;
-    for(u32 k = 0; k < 16; k++)
-    {
-      u32 bit = part * 16 + k;
-      u64 nib = ((p0 >> bit) & 1) | (((p1 >> bit) & 1) << 1) | (((p2 >> bit) & 1) << 2) | (((smp >> bit) & 1) << 3);
-      v |= nib << (4 * k);
-    }
-    out[w * 4 + part] = v;
-  }
-}
-
-__device__ __forceinline__ u32 pred4_get(const u64* pred4, u64 node)
-{
-  return u32(pred4[node >> 4] >> ((node & 15) * 4)) & 15;
-}
-
-// one lane per (query, path node): locateInternal (gcsa.cpp:880-896), wave-cooperative.
-// The LF(path_node) walk uses the pred4 nibble (which comp, already sampled?) and then ONE fused
-// block per step for C[c] + rank(B_c, node) and rank(edges, .), fetched like in k_find2.
-__global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* __restrict__ ranges, u64 nq,
-                                                      const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
-                                                      u64 total_nodes, u64* __restrict__ values)
-{
-  __shared__ ulonglong2 stage[TPB2 * 8];
-  const u32 lane = threadIdx.x & 63;
-  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  u64 g = u64(blockIdx.x) * TPB2 + threadIdx.x;
-  bool live = g < total_nodes;
-  u64 node = 0, dest = 0, steps = 0;
-  if(live)
-  {
-    u64 lo = 0, hi = nq - 1;            // query owning flattened node g: last q with node_off[q] <= g
-    while(lo < hi)
-    {
-      u64 mid = (lo + hi + 1) >> 1;
-      if(node_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
-    }
-    u64 sp = ranges[2 * lo];
-    node = sp + (g - node_off[lo]);
-    dest = raw_off[lo] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0);
-  }
-  bool walking = live;
-  while(__any(walking))
-  {
-    u32 idx = 0, r = 0;
-    if(walking)
-    {
-      u32 nib = pred4_get(img.pred4, node);
-      if(nib & 8) { walking = false; }                       // sampled(node), gcsa.cpp:883
-      else
-      {
-        u64 b = node / BLOCK_BITS;
-        r = u32(node - b * BLOCK_BITS);
-        idx = u32(u64(nib & 7) * img.flb_nblocks + b);
-      }
-    }
-    if(!__any(walking)) { break; }
-    fetch_blocks(img.flb, idx, walking, wave_stage, lane);
-    if(walking)
-    {
-      ulonglong2 blk[8];
-      read_block(wave_stage, lane, blk);
-      u64 edge, next;
-      eval_endpoint(blk, r, 0, edge, next);                  // LF(path_node), gcsa.h:165-183
-      node = next; steps++;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if(live)
-  {
-    u64 srank = bv_rank(img.sampled, node);
-    u64 s = (srank > 0 ? bv_select(img.samples, srank) + 1 : 0);   // firstSample, gcsa.h:202-206
-    do
-    {
-      values[dest++] = packed_get(img.stored, img.sample_width, s) + steps;   // gcsa.cpp:893
-      s++;
-    }
-    while(!bv_get(img.samples, s - 1));                      // lastSample, gcsa.h:208
-  }
-}
-
-// segments with more than one raw value (the only ones removeDuplicates has to sort)
-__global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ raw_off, u64 nq,
-                                                       unsigned long long* __restrict__ counter,
-                                                       u64* __restrict__ seg_begin, u64* __restrict__ seg_end)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  u64 b = raw_off[q], e = raw_off[q + 1];
-  if(e - b >= 2)
-  {
-    unsigned long long slot = atomicAdd(counter, 1ull);
-    seg_begin[slot] = b; seg_end[slot] = e;
-  }
-}
-
-// ---- countKMers frontier expansion (src/algorithms.cpp:364-421) -------------------------------
-// One lane per search state (a non-empty range at depth d): its children are LF_fast / LF_all of
-// the range (src/gcsa.cpp:742-798) for comps 1..limit; non-empty children are appended to `out`
-// (wave-aggregated atomic slot allocation) or, when out == nullptr, only counted.
-__global__ __launch_bounds__(TPB) void k_kmer_expand(DevImage img, const u64* __restrict__ in, u64 n_in, u32 limit,
-                                                     u64* __restrict__ out, unsigned long long* __restrict__ counter)
-{
-  __shared__ Tables t;
-  stage_tables(img, t);
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  const u32 lane = threadIdx.x & 63;
-  bool live = q < n_in;
-  ulonglong2 r = live ? reinterpret_cast<const ulonglong2*>(in)[q] : make_ulonglong2(1, 0);
-  for(u32 c = 1; c <= limit; c++)
-  {
-    u64 sp = 1, ep = 0;
-    if(live)
-    {
-      DevBV bv = bwt_of(img, c);
-      if(r.x == r.y)      // single path node: bit probe (gcsa.cpp:748-757)
-      {
-        u64 rk;
-        if(bv_get_rank(bv, r.x, rk)) { sp = ep = bv_rank(img.edges, t.C[c] + rk); }
-      }
-      else
-      {
-        u64 ra, rb;
-        bv_rank2(bv, r.x, r.y + 1, ra, rb);
-        sp = t.C[c] + ra; ep = t.C[c] + rb - 1;
-        if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
-      }
-    }
-    bool has = live && !range_empty(sp, ep);
-    u64 mask = __ballot(has);
-    if(mask != 0)
-    {
-      u32 leader = u32(__ffsll((long long)mask)) - 1;
-      unsigned long long base = 0;
-      if(lane == leader) { base = atomicAdd(counter, (unsigned long long)__popcll(mask)); }
-      base = __shfl(base, leader, 64);
-      if(has && out != nullptr)
-      {
-        u64 slot = base + __popcll(mask & ((u64(1) << lane) - 1));
-        reinterpret_cast<ulonglong2*>(out)[slot] = make_ulonglong2(sp, ep);
-      }
-    }
-  }
-}
-
-// ---- locate ------------------------------------------------------------------------------
-
-// per query: number of path nodes to walk and number of values before deduplication
-__global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* __restrict__ ranges, u64 nq,
-                                                      u64* __restrict__ node_counts, u64* __restrict__ raw_counts)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
-  u64 nodes = 0, raw = 0;
-  if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831
-  {
-    nodes = r.y + 1 - r.x;
-    raw = nodes + sada_sparse_count(img, r.x, r.y);         // sum of |values(i)| = sum of (A[i] + 1)
-  }
-  node_counts[q] = nodes; raw_counts[q] = raw;
-}
-
-// one lane per (query, path node): locateInternal (gcsa.cpp:880-896)
-__global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __restrict__ ranges, u64 nq,
-                                                     const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
-                                                     u64 total_nodes, u64* __restrict__ values)
-{
-  __shared__ Tables t;
-  stage_tables(img, t);
-  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(g >= total_nodes) { return; }
-  // query owning flattened node g: last q with node_off[q] <= g
-  u64 lo = 0, hi = nq - 1;
-  while(lo < hi)
-  {
-    u64 mid = (lo + hi + 1) >> 1;
-    if(node_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
-  }
-  u64 sp = ranges[2 * lo];
-  u64 node = sp + (g - node_off[lo]);
-  u64 dest = raw_off[lo] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0);
-
-  u64 steps = 0, srank;
-  while(!bv_get_rank(img.sampled, node, srank))             // gcsa.cpp:883-887
-  {
-    node = lf_node(img, t.C, node); steps++;
-  }
-  u64 s = (srank > 0 ? bv_select(img.samples, srank) + 1 : 0);   // firstSample, gcsa.h:202-206
-  do
-  {
-    values[dest++] = packed_get(img.stored, img.sample_width, s) + steps;   // gcsa.cpp:893
-    s++;
-  }
-  while(!bv_get(img.samples, s - 1));                        // lastSample, gcsa.h:208
-}
-
-// flag the first occurrence of every value inside its (sorted) segment
-__global__ __launch_bounds__(TPB) void k_mark_unique(const u64* __restrict__ sorted, const u64* __restrict__ raw_off,
-                                                     u64 nq, u64 total, u32* __restrict__ flags)
-{
-  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(g >= total) { return; }
-  u64 lo = 0, hi = nq - 1;
-  while(lo < hi)
-  {
-    u64 mid = (lo + hi + 1) >> 1;
-    if(raw_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
-  }
-  // segments of empty queries share their start with the next one; lo is the last of them,
-  // which is the only one that can contain g.
-  flags[g] = (g == raw_off[lo] || sorted[g] != sorted[g - 1]) ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted, const u32* __restrict__ flags,
-                                                 const u64* __restrict__ flag_scan, u64 total, u64* __restrict__ out)
-{
-  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(g >= total) { return; }
-  if(flags[g]) { out[flag_scan[g]] = sorted[g]; }
-}
-
-__global__ __launch_bounds__(TPB) void k_final_offsets(const u64* __restrict__ raw_off, const u64* __restrict__ flag_scan,
-                                                       u64 nq, u64 total, u64 total_unique, u64* __restrict__ offsets)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q > nq) { return; }
-  u64 r = (q < nq ? raw_off[q] : total);
-  offsets[q] = (r < total ? flag_scan[r] : total_unique);
-}
-
-// ---- suffix-tree operations over the LCP range-minimum tree ------------------------------
-
-struct Lcp
-{
-  const DevImage& img;
-  __device__ __forceinline__ u64 at(u64 i) const { return img.lcp[i]; }
-  __device__ __forceinline__ u64 root() const { return img.lcp_values - 1; }
-  __device__ __forceinline__ u64 parent(u64 node, u64 level) const
-  { return img.lcp_offsets[level + 1] + (node - img.lcp_offsets[level]) / img.lcp_branching; }
-  __device__ __forceinline__ u64 first_sibling(u64 node, u64 level) const
-  { return node - (node - img.lcp_offsets[level]) % img.lcp_branching; }
-  __device__ __forceinline__ u64 last_sibling(u64 first_child, u64 level) const
-  {
-    u64 a = img.lcp_offsets[level + 1], b = first_child + img.lcp_branching;
-    return (a < b ? a : b) - 1;
-  }
-  __device__ __forceinline__ u64 first_child(u64 node, u64 level) const
-  { return img.lcp_offsets[level - 1] + (node - img.lcp_offsets[level]) * img.lcp_branching; }
-  __device__ __forceinline__ u64 last_child(u64 node, u64 level) const
-  { return last_sibling(first_child(node, level), level - 1); }
-  __device__ __forceinline__ u64 level_of(u64 node) const
-  { u64 level = 0; while(img.lcp_offsets[level + 1] <= node) { level++; } return level; }
-};
-
-__device__ __forceinline__ bool sv_cmp(bool equal, u64 a, u64 b) { return equal ? (a <= b) : (a < b); }
-
-// psv / psev (src/lcp.cpp:345-382)
-__device__ void lcp_psv(const DevImage& img, u64 to, bool equal, u64& rpos, u64& rval)
-{
-  Lcp L{img};
-  rpos = rval = img.lcp_values;                     // notFound()
-  if(to == 0 || to >= img.lcp_size) { return; }
-  u64 level = 0, val = L.at(to);
-  bool found = false;
-  while(to != L.root())
-  {
-    u64 from = L.first_sibling(to, level);
-    for(u64 i = to; i > from; )
-    {
-      i--;
-      u64 v = L.at(i);
-      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; found = true; break; }
-    }
-    if(found) { break; }
-    to = L.parent(to, level); level++;
-  }
-  if(!found) { return; }
-  while(level > 0)
-  {
-    u64 from = L.first_child(rpos, level); level--;
-    for(u64 i = L.last_sibling(from, level) + 1; i > from; )
-    {
-      i--;
-      u64 v = L.at(i);
-      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; break; }
-    }
-  }
-}
-
-// nsv / nsev (src/lcp.cpp:401-438)
-__device__ void lcp_nsv(const DevImage& img, u64 from, bool equal, u64& rpos, u64& rval)
-{
-  Lcp L{img};
-  rpos = rval = img.lcp_values;
-  if(from + 1 >= img.lcp_size) { return; }
-  u64 level = 0, val = L.at(from);
-  bool found = false;
-  while(from != L.root())
-  {
-    u64 last = L.last_sibling(L.first_sibling(from, level), level);
-    for(u64 i = from + 1; i <= last; i++)
-    {
-      u64 v = L.at(i);
-      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; found = true; break; }
-    }
-    if(found) { break; }
-    from = L.parent(from, level); level++;
-  }
-  if(!found) { return; }
-  while(level > 0)
-  {
-    from = L.first_child(rpos, level); level--;
-    u64 last = L.last_sibling(from, level);
-    for(u64 i = from; i <= last; i++)
-    {
-      u64 v = L.at(i);
-      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; break; }
-    }
-  }
-}
-
-// rmq (src/lcp.cpp:448-513): leftmost minimum of LCP[sp..ep].  Same tree walk as the reference;
-// its explicit stack of right-hand tails is replaced by one accumulator that prefers the later
-// (= more leftward) candidate on ties, which yields the same leftmost minimum.
-__device__ void lcp_rmq(const DevImage& img, u64 sp, u64 ep, u64& rpos, u64& rval)
-{
-  Lcp L{img};
-  if(sp > ep || ep >= img.lcp_size) { rpos = rval = img.lcp_values; return; }
-  if(sp == ep) { rpos = sp; rval = L.at(sp); return; }
-  const u64 INF = ~u64(0);
-  u64 lpos = img.lcp_values, lval = INF, tpos = img.lcp_values, tval = INF;
-  u64 level = 0, left = sp, right = ep;
-  while(true)
-  {
-    u64 left_par = L.parent(left, level), right_par = L.parent(right, level);
-    if(left_par == right_par)
-    {
-      for(u64 i = left; i <= right; i++) { u64 v = L.at(i); if(v < lval) { lpos = i; lval = v; } }
-      break;
-    }
-    u64 left_child = L.first_child(left_par, level + 1);
-    if(left != left_child)
-    {
-      u64 last = L.last_sibling(left_child, level);
-      for(u64 i = left; i <= last; i++) { u64 v = L.at(i); if(v < lval) { lpos = i; lval = v; } }
-      left_par++;
-    }
-    u64 right_child = L.last_child(right_par, level + 1);
-    if(right != right_child)
-    {
-      u64 first = L.first_sibling(right_child, level);
-      u64 gpos = img.lcp_values, gval = INF;
-      for(u64 i = first; i <= right; i++) { u64 v = L.at(i); if(v < gval) { gpos = i; gval = v; } }
-      if(gval <= tval) { tpos = gpos; tval = gval; }      // this group lies left of earlier tails
-      right_par--;
-    }
-    if(left_par >= right_par)
-    {
-      if(left_par == right_par) { u64 v = L.at(left_par); if(v < lval) { lpos = left_par; lval = v; } }
-      break;
-    }
-    left = left_par; right = right_par; level++;
-  }
-  if(lval <= tval) { rpos = lpos; rval = lval; } else { rpos = tpos; rval = tval; }
-  level = L.level_of(rpos);
-  while(level > 0)
-  {
-    rpos = L.first_child(rpos, level); level--;
-    while(L.at(rpos) != rval) { rpos++; }
-  }
-}
-
-// nodeFor (lcp.h:163-175) + parent (src/lcp.cpp:276-301)
-__device__ void lcp_parent(const DevImage& img, u64 sp, u64 ep, gcsa2_stnode& out)
-{
-  if(sp == 0 && ep == img.lcp_size - 1) { out = gcsa2_stnode{0, img.lcp_size - 1, 0, 0, 0}; return; }
-  u64 sp_safe = clampu(sp, img.lcp_size - 1);
-  u64 left_lcp = img.lcp[sp_safe];
-  u64 right_lcp = (ep + 1 < img.lcp_size ? img.lcp[ep + 1] : 0);
-  u64 node_lcp = (left_lcp > right_lcp ? left_lcp : right_lcp);
-  u64 lpos = sp, lval = left_lcp, rpos = ep + 1, rval = right_lcp;
-  if(left_lcp == node_lcp)
-  {
-    lcp_psv(img, sp, false, lpos, lval);
-    if(lpos == img.lcp_values && lval == img.lcp_values) { lpos = 0; lval = 0; }
-  }
-  if(right_lcp == node_lcp)
-  {
-    lcp_nsv(img, ep + 1, false, rpos, rval);
-    if(rpos == img.lcp_values && rval == img.lcp_values) { rpos = img.lcp_size; rval = 0; }
-  }
-  out = gcsa2_stnode{lpos, rpos - 1, lval, rval, node_lcp};
-}
-
-__global__ __launch_bounds__(TPB) void k_parent(DevImage img, const u64* __restrict__ ranges, u64 nq,
-                                                gcsa2_stnode* __restrict__ out)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
-  gcsa2_stnode node;
-  lcp_parent(img, r.x, r.y, node);
-  out[q] = node;
-}
-
-// depth(range) (src/lcp.cpp:319-325)
-__global__ __launch_bounds__(TPB) void k_depth(DevImage img, const u64* __restrict__ ranges, u64 nq,
-                                               u64* __restrict__ out)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
-  u64 res = GCSA2_UNKNOWN;
-  if(r.y + 1 - r.x > 1)
-  {
-    u64 pos, val;
-    lcp_rmq(img, r.x + 1, r.y, pos, val);
-    if(!(pos == img.lcp_values && val == img.lcp_values)) { res = val; }
-  }
-  out[q] = res;
-}
-
-__global__ __launch_bounds__(TPB) void k_sv(DevImage img, int op, const u64* __restrict__ positions, u64 nq,
-                                            u64* __restrict__ out)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  u64 pos, val;
-  if(op < 2) { lcp_psv(img, positions[q], op & 1, pos, val); }
-  else { lcp_nsv(img, positions[q], op & 1, pos, val); }
-  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(pos, val);
-}
-
-__global__ __launch_bounds__(TPB) void k_rmq(DevImage img, const u64* __restrict__ ranges, u64 nq,
-                                             u64* __restrict__ out)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
-  u64 pos, val;
-  lcp_rmq(img, r.x, r.y, pos, val);
-  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(pos, val);
-}
-
-// sampled / sampleRange / firstSample (gcsa.h:191-206): out[3q] = sampled(node),
-// out[3q+1] = sampleRange(node).first = firstSample(node), out[3q+2] = sampleRange(node).second
-__global__ __launch_bounds__(TPB) void k_sample_range(DevImage img, const u64* __restrict__ nodes, u64 nq,
-                                                      u64* __restrict__ out)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  u64 node = clampu(nodes[q], img.n), r;
-  bool s = (node < img.n ? bv_get_rank(img.sampled, node, r) : (r = bv_rank(img.sampled, node), false));
-  u64 first = (r > 0 ? bv_select(img.samples, r) + 1 : 0);
-  u64 second = (r + 1 <= img.samples.ones ? bv_select(img.samples, r + 1) : img.sample_count);
-  out[3 * q] = s ? 1 : 0; out[3 * q + 1] = first; out[3 * q + 2] = second;
-}
-
-// sample(i), lastSample(i) (gcsa.h:208-210)
-__global__ __launch_bounds__(TPB) void k_sample(DevImage img, const u64* __restrict__ idx, u64 nq,
-                                                u64* __restrict__ values, u8* __restrict__ last)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  u64 i = idx[q];
-  bool ok = (i < img.sample_count);
-  values[q] = ok ? packed_get(img.stored, img.sample_width, i) : 0;
-  last[q] = (ok && bv_get(img.samples, i)) ? 1 : 0;
-}
-
-// LCPArray::operator[] (lcp.h:129)
-__global__ __launch_bounds__(TPB) void k_lcp_access(DevImage img, const u64* __restrict__ pos, u64 nq, u64* __restrict__ out)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  out[q] = (pos[q] < img.lcp_values ? img.lcp[pos[q]] : 0);
-}
-
-}  // namespace
+#include "kernels_common.hpp"
+#include "kernels_find.hpp"
+#include "kernels_locate.hpp"
+#include "kernels_lcp.hpp"
 
 // ==========================================================================================
 // host code
@@ -1378,9 +466,9 @@ int gcsa2_lf_device(const gcsa2_index* ix, const uint64_t* d_in, const uint8_t* 
 {
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
-  hipLaunchKernelGGL(k_lf, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(k_lf2, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
                      ix->img, d_in, d_comps, nq, d_out);
-  LAUNCH_CHECK("k_lf");
+  LAUNCH_CHECK("k_lf2");
   return GCSA2_OK;
 }
 

@@ -1,0 +1,389 @@
+// kernels_find.hpp -- find() / LF: k_find (v1), the k-mer seed table, k_find2 and k_lf2 over fused 128-byte blocks, LF(path_node), LF_fast / LF_all.
+// Part of the single translation unit gcsa2_hip.hip (device code, anonymous namespace).
+#pragma once
+
+#include "kernels_common.hpp"
+
+using namespace g2;
+
+namespace {
+
+// STATS = true additionally counts, per launch, the distinct rank blocks fetched and the LF steps
+// executed (the "algorithmic bytes" of the roofline model): stats[0] += blocks,
+// stats[1] += steps.  The timed path is the STATS = false instantiation.
+template<bool STATS>
+__global__ __launch_bounds__(TPB) void k_find(DevImage img, const u8* __restrict__ patterns,
+                                              const u64* __restrict__ offsets, u64 nq,
+                                              u64* __restrict__ out, unsigned long long* __restrict__ stats)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  u64 blocks = 0, steps = 0;
+  if(q < nq)
+  {
+    u64 begin = offsets[q], len = offsets[q + 1] - begin;
+    u64 sp = 0, ep = img.n - 1;
+    if(len > 0 && img.n > 0)                                  // gcsa.h:99
+    {
+      const u8* p = patterns + begin;
+      u64 i = len - 1;
+      u32 comp = t.c2c[p[i]];
+      sp = t.C[comp]; ep = t.C[comp + 1] - 1;                 // charRange, utils.h:414-419
+      if(STATS) { blocks += 1 + (block_of(clampu(sp, img.e)) != block_of(clampu(ep, img.e))); }
+      path_node_range(img, sp, ep);                           // gcsa.h:150-153 (no emptiness check)
+      while(!range_empty(sp, ep) && i > 0)                    // gcsa.h:103
+      {
+        i--;
+        comp = t.c2c[p[i]];
+        DevBV bv = bwt_of(img, comp);
+        u64 ra, rb;
+        if(STATS) { steps++; blocks += 1 + (block_of(sp) != block_of(ep + 1)); }
+        bv_rank2(bv, sp, ep + 1, ra, rb);                     // gcsa.h:271-272
+        sp = t.C[comp] + ra; ep = t.C[comp] + rb - 1;
+        if(range_empty(sp, ep)) { break; }                    // gcsa.h:160: edge-space integers
+        if(STATS) { blocks += 1 + (block_of(sp) != block_of(ep)); }
+        path_node_range(img, sp, ep);                         // gcsa.h:161
+      }
+    }
+    reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep);
+  }
+  if(STATS)
+  {
+    // wave reduction, one atomic per wave
+    for(int o = 32; o > 0; o >>= 1) { blocks += __shfl_down(blocks, o, 64); steps += __shfl_down(steps, o, 64); }
+    if((threadIdx.x & 63) == 0) { atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps); }
+  }
+}
+
+// ---- k-mer seed table ----------------------------------------------------------------------
+// table[t] = find() of the k-mer whose j-th character FROM THE END has comp 1 + ((t >> 2j) & 3):
+// the exact (sp, ep) the backward search returns, including edge-space empty ranges, so that
+// k_find2 can start a pattern whose last k characters are all fast characters at step k.
+// Pure memoisation of gcsa.h:96-110; results are unchanged.
+__global__ __launch_bounds__(TPB) void k_build_kmer_table(DevImage img, u32 k, u64 entries, u64* __restrict__ table)
+{
+  u64 tix = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(tix >= entries) { return; }
+  u32 comp = 1 + u32(tix & 3);                               // last character
+  u64 sp = img.crange[2 * comp], ep = img.crange[2 * comp + 1];
+  for(u32 j = 1; j < k && !range_empty(sp, ep); j++)
+  {
+    comp = 1 + u32((tix >> (2 * j)) & 3);
+    DevBV bv = bwt_of(img, comp);
+    u64 ra, rb;
+    bv_rank2(bv, sp, ep + 1, ra, rb);
+    sp = img.C[comp] + ra; ep = img.C[comp] + rb - 1;
+    if(range_empty(sp, ep)) { break; }
+    path_node_range(img, sp, ep);
+  }
+  reinterpret_cast<ulonglong2*>(table)[tix] = make_ulonglong2(sp, ep);
+}
+
+// ---- find, version 2: fused 128-byte LF blocks, wave-cooperative fetch through LDS -----------
+//
+// One lane = one pattern, 64 patterns per wave walk their LF chains in lockstep.  Per step the
+// wave fetches the 64 fused blocks its lanes need with 8 line-coalesced instructions (8 adjacent
+// lanes x 16 bytes = one 128-byte block per request), stages them in LDS (XOR-swizzled so that the
+// ds_read_b128 read-back is conflict free) and every lane then evaluates its own
+// C[c] + rank(B_c, .) and rank(edges, .) from the staged block.  A second fetch round runs only
+// for lanes whose sp and ep + 1 fall into different blocks.
+constexpr int TPB2 = 128;          // 2 waves: 16 KB of staging + tables -> 9 workgroups / CU
+
+struct Tables2
+{
+  u64 crange[2 * MAX_SIGMA];
+  u8 c2c[256];
+};
+
+struct Endpoint { u64 edge; u64 node; u32 ones; };
+
+// lane-private evaluation of one LF endpoint from a staged fused block
+//   blk = 8 x ulonglong2 (w0..w15), r = bit offset inside the block
+//   edge = C[c] + rank(B_c, i);  node = rank(edges, edge - back) with back = 0 (sp) or 1 (ep)
+__device__ __forceinline__ void eval_endpoint(const ulonglong2 (&blk)[8], u32 r, u32 back, u64& edge, u64& node)
+{
+  const u64 w[16] = { blk[0].x, blk[0].y, blk[1].x, blk[1].y, blk[2].x, blk[2].y, blk[3].x, blk[3].y,
+                      blk[4].x, blk[4].y, blk[5].x, blk[5].y, blk[6].x, blk[6].y, blk[7].x, blk[7].y };
+  u32 wq = r >> 6;
+  u64 part = (u64(1) << (r & 63)) - 1;
+  u32 ones = 0;
+#pragma unroll
+  for(u32 j = 0; j < 7; j++)
+  {
+    u64 m = (j < wq ? ~u64(0) : (j == wq ? part : u64(0)));
+    ones += __popcll(w[2 + j] & m);
+  }
+  edge = w[0] + ones;
+  u64 ncnt = w[1] & ~PREV_BIT;
+  if(back > ones) { node = ncnt - (w[1] >> 63); return; }    // rank(edges, ecnt - 1)
+  u32 k = ones - back, kq = k >> 6;
+  u64 kpart = (u64(1) << (k & 63)) - 1;
+  u32 cnt = 0;
+#pragma unroll
+  for(u32 j = 0; j < 7; j++)
+  {
+    u64 m = (j < kq ? ~u64(0) : (j == kq ? kpart : u64(0)));
+    cnt += __popcll(w[9 + j] & m);
+  }
+  node = ncnt + cnt;
+}
+
+// wave-cooperative fetch: every lane with need != 0 gets flb block `idx` staged at its slot
+__device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane)
+{
+  u32 sub = lane & 7;
+#pragma unroll
+  for(u32 j = 0; j < 8; j++)
+  {
+    u32 owner = 8 * j + (lane >> 3);
+    u32 oidx = __shfl(idx, owner, 64);
+    bool oneed = __shfl(int(need), owner, 64) != 0;
+    if(oneed)
+    {
+      ulonglong2 a = reinterpret_cast<const ulonglong2*>(flb + u64(oidx) * FLB_WORDS)[sub];
+      wave_stage[owner * 8 + (sub ^ (owner & 7))] = a;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void read_block(const ulonglong2* wave_stage, u32 lane, ulonglong2 (&blk)[8])
+{
+#pragma unroll
+  for(u32 k = 0; k < 8; k++) { blk[k] = wave_stage[lane * 8 + (k ^ (lane & 7))]; }
+}
+
+template<bool STATS>
+__global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restrict__ patterns,
+                                               const u64* __restrict__ offsets, u64 nq,
+                                               u64* __restrict__ out, unsigned long long* __restrict__ stats)
+{
+  __shared__ ulonglong2 stage[TPB2 * 8];
+  __shared__ Tables2 t;
+  if(threadIdx.x < 2 * MAX_SIGMA) { t.crange[threadIdx.x] = img.crange[threadIdx.x]; }
+  t.c2c[threadIdx.x] = img.char2comp[threadIdx.x];
+  t.c2c[threadIdx.x + TPB2] = img.char2comp[threadIdx.x + TPB2];
+  __syncthreads();
+
+  const u32 lane = threadIdx.x & 63;
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  const u64 q = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  u64 blocks = 0, steps = 0, lookups = 0;
+
+  u64 sp = 0, ep = img.n - 1, i = 0;
+  const u8* p = patterns;
+  bool done = true;
+  u64 word = 0, word_addr = ~u64(0);        // pattern bytes are consumed back to front from aligned 8-byte words
+  auto byte_at = [&](u64 pos) -> u32
+  {
+    u64 addr = reinterpret_cast<u64>(p) + pos, aligned = addr & ~u64(7);
+    if(aligned != word_addr) { word = *reinterpret_cast<const u64*>(aligned); word_addr = aligned; }
+    return u32(word >> ((addr & 7) * 8)) & 0xFF;
+  };
+  if(q < nq)
+  {
+    u64 begin = offsets[q], len = offsets[q + 1] - begin;
+    if(len > 0 && img.n > 0)                                   // gcsa.h:99
+    {
+      p = patterns + begin;
+      const u32 k = img.kmer_k;
+      bool seeded = false;
+      if(k > 0 && len >= k)
+      {
+        u64 tix = 0;
+        bool fast = true;
+        for(u32 j = 0; j < k; j++)                             // j-th character from the end
+        {
+          u32 comp = t.c2c[byte_at(len - 1 - j)];
+          fast = fast && (comp - 1 < 4);
+          tix |= u64((comp - 1) & 3) << (2 * j);
+        }
+        if(fast)
+        {
+          ulonglong2 r = reinterpret_cast<const ulonglong2*>(img.kmer_table)[tix];
+          sp = r.x; ep = r.y; i = len - k; seeded = true;
+          if(STATS) { lookups++; }
+        }
+      }
+      if(!seeded)
+      {
+        i = len - 1;
+        u32 comp = t.c2c[byte_at(i)];
+        sp = t.crange[2 * comp]; ep = t.crange[2 * comp + 1];  // charRange, gcsa.h:101-102, 150-153
+      }
+      done = range_empty(sp, ep) || i == 0;                    // gcsa.h:103
+    }
+  }
+
+  while(__any(!done))
+  {
+    u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
+    if(!done)
+    {
+      i--;
+      comp = t.c2c[byte_at(i)];
+      u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
+      r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
+      idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
+    }
+    ulonglong2 blk[8];
+    u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
+    fetch_blocks(img.flb, idx_sp, !done, wave_stage, lane);
+    if(!done)
+    {
+      read_block(wave_stage, lane, blk);
+      eval_endpoint(blk, r_sp, 0, e_sp, n_sp);                 // gcsa.h:271, then rank(edges, sp')
+      if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
+    }
+    bool need2 = !done && idx_ep != idx_sp;
+    if(STATS && !done) { steps++; blocks += 1 + (need2 ? 1 : 0); }
+    if(__any(need2))
+    {
+      __builtin_amdgcn_wave_barrier();
+      fetch_blocks(img.flb, idx_ep, need2, wave_stage, lane);
+      if(need2)
+      {
+        read_block(wave_stage, lane, blk);
+        eval_endpoint(blk, r_ep, 1, e_ep, n_ep);               // gcsa.h:272: LF(ep + 1) - 1
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if(!done)
+    {
+      u64 a = e_sp, b = e_ep - 1;                              // edge space
+      if(range_empty(a, b)) { sp = a; ep = b; done = true; }   // gcsa.h:160
+      else { sp = n_sp; ep = n_ep; done = (i == 0); }          // gcsa.h:161, 103
+    }
+  }
+  if(q < nq) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); }
+  if(STATS)
+  {
+    for(int o = 32; o > 0; o >>= 1)
+    {
+      blocks += __shfl_down(blocks, o, 64); steps += __shfl_down(steps, o, 64); lookups += __shfl_down(lookups, o, 64);
+    }
+    if(lane == 0)
+    {
+      atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps);
+      atomicAdd(stats + 2, (unsigned long long)lookups);
+    }
+  }
+}
+
+// LF(range, comp) (gcsa.h:155-162) for a batch, one step: same fused-block machinery as k_find2.
+// This is the primitive vg's MEM loop calls once per character.
+__global__ __launch_bounds__(TPB2) void k_lf2(DevImage img, const u64* __restrict__ in, const u8* __restrict__ comps,
+                                             u64 nq, u64* __restrict__ out)
+{
+  __shared__ ulonglong2 stage[TPB2 * 8];
+  const u32 lane = threadIdx.x & 63;
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  const u64 q = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  bool live = q < nq;
+  u64 sp = 0, ep = 0;
+  u32 idx_sp = 0, idx_ep = 0, r_sp = 0, r_ep = 0;
+  if(live)
+  {
+    ulonglong2 r = reinterpret_cast<const ulonglong2*>(in)[q];
+    u32 comp = comps[q];
+    if(comp >= img.sigma) { comp = u32(img.sigma - 1); }     // memory safety only
+    sp = clampu(r.x, img.n);
+    u64 e1 = clampu(r.y + 1, img.n);
+    u64 b_sp = sp / BLOCK_BITS, b_ep = e1 / BLOCK_BITS;
+    r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(e1 - b_ep * BLOCK_BITS);
+    idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
+  }
+  ulonglong2 blk[8];
+  u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
+  fetch_blocks(img.flb, idx_sp, live, wave_stage, lane);
+  if(live)
+  {
+    read_block(wave_stage, lane, blk);
+    eval_endpoint(blk, r_sp, 0, e_sp, n_sp);
+    if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
+  }
+  bool need2 = live && idx_ep != idx_sp;
+  if(__any(need2))
+  {
+    __builtin_amdgcn_wave_barrier();
+    fetch_blocks(img.flb, idx_ep, need2, wave_stage, lane);
+    if(need2)
+    {
+      read_block(wave_stage, lane, blk);
+      eval_endpoint(blk, r_ep, 1, e_ep, n_ep);
+    }
+  }
+  if(live)
+  {
+    u64 a = e_sp, b = e_ep - 1;
+    if(range_empty(a, b)) { sp = a; ep = b; } else { sp = n_sp; ep = n_ep; }     // gcsa.h:160-161
+    reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep);
+  }
+}
+
+// LF(path_node): first incoming edge, comps 1..fast_chars, then fast_chars+1..sigma-1, else 0
+__device__ __forceinline__ u64 lf_node(const DevImage& img, const u64* C, u64 node)
+{
+  u32 sigma = u32(img.sigma);
+  u32 comp = 0; u64 rank = 0; bool hit = false;
+  for(u32 c = 1; c < sigma && !hit; c++)
+  {
+    u64 r;
+    if(bv_get_rank(bwt_of(img, c), node, r)) { comp = c; rank = r; hit = true; }
+  }
+  if(!hit) { rank = bv_rank(bwt_of(img, 0), node); }
+  return bv_rank(img.edges, clampu(C[comp] + rank, img.e));
+}
+
+__global__ __launch_bounds__(TPB) void k_lf_node(DevImage img, const u64* __restrict__ in, u64 nq,
+                                                 u64* __restrict__ out)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  u64 node = in[q];
+  out[q] = (node < img.n ? lf_node(img, t.C, node) : 0);
+}
+
+// LF_fast (all = 0, comps 1..fast_chars) / LF_all (all = 1, comps 1..sigma-2); src/gcsa.cpp:742-798
+__global__ __launch_bounds__(TPB) void k_lf_all(DevImage img, const u64* __restrict__ in, u64 nq, int all,
+                                                u64* __restrict__ out)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  ulonglong2 r = reinterpret_cast<const ulonglong2*>(in)[q];
+  u32 sigma = u32(img.sigma);
+  ulonglong2* dst = reinterpret_cast<ulonglong2*>(out) + q * sigma;
+  for(u32 c = 0; c < sigma; c++) { dst[c] = make_ulonglong2(1, 0); }
+  if(range_empty(r.x, r.y)) { return; }
+  u32 limit = (all ? sigma - 2 : u32(img.fast_chars));
+  u64 sp0 = clampu(r.x, img.n), ep0 = clampu(r.y, img.n);
+  for(u32 c = 1; c <= limit; c++)
+  {
+    DevBV bv = bwt_of(img, c);
+    if(r.x == r.y)     // single path node: bit probe (gcsa.cpp:748-757)
+    {
+      u64 rk;
+      if(sp0 < img.n && bv_get_rank(bv, sp0, rk))
+      {
+        u64 v = bv_rank(img.edges, clampu(t.C[c] + rk, img.e));
+        dst[c] = make_ulonglong2(v, v);
+      }
+    }
+    else               // general case (gcsa.cpp:758-765)
+    {
+      u64 ra, rb;
+      bv_rank2(bv, sp0, clampu(ep0 + 1, img.n), ra, rb);
+      u64 sp = t.C[c] + ra, ep = t.C[c] + rb - 1;
+      if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
+      dst[c] = make_ulonglong2(sp, ep);
+    }
+  }
+}
+
+
+}  // namespace

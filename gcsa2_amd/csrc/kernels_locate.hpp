@@ -1,0 +1,298 @@
+// kernels_locate.hpp -- count(), the locate() pipeline (pred4 nibbles, walks, removeDuplicates) and the countKMers frontier expansion.
+// Part of the single translation unit gcsa2_hip.hip (device code, anonymous namespace).
+#pragma once
+
+#include "kernels_find.hpp"
+
+using namespace g2;
+
+namespace {
+
+// ---- counting ----------------------------------------------------------------------------
+
+// SadaSparse::count (support.h:329-335)
+__device__ __forceinline__ u64 sada_sparse_count(const DevImage& img, u64 sp, u64 ep)
+{
+  u64 a, b;
+  bv_rank2(img.xfilter, sp, ep + 1, a, b);
+  if(b <= a) { return 0; }
+  return (bv_select(img.xvalues, b) + 1) - (a > 0 ? bv_select(img.xvalues, a) + 1 : 0);
+}
+
+// SadaCount::count (support.h:255-258)
+__device__ __forceinline__ u64 sada_count(const DevImage& img, u64 sp, u64 ep)
+{
+  return (bv_select(img.redundant, ep + 1) - ep) - (sp > 0 ? bv_select(img.redundant, sp) + 1 - sp : 0);
+}
+
+__device__ __forceinline__ u64 count_range(const DevImage& img, u64 sp, u64 ep)
+{
+  if(range_empty(sp, ep) || ep >= img.n) { return 0; }                  // gcsa.cpp:805
+  u64 res = sada_sparse_count(img, sp, ep) + (ep + 1 - sp);            // gcsa.cpp:806
+  if(ep > sp) { res -= sada_count(img, sp, ep - 1); }                  // gcsa.cpp:807
+  return res;
+}
+
+__global__ __launch_bounds__(TPB) void k_count(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                               u64* __restrict__ out)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
+  out[q] = count_range(img, r.x, r.y);
+}
+
+// ---- pred4: first-predecessor code + sampled flag, 4 bits per path node ------------------------
+// One thread per 64 nodes: reads the payload word of every B_c and of sampled_paths and writes
+// four u64 (16 nibbles each).  Derived data: LF(path_node) probes comps 1..sigma-1 in order and
+// falls back to comp 0 (gcsa.h:165-183); the nibble records which probe hits first.
+__global__ __launch_bounds__(TPB) void k_build_pred4(DevImage img, u64 nwords, u64* __restrict__ out)
+{
+  u64 w = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(w >= nwords) { return; }
+  u64 blk = w / PAYLOAD_WORDS, j = w - blk * PAYLOAD_WORDS;
+  u64 remaining = ~u64(0), p0 = 0, p1 = 0, p2 = 0;
+  for(u32 c = 1; c < u32(img.sigma); c++)
+  {
+    u64 bits = bwt_of(img, c).blocks[blk * BLOCK_WORDS + 1 + j] & remaining;
+    if(c & 1) { p0 |= bits; }
+    if(c & 2) { p1 |= bits; }
+    if(c & 4) { p2 |= bits; }
+    remaining &= ~bits;
+  }
+  u64 smp = (img.has_samples ? img.sampled.blocks[blk * BLOCK_WORDS + 1 + j] : 0);
+  for(u32 part = 0; part < 4; part++)
+  {
+    u64 v = 0;
+    for(u32 k = 0; k < 16; k++)
+    {
+      u32 bit = part * 16 + k;
+      u64 nib = ((p0 >> bit) & 1) | (((p1 >> bit) & 1) << 1) | (((p2 >> bit) & 1) << 2) | (((smp >> bit) & 1) << 3);
+      v |= nib << (4 * k);
+    }
+    out[w * 4 + part] = v;
+  }
+}
+
+__device__ __forceinline__ u32 pred4_get(const u64* pred4, u64 node)
+{
+  return u32(pred4[node >> 4] >> ((node & 15) * 4)) & 15;
+}
+
+// one lane per (query, path node): locateInternal (gcsa.cpp:880-896), wave-cooperative.
+// The LF(path_node) walk uses the pred4 nibble (which comp, already sampled?) and then ONE fused
+// block per step for C[c] + rank(B_c, node) and rank(edges, .), fetched like in k_find2.
+__global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                                      const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
+                                                      u64 total_nodes, u64* __restrict__ values)
+{
+  __shared__ ulonglong2 stage[TPB2 * 8];
+  const u32 lane = threadIdx.x & 63;
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  u64 g = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  bool live = g < total_nodes;
+  u64 node = 0, dest = 0, steps = 0;
+  if(live)
+  {
+    u64 lo = 0, hi = nq - 1;            // query owning flattened node g: last q with node_off[q] <= g
+    while(lo < hi)
+    {
+      u64 mid = (lo + hi + 1) >> 1;
+      if(node_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
+    }
+    u64 sp = ranges[2 * lo];
+    node = sp + (g - node_off[lo]);
+    dest = raw_off[lo] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0);
+  }
+  bool walking = live;
+  while(__any(walking))
+  {
+    u32 idx = 0, r = 0;
+    if(walking)
+    {
+      u32 nib = pred4_get(img.pred4, node);
+      if(nib & 8) { walking = false; }                       // sampled(node), gcsa.cpp:883
+      else
+      {
+        u64 b = node / BLOCK_BITS;
+        r = u32(node - b * BLOCK_BITS);
+        idx = u32(u64(nib & 7) * img.flb_nblocks + b);
+      }
+    }
+    if(!__any(walking)) { break; }
+    fetch_blocks(img.flb, idx, walking, wave_stage, lane);
+    if(walking)
+    {
+      ulonglong2 blk[8];
+      read_block(wave_stage, lane, blk);
+      u64 edge, next;
+      eval_endpoint(blk, r, 0, edge, next);                  // LF(path_node), gcsa.h:165-183
+      node = next; steps++;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if(live)
+  {
+    u64 srank = bv_rank(img.sampled, node);
+    u64 s = (srank > 0 ? bv_select(img.samples, srank) + 1 : 0);   // firstSample, gcsa.h:202-206
+    do
+    {
+      values[dest++] = packed_get(img.stored, img.sample_width, s) + steps;   // gcsa.cpp:893
+      s++;
+    }
+    while(!bv_get(img.samples, s - 1));                      // lastSample, gcsa.h:208
+  }
+}
+
+// segments with more than one raw value (the only ones removeDuplicates has to sort)
+__global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ raw_off, u64 nq,
+                                                       unsigned long long* __restrict__ counter,
+                                                       u64* __restrict__ seg_begin, u64* __restrict__ seg_end)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  u64 b = raw_off[q], e = raw_off[q + 1];
+  if(e - b >= 2)
+  {
+    unsigned long long slot = atomicAdd(counter, 1ull);
+    seg_begin[slot] = b; seg_end[slot] = e;
+  }
+}
+
+// ---- countKMers frontier expansion (src/algorithms.cpp:364-421) -------------------------------
+// One lane per search state (a non-empty range at depth d): its children are LF_fast / LF_all of
+// the range (src/gcsa.cpp:742-798) for comps 1..limit; non-empty children are appended to `out`
+// (wave-aggregated atomic slot allocation) or, when out == nullptr, only counted.
+__global__ __launch_bounds__(TPB) void k_kmer_expand(DevImage img, const u64* __restrict__ in, u64 n_in, u32 limit,
+                                                     u64* __restrict__ out, unsigned long long* __restrict__ counter)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  const u32 lane = threadIdx.x & 63;
+  bool live = q < n_in;
+  ulonglong2 r = live ? reinterpret_cast<const ulonglong2*>(in)[q] : make_ulonglong2(1, 0);
+  for(u32 c = 1; c <= limit; c++)
+  {
+    u64 sp = 1, ep = 0;
+    if(live)
+    {
+      DevBV bv = bwt_of(img, c);
+      if(r.x == r.y)      // single path node: bit probe (gcsa.cpp:748-757)
+      {
+        u64 rk;
+        if(bv_get_rank(bv, r.x, rk)) { sp = ep = bv_rank(img.edges, t.C[c] + rk); }
+      }
+      else
+      {
+        u64 ra, rb;
+        bv_rank2(bv, r.x, r.y + 1, ra, rb);
+        sp = t.C[c] + ra; ep = t.C[c] + rb - 1;
+        if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
+      }
+    }
+    bool has = live && !range_empty(sp, ep);
+    u64 mask = __ballot(has);
+    if(mask != 0)
+    {
+      u32 leader = u32(__ffsll((long long)mask)) - 1;
+      unsigned long long base = 0;
+      if(lane == leader) { base = atomicAdd(counter, (unsigned long long)__popcll(mask)); }
+      base = __shfl(base, leader, 64);
+      if(has && out != nullptr)
+      {
+        u64 slot = base + __popcll(mask & ((u64(1) << lane) - 1));
+        reinterpret_cast<ulonglong2*>(out)[slot] = make_ulonglong2(sp, ep);
+      }
+    }
+  }
+}
+
+// ---- locate ------------------------------------------------------------------------------
+
+// per query: number of path nodes to walk and number of values before deduplication
+__global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                                      u64* __restrict__ node_counts, u64* __restrict__ raw_counts)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
+  u64 nodes = 0, raw = 0;
+  if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831
+  {
+    nodes = r.y + 1 - r.x;
+    raw = nodes + sada_sparse_count(img, r.x, r.y);         // sum of |values(i)| = sum of (A[i] + 1)
+  }
+  node_counts[q] = nodes; raw_counts[q] = raw;
+}
+
+// one lane per (query, path node): locateInternal (gcsa.cpp:880-896)
+__global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                                     const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
+                                                     u64 total_nodes, u64* __restrict__ values)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(g >= total_nodes) { return; }
+  // query owning flattened node g: last q with node_off[q] <= g
+  u64 lo = 0, hi = nq - 1;
+  while(lo < hi)
+  {
+    u64 mid = (lo + hi + 1) >> 1;
+    if(node_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
+  }
+  u64 sp = ranges[2 * lo];
+  u64 node = sp + (g - node_off[lo]);
+  u64 dest = raw_off[lo] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0);
+
+  u64 steps = 0, srank;
+  while(!bv_get_rank(img.sampled, node, srank))             // gcsa.cpp:883-887
+  {
+    node = lf_node(img, t.C, node); steps++;
+  }
+  u64 s = (srank > 0 ? bv_select(img.samples, srank) + 1 : 0);   // firstSample, gcsa.h:202-206
+  do
+  {
+    values[dest++] = packed_get(img.stored, img.sample_width, s) + steps;   // gcsa.cpp:893
+    s++;
+  }
+  while(!bv_get(img.samples, s - 1));                        // lastSample, gcsa.h:208
+}
+
+// flag the first occurrence of every value inside its (sorted) segment
+__global__ __launch_bounds__(TPB) void k_mark_unique(const u64* __restrict__ sorted, const u64* __restrict__ raw_off,
+                                                     u64 nq, u64 total, u32* __restrict__ flags)
+{
+  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(g >= total) { return; }
+  u64 lo = 0, hi = nq - 1;
+  while(lo < hi)
+  {
+    u64 mid = (lo + hi + 1) >> 1;
+    if(raw_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
+  }
+  // segments of empty queries share their start with the next one; lo is the last of them,
+  // which is the only one that can contain g.
+  flags[g] = (g == raw_off[lo] || sorted[g] != sorted[g - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted, const u32* __restrict__ flags,
+                                                 const u64* __restrict__ flag_scan, u64 total, u64* __restrict__ out)
+{
+  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(g >= total) { return; }
+  if(flags[g]) { out[flag_scan[g]] = sorted[g]; }
+}
+
+__global__ __launch_bounds__(TPB) void k_final_offsets(const u64* __restrict__ raw_off, const u64* __restrict__ flag_scan,
+                                                       u64 nq, u64 total, u64 total_unique, u64* __restrict__ offsets)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q > nq) { return; }
+  u64 r = (q < nq ? raw_off[q] : total);
+  offsets[q] = (r < total ? flag_scan[r] : total_unique);
+}
+
+
+}  // namespace
