@@ -1042,15 +1042,37 @@ int kmer_run(const gcsa2_index* ix, u64* d_frontier, u64 n, u64 depth, u64 k, u3
       return GCSA2_OK;
     }
     u64 produced = 0;
-    int rc = kmer_level(ix, d_frontier, n, limit, nullptr, d_counter, produced);     // count pass
-    if(rc != GCSA2_OK) { return rc; }
-    if(depth + 1 == k) { total += produced; return GCSA2_OK; }
-    if(produced == 0) { return GCSA2_OK; }
+    int rc = GCSA2_OK;
+    if(depth + 1 == k)      // last level: the children only have to be counted
+    {
+      rc = kmer_level(ix, d_frontier, n, limit, nullptr, d_counter, produced);
+      if(rc != GCSA2_OK) { return rc; }
+      total += produced;
+      return GCSA2_OK;
+    }
+    // one pass into a buffer sized for the worst case (every state has `limit` children) while that
+    // stays below 2 GB; otherwise count first, then fill an exactly sized buffer
     u64* next = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&next), produced * 2 * sizeof(u64)));
-    u64 again = 0;
-    rc = kmer_level(ix, d_frontier, n, limit, next, d_counter, again);               // fill pass
-    if(rc != GCSA2_OK || again != produced) { (void)hipFree(next); return rc != GCSA2_OK ? rc : fail(GCSA2_ERR_HIP, "k-mer frontier changed between passes"); }
+    const u64 worst = n * limit;
+    if(worst <= (u64(1) << 27))
+    {
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&next), worst * 2 * sizeof(u64)));
+      rc = kmer_level(ix, d_frontier, n, limit, next, d_counter, produced);
+      if(rc != GCSA2_OK) { (void)hipFree(next); return rc; }
+    }
+    else
+    {
+      rc = kmer_level(ix, d_frontier, n, limit, nullptr, d_counter, produced);     // count pass
+      if(rc != GCSA2_OK) { return rc; }
+      if(produced > 0)
+      {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&next), produced * 2 * sizeof(u64)));
+        u64 again = 0;
+        rc = kmer_level(ix, d_frontier, n, limit, next, d_counter, again);         // fill pass
+        if(rc != GCSA2_OK || again != produced) { (void)hipFree(next); return rc != GCSA2_OK ? rc : fail(GCSA2_ERR_HIP, "k-mer frontier changed between passes"); }
+      }
+    }
+    if(produced == 0) { if(next) { (void)hipFree(next); } return GCSA2_OK; }
     (void)hipFree(d_frontier);
     d_frontier = next; n = produced; depth++;
   }

@@ -330,6 +330,24 @@ private:
   gcsa2_index* handle;
 };
 
+// algorithms.h:59-84 -- k-mer counting over the index.
+struct KMerSearchParameters
+{
+  size_type seed_length;  // kept for source compatibility; the device version needs no seeds
+  bool include_Ns;        // also count k-mers containing Ns (comps fast_chars + 1 .. sigma - 2)
+  bool force;             // allow k > order()
+  std::string output;     // unused (compareKMers is not provided)
+  constexpr static size_type SEED_LENGTH = 5;
+  KMerSearchParameters() : seed_length(SEED_LENGTH), include_Ns(false), force(false), output() {}
+};
+
+inline size_type countKMers(const GCSA& index, size_type k, const KMerSearchParameters& parameters = KMerSearchParameters())
+{
+  size_type result = 0;
+  check(gcsa2_count_kmers(index.handle, k, parameters.include_Ns ? 1 : 0, parameters.force ? 1 : 0, &result), "countKMers()");
+  return result;
+}
+
 } // namespace gcsa
 
 #endif // GCSA2_HIP_GCSA_HPP

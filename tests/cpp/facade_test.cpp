@@ -57,6 +57,8 @@ int main(int argc, char** argv)
             << index.sampleCount() << " " << index.sampleBits() << " " << index.sampledPositions() << " "
             << lcp.size() << " " << lcp.values() << " " << lcp.levels() << " " << lcp.branching() << "\n";
 
+  for(gcsa::size_type k = 0; k <= 6; k++) { std::cout << "kmers " << k << " " << gcsa::countKMers(index, k) << "\n"; }
+
   std::ifstream pin(argv[2]);
   std::string pattern;
   std::vector<std::string> patterns;

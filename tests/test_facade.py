@@ -66,6 +66,8 @@ def test_facade_matches_oracle(tmp_path):
     it = iter(lines)
     head = next(it).split()
     assert [int(x) for x in head[1:6]] == [ix.n, ix.e, ix.order, ix.sample_count, ix.sample_width]
+    for k in range(7):
+        assert next(it) == f"kmers {k} {cpu.count_kmers(k)}"
     ranges = []
     for p in pats:
         want = cpu.find(p)
