@@ -34,7 +34,7 @@ EXPORTS = [
     "gcsa2_lcp_size", "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching",
     "gcsa2_lcp_access_batch",
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
-    "gcsa2_group_find_batch", "gcsa2_count_kmers",
+    "gcsa2_group_find_batch", "gcsa2_count_kmers", "gcsa2_match_stats_batch", "gcsa2_match_stats_device",
 ]
 
 
@@ -101,6 +101,8 @@ def load_library():
     L.gcsa2_alphabet.restype = None
     L.gcsa2_lcp_access_batch.argtypes = [vp, u64p, u64, u64p]
     L.gcsa2_count_kmers.argtypes = [vp, u64, i32, i32, u64p]
+    L.gcsa2_match_stats_batch.argtypes = [vp, u8p, u64p, u64, vp, u64p, u64p]
+    L.gcsa2_match_stats_device.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
     L.gcsa2_group_destroy.argtypes = [vp]
     L.gcsa2_group_destroy.restype = None
@@ -335,6 +337,22 @@ class GCSA:
         cnt = C.c_uint64()
         _check(self._L.gcsa2_locate_max(self._h, rng[0], rng[1], max_positions, _p64(values), cap, C.byref(cnt)))
         return values[: cnt.value]
+
+    def match_stats_batch(self, patterns, offsets):
+        """Matching statistics by fused LF + parent (needs the LCP array):
+        (ms uint16[total bytes], ranges (nq, 2), parent() calls per pattern)."""
+        patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nq = offsets.shape[0] - 1
+        ms = np.zeros(max(int(offsets[nq]), 1), dtype=np.uint16)
+        ranges = np.zeros((nq, 2), dtype=np.uint64)
+        fallbacks = np.zeros(nq, dtype=np.uint64)
+        _check(self._L.gcsa2_match_stats_batch(self._h, _p8(patterns), _p64(offsets), nq, ms.ctypes.data,
+                                               _p64(ranges), _p64(fallbacks)))
+        return ms[: int(offsets[nq])], ranges, fallbacks
+
+    def match_stats_device(self, d_patterns, d_offsets, nq, d_ms, d_ranges, d_fallbacks=0, stream=0):
+        _check(self._L.gcsa2_match_stats_device(self._h, d_patterns, d_offsets, nq, d_ms, d_ranges, d_fallbacks, stream))
 
     def count_kmers(self, k, include_Ns=False, force=False):
         """`countKMers` (reference src/algorithms.cpp:387-421)."""

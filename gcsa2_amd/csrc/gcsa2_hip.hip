@@ -1105,3 +1105,37 @@ extern "C" int gcsa2_count_kmers(const gcsa2_index* ix, uint64_t k, int include_
   *result = total;
   return GCSA2_OK;
 }
+
+// Matching statistics (LF + parent fused); see k_match_stats.
+extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq,
+                                        uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
+{
+  CHECK_INDEX(ix);
+  if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
+  if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_match_stats, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+                     ix->img, d_patterns, d_offsets, nq, reinterpret_cast<unsigned short*>(d_ms), d_ranges, d_fallbacks);
+  LAUNCH_CHECK("k_match_stats");
+  return GCSA2_OK;
+}
+
+extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq,
+                                       uint16_t* ms, uint64_t* ranges, uint64_t* fallbacks)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  if(offsets == nullptr || ms == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  DeviceGuard guard(ix->device);
+  u64 total = offsets[nq];
+  DBuf<u8> d_pat; DBuf<u64> d_off, d_rng, d_fb; DBuf<uint16_t> d_ms;
+  HIP_TRY(d_pat.alloc(total + 8)); HIP_TRY(d_off.alloc(nq + 1)); HIP_TRY(d_rng.alloc(2 * nq)); HIP_TRY(d_fb.alloc(nq));
+  HIP_TRY(d_ms.alloc(total + 1));
+  if(total > 0) { HIP_TRY(hipMemcpy(d_pat.p, patterns, total, hipMemcpyHostToDevice)); }
+  HIP_TRY(hipMemcpy(d_off.p, offsets, (nq + 1) * sizeof(u64), hipMemcpyHostToDevice));
+  int rc = gcsa2_match_stats_device(ix, d_pat.p, d_off.p, nq, d_ms.p, d_rng.p, d_fb.p, nullptr);
+  if(rc != GCSA2_OK) { return rc; }
+  if(total > 0) { HIP_TRY(hipMemcpy(ms, d_ms.p, total * sizeof(uint16_t), hipMemcpyDeviceToHost)); }
+  HIP_TRY(hipMemcpy(ranges, d_rng.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
+  if(fallbacks != nullptr) { HIP_TRY(hipMemcpy(fallbacks, d_fb.p, nq * sizeof(u64), hipMemcpyDeviceToHost)); }
+  return GCSA2_OK;
+}

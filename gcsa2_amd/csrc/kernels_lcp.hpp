@@ -257,4 +257,47 @@ __global__ __launch_bounds__(TPB) void k_lcp_access(DevImage img, const u64* __r
 }
 
 
+// ---- matching statistics: LF + parent fused (the interplay vg's MEM finder drives) -------------
+// One lane per pattern, right to left: try LF(range, comp) (gcsa.h:155-162); while the result is
+// empty, replace the range by its parent (lcp.cpp:276-301) and retry; at the root the character is
+// skipped.  ms[offset + i] = length of the longest match starting at i (capped at 65535), the final
+// range is the one of position 0.  Paper: paper.tex:344 (after Ohlebusch et al. 2010).
+__global__ __launch_bounds__(TPB) void k_match_stats(DevImage img, const u8* __restrict__ patterns,
+                                                     const u64* __restrict__ offsets, u64 nq,
+                                                     unsigned short* __restrict__ ms, u64* __restrict__ ranges,
+                                                     u64* __restrict__ fallbacks)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  u64 begin = offsets[q], len = offsets[q + 1] - begin;
+  const u8* p = patterns + begin;
+  u64 sp = 0, ep = img.n - 1, depth = 0, calls = 0;
+  for(u64 i = len; i-- > 0; )
+  {
+    u32 comp = t.c2c[p[i]];
+    DevBV bv = bwt_of(img, comp);
+    while(true)
+    {
+      u64 ra, rb;
+      bv_rank2(bv, sp, ep + 1, ra, rb);
+      u64 a = t.C[comp] + ra, b = t.C[comp] + rb - 1;
+      if(!range_empty(a, b))
+      {
+        path_node_range(img, a, b);
+        sp = a; ep = b; depth++;
+        break;
+      }
+      if(sp == 0 && ep == img.n - 1) { depth = 0; break; }     // at the root: no such character
+      gcsa2_stnode node;
+      lcp_parent(img, sp, ep, node); calls++;
+      sp = node.sp; ep = node.ep; depth = node.node_lcp;
+    }
+    ms[begin + i] = (unsigned short)(depth > 65535 ? 65535 : depth);
+  }
+  reinterpret_cast<ulonglong2*>(ranges)[q] = make_ulonglong2(sp, ep);
+  if(fallbacks != nullptr) { fallbacks[q] = calls; }
+}
+
 }  // namespace

@@ -243,6 +243,20 @@ int gcsa2_lcp_access_batch(const gcsa2_index* index, const uint64_t* positions, 
  * force != 0, k == 0 yields 1, as in the reference. */
 int gcsa2_count_kmers(const gcsa2_index* index, uint64_t k, int include_ns, int force, uint64_t* result);
 
+/* ---- matching statistics: the LF + parent interplay of vg's MEM finder, fused ---------------
+ * (paper/paper.tex:344 "maximal exact matches by using LF-mapping and parent
+ * queries").  Composition of GCSA::LF(range, comp) (gcsa.h:155-162) and LCPArray::parent(range)
+ * (src/lcp.cpp:276-301), scanning each pattern right to left: on an empty LF result the range is
+ * replaced by its parent and the character retried; at the root the character is skipped.
+ * ms[offsets[q] + i] = length of the longest match starting at byte i of pattern q that the
+ * index reports (capped at 65535; exact for lengths <= order()), ranges[2q..] = range of that
+ * match for i = 0, fallbacks[q] = number of parent() calls (may be NULL).  Needs the LCP array. */
+int gcsa2_match_stats_batch(const gcsa2_index* index, const uint8_t* patterns, const uint64_t* offsets,
+                            uint64_t n_queries, uint16_t* ms, uint64_t* ranges, uint64_t* fallbacks);
+int gcsa2_match_stats_device(const gcsa2_index* index, const uint8_t* d_patterns, const uint64_t* d_offsets,
+                             uint64_t n_queries, uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks,
+                             void* stream);
+
 /* ---- single-process multi-GPU -------------------------------------------------------------
  * A group holds one replica of the index per listed device (a device may be listed more than
  * once).  group_find_batch splits the batch into contiguous shards (sizes differ by at most one,

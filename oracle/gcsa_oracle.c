@@ -989,3 +989,46 @@ uint64_t oracle_count_kmers(const oracle_index* ix, uint64_t k, int include_ns, 
   free(seeds);
   return result;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Matching statistics = the LF + parent interplay vg's MEM finder drives (paper/paper.tex:344  */
+/* "we can search for maximal exact matches by using LF-mapping and parent queries", after      */
+/* Ohlebusch et al. 2010; the same interplay is what verifyIndex checks, algorithms.cpp:146-167).*/
+/* Composition of the restated reference primitives only: GCSA::LF(range, comp) (gcsa.h:155-162) */
+/* and LCPArray::parent(range) (lcp.cpp:276-301).  Scanning the pattern right to left, ms[i] is  */
+/* the length of the longest match starting at i that the index reports, (sp, ep) its range for  */
+/* i = 0; *fallbacks counts parent() calls.                                                       */
+void oracle_match_stats(const oracle_index* ix, const uint8_t* pattern, u64 len, uint16_t* ms,
+                        u64* sp_out, u64* ep_out, u64* fallbacks)
+{
+  u64 sp = 0, ep = ix->n - 1, depth = 0, calls = 0;
+  for(u64 i = len; i-- > 0; )
+  {
+    uint8_t comp = ix->char2comp[pattern[i]];
+    while(1)
+    {
+      u64 a = sp, b = ep;
+      oracle_lf_range(ix, &a, &b, comp);
+      if(!range_empty(a, b)) { sp = a; ep = b; depth++; break; }
+      if(sp == 0 && ep == ix->n - 1) { depth = 0; break; }          /* at the root: no such character */
+      gcsa2_stnode node;
+      oracle_parent(ix, sp, ep, &node); calls++;
+      sp = node.sp; ep = node.ep; depth = node.node_lcp;
+    }
+    ms[i] = (uint16_t)(depth > 65535 ? 65535 : depth);
+  }
+  *sp_out = sp; *ep_out = ep; *fallbacks = calls;
+}
+
+double oracle_match_stats_batch(const oracle_index* ix, const uint8_t* patterns, const u64* offsets, u64 nq,
+                                uint16_t* ms, u64* ranges, u64* fallbacks, int threads)
+{
+  double start = omp_get_wtime();
+  #pragma omp parallel for schedule(dynamic, 64) num_threads(threads > 0 ? threads : 1)
+  for(u64 q = 0; q < nq; q++)
+  {
+    oracle_match_stats(ix, patterns + offsets[q], offsets[q + 1] - offsets[q], ms + offsets[q],
+                       ranges + 2 * q, ranges + 2 * q + 1, fallbacks + q);
+  }
+  return omp_get_wtime() - start;
+}

@@ -94,6 +94,12 @@ void oracle_find_traffic(const oracle_index* ix, const uint8_t* patterns, const 
 /* countKMers (src/algorithms.cpp:387-421); seed_length = KMerSearchParameters::SEED_LENGTH = 5. */
 uint64_t oracle_count_kmers(const oracle_index* ix, uint64_t k, int include_ns, int force, uint64_t seed_length, int threads);
 
+/* Matching statistics by LF + parent (paper.tex:344): ms has one uint16 per pattern byte. */
+void oracle_match_stats(const oracle_index* ix, const uint8_t* pattern, uint64_t len, uint16_t* ms,
+                        uint64_t* sp, uint64_t* ep, uint64_t* fallbacks);
+double oracle_match_stats_batch(const oracle_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq,
+                                uint16_t* ms, uint64_t* ranges, uint64_t* fallbacks, int threads);
+
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -76,6 +76,8 @@ def lib():
         L.oracle_find_traffic.argtypes = [vp, u8p, u64p, u64, u64, u64p, u64p]
         L.oracle_count_kmers.restype = u64
         L.oracle_count_kmers.argtypes = [vp, u64, i32, i32, u64, i32]
+        L.oracle_match_stats_batch.restype = dbl
+        L.oracle_match_stats_batch.argtypes = [vp, u8p, u64p, u64, vp, u64p, u64p, i32]
         L.oracle_max_threads.restype = i32
         _lib = L
     return _lib
@@ -258,6 +260,16 @@ class OracleIndex:
     def count_kmers(self, k, include_Ns=False, force=False, threads=1):
         """`countKMers` (reference src/algorithms.cpp:387-421)."""
         return int(lib().oracle_count_kmers(self._h, k, int(include_Ns), int(force), 5, threads))
+
+    def match_stats_batch(self, patterns, offsets, threads=1):
+        """Matching statistics by LF + parent: (ms uint16[total bytes], ranges (nq, 2), fallbacks)."""
+        nq = offsets.shape[0] - 1
+        ms = np.zeros(max(int(offsets[nq]), 1), dtype=np.uint16)
+        ranges = np.zeros((nq, 2), dtype=np.uint64)
+        fallbacks = np.zeros(nq, dtype=np.uint64)
+        self.last_seconds = lib().oracle_match_stats_batch(self._h, _p8(patterns), _p64(offsets), nq, ms.ctypes.data,
+                                                           _p64(ranges), _p64(fallbacks), threads)
+        return ms[: int(offsets[nq])], ranges, fallbacks
 
     def find_traffic(self, patterns, offsets, block_bits):
         blocks, steps = C.c_uint64(), C.c_uint64()

@@ -193,3 +193,15 @@ def test_count_kmers(case):
         for ns in (False, True):
             assert gpu.count_kmers(k, include_Ns=ns) == cpu.count_kmers(k, include_Ns=ns, threads=2), (name, k, ns)
     assert gpu.count_kmers(K + 3, force=True) == cpu.count_kmers(K + 3, force=True)
+
+
+def test_match_stats(case):
+    """Fused LF + parent (matching statistics, the MEM-finder interplay) vs the oracle's composition
+    of the restated reference primitives."""
+    name, g, K, ix, gpu, lcp, cpu = case
+    pats = [p for p in random_patterns(g, 3 * K, 0x92, 200)] + [b"", b"N", b"ACGTNACGT", b"$", b"#A"]
+    data, off = concat_patterns(pats)
+    gm, gr, gf = gpu.match_stats_batch(data, off)
+    cm, cr, cf = cpu.match_stats_batch(data, off, threads=2)
+    assert np.array_equal(gm, cm), name
+    assert np.array_equal(gr, cr) and np.array_equal(gf, cf), name

@@ -272,3 +272,19 @@ def test_count_kmers_vs_input_graph(case):
         assert o.count_kmers(k) == want, (name, k)
         assert o.count_kmers(k, threads=3) == want
     assert o.count_kmers(K + 1) == 0
+
+
+def test_match_stats_vs_input_graph(case):
+    """LF + parent interplay (paper.tex:344): ms[i] = longest prefix of P[i:] that labels a path of
+    the input graph, for lengths up to the order of the index."""
+    name, g, K, ix, o, nv, gb = case
+    pats = [p for p in random_patterns(g, 2 * K, 0x91, 40) if b"$" not in p]
+    data, off = concat_patterns(pats)
+    ms, rng, fb = o.match_stats_batch(data, off, threads=2)
+    for q, p in enumerate(pats):
+        comps = [int(ix.char2comp[b]) for b in p]
+        for i in range(len(p)):
+            L = 0
+            while i + L < len(p) and L < K and gb.starts(comps[i:i + L + 1]):
+                L += 1
+            assert min(int(ms[int(off[q]) + i]), K) == L, (name, p, i)
