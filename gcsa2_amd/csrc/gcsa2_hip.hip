@@ -513,6 +513,7 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
   {
     return fail(GCSA2_ERR_MISSING_COMPONENT, "locate needs samples and counters (extra_pointers sizes the output)");
   }
+  if(nq >= (u64(1) << 31) - 1) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate batch of >= 2^31 queries; split the batch"); }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard guard(ix->device);
   gcsa2_locate_job* job = new(std::nothrow) gcsa2_locate_job();
@@ -879,6 +880,7 @@ int gcsa2_locate_max(const gcsa2_index* ix, uint64_t sp, uint64_t ep, uint64_t m
   CHECK_INDEX(ix);
   if(count_out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null count pointer"); }
   *count_out = 0;
+  try {   // no C++ exception may cross the C boundary
   uint64_t range[2] = {sp, ep}, total = 0;
   int rc = gcsa2_count_batch(ix, range, 1, &total);
   if(rc != GCSA2_OK) { return rc; }
@@ -926,6 +928,7 @@ int gcsa2_locate_max(const gcsa2_index* ix, uint64_t sp, uint64_t ep, uint64_t m
   std::memcpy(values, results.data(), results.size() * sizeof(u64));
   *count_out = results.size();
   return GCSA2_OK;
+  } catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_locate_max: ") + e.what()); }
 }
 
 // ---- single-process multi-GPU: replicated index, contiguous query shards ---------------------
@@ -980,6 +983,7 @@ int gcsa2_group_find_batch(const gcsa2_group* g, const uint8_t* patterns, const 
   if(g == nullptr || g->replicas.empty()) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null or empty group"); }
   if(nq == 0) { return GCSA2_OK; }
   if(offsets == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  try {   // no C++ exception may cross the C boundary
   const u64 G = g->replicas.size(), base = nq / G, rem = nq % G;
   std::vector<int> status(G, GCSA2_OK);
   std::vector<std::string> messages(G);
@@ -992,15 +996,20 @@ int gcsa2_group_find_batch(const gcsa2_group* g, const uint8_t* patterns, const 
     if(count == 0) { continue; }
     workers.emplace_back([&, r, b, count]()
     {
-      std::vector<u64> local(count + 1);
-      for(u64 i = 0; i <= count; i++) { local[i] = offsets[b + i] - offsets[b]; }
-      status[r] = gcsa2_find_batch(g->replicas[r], patterns + offsets[b], local.data(), count, ranges + 2 * b);
-      if(status[r] != GCSA2_OK) { messages[r] = g_error; }     // g_error is thread-local
+      try
+      {
+        std::vector<u64> local(count + 1);
+        for(u64 i = 0; i <= count; i++) { local[i] = offsets[b + i] - offsets[b]; }
+        status[r] = gcsa2_find_batch(g->replicas[r], patterns + offsets[b], local.data(), count, ranges + 2 * b);
+        if(status[r] != GCSA2_OK) { messages[r] = g_error; }     // g_error is thread-local
+      }
+      catch(const std::exception& e) { status[r] = GCSA2_ERR_OUT_OF_MEMORY; messages[r] = e.what(); }
     });
   }
   for(std::thread& t : workers) { t.join(); }
   for(u64 r = 0; r < G; r++) { if(status[r] != GCSA2_OK) { return fail(status[r], "shard " + std::to_string(r) + ": " + messages[r]); } }
   return GCSA2_OK;
+  } catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_group_find_batch: ") + e.what()); }
 }
 
 }  // extern "C"
