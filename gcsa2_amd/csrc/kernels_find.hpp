@@ -136,14 +136,13 @@ __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 id
 #pragma unroll
   for(u32 j = 0; j < 8; j++)
   {
+    // Branch-free on purpose: a load inside `if(need)` makes hipcc wait for it (s_waitcnt
+    // vmcnt(0)) before the next one is issued, i.e. 8 serialized round trips per step.  Lanes
+    // whose owner needs nothing fetch block 0 (one cached line) into a slot nobody reads.
     u32 owner = 8 * j + (lane >> 3);
-    u32 oidx = __shfl(idx, owner, 64);
-    bool oneed = __shfl(int(need), owner, 64) != 0;
-    if(oneed)
-    {
-      ulonglong2 a = reinterpret_cast<const ulonglong2*>(flb + u64(oidx) * FLB_WORDS)[sub];
-      wave_stage[owner * 8 + (sub ^ (owner & 7))] = a;
-    }
+    u32 oidx = __shfl(need ? idx : 0u, owner, 64);
+    ulonglong2 a = reinterpret_cast<const ulonglong2*>(flb + u64(oidx) * FLB_WORDS)[sub];
+    wave_stage[owner * 8 + (sub ^ (owner & 7))] = a;
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -227,8 +226,10 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
       idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
     }
-    ulonglong2 blk[8];
     u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
+    const bool need2 = !done && idx_ep != idx_sp;
+    if(STATS && !done) { steps++; blocks += 1 + (need2 ? 1 : 0); }
+    ulonglong2 blk[8];
     fetch_blocks(img.flb, idx_sp, !done, wave_stage, lane);
     if(!done)
     {
@@ -236,8 +237,6 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       eval_endpoint(blk, r_sp, 0, e_sp, n_sp);                 // gcsa.h:271, then rank(edges, sp')
       if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
     }
-    bool need2 = !done && idx_ep != idx_sp;
-    if(STATS && !done) { steps++; blocks += 1 + (need2 ? 1 : 0); }
     if(__any(need2))
     {
       __builtin_amdgcn_wave_barrier();
