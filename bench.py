@@ -184,7 +184,7 @@ def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup):
 
 def pmc_traffic(args, key, nq, m):
     """Memory-side read bytes of one launch from the committed rocprofv3 --pmc pass of this exact
-    workload (profiles/traffic.json, derivation in profiles/r01_v3_pmc.md).  PMC counters cannot
+    workload (profiles/traffic.json, derivation in profiles/r01_v4_pmc.md).  PMC counters cannot
     be read from inside the timed process, so this is looked up, never estimated: any mismatch in
     workload, batch shape or kernel generation yields None."""
     try:
