@@ -205,3 +205,57 @@ def test_match_stats(case):
     cm, cr, cf = cpu.match_stats_batch(data, off, threads=2)
     assert np.array_equal(gm, cm), name
     assert np.array_equal(gr, cr) and np.array_equal(gf, cf), name
+
+
+def widen_alphabet(ix):
+    """Same index over a 9-letter alphabet: two never-occurring comps are inserted after T, so
+    N becomes comp 7 and # comp 8.  Exercises sigma != 7 (sigma > 8 disables the pred4 nibbles and
+    routes locate through the probing LF(path_node) walk)."""
+    import copy
+    wide = copy.copy(ix)
+    order = [0, 1, 2, 3, 4, None, None, 5, 6]          # new comp -> old comp
+    wide.sigma = 9
+    zero = np.zeros_like(ix.bwt[0])
+    wide.bwt = [zero if o is None else ix.bwt[o] for o in order]
+    C = [0]
+    for o in order:
+        C.append(C[-1] + (0 if o is None else int(ix.C[o + 1]) - int(ix.C[o])))
+    wide.C = np.array(C, dtype=np.uint64)
+    remap = np.zeros(7, dtype=np.uint8)
+    for new, o in enumerate(order):
+        if o is not None:
+            remap[o] = new
+    wide.char2comp = remap[ix.char2comp]
+    return wide
+
+
+def test_other_alphabet_size(engine):
+    from oracle.oracle import OracleIndex
+    name, g, K = CASES[-1]
+    ix = widen_alphabet(build(g, K, sample_period=8, branching=4))
+    gpu, lcp = engine.open_index(ix)
+    cpu = OracleIndex(ix)
+    base = OracleIndex(build(g, K, sample_period=8, branching=4))
+    pats = [truncate_at_sink(p) for p in random_patterns(g, K, 0x93, 300)] + [b"", b"N", b"#", b"$", b"ANA"]
+    data, off = concat_patterns(pats)
+    ranges = gpu.find_batch(data, off)
+    assert np.array_equal(ranges, cpu.find_batch(data, off))
+    assert np.array_equal(ranges, base.find_batch(data, off))        # relabelling does not change results
+    arr = np.array(all_ranges(ix, 0x17, 80), dtype=np.uint64)
+    go, gv = gpu.locate_batch(arr)
+    co, cv = cpu.locate_batch(arr)
+    assert np.array_equal(go, co) and np.array_equal(gv, cv)
+    assert np.array_equal(gpu.count_batch(arr), cpu.count_batch(arr))
+    nodes = np.arange(ix.n, dtype=np.uint64)
+    assert gpu.lf_node_batch(nodes).tolist() == [cpu.LF(int(i)) for i in nodes]
+    for all_ in (0, 1):
+        got = gpu.lf_all_batch(arr[:50], all_)
+        for i, r in enumerate(arr[:50]):
+            r = tuple(int(x) for x in r)
+            want = cpu.LF_all(r) if all_ else cpu.LF_fast(r)
+            assert [tuple(int(x) for x in t) for t in got[i]] == want
+    for k in range(0, 5):
+        assert gpu.count_kmers(k, include_Ns=True) == cpu.count_kmers(k, include_Ns=True)
+    gm, gr, gf = gpu.match_stats_batch(data, off)
+    cm, cr, cf = cpu.match_stats_batch(data, off)
+    assert np.array_equal(gm, cm) and np.array_equal(gr, cr)
