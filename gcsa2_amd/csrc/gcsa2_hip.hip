@@ -427,7 +427,7 @@ int gcsa2_find_device(const gcsa2_index* ix, const uint8_t* d_patterns, const ui
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   hipLaunchKernelGGL(k_find2<false>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
-                     ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr);
+                     ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr);
   LAUNCH_CHECK("k_find2");
   return GCSA2_OK;
 }
@@ -438,6 +438,30 @@ int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t*
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   if(variant == 2) { return gcsa2_find_device(ix, d_patterns, d_offsets, nq, d_ranges, stream); }
+  if(variant == 4)   // length-bucketed: sort query ids by pattern length, then k_find2 through the permutation
+  {
+    if(nq >= (u64(1) << 31)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "length-bucketed find is limited to 2^31 queries per launch"); }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DeviceGuard guard(ix->device);
+    u32 *len_in = nullptr, *len_out = nullptr, *idx_in = nullptr, *idx_out = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, len_in, len_out, idx_in, idx_out, int(nq), 0, 32, st));
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&len_in), 4 * nq * sizeof(u32), st));     // four u32 arrays
+    HIP_TRY(hipMallocAsync(&tmp, tmp_bytes, st));
+    len_out = len_in + nq; idx_in = len_out + nq; idx_out = idx_in + nq;
+    hipLaunchKernelGGL(k_pattern_lengths, dim3(grid_for(nq)), dim3(TPB), 0, st, d_offsets, nq, len_in, idx_in);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, len_in, len_out, idx_in, idx_out, int(nq), 0, 32, st);
+    if(e == hipSuccess)
+    {
+      hipLaunchKernelGGL(k_find2<false>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
+                         ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)idx_out);
+      e = hipGetLastError();
+    }
+    (void)hipFreeAsync(tmp, st); (void)hipFreeAsync(len_in, st);    // stream-ordered: freed after the kernel
+    if(e != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("length-bucketed find: ") + hipGetErrorString(e)); }
+    return GCSA2_OK;
+  }
   if(variant != 1) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown find variant"); }
   hipLaunchKernelGGL(k_find<false>, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
                      ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr);
@@ -453,7 +477,7 @@ int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, co
   if(nq == 0) { return GCSA2_OK; }
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64 atomics");
   hipLaunchKernelGGL(k_find2<true>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
-                     ix->img, d_patterns, d_offsets, nq, d_ranges, reinterpret_cast<unsigned long long*>(d_stats));
+                     ix->img, d_patterns, d_offsets, nq, d_ranges, reinterpret_cast<unsigned long long*>(d_stats), (const u32*)nullptr);
   LAUNCH_CHECK("k_find2<stats>");
   return GCSA2_OK;
 }

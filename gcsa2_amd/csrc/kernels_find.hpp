@@ -156,7 +156,8 @@ __device__ __forceinline__ void read_block(const ulonglong2* wave_stage, u32 lan
 template<bool STATS>
 __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restrict__ patterns,
                                                const u64* __restrict__ offsets, u64 nq,
-                                               u64* __restrict__ out, unsigned long long* __restrict__ stats)
+                                               u64* __restrict__ out, unsigned long long* __restrict__ stats,
+                                               const u32* __restrict__ perm)
 {
   __shared__ ulonglong2 stage[TPB2 * 8];
   __shared__ Tables2 t;
@@ -167,7 +168,10 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
 
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  const u64 q = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  // perm != nullptr: lane g works on query perm[g] (queries ordered by length, so that the 64
+  // chains of a wave finish together); results still go to out[query].
+  const u64 gid = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  const u64 q = (perm != nullptr && gid < nq) ? u64(perm[gid]) : gid;
   u64 blocks = 0, steps = 0, lookups = 0;
 
   u64 sp = 0, ep = img.n - 1, i = 0;
@@ -268,6 +272,17 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       atomicAdd(stats + 2, (unsigned long long)lookups);
     }
   }
+}
+
+// keys for the length-bucketed launch: len[q] = offsets[q + 1] - offsets[q] (saturated), idx[q] = q
+__global__ __launch_bounds__(TPB) void k_pattern_lengths(const u64* __restrict__ offsets, u64 nq,
+                                                         u32* __restrict__ len, u32* __restrict__ idx)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  u64 l = offsets[q + 1] - offsets[q];
+  len[q] = u32(l > 0xFFFFFFFFull ? 0xFFFFFFFFull : l);
+  idx[q] = u32(q);
 }
 
 // LF(range, comp) (gcsa.h:155-162) for a batch, one step: same fused-block machinery as k_find2.

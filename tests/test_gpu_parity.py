@@ -259,3 +259,22 @@ def test_other_alphabet_size(engine):
     gm, gr, gf = gpu.match_stats_batch(data, off)
     cm, cr, cf = cpu.match_stats_batch(data, off)
     assert np.array_equal(gm, cm) and np.array_equal(gr, cr)
+
+
+def test_find_variants_on_device(case):
+    """All kernel generations (1 = k_find, 2 = k_find2, 4 = length-bucketed k_find2) through the
+    device-pointer entry point, ragged pattern lengths."""
+    import torch
+    name, g, K, ix, gpu, lcp, cpu = case
+    pats = [truncate_at_sink(p) for p in random_patterns(g, 3 * K, 0x94, 500)] + [b"", b"N", b"$"]
+    data, off = concat_patterns(pats)
+    want = cpu.find_batch(data, off)
+    dev = torch.device("cuda", 0)
+    d_pat = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    for variant in (1, 2, 4):
+        d_out = torch.full((len(pats), 2), -7, dtype=torch.int64, device=dev)
+        gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), (name, variant)

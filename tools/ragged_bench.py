@@ -1,0 +1,36 @@
+import sys, time, json
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+from workload import graphs, builder, patterns
+from gcsa2_amd.binding import open_index
+from oracle.oracle import OracleIndex
+g = graphs.snp_graph(1 << 23, 0x6C5A0010, 0x6C5A0011)
+ix = builder.build(g, 256, keep_table=False)
+gpu, lcp = open_index(ix)
+nq = 2_000_000
+full = patterns.walk_patterns(g, nq, 256, 0x6C5A0060)
+lens = 16 + (np.arange(nq) * 2654435761 % 241)          # 16..256, scattered
+flat = np.concatenate([full[q, :lens[q]] for q in range(0, nq)]) if False else None
+# vectorised ragged concatenation
+mask = np.arange(256)[None, :] < lens[:, None]
+flat = full[mask]
+off = np.zeros(nq + 1, dtype=np.uint64); off[1:] = np.cumsum(lens)
+dev = torch.device("cuda", 0)
+d_pat = torch.from_numpy(np.ascontiguousarray(flat)).to(dev); d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+st = torch.cuda.current_stream()
+res = {}
+outs = {}
+for v in (2, 4):
+    d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    gpu.find_device_variant(v, d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), st.cuda_stream); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(5):
+        gpu.find_device_variant(v, d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), st.cuda_stream)
+    e1.record(st); torch.cuda.synchronize()
+    res[v] = e0.elapsed_time(e1) / 5
+    outs[v] = d_out.cpu().numpy().view(np.uint64)
+cpu = OracleIndex(ix, with_samples=False, with_counters=False, with_lcp=False)
+want = cpu.find_batch(flat, off[:200001], threads=64)
+print(json.dumps({"ragged 16..256-mers, 2 M queries": {"k_find2 ms": res[2], "length-bucketed ms": res[4]},
+                  "equal": bool(np.array_equal(outs[2], outs[4])), "oracle_sample": bool(np.array_equal(outs[4][:200000], want))}))
