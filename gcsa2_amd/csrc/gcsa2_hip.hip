@@ -46,6 +46,7 @@ struct gcsa2_index
   void* d_base = nullptr;
   void* d_kmer = nullptr;
   void* d_pred4 = nullptr;
+  int compute_units = 256;
   u64 bytes = 0;
   u64 order = 0;
 };
@@ -318,6 +319,10 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
 
     DeviceGuard guard(device);
     if(!guard.ok) { delete ix; return fail(GCSA2_ERR_HIP, "hipSetDevice failed"); }
+    {
+      int cus = 0;
+      if(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) { ix->compute_units = cus; }
+    }
     ix->bytes = st.words.size() * sizeof(u64);
     hipError_t e = hipMalloc(&ix->d_base, ix->bytes > 0 ? ix->bytes : 8);
     if(e != hipSuccess) { delete ix; return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(image): ") + hipGetErrorString(e)); }
@@ -426,8 +431,8 @@ int gcsa2_find_device(const gcsa2_index* ix, const uint8_t* d_patterns, const ui
 {
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
-  hipLaunchKernelGGL(k_find2<false>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
-                     ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr);
+  hipLaunchKernelGGL((k_find2<false, false>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
+                     ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr, (unsigned long long*)nullptr);
   LAUNCH_CHECK("k_find2");
   return GCSA2_OK;
 }
@@ -454,12 +459,28 @@ int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t*
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, len_in, len_out, idx_in, idx_out, int(nq), 0, 32, st);
     if(e == hipSuccess)
     {
-      hipLaunchKernelGGL(k_find2<false>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)idx_out);
+      hipLaunchKernelGGL((k_find2<false, false>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
+                         ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)idx_out, (unsigned long long*)nullptr);
       e = hipGetLastError();
     }
     (void)hipFreeAsync(tmp, st); (void)hipFreeAsync(len_in, st);    // stream-ordered: freed after the kernel
     if(e != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("length-bucketed find: ") + hipGetErrorString(e)); }
+    return GCSA2_OK;
+  }
+  if(variant == 5)   // persistent waves with work refill
+  {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DeviceGuard guard(ix->device);
+    unsigned long long* queue = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), st));
+    u64 resident = u64(ix->compute_units) * 9;                    // workgroups the LDS footprint lets a CU hold
+    u64 wanted = (nq + TPB2 - 1) / TPB2;
+    hipLaunchKernelGGL((k_find2<false, true>), dim3(unsigned(wanted < resident ? wanted : resident)), dim3(TPB2), 0, st,
+                       ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr, queue);
+    hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(queue, st);
+    if(e != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_find2<refill>: ") + hipGetErrorString(e)); }
     return GCSA2_OK;
   }
   if(variant != 1) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown find variant"); }
@@ -476,8 +497,8 @@ int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, co
   if(d_stats == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null stats buffer"); }
   if(nq == 0) { return GCSA2_OK; }
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64 atomics");
-  hipLaunchKernelGGL(k_find2<true>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
-                     ix->img, d_patterns, d_offsets, nq, d_ranges, reinterpret_cast<unsigned long long*>(d_stats), (const u32*)nullptr);
+  hipLaunchKernelGGL((k_find2<true, false>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
+                     ix->img, d_patterns, d_offsets, nq, d_ranges, reinterpret_cast<unsigned long long*>(d_stats), (const u32*)nullptr, (unsigned long long*)nullptr);
   LAUNCH_CHECK("k_find2<stats>");
   return GCSA2_OK;
 }

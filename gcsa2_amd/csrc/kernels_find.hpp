@@ -153,11 +153,16 @@ __device__ __forceinline__ void read_block(const ulonglong2* wave_stage, u32 lan
   for(u32 k = 0; k < 8; k++) { blk[k] = wave_stage[lane * 8 + (k ^ (lane & 7))]; }
 }
 
-template<bool STATS>
+// REFILL = true: persistent waves.  Lanes do not own a fixed query; whenever at least half of a
+// wave's lanes are idle (their chains ended early: mismatches, short patterns) the idle lanes draw
+// new query ids from a global counter (one wave-aggregated atomic) and start them, so that a batch
+// mixing hits and misses keeps all 64 lanes busy.  `queue` points to that counter (zeroed by the
+// host); the grid is sized to the machine, not to the batch.
+template<bool STATS, bool REFILL>
 __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restrict__ patterns,
                                                const u64* __restrict__ offsets, u64 nq,
                                                u64* __restrict__ out, unsigned long long* __restrict__ stats,
-                                               const u32* __restrict__ perm)
+                                               const u32* __restrict__ perm, unsigned long long* __restrict__ queue)
 {
   __shared__ ulonglong2 stage[TPB2 * 8];
   __shared__ Tables2 t;
@@ -168,13 +173,9 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
 
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  // perm != nullptr: lane g works on query perm[g] (queries ordered by length, so that the 64
-  // chains of a wave finish together); results still go to out[query].
-  const u64 gid = u64(blockIdx.x) * TPB2 + threadIdx.x;
-  const u64 q = (perm != nullptr && gid < nq) ? u64(perm[gid]) : gid;
   u64 blocks = 0, steps = 0, lookups = 0;
 
-  u64 sp = 0, ep = img.n - 1, i = 0;
+  u64 q = ~u64(0), sp = 0, ep = img.n - 1, i = 0;
   const u8* p = patterns;
   bool done = true;
   u64 word = 0, word_addr = ~u64(0);        // pattern bytes are consumed back to front from aligned 8-byte words
@@ -184,8 +185,9 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     if(aligned != word_addr) { word = *reinterpret_cast<const u64*>(aligned); word_addr = aligned; }
     return u32(word >> ((addr & 7) * 8)) & 0xFF;
   };
-  if(q < nq)
+  auto start = [&](u64 query)               // begin the backward search of `query` (< nq)
   {
+    q = query; sp = 0; ep = img.n - 1; i = 0; done = true; word_addr = ~u64(0);
     u64 begin = offsets[q], len = offsets[q + 1] - begin;
     if(len > 0 && img.n > 0)                                   // gcsa.h:99
     {
@@ -217,10 +219,46 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       }
       done = range_empty(sp, ep) || i == 0;                    // gcsa.h:103
     }
+  };
+
+  bool has = false, exhausted = false;      // REFILL: lane holds a query / the queue is empty
+  if constexpr(!REFILL)
+  {
+    // perm != nullptr: lane g works on query perm[g] (queries ordered by length, so that the 64
+    // chains of a wave finish together); results still go to out[query].
+    const u64 gid = u64(blockIdx.x) * TPB2 + threadIdx.x;
+    if(gid < nq) { start(perm != nullptr ? u64(perm[gid]) : gid); has = true; }
   }
 
-  while(__any(!done))
+  while(true)
   {
+    if constexpr(REFILL)
+    {
+      if(has && done) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); has = false; }
+      const u64 idle = __ballot(!has);
+      if(!exhausted && __popcll(idle) >= 32)
+      {
+        const u32 want = u32(__popcll(idle)), leader = u32(__ffsll((long long)idle)) - 1;
+        unsigned long long base = 0;
+        if(lane == leader) { base = atomicAdd(queue, (unsigned long long)want); }
+        base = __shfl(base, leader, 64);
+        if(!has)
+        {
+          const u64 mine = base + __popcll(idle & ((u64(1) << lane) - 1));
+          if(mine < nq) { start(mine); has = true; }
+        }
+        exhausted = (base + want >= nq);
+      }
+      if(!__any(has && !done))
+      {
+        if(exhausted && !__any(has)) { break; }
+        if(!exhausted || __any(has)) { continue; }            // retire / refill in the next round
+      }
+    }
+    else
+    {
+      if(!__any(!done)) { break; }
+    }
     u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
     if(!done)
     {
@@ -259,7 +297,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       else { sp = n_sp; ep = n_ep; done = (i == 0); }          // gcsa.h:161, 103
     }
   }
-  if(q < nq) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); }
+  if(!REFILL && has) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); }
   if(STATS)
   {
     for(int o = 32; o > 0; o >>= 1)

@@ -140,8 +140,9 @@ int gcsa2_find_device(const gcsa2_index* index, const uint8_t* d_patterns,
  * gcsa2_find_device runs); variant 4 = the same kernel behind a device-side sort of the queries by
  * pattern length, for batches of very uneven lengths (the 64 chains of a wavefront then finish
  * together; results are written in query order as always; stream-ordered scratch, no host sync);
- * variant 1 = the first generation (k_find, one lane per query over 64-byte rank blocks), kept for
- * A/B measurements. */
+ * variant 5 = k_find2 as persistent wavefronts that refill idle lanes from a global queue, for
+ * batches mixing hits and early misses; variant 1 = the first generation (k_find, one lane per
+ * query over 64-byte rank blocks), kept for A/B measurements. */
 int gcsa2_find_device_variant(const gcsa2_index* index, int variant, const uint8_t* d_patterns,
                               const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
                               void* stream);

@@ -262,7 +262,7 @@ def test_other_alphabet_size(engine):
 
 
 def test_find_variants_on_device(case):
-    """All kernel generations (1 = k_find, 2 = k_find2, 4 = length-bucketed k_find2) through the
+    """All kernel generations (1 = k_find, 2 = k_find2, 4 = length-bucketed, 5 = persistent waves with refill) through the
     device-pointer entry point, ragged pattern lengths."""
     import torch
     name, g, K, ix, gpu, lcp, cpu = case
@@ -272,7 +272,7 @@ def test_find_variants_on_device(case):
     dev = torch.device("cuda", 0)
     d_pat = torch.from_numpy(data).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)
-    for variant in (1, 2, 4):
+    for variant in (1, 2, 4, 5):
         d_out = torch.full((len(pats), 2), -7, dtype=torch.int64, device=dev)
         gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(),
                                 torch.cuda.current_stream().cuda_stream)

@@ -20,7 +20,7 @@ d_pat = torch.from_numpy(np.ascontiguousarray(flat)).to(dev); d_off = torch.from
 st = torch.cuda.current_stream()
 res = {}
 outs = {}
-for v in (2, 4):
+for v in (2, 4, 5):
     d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
     gpu.find_device_variant(v, d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), st.cuda_stream); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,5 +32,29 @@ for v in (2, 4):
     outs[v] = d_out.cpu().numpy().view(np.uint64)
 cpu = OracleIndex(ix, with_samples=False, with_counters=False, with_lcp=False)
 want = cpu.find_batch(flat, off[:200001], threads=64)
-print(json.dumps({"ragged 16..256-mers, 2 M queries": {"k_find2 ms": res[2], "length-bucketed ms": res[4]},
-                  "equal": bool(np.array_equal(outs[2], outs[4])), "oracle_sample": bool(np.array_equal(outs[4][:200000], want))}))
+print(json.dumps({"ragged 16..256-mers, 2 M queries": {"k_find2 ms": res[2], "length-bucketed ms": res[4], "refill ms": res[5]},
+                  "equal": bool(np.array_equal(outs[2], outs[4])) and bool(np.array_equal(outs[2], outs[5])),
+                  "oracle_sample": bool(np.array_equal(outs[4][:200000], want))}))
+# mixed hits and misses, equal lengths: every second 128-mer carries one substitution at a random place
+nq2 = 4_000_000
+mix = patterns.walk_patterns(g, nq2, 128, 0x6C5A0061)
+pos = (np.arange(nq2) * 40503 % 128)
+sub = np.frombuffer(b"ACGT", dtype=np.uint8)
+rows = np.arange(1, nq2, 2)
+mix[rows, pos[rows]] = sub[(np.searchsorted(sub, mix[rows, pos[rows]]) + 1) % 4]
+flat2, off2 = patterns.as_batch(mix)
+d_pat2 = torch.from_numpy(flat2).to(dev); d_off2 = torch.from_numpy(off2.view(np.int64)).to(dev)
+res2, outs2 = {}, {}
+for v in (2, 5):
+    d_out = torch.zeros((nq2, 2), dtype=torch.int64, device=dev)
+    gpu.find_device_variant(v, d_pat2.data_ptr(), d_off2.data_ptr(), nq2, d_out.data_ptr(), st.cuda_stream); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(5):
+        gpu.find_device_variant(v, d_pat2.data_ptr(), d_off2.data_ptr(), nq2, d_out.data_ptr(), st.cuda_stream)
+    e1.record(st); torch.cuda.synchronize()
+    res2[v] = e0.elapsed_time(e1) / 5
+    outs2[v] = d_out.cpu().numpy().view(np.uint64)
+want2 = cpu.find_batch(flat2, off2[:200001], threads=64)
+print(json.dumps({"mixed hit/miss 128-mers, 4 M queries": {"k_find2 ms": res2[2], "refill ms": res2[5]},
+                  "equal": bool(np.array_equal(outs2[2], outs2[5])), "oracle_sample": bool(np.array_equal(outs2[5][:200000], want2))}))
