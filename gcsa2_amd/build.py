@@ -25,5 +25,18 @@ def build(force=False, verbose=False):
     return OUT
 
 
+BENCH_SRC = os.path.join(HERE, "csrc", "gather_bench.hip")
+BENCH_OUT = os.path.join(HERE, "lib", "gather_bench")
+
+
+def build_gather_bench(force=False):
+    """The random-gather ceiling microbenchmark (a standalone HIP program, profiles/r01_gather_bench.md)."""
+    os.makedirs(os.path.dirname(BENCH_OUT), exist_ok=True)
+    if not force and os.path.exists(BENCH_OUT) and os.path.getmtime(BENCH_OUT) >= os.path.getmtime(BENCH_SRC):
+        return BENCH_OUT
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-o", BENCH_OUT, BENCH_SRC])
+    return BENCH_OUT
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
