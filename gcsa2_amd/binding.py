@@ -35,6 +35,8 @@ EXPORTS = [
     "gcsa2_lcp_access_batch",
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
     "gcsa2_group_find_batch", "gcsa2_count_kmers", "gcsa2_match_stats_batch", "gcsa2_match_stats_device",
+    "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
+    "gcsa2_index_create_from_file",
 ]
 
 
@@ -101,6 +103,13 @@ def load_library():
     L.gcsa2_alphabet.restype = None
     L.gcsa2_lcp_access_batch.argtypes = [vp, u64p, u64, u64p]
     L.gcsa2_count_kmers.argtypes = [vp, u64, i32, i32, u64p]
+    L.gcsa2_host_view_save.argtypes = [C.POINTER(HostView), C.c_char_p]
+    L.gcsa2_host_view_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.gcsa2_host_view_get.argtypes = [vp]
+    L.gcsa2_host_view_get.restype = C.POINTER(HostView)
+    L.gcsa2_host_view_free.argtypes = [vp]
+    L.gcsa2_host_view_free.restype = None
+    L.gcsa2_index_create_from_file.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
     L.gcsa2_match_stats_batch.argtypes = [vp, u8p, u64p, u64, vp, u64p, u64p]
     L.gcsa2_match_stats_device.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
@@ -179,6 +188,34 @@ class Node:
         return int(node) & 1023
 
 
+def save_host_view(index_arrays, path, **view_kwargs):
+    """Write the G2HV container file of an index (host only)."""
+    holder = make_host_view(index_arrays, **view_kwargs)
+    _check(load_library().gcsa2_host_view_save(holder.ref(), os.fsencode(path)))
+
+
+class LoadedHostView:
+    """A G2HV file read back into host memory (host only); `.view` is the ctypes HostView."""
+
+    def __init__(self, path):
+        self._L = load_library()
+        h = C.c_void_p()
+        _check(self._L.gcsa2_host_view_load(os.fsencode(path), C.byref(h)))
+        self._h = h
+        self.view = self._L.gcsa2_host_view_get(h).contents
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gcsa2_host_view_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GCSA:
     """Device-resident index with the reference's query methods.
 
@@ -188,8 +225,16 @@ class GCSA:
 
     def __init__(self, index_arrays, device=0, **view_kwargs):
         L = load_library()
-        holder = make_host_view(index_arrays, **view_kwargs)
         h = C.c_void_p()
+        if isinstance(index_arrays, (str, bytes, os.PathLike)):      # a G2HV container file
+            _check(L.gcsa2_index_create_from_file(os.fsencode(index_arrays), device, C.byref(h)))
+            self._h, self._L = h, L
+            self.sigma = int(L.gcsa2_sigma(h))
+            self.fast_chars = int(L.gcsa2_fast_chars(h))
+            self.char2comp = np.zeros(256, dtype=np.uint8)
+            L.gcsa2_alphabet(h, _p8(self.char2comp), None)
+            return
+        holder = make_host_view(index_arrays, **view_kwargs)
         _check(L.gcsa2_index_create(holder.ref(), device, C.byref(h)))
         self._h = h
         self._L = L

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <memory>
 #include <new>
 #include <random>
 #include <string>
@@ -1192,4 +1193,159 @@ extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* pat
   HIP_TRY(hipMemcpy(ranges, d_rng.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
   if(fallbacks != nullptr) { HIP_TRY(hipMemcpy(fallbacks, d_fb.p, nq * sizeof(u64), hipMemcpyDeviceToHost)); }
   return GCSA2_OK;
+}
+
+// ---- host-view container file ("G2HV"): the interchange format between a process that can read
+// .gcsa / .lcp files (the reference + SDSL) and GPU nodes that cannot. --------
+// Layout (little endian): char magic[4] = "G2HV"; u32 version = 1; u64 header[12] = path_nodes,
+// edges, order, sigma, fast_chars, sample_count, sample_width, extra_values_len, redundant_len,
+// lcp_size, lcp_branching, lcp_levels; u64 flags (bit 0 samples, bit 1 counters, bit 2 lcp);
+// then the arrays in the order of gcsa2_host_view, each as u64 byte length + bytes padded to 8.
+
+struct gcsa2_view_storage
+{
+  gcsa2_host_view view;
+  std::vector<std::vector<u64>> blobs;    // 8-byte aligned backing store
+  std::vector<const u64*> bwt;
+};
+
+namespace {
+
+constexpr u32 G2HV_VERSION = 1;
+
+u64 words_for_bits(u64 bits) { return (bits + 63) / 64; }
+
+bool write_blob(FILE* f, const void* data, u64 bytes)
+{
+  u64 padded = (bytes + 7) & ~u64(7);
+  static const char zeros[8] = {0};
+  if(fwrite(&bytes, 8, 1, f) != 1) { return false; }
+  if(bytes > 0 && fwrite(data, 1, bytes, f) != bytes) { return false; }
+  if(padded > bytes && fwrite(zeros, 1, padded - bytes, f) != padded - bytes) { return false; }
+  return true;
+}
+
+bool read_blob(FILE* f, std::vector<u64>& dst, u64& bytes)
+{
+  if(fread(&bytes, 8, 1, f) != 1) { return false; }
+  if(bytes > (u64(1) << 40)) { return false; }
+  dst.assign((bytes + 7) / 8 + 2, 0);        // two spare words: word-granular readers may overrun
+  u64 padded = (bytes + 7) & ~u64(7);
+  return padded == 0 || fread(dst.data(), 1, padded, f) == padded;
+}
+
+}  // namespace
+
+extern "C" int gcsa2_host_view_save(const gcsa2_host_view* v, const char* path)
+{
+  if(v == nullptr || path == nullptr || v->char2comp == nullptr || v->C == nullptr || v->bwt == nullptr || v->edge_bits == nullptr)
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "incomplete host view");
+  }
+  FILE* f = fopen(path, "wb");
+  if(f == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, std::string("cannot open ") + path); }
+  bool ok = true;
+  u64 flags = (v->sampled_path_bits ? 1 : 0) | (v->extra_filter_bits ? 2 : 0) | (v->lcp_data ? 4 : 0);
+  u64 header[12] = { v->path_nodes, v->edges, v->order, v->sigma, v->fast_chars, v->sample_count, v->sample_width,
+                     v->extra_values_len, v->redundant_len, v->lcp_size, v->lcp_branching, v->lcp_levels };
+  ok = ok && fwrite("G2HV", 1, 4, f) == 4 && fwrite(&G2HV_VERSION, 4, 1, f) == 1;
+  ok = ok && fwrite(header, 8, 12, f) == 12 && fwrite(&flags, 8, 1, f) == 1;
+  ok = ok && write_blob(f, v->char2comp, 256) && write_blob(f, v->C, (v->sigma + 1) * 8);
+  for(u64 c = 0; ok && c < v->sigma; c++) { ok = write_blob(f, v->bwt[c], words_for_bits(v->path_nodes) * 8); }
+  ok = ok && write_blob(f, v->edge_bits, words_for_bits(v->edges) * 8);
+  if(flags & 1)
+  {
+    ok = ok && write_blob(f, v->sampled_path_bits, words_for_bits(v->path_nodes) * 8);
+    ok = ok && write_blob(f, v->stored_samples, words_for_bits(v->sample_count * v->sample_width) * 8);
+    ok = ok && write_blob(f, v->sample_bits, words_for_bits(v->sample_count) * 8);
+  }
+  if(flags & 2)
+  {
+    ok = ok && write_blob(f, v->extra_filter_bits, words_for_bits(v->path_nodes) * 8);
+    ok = ok && write_blob(f, v->extra_values_bits, words_for_bits(v->extra_values_len) * 8);
+    ok = ok && write_blob(f, v->redundant_bits, words_for_bits(v->redundant_len) * 8);
+  }
+  if(flags & 4)
+  {
+    ok = ok && write_blob(f, v->lcp_offsets, (v->lcp_levels + 1) * 8);
+    ok = ok && write_blob(f, v->lcp_data, v->lcp_offsets[v->lcp_levels]);
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? GCSA2_OK : fail(GCSA2_ERR_INVALID_ARGUMENT, std::string("write error on ") + path);
+}
+
+extern "C" void gcsa2_host_view_free(gcsa2_view_storage* storage) { delete storage; }
+
+extern "C" const gcsa2_host_view* gcsa2_host_view_get(const gcsa2_view_storage* storage) { return storage ? &storage->view : nullptr; }
+
+extern "C" int gcsa2_host_view_load(const char* path, gcsa2_view_storage** out)
+{
+  if(path == nullptr || out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null argument"); }
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if(f == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, std::string("cannot open ") + path); }
+  struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+  try
+  {
+    char magic[4]; u32 version = 0; u64 header[12], flags = 0;
+    if(fread(magic, 1, 4, f) != 4 || std::memcmp(magic, "G2HV", 4) != 0) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "not a G2HV file: invalid tag"); }
+    if(fread(&version, 4, 1, f) != 1 || version != G2HV_VERSION) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: unsupported version"); }
+    if(fread(header, 8, 12, f) != 12 || fread(&flags, 8, 1, f) != 1) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: truncated header"); }
+    if(header[3] == 0 || header[3] > GCSA2_MAX_SIGMA || header[11] > u64(MAX_LCP_LEVELS)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: header out of range"); }
+    std::unique_ptr<gcsa2_view_storage> st(new gcsa2_view_storage());
+    gcsa2_host_view& v = st->view;
+    std::memset(&v, 0, sizeof(v));
+    v.path_nodes = header[0]; v.edges = header[1]; v.order = header[2]; v.sigma = header[3]; v.fast_chars = header[4];
+    v.sample_count = header[5]; v.sample_width = header[6]; v.extra_values_len = header[7]; v.redundant_len = header[8];
+    v.lcp_size = header[9]; v.lcp_branching = header[10]; v.lcp_levels = header[11];
+    u64 nblobs = 2 + v.sigma + 1 + ((flags & 1) ? 3 : 0) + ((flags & 2) ? 3 : 0) + ((flags & 4) ? 2 : 0);
+    st->blobs.resize(nblobs);
+    std::vector<u64> sizes(nblobs, 0);
+    for(u64 b = 0; b < nblobs; b++)
+    {
+      if(!read_blob(f, st->blobs[b], sizes[b])) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: truncated array"); }
+    }
+    u64 b = 0;
+    auto expect = [&](u64 bytes) -> bool { return sizes[b] == bytes; };
+    if(!expect(256)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: char2comp size"); }
+    v.char2comp = reinterpret_cast<const uint8_t*>(st->blobs[b++].data());
+    if(!expect((v.sigma + 1) * 8)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: C size"); }
+    v.C = st->blobs[b++].data();
+    for(u64 c = 0; c < v.sigma; c++)
+    {
+      if(!expect(words_for_bits(v.path_nodes) * 8)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: bwt size"); }
+      st->bwt.push_back(st->blobs[b++].data());
+    }
+    v.bwt = st->bwt.data();
+    if(!expect(words_for_bits(v.edges) * 8)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: edges size"); }
+    v.edge_bits = st->blobs[b++].data();
+    if(flags & 1)
+    {
+      v.sampled_path_bits = st->blobs[b++].data(); v.stored_samples = st->blobs[b++].data(); v.sample_bits = st->blobs[b++].data();
+    }
+    if(flags & 2)
+    {
+      v.extra_filter_bits = st->blobs[b++].data(); v.extra_values_bits = st->blobs[b++].data(); v.redundant_bits = st->blobs[b++].data();
+    }
+    if(flags & 4)
+    {
+      if(!expect((v.lcp_levels + 1) * 8)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: lcp offsets size"); }
+      v.lcp_offsets = st->blobs[b++].data();
+      if(sizes[b] != v.lcp_offsets[v.lcp_levels]) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: lcp data size"); }
+      v.lcp_data = reinterpret_cast<const uint8_t*>(st->blobs[b++].data());
+    }
+    *out = st.release();
+    return GCSA2_OK;
+  }
+  catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_host_view_load: ") + e.what()); }
+}
+
+extern "C" int gcsa2_index_create_from_file(const char* path, int device, gcsa2_index** out)
+{
+  gcsa2_view_storage* st = nullptr;
+  int rc = gcsa2_host_view_load(path, &st);
+  if(rc != GCSA2_OK) { return rc; }
+  rc = gcsa2_index_create(&st->view, device, out);
+  gcsa2_host_view_free(st);
+  return rc;
 }

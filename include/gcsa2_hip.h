@@ -262,6 +262,21 @@ int gcsa2_match_stats_device(const gcsa2_index* index, const uint8_t* d_patterns
                              uint64_t n_queries, uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks,
                              void* stream);
 
+/* ---- host-view container file ("G2HV") ---------------------------------------------------
+ * Interchange between a process that can read .gcsa / .lcp files (the reference linked with SDSL:
+ * GCSA::load, src/gcsa.cpp:184-216; LCPArray::load, src/lcp.cpp:130-143; exporter stub in
+ * INTEGRATION.md) and GPU nodes that cannot.  The file is the gcsa2_host_view verbatim: header
+ * fields, then every array with its byte length.  A bad tag or version fails like the reference's
+ * load() does ("Invalid header", src/gcsa.cpp:188-193), as an error code.  These three functions
+ * are host-only (no device needed). */
+typedef struct gcsa2_view_storage gcsa2_view_storage;   /* owns the arrays of a loaded view */
+int gcsa2_host_view_save(const gcsa2_host_view* view, const char* path);
+int gcsa2_host_view_load(const char* path, gcsa2_view_storage** out);
+const gcsa2_host_view* gcsa2_host_view_get(const gcsa2_view_storage* storage);
+void gcsa2_host_view_free(gcsa2_view_storage* storage);
+/* load + gcsa2_index_create in one call */
+int gcsa2_index_create_from_file(const char* path, int device, gcsa2_index** out);
+
 /* ---- single-process multi-GPU -------------------------------------------------------------
  * A group holds one replica of the index per listed device (a device may be listed more than
  * once).  group_find_batch splits the batch into contiguous shards (sizes differ by at most one,

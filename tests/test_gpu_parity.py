@@ -278,3 +278,23 @@ def test_find_variants_on_device(case):
                                 torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), (name, variant)
+
+
+def test_create_from_container_file(engine, tmp_path):
+    """G2HV file -> device image: same results as creating from the in-memory view."""
+    from oracle.oracle import OracleIndex
+    name, g, K = CASES[-1]
+    ix = build(g, K, sample_period=8, branching=4)
+    path = str(tmp_path / "index.g2hv")
+    engine.save_host_view(ix, path)
+    gpu = engine.GCSA(path)
+    cpu = OracleIndex(ix)
+    pats = [truncate_at_sink(p) for p in random_patterns(g, K, 0x95, 200)]
+    data, off = concat_patterns(pats)
+    ranges = gpu.find_batch(data, off)
+    assert np.array_equal(ranges, cpu.find_batch(data, off))
+    go, gv = gpu.locate_batch(ranges)
+    co, cv = cpu.locate_batch(ranges)
+    assert np.array_equal(go, co) and np.array_equal(gv, cv)
+    assert (gpu.size(), gpu.edgeCount(), gpu.order(), gpu.sigma) == (ix.n, ix.e, ix.order, ix.sigma)
+    assert gpu.char2comp.tolist() == ix.char2comp.tolist()

@@ -108,3 +108,40 @@ def test_sharded_find_gloo_world2(tmp_path, nq):
     out = tmp_path / "ok.txt"
     mp.spawn(_worker, args=(2, _free_port(), nq, str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
+
+
+def test_host_view_file_round_trip(built, tmp_path):
+    """G2HV container: save -> load -> identical arrays (host only, no device)."""
+    import ctypes as C
+    from workload import graphs
+    from workload.brute_builder import build
+    ix = build(graphs.snp_graph(150, 0x52, 0x53, snp_period=8, node_len=8), 6, sample_period=8, branching=4)
+    path = str(tmp_path / "index.g2hv")
+    built.save_host_view(ix, path)
+    loaded = built.LoadedHostView(path)
+    v = loaded.view
+    assert (v.path_nodes, v.edges, v.order, v.sigma, v.fast_chars) == (ix.n, ix.e, ix.order, ix.sigma, ix.fast_chars)
+    assert (v.sample_count, v.sample_width, v.extra_values_len, v.redundant_len) == \
+        (ix.sample_count, ix.sample_width, ix.extra_values_len, ix.redundant_len)
+    words = (ix.n + 63) // 64
+    for c in range(ix.sigma):
+        assert np.ctypeslib.as_array(v.bwt[c], shape=(words,)).tolist() == ix.bwt[c][:words].tolist()
+    assert np.ctypeslib.as_array(v.edge_bits, shape=((ix.e + 63) // 64,)).tolist() == ix.edges[: (ix.e + 63) // 64].tolist()
+    assert np.ctypeslib.as_array(v.C, shape=(ix.sigma + 1,)).tolist() == ix.C.tolist()
+    assert np.ctypeslib.as_array(v.char2comp, shape=(256,)).tolist() == ix.char2comp.tolist()
+    nvals = int(ix.lcp_offsets[-1])
+    assert np.ctypeslib.as_array(v.lcp_data, shape=(nvals,)).tolist() == ix.lcp_data.tolist()
+    sw = (ix.sample_count * ix.sample_width + 63) // 64
+    assert np.ctypeslib.as_array(v.stored_samples, shape=(sw,)).tolist() == ix.stored_samples[:sw].tolist()
+    loaded.close()
+    # a file with a bad tag is refused, like GCSA::load does for an invalid header
+    bad = tmp_path / "bad.g2hv"
+    bad.write_bytes(b"XXXX" + open(path, "rb").read()[4:])
+    with pytest.raises(built.Gcsa2Error):
+        built.LoadedHostView(str(bad))
+    with pytest.raises(built.Gcsa2Error):
+        built.LoadedHostView(str(tmp_path / "missing.g2hv"))
+    # view without LCP / counters
+    built.save_host_view(ix, path, with_lcp=False, with_counters=False)
+    v2 = built.LoadedHostView(path).view
+    assert not v2.lcp_data and not v2.extra_filter_bits and bool(v2.sampled_path_bits)
