@@ -94,6 +94,15 @@ public:
     alpha.char2comp.resize(256); alpha.C.resize(alpha.sigma + 1);
     gcsa2_alphabet(handle, alpha.char2comp.data(), alpha.C.data());
   }
+  // Opens a G2HV container file (gcsa2_host_view_save).  Like the reference's
+  // load() (src/gcsa.cpp:184-216) this throws std::runtime_error on an invalid header.
+  explicit GCSA(const std::string& container_file, int device = 0) : handle(nullptr)
+  {
+    check(gcsa2_index_create_from_file(container_file.c_str(), device, &handle), "GCSA::GCSA()");
+    alpha.sigma = gcsa2_sigma(handle); alpha.fast_chars = gcsa2_fast_chars(handle);
+    alpha.char2comp.resize(256); alpha.C.resize(alpha.sigma + 1);
+    gcsa2_alphabet(handle, alpha.char2comp.data(), alpha.C.data());
+  }
   GCSA(const GCSA&) = delete;
   GCSA& operator=(const GCSA&) = delete;
   GCSA(GCSA&& source) noexcept : alpha(std::move(source.alpha)), handle(source.handle) { source.handle = nullptr; }

@@ -51,7 +51,12 @@ int main(int argc, char** argv)
   view.lcp_offsets = reinterpret_cast<const u64*>(blobs[b++].data());
   view.lcp_data = reinterpret_cast<const std::uint8_t*>(blobs[b++].data());
 
-  gcsa::GCSA index(view, 0);
+  // round trip through the container file: save the view, open the index from the file
+  std::string container = std::string(argv[1]) + ".g2hv";
+  gcsa::check(gcsa2_host_view_save(&view, container.c_str()), "gcsa2_host_view_save()");
+  gcsa::GCSA index(container, 0);
+  try { gcsa::GCSA broken(std::string(argv[2]), 0); std::cerr << "invalid container accepted" << std::endl; return 1; }
+  catch(const std::runtime_error&) {}
   gcsa::LCPArray lcp(index);
   std::cout << "header " << index.size() << " " << index.edgeCount() << " " << index.order() << " "
             << index.sampleCount() << " " << index.sampleBits() << " " << index.sampledPositions() << " "
