@@ -119,3 +119,18 @@ def test_config2_full_size_properties():
     assert np.array_equal(ranges, want)
     with np.errstate(over="ignore"):
         assert int((ranges * np.uint64(0x9E3779B97F4A7C15)).sum()) == int((want * np.uint64(0x9E3779B97F4A7C15)).sum())
+
+
+def test_mseq_index_closed_form_on_gpu():
+    """1 M-node index with analytic answers (workload/mseq_torch.py): every find() of a substring of
+    the cyclic text returns the closed-form rank of its rotation; countKMers(10) = all 4^10 - 1."""
+    import torch
+    from workload import mseq_torch
+    from gcsa2_amd.binding import GCSA
+    ix, sym_t, rank = mseq_torch.build_mseq(20, device=torch.device("cuda", 0))
+    gpu = GCSA(ix, with_samples=False, with_counters=False, with_lcp=False)
+    for m in (10, 17, 32, 100):
+        pats, exp = mseq_torch.substring_patterns(sym_t, rank, 200_000, m, 0xE0 + m)
+        flat, off = patterns.as_batch(pats)
+        assert np.array_equal(gpu.find_batch(flat, off), exp), m
+    assert gpu.count_kmers(10, force=True) == ix.n

@@ -47,3 +47,22 @@ def test_linear_torch_matches_general_builder(n, seed):
     assert a.extra_values_len == b.extra_values_len == 0 and a.redundant_len == b.redundant_len
     assert np.array_equal(a.redundant[: (a.redundant_len + 63) // 64], b.redundant[: (a.redundant_len + 63) // 64])
     assert not a.extra_filter[:w].any() and not b.extra_filter[:w].any()
+
+
+@pytest.mark.parametrize("degree", [8, 12, 16])
+def test_mseq_index_has_analytic_answers(degree):
+    """The sort-free m-sequence index: find() of any substring of length >= degree / 2 is the
+    closed-form rank of its rotation (checked through the oracle), shorter ones cover 4^(k-m) ranks."""
+    import torch
+    from workload import mseq_torch
+    from oracle.oracle import OracleIndex
+    ix, sym_t, rank = mseq_torch.build_mseq(degree, device=torch.device("cpu"))
+    assert ix.n == (1 << degree) - 1 and sorted(rank.tolist()) == list(range(ix.n))
+    cpu = OracleIndex(ix, with_samples=False, with_counters=False, with_lcp=False)
+    for m in (degree // 2, degree // 2 + 3, 32):
+        pats, exp = mseq_torch.substring_patterns(sym_t, rank, 500, m, 0xD0 + m)
+        flat = np.ascontiguousarray(pats.reshape(-1))
+        off = np.arange(501, dtype=np.uint64) * np.uint64(m)
+        assert np.array_equal(cpu.find_batch(flat, off), exp)
+    # every (degree/2)-mer except A^(degree/2) occurs exactly once: countKMers
+    assert cpu.count_kmers(degree // 2, force=True) == ix.n

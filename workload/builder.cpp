@@ -414,4 +414,45 @@ void gcsa_pack_ints(const u64* values, u64 count, u64 width, u64* out_words)
   }
 }
 
+
+// Cyclic "de Bruijn-like" text for footprint-scale indexes that need NO suffix sorting.
+// A binary m-sequence of even degree d (maximal-length LFSR, period 2^d - 1) read two bits at a
+// time is a cyclic text over {A,C,G,T} of length N = 2^d - 1 in which every d/2-mer except A^(d/2)
+// occurs exactly once (the period is odd, so the symbol windows sweep all bit offsets).  The rank
+// of rotation i among all rotations is therefore the value of its first d/2 symbols minus one.
+//   sym[i]  = symbol i (0..3),   rank[i] = lexicographic rank of the rotation starting at i.
+// Returns 0, or -1 if `taps` is not primitive (the state did not return after exactly 2^d - 1 steps).
+int gcsa_mseq_text(int degree, const int* taps, int ntaps, u8* sym, u32* rank)
+{
+  if(degree < 4 || degree > 32 || (degree & 1)) { return -2; }
+  const u64 period = (u64(1) << degree) - 1, mask = period;
+  u64 tapmask = 0;
+  for(int t = 0; t < ntaps; t++) { tapmask |= u64(1) << (degree - taps[t]); }   // Fibonacci LFSR, window = next d output bits
+  // state = the next `degree` output bits, MSB = next bit; new bit = parity(state & tapmask')
+  // Use the recurrence a[n + d] = XOR of a[n + d - tap] over taps (tap = d contributes a[n]).
+  u64 state = 1;           // any non-zero start
+  const u64 start = state;
+  auto step = [&](u64 st) -> u64
+  {
+    u64 fb = 0;
+    for(int t = 0; t < ntaps; t++) { fb ^= (st >> (taps[t] - 1)) & 1; }   // bit (tap - 1) counted from the LSB = a[n + d - tap]
+    return ((st << 1) | fb) & mask;
+  };
+  (void)tapmask;
+  // symbol i consumes output bits 2i, 2i + 1; the window of rotation i is the state before them.
+  // Here the state's MSB is the OLDEST bit of the window, i.e. the first bit of the rotation.
+  for(u64 i = 0; i < period; i++)
+  {
+    rank[i] = u32(state - 1);
+    sym[i] = u8((state >> (degree - 2)) & 3);
+    state = step(step(state));
+  }
+  // after `period` symbols = 2 * period bits the state must be back at the start, and not earlier
+  if(state != start) { return -1; }
+  u64 st = start, n = 0;
+  do { st = step(st); n++; } while(st != start && n <= period);
+  return n == period ? 0 : -1;
+}
+
 }  // extern "C"
+
