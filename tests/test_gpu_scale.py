@@ -127,10 +127,29 @@ def test_mseq_index_closed_form_on_gpu():
     import torch
     from workload import mseq_torch
     from gcsa2_amd.binding import GCSA
-    ix, sym_t, rank = mseq_torch.build_mseq(20, device=torch.device("cuda", 0))
-    gpu = GCSA(ix, with_samples=False, with_counters=False, with_lcp=False)
+    from gcsa2_amd.binding import LCPArray
+    ix, sym_t, rank = mseq_torch.build_mseq(20, device=torch.device("cuda", 0), full=True)
+    gpu = GCSA(ix)
+    lcp = LCPArray(gpu, int(ix.lcp_offsets[-1]), ix.n)
     for m in (10, 17, 32, 100):
         pats, exp = mseq_torch.substring_patterns(sym_t, rank, 200_000, m, 0xE0 + m)
         flat, off = patterns.as_batch(pats)
         assert np.array_equal(gpu.find_batch(flat, off), exp), m
     assert gpu.count_kmers(10, force=True) == ix.n
+    # locate: the rotation starting at position p carries exactly the value of p
+    starts = (mseq_torch._lsr(mseq_torch.splitmix64_torch(0xE0 + 100, 200_000, sym_t.device), 11) % ix.n).cpu().numpy()
+    offs, vals = gpu.locate_batch(exp)
+    assert np.array_equal(np.diff(offs), np.ones(exp.shape[0], dtype=np.uint64))
+    assert np.array_equal(vals, mseq_torch.node_values(starts))
+    assert np.array_equal(gpu.count_batch(exp), np.ones(exp.shape[0], dtype=np.uint64))
+    # parent of a singleton: all k-mer values sharing the first L digits, L = max of the two LCPs
+    k = 10
+    lcpv = ix.lcp_data[: ix.n].astype(np.int64)
+    r = exp[:, 0].astype(np.int64)
+    L = np.maximum(lcpv[r], np.where(r + 1 < ix.n, lcpv[np.minimum(r + 1, ix.n - 1)], 0))
+    shift = 2 * (k - L)
+    lo = ((r + 1) >> shift) << shift
+    par = lcp.parent_batch(exp)
+    assert np.array_equal(par["sp"].astype(np.int64), np.maximum(lo, 1) - 1)
+    assert np.array_equal(par["ep"].astype(np.int64), np.minimum(lo + (np.int64(1) << shift) - 1, ix.n) - 1)
+    assert np.array_equal(par["node_lcp"].astype(np.int64), L)

@@ -66,3 +66,24 @@ def test_mseq_index_has_analytic_answers(degree):
         assert np.array_equal(cpu.find_batch(flat, off), exp)
     # every (degree/2)-mer except A^(degree/2) occurs exactly once: countKMers
     assert cpu.count_kmers(degree // 2, force=True) == ix.n
+
+
+@pytest.mark.parametrize("degree", [8, 12])
+def test_mseq_closed_form_equals_general_builder(degree):
+    """The closed-form m-sequence index (samples, counters, LCP included) is exactly what the
+    general builder produces for the cycle graph of the same text."""
+    import torch
+    from workload import mseq_torch
+    a = builder.build(mseq_torch.cycle_graph(degree), degree // 2)
+    b, _, _ = mseq_torch.build_mseq(degree, device=torch.device("cpu"), full=True)
+    assert (a.n, a.e, a.order, a.sample_count, a.sample_width) == (b.n, b.e, b.order, b.sample_count, b.sample_width)
+    assert np.array_equal(a.C, b.C)
+    w = (a.n + 63) // 64
+    for c in range(a.sigma):
+        assert np.array_equal(a.bwt[c][:w], b.bwt[c][:w]), c
+    assert np.array_equal(a.edges[:w], b.edges[:w])
+    assert np.array_equal(a.sampled_paths[:w], b.sampled_paths[:w])
+    assert np.array_equal(a.stored_samples_plain, b.stored_samples_plain)
+    assert np.array_equal(a.lcp_data, b.lcp_data) and np.array_equal(a.lcp_offsets, b.lcp_offsets)
+    assert a.extra_values_len == b.extra_values_len == 0 and a.redundant_len == b.redundant_len
+    assert np.array_equal(a.redundant[: (a.redundant_len + 63) // 64], b.redundant[: (b.redundant_len + 63) // 64])

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--pattern-len", type=int, default=32)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--oracle-sample", type=int, default=0, help="also check this many queries against the CPU oracle")
+    ap.add_argument("--full", action="store_true", help="also build samples / counters / LCP in closed form and run locate + parent")
+    ap.add_argument("--full-queries", type=int, default=2_000_000)
     args = ap.parse_args()
     import torch
     from workload import mseq_torch, patterns
@@ -35,14 +37,15 @@ def main():
 
     dev = torch.device("cuda", 0)
     t = time.time()
-    ix, sym_t, rank = mseq_torch.build_mseq(args.degree, device=dev, verbose=log)
+    ix, sym_t, rank = mseq_torch.build_mseq(args.degree, device=dev, verbose=log, full=args.full)
     log(f"index arrays: n = {ix.n} ({time.time() - t:.1f} s)")
     nq, m = args.queries, args.pattern_len
     pats, exp = mseq_torch.substring_patterns(sym_t, rank, nq, m, 0x6C5A0070)
+    starts = (mseq_torch._lsr(mseq_torch.splitmix64_torch(0x6C5A0070, nq, dev), 11) % ix.n).cpu().numpy()
     del sym_t
     torch.cuda.empty_cache()
     t = time.time()
-    gpu = GCSA(ix, device=0, with_samples=False, with_counters=False, with_lcp=False)
+    gpu = GCSA(ix, device=0, with_samples=args.full, with_counters=args.full, with_lcp=args.full)
     log(f"device image: {gpu.device_bytes() / 1e9:.2f} GB, seed table k = {gpu.kmer_table_k()} ({time.time() - t:.1f} s)")
     flat, off = patterns.as_batch(pats)
     d_pat = torch.from_numpy(flat).to(dev)
@@ -74,6 +77,49 @@ def main():
            "kernel_ms": ms, "queries_per_s": nq / (ms * 1e-3), "blocks_per_query": blocks / nq, "lf_steps_per_query": steps / nq,
            "algorithmic_GBps": algo / (ms * 1e-3) / 1e9, "frac_of_8TBps": algo / (ms * 1e-3) / 8e12,
            "all_results_equal_closed_form": exact}
+    if args.full:
+        nf = min(nq, args.full_queries)
+        sub = d_out[:nf].contiguous()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        job, d_o, d_v, total = gpu.locate_device(sub.data_ptr(), nf, st.cuda_stream)
+        torch.cuda.synchronize()
+        t_loc = time.perf_counter() - t0
+        import ctypes
+        vals = np.ctypeslib.as_array(ctypes.cast(0, ctypes.POINTER(ctypes.c_uint64)), shape=(0,)) if total == 0 else None
+        d_vals = torch.empty(total, dtype=torch.int64, device=dev)
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so.7")
+        hip.hipMemcpy(C.c_void_p(d_vals.data_ptr()), C.c_void_p(d_v), C.c_size_t(total * 8), C.c_int(3))
+        torch.cuda.synchronize()
+        gpu.locate_discard(job)
+        located = d_vals.cpu().numpy().view(np.uint64)
+        res["locate_queries_per_s"] = nf / t_loc
+        res["locate_equals_closed_form"] = bool(total == nf and np.array_equal(located, mseq_torch.node_values(starts[:nf])))
+        d_nodes = torch.zeros((nf, 5), dtype=torch.int64, device=dev)
+        gpu.parent_device(sub.data_ptr(), nf, d_nodes.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize()
+        e0.record(st)
+        for _ in range(3):
+            gpu.parent_device(sub.data_ptr(), nf, d_nodes.data_ptr(), st.cuda_stream)
+        e1.record(st)
+        torch.cuda.synchronize()
+        res["parent_queries_per_s"] = nf / (e0.elapsed_time(e1) / 3 * 1e-3)
+        # closed form: the parent of the singleton with k-mer value v = rank + 1 is the set of values
+        # sharing the first L base-4 digits, L = max(lcp[rank], lcp[rank + 1])
+        k = args.degree // 2
+        lcp = ix.lcp_data[: ix.n].astype(np.int64)
+        r = exp[:nf, 0].astype(np.int64)
+        right = np.where(r + 1 < ix.n, lcp[np.minimum(r + 1, ix.n - 1)], 0)
+        L = np.maximum(lcp[r], right)
+        shift = 2 * (k - L)
+        lo_val = ((r + 1) >> shift) << shift
+        hi_val = lo_val + (np.int64(1) << shift) - 1
+        psp = np.maximum(lo_val, 1) - 1
+        pep = np.minimum(hi_val, ix.n) - 1
+        nodes = d_nodes.cpu().numpy()
+        ok = np.array_equal(nodes[:, 0], psp) and np.array_equal(nodes[:, 1], pep) and np.array_equal(nodes[:, 4], L)
+        res["parent_equals_closed_form"] = bool(ok)
     if args.oracle_sample > 0:
         from oracle.oracle import OracleIndex
         cpu = OracleIndex(ix, with_samples=False, with_counters=False, with_lcp=False)

@@ -14,8 +14,8 @@ import ctypes as C
 import numpy as np
 import torch
 
-from .graphs import SIGMA, FAST_CHARS, default_char2comp
-from .index_arrays import IndexArrays
+from .graphs import SIGMA, FAST_CHARS, ID_OFFSET, default_char2comp
+from .index_arrays import IndexArrays, bit_length, build_lcp_tree
 from .linear_torch import pack_bits_torch, splitmix64_torch, _lsr
 
 # primitive polynomials x^d + ... + 1 as tap lists (verified at run time by gcsa_mseq_text)
@@ -38,8 +38,22 @@ def mseq_text(degree: int):
     return sym, rank
 
 
-def build_mseq(degree: int, device=None, verbose=None):
-    """Returns (IndexArrays, sym tensor on `device`, rank numpy uint32)."""
+NODE_LEN = 32      # vg-style nodes of 32 positions: value = (p // 32 + 1) << 11 | p % 32
+
+
+def node_values(pos: np.ndarray) -> np.ndarray:
+    pos = pos.astype(np.uint64)
+    return ((pos // np.uint64(NODE_LEN) + np.uint64(1)) << np.uint64(ID_OFFSET)) | (pos % np.uint64(NODE_LEN))
+
+
+def build_mseq(degree: int, device=None, verbose=None, full: bool = False, branching: int = 64):
+    """Returns (IndexArrays, sym tensor on `device`, rank numpy uint32).
+
+    full = True also derives, in closed form, the samples (position p carries the value
+    node_values(p); a node is sampled iff p % 32 == 0, which is what the rules of
+    src/gcsa.cpp:621-646 give for these values), the counters (one value per node: A = 0, R = 0)
+    and the LCP array: adjacent rotations j-1, j hold the k-mer values j, j+1, so their common
+    prefix is k - 1 - (number of trailing base-4 digits of j equal to 3)."""
     if device is None:
         device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
     sym, rank = mseq_text(degree)
@@ -73,15 +87,64 @@ def build_mseq(degree: int, device=None, verbose=None):
     edges = pack_bits_torch(torch.ones(N, dtype=torch.bool, device=device))
     if verbose:
         verbose("B_c and edges packed")
-    ix = IndexArrays(
-        n=N, e=N, order=degree // 2, sigma=SIGMA, fast_chars=FAST_CHARS, char2comp=default_char2comp(), C=Carr,
-        bwt=bwt, edges=edges, sampled_paths=zero, sample_count=0, sample_width=1,
-        stored_samples=np.zeros(2, dtype=np.uint64), stored_samples_plain=np.zeros(0, dtype=np.uint64),
-        samples=np.zeros(2, dtype=np.uint64), extra_filter=zero, extra_values_len=0,
-        extra_values=np.zeros(2, dtype=np.uint64), redundant_len=0, redundant=np.zeros(2, dtype=np.uint64),
-        lcp_size=0, lcp_branching=64, lcp_offsets=np.zeros(2, dtype=np.uint64), lcp_data=np.zeros(1, dtype=np.uint8),
-        table=None)
+    extras = dict(sampled_paths=zero, sample_count=0, sample_width=1,
+                  stored_samples=np.zeros(2, dtype=np.uint64), stored_samples_plain=np.zeros(0, dtype=np.uint64),
+                  samples=np.zeros(2, dtype=np.uint64), extra_filter=zero, extra_values_len=0,
+                  extra_values=np.zeros(2, dtype=np.uint64), redundant_len=0, redundant=np.zeros(2, dtype=np.uint64),
+                  lcp_size=0, lcp_branching=branching, lcp_offsets=np.zeros(2, dtype=np.uint64),
+                  lcp_data=np.zeros(1, dtype=np.uint8))
+    if full:
+        k = degree // 2
+        # samples: positions p = 0, 32, 64, ... in rank order
+        spos = np.arange(0, N, NODE_LEN, dtype=np.int64)
+        srank = rank[spos].astype(np.int64)
+        order = np.argsort(srank, kind="stable")
+        stored = node_values(spos[order])
+        S = int(stored.shape[0])
+        width = bit_length(int(stored.max()))
+        from . import builder as _b
+        lib = _b._load()
+        lib.gcsa_pack_ints.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        packed = np.zeros((S * width + 63) // 64 + 2, dtype=np.uint64)
+        lib.gcsa_pack_ints(stored.ctypes.data, S, width, packed.ctypes.data)
+        sampled = torch.zeros(N, dtype=torch.bool, device=device)
+        sampled[torch.from_numpy(srank).to(device)] = True
+        # LCP bytes in closed form
+        lcp = torch.empty(N, dtype=torch.uint8, device=device)
+        for b in range(0, N, chunk):
+            e = min(N, b + chunk)
+            j = torch.arange(b, e, dtype=torch.int64, device=device)
+            q = torch.zeros(e - b, dtype=torch.int64, device=device)
+            run = torch.ones(e - b, dtype=torch.bool, device=device)
+            for m in range(k):
+                run &= ((j >> (2 * m)) & 3) == 3
+                q += run.to(torch.int64)
+            lcp[b:e] = (k - 1 - q).clamp(min=0).to(torch.uint8)
+        lcp[0] = 0
+        lcp_data, lcp_offsets = build_lcp_tree(lcp.cpu().numpy(), branching)
+        extras = dict(sampled_paths=pack_bits_torch(sampled), sample_count=S, sample_width=width,
+                      stored_samples=packed, stored_samples_plain=stored,
+                      samples=pack_bits_torch(torch.ones(S, dtype=torch.bool, device=device)),
+                      extra_filter=zero, extra_values_len=0, extra_values=np.zeros(2, dtype=np.uint64),
+                      redundant_len=N - 1, redundant=pack_bits_torch(torch.ones(N - 1, dtype=torch.bool, device=device)),
+                      lcp_size=N, lcp_branching=branching, lcp_offsets=lcp_offsets,
+                      lcp_data=np.ascontiguousarray(lcp_data))
+        del sampled, lcp
+        if verbose:
+            verbose(f"samples ({S}), counters and LCP derived in closed form")
+    ix = IndexArrays(n=N, e=N, order=degree // 2, sigma=SIGMA, fast_chars=FAST_CHARS, char2comp=default_char2comp(),
+                     C=Carr, bwt=bwt, edges=edges, table=None, **extras)
     return ix, sym_t, rank
+
+
+def cycle_graph(degree: int):
+    """The input graph of the m-sequence text: one cycle of N positions (no source / sink)."""
+    from .graphs import Graph
+    sym, rank = mseq_text(degree)
+    N = sym.shape[0]
+    succ = np.roll(np.arange(N, dtype=np.uint32), -1)
+    return Graph(comp=(sym + 1).astype(np.uint8), value=node_values(np.arange(N)), succ_off=np.arange(N + 1, dtype=np.uint64),
+                 succ=succ, source=0, sink=N - 1)
 
 
 def substring_patterns(sym_t: torch.Tensor, rank: np.ndarray, nq: int, m: int, seed: int):
