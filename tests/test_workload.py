@@ -87,3 +87,35 @@ def test_mseq_closed_form_equals_general_builder(degree):
     assert np.array_equal(a.lcp_data, b.lcp_data) and np.array_equal(a.lcp_offsets, b.lcp_offsets)
     assert a.extra_values_len == b.extra_values_len == 0 and a.redundant_len == b.redundant_len
     assert np.array_equal(a.redundant[: (a.redundant_len + 63) // 64], b.redundant[: (b.redundant_len + 63) // 64])
+
+
+def test_oracle_locate_parent_closed_form():
+    """Oracle locate() / parent() / count() against the closed forms of the m-sequence index."""
+    import torch
+    from workload import mseq_torch
+    from oracle.oracle import OracleIndex
+    degree, k = 12, 6
+    ix, sym_t, rank = mseq_torch.build_mseq(degree, device=torch.device("cpu"), full=True)
+    cpu = OracleIndex(ix)
+    pos = np.arange(0, ix.n, 7)
+    r = rank[pos].astype(np.uint64)
+    ranges = np.stack([r, r], axis=1)
+    offs, vals = cpu.locate_batch(ranges)
+    assert np.array_equal(vals, mseq_torch.node_values(pos)) and np.array_equal(np.diff(offs), np.ones(len(pos), dtype=np.uint64))
+    assert np.array_equal(cpu.count_batch(ranges), np.ones(len(pos), dtype=np.uint64))
+    lcpv = ix.lcp_data[: ix.n].astype(np.int64)
+    ri = r.astype(np.int64)
+    L = np.maximum(lcpv[ri], np.where(ri + 1 < ix.n, lcpv[np.minimum(ri + 1, ix.n - 1)], 0))
+    shift = 2 * (k - L)
+    lo = ((ri + 1) >> shift) << shift
+    par = cpu.parent_batch(ranges)
+    assert np.array_equal(par["sp"].astype(np.int64), np.maximum(lo, 1) - 1)
+    assert np.array_equal(par["ep"].astype(np.int64), np.minimum(lo + (np.int64(1) << shift) - 1, ix.n) - 1)
+    assert np.array_equal(par["node_lcp"].astype(np.int64), L)
+    # a wider range: all rotations starting with a given 3-mer -> 4^(k-3) values, the start positions of that 3-mer
+    sym = sym_t.numpy()
+    pat = bytes(b"ACGT"[s] for s in sym[100:103])
+    rng = cpu.find(pat)
+    occ = [p for p in range(ix.n) if all(sym[(p + j) % ix.n] == sym[100 + j] for j in range(3))]
+    assert rng[1] - rng[0] + 1 == len(occ)
+    assert cpu.locate(rng).tolist() == sorted(int(v) for v in mseq_torch.node_values(np.array(occ)))
