@@ -90,27 +90,54 @@ struct Stager
 
 struct BVPlan { u64 blocks_off = 0, hints_off = 0, size = 0, nblocks = 0, ones = 0; bool hints = false; };
 
+// Run fn(begin, end) over [0, n) on several host threads (image staging of multi-GB indexes).
+template<class F> void parallel_ranges(u64 n, F fn)
+{
+  unsigned hw = std::thread::hardware_concurrency();
+  u64 threads = (hw == 0 ? 4 : (hw > 32 ? 32 : hw));
+  if(n < (u64(1) << 16)) { threads = 1; }
+  if(threads <= 1) { fn(u64(0), n); return; }
+  std::vector<std::thread> pool;
+  u64 per = (n + threads - 1) / threads;
+  for(u64 t = 0; t < threads; t++)
+  {
+    u64 b = t * per, e = (b + per < n ? b + per : n);
+    if(b >= e) { break; }
+    pool.emplace_back([=]() { fn(b, e); });
+  }
+  for(std::thread& t : pool) { t.join(); }
+}
+
 BVPlan stage_bv(Stager& st, const u64* plain, u64 size, bool with_select)
 {
   BVPlan p;
   p.size = size; p.nblocks = size / BLOCK_BITS + 1; p.hints = with_select;
   p.blocks_off = st.reserve(p.nblocks * BLOCK_WORDS);
-  u64 total_words = (size + 63) / 64, cumul = 0;
-  for(u64 b = 0; b < p.nblocks; b++)
+  const u64 total_words = (size + 63) / 64;
+  u64* base = st.words.data() + p.blocks_off;
+  // pass 1: payload words and per-block popcounts (kept in word 0 for the moment)
+  parallel_ranges(p.nblocks, [=](u64 b0, u64 b1)
   {
-    u64* dst = st.words.data() + p.blocks_off + b * BLOCK_WORDS;
-    dst[0] = cumul;
-    for(u64 j = 0; j < PAYLOAD_WORDS; j++)
+    for(u64 b = b0; b < b1; b++)
     {
-      u64 w = b * PAYLOAD_WORDS + j, val = 0;
-      if(w < total_words)
+      u64* dst = base + b * BLOCK_WORDS;
+      u64 ones = 0;
+      for(u64 j = 0; j < PAYLOAD_WORDS; j++)
       {
-        val = plain[w];
-        if(w == (size >> 6) && (size & 63)) { val &= (u64(1) << (size & 63)) - 1; }
+        u64 w = b * PAYLOAD_WORDS + j, val = 0;
+        if(w < total_words)
+        {
+          val = plain[w];
+          if(w == (size >> 6) && (size & 63)) { val &= (u64(1) << (size & 63)) - 1; }
+        }
+        dst[1 + j] = val; ones += u64(__builtin_popcountll(val));
       }
-      dst[1 + j] = val; cumul += u64(__builtin_popcountll(val));
+      dst[0] = ones;
     }
-  }
+  });
+  // pass 2: exclusive prefix sum over the blocks
+  u64 cumul = 0;
+  for(u64 b = 0; b < p.nblocks; b++) { u64 ones = base[b * BLOCK_WORDS]; base[b * BLOCK_WORDS] = cumul; cumul += ones; }
   p.ones = cumul;
   if(with_select)
   {
@@ -130,7 +157,7 @@ BVPlan stage_bv(Stager& st, const u64* plain, u64 size, bool with_select)
 
 // Fused LF blocks (layout.hpp "FLB128") and the charRange table, built on the host from the plain
 // B_c and edges bits.
-u64 stage_flb(Stager& st, const gcsa2_host_view* v, DevImage& img)
+u64 stage_flb(Stager& st, const gcsa2_host_view* v, DevImage& img, const std::vector<u64>& bwt_blocks_off)
 {
   const u64 n = v->path_nodes, e = v->edges, sigma = v->sigma;
   const u64 ewords = (e + 63) / 64;
@@ -161,32 +188,33 @@ u64 stage_flb(Stager& st, const gcsa2_host_view* v, DevImage& img)
     img.crange[2 * c + 1] = erank(v->C[c + 1] - 1);
   }
 
-  const u64 nblocks = n / BLOCK_BITS + 1, nwords = (n + 63) / 64;
+  const u64 nblocks = n / BLOCK_BITS + 1;
   img.flb_nblocks = nblocks;
   u64 off = st.reserve(sigma * nblocks * FLB_WORDS, FLB_WORDS);
+  u64* words = st.words.data();
   for(u64 c = 0; c < sigma; c++)
   {
-    const u64* plain = v->bwt[c];
-    u64 cumul = 0;
-    for(u64 b = 0; b < nblocks; b++)
+    // the RB64 copy of B_c staged just before holds payload words and cumulative counts already
+    const u64* rb = words + bwt_blocks_off[c];
+    u64* dst_base = words + off + c * nblocks * FLB_WORDS;
+    const u64 Cc = v->C[c];
+    parallel_ranges(nblocks, [=, &ew, &ecum](u64 b0, u64 b1)
     {
-      u64* dst = st.words.data() + off + (c * nblocks + b) * FLB_WORDS;
-      u64 ecnt = v->C[c] + cumul;
-      u64 prev = (ecnt > 0 && ecnt - 1 < e) ? ((ew[(ecnt - 1) >> 6] >> ((ecnt - 1) & 63)) & 1) : 0;
-      dst[0] = ecnt;
-      dst[1] = erank(ecnt) | (prev << 63);
-      for(u64 j = 0; j < PAYLOAD_WORDS; j++)
+      for(u64 b = b0; b < b1; b++)
       {
-        u64 w = b * PAYLOAD_WORDS + j, val = 0;
-        if(w < nwords)
+        const u64* src = rb + b * BLOCK_WORDS;
+        u64* dst = dst_base + b * FLB_WORDS;
+        u64 ecnt = Cc + src[0];
+        u64 prev = (ecnt > 0 && ecnt - 1 < e) ? ((ew[(ecnt - 1) >> 6] >> ((ecnt - 1) & 63)) & 1) : 0;
+        dst[0] = ecnt;
+        dst[1] = erank(ecnt) | (prev << 63);
+        for(u64 j = 0; j < PAYLOAD_WORDS; j++)
         {
-          val = plain[w];
-          if(w == (n >> 6) && (n & 63)) { val &= (u64(1) << (n & 63)) - 1; }
+          dst[2 + j] = src[1 + j];
+          dst[9 + j] = ebits(ecnt + 64 * j);
         }
-        dst[2 + j] = val; cumul += u64(__builtin_popcountll(val));
-        dst[9 + j] = ebits(ecnt + 64 * j);
       }
-    }
+    });
   }
   return off;
 }
@@ -288,7 +316,9 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       }
     }
     BVPlan edges = stage_bv(st, v->edge_bits, img.e, false);
-    u64 flb_off = stage_flb(st, v, img);
+    std::vector<u64> bwt_blocks_off(v->sigma);
+    for(u64 c = 0; c < v->sigma; c++) { bwt_blocks_off[c] = bwt[c].blocks_off; }
+    u64 flb_off = stage_flb(st, v, img, bwt_blocks_off);
     BVPlan sampled, samples, xfilter, xvalues, redundant;
     u64 stored_off = 0, lcp_off = 0;
     img.has_samples = (v->sampled_path_bits != nullptr);

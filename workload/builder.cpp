@@ -426,32 +426,64 @@ int gcsa_mseq_text(int degree, const int* taps, int ntaps, u8* sym, u32* rank)
 {
   if(degree < 4 || degree > 32 || (degree & 1)) { return -2; }
   const u64 period = (u64(1) << degree) - 1, mask = period;
-  u64 tapmask = 0;
-  for(int t = 0; t < ntaps; t++) { tapmask |= u64(1) << (degree - taps[t]); }   // Fibonacci LFSR, window = next d output bits
-  // state = the next `degree` output bits, MSB = next bit; new bit = parity(state & tapmask')
-  // Use the recurrence a[n + d] = XOR of a[n + d - tap] over taps (tap = d contributes a[n]).
-  u64 state = 1;           // any non-zero start
-  const u64 start = state;
+  // Fibonacci LFSR on the window of the next `degree` output bits (MSB = oldest = first bit of the
+  // rotation): a[n + d] = XOR of a[n + d - tap] over the taps.  The step is linear over GF(2).
   auto step = [&](u64 st) -> u64
   {
     u64 fb = 0;
-    for(int t = 0; t < ntaps; t++) { fb ^= (st >> (taps[t] - 1)) & 1; }   // bit (tap - 1) counted from the LSB = a[n + d - tap]
+    for(int t = 0; t < ntaps; t++) { fb ^= (st >> (taps[t] - 1)) & 1; }
     return ((st << 1) | fb) & mask;
   };
-  (void)tapmask;
-  // symbol i consumes output bits 2i, 2i + 1; the window of rotation i is the state before them.
-  // Here the state's MSB is the OLDEST bit of the window, i.e. the first bit of the rotation.
-  for(u64 i = 0; i < period; i++)
+  // transition matrix A (column c = image of bit c) and its powers A^(2^j), for jump-ahead
+  typedef std::vector<u64> Mat;
+  auto mat_vec = [&](const Mat& M, u64 v) -> u64
   {
-    rank[i] = u32(state - 1);
-    sym[i] = u8((state >> (degree - 2)) & 3);
-    state = step(step(state));
+    u64 r = 0;
+    while(v) { int c = __builtin_ctzll(v); v &= v - 1; r ^= M[size_t(c)]; }
+    return r;
+  };
+  std::vector<Mat> power(size_t(degree) + 2, Mat(size_t(degree), 0));
+  for(int c = 0; c < degree; c++) { power[0][size_t(c)] = step(u64(1) << c); }
+  for(size_t j = 1; j < power.size(); j++)
+  {
+    for(int c = 0; c < degree; c++) { power[j][size_t(c)] = mat_vec(power[j - 1], power[j - 1][size_t(c)]); }
   }
-  // after `period` symbols = 2 * period bits the state must be back at the start, and not earlier
-  if(state != start) { return -1; }
-  u64 st = start, n = 0;
-  do { st = step(st); n++; } while(st != start && n <= period);
-  return n == period ? 0 : -1;
+  auto jump = [&](u64 st, u64 steps) -> u64      // A^steps * st
+  {
+    for(size_t j = 0; steps != 0; j++, steps >>= 1) { if(steps & 1) { st = mat_vec(power[j], st); } }
+    return st;
+  };
+  const u64 start = 1;
+  // primitivity: A^period fixes the start state and A^(period / p) does not, for every prime p | period
+  if(jump(start, period) != start) { return -1; }
+  {
+    u64 rest = period;
+    for(u64 p = 2; p * p <= rest; p++)
+    {
+      if(rest % p != 0) { continue; }
+      while(rest % p == 0) { rest /= p; }
+      if(jump(start, period / p) == start) { return -1; }
+    }
+    if(rest > 1 && rest != period && jump(start, period / rest) == start) { return -1; }
+    if(rest == period && period > 1 && false) { return -1; }
+  }
+  // symbol i consumes output bits 2i, 2i + 1; the window of rotation i is the state before them
+  const int threads = omp_get_max_threads();
+  const u64 chunks = u64(threads) * 4, per = (period + chunks - 1) / chunks;
+  #pragma omp parallel for schedule(dynamic, 1)
+  for(u64 ch = 0; ch < chunks; ch++)
+  {
+    u64 begin = ch * per, end = begin + per < period ? begin + per : period;
+    if(begin >= end) { continue; }
+    u64 state = jump(start, 2 * begin);
+    for(u64 i = begin; i < end; i++)
+    {
+      rank[i] = u32(state - 1);
+      sym[i] = u8((state >> (degree - 2)) & 3);
+      state = step(step(state));
+    }
+  }
+  return 0;
 }
 
 }  // extern "C"
