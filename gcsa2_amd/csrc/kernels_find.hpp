@@ -129,6 +129,32 @@ __device__ __forceinline__ void eval_endpoint(const ulonglong2 (&blk)[8], u32 r,
   node = ncnt + cnt;
 }
 
+// One lane evaluates LF(range, comp) from the fused blocks on its own (no cooperation): used where
+// lanes run independently (matching statistics).  Returns the edge-space pair (a, b) and, when it is
+// not empty, the node-space range.  One 128-byte block per endpoint instead of two dependent
+// 64-byte fetches (B_c, then edges).
+__device__ __forceinline__ void lf_fused_lane(const DevImage& img, u32 comp, u64 sp, u64 ep,
+                                              u64& a, u64& b, u64& nsp, u64& nep)
+{
+  const u64 e1 = ep + 1;
+  const u64 b_sp = sp / BLOCK_BITS, b_ep = e1 / BLOCK_BITS;
+  const u64* base = img.flb + u64(comp) * img.flb_nblocks * FLB_WORDS;
+  ulonglong2 blk[8];
+  const ulonglong2* src = reinterpret_cast<const ulonglong2*>(base + b_sp * FLB_WORDS);
+#pragma unroll
+  for(u32 k = 0; k < 8; k++) { blk[k] = src[k]; }
+  u64 e_ep, n_ep;
+  eval_endpoint(blk, u32(sp - b_sp * BLOCK_BITS), 0, a, nsp);
+  if(b_ep != b_sp)
+  {
+    src = reinterpret_cast<const ulonglong2*>(base + b_ep * FLB_WORDS);
+#pragma unroll
+    for(u32 k = 0; k < 8; k++) { blk[k] = src[k]; }
+  }
+  eval_endpoint(blk, u32(e1 - b_ep * BLOCK_BITS), 1, e_ep, n_ep);
+  b = e_ep - 1; nep = n_ep;
+}
+
 // wave-cooperative fetch: every lane with need != 0 gets flb block `idx` staged at its slot
 __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane)
 {

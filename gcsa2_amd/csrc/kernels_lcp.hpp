@@ -2,7 +2,7 @@
 // Part of the single translation unit gcsa2_hip.hip (device code, anonymous namespace).
 #pragma once
 
-#include "kernels_common.hpp"
+#include "kernels_find.hpp"
 
 using namespace g2;
 
@@ -277,16 +277,13 @@ __global__ __launch_bounds__(TPB) void k_match_stats(DevImage img, const u8* __r
   for(u64 i = len; i-- > 0; )
   {
     u32 comp = t.c2c[p[i]];
-    DevBV bv = bwt_of(img, comp);
     while(true)
     {
-      u64 ra, rb;
-      bv_rank2(bv, sp, ep + 1, ra, rb);
-      u64 a = t.C[comp] + ra, b = t.C[comp] + rb - 1;
+      u64 a, b, nsp, nep;
+      lf_fused_lane(img, comp, sp, ep, a, b, nsp, nep);          // gcsa.h:155-162
       if(!range_empty(a, b))
       {
-        path_node_range(img, a, b);
-        sp = a; ep = b; depth++;
+        sp = nsp; ep = nep; depth++;
         break;
       }
       if(sp == 0 && ep == img.n - 1) { depth = 0; break; }     // at the root: no such character
