@@ -34,7 +34,7 @@ EXPORTS = [
     "gcsa2_lcp_size", "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching",
     "gcsa2_lcp_access_batch",
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
-    "gcsa2_group_find_batch", "gcsa2_count_kmers", "gcsa2_match_stats_batch", "gcsa2_match_stats_device",
+    "gcsa2_group_find_batch", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_match_stats_batch", "gcsa2_match_stats_device",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file",
 ]
@@ -103,6 +103,7 @@ def load_library():
     L.gcsa2_alphabet.restype = None
     L.gcsa2_lcp_access_batch.argtypes = [vp, u64p, u64, u64p]
     L.gcsa2_count_kmers.argtypes = [vp, u64, i32, i32, u64p]
+    L.gcsa2_compare_kmers.argtypes = [vp, vp, u64, i32, i32, u64p]
     L.gcsa2_host_view_save.argtypes = [C.POINTER(HostView), C.c_char_p]
     L.gcsa2_host_view_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.gcsa2_host_view_get.argtypes = [vp]
@@ -382,6 +383,12 @@ class GCSA:
         cnt = C.c_uint64()
         _check(self._L.gcsa2_locate_max(self._h, rng[0], rng[1], max_positions, _p64(values), cap, C.byref(cnt)))
         return values[: cnt.value]
+
+    def compare_kmers(self, other, k, include_Ns=False, force=False):
+        """`compareKMers(self, other, k)` (reference src/algorithms.cpp:534-616): (shared, left, right)."""
+        out = np.zeros(3, dtype=np.uint64)
+        _check(self._L.gcsa2_compare_kmers(self._h, other._h, k, int(include_Ns), int(force), _p64(out)))
+        return tuple(int(x) for x in out)
 
     def match_stats_batch(self, patterns, offsets):
         """Matching statistics by fused LF + parent (needs the LCP array):

@@ -1379,3 +1379,47 @@ extern "C" int gcsa2_index_create_from_file(const char* path, int device, gcsa2_
   gcsa2_host_view_free(st);
   return rc;
 }
+
+// compareKMers(left, right, k, parameters) (src/algorithms.cpp:534-616): counts only.
+extern "C" int gcsa2_compare_kmers(const gcsa2_index* left, const gcsa2_index* right, uint64_t k, int include_ns, int force,
+                                   uint64_t* result)
+{
+  CHECK_INDEX(left); CHECK_INDEX(right);
+  if(result == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null result"); }
+  result[0] = result[1] = result[2] = 0;
+  if(k == 0) { result[0] = 1; return GCSA2_OK; }                                            // :539
+  if((k > left->order || k > right->order) && !force) { return GCSA2_OK; }                   // :540-549
+  if(k > 64) { return GCSA2_OK; }                                                            // :550-554 (MAX_K)
+  if(left->img.sigma != right->img.sigma || left->img.fast_chars != right->img.fast_chars) { return GCSA2_OK; }   // :556-560
+  if(left->device != right->device) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "both indexes must live on the same device"); }
+  if(left->img.n == 0 || right->img.n == 0 || left->img.sigma < 3) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "empty index or alphabet too small"); }
+  const u32 limit = u32(include_ns ? left->img.sigma - 2 : left->img.fast_chars);
+  DeviceGuard guard(left->device);
+  DBuf<DevImage> images; DBuf<unsigned long long> counters;
+  HIP_TRY(images.alloc(2)); HIP_TRY(counters.alloc(4));
+  HIP_TRY(hipMemcpy(images.p, &left->img, sizeof(DevImage), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(images.p + 1, &right->img, sizeof(DevImage), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(counters.p, 0, 4 * sizeof(unsigned long long)));
+  DBuf<u64> frontier;
+  HIP_TRY(frontier.alloc(4));
+  u64 root[4] = {0, left->img.n - 1, 0, right->img.n - 1};
+  HIP_TRY(hipMemcpy(frontier.p, root, sizeof(root), hipMemcpyHostToDevice));
+  u64 n = 1;
+  for(u64 depth = 0; depth < k && n > 0; depth++)
+  {
+    const bool last = (depth + 1 == k);
+    if(n * limit > (u64(1) << 27)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "compareKMers frontier exceeds 2^27 states; use a smaller k"); }
+    DBuf<u64> next;
+    if(!last) { HIP_TRY(next.alloc(n * limit * 4)); }
+    HIP_TRY(hipMemset(counters.p, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, images.p, images.p + 1, frontier.p, n, limit,
+                       last ? 1 : 0, next.p, counters.p);
+    LAUNCH_CHECK("k_kmer_compare");
+    unsigned long long host_counters[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(host_counters, counters.p, sizeof(host_counters), hipMemcpyDeviceToHost));
+    if(last) { result[0] = host_counters[1]; result[1] = host_counters[2]; result[2] = host_counters[3]; break; }
+    n = host_counters[0];
+    std::swap(frontier.p, next.p);      // `next` now owns the old frontier and frees it
+  }
+  return GCSA2_OK;
+}

@@ -208,6 +208,73 @@ __global__ __launch_bounds__(TPB) void k_kmer_expand(DevImage img, const u64* __
   }
 }
 
+// ---- compareKMers frontier expansion (src/algorithms.cpp:505-616) ------------------------------
+// A state is a pair of ranges, one per index; a child survives if it is non-empty in at least one
+// index.  The two images are read through pointers (two DevImage values would not fit the 4 KB
+// kernel-argument segment).  final != 0: classify the children instead of storing them:
+// counters[1] += shared, counters[2] += left only, counters[3] += right only.
+__device__ __forceinline__ void lf_child(const DevImage& img, u32 c, u64 sp0, u64 ep0, u64& sp, u64& ep)
+{
+  sp = 1; ep = 0;
+  if(range_empty(sp0, ep0)) { return; }
+  DevBV bv = bwt_of(img, c);
+  if(sp0 == ep0)          // single path node: bit probe (gcsa.cpp:748-757)
+  {
+    u64 rk;
+    if(bv_get_rank(bv, sp0, rk)) { sp = ep = bv_rank(img.edges, img.C[c] + rk); }
+  }
+  else
+  {
+    u64 ra, rb;
+    bv_rank2(bv, sp0, ep0 + 1, ra, rb);
+    sp = img.C[c] + ra; ep = img.C[c] + rb - 1;
+    if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_kmer_compare(const DevImage* __restrict__ left, const DevImage* __restrict__ right,
+                                                      const u64* __restrict__ in, u64 n_in, u32 limit, int final,
+                                                      u64* __restrict__ out, unsigned long long* __restrict__ counters)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  const u32 lane = threadIdx.x & 63;
+  bool live = q < n_in;
+  ulonglong2 l = make_ulonglong2(1, 0), r = make_ulonglong2(1, 0);
+  if(live) { l = reinterpret_cast<const ulonglong2*>(in)[2 * q]; r = reinterpret_cast<const ulonglong2*>(in)[2 * q + 1]; }
+  for(u32 c = 1; c <= limit; c++)
+  {
+    u64 lsp = 1, lep = 0, rsp = 1, rep = 0;
+    if(live) { lf_child(*left, c, l.x, l.y, lsp, lep); lf_child(*right, c, r.x, r.y, rsp, rep); }
+    const bool lhas = live && !range_empty(lsp, lep), rhas = live && !range_empty(rsp, rep);
+    const bool has = lhas || rhas;
+    if(final)
+    {
+      u64 both = __ballot(lhas && rhas), lonly = __ballot(lhas && !rhas), ronly = __ballot(rhas && !lhas);
+      if(lane == 0)
+      {
+        if(both) { atomicAdd(counters + 1, (unsigned long long)__popcll(both)); }
+        if(lonly) { atomicAdd(counters + 2, (unsigned long long)__popcll(lonly)); }
+        if(ronly) { atomicAdd(counters + 3, (unsigned long long)__popcll(ronly)); }
+      }
+      continue;
+    }
+    u64 mask = __ballot(has);
+    if(mask != 0)
+    {
+      u32 leader = u32(__ffsll((long long)mask)) - 1;
+      unsigned long long base = 0;
+      if(lane == leader) { base = atomicAdd(counters, (unsigned long long)__popcll(mask)); }
+      base = __shfl(base, leader, 64);
+      if(has && out != nullptr)
+      {
+        u64 slot = base + __popcll(mask & ((u64(1) << lane) - 1));
+        reinterpret_cast<ulonglong2*>(out)[2 * slot] = make_ulonglong2(lsp, lep);
+        reinterpret_cast<ulonglong2*>(out)[2 * slot + 1] = make_ulonglong2(rsp, rep);
+      }
+    }
+  }
+}
+
 // ---- locate ------------------------------------------------------------------------------
 
 // per query: number of path nodes to walk and number of values before deduplication

@@ -248,6 +248,14 @@ int gcsa2_lcp_access_batch(const gcsa2_index* index, const uint64_t* positions, 
  * force != 0, k == 0 yields 1, as in the reference. */
 int gcsa2_count_kmers(const gcsa2_index* index, uint64_t k, int include_ns, int force, uint64_t* result);
 
+/* compareKMers(left, right, k, parameters) (include/gcsa/algorithms.h:86-92, src/algorithms.cpp:534-616):
+ * result[0..2] = number of k-mers in both indexes, only in the left, only in the right one (counts
+ * only: the reference's optional .left / .right dumps are not produced).  Same early exits as the
+ * reference (k == 0 -> {1,0,0}; k > order without force, k > 64, incompatible alphabets -> zeros).
+ * Both indexes must be on the same device. */
+int gcsa2_compare_kmers(const gcsa2_index* left, const gcsa2_index* right, uint64_t k, int include_ns,
+                        int force, uint64_t* result);
+
 /* ---- matching statistics: the LF + parent interplay of vg's MEM finder, fused ---------------
  * (paper/paper.tex:344 "maximal exact matches by using LF-mapping and parent
  * queries").  Composition of GCSA::LF(range, comp) (gcsa.h:155-162) and LCPArray::parent(range)

@@ -21,6 +21,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <array>
 #include <vector>
 
 namespace gcsa
@@ -355,6 +356,17 @@ inline size_type countKMers(const GCSA& index, size_type k, const KMerSearchPara
   size_type result = 0;
   check(gcsa2_count_kmers(index.handle, k, parameters.include_Ns ? 1 : 0, parameters.force ? 1 : 0, &result), "countKMers()");
   return result;
+}
+
+// compareKMers(left, right, k, parameters) (include/gcsa/algorithms.h:86-92): {shared, left only, right only}.
+// The reference prints the unique k-mers to parameters.output + ".left"/".right"; only the counts are produced here.
+inline std::array<size_type, 3> compareKMers(const GCSA& left, const GCSA& right, size_type k,
+                                             const KMerSearchParameters& parameters = KMerSearchParameters())
+{
+  uint64_t result[3] = {0, 0, 0};
+  check(gcsa2_compare_kmers(left.handle, right.handle, k, parameters.include_Ns ? 1 : 0, parameters.force ? 1 : 0, result),
+        "compareKMers()");
+  return {size_type(result[0]), size_type(result[1]), size_type(result[2])};
 }
 
 } // namespace gcsa

@@ -1032,3 +1032,47 @@ double oracle_match_stats_batch(const oracle_index* ix, const uint8_t* patterns,
   }
   return omp_get_wtime() - start;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* compareKMers (src/algorithms.cpp:505-616): simultaneous search of two indexes; result =       */
+/* { k-mers in both, only in the left index, only in the right index }.  Counts only (the        */
+/* reference can also dump the unshared k-mers to files, algorithms.cpp:606-610).                 */
+
+typedef struct { u64 lsp, lep, rsp, rep, k; } cstate;
+
+void oracle_compare_kmers(const oracle_index* left, const oracle_index* right, uint64_t k, int include_ns, int force,
+                          uint64_t* result)
+{
+  result[0] = result[1] = result[2] = 0;
+  if(k == 0) { result[0] = 1; return; }                                                   /* :539 */
+  if((k > left->order || k > right->order) && !force) { return; }                         /* :540-549 */
+  if(k > 64) { return; }                                                                  /* :550-554, MAX_K */
+  if(left->sigma != right->sigma || left->fast_chars != right->fast_chars) { return; }    /* :556-560 */
+  u64 limit = (include_ns ? left->sigma : left->fast_chars + 2);                           /* :511 */
+  u64 cap = 1024, top = 0;
+  cstate* stack = (cstate*)malloc(cap * sizeof(cstate));
+  u64* lp = (u64*)malloc(2 * left->sigma * sizeof(u64));
+  u64* rp = (u64*)malloc(2 * right->sigma * sizeof(u64));
+  cstate root = { 0, left->n - 1, 0, right->n - 1, 0 };
+  stack[top++] = root;
+  while(top > 0)
+  {
+    cstate cur = stack[--top];
+    int le = range_empty(cur.lsp, cur.lep), re = range_empty(cur.rsp, cur.rep);
+    if(le && re) { continue; }                                                             /* :515 */
+    if(cur.k == k)                                                                         /* report, :473-491 */
+    {
+      if(!le && !re) { result[0]++; } else if(!le) { result[1]++; } else { result[2]++; }
+      continue;
+    }
+    oracle_lf_all(left, cur.lsp, cur.lep, include_ns, lp);                                 /* :519-526 */
+    oracle_lf_all(right, cur.rsp, cur.rep, include_ns, rp);
+    for(u64 comp = 1; comp + 1 < limit; comp++)
+    {
+      if(top == cap) { cap *= 2; stack = (cstate*)realloc(stack, cap * sizeof(cstate)); }
+      cstate next = { lp[2 * comp], lp[2 * comp + 1], rp[2 * comp], rp[2 * comp + 1], cur.k + 1 };
+      stack[top++] = next;
+    }
+  }
+  free(stack); free(lp); free(rp);
+}

@@ -100,6 +100,10 @@ void oracle_match_stats(const oracle_index* ix, const uint8_t* pattern, uint64_t
 double oracle_match_stats_batch(const oracle_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq,
                                 uint16_t* ms, uint64_t* ranges, uint64_t* fallbacks, int threads);
 
+/* compareKMers (src/algorithms.cpp:534-616): result = { shared, left only, right only }. */
+void oracle_compare_kmers(const oracle_index* left, const oracle_index* right, uint64_t k, int include_ns, int force,
+                          uint64_t* result);
+
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -78,6 +78,7 @@ def lib():
         L.oracle_count_kmers.argtypes = [vp, u64, i32, i32, u64, i32]
         L.oracle_match_stats_batch.restype = dbl
         L.oracle_match_stats_batch.argtypes = [vp, u8p, u64p, u64, vp, u64p, u64p, i32]
+        L.oracle_compare_kmers.argtypes = [vp, vp, u64, i32, i32, u64p]
         L.oracle_max_threads.restype = i32
         _lib = L
     return _lib
@@ -270,6 +271,12 @@ class OracleIndex:
         self.last_seconds = lib().oracle_match_stats_batch(self._h, _p8(patterns), _p64(offsets), nq, ms.ctypes.data,
                                                            _p64(ranges), _p64(fallbacks), threads)
         return ms[: int(offsets[nq])], ranges, fallbacks
+
+    def compare_kmers(self, other, k, include_Ns=False, force=False):
+        """`compareKMers(self, other, k)` (reference src/algorithms.cpp:534-616): (shared, left, right)."""
+        out = np.zeros(3, dtype=np.uint64)
+        lib().oracle_compare_kmers(self._h, other._h, k, int(include_Ns), int(force), _p64(out))
+        return tuple(int(x) for x in out)
 
     def find_traffic(self, patterns, offsets, block_bits):
         blocks, steps = C.c_uint64(), C.c_uint64()

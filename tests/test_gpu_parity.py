@@ -298,3 +298,18 @@ def test_create_from_container_file(engine, tmp_path):
     assert np.array_equal(go, co) and np.array_equal(gv, cv)
     assert (gpu.size(), gpu.edgeCount(), gpu.order(), gpu.sigma) == (ix.n, ix.e, ix.order, ix.sigma)
     assert gpu.char2comp.tolist() == ix.char2comp.tolist()
+
+
+def test_compare_kmers(engine):
+    """compareKMers (reference src/algorithms.cpp:534-616) on two graphs sharing a backbone."""
+    from oracle.oracle import OracleIndex
+    g1 = graphs.snp_graph(400, 0x52, 0x53, snp_period=8, node_len=8)
+    g2 = graphs.snp_graph(400, 0x52, 0x99, snp_period=6, node_len=8)
+    i1, i2 = build(g1, 8, sample_period=8, branching=4), build(g2, 8, sample_period=8, branching=4)
+    ga, gb = engine.GCSA(i1), engine.GCSA(i2)
+    ca, cb = OracleIndex(i1), OracleIndex(i2)
+    for k in range(0, 10):
+        for ns in (False, True):
+            assert ga.compare_kmers(gb, k, include_Ns=ns) == ca.compare_kmers(cb, k, include_Ns=ns), (k, ns)
+    assert ga.compare_kmers(gb, 12, force=True) == ca.compare_kmers(cb, 12, force=True)
+    assert ga.compare_kmers(ga, 6) == (ga.count_kmers(6), 0, 0)

@@ -288,3 +288,17 @@ def test_match_stats_vs_input_graph(case):
             while i + L < len(p) and L < K and gb.starts(comps[i:i + L + 1]):
                 L += 1
             assert min(int(ms[int(off[q]) + i]), K) == L, (name, p, i)
+
+
+def test_compare_kmers_vs_input_graphs():
+    """compareKMers == set algebra on the base-only k-mers spelled by the two input graphs."""
+    import itertools
+    g1 = graphs.snp_graph(120, 0x52, 0x53, snp_period=8, node_len=8)
+    g2 = graphs.snp_graph(120, 0x52, 0x99, snp_period=6, node_len=8)
+    a, b = OracleIndex(build(g1, 6, sample_period=8, branching=4)), OracleIndex(build(g2, 6, sample_period=8, branching=4))
+    A, B = GraphBrute(g1), GraphBrute(g2)
+    for k in range(0, 6):
+        sa = {t for t in itertools.product([1, 2, 3, 4], repeat=k) if A.starts(list(t))} if k else {()}
+        sb = {t for t in itertools.product([1, 2, 3, 4], repeat=k) if B.starts(list(t))} if k else {()}
+        assert a.compare_kmers(b, k) == (len(sa & sb), len(sa - sb), len(sb - sa)), k
+    assert a.compare_kmers(b, 7) == (0, 0, 0) and a.compare_kmers(a, 4)[1:] == (0, 0)
