@@ -36,7 +36,7 @@ EXPORTS = [
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
     "gcsa2_group_find_batch", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_match_stats_batch", "gcsa2_match_stats_device",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
-    "gcsa2_index_create_from_file",
+    "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
 ]
 
 
@@ -111,6 +111,8 @@ def load_library():
     L.gcsa2_host_view_free.argtypes = [vp]
     L.gcsa2_host_view_free.restype = None
     L.gcsa2_index_create_from_file.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.gcsa2_host_view_load_gcsa.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.gcsa2_index_create_from_gcsa.argtypes = [C.c_char_p, C.c_char_p, i32, C.POINTER(vp)]
     L.gcsa2_match_stats_batch.argtypes = [vp, u8p, u64p, u64, vp, u64p, u64p]
     L.gcsa2_match_stats_device.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
@@ -196,12 +198,16 @@ def save_host_view(index_arrays, path, **view_kwargs):
 
 
 class LoadedHostView:
-    """A G2HV file read back into host memory (host only); `.view` is the ctypes HostView."""
+    """A G2HV file, or a `.gcsa` (+ `.lcp`) pair, read back into host memory (host only); `.view` is
+    the ctypes HostView."""
 
-    def __init__(self, path):
+    def __init__(self, path, lcp_path=None):
         self._L = load_library()
         h = C.c_void_p()
-        _check(self._L.gcsa2_host_view_load(os.fsencode(path), C.byref(h)))
+        if os.fspath(path).endswith(".gcsa"):
+            _check(self._L.gcsa2_host_view_load_gcsa(os.fsencode(path), os.fsencode(lcp_path) if lcp_path else None, C.byref(h)))
+        else:
+            _check(self._L.gcsa2_host_view_load(os.fsencode(path), C.byref(h)))
         self._h = h
         self.view = self._L.gcsa2_host_view_get(h).contents
 
@@ -227,8 +233,16 @@ class GCSA:
     def __init__(self, index_arrays, device=0, **view_kwargs):
         L = load_library()
         h = C.c_void_p()
-        if isinstance(index_arrays, (str, bytes, os.PathLike)):      # a G2HV container file
-            _check(L.gcsa2_index_create_from_file(os.fsencode(index_arrays), device, C.byref(h)))
+        if isinstance(index_arrays, (str, bytes, os.PathLike)):      # a G2HV container or a `.gcsa` file (+ `.lcp` beside it)
+            path = os.fspath(index_arrays)
+            path = path.decode() if isinstance(path, bytes) else path
+            if path.endswith(".gcsa"):     # GCSA::EXTENSION / LCPArray::EXTENSION (gcsa.h:63, lcp.h:110)
+                # query_gcsa names the pair base.gcsa + base.lcp (benchmark/query_gcsa.cpp:53-63), vg base.gcsa + base.gcsa.lcp
+                beside = [p for p in (path[:-5] + ".lcp", path + ".lcp") if os.path.exists(p)]
+                lcp = view_kwargs.pop("lcp_path", beside[0] if beside else None)
+                _check(L.gcsa2_index_create_from_gcsa(os.fsencode(path), os.fsencode(lcp) if lcp else None, device, C.byref(h)))
+            else:
+                _check(L.gcsa2_index_create_from_file(os.fsencode(path), device, C.byref(h)))
             self._h, self._L = h, L
             self.sigma = int(L.gcsa2_sigma(h))
             self.fast_chars = int(L.gcsa2_fast_chars(h))
@@ -603,7 +617,8 @@ class GCSAGroup:
 
 
 def open_index(index_arrays, device=0):
-    """(GCSA, LCPArray) over one device image."""
+    """(GCSA, LCPArray) over one device image; `index_arrays` may be an IndexArrays, a G2HV file or a
+    `.gcsa` file with its `.lcp` beside it."""
     g = GCSA(index_arrays, device=device)
-    lcp = LCPArray(g, int(index_arrays.lcp_offsets[-1]), int(index_arrays.lcp_size))
+    lcp = LCPArray(g, int(g._L.gcsa2_lcp_values(g.handle)), int(g._L.gcsa2_lcp_size(g.handle)))
     return g, lcp

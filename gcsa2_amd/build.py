@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "gcsa2_hip.hip")
 DEPS = [SRC, os.path.join(os.path.dirname(HERE), "include", "gcsa2_hip.h")] + \
        [os.path.join(HERE, "csrc", f) for f in ("layout.hpp", "kernels_common.hpp", "kernels_find.hpp",
-                                                 "kernels_locate.hpp", "kernels_lcp.hpp")]
+                                                 "kernels_locate.hpp", "kernels_lcp.hpp", "sdsl_reader.hpp")]
 OUT = os.path.join(HERE, "lib", "libgcsa2_hip.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
@@ -36,6 +36,24 @@ def build_gather_bench(force=False):
         return BENCH_OUT
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-o", BENCH_OUT, BENCH_SRC])
     return BENCH_OUT
+
+
+ROOT = os.path.dirname(HERE)
+CLI_SRC = os.path.join(ROOT, "tools", "cpp", "query_gcsa.cpp")
+CLI_OUT = os.path.join(HERE, "lib", "query_gcsa")
+
+
+def build_query_gcsa(force=False):
+    """The reference's query_gcsa command line as a client of the C++ facade (host compiler only)."""
+    build()
+    deps = [CLI_SRC, os.path.join(ROOT, "include", "gcsa2_hip", "gcsa.hpp"), os.path.join(ROOT, "include", "gcsa2_hip.h")]
+    if not force and os.path.exists(CLI_OUT) and all(os.path.getmtime(CLI_OUT) >= os.path.getmtime(d) for d in deps):
+        return CLI_OUT
+    libdir = os.path.dirname(OUT)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), CLI_SRC, "-o", CLI_OUT,
+                           "-L", libdir, "-lgcsa2_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
+                           "-Wl,--allow-shlib-undefined"])
+    return CLI_OUT
 
 
 if __name__ == "__main__":

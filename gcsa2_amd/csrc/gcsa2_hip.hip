@@ -15,6 +15,7 @@
 //                       k_kmer_expand         countKMers                 src/algorithms.cpp:364-421
 //   kernels_lcp.hpp     k_parent / k_depth / k_sv / k_rmq   LCPArray     include/gcsa/lcp.h:137-178, src/lcp.cpp:276-519
 #include "layout.hpp"
+#include "sdsl_reader.hpp"
 #include "../../include/gcsa2_hip.h"
 
 #include <hipcub/hipcub.hpp>
@@ -1422,4 +1423,149 @@ extern "C" int gcsa2_compare_kmers(const gcsa2_index* left, const gcsa2_index* r
     std::swap(frontier.p, next.p);      // `next` now owns the old frontier and frees it
   }
   return GCSA2_OK;
+}
+
+// ---- `.gcsa` / `.lcp` files as written by GCSA::serialize / LCPArray::serialize ---------------------
+// Member order: src/gcsa.cpp:140-216 (GCSA), src/support.cpp:229-250 (Alphabet), :401-418 (SadaCount),
+// :493-516 (SadaSparse), src/files.cpp:513-537 / :581-603 (headers), src/lcp.cpp:116-143 (LCPArray).
+// SDSL container encodings: sdsl_reader.hpp (format parity unpinned, see its header).
+
+namespace {
+
+void load_gcsa_members(const char* path, gcsa2_view_storage& st)
+{
+  using namespace sdsl_file;
+  Mapping map(path);
+  Cursor in(map, std::string("GCSA::load(") + path + ")");
+  gcsa2_host_view& v = st.view;
+
+  // GCSAHeader (files.cpp:527-543): tag, version, path_nodes, edges, order, flags
+  u32 tag = in.get<u32>("header.tag"), version = in.get<u32>("header.version");
+  v.path_nodes = in.get<u64>("header.path_nodes"); v.edges = in.get<u64>("header.edges"); v.order = in.get<u64>("header.order");
+  u64 flags = in.get<u64>("header.flags");
+  if(tag != 0x6C5A6C5Au || version != 3 || flags != 0)
+  {
+    in.error("Invalid header: tag " + std::to_string(tag) + ", version " + std::to_string(version) + ", flags " + std::to_string(flags)
+             + " (expected GCSA version 3)");
+  }
+
+  // Alphabet (support.cpp:243-250)
+  IntVector char2comp = read_int_vector(in, 8, "alpha.char2comp");
+  read_int_vector(in, 8, "alpha.comp2char");
+  IntVector C = read_int_vector(in, 64, "alpha.C");
+  v.sigma = in.get<u64>("alpha.sigma"); v.fast_chars = in.get<u64>("alpha.fast_chars");
+  if(char2comp.size() != 256) { in.error("alpha.char2comp must have 256 entries"); }
+  if(v.sigma == 0 || v.sigma > GCSA2_MAX_SIGMA || C.size() != v.sigma + 1) { in.error("alphabet size out of range or alpha.C of the wrong length"); }
+  if(v.fast_chars >= v.sigma) { in.error("alpha.fast_chars out of range"); }
+
+  st.blobs.resize(2 + v.sigma + 9);
+  u64 b = 0;
+  char2comp.copy_words(st.blobs[b]); v.char2comp = reinterpret_cast<const uint8_t*>(st.blobs[b++].data());
+  C.copy_words(st.blobs[b]); v.C = st.blobs[b++].data();
+
+  // fast_bwt, fast_rank (empty), sparse_bwt, sparse_rank (empty): gcsa.cpp:196-202.  LF reads fast_bwt for
+  // 1 <= comp <= fast_chars and sparse_bwt otherwise (gcsa.h:262-274).
+  std::vector<std::vector<u64>> fast(v.sigma), sparse(v.sigma);
+  std::vector<u64> fast_size(v.sigma), sparse_size(v.sigma);
+  for(u64 c = 0; c < v.sigma; c++) { read_bit_vector_il(in, fast[c], fast_size[c], "fast_bwt"); }
+  for(u64 c = 0; c < v.sigma; c++) { read_sd_vector(in, sparse[c], sparse_size[c], "sparse_bwt"); }
+  for(u64 c = 0; c < v.sigma; c++)
+  {
+    const bool is_fast = (c > 0 && c <= v.fast_chars);
+    if((is_fast ? fast_size[c] : sparse_size[c]) != v.path_nodes) { in.error("BWT bitvector of comp " + std::to_string(c) + " does not have path_nodes bits"); }
+    st.blobs[b].swap(is_fast ? fast[c] : sparse[c]);
+    st.bwt.push_back(st.blobs[b++].data());
+  }
+  v.bwt = st.bwt.data();
+
+  u64 size = 0;
+  read_bit_vector_il(in, st.blobs[b], size, "edges");                   // + edge_rank (empty)
+  if(size != v.edges) { in.error("edges does not have header.edges bits"); }
+  v.edge_bits = st.blobs[b++].data();
+  read_bit_vector_il(in, st.blobs[b], size, "sampled_paths");           // + sampled_path_rank (empty)
+  if(size != v.path_nodes) { in.error("sampled_paths does not have path_nodes bits"); }
+  v.sampled_path_bits = st.blobs[b++].data();
+
+  IntVector stored = read_int_vector(in, 0, "stored_samples");
+  v.sample_count = stored.size(); v.sample_width = stored.width;
+  stored.copy_words(st.blobs[b]); v.stored_samples = st.blobs[b++].data();
+  read_bit_vector(in, st.blobs[b], size, "samples");
+  if(size != v.sample_count) { in.error("samples and stored_samples differ in length"); }
+  v.sample_bits = st.blobs[b++].data();
+  skip_select_mcl(in, "sample_select");
+
+  // extra_pointers (SadaSparse, support.cpp:509-516): filter, filter_rank (empty), values, value_select (empty)
+  read_sd_vector(in, st.blobs[b], size, "extra_pointers.filter");
+  if(size != v.path_nodes) { in.error("extra_pointers.filter does not have path_nodes bits"); }
+  v.extra_filter_bits = st.blobs[b++].data();
+  read_sd_vector(in, st.blobs[b], v.extra_values_len, "extra_pointers.values");
+  v.extra_values_bits = st.blobs[b++].data();
+  // redundant_pointers (SadaCount, support.cpp:414-418): data, select
+  read_bit_vector(in, st.blobs[b], v.redundant_len, "redundant_pointers.data");
+  v.redundant_bits = st.blobs[b++].data();
+  skip_select_mcl(in, "redundant_pointers.select");
+
+  if(!in.at_end()) { in.error(std::to_string(in.remaining()) + " unaccounted bytes after redundant_pointers"); }
+}
+
+void load_lcp_members(const char* path, gcsa2_view_storage& st)
+{
+  using namespace sdsl_file;
+  Mapping map(path);
+  Cursor in(map, std::string("LCP::load(") + path + ")");
+  gcsa2_host_view& v = st.view;
+
+  // LCPHeader (files.cpp:595-609): tag, version, size, branching, flags
+  u32 tag = in.get<u32>("header.tag"), version = in.get<u32>("header.version");
+  v.lcp_size = in.get<u64>("header.size"); v.lcp_branching = in.get<u64>("header.branching");
+  u64 flags = in.get<u64>("header.flags");
+  if(tag != 0x6C5A7C94u || version != 1 || flags != 0)
+  {
+    in.error("Invalid header: tag " + std::to_string(tag) + ", version " + std::to_string(version) + ", flags " + std::to_string(flags)
+             + " (expected LCP version 1)");
+  }
+  IntVector data = read_int_vector(in, 0, "data");
+  IntVector offsets = read_int_vector(in, 64, "offsets");
+  if(!in.at_end()) { in.error(std::to_string(in.remaining()) + " unaccounted bytes after offsets"); }
+  if(data.width > 8) { in.error("LCP values wider than 8 bits are not supported"); }
+  if(offsets.size() < 2 || offsets.size() - 1 > u64(MAX_LCP_LEVELS)) { in.error("offsets: number of levels out of range"); }
+  v.lcp_levels = offsets.size() - 1;
+  if(offsets.word(0) != 0 || offsets.word(1) != v.lcp_size || offsets.word(v.lcp_levels) != data.size()) { in.error("offsets do not match header.size / data"); }
+
+  st.blobs.emplace_back(); offsets.copy_words(st.blobs.back());
+  const u64* offsets_ptr = st.blobs.back().data();
+  st.blobs.emplace_back((data.size() + 7) / 8 + 2, 0);
+  uint8_t* bytes = reinterpret_cast<uint8_t*>(st.blobs.back().data());
+  for(u64 i = 0; i < data.size(); i++) { bytes[i] = uint8_t(data.get(i)); }
+  v.lcp_offsets = offsets_ptr; v.lcp_data = bytes;
+}
+
+} // namespace
+
+extern "C" int gcsa2_host_view_load_gcsa(const char* gcsa_path, const char* lcp_path, gcsa2_view_storage** out)
+{
+  if(gcsa_path == nullptr || out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null argument"); }
+  *out = nullptr;
+  try
+  {
+    std::unique_ptr<gcsa2_view_storage> st(new gcsa2_view_storage());
+    std::memset(&st->view, 0, sizeof(st->view));
+    st->blobs.reserve(64);      // pointers into the blobs' heap buffers stay valid either way; avoids reallocation churn
+    load_gcsa_members(gcsa_path, *st);
+    if(lcp_path != nullptr) { load_lcp_members(lcp_path, *st); }
+    *out = st.release();
+    return GCSA2_OK;
+  }
+  catch(const sdsl_file::FormatError& e) { return fail(GCSA2_ERR_INVALID_ARGUMENT, e.what()); }
+  catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_host_view_load_gcsa: ") + e.what()); }
+}
+
+extern "C" int gcsa2_index_create_from_gcsa(const char* gcsa_path, const char* lcp_path, int device, gcsa2_index** out)
+{
+  gcsa2_view_storage* st = nullptr;
+  int rc = gcsa2_host_view_load_gcsa(gcsa_path, lcp_path, &st);
+  if(rc != GCSA2_OK) { return rc; }
+  rc = gcsa2_index_create(&st->view, device, out);
+  gcsa2_host_view_free(st);
+  return rc;
 }

@@ -285,6 +285,18 @@ void gcsa2_host_view_free(gcsa2_view_storage* storage);
 /* load + gcsa2_index_create in one call */
 int gcsa2_index_create_from_file(const char* path, int device, gcsa2_index** out);
 
+/* ---- the reference's own files ----------------------------------------------------------------
+ * GCSA::load (src/gcsa.cpp:184-216) and LCPArray::load (src/lcp.cpp:130-143) for `.gcsa` / `.lcp`
+ * files written by GCSA::serialize / LCPArray::serialize (GCSA version 3, LCP version 1), without
+ * SDSL: each serialized SDSL container is decoded into the plain arrays of a gcsa2_host_view and the
+ * rank / select supports are skipped.  lcp_path may be NULL (no parent / depth support then).
+ * An invalid header fails like the reference's load() ("Invalid header", src/gcsa.cpp:188-193), as
+ * GCSA2_ERR_INVALID_ARGUMENT; so does any structural inconsistency or any unaccounted byte.
+ * FORMAT PARITY UNPINNED: the container encodings follow sdsl-lite 2.1.1 as recalled in SURVEY.md
+ * section 8(f)-1; no real file was available to validate against (gcsa2_amd/csrc/sdsl_reader.hpp). */
+int gcsa2_host_view_load_gcsa(const char* gcsa_path, const char* lcp_path, gcsa2_view_storage** out);
+int gcsa2_index_create_from_gcsa(const char* gcsa_path, const char* lcp_path, int device, gcsa2_index** out);
+
 /* ---- single-process multi-GPU -------------------------------------------------------------
  * A group holds one replica of the index per listed device (a device may be listed more than
  * once).  group_find_batch splits the batch into contiguous shards (sizes differ by at most one,

@@ -104,6 +104,15 @@ public:
     alpha.char2comp.resize(256); alpha.C.resize(alpha.sigma + 1);
     gcsa2_alphabet(handle, alpha.char2comp.data(), alpha.C.data());
   }
+  // Opens the reference's own files: base.gcsa + (optionally) its .lcp, as query_gcsa does with
+  // sdsl::load_from_file (benchmark/query_gcsa.cpp:53-63).  Pass an empty lcp_file for no LCPArray.
+  GCSA(const std::string& gcsa_file, const std::string& lcp_file, int device) : handle(nullptr)
+  {
+    check(gcsa2_index_create_from_gcsa(gcsa_file.c_str(), lcp_file.empty() ? nullptr : lcp_file.c_str(), device, &handle), "GCSA::load()");
+    alpha.sigma = gcsa2_sigma(handle); alpha.fast_chars = gcsa2_fast_chars(handle);
+    alpha.char2comp.resize(256); alpha.C.resize(alpha.sigma + 1);
+    gcsa2_alphabet(handle, alpha.char2comp.data(), alpha.C.data());
+  }
   GCSA(const GCSA&) = delete;
   GCSA& operator=(const GCSA&) = delete;
   GCSA(GCSA&& source) noexcept : alpha(std::move(source.alpha)), handle(source.handle) { source.handle = nullptr; }
@@ -146,6 +155,15 @@ public:
   {
     size_type in[2] = { range.first, range.second }, out = 0;
     check(gcsa2_count_batch(handle, in, 1, &out), "GCSA::count()");
+    return out;
+  }
+
+  std::vector<size_type> count_batch(const std::vector<range_type>& ranges) const
+  {
+    std::vector<size_type> out(ranges.size());
+    size_type dummy_in[2] = { 1, 0 }, dummy_out = 0;
+    check(gcsa2_count_batch(handle, ranges.empty() ? dummy_in : reinterpret_cast<const size_type*>(ranges.data()), ranges.size(),
+                            ranges.empty() ? &dummy_out : out.data()), "GCSA::count_batch()");
     return out;
   }
 
@@ -307,6 +325,14 @@ public:
   {
     size_type in[2] = { range.first, range.second }, out;
     check(gcsa2_depth_batch(handle, in, 1, &out), "LCPArray::depth()");
+    return out;
+  }
+  std::vector<size_type> depth_batch(const std::vector<range_type>& ranges) const
+  {
+    std::vector<size_type> out(ranges.size());
+    size_type dummy_in[2] = { 0, 0 }, dummy_out = 0;
+    check(gcsa2_depth_batch(handle, ranges.empty() ? dummy_in : reinterpret_cast<const size_type*>(ranges.data()), ranges.size(),
+                            ranges.empty() ? &dummy_out : out.data()), "LCPArray::depth_batch()");
     return out;
   }
   size_type depth(const node_type& node) const { return node.lcp() != node_type::UNKNOWN ? node.lcp() : depth(node.range()); }  // lcp.cpp:305-309

@@ -91,3 +91,69 @@ def test_facade_matches_oracle(tmp_path):
         assert next(it) == f"LF {lf[0]} {lf[1]} {cpu.LF(r[0])}"
         assert next(it) == f"sample {int(cpu.sampled(r[0]))} {cpu.firstSample(r[0])} {cpu.sample(0)} {int(cpu.lastSample(0))}"
         assert next(it) == f"sv {cpu.psv(r[0])[0]} {cpu.nsv(r[0])[0]} {cpu.rmq(*r)[0]} {int(ix.lcp_data[r[0]])}"
+
+
+def _run_env():
+    env = dict(os.environ)
+    try:
+        import torch
+        env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    except Exception:
+        pass
+    return env
+
+
+def test_query_gcsa_cli_builds():
+    from gcsa2_amd import build
+    exe = build.build_query_gcsa()
+    assert os.access(exe, os.X_OK)
+    out = subprocess.run([exe], env=_run_env(), capture_output=True, text=True)
+    assert out.returncode == 0 and "usage: query_gcsa base_name [patterns]" in out.stderr      # query_gcsa.cpp:37-43
+
+
+@pytest.mark.gpu
+def test_query_gcsa_cli_matches_oracle(tmp_path):
+    """`query_gcsa base_name patterns` on .gcsa / .lcp files: the totals of every phase
+    (reference benchmark/query_gcsa.cpp:87-169) equal the oracle's."""
+    import re
+    from gcsa2_amd import build
+    from workload import graphs, builder, patterns, sdsl_format
+    from oracle.oracle import OracleIndex
+    g = graphs.snp_graph(3000, 0x81, 0x82, snp_period=12, node_len=16)
+    ix = builder.build(g, 16, sample_period=16, branching=8)
+    cpu = OracleIndex(ix)
+    pats = [bytes(p[: 3 + q % 12]) for q, p in enumerate(patterns.walk_patterns(g, 300, 14, 0x83))]
+    pats += [bytes(p) for p in patterns.uniform_patterns(60, 7, 0x84)]
+    rows = [p.decode() for p in pats]
+    rows[5:5] = ["", "NNNN", "N"]                       # skipped / filtered rows (query_gcsa.cpp:80-85,186-204)
+    base = str(tmp_path / "index")
+    sdsl_format.write(ix, base)
+    (tmp_path / "patterns.txt").write_text("\n".join(rows) + "\n")
+    exe = build.build_query_gcsa()
+
+    stats = subprocess.run([exe, base], env=_run_env(), capture_output=True, text=True, timeout=300)
+    assert stats.returncode == 0, stats.stderr
+    assert re.search(rf"Paths:\s+{ix.n}\n", stats.stdout) and re.search(rf"Edges:\s+{ix.e}\n", stats.stdout)
+    assert re.search(rf"Max query:\s+{ix.order}\n", stats.stdout)
+
+    run = subprocess.run([exe, base, str(tmp_path / "patterns.txt")], env=_run_env(), capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    text = run.stdout
+    ranges = [cpu.find(p) for p in pats]
+    found = [(r, len(p)) for r, p in zip(ranges, pats) if r[0] <= r[1]]
+    matching = sum(((r[1] + 1 - r[0]) % (1 << 64)) for r in ranges) % (1 << 64)
+    assert re.search(rf"Patterns:\s+{len(pats)} \(total", text)
+    assert f"Found {len(found)} patterns matching {matching} paths" in text
+    parents = [cpu.parent(r) for r, _ in found]
+    pdist = sum(m - node[4] for (_, m), node in zip(found, parents)) / len(found)
+    ddist = sum(m - cpu.depth((node[0], node[1])) for (_, m), node in zip(found, parents)) / len(found)
+    got = [float(x) for x in re.findall(r"Average distance ([0-9.e+-]+) characters", text)]
+    assert len(got) == 2 and abs(got[0] - pdist) < 1e-4 * max(1.0, pdist) and abs(got[1] - ddist) < 1e-4 * max(1.0, ddist)
+    occurrences = sum(cpu.count(r) for r, _ in found)
+    located = sum(len(cpu.locate(r)) for r, _ in found)
+    assert re.search(rf"count\(\):\s+{occurrences} occurrences", text)
+    assert re.search(rf"locate\(\):\s+{located} occurrences", text)
+    assert "inconsistent" not in text
+
+    missing = subprocess.run([exe, str(tmp_path / "nothing")], env=_run_env(), capture_output=True, text=True)
+    assert missing.returncode != 0 and "Cannot load the index" in missing.stderr        # query_gcsa.cpp:55-59

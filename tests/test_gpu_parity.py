@@ -300,6 +300,29 @@ def test_create_from_container_file(engine, tmp_path):
     assert gpu.char2comp.tolist() == ix.char2comp.tolist()
 
 
+def test_create_from_gcsa_files(engine, tmp_path):
+    """`.gcsa` + `.lcp` byte streams -> device image: find / locate / count / parent equal the oracle
+    (encodings as restated in workload/sdsl_format.py: format parity unpinned, see sdsl_reader.hpp)."""
+    from oracle.oracle import OracleIndex
+    from workload import sdsl_format
+    name, g, K = CASES[-1]
+    ix = build(g, K, sample_period=8, branching=4)
+    gcsa_path, _ = sdsl_format.write(ix, str(tmp_path / "index"))
+    gpu, lcp = engine.open_index(gcsa_path)
+    cpu = OracleIndex(ix)
+    pats = [truncate_at_sink(p) for p in random_patterns(g, K, 0x96, 200)]
+    data, off = concat_patterns(pats)
+    ranges = gpu.find_batch(data, off)
+    assert np.array_equal(ranges, cpu.find_batch(data, off))
+    go, gv = gpu.locate_batch(ranges)
+    co, cv = cpu.locate_batch(ranges)
+    assert np.array_equal(go, co) and np.array_equal(gv, cv)
+    assert np.array_equal(gpu.count_batch(ranges), cpu.count_batch(ranges))
+    found = ranges[ranges[:, 0] <= ranges[:, 1]]
+    assert np.array_equal(lcp.parent_batch(found), cpu.parent_batch(found))
+    assert (gpu.size(), gpu.edgeCount(), gpu.order(), gpu.sigma, lcp.size()) == (ix.n, ix.e, ix.order, ix.sigma, ix.lcp_size)
+
+
 def test_compare_kmers(engine):
     """compareKMers (reference src/algorithms.cpp:534-616) on two graphs sharing a backbone."""
     from oracle.oracle import OracleIndex

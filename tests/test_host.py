@@ -145,3 +145,107 @@ def test_host_view_file_round_trip(built, tmp_path):
     built.save_host_view(ix, path, with_lcp=False, with_counters=False)
     v2 = built.LoadedHostView(path).view
     assert not v2.lcp_data and not v2.extra_filter_bits and bool(v2.sampled_path_bits)
+
+
+def _view_matches(v, ix):
+    def words(ptr, nbits):
+        n = (nbits + 63) // 64
+        return np.ctypeslib.as_array(ptr, shape=(n,)).tolist() if n else []
+
+    def plain(arr, nbits):
+        n = (nbits + 63) // 64
+        return np.asarray(arr, dtype=np.uint64)[:n].tolist()
+
+    assert (v.path_nodes, v.edges, v.order, v.sigma, v.fast_chars) == (ix.n, ix.e, ix.order, ix.sigma, ix.fast_chars)
+    assert (v.sample_count, v.sample_width, v.extra_values_len, v.redundant_len) == \
+        (ix.sample_count, ix.sample_width, ix.extra_values_len, ix.redundant_len)
+    for c in range(ix.sigma):
+        assert words(v.bwt[c], ix.n) == plain(ix.bwt[c], ix.n), c
+    assert words(v.edge_bits, ix.e) == plain(ix.edges, ix.e)
+    assert words(v.sampled_path_bits, ix.n) == plain(ix.sampled_paths, ix.n)
+    assert words(v.stored_samples, ix.sample_count * ix.sample_width) == plain(ix.stored_samples, ix.sample_count * ix.sample_width)
+    assert words(v.sample_bits, ix.sample_count) == plain(ix.samples, ix.sample_count)
+    assert words(v.extra_filter_bits, ix.n) == plain(ix.extra_filter, ix.n)
+    assert words(v.extra_values_bits, ix.extra_values_len) == plain(ix.extra_values, ix.extra_values_len)
+    assert words(v.redundant_bits, ix.redundant_len) == plain(ix.redundant, ix.redundant_len)
+    assert np.ctypeslib.as_array(v.C, shape=(ix.sigma + 1,)).tolist() == ix.C.tolist()
+    assert np.ctypeslib.as_array(v.char2comp, shape=(256,)).tolist() == ix.char2comp.tolist()
+
+
+def test_gcsa_file_loader(built, tmp_path):
+    """`.gcsa` / `.lcp` byte streams (GCSA::serialize order, SDSL container encodings as restated in
+    workload/sdsl_format.py) -> gcsa2_host_view_load_gcsa -> the same members.  Host only."""
+    from workload import graphs, sdsl_format
+    from workload import builder
+    from workload.brute_builder import build
+    cases = [build(graphs.paper_graph(), 3, sample_period=2, branching=2),
+             build(graphs.snp_graph(150, 0x52, 0x53, snp_period=8, node_len=8), 6, sample_period=8, branching=4),
+             builder.build(graphs.snp_graph(40000, 0x61, 0x62), 16)]       # > 4096 ones per select directory, several LCP levels
+    for k, ix in enumerate(cases):
+        gcsa_path, lcp_path = sdsl_format.write(ix, str(tmp_path / f"case{k}"))
+        loaded = built.LoadedHostView(gcsa_path, lcp_path)
+        v = loaded.view
+        _view_matches(v, ix)
+        assert (v.lcp_size, v.lcp_branching, v.lcp_levels) == (ix.lcp_size, ix.lcp_branching, len(ix.lcp_offsets) - 1)
+        assert np.ctypeslib.as_array(v.lcp_offsets, shape=(len(ix.lcp_offsets),)).tolist() == ix.lcp_offsets.tolist()
+        nvals = int(ix.lcp_offsets[-1])
+        assert np.ctypeslib.as_array(v.lcp_data, shape=(nvals,)).tolist() == ix.lcp_data.tolist()
+        loaded.close()
+        without = built.LoadedHostView(gcsa_path)
+        assert not without.view.lcp_data and bool(without.view.redundant_bits)
+        without.close()
+
+    # refusals: wrong tag / version (GCSA::load "Invalid header", src/gcsa.cpp:188-193), truncation, trailing bytes
+    raw = open(gcsa_path, "rb").read()
+    for name, data in (("tag", b"\0\0\0\0" + raw[4:]), ("version", raw[:4] + b"\x02\0\0\0" + raw[8:]),
+                       ("truncated", raw[: len(raw) // 2]), ("trailing", raw + b"\0" * 8), ("empty", b"")):
+        bad = tmp_path / f"bad_{name}.gcsa"
+        bad.write_bytes(data)
+        with pytest.raises(built.Gcsa2Error):
+            built.LoadedHostView(str(bad))
+    flipped = bytearray(raw)
+    flipped[len(raw) // 3] ^= 0x10          # a payload or count word somewhere inside the BWT vectors
+    bad = tmp_path / "bad_flip.gcsa"
+    bad.write_bytes(bytes(flipped))
+    try:
+        corrupted = built.LoadedHostView(str(bad))
+    except built.Gcsa2Error:
+        corrupted = None
+    if corrupted is not None:             # a flipped low bit of an sd_vector can still decode; it must then differ
+        with pytest.raises(AssertionError):
+            _view_matches(corrupted.view, ix)
+    with pytest.raises(built.Gcsa2Error):
+        built.LoadedHostView(gcsa_path, str(tmp_path / "missing.lcp"))
+    lcp_raw = open(lcp_path, "rb").read()
+    (tmp_path / "bad.lcp").write_bytes(lcp_raw[:-8])
+    with pytest.raises(built.Gcsa2Error):
+        built.LoadedHostView(gcsa_path, str(tmp_path / "bad.lcp"))
+
+
+def test_sdsl_select_directory_shapes(built, tmp_path):
+    """The reader must step over both kinds of select_support_mcl superblocks: a sparse `redundant`
+    vector forces "long" blocks, a dense one "mini" blocks (loader checks exact end of file)."""
+    import copy
+    from workload import graphs, sdsl_format
+    from workload.brute_builder import build
+    ix = copy.copy(build(graphs.snp_graph(150, 0x52, 0x53, snp_period=8, node_len=8), 6, sample_period=8, branching=4))
+    nbits = 1 << 23
+    pos = np.unique((np.arange(9000, dtype=np.uint64) * np.uint64(911)) % np.uint64(nbits))
+    dense = np.arange(5000, dtype=np.uint64) + np.uint64(nbits - 6000)
+    bits = np.zeros(nbits, dtype=np.uint8)
+    bits[pos.astype(np.int64)] = 1
+    bits[dense.astype(np.int64)] = 1
+    ix.redundant = np.packbits(bits, bitorder="little").view(np.uint64)
+    ix.redundant_len = nbits
+    raw = sdsl_format.select_support_mcl(ix.redundant, nbits, 1)
+    gcsa_path, _ = sdsl_format.write(ix, str(tmp_path / "shapes"))
+    loaded = built.LoadedHostView(gcsa_path)
+    v = loaded.view
+    assert v.redundant_len == nbits
+    assert np.ctypeslib.as_array(v.redundant_bits, shape=(nbits // 64,)).tolist() == ix.redundant.tolist()
+    args = int.from_bytes(raw[:8], "little")
+    sb = (args + 4095) // 4096
+    sb_bits = int.from_bytes(raw[8:16], "little")
+    kinds = raw[8 + 9 + 8 * ((sb_bits + 63) // 64):]           # after arg_cnt and the superblock vector: mini_or_long
+    assert int.from_bytes(kinds[:8], "little") == sb and kinds[8] not in (0, (1 << sb) - 1)      # both kinds present
+    loaded.close()

@@ -13,5 +13,6 @@ caveat").
   builder.cpp/.py   scalable trie-refinement builder producing the same table (cross-checked in tests)
   linear_torch.py   footprint-scale linear-graph index by prefix doubling with torch (GPU when present)
   patterns.py       seeded query sets (walks through the graph "S", uniform random "U")
+  sdsl_format.py    writer of .gcsa / .lcp byte streams (restated SDSL encodings) for the file-reader tests
   cache.py          .npz save / load of an index (one build per node in multi-rank runs)
 """
