@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <new>
 #include <random>
@@ -41,6 +42,8 @@ using namespace g2;
 // ==========================================================================================
 // host code
 
+constexpr unsigned RESULT_SLOTS = 1024;     // concurrent locate calls per handle before two share a slot
+
 struct gcsa2_index
 {
   int device = 0;
@@ -48,6 +51,12 @@ struct gcsa2_index
   void* d_base = nullptr;
   void* d_kmer = nullptr;
   void* d_pred4 = nullptr;
+  void* d_locate = nullptr;
+  // Small results the host reads back (totals of the locate pipeline) live in plain hipMalloc memory:
+  // device-to-host copies out of stream-ordered pool memory were observed to return stale data
+  // (about one call in 5000 on ROCm 7.2 / gfx950), copies out of hipMalloc memory never.
+  unsigned long long* d_slots = nullptr;
+  mutable std::atomic<unsigned> next_slot{0};
   int compute_units = 256;
   u64 bytes = 0;
   u64 order = 0;
@@ -59,6 +68,7 @@ struct gcsa2_locate_job
   u64 nq = 0, total = 0;
   u64* d_offsets = nullptr;   // nq + 1
   u64* d_values = nullptr;    // total
+  hipStream_t stream = nullptr;   // the stream the job ran on
 };
 
 namespace {
@@ -249,13 +259,33 @@ template<class T> struct DBuf
   ~DBuf() { if(p) { (void)hipFree(p); } }
 };
 
+// stream-ordered scratch: no device-wide synchronisation from allocation or release
+struct Scratch
+{
+  hipStream_t stream; std::vector<void*> held;
+  explicit Scratch(hipStream_t s) : stream(s) {}
+  ~Scratch() { for(void* p : held) { (void)hipFreeAsync(p, stream); } }
+  template<class T> hipError_t get(T*& p, u64 count)
+  {
+    void* raw = nullptr;
+    hipError_t e = hipMallocAsync(&raw, (count > 0 ? count : 1) * sizeof(T), stream);
+    if(e == hipSuccess) { held.push_back(raw); p = static_cast<T*>(raw); }
+    return e;
+  }
+};
+
 }  // namespace
 
 namespace {
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
                         u64 total_nodes, u64* values, hipStream_t stream)
 {
-  if(ix->img.pred4 != nullptr)
+  if(ix->img.locate_tab != nullptr)
+  {
+    hipLaunchKernelGGL(k_locate_tab, dim3(grid_for(total_nodes)), dim3(TPB), 0, stream,
+                       ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values);
+  }
+  else if(ix->img.pred4 != nullptr)
   {
     hipLaunchKernelGGL(k_locate_walk2, dim3(unsigned((total_nodes + TPB2 - 1) / TPB2)), dim3(TPB2), 0, stream,
                        ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values);
@@ -354,11 +384,21 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     {
       int cus = 0;
       if(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) { ix->compute_units = cus; }
+      // Query scratch comes from the device's stream-ordered pool; keep what it has grown to instead
+      // of returning it to the driver at every synchronisation.
+      hipMemPool_t pool = nullptr;
+      if(hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool != nullptr)
+      {
+        uint64_t keep = ~uint64_t(0);
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      }
+      (void)hipGetLastError();
     }
     ix->bytes = st.words.size() * sizeof(u64);
     hipError_t e = hipMalloc(&ix->d_base, ix->bytes > 0 ? ix->bytes : 8);
     if(e != hipSuccess) { delete ix; return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(image): ") + hipGetErrorString(e)); }
     e = hipMemcpy(ix->d_base, st.words.data(), ix->bytes, hipMemcpyHostToDevice);
+    if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&ix->d_slots), RESULT_SLOTS * 4 * sizeof(unsigned long long)); }
     if(e != hipSuccess) { (void)hipFree(ix->d_base); delete ix; return fail(GCSA2_ERR_HIP, std::string("hipMemcpy(image): ") + hipGetErrorString(e)); }
 
     const u64* base = static_cast<const u64*>(ix->d_base);
@@ -429,6 +469,40 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
   {
     delete ix; return fail(GCSA2_ERR_OUT_OF_MEMORY, "host staging allocation failed");
   }
+
+  // memoised locate walks: 8 bytes per path node, built with the walk kernel itself.  Optional: skipped
+  // when GCSA2_LOCATE_TABLE=0, when it would take more than a quarter of the free memory, or when an
+  // entry does not fit (then locate() walks as before).
+  ix->img.locate_tab = nullptr;
+  {
+    const char* env = std::getenv("GCSA2_LOCATE_TABLE");
+    size_t free_bytes = 0, total_bytes = 0;
+    bool wanted = ix->img.has_samples && ix->img.pred4 != nullptr && ix->img.n > 0 && !(env != nullptr && std::atoi(env) == 0);
+    if(wanted && hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && ix->img.n * sizeof(u64) <= free_bytes / 4)
+    {
+      u32* d_overflow = nullptr; u32 overflow = 1;
+      hipError_t e = hipMalloc(&ix->d_locate, ix->img.n * sizeof(u64));
+      if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&d_overflow), sizeof(u32)); }
+      if(e == hipSuccess) { e = hipMemset(d_overflow, 0, sizeof(u32)); }
+      if(e == hipSuccess)
+      {
+        hipLaunchKernelGGL(k_build_locate_table, dim3(unsigned((ix->img.n + TPB2 - 1) / TPB2)), dim3(TPB2), 0, nullptr,
+                           ix->img, static_cast<u64*>(ix->d_locate), d_overflow);
+        e = hipMemcpy(&overflow, d_overflow, sizeof(u32), hipMemcpyDeviceToHost);
+      }
+      if(d_overflow) { (void)hipFree(d_overflow); }
+      if(e == hipSuccess && overflow == 0)
+      {
+        ix->img.locate_tab = static_cast<const u64*>(ix->d_locate);
+        ix->bytes += ix->img.n * sizeof(u64);
+      }
+      else
+      {
+        if(ix->d_locate) { (void)hipFree(ix->d_locate); ix->d_locate = nullptr; }
+        (void)hipGetLastError();
+      }
+    }
+  }
   *out = ix;
   return GCSA2_OK;
 }
@@ -440,6 +514,8 @@ void gcsa2_index_destroy(gcsa2_index* ix)
   if(ix->d_base) { (void)hipFree(ix->d_base); }
   if(ix->d_kmer) { (void)hipFree(ix->d_kmer); }
   if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
+  if(ix->d_locate) { (void)hipFree(ix->d_locate); }
+  if(ix->d_slots) { (void)hipFree(ix->d_slots); }
   delete ix;
 }
 
@@ -537,6 +613,7 @@ int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, co
 
 uint64_t gcsa2_find_block_bytes(const gcsa2_index*) { return FLB_BYTES; }
 uint64_t gcsa2_kmer_table_k(const gcsa2_index* ix) { return ix->img.kmer_k; }
+uint64_t gcsa2_locate_table_bytes(const gcsa2_index* ix) { return ix->img.locate_tab != nullptr ? ix->img.n * sizeof(u64) : 0; }
 
 int gcsa2_lf_device(const gcsa2_index* ix, const uint64_t* d_in, const uint8_t* d_comps, uint64_t nq,
                     uint64_t* d_out, void* stream)
@@ -595,11 +672,11 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
   DeviceGuard guard(ix->device);
   gcsa2_locate_job* job = new(std::nothrow) gcsa2_locate_job();
   if(job == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
-  job->device = ix->device; job->nq = nq;
+  job->device = ix->device; job->nq = nq; job->stream = stream;
   struct Cleanup { gcsa2_locate_job*& j; bool armed = true; ~Cleanup() { if(armed) { gcsa2_locate_discard(j); j = nullptr; } } };
   Cleanup cleanup{job};
 
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_offsets), (nq + 1) * sizeof(u64)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_offsets), (nq + 1) * sizeof(u64)));    // read by the host: not pool memory
   if(nq == 0)
   {
     HIP_TRY(hipMemsetAsync(job->d_offsets, 0, sizeof(u64), stream));
@@ -611,27 +688,33 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
     return GCSA2_OK;
   }
 
-  DBuf<u64> node_counts, raw_counts, node_off, raw_off;
-  HIP_TRY(node_counts.alloc(nq + 1)); HIP_TRY(raw_counts.alloc(nq + 1));
-  HIP_TRY(node_off.alloc(nq + 1)); HIP_TRY(raw_off.alloc(nq + 1));
-  HIP_TRY(hipMemsetAsync(node_counts.p + nq, 0, sizeof(u64), stream));
-  HIP_TRY(hipMemsetAsync(raw_counts.p + nq, 0, sizeof(u64), stream));
-  hipLaunchKernelGGL(k_locate_sizes, dim3(grid_for(nq)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_counts.p, raw_counts.p);
+  Scratch scratch(stream);
+
+  // [node_counts | raw_counts | node_off] (nq + 1 each), [seg_begin | seg_end] (nq each), 3 totals; the
+  // scan of the raw counts goes straight into the job's offsets (final as they are unless duplicates
+  // have to be removed, rewritten in place otherwise)
+  u64* sizes = nullptr; u64* segs = nullptr;
+  unsigned long long* d_totals = ix->d_slots + 4 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);   // {nodes, raw, multi, unique}
+  HIP_TRY(scratch.get(sizes, 3 * (nq + 1))); HIP_TRY(scratch.get(segs, 2 * nq));
+  u64 *node_counts = sizes, *raw_counts = sizes + (nq + 1), *node_off = sizes + 2 * (nq + 1), *raw_off = job->d_offsets;
+  u64 *seg_begin = segs, *seg_end = segs + nq;
+  hipLaunchKernelGGL(k_locate_sizes, dim3(grid_for(nq)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_counts, raw_counts, d_totals);
   LAUNCH_CHECK("k_locate_sizes");
 
   // exclusive scans over nq + 1 entries: entry nq becomes the total
-  size_t tmp_bytes = 0, need = 0;
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, node_counts.p, node_off.p, int(nq + 1), stream));
-  tmp_bytes = need;
-  DBuf<char> tmp;
-  HIP_TRY(tmp.alloc(tmp_bytes));
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, node_counts.p, node_off.p, int(nq + 1), stream));
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, raw_counts.p, raw_off.p, int(nq + 1), stream));
-  u64 totals[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(&totals[0], node_off.p + nq, sizeof(u64), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipMemcpyAsync(&totals[1], raw_off.p + nq, sizeof(u64), hipMemcpyDeviceToHost, stream));
+  size_t tmp_bytes = 0;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, node_counts, node_off, int(nq + 1), stream));
+  char* tmp = nullptr;
+  HIP_TRY(scratch.get(tmp, tmp_bytes));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, node_counts, node_off, int(nq + 1), stream));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, raw_counts, raw_off, int(nq + 1), stream));
+  // segments with more than one raw value: the only ones removeDuplicates has to touch
+  hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end);
+  LAUNCH_CHECK("k_collect_multi");
+  unsigned long long totals[3] = {0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
-  u64 total_nodes = totals[0], total_raw = totals[1];
+  const u64 total_nodes = totals[0], total_raw = totals[1], multi = totals[2];
   if(total_raw >= (u64(1) << 31)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate batch produces >= 2^31 values; split the batch"); }
 
   if(total_raw == 0)
@@ -639,66 +722,55 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
     HIP_TRY(hipMemsetAsync(job->d_offsets, 0, (nq + 1) * sizeof(u64), stream));
     HIP_TRY(hipStreamSynchronize(stream));
   }
-  else if(!sort)
+  else if(!sort || multi == 0)
   {
-    // sort == false (gcsa.cpp:827-842 without removeDuplicates): values in path order, the
-    // values of one path node in sample order, duplicates kept -- exactly the walk's output.
+    // sort == false (gcsa.cpp:827-842 without removeDuplicates): values in path order, the values of
+    // one path node in sample order, duplicates kept -- exactly the walk's output.  With at most one
+    // value per query that output is already sorted and distinct.
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_values), total_raw * sizeof(u64)));
-    launch_walk(ix, d_ranges, nq, node_off.p, raw_off.p, total_nodes, job->d_values, stream);
+    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, job->d_values, stream);
     LAUNCH_CHECK("k_locate_walk");
-    HIP_TRY(hipMemcpyAsync(job->d_offsets, raw_off.p, (nq + 1) * sizeof(u64), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     job->total = total_raw;
   }
   else
   {
-    DBuf<u64> raw, sorted, flag_scan;
-    DBuf<u32> flags;
-    HIP_TRY(raw.alloc(total_raw)); HIP_TRY(sorted.alloc(total_raw));
-    HIP_TRY(flags.alloc(total_raw + 1)); HIP_TRY(flag_scan.alloc(total_raw + 1));
-    launch_walk(ix, d_ranges, nq, node_off.p, raw_off.p, total_nodes, raw.p, stream);
+    u64 *raw = nullptr, *sorted = nullptr, *flag_scan = nullptr; u32* flags = nullptr;
+    HIP_TRY(scratch.get(raw, total_raw)); HIP_TRY(scratch.get(sorted, total_raw));
+    HIP_TRY(scratch.get(flags, total_raw + 1)); HIP_TRY(scratch.get(flag_scan, total_raw + 1));
+    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, raw, stream);
     LAUNCH_CHECK("k_locate_walk");
 
     // removeDuplicates: sort only the segments that hold more than one value (single-value
     // segments are copied through), then flag + scan + compact
-    DBuf<u64> seg_begin, seg_end;
-    DBuf<unsigned long long> seg_count;
-    HIP_TRY(seg_begin.alloc(nq)); HIP_TRY(seg_end.alloc(nq)); HIP_TRY(seg_count.alloc(1));
-    HIP_TRY(hipMemsetAsync(seg_count.p, 0, sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off.p, nq, seg_count.p, seg_begin.p, seg_end.p);
-    LAUNCH_CHECK("k_collect_multi");
-    HIP_TRY(hipMemcpyAsync(sorted.p, raw.p, total_raw * sizeof(u64), hipMemcpyDeviceToDevice, stream));
-    unsigned long long multi = 0;
-    HIP_TRY(hipMemcpyAsync(&multi, seg_count.p, sizeof(multi), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    DBuf<char> sort_tmp;
-    if(multi > 0)
-    {
-      size_t sort_bytes = 0;
-      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw.p, sorted.p, int(total_raw), int(multi),
-                                                         seg_begin.p, seg_end.p, 0, 64, stream));
-      HIP_TRY(sort_tmp.alloc(sort_bytes));
-      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp.p, sort_bytes, raw.p, sorted.p, int(total_raw), int(multi),
-                                                         seg_begin.p, seg_end.p, 0, 64, stream));
-    }
-    hipLaunchKernelGGL(k_mark_unique, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted.p, raw_off.p, nq, total_raw, flags.p);
+    HIP_TRY(hipMemcpyAsync(sorted, raw, total_raw * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    size_t sort_bytes = 0;
+    HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw, sorted, int(total_raw), int(multi),
+                                                       seg_begin, seg_end, 0, 64, stream));
+    char* sort_tmp = nullptr;
+    HIP_TRY(scratch.get(sort_tmp, sort_bytes));
+    HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(multi),
+                                                       seg_begin, seg_end, 0, 64, stream));
+    hipLaunchKernelGGL(k_mark_unique, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, raw_off, nq, total_raw, flags);
     LAUNCH_CHECK("k_mark_unique");
-    HIP_TRY(hipMemsetAsync(flags.p + total_raw, 0, sizeof(u32), stream));
+    HIP_TRY(hipMemsetAsync(flags + total_raw, 0, sizeof(u32), stream));
     size_t scan_bytes = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.p, flag_scan.p, int(total_raw + 1), stream));
-    DBuf<char> scan_tmp;
-    HIP_TRY(scan_tmp.alloc(scan_bytes));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, flags.p, flag_scan.p, int(total_raw + 1), stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, flag_scan, int(total_raw + 1), stream));
+    char* scan_tmp = nullptr;
+    HIP_TRY(scratch.get(scan_tmp, scan_bytes));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flags, flag_scan, int(total_raw + 1), stream));
     u64 total_unique = 0;
-    HIP_TRY(hipMemcpyAsync(&total_unique, flag_scan.p + total_raw, sizeof(u64), hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, flag_scan + total_raw, d_totals + 3);
+    LAUNCH_CHECK("k_publish");
+    HIP_TRY(hipMemcpyAsync(&total_unique, d_totals + 3, sizeof(u64), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     job->total = total_unique;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_values), (total_unique > 0 ? total_unique : 1) * sizeof(u64)));
-    hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted.p, flags.p, flag_scan.p, total_raw, job->d_values);
+    hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, flags, flag_scan, total_raw, job->d_values);
     LAUNCH_CHECK("k_compact");
-    hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, raw_off.p, flag_scan.p, nq, total_raw, total_unique, job->d_offsets);
+    hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, flag_scan, nq, total_raw, total_unique, job->d_offsets);
     LAUNCH_CHECK("k_final_offsets");
-    HIP_TRY(hipStreamSynchronize(stream));   // temporaries die at scope exit
+    HIP_TRY(hipStreamSynchronize(stream));
   }
 
   cleanup.armed = false; *job_out = job;
@@ -812,7 +884,8 @@ int gcsa2_locate_run(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq,
   const u64* d_off = nullptr;
   int rc = gcsa2_locate_device(ix, d_in.p, nq, sort, job, &d_off, nullptr, nullptr, nullptr);
   if(rc != GCSA2_OK) { return rc; }
-  HIP_TRY(hipMemcpy(offsets, d_off, (nq + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(offsets, d_off, (nq + 1) * sizeof(u64), hipMemcpyDeviceToHost, nullptr));   // in the job's stream order
+  HIP_TRY(hipStreamSynchronize(nullptr));
   return GCSA2_OK;
 }
 
@@ -822,7 +895,11 @@ int gcsa2_locate_fetch(gcsa2_locate_job* job, uint64_t* values, uint64_t capacit
   if(capacity < job->total) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer smaller than offsets[n_queries]"); }
   {
     DeviceGuard guard(job->device);
-    if(job->total > 0) { HIP_TRY(hipMemcpy(values, job->d_values, job->total * sizeof(u64), hipMemcpyDeviceToHost)); }
+    if(job->total > 0)
+    {
+      HIP_TRY(hipMemcpyAsync(values, job->d_values, job->total * sizeof(u64), hipMemcpyDeviceToHost, job->stream));
+      HIP_TRY(hipStreamSynchronize(job->stream));
+    }
   }
   gcsa2_locate_discard(job);
   return GCSA2_OK;

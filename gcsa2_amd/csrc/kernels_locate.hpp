@@ -79,31 +79,56 @@ __device__ __forceinline__ u32 pred4_get(const u64* pred4, u64 node)
   return u32(pred4[node >> 4] >> ((node & 15) * 4)) & 15;
 }
 
-// one lane per (query, path node): locateInternal (gcsa.cpp:880-896), wave-cooperative.
-// The LF(path_node) walk uses the pred4 nibble (which comp, already sampled?) and then ONE fused
-// block per step for C[c] + rank(B_c, node) and rank(edges, .), fetched like in k_find2.
-__global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* __restrict__ ranges, u64 nq,
-                                                      const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
-                                                      u64 total_nodes, u64* __restrict__ values)
+// Query owning flattened node g: the last q with node_off[q] <= g.  Starts from the proportional
+// guess and gallops, so batches of similar-sized ranges cost O(1) probes instead of log2(nq).
+__device__ __forceinline__ u64 owner_of(const u64* __restrict__ node_off, u64 nq, u64 total_nodes, u64 g)
 {
-  __shared__ ulonglong2 stage[TPB2 * 8];
-  const u32 lane = threadIdx.x & 63;
-  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  u64 g = u64(blockIdx.x) * TPB2 + threadIdx.x;
-  bool live = g < total_nodes;
-  u64 node = 0, dest = 0, steps = 0;
-  if(live)
+  u64 q = u64(double(g) / double(total_nodes) * double(nq));
+  if(q >= nq) { q = nq - 1; }
+  u64 lo, hi;
+  if(node_off[q] <= g)
   {
-    u64 lo = 0, hi = nq - 1;            // query owning flattened node g: last q with node_off[q] <= g
-    while(lo < hi)
+    lo = q; hi = nq - 1;
+    for(u64 step = 1; lo + step < nq; step <<= 1)
     {
-      u64 mid = (lo + hi + 1) >> 1;
-      if(node_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
+      if(node_off[lo + step] > g) { hi = lo + step - 1; break; }
+      lo += step;
     }
-    u64 sp = ranges[2 * lo];
-    node = sp + (g - node_off[lo]);
-    dest = raw_off[lo] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0);
   }
+  else
+  {
+    hi = q - 1; lo = 0;                    // node_off[0] == 0 <= g
+    for(u64 step = 1; step <= hi; step <<= 1)
+    {
+      if(node_off[hi - step] <= g) { lo = hi - step; break; }
+      hi -= step;
+    }
+  }
+  while(lo < hi)
+  {
+    u64 mid = (lo + hi + 1) >> 1;
+    if(node_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
+  }
+  return lo;
+}
+
+__device__ __forceinline__ void locate_item(const DevImage& img, const u64* __restrict__ ranges, u64 nq,
+                                            const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
+                                            u64 total_nodes, u64 g, u64& node, u64& dest)
+{
+  u64 q = owner_of(node_off, nq, total_nodes, g);
+  u64 sp = ranges[2 * q];
+  node = sp + (g - node_off[q]);
+  dest = raw_off[q] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0);
+}
+
+// while(!sampled(node)) { node = LF(node); steps++; } (gcsa.cpp:883-887) for the 64 lanes of a wave:
+// the pred4 nibble says which comp's fused block holds the incoming edge (and whether the node is
+// sampled), then ONE fused block per step gives C[c] + rank(B_c, node) and rank(edges, .), fetched
+// like in k_find2.
+__device__ __forceinline__ void walk_to_sample(const DevImage& img, u64& node, u64& steps, bool live,
+                                               ulonglong2* wave_stage, u32 lane)
+{
   bool walking = live;
   while(__any(walking))
   {
@@ -131,10 +156,30 @@ __global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* 
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+__device__ __forceinline__ u64 first_sample(const DevImage& img, u64 node)      // gcsa.h:202-206
+{
+  u64 srank = bv_rank(img.sampled, node);
+  return (srank > 0 ? bv_select(img.samples, srank) + 1 : 0);
+}
+
+// one lane per (query, path node): locateInternal (gcsa.cpp:880-896), wave-cooperative walk.
+__global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                                      const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
+                                                      u64 total_nodes, u64* __restrict__ values)
+{
+  __shared__ ulonglong2 stage[TPB2 * 8];
+  const u32 lane = threadIdx.x & 63;
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  u64 g = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  bool live = g < total_nodes;
+  u64 node = 0, dest = 0, steps = 0;
+  if(live) { locate_item(img, ranges, nq, node_off, raw_off, total_nodes, g, node, dest); }
+  walk_to_sample(img, node, steps, live, wave_stage, lane);
   if(live)
   {
-    u64 srank = bv_rank(img.sampled, node);
-    u64 s = (srank > 0 ? bv_select(img.samples, srank) + 1 : 0);   // firstSample, gcsa.h:202-206
+    u64 s = first_sample(img, node);
     do
     {
       values[dest++] = packed_get(img.stored, img.sample_width, s) + steps;   // gcsa.cpp:893
@@ -144,13 +189,63 @@ __global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* 
   }
 }
 
+// ---- memoised walks ------------------------------------------------------------------------------
+// The walk of locateInternal depends on the start node only, so it is done once per path node at
+// load time (8 bytes per node; HBM is large) and locate() becomes one gather per path node.
+constexpr u64 LOCATE_DIRECT = u64(1) << 63;
+constexpr u64 LOCATE_INDEX_BITS = 40, LOCATE_STEP_LIMIT = u64(1) << 23;
+
+__global__ __launch_bounds__(TPB2) void k_build_locate_table(DevImage img, u64* __restrict__ table, u32* __restrict__ overflow)
+{
+  __shared__ ulonglong2 stage[TPB2 * 8];
+  const u32 lane = threadIdx.x & 63;
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  u64 g = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  bool live = g < img.n;
+  u64 node = g, steps = 0;
+  walk_to_sample(img, node, steps, live, wave_stage, lane);
+  if(!live) { return; }
+  u64 s = first_sample(img, node);
+  u64 entry;
+  if(bv_get(img.samples, s))            // lastSample(s): a single value
+  {
+    u64 value = packed_get(img.stored, img.sample_width, s) + steps;
+    if(value < LOCATE_DIRECT) { table[g] = LOCATE_DIRECT | value; return; }
+  }
+  if(steps >= LOCATE_STEP_LIMIT || s >= (u64(1) << LOCATE_INDEX_BITS)) { atomicOr(overflow, 1u); entry = 0; }
+  else { entry = s | (steps << LOCATE_INDEX_BITS); }
+  table[g] = entry;
+}
+
+__global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                                    const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
+                                                    u64 total_nodes, u64* __restrict__ values)
+{
+  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(g >= total_nodes) { return; }
+  u64 node, dest;
+  locate_item(img, ranges, nq, node_off, raw_off, total_nodes, g, node, dest);
+  u64 entry = img.locate_tab[node];
+  if(entry & LOCATE_DIRECT) { values[dest] = entry & ~LOCATE_DIRECT; return; }
+  u64 s = entry & ((u64(1) << LOCATE_INDEX_BITS) - 1), steps = entry >> LOCATE_INDEX_BITS;
+  do
+  {
+    values[dest++] = packed_get(img.stored, img.sample_width, s) + steps;     // gcsa.cpp:893
+    s++;
+  }
+  while(!bv_get(img.samples, s - 1));
+}
+
 // segments with more than one raw value (the only ones removeDuplicates has to sort)
-__global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ raw_off, u64 nq,
-                                                       unsigned long long* __restrict__ counter,
+// also publishes the two scan totals next to the counter: totals = {nodes, raw values, multi-value segments}
+__global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
+                                                       unsigned long long* __restrict__ totals,
                                                        u64* __restrict__ seg_begin, u64* __restrict__ seg_end)
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q >= nq) { return; }
+  unsigned long long* counter = totals + 2;
+  if(q == 0) { totals[0] = node_off[nq]; totals[1] = raw_off[nq]; }
   u64 b = raw_off[q], e = raw_off[q + 1];
   if(e - b >= 2)
   {
@@ -278,11 +373,14 @@ __global__ __launch_bounds__(TPB) void k_kmer_compare(const DevImage* __restrict
 // ---- locate ------------------------------------------------------------------------------
 
 // per query: number of path nodes to walk and number of values before deduplication
+// (also clears entry nq of both arrays -- the scans turn it into the totals -- and the segment counter)
 __global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* __restrict__ ranges, u64 nq,
-                                                      u64* __restrict__ node_counts, u64* __restrict__ raw_counts)
+                                                      u64* __restrict__ node_counts, u64* __restrict__ raw_counts,
+                                                      unsigned long long* __restrict__ totals)
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q >= nq) { return; }
+  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; totals[0] = totals[1] = totals[2] = 0; }
   ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
   u64 nodes = 0, raw = 0;
   if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831
@@ -352,12 +450,15 @@ __global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted,
   if(flags[g]) { out[flag_scan[g]] = sorted[g]; }
 }
 
-__global__ __launch_bounds__(TPB) void k_final_offsets(const u64* __restrict__ raw_off, const u64* __restrict__ flag_scan,
-                                                       u64 nq, u64 total, u64 total_unique, u64* __restrict__ offsets)
+__global__ void k_publish(const u64* __restrict__ src, unsigned long long* __restrict__ dst) { *dst = *src; }
+
+// in place: offsets[] holds the raw (with duplicates) offsets on entry, the final ones on return
+__global__ __launch_bounds__(TPB) void k_final_offsets(const u64* __restrict__ flag_scan, u64 nq, u64 total, u64 total_unique,
+                                                       u64* offsets)
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q > nq) { return; }
-  u64 r = (q < nq ? raw_off[q] : total);
+  u64 r = (q < nq ? offsets[q] : total);
   offsets[q] = (r < total ? flag_scan[r] : total_unique);
 }
 

@@ -157,6 +157,11 @@ uint64_t gcsa2_find_block_bytes(const gcsa2_index* index);
  * memoised: a pattern whose last k characters are fast characters starts at step k).  0 = none.
  * Environment variable GCSA2_KMER_TABLE caps k (0 disables). */
 uint64_t gcsa2_kmer_table_k(const gcsa2_index* index);
+/* Bytes of the memoised locate table (0 = none): the walk of locateInternal (src/gcsa.cpp:880-896)
+ * depends on the start node only, so it is run once per path node at create time and locate() reads
+ * one 8-byte entry per path node instead of walking.  Needs samples; skipped when it would take
+ * more than a quarter of the free device memory or when GCSA2_LOCATE_TABLE=0. */
+uint64_t gcsa2_locate_table_bytes(const gcsa2_index* index);
 int gcsa2_find_stats_device(const gcsa2_index* index, const uint8_t* d_patterns,
                             const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
                             uint64_t* d_stats, void* stream);

@@ -336,3 +336,57 @@ def test_compare_kmers(engine):
             assert ga.compare_kmers(gb, k, include_Ns=ns) == ca.compare_kmers(cb, k, include_Ns=ns), (k, ns)
     assert ga.compare_kmers(gb, 12, force=True) == ca.compare_kmers(cb, 12, force=True)
     assert ga.compare_kmers(ga, 6) == (ga.count_kmers(6), 0, 0)
+
+
+def test_locate_table_and_walk_agree(engine, monkeypatch):
+    """locate() through the memoised table (default) and through the walk kernel
+    (GCSA2_LOCATE_TABLE=0) both equal the oracle, sorted and unsorted, single-node ranges
+    (fast path: no duplicate removal needed) and wide ranges alike."""
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    g = graphs.snp_graph(6000, 0xA1, 0xA2, snp_period=10, node_len=16)
+    ix = builder.build(g, 16, sample_period=16, branching=8)
+    cpu = OracleIndex(ix)
+    rng = SplitMix64(0xA3)
+    singles = np.array([(v, v) for v in (rng.below(ix.n) for _ in range(4000))], dtype=np.uint64)
+    wide = []
+    for _ in range(300):
+        a = rng.below(ix.n)
+        wide.append((a, min(ix.n - 1, a + rng.below(40))))
+    wide += [(1, 0), (0, ix.n - 1), (ix.n, ix.n + 1)]
+    wide = np.array(wide, dtype=np.uint64)
+    engines = []
+    with_table = engine.GCSA(ix)
+    assert with_table.locate_table_bytes() == 8 * ix.n
+    engines.append(with_table)
+    monkeypatch.setenv("GCSA2_LOCATE_TABLE", "0")
+    without = engine.GCSA(ix)
+    assert without.locate_table_bytes() == 0
+    engines.append(without)
+    for arr in (singles, wide):
+        for sort in (True, False):
+            co, cv = cpu.locate_batch(arr) if sort else (None, None)
+            for gpu in engines:
+                go, gv = gpu.locate_batch(arr, sort=sort)
+                if sort:
+                    assert np.array_equal(go, co) and np.array_equal(gv, cv)
+                else:
+                    want = [cpu.locate((int(a), int(b)), sort=False) for a, b in arr]
+                    assert np.array_equal(np.diff(go), [len(w) for w in want])
+                    assert np.array_equal(gv, np.concatenate(want) if len(want) else gv)
+
+
+def test_locate_many_small_calls(engine):
+    """Thousands of one-range locate() calls in a row (the access pattern of locate(range, max_positions),
+    gcsa.cpp:859-871): every call returns exactly count() values.  Guards the host read-backs of the
+    pipeline (stale reads out of stream-ordered pool memory were seen at a rate of ~1 in 5000 calls)."""
+    from workload import builder
+    g = graphs.snp_graph(2000, 0x71, 0x72, snp_period=12, node_len=16)
+    ix = builder.build(g, 16, sample_period=16, branching=8)
+    gpu = engine.GCSA(ix)
+    rng = SplitMix64(0xB1)
+    nodes = np.array([rng.below(ix.n) for _ in range(6000)], dtype=np.uint64)
+    counts = gpu.count_batch(np.stack([nodes, nodes], axis=1))
+    for v, c in zip(nodes, counts):
+        offs, vals = gpu.locate_batch(np.array([(v, v)], dtype=np.uint64))
+        assert offs.tolist() == [0, int(c)] and len(vals) == int(c), int(v)
