@@ -27,7 +27,7 @@ EXPORTS = [
     "gcsa2_find_block_bytes", "gcsa2_kmer_table_k", "gcsa2_locate_table_bytes", "gcsa2_lf_batch", "gcsa2_lf_device",
     "gcsa2_lf_node_batch", "gcsa2_char_range", "gcsa2_lf_all_batch",
     "gcsa2_count_batch", "gcsa2_count_device",
-    "gcsa2_locate_run", "gcsa2_locate_fetch", "gcsa2_locate_discard", "gcsa2_locate_device",
+    "gcsa2_locate_run", "gcsa2_locate_fetch", "gcsa2_locate_discard", "gcsa2_locate_device", "gcsa2_locate_into",
     "gcsa2_parent_batch", "gcsa2_parent_device", "gcsa2_depth_batch", "gcsa2_sv_batch",
     "gcsa2_rmq_batch", "gcsa2_locate_max", "gcsa2_sample_range_batch", "gcsa2_sample_batch",
     "gcsa2_sampled_positions", "gcsa2_sigma", "gcsa2_fast_chars", "gcsa2_alphabet",
@@ -91,6 +91,7 @@ def load_library():
     L.gcsa2_locate_discard.restype = None
     L.gcsa2_locate_device.argtypes = [vp, vp, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                       u64p, vp]
+    L.gcsa2_locate_into.argtypes = [vp, vp, u64, i32, vp, vp, u64, u64p, vp]
     L.gcsa2_parent_batch.argtypes = [vp, u64p, u64, vp]
     L.gcsa2_parent_device.argtypes = [vp, vp, u64, vp, vp]
     L.gcsa2_depth_batch.argtypes = [vp, u64p, u64, u64p]
@@ -472,6 +473,17 @@ class GCSA:
 
     def locate_discard(self, job):
         self._L.gcsa2_locate_discard(job)
+
+    def locate_into(self, d_ranges, nq, d_offsets, d_values, capacity, stream=0, sort=True):
+        """locate() into caller-owned device buffers; returns the number of values.  Raises
+        Gcsa2Error (BUFFER_TOO_SMALL, `.needed` = values required) when capacity is insufficient."""
+        total = C.c_uint64()
+        rc = self._L.gcsa2_locate_into(self._h, d_ranges, nq, int(sort), d_offsets, d_values, capacity, C.byref(total), stream)
+        if rc != 0:
+            err = Gcsa2Error(rc, self._L.gcsa2_last_error().decode(errors="replace"))
+            err.needed = total.value
+            raise err
+        return total.value
 
     def count_device(self, d_ranges, nq, d_counts, stream=0):
         _check(self._L.gcsa2_count_device(self._h, d_ranges, nq, d_counts, stream))

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <functional>
 #include <atomic>
 #include <memory>
 #include <new>
@@ -657,37 +658,25 @@ void gcsa2_locate_discard(gcsa2_locate_job* job)
   delete job;
 }
 
-int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t nq, int sort, gcsa2_locate_job** job_out,
-                        const uint64_t** d_offsets, const uint64_t** d_values, uint64_t* total_values, void* stream_)
-{
-  CHECK_INDEX(ix);
-  if(job_out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null job pointer"); }
-  *job_out = nullptr;
-  if(!ix->img.has_samples || !ix->img.has_counters)
-  {
-    return fail(GCSA2_ERR_MISSING_COMPONENT, "locate needs samples and counters (extra_pointers sizes the output)");
-  }
-  if(nq >= (u64(1) << 31) - 1) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate batch of >= 2^31 queries; split the batch"); }
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  DeviceGuard guard(ix->device);
-  gcsa2_locate_job* job = new(std::nothrow) gcsa2_locate_job();
-  if(job == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
-  job->device = ix->device; job->nq = nq; job->stream = stream;
-  struct Cleanup { gcsa2_locate_job*& j; bool armed = true; ~Cleanup() { if(armed) { gcsa2_locate_discard(j); j = nullptr; } } };
-  Cleanup cleanup{job};
+// The locate pipeline proper.  d_offsets (nq + 1 entries) is written on the device; values_for(count)
+// hands out the buffer for `count` values once that is known (nullptr = refuse); *total_out = number of
+// values.  Complete (stream synchronised) on return.
+typedef std::function<u64*(u64)> ValuesProvider;
 
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_offsets), (nq + 1) * sizeof(u64)));    // read by the host: not pool memory
+} // extern "C"
+
+namespace {
+
+int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u64* d_offsets,
+                const ValuesProvider& values_for, u64* total_out, hipStream_t stream)
+{
+  *total_out = 0;
   if(nq == 0)
   {
-    HIP_TRY(hipMemsetAsync(job->d_offsets, 0, sizeof(u64), stream));
+    HIP_TRY(hipMemsetAsync(d_offsets, 0, sizeof(u64), stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    cleanup.armed = false; *job_out = job;
-    if(d_offsets) { *d_offsets = job->d_offsets; }
-    if(d_values) { *d_values = nullptr; }
-    if(total_values) { *total_values = 0; }
     return GCSA2_OK;
   }
-
   Scratch scratch(stream);
 
   // [node_counts | raw_counts | node_off] (nq + 1 each), [seg_begin | seg_end] (nq each), 3 totals; the
@@ -696,7 +685,7 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
   u64* sizes = nullptr; u64* segs = nullptr;
   unsigned long long* d_totals = ix->d_slots + 4 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);   // {nodes, raw, multi, unique}
   HIP_TRY(scratch.get(sizes, 3 * (nq + 1))); HIP_TRY(scratch.get(segs, 2 * nq));
-  u64 *node_counts = sizes, *raw_counts = sizes + (nq + 1), *node_off = sizes + 2 * (nq + 1), *raw_off = job->d_offsets;
+  u64 *node_counts = sizes, *raw_counts = sizes + (nq + 1), *node_off = sizes + 2 * (nq + 1), *raw_off = d_offsets;
   u64 *seg_begin = segs, *seg_end = segs + nq;
   hipLaunchKernelGGL(k_locate_sizes, dim3(grid_for(nq)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_counts, raw_counts, d_totals);
   LAUNCH_CHECK("k_locate_sizes");
@@ -719,7 +708,7 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
 
   if(total_raw == 0)
   {
-    HIP_TRY(hipMemsetAsync(job->d_offsets, 0, (nq + 1) * sizeof(u64), stream));
+    HIP_TRY(hipMemsetAsync(d_offsets, 0, (nq + 1) * sizeof(u64), stream));
     HIP_TRY(hipStreamSynchronize(stream));
   }
   else if(!sort || multi == 0)
@@ -727,11 +716,12 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
     // sort == false (gcsa.cpp:827-842 without removeDuplicates): values in path order, the values of
     // one path node in sample order, duplicates kept -- exactly the walk's output.  With at most one
     // value per query that output is already sorted and distinct.
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_values), total_raw * sizeof(u64)));
-    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, job->d_values, stream);
+    u64* out = values_for(total_raw);
+    if(out == nullptr) { *total_out = total_raw; return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
+    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, out, stream);
     LAUNCH_CHECK("k_locate_walk");
     HIP_TRY(hipStreamSynchronize(stream));
-    job->total = total_raw;
+    *total_out = total_raw;
   }
   else
   {
@@ -764,20 +754,81 @@ int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_
     LAUNCH_CHECK("k_publish");
     HIP_TRY(hipMemcpyAsync(&total_unique, d_totals + 3, sizeof(u64), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    job->total = total_unique;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_values), (total_unique > 0 ? total_unique : 1) * sizeof(u64)));
-    hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, flags, flag_scan, total_raw, job->d_values);
+    *total_out = total_unique;
+    u64* out = values_for(total_unique);
+    if(out == nullptr) { return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
+    hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, flags, flag_scan, total_raw, out);
     LAUNCH_CHECK("k_compact");
-    hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, flag_scan, nq, total_raw, total_unique, job->d_offsets);
+    hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, flag_scan, nq, total_raw, total_unique, d_offsets);
     LAUNCH_CHECK("k_final_offsets");
     HIP_TRY(hipStreamSynchronize(stream));
   }
 
+  return GCSA2_OK;
+}
+
+int locate_checks(const gcsa2_index* ix, u64 nq)
+{
+  if(!ix->img.has_samples || !ix->img.has_counters)
+  {
+    return fail(GCSA2_ERR_MISSING_COMPONENT, "locate needs samples and counters (extra_pointers sizes the output)");
+  }
+  if(nq >= (u64(1) << 31) - 1) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate batch of >= 2^31 queries; split the batch"); }
+  return GCSA2_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcsa2_locate_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t nq, int sort, gcsa2_locate_job** job_out,
+                        const uint64_t** d_offsets, const uint64_t** d_values, uint64_t* total_values, void* stream_)
+{
+  CHECK_INDEX(ix);
+  if(job_out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null job pointer"); }
+  *job_out = nullptr;
+  int rc = locate_checks(ix, nq);
+  if(rc != GCSA2_OK) { return rc; }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(ix->device);
+  gcsa2_locate_job* job = new(std::nothrow) gcsa2_locate_job();
+  if(job == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+  job->device = ix->device; job->nq = nq; job->stream = stream;
+  struct Cleanup { gcsa2_locate_job*& j; bool armed = true; ~Cleanup() { if(armed) { gcsa2_locate_discard(j); j = nullptr; } } };
+  Cleanup cleanup{job};
+
+  // the job's buffers are read back by the host (locate_run / locate_fetch): plain hipMalloc, not pool memory
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&job->d_offsets), (nq + 1) * sizeof(u64)));
+  ValuesProvider provide = [job](u64 count) -> u64*
+  {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&job->d_values), (count > 0 ? count : 1) * sizeof(u64));
+    if(e != hipSuccess) { fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(values): ") + hipGetErrorString(e)); return nullptr; }
+    return job->d_values;
+  };
+  g_error.clear();
+  rc = locate_core(ix, d_ranges, nq, sort, job->d_offsets, provide, &job->total, stream);
+  if(rc != GCSA2_OK) { return rc; }
   cleanup.armed = false; *job_out = job;
   if(d_offsets) { *d_offsets = job->d_offsets; }
   if(d_values) { *d_values = job->d_values; }
   if(total_values) { *total_values = job->total; }
   return GCSA2_OK;
+}
+
+int gcsa2_locate_into(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t nq, int sort, uint64_t* d_offsets,
+                      uint64_t* d_values, uint64_t capacity, uint64_t* total_values, void* stream_)
+{
+  CHECK_INDEX(ix);
+  if(d_offsets == nullptr || total_values == nullptr || (d_values == nullptr && capacity > 0))
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer");
+  }
+  int rc = locate_checks(ix, nq);
+  if(rc != GCSA2_OK) { return rc; }
+  DeviceGuard guard(ix->device);
+  ValuesProvider provide = [d_values, capacity](u64 count) -> u64* { return count <= capacity ? d_values : nullptr; };
+  g_error.clear();
+  return locate_core(ix, d_ranges, nq, sort, d_offsets, provide, total_values, static_cast<hipStream_t>(stream_));
 }
 
 // ---- host-pointer entry points: copy in, run, copy out, synchronise ----------------------

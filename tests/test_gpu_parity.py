@@ -390,3 +390,34 @@ def test_locate_many_small_calls(engine):
     for v, c in zip(nodes, counts):
         offs, vals = gpu.locate_batch(np.array([(v, v)], dtype=np.uint64))
         assert offs.tolist() == [0, int(c)] and len(vals) == int(c), int(v)
+
+
+def test_locate_into_caller_buffers(engine):
+    """gcsa2_locate_into: same CSR result as locate_run/fetch, written into caller-owned device
+    buffers; an undersized buffer is refused and reports the size needed."""
+    import torch
+    from oracle.oracle import OracleIndex
+    name, g, K = CASES[-1]
+    ix = build(g, K, sample_period=8, branching=4)
+    gpu, cpu = engine.GCSA(ix), OracleIndex(ix)
+    ranges = np.array(all_ranges(ix, 0x17) + [(1, 0), (0, ix.n - 1)], dtype=np.uint64)
+    dev = torch.device("cuda", 0)
+    d_r = torch.from_numpy(ranges.view(np.int64)).to(dev)
+    for sort in (True, False):
+        if sort:
+            co, cv = cpu.locate_batch(ranges)
+        else:
+            parts = [cpu.locate((int(a), int(b)), sort=False) for a, b in ranges]
+            co = np.concatenate([[0], np.cumsum([len(x) for x in parts])]).astype(np.uint64)
+            cv = np.concatenate(parts)
+        d_o = torch.full((len(ranges) + 1,), -1, dtype=torch.int64, device=dev)
+        d_v = torch.full((len(cv) + 5,), -1, dtype=torch.int64, device=dev)
+        total = gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), d_v.shape[0], sort=sort)
+        assert total == len(cv)
+        assert np.array_equal(d_o.cpu().numpy().view(np.uint64), co)
+        assert np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], cv)
+        assert (d_v[total:] == -1).all()
+        with pytest.raises(engine.Gcsa2Error) as e:
+            gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), len(cv) - 1, sort=sort)
+        assert e.value.code == -6 and e.value.needed == len(cv)
+    assert gpu.locate_into(d_r.data_ptr(), 0, d_o.data_ptr(), 0, 0) == 0 and int(d_o[0]) == 0

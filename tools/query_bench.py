@@ -111,9 +111,14 @@ def main():
     t_locate = (time.perf_counter() - t0) / reps
     line("locate()", nl, t_locate)
     print(f"{locate_once.total} occurrences ({t_locate / max(locate_once.total, 1) * 1e6:.4f} µs/occurrence)")
+    # the same query into caller-owned buffers (no result allocation inside the call)
+    d_lo = torch.zeros(nl + 1, dtype=torch.int64, device=dev)
+    d_lv = torch.zeros(max(int(locate_once.total), 1), dtype=torch.int64, device=dev)
+    t_into = timed(lambda: gpu.locate_into(sub.data_ptr(), nl, d_lo.data_ptr(), d_lv.data_ptr(), d_lv.shape[0], sp))
+    line("locate_into", nl, t_into)
     res["gpu"] = {"find_qps": nq / t_find, "parent_qps": nh / t_parent, "count_qps": nh / t_count,
                   "locate_qps": nl / t_locate, "locate_values_per_s": locate_once.total / t_locate,
-                  "locate_values": int(locate_once.total)}
+                  "locate_values": int(locate_once.total), "locate_into_qps": nl / t_into}
 
     # CPU oracle beside it (bounded sample, all threads)
     cores = max_threads()
