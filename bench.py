@@ -182,6 +182,31 @@ def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup):
                 found=found, d_out=d_out)
 
 
+def measure_locate(gpu, d_ranges, dev, steps):
+    """Secondary figure (BASELINE configs[2]): locate() of the ranges the timed find() returned, into
+    caller-owned device buffers (gcsa2_locate_into); reported beside the headline, never part of `value`."""
+    import torch
+    nq = int(d_ranges.shape[0])
+    stream = torch.cuda.current_stream()
+    d_off = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
+    d_val = torch.zeros(1, dtype=torch.int64, device=dev)
+    try:
+        total = gpu.locate_into(d_ranges.data_ptr(), nq, d_off.data_ptr(), d_val.data_ptr(), 1, stream.cuda_stream)
+    except Exception as e:           # BUFFER_TOO_SMALL carries the size needed
+        total = getattr(e, "needed", 0)
+    d_val = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+    gpu.locate_into(d_ranges.data_ptr(), nq, d_off.data_ptr(), d_val.data_ptr(), d_val.shape[0], stream.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gpu.locate_into(d_ranges.data_ptr(), nq, d_off.data_ptr(), d_val.data_ptr(), d_val.shape[0], stream.cuda_stream)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"workload": f"locate() of the {nq} ranges found above, sorted distinct values per range, results into caller-owned HBM buffers",
+            "value": nq / (ms * 1e-3), "unit": "queries/s", "ms_per_step": ms, "values": int(total),
+            "locate_table_bytes": gpu.locate_table_bytes()}
+
+
 def pmc_traffic(args, key, nq, m):
     """Memory-side read bytes of one launch from the committed rocprofv3 --pmc pass of this exact
     workload (profiles/traffic.json, derivation in profiles/r01_v4_pmc.md).  PMC counters cannot
@@ -272,6 +297,8 @@ def main():
                                           "kernel time, served mostly on-die; see hbm_resident for the HBM-bound figure")
         if not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(args, ix, flat, offsets, r["d_out"], m)
+        if args.workload == "snp" and world == 1:
+            result["locate"] = measure_locate(gpu, r["d_out"], dev, max(3, args.steps // 4))
     del r
 
     # secondary measurement: the same kernel on an index far larger than the Infinity Cache
