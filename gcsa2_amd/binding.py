@@ -34,7 +34,7 @@ EXPORTS = [
     "gcsa2_lcp_size", "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching",
     "gcsa2_lcp_access_batch",
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
-    "gcsa2_group_find_batch", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_match_stats_batch", "gcsa2_match_stats_device",
+    "gcsa2_group_find_batch", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
 ]
@@ -105,6 +105,7 @@ def load_library():
     L.gcsa2_lcp_access_batch.argtypes = [vp, u64p, u64, u64p]
     L.gcsa2_count_kmers.argtypes = [vp, u64, i32, i32, u64p]
     L.gcsa2_compare_kmers.argtypes = [vp, vp, u64, i32, i32, u64p]
+    L.gcsa2_compare_kmers_records.argtypes = [vp, vp, u64, i32, i32, u64p, u64p, u64, u64p, u64]
     L.gcsa2_host_view_save.argtypes = [C.POINTER(HostView), C.c_char_p]
     L.gcsa2_host_view_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.gcsa2_host_view_get.argtypes = [vp]
@@ -407,6 +408,17 @@ class GCSA:
         out = np.zeros(3, dtype=np.uint64)
         _check(self._L.gcsa2_compare_kmers(self._h, other._h, k, int(include_Ns), int(force), _p64(out)))
         return tuple(int(x) for x in out)
+
+    def compare_kmers_records(self, other, k, include_Ns=False, force=False):
+        """compareKMers with parameters.output: (counts, left_states, right_states), states as
+        (count, 8) uint64 arrays in the layout of the reference's .left / .right dumps."""
+        counts = self.compare_kmers(other, k, include_Ns, force)
+        left = np.zeros((max(counts[1], 1), 8), dtype=np.uint64)
+        right = np.zeros((max(counts[2], 1), 8), dtype=np.uint64)
+        out = np.zeros(3, dtype=np.uint64)
+        _check(self._L.gcsa2_compare_kmers_records(self._h, other._h, k, int(include_Ns), int(force), _p64(out),
+                                                   _p64(left), counts[1], _p64(right), counts[2]))
+        return tuple(int(x) for x in out), left[: counts[1]], right[: counts[2]]
 
     def match_stats_batch(self, patterns, offsets):
         """Matching statistics by fused LF + parent (needs the LCP array):

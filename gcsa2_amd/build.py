@@ -43,17 +43,26 @@ CLI_SRC = os.path.join(ROOT, "tools", "cpp", "query_gcsa.cpp")
 CLI_OUT = os.path.join(HERE, "lib", "query_gcsa")
 
 
-def build_query_gcsa(force=False):
-    """The reference's query_gcsa command line as a client of the C++ facade (host compiler only)."""
+def build_cli(name, force=False):
+    """A reference command line tool (tools/cpp/<name>.cpp) as a client of the C++ facade (host compiler only)."""
     build()
-    deps = [CLI_SRC, os.path.join(ROOT, "include", "gcsa2_hip", "gcsa.hpp"), os.path.join(ROOT, "include", "gcsa2_hip.h")]
-    if not force and os.path.exists(CLI_OUT) and all(os.path.getmtime(CLI_OUT) >= os.path.getmtime(d) for d in deps):
-        return CLI_OUT
+    src, out = os.path.join(ROOT, "tools", "cpp", name + ".cpp"), os.path.join(HERE, "lib", name)
+    deps = [src, os.path.join(ROOT, "include", "gcsa2_hip", "gcsa.hpp"), os.path.join(ROOT, "include", "gcsa2_hip.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
     libdir = os.path.dirname(OUT)
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), CLI_SRC, "-o", CLI_OUT,
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", out,
                            "-L", libdir, "-lgcsa2_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
                            "-Wl,--allow-shlib-undefined"])
-    return CLI_OUT
+    return out
+
+
+def build_query_gcsa(force=False):
+    return build_cli("query_gcsa", force)
+
+
+def build_count_kmers(force=False):
+    return build_cli("count_kmers", force)
 
 
 if __name__ == "__main__":

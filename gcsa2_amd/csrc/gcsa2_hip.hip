@@ -210,7 +210,7 @@ u64 stage_flb(Stager& st, const gcsa2_host_view* v, DevImage& img, const std::ve
     const u64* rb = words + bwt_blocks_off[c];
     u64* dst_base = words + off + c * nblocks * FLB_WORDS;
     const u64 Cc = v->C[c];
-    parallel_ranges(nblocks, [=, &ew, &ecum](u64 b0, u64 b1)
+    parallel_ranges(nblocks, [=, &ew](u64 b0, u64 b1)
     {
       for(u64 b = b0; b < b1; b++)
       {
@@ -1509,9 +1509,12 @@ extern "C" int gcsa2_index_create_from_file(const char* path, int device, gcsa2_
   return rc;
 }
 
-// compareKMers(left, right, k, parameters) (src/algorithms.cpp:534-616): counts only.
-extern "C" int gcsa2_compare_kmers(const gcsa2_index* left, const gcsa2_index* right, uint64_t k, int include_ns, int force,
-                                   uint64_t* result)
+// compareKMers(left, right, k, parameters) (src/algorithms.cpp:534-616).  With record buffers the states of
+// the unique k-mers are returned as the reference dumps them to output.left / output.right (:606-610).
+namespace {
+
+int compare_kmers_impl(const gcsa2_index* left, const gcsa2_index* right, uint64_t k, int include_ns, int force, uint64_t* result,
+                       uint64_t* left_records, uint64_t left_capacity, uint64_t* right_records, uint64_t right_capacity, bool records)
 {
   CHECK_INDEX(left); CHECK_INDEX(right);
   if(result == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null result"); }
@@ -1528,29 +1531,67 @@ extern "C" int gcsa2_compare_kmers(const gcsa2_index* left, const gcsa2_index* r
   HIP_TRY(images.alloc(2)); HIP_TRY(counters.alloc(4));
   HIP_TRY(hipMemcpy(images.p, &left->img, sizeof(DevImage), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(images.p + 1, &right->img, sizeof(DevImage), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(counters.p, 0, 4 * sizeof(unsigned long long)));
-  DBuf<u64> frontier;
+  DBuf<u64> frontier, keys;
   HIP_TRY(frontier.alloc(4));
   u64 root[4] = {0, left->img.n - 1, 0, right->img.n - 1};
   HIP_TRY(hipMemcpy(frontier.p, root, sizeof(root), hipMemcpyHostToDevice));
+  if(records) { HIP_TRY(keys.alloc(3)); HIP_TRY(hipMemset(keys.p, 0, 3 * sizeof(u64))); }
   u64 n = 1;
+  unsigned long long host_counters[4] = {0, 0, 0, 0};
   for(u64 depth = 0; depth < k && n > 0; depth++)
   {
     const bool last = (depth + 1 == k);
     if(n * limit > (u64(1) << 27)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "compareKMers frontier exceeds 2^27 states; use a smaller k"); }
-    DBuf<u64> next;
-    if(!last) { HIP_TRY(next.alloc(n * limit * 4)); }
-    HIP_TRY(hipMemset(counters.p, 0, sizeof(unsigned long long)));
-    hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, images.p, images.p + 1, frontier.p, n, limit,
-                       last ? 1 : 0, next.p, counters.p);
+    HIP_TRY(hipMemset(counters.p, 0, 4 * sizeof(unsigned long long)));
+    if(last)
+    {
+      hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, images.p, images.p + 1, frontier.p, keys.p, n, limit,
+                         u32(depth), 1, (u64*)nullptr, (u64*)nullptr, counters.p, (u64*)nullptr, (u64*)nullptr);
+      LAUNCH_CHECK("k_kmer_compare");
+      HIP_TRY(hipMemcpy(host_counters, counters.p, sizeof(host_counters), hipMemcpyDeviceToHost));
+      result[0] = host_counters[1]; result[1] = host_counters[2]; result[2] = host_counters[3];
+      if(records)
+      {
+        if(result[1] > left_capacity || result[2] > right_capacity) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "record buffers smaller than result[1] / result[2]"); }
+        DBuf<u64> d_left, d_right;
+        HIP_TRY(d_left.alloc(8 * result[1])); HIP_TRY(d_right.alloc(8 * result[2]));
+        HIP_TRY(hipMemset(counters.p, 0, 4 * sizeof(unsigned long long)));
+        hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, images.p, images.p + 1, frontier.p, keys.p, n, limit,
+                           u32(depth), 2, (u64*)nullptr, (u64*)nullptr, counters.p, d_left.p, d_right.p);
+        LAUNCH_CHECK("k_kmer_compare");
+        if(result[1] > 0) { HIP_TRY(hipMemcpy(left_records, d_left.p, 8 * result[1] * sizeof(u64), hipMemcpyDeviceToHost)); }
+        if(result[2] > 0) { HIP_TRY(hipMemcpy(right_records, d_right.p, 8 * result[2] * sizeof(u64), hipMemcpyDeviceToHost)); }
+      }
+      break;
+    }
+    DBuf<u64> next, next_keys;
+    HIP_TRY(next.alloc(n * limit * 4));
+    if(records) { HIP_TRY(next_keys.alloc(n * limit * 3)); }
+    hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, images.p, images.p + 1, frontier.p, keys.p, n, limit,
+                       u32(depth), 0, next.p, next_keys.p, counters.p, (u64*)nullptr, (u64*)nullptr);
     LAUNCH_CHECK("k_kmer_compare");
-    unsigned long long host_counters[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(host_counters, counters.p, sizeof(host_counters), hipMemcpyDeviceToHost));
-    if(last) { result[0] = host_counters[1]; result[1] = host_counters[2]; result[2] = host_counters[3]; break; }
     n = host_counters[0];
-    std::swap(frontier.p, next.p);      // `next` now owns the old frontier and frees it
+    std::swap(frontier.p, next.p);      // `next` / `next_keys` now own the old buffers and free them
+    std::swap(keys.p, next_keys.p);
   }
   return GCSA2_OK;
+}
+
+} // namespace
+
+extern "C" int gcsa2_compare_kmers(const gcsa2_index* left, const gcsa2_index* right, uint64_t k, int include_ns, int force,
+                                   uint64_t* result)
+{
+  return compare_kmers_impl(left, right, k, include_ns, force, result, nullptr, 0, nullptr, 0, false);
+}
+
+extern "C" int gcsa2_compare_kmers_records(const gcsa2_index* left, const gcsa2_index* right, uint64_t k, int include_ns, int force,
+                                           uint64_t* result, uint64_t* left_records, uint64_t left_capacity,
+                                           uint64_t* right_records, uint64_t right_capacity)
+{
+  if((left_records == nullptr && left_capacity > 0) || (right_records == nullptr && right_capacity > 0)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null record buffer"); }
+  return compare_kmers_impl(left, right, k, include_ns, force, result, left_records, left_capacity, right_records, right_capacity, true);
 }
 
 // ---- `.gcsa` / `.lcp` files as written by GCSA::serialize / LCPArray::serialize ---------------------

@@ -327,29 +327,65 @@ __device__ __forceinline__ void lf_child(const DevImage& img, u32 c, u64 sp0, u6
   }
 }
 
+// KMerComparisonState::set (algorithms.cpp:451-457): comp of extension step i at bits [3i, 3i + 3).
+// (The reference also evaluates `comp >> (64 - bit)` for bit == 0, a shift by the word size; the intended
+// "|= 0 unless the comp straddles two words" is what is restated here.)
+__device__ __forceinline__ void kmer_set(u64* kmer, u32 i, u64 comp)
+{
+  u32 offset = (i * 3) >> 6, bit = (i * 3) & 63;
+  kmer[offset] |= comp << bit;
+  if(bit > 61) { kmer[offset + 1] |= comp >> (64 - bit); }
+}
+
+// mode 0: expand (children appended to out / out_keys, counters[0] = number of children)
+// mode 1: classify the children: counters[1] += shared, counters[2] += left only, counters[3] += right only
+// mode 2: like 1, and the left-only / right-only children are written as 8-u64 KMerComparisonState
+//         records (left range, right range, k, kmer[3]) to left_records / right_records
 __global__ __launch_bounds__(TPB) void k_kmer_compare(const DevImage* __restrict__ left, const DevImage* __restrict__ right,
-                                                      const u64* __restrict__ in, u64 n_in, u32 limit, int final,
-                                                      u64* __restrict__ out, unsigned long long* __restrict__ counters)
+                                                      const u64* __restrict__ in, const u64* __restrict__ in_keys, u64 n_in,
+                                                      u32 limit, u32 depth, int mode,
+                                                      u64* __restrict__ out, u64* __restrict__ out_keys,
+                                                      unsigned long long* __restrict__ counters,
+                                                      u64* __restrict__ left_records, u64* __restrict__ right_records)
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   const u32 lane = threadIdx.x & 63;
+  const u64 below = (u64(1) << lane) - 1;
   bool live = q < n_in;
   ulonglong2 l = make_ulonglong2(1, 0), r = make_ulonglong2(1, 0);
-  if(live) { l = reinterpret_cast<const ulonglong2*>(in)[2 * q]; r = reinterpret_cast<const ulonglong2*>(in)[2 * q + 1]; }
+  u64 key[3] = {0, 0, 0};
+  if(live)
+  {
+    l = reinterpret_cast<const ulonglong2*>(in)[2 * q]; r = reinterpret_cast<const ulonglong2*>(in)[2 * q + 1];
+    if(in_keys != nullptr) { key[0] = in_keys[3 * q]; key[1] = in_keys[3 * q + 1]; key[2] = in_keys[3 * q + 2]; }
+  }
   for(u32 c = 1; c <= limit; c++)
   {
     u64 lsp = 1, lep = 0, rsp = 1, rep = 0;
     if(live) { lf_child(*left, c, l.x, l.y, lsp, lep); lf_child(*right, c, r.x, r.y, rsp, rep); }
     const bool lhas = live && !range_empty(lsp, lep), rhas = live && !range_empty(rsp, rep);
     const bool has = lhas || rhas;
-    if(final)
+    u64 child[3] = {key[0], key[1], key[2]};
+    if(has && (out_keys != nullptr || mode == 2)) { kmer_set(child, depth, c); }
+    if(mode != 0)
     {
-      u64 both = __ballot(lhas && rhas), lonly = __ballot(lhas && !rhas), ronly = __ballot(rhas && !lhas);
-      if(lane == 0)
+      const bool lonly = lhas && !rhas, ronly = rhas && !lhas;
+      u64 both = __ballot(lhas && rhas), lmask = __ballot(lonly), rmask = __ballot(ronly);
+      if(lane == 0 && both) { atomicAdd(counters + 1, (unsigned long long)__popcll(both)); }
+      for(int side = 0; side < 2; side++)
       {
-        if(both) { atomicAdd(counters + 1, (unsigned long long)__popcll(both)); }
-        if(lonly) { atomicAdd(counters + 2, (unsigned long long)__popcll(lonly)); }
-        if(ronly) { atomicAdd(counters + 3, (unsigned long long)__popcll(ronly)); }
+        u64 mask = (side == 0 ? lmask : rmask);
+        if(mask == 0) { continue; }
+        u32 leader = u32(__ffsll((long long)mask)) - 1;
+        unsigned long long base = 0;
+        if(lane == leader) { base = atomicAdd(counters + 2 + side, (unsigned long long)__popcll(mask)); }
+        base = __shfl(base, leader, 64);
+        if(mode == 2 && (side == 0 ? lonly : ronly))
+        {
+          u64* rec = (side == 0 ? left_records : right_records) + 8 * (base + __popcll(mask & below));
+          rec[0] = lsp; rec[1] = lep; rec[2] = rsp; rec[3] = rep; rec[4] = u64(depth) + 1;
+          rec[5] = child[0]; rec[6] = child[1]; rec[7] = child[2];
+        }
       }
       continue;
     }
@@ -362,9 +398,10 @@ __global__ __launch_bounds__(TPB) void k_kmer_compare(const DevImage* __restrict
       base = __shfl(base, leader, 64);
       if(has && out != nullptr)
       {
-        u64 slot = base + __popcll(mask & ((u64(1) << lane) - 1));
+        u64 slot = base + __popcll(mask & below);
         reinterpret_cast<ulonglong2*>(out)[2 * slot] = make_ulonglong2(lsp, lep);
         reinterpret_cast<ulonglong2*>(out)[2 * slot + 1] = make_ulonglong2(rsp, rep);
+        if(out_keys != nullptr) { out_keys[3 * slot] = child[0]; out_keys[3 * slot + 1] = child[1]; out_keys[3 * slot + 2] = child[2]; }
       }
     }
   }

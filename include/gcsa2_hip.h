@@ -262,12 +262,21 @@ int gcsa2_lcp_access_batch(const gcsa2_index* index, const uint64_t* positions, 
 int gcsa2_count_kmers(const gcsa2_index* index, uint64_t k, int include_ns, int force, uint64_t* result);
 
 /* compareKMers(left, right, k, parameters) (include/gcsa/algorithms.h:86-92, src/algorithms.cpp:534-616):
- * result[0..2] = number of k-mers in both indexes, only in the left, only in the right one (counts
- * only: the reference's optional .left / .right dumps are not produced).  Same early exits as the
+ * result[0..2] = number of k-mers in both indexes, only in the left, only in the right one.  Same early exits as the
  * reference (k == 0 -> {1,0,0}; k > order without force, k > 64, incompatible alphabets -> zeros).
  * Both indexes must be on the same device. */
 int gcsa2_compare_kmers(const gcsa2_index* left, const gcsa2_index* right, uint64_t k, int include_ns,
                         int force, uint64_t* result);
+/* The same, also returning the search states of the k-mers found in one index only, as the reference
+ * writes them to parameters.output + ".left" / ".right" (src/algorithms.cpp:425-457, 606-610): 8 u64
+ * per state = left range, right range, k, kmer[3] (3 bits per comp, extension step i at bits
+ * [3i, 3i+3), i.e. the LAST character of the k-mer first).  Order within a buffer is unspecified (the
+ * reference's depends on its OpenMP schedule).  Capacities are in states; if result[1] / result[2]
+ * exceed them the call fails with GCSA2_ERR_BUFFER_TOO_SMALL and result[] holds the sizes needed. */
+int gcsa2_compare_kmers_records(const gcsa2_index* left, const gcsa2_index* right, uint64_t k,
+                                int include_ns, int force, uint64_t* result,
+                                uint64_t* left_records, uint64_t left_capacity,
+                                uint64_t* right_records, uint64_t right_capacity);
 
 /* ---- matching statistics: the LF + parent interplay of vg's MEM finder, fused ---------------
  * (paper/paper.tex:344 "maximal exact matches by using LF-mapping and parent

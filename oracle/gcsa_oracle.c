@@ -1038,22 +1038,35 @@ double oracle_match_stats_batch(const oracle_index* ix, const uint8_t* patterns,
 /* { k-mers in both, only in the left index, only in the right index }.  Counts only (the        */
 /* reference can also dump the unshared k-mers to files, algorithms.cpp:606-610).                 */
 
-typedef struct { u64 lsp, lep, rsp, rep, k; } cstate;
+/* KMerComparisonState (algorithms.cpp:425-457): the two ranges, the depth and the k-mer, 3 bits per
+ * comp, character i of the backward extension at bits [3i, 3i+3) of kmer[0..2]. */
+typedef struct { u64 lsp, lep, rsp, rep, k, kmer[3]; } cstate;
 
-void oracle_compare_kmers(const oracle_index* left, const oracle_index* right, uint64_t k, int include_ns, int force,
-                          uint64_t* result)
+static void cstate_set(cstate* st, u64 i, u64 comp)                                        /* :451-457 */
+{
+  u64 offset = (i * 3) >> 6, bit = (i * 3) & 63;
+  st->kmer[offset] |= comp << bit;
+  if(bit > 61) { st->kmer[offset + 1] |= comp >> (64 - bit); }
+}
+
+/* records != NULL: *left_records / *right_records receive malloc'ed arrays of 8-u64 states (the structs
+ * the reference writes to output.left / output.right, :606-610), result[1] / result[2] of them. */
+void oracle_compare_kmers_records(const oracle_index* left, const oracle_index* right, uint64_t k, int include_ns, int force,
+                                  uint64_t* result, uint64_t** left_records, uint64_t** right_records)
 {
   result[0] = result[1] = result[2] = 0;
+  if(left_records) { *left_records = NULL; }
+  if(right_records) { *right_records = NULL; }
   if(k == 0) { result[0] = 1; return; }                                                   /* :539 */
   if((k > left->order || k > right->order) && !force) { return; }                         /* :540-549 */
   if(k > 64) { return; }                                                                  /* :550-554, MAX_K */
   if(left->sigma != right->sigma || left->fast_chars != right->fast_chars) { return; }    /* :556-560 */
   u64 limit = (include_ns ? left->sigma : left->fast_chars + 2);                           /* :511 */
-  u64 cap = 1024, top = 0;
+  u64 cap = 1024, top = 0, lcap = 0, rcap = 0;
   cstate* stack = (cstate*)malloc(cap * sizeof(cstate));
   u64* lp = (u64*)malloc(2 * left->sigma * sizeof(u64));
   u64* rp = (u64*)malloc(2 * right->sigma * sizeof(u64));
-  cstate root = { 0, left->n - 1, 0, right->n - 1, 0 };
+  cstate root = { 0, left->n - 1, 0, right->n - 1, 0, {0, 0, 0} };
   stack[top++] = root;
   while(top > 0)
   {
@@ -1062,7 +1075,19 @@ void oracle_compare_kmers(const oracle_index* left, const oracle_index* right, u
     if(le && re) { continue; }                                                             /* :515 */
     if(cur.k == k)                                                                         /* report, :473-491 */
     {
-      if(!le && !re) { result[0]++; } else if(!le) { result[1]++; } else { result[2]++; }
+      if(!le && !re) { result[0]++; }
+      else
+      {
+        uint64_t** dst = (!le ? left_records : right_records);
+        u64* count = (!le ? &result[1] : &result[2]);
+        u64* capacity = (!le ? &lcap : &rcap);
+        if(dst != NULL)
+        {
+          if(*count == *capacity) { *capacity = (*capacity ? 2 * *capacity : 256); *dst = (u64*)realloc(*dst, *capacity * sizeof(cstate)); }
+          memcpy(*dst + 8 * *count, &cur, sizeof(cstate));
+        }
+        (*count)++;
+      }
       continue;
     }
     oracle_lf_all(left, cur.lsp, cur.lep, include_ns, lp);                                 /* :519-526 */
@@ -1070,9 +1095,16 @@ void oracle_compare_kmers(const oracle_index* left, const oracle_index* right, u
     for(u64 comp = 1; comp + 1 < limit; comp++)
     {
       if(top == cap) { cap *= 2; stack = (cstate*)realloc(stack, cap * sizeof(cstate)); }
-      cstate next = { lp[2 * comp], lp[2 * comp + 1], rp[2 * comp], rp[2 * comp + 1], cur.k + 1 };
+      cstate next = { lp[2 * comp], lp[2 * comp + 1], rp[2 * comp], rp[2 * comp + 1], cur.k + 1, { cur.kmer[0], cur.kmer[1], cur.kmer[2] } };
+      cstate_set(&next, cur.k, comp);
       stack[top++] = next;
     }
   }
   free(stack); free(lp); free(rp);
+}
+
+void oracle_compare_kmers(const oracle_index* left, const oracle_index* right, uint64_t k, int include_ns, int force,
+                          uint64_t* result)
+{
+  oracle_compare_kmers_records(left, right, k, include_ns, force, result, NULL, NULL);
 }

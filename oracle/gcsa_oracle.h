@@ -103,6 +103,11 @@ double oracle_match_stats_batch(const oracle_index* ix, const uint8_t* patterns,
 /* compareKMers (src/algorithms.cpp:534-616): result = { shared, left only, right only }. */
 void oracle_compare_kmers(const oracle_index* left, const oracle_index* right, uint64_t k, int include_ns, int force,
                           uint64_t* result);
+/* The same with the states of the unique k-mers (8 u64 each: left range, right range, k, kmer[3]), as
+ * the reference dumps them to output.left / output.right (src/algorithms.cpp:425-457, 606-610);
+ * free the arrays with oracle_free. */
+void oracle_compare_kmers_records(const oracle_index* left, const oracle_index* right, uint64_t k, int include_ns, int force,
+                                  uint64_t* result, uint64_t** left_records, uint64_t** right_records);
 
 int oracle_max_threads(void);
 

@@ -79,6 +79,7 @@ def lib():
         L.oracle_match_stats_batch.restype = dbl
         L.oracle_match_stats_batch.argtypes = [vp, u8p, u64p, u64, vp, u64p, u64p, i32]
         L.oracle_compare_kmers.argtypes = [vp, vp, u64, i32, i32, u64p]
+        L.oracle_compare_kmers_records.argtypes = [vp, vp, u64, i32, i32, u64p, C.POINTER(vp), C.POINTER(vp)]
         L.oracle_max_threads.restype = i32
         _lib = L
     return _lib
@@ -277,6 +278,21 @@ class OracleIndex:
         out = np.zeros(3, dtype=np.uint64)
         lib().oracle_compare_kmers(self._h, other._h, k, int(include_Ns), int(force), _p64(out))
         return tuple(int(x) for x in out)
+
+    def compare_kmers_records(self, other, k, include_Ns=False, force=False):
+        """compareKMers with parameters.output set: (counts, left_states, right_states); a state is the
+        8-u64 KMerComparisonState the reference writes to output.left / output.right."""
+        out = np.zeros(3, dtype=np.uint64)
+        lp, rp = C.c_void_p(), C.c_void_p()
+        lib().oracle_compare_kmers_records(self._h, other._h, k, int(include_Ns), int(force), _p64(out), C.byref(lp), C.byref(rp))
+        res = []
+        for ptr, cnt in ((lp, int(out[1])), (rp, int(out[2]))):
+            if ptr.value:
+                res.append(np.ctypeslib.as_array(C.cast(ptr, u64p), shape=(cnt * 8,)).copy().reshape(cnt, 8))
+                lib().oracle_free(ptr)
+            else:
+                res.append(np.zeros((0, 8), dtype=np.uint64))
+        return tuple(int(x) for x in out), res[0], res[1]
 
     def find_traffic(self, patterns, offsets, block_bits):
         blocks, steps = C.c_uint64(), C.c_uint64()

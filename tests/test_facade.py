@@ -157,3 +157,45 @@ def test_query_gcsa_cli_matches_oracle(tmp_path):
 
     missing = subprocess.run([exe, str(tmp_path / "nothing")], env=_run_env(), capture_output=True, text=True)
     assert missing.returncode != 0 and "Cannot load the index" in missing.stderr        # query_gcsa.cpp:55-59
+
+
+def test_count_kmers_cli_builds():
+    from gcsa2_amd import build
+    exe = build.build_count_kmers()
+    out = subprocess.run([exe], env=_run_env(), capture_output=True, text=True)
+    assert out.returncode == 0 and "usage: count_kmers [options] base_name [base_name2]" in out.stderr     # count_kmers.cpp:45-59
+
+
+@pytest.mark.gpu
+def test_count_kmers_cli_matches_oracle(tmp_path):
+    """`count_kmers -k K base` and `count_kmers -k K -o X left right` on .gcsa files
+    (reference benchmark/count_kmers.cpp): counts and the dumped symmetric difference equal the oracle's."""
+    import re
+    from gcsa2_amd import build
+    from workload import graphs, sdsl_format
+    from workload import builder
+    from oracle.oracle import OracleIndex
+    g1 = graphs.snp_graph(1500, 0x91, 0x92, snp_period=9, node_len=16)
+    g2 = graphs.snp_graph(1500, 0x91, 0x99, snp_period=7, node_len=16)
+    i1, i2 = builder.build(g1, 16), builder.build(g2, 16)
+    sdsl_format.write(i1, str(tmp_path / "left"))
+    sdsl_format.write(i2, str(tmp_path / "right"))
+    c1, c2 = OracleIndex(i1), OracleIndex(i2)
+    exe = build.build_count_kmers()
+    for k, flags in ((8, []), (11, ["-N"]), (20, ["-f"]), (20, [])):
+        run = subprocess.run([exe, "-k", str(k)] + flags + [str(tmp_path / "left")], env=_run_env(), capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, run.stderr
+        want = c1.count_kmers(k, include_Ns="-N" in flags, force="-f" in flags)
+        assert re.search(rf"Kmers:\s+{want}\n", run.stdout), (k, flags, run.stdout)
+        assert re.search(rf"GCSA:\s+{i1.n} paths, order 16\n", run.stdout)
+    out = str(tmp_path / "diff")
+    run = subprocess.run([exe, "-k", "9", "-o", out, str(tmp_path / "left"), str(tmp_path / "right")], env=_run_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    counts, left, right = c1.compare_kmers_records(c2, 9)
+    assert re.search(rf"Shared:\s+{counts[0]} kmers\nLeft:\s+{counts[1]} unique kmers\nRight:\s+{counts[2]} unique kmers", run.stdout)
+    for path, want in ((out + ".left", left), (out + ".right", right)):
+        got = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
+        assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, want.tolist()))
+    bad = subprocess.run([exe, "-k", "9", str(tmp_path / "nothing")], env=_run_env(), capture_output=True, text=True)
+    assert bad.returncode != 0 and "Cannot load the index" in bad.stderr

@@ -336,6 +336,14 @@ def test_compare_kmers(engine):
             assert ga.compare_kmers(gb, k, include_Ns=ns) == ca.compare_kmers(cb, k, include_Ns=ns), (k, ns)
     assert ga.compare_kmers(gb, 12, force=True) == ca.compare_kmers(cb, 12, force=True)
     assert ga.compare_kmers(ga, 6) == (ga.count_kmers(6), 0, 0)
+    # the states of the unique k-mers (the reference's .left / .right dumps): same set of 64-byte records
+    def canon(rows):
+        return sorted(tuple(int(x) for x in r) for r in rows)
+    for k, ns in ((1, False), (5, False), (7, True), (12, False)):
+        gc, gl, gr = ga.compare_kmers_records(gb, k, include_Ns=ns, force=True)
+        cc, cl, cr = ca.compare_kmers_records(cb, k, include_Ns=ns, force=True)
+        assert gc == cc and canon(gl) == canon(cl) and canon(gr) == canon(cr), (k, ns)
+        assert len(gl) == gc[1] and len(gr) == gc[2]
 
 
 def test_locate_table_and_walk_agree(engine, monkeypatch):
@@ -421,3 +429,40 @@ def test_locate_into_caller_buffers(engine):
             gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), len(cv) - 1, sort=sort)
         assert e.value.code == -6 and e.value.needed == len(cv)
     assert gpu.locate_into(d_r.data_ptr(), 0, d_o.data_ptr(), 0, 0) == 0 and int(d_o[0]) == 0
+
+
+def test_concurrent_host_threads(engine):
+    """One handle, several host threads (the reference's const query methods are called that way,
+    src/algorithms.cpp:113-132, 409-417): every thread gets the oracle's answers."""
+    import threading
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    g = graphs.snp_graph(4000, 0xC1, 0xC2, snp_period=10, node_len=16)
+    ix = builder.build(g, 16, sample_period=16, branching=8)
+    gpu, lcp = engine.open_index(ix)
+    cpu = OracleIndex(ix)
+    errors = []
+
+    def worker(seed):
+        try:
+            pats = [truncate_at_sink(p) for p in random_patterns(g, 16, seed, 300)]
+            data, off = concat_patterns(pats)
+            want = cpu.find_batch(data, off)
+            for _ in range(8):
+                got = gpu.find_batch(data, off)
+                assert np.array_equal(got, want)
+                hit = got[got[:, 0] <= got[:, 1]]
+                go, gv = gpu.locate_batch(hit)
+                co, cv = cpu.locate_batch(hit)
+                assert np.array_equal(go, co) and np.array_equal(gv, cv)
+                assert np.array_equal(gpu.count_batch(hit), cpu.count_batch(hit))
+                assert np.array_equal(lcp.parent_batch(hit), cpu.parent_batch(hit))
+        except Exception as e:          # noqa: BLE001  (reported below, in the main thread)
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(0xD0 + i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:2]

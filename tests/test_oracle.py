@@ -302,3 +302,17 @@ def test_compare_kmers_vs_input_graphs():
         sb = {t for t in itertools.product([1, 2, 3, 4], repeat=k) if B.starts(list(t))} if k else {()}
         assert a.compare_kmers(b, k) == (len(sa & sb), len(sa - sb), len(sb - sa)), k
     assert a.compare_kmers(b, 7) == (0, 0, 0) and a.compare_kmers(a, 4)[1:] == (0, 0)
+
+    def label(rec):      # KMerComparisonState::set, algorithms.cpp:451-457: extension step i (last character first) at bits [3i, 3i+3)
+        bits = int(rec[5]) | (int(rec[6]) << 64) | (int(rec[7]) << 128)
+        return tuple(reversed([(bits >> (3 * i)) & 7 for i in range(int(rec[4]))]))
+    for k in range(1, 6):
+        counts, left, right = a.compare_kmers_records(b, k)
+        sa = {t for t in itertools.product([1, 2, 3, 4], repeat=k) if A.starts(list(t))}
+        sb = {t for t in itertools.product([1, 2, 3, 4], repeat=k) if B.starts(list(t))}
+        assert counts == (len(sa & sb), len(sa - sb), len(sb - sa))
+        assert {label(r) for r in left} == sa - sb and {label(r) for r in right} == sb - sa
+        for r in left:       # the left range is find() of the label in the left index; the label is absent from the right one
+            pattern = bytes(b"ACGT"[c - 1] for c in label(r))
+            assert (int(r[0]), int(r[1])) == tuple(a.find(pattern))
+            assert int(r[2]) == int(r[3]) + 1 and b.find(pattern)[0] > b.find(pattern)[1]
