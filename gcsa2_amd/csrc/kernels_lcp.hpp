@@ -32,7 +32,85 @@ struct Lcp
   { u64 level = 0; while(img.lcp_offsets[level + 1] <= node) { level++; } return level; }
 };
 
-__device__ __forceinline__ bool sv_cmp(bool equal, u64 a, u64 b) { return equal ? (a <= b) : (a < b); }
+// ---- byte scans of a sibling group, eight bytes per load ------------------------------------------
+// The reference scans a sibling group one value at a time (lcp.cpp:352-366, 408-422); here the group's
+// aligned 8-byte words are fetched with independent loads and compared eight bytes at a time: the
+// position found is the same (the nearest one in scan direction), the dependent load chain is one
+// round trip per level instead of one per byte.
+
+// bit b set iff byte b of w < bound (bound <= 256): bytes in 16-bit lanes, borrow-free subtract
+__device__ __forceinline__ u32 bytes_below(u64 w, u64 bound)
+{
+  const u64 H = 0x8000800080008000ull, M = 0x00FF00FF00FF00FFull;
+  const u64 v16 = bound * 0x0001000100010001ull;
+  u64 even = ~(((w & M) | H) - v16) & H;             // lane bit 15 set iff the even byte < bound
+  u64 odd = ~((((w >> 8) & M) | H) - v16) & H;
+  u64 m = (even >> 15) | (odd >> 14);                // bits 16j (byte 2j) and 16j + 1 (byte 2j + 1)
+  return u32((m & 3) | ((m >> 14) & 0xC) | ((m >> 28) & 0x30) | ((m >> 42) & 0xC0));
+}
+
+constexpr u32 SCAN_WORDS = 8;      // one batch covers a 64-value sibling group (the reference's default branching)
+
+// nearest i in [from, to) below `to` with LCP[i] < bound
+__device__ __forceinline__ bool scan_left(const DevImage& img, u64 from, u64 to, u64 bound, u64& rpos, u64& rval)
+{
+  const u64* words = reinterpret_cast<const u64*>(img.lcp);
+  while(to > from)
+  {
+    const u64 top = (to - 1) >> 3, bottom = from >> 3;
+    u64 w[SCAN_WORDS];
+#pragma unroll
+    for(u32 k = 0; k < SCAN_WORDS; k++) { w[k] = (top >= bottom + k ? words[top - k] : 0); }
+#pragma unroll
+    for(u32 k = 0; k < SCAN_WORDS; k++)
+    {
+      if(top < bottom + k) { return false; }
+      const u64 base = (top - k) << 3;
+      u32 mask = bytes_below(w[k], bound);
+      if(to < base + 8) { mask &= (1u << (to - base)) - 1; }
+      if(from > base) { mask &= ~((1u << (from - base)) - 1); }
+      if(mask != 0)
+      {
+        u32 byte = 31 - __clz(int(mask));
+        rpos = base + byte; rval = (w[k] >> (8 * byte)) & 0xFF;
+        return true;
+      }
+    }
+    if(top < bottom + SCAN_WORDS) { return false; }
+    to = (top - (SCAN_WORDS - 1)) << 3;
+  }
+  return false;
+}
+
+// first i in [from, last] with LCP[i] < bound
+__device__ __forceinline__ bool scan_right(const DevImage& img, u64 from, u64 last, u64 bound, u64& rpos, u64& rval)
+{
+  const u64* words = reinterpret_cast<const u64*>(img.lcp);
+  while(from <= last)
+  {
+    const u64 bottom = from >> 3, top = last >> 3;
+    u64 w[SCAN_WORDS];
+#pragma unroll
+    for(u32 k = 0; k < SCAN_WORDS; k++) { w[k] = (bottom + k <= top ? words[bottom + k] : 0); }
+#pragma unroll
+    for(u32 k = 0; k < SCAN_WORDS; k++)
+    {
+      if(bottom + k > top) { return false; }
+      const u64 base = (bottom + k) << 3;
+      u32 mask = bytes_below(w[k], bound);
+      if(from > base) { mask &= ~((1u << (from - base)) - 1); }
+      if(last < base + 7) { mask &= (2u << (last - base)) - 1; }
+      if(mask != 0)
+      {
+        u32 byte = u32(__ffs(int(mask))) - 1;
+        rpos = base + byte; rval = (w[k] >> (8 * byte)) & 0xFF;
+        return true;
+      }
+    }
+    from = (bottom + SCAN_WORDS) << 3;
+  }
+  return false;
+}
 
 // psv / psev (src/lcp.cpp:345-382)
 __device__ void lcp_psv(const DevImage& img, u64 to, bool equal, u64& rpos, u64& rval)
@@ -40,30 +118,19 @@ __device__ void lcp_psv(const DevImage& img, u64 to, bool equal, u64& rpos, u64&
   Lcp L{img};
   rpos = rval = img.lcp_values;                     // notFound()
   if(to == 0 || to >= img.lcp_size) { return; }
-  u64 level = 0, val = L.at(to);
+  u64 level = 0;
+  const u64 bound = L.at(to) + (equal ? 1 : 0);     // v < val, or v <= val
   bool found = false;
   while(to != L.root())
   {
-    u64 from = L.first_sibling(to, level);
-    for(u64 i = to; i > from; )
-    {
-      i--;
-      u64 v = L.at(i);
-      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; found = true; break; }
-    }
-    if(found) { break; }
+    if(scan_left(img, L.first_sibling(to, level), to, bound, rpos, rval)) { found = true; break; }
     to = L.parent(to, level); level++;
   }
-  if(!found) { return; }
+  if(!found) { rpos = rval = img.lcp_values; return; }
   while(level > 0)
   {
     u64 from = L.first_child(rpos, level); level--;
-    for(u64 i = L.last_sibling(from, level) + 1; i > from; )
-    {
-      i--;
-      u64 v = L.at(i);
-      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; break; }
-    }
+    scan_left(img, from, L.last_sibling(from, level) + 1, bound, rpos, rval);
   }
 }
 
@@ -73,29 +140,20 @@ __device__ void lcp_nsv(const DevImage& img, u64 from, bool equal, u64& rpos, u6
   Lcp L{img};
   rpos = rval = img.lcp_values;
   if(from + 1 >= img.lcp_size) { return; }
-  u64 level = 0, val = L.at(from);
+  u64 level = 0;
+  const u64 bound = L.at(from) + (equal ? 1 : 0);
   bool found = false;
   while(from != L.root())
   {
     u64 last = L.last_sibling(L.first_sibling(from, level), level);
-    for(u64 i = from + 1; i <= last; i++)
-    {
-      u64 v = L.at(i);
-      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; found = true; break; }
-    }
-    if(found) { break; }
+    if(from + 1 <= last && scan_right(img, from + 1, last, bound, rpos, rval)) { found = true; break; }
     from = L.parent(from, level); level++;
   }
-  if(!found) { return; }
+  if(!found) { rpos = rval = img.lcp_values; return; }
   while(level > 0)
   {
     from = L.first_child(rpos, level); level--;
-    u64 last = L.last_sibling(from, level);
-    for(u64 i = from; i <= last; i++)
-    {
-      u64 v = L.at(i);
-      if(sv_cmp(equal, v, val)) { rpos = i; rval = v; break; }
-    }
+    scan_right(img, from, L.last_sibling(from, level), bound, rpos, rval);
   }
 }
 
@@ -274,9 +332,13 @@ __global__ __launch_bounds__(TPB) void k_match_stats(DevImage img, const u8* __r
   u64 begin = offsets[q], len = offsets[q + 1] - begin;
   const u8* p = patterns + begin;
   u64 sp = 0, ep = img.n - 1, depth = 0, calls = 0;
+  u64 word = 0, word_addr = ~u64(0);        // pattern bytes: back to front from aligned 8-byte words (one load per 8 steps)
+  u64 packed = 0; u32 have = 0;             // results: four u16 per aligned 8-byte store
   for(u64 i = len; i-- > 0; )
   {
-    u32 comp = t.c2c[p[i]];
+    u64 addr = reinterpret_cast<u64>(p) + i, aligned = addr & ~u64(7);
+    if(aligned != word_addr) { word = *reinterpret_cast<const u64*>(aligned); word_addr = aligned; }
+    u32 comp = t.c2c[u32(word >> ((addr & 7) * 8)) & 0xFF];
     while(true)
     {
       u64 a, b, nsp, nep;
@@ -291,7 +353,16 @@ __global__ __launch_bounds__(TPB) void k_match_stats(DevImage img, const u8* __r
       lcp_parent(img, sp, ep, node); calls++;
       sp = node.sp; ep = node.ep; depth = node.node_lcp;
     }
-    ms[begin + i] = (unsigned short)(depth > 65535 ? 65535 : depth);
+    const u64 idx = begin + i;
+    const u32 slot = u32(idx & 3);
+    packed |= u64(depth > 65535 ? 65535 : depth) << (16 * slot); have |= 1u << slot;
+    if(slot == 0 || i == 0)                   // the group of four is complete, or the pattern ends inside it
+    {
+      unsigned short* group = ms + (idx & ~u64(3));
+      if(have == 15u) { *reinterpret_cast<u64*>(group) = packed; }
+      else { for(u32 s = 0; s < 4; s++) { if((have >> s) & 1) { group[s] = (unsigned short)(packed >> (16 * s)); } } }
+      packed = 0; have = 0;
+    }
   }
   reinterpret_cast<ulonglong2*>(ranges)[q] = make_ulonglong2(sp, ep);
   if(fallbacks != nullptr) { fallbacks[q] = calls; }

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--queries", type=int, default=1_000_000)
     ap.add_argument("--pattern-len", type=int, default=256)
     ap.add_argument("--cpu-queries", type=int, default=50_000)
+    ap.add_argument("--substituted", type=float, default=0.5, help="fraction of patterns carrying substitutions (0, 0.5 or 1)")
     args = ap.parse_args()
     import torch
     from workload import graphs, builder, patterns
@@ -36,8 +37,9 @@ def main():
     nq, m = args.queries, args.pattern_len
     pats = patterns.walk_patterns(g, nq, m, 0x6C5A0050)
     sub = np.frombuffer(b"ACGT", dtype=np.uint8)
-    for col in range(37, m, 41):               # substitutions in every second pattern
-        pats[1::2, col] = sub[(np.searchsorted(sub, pats[1::2, col]) + 1) % 4]
+    rows = slice(1, None, 2) if args.substituted == 0.5 else (slice(0, 0) if args.substituted == 0 else slice(None))
+    for col in range(37, m, 41):               # substitutions in every second pattern (default)
+        pats[rows, col] = sub[(np.searchsorted(sub, pats[rows, col]) + 1) % 4]
     flat, off = patterns.as_batch(pats)
     dev = torch.device("cuda", 0)
     gpu, lcp = open_index(ix)
@@ -73,7 +75,7 @@ def main():
     t_cpu = cpu.last_seconds
     parity = bool(np.array_equal(d_ms[: nc * m].cpu().numpy().view(np.uint16), cm)) and \
         bool(np.array_equal(d_rng[:nc].cpu().numpy().view(np.uint64), cr))
-    res = {"config": f"config 5 shape: chr22-like SNP graph 2^{args.log2_bases}, {nq} x {m} bp, 50 % with a substitution every 41 bp",
+    res = {"config": f"config 5 shape: chr22-like SNP graph 2^{args.log2_bases}, {nq} x {m} bp, {int(100 * args.substituted)} % with a substitution every 41 bp",
            "gpu_match_stats_patterns_per_s": nq / t_ms, "gpu_bases_per_s": nq * m / t_ms, "gpu_ms": t_ms * 1e3,
            "parent_calls_per_pattern": float(d_fb.double().mean().item()),
            "locate_final_ranges_s": t_loc, "located_values": int(total),
