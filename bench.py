@@ -207,9 +207,9 @@ def measure_locate(gpu, d_ranges, dev, steps):
             "locate_table_bytes": gpu.locate_table_bytes()}
 
 
-def pmc_traffic(args, key, nq, m):
+def pmc_traffic(args, key, nq, m, kmer_k):
     """Memory-side read bytes of one launch from the committed rocprofv3 --pmc pass of this exact
-    workload (profiles/traffic.json, derivation in profiles/r01_v4_pmc.md).  PMC counters cannot
+    workload (profiles/traffic.json, derivation in profiles/r01_v5_pmc.md).  PMC counters cannot
     be read from inside the timed process, so this is looked up, never estimated: any mismatch in
     workload, batch shape or kernel generation yields None."""
     try:
@@ -219,12 +219,14 @@ def pmc_traffic(args, key, nq, m):
         return None
     if not entry or args.variant != 2 or args.set != "S" or entry["queries"] != nq or entry["pattern_len"] != m:
         return None
+    if entry.get("kmer_table_k") != kmer_k:        # profiled with another seed table: not this kernel's traffic
+        return None
     return entry["read_bytes_per_launch"]
 
 
-def roofline(args, r, key, nq, m):
+def roofline(args, r, key, nq, m, kmer_k):
     achieved = r["algo_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9
-    traffic = pmc_traffic(args, key, nq, m)
+    traffic = pmc_traffic(args, key, nq, m, kmer_k)
     out = {"bound": "hbm", "kernel": "k_find2" if args.variant == 2 else "k_find", "achieved": achieved,
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
            "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"]}
@@ -290,7 +292,7 @@ def main():
                        "blocks_per_query": r["blocks"] / nq, "block_bytes": gpu.find_block_bytes(),
                        "kmer_table_k": gpu.kmer_table_k(),
                        "parallelism": f"replicated index, query shards x{world}, one RCCL gather of ranges per step"},
-            "roofline": roofline(args, r, f"{args.workload}_{log2_bases}", nq, m),
+            "roofline": roofline(args, r, f"{args.workload}_{log2_bases}", nq, m, gpu.kmer_table_k()),
         }
         if args.workload == "snp":
             result["roofline"]["note"] = ("fused blocks of this index fit the 256 MiB Infinity Cache: achieved = algorithmic bytes / "
@@ -315,7 +317,8 @@ def main():
             "workload": f"linear graph 2^{lb} bases (FM-index shaped GCSA, built on the GPU), {nq} x {m}-mer find(), substrings of the text",
             "path_nodes": int(ix2.n), "find_bytes_hbm": int(ix2.sigma) * (int(ix2.n) // 448 + 1) * 128,
             "value": nq / (r2["kernel_ms"] * 1e-3), "unit": "queries/s", "blocks_per_query": r2["blocks"] / nq,
-            "roofline": roofline(args, r2, f"linear_{lb}", nq, m)}
+            "kmer_table_k": gpu2.kmer_table_k(),
+            "roofline": roofline(args, r2, f"linear_{lb}", nq, m, gpu2.kmer_table_k())}
     if rank == 0:
         print(json.dumps(result), flush=True)
     D.barrier()

@@ -438,12 +438,27 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       ix->bytes += nwords * 4 * sizeof(u64);
     }
 
-    // k-mer seed table: largest k <= 12 with 4^k <= n / 4, and only if comps 1..4 exist
+    // k-mer seed table, only if comps 1..4 exist.  Default: the largest k <= 16 whose table (16 * 4^k
+    // bytes) is at most twice the index image itself -- each extra character saves one LF step per query
+    // (~5 % of a 32-mer) and quadruples the table; HBM capacity is what this GPU has to spare.  GCSA2_KMER_TABLE=k asks for exactly k (<= 16;
+    // 0 disables).  Either way the table must fit in a quarter of the free device memory.
     u32 k = 0;
     const char* env = std::getenv("GCSA2_KMER_TABLE");
-    u32 kmax = (env != nullptr ? u32(std::atoi(env)) : 12);
-    if(kmax > 12) { kmax = 12; }
-    while(k < kmax && (u64(1) << (2 * (k + 1))) <= img.n / 4) { k++; }
+    if(env != nullptr)
+    {
+      k = u32(std::atoi(env));
+      if(k > 16) { k = 16; }
+      size_t free_bytes = 0, total_bytes = 0;
+      if(hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { free_bytes = 0; }
+      while(k > 0 && (u64(16) << (2 * k)) > free_bytes / 4) { k--; }
+    }
+    else
+    {
+      const u64 image_bytes = 2 * st.words.size() * sizeof(u64);
+      size_t free_bytes = 0, total_bytes = 0;
+      if(hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { free_bytes = 0; }
+      while(k < 16 && (u64(16) << (2 * (k + 1))) <= image_bytes && (u64(16) << (2 * (k + 1))) <= free_bytes / 4) { k++; }
+    }
     if(img.sigma < 5) { k = 0; }
     img.kmer_k = 0; img.kmer_table = nullptr;
     if(k > 0)

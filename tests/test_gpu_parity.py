@@ -466,3 +466,30 @@ def test_concurrent_host_threads(engine):
     for t in threads:
         t.join()
     assert not errors, errors[:2]
+
+
+def test_seed_table_sizes(engine, monkeypatch):
+    """find() is independent of the k-mer seed table: none, the default size, and forced sizes up to
+    patterns longer / shorter than k all equal the oracle (including edge-space empty ranges)."""
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    g = graphs.snp_graph(5000, 0xE1, 0xE2, snp_period=11, node_len=16)
+    ix = builder.build(g, 16)
+    cpu = OracleIndex(ix)
+    pats = [truncate_at_sink(p)[: 1 + q % 16] for q, p in enumerate(random_patterns(g, 16, 0xE3, 1500))]
+    rng = SplitMix64(0xE4)
+    pats += [bytes(b"ACGTN"[rng.below(5)] for _ in range(1 + rng.below(14))) for _ in range(500)]
+    data, off = concat_patterns(pats)
+    want = cpu.find_batch(data, off)
+    seen = set()
+    for setting in (None, "0", "1", "5", "8", "9"):
+        if setting is None:
+            monkeypatch.delenv("GCSA2_KMER_TABLE", raising=False)
+        else:
+            monkeypatch.setenv("GCSA2_KMER_TABLE", setting)
+        gpu = engine.GCSA(ix, with_samples=False, with_counters=False, with_lcp=False)
+        seen.add(gpu.kmer_table_k())
+        if setting is not None:
+            assert gpu.kmer_table_k() == int(setting)
+        assert np.array_equal(gpu.find_batch(data, off), want), setting
+    assert len(seen) >= 5
