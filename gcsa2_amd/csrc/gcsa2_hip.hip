@@ -426,7 +426,8 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       if(e == hipSuccess)
       {
         hipLaunchKernelGGL(k_build_pred4, dim3(grid_for(nwords)), dim3(TPB), 0, nullptr, img, nwords, static_cast<u64*>(ix->d_pred4));
-        e = hipDeviceSynchronize();
+        e = hipGetLastError();
+        if(e == hipSuccess) { e = hipDeviceSynchronize(); }
       }
       if(e != hipSuccess)
       {
@@ -467,8 +468,14 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       e = hipMalloc(&ix->d_kmer, entries * 2 * sizeof(u64));
       if(e == hipSuccess)
       {
-        hipLaunchKernelGGL(k_build_kmer_table, dim3(grid_for(entries)), dim3(TPB), 0, nullptr, img, k, entries, static_cast<u64*>(ix->d_kmer));
-        e = hipDeviceSynchronize();
+        const u64 slice = u64(1) << 30;
+        for(u64 first = 0; first < entries && e == hipSuccess; first += slice)
+        {
+          u64 count = (entries - first < slice ? entries - first : slice);
+          hipLaunchKernelGGL(k_build_kmer_table, dim3(grid_for(count)), dim3(TPB), 0, nullptr, img, k, first, entries, static_cast<u64*>(ix->d_kmer));
+          e = hipGetLastError();
+        }
+        if(e == hipSuccess) { e = hipDeviceSynchronize(); }
       }
       if(e != hipSuccess)
       {
@@ -502,9 +509,15 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       if(e == hipSuccess) { e = hipMemset(d_overflow, 0, sizeof(u32)); }
       if(e == hipSuccess)
       {
-        hipLaunchKernelGGL(k_build_locate_table, dim3(unsigned((ix->img.n + TPB2 - 1) / TPB2)), dim3(TPB2), 0, nullptr,
-                           ix->img, static_cast<u64*>(ix->d_locate), d_overflow);
-        e = hipMemcpy(&overflow, d_overflow, sizeof(u32), hipMemcpyDeviceToHost);
+        const u64 slice = u64(1) << 30;
+        for(u64 first = 0; first < ix->img.n && e == hipSuccess; first += slice)
+        {
+          u64 count = (ix->img.n - first < slice ? ix->img.n - first : slice);
+          hipLaunchKernelGGL(k_build_locate_table, dim3(unsigned((count + TPB2 - 1) / TPB2)), dim3(TPB2), 0, nullptr,
+                             ix->img, first, static_cast<u64*>(ix->d_locate), d_overflow);
+          e = hipGetLastError();
+        }
+        if(e == hipSuccess) { e = hipMemcpy(&overflow, d_overflow, sizeof(u32), hipMemcpyDeviceToHost); }
       }
       if(d_overflow) { (void)hipFree(d_overflow); }
       if(e == hipSuccess && overflow == 0)

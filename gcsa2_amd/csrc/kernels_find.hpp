@@ -61,9 +61,9 @@ __global__ __launch_bounds__(TPB) void k_find(DevImage img, const u8* __restrict
 // the exact (sp, ep) the backward search returns, including edge-space empty ranges, so that
 // k_find2 can start a pattern whose last k characters are all fast characters at step k.
 // Pure memoisation of gcsa.h:96-110; results are unchanged.
-__global__ __launch_bounds__(TPB) void k_build_kmer_table(DevImage img, u32 k, u64 entries, u64* __restrict__ table)
+__global__ __launch_bounds__(TPB) void k_build_kmer_table(DevImage img, u32 k, u64 first, u64 entries, u64* __restrict__ table)
 {
-  u64 tix = u64(blockIdx.x) * TPB + threadIdx.x;
+  u64 tix = first + u64(blockIdx.x) * TPB + threadIdx.x;     // launched in slices: a grid holds < 2^32 threads
   if(tix >= entries) { return; }
   u32 comp = 1 + u32(tix & 3);                               // last character
   u64 sp = img.crange[2 * comp], ep = img.crange[2 * comp + 1];

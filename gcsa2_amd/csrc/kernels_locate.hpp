@@ -195,12 +195,12 @@ __global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* 
 constexpr u64 LOCATE_DIRECT = u64(1) << 63;
 constexpr u64 LOCATE_INDEX_BITS = 40, LOCATE_STEP_LIMIT = u64(1) << 23;
 
-__global__ __launch_bounds__(TPB2) void k_build_locate_table(DevImage img, u64* __restrict__ table, u32* __restrict__ overflow)
+__global__ __launch_bounds__(TPB2) void k_build_locate_table(DevImage img, u64 first, u64* __restrict__ table, u32* __restrict__ overflow)
 {
   __shared__ ulonglong2 stage[TPB2 * 8];
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  u64 g = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  u64 g = first + u64(blockIdx.x) * TPB2 + threadIdx.x;       // launched in slices: a grid holds < 2^32 threads
   bool live = g < img.n;
   u64 node = g, steps = 0;
   walk_to_sample(img, node, steps, live, wave_stage, lane);

@@ -80,19 +80,16 @@ def main():
     if args.full:
         nf = min(nq, args.full_queries)
         sub = d_out[:nf].contiguous()
+        d_loff = torch.zeros(nf + 1, dtype=torch.int64, device=dev)
+        d_vals = torch.zeros(nf, dtype=torch.int64, device=dev)          # one value per hit in this index
+        total = gpu.locate_into(sub.data_ptr(), nf, d_loff.data_ptr(), d_vals.data_ptr(), nf, st.cuda_stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        job, d_o, d_v, total = gpu.locate_device(sub.data_ptr(), nf, st.cuda_stream)
+        for _ in range(3):
+            gpu.locate_into(sub.data_ptr(), nf, d_loff.data_ptr(), d_vals.data_ptr(), nf, st.cuda_stream)
         torch.cuda.synchronize()
-        t_loc = time.perf_counter() - t0
-        import ctypes
-        vals = np.ctypeslib.as_array(ctypes.cast(0, ctypes.POINTER(ctypes.c_uint64)), shape=(0,)) if total == 0 else None
-        d_vals = torch.empty(total, dtype=torch.int64, device=dev)
-        import ctypes as C
-        hip = C.CDLL("libamdhip64.so.7")
-        hip.hipMemcpy(C.c_void_p(d_vals.data_ptr()), C.c_void_p(d_v), C.c_size_t(total * 8), C.c_int(3))
-        torch.cuda.synchronize()
-        gpu.locate_discard(job)
+        t_loc = (time.perf_counter() - t0) / 3
+        res["locate_table_GB"] = gpu.locate_table_bytes() / 1e9
         located = d_vals.cpu().numpy().view(np.uint64)
         res["locate_queries_per_s"] = nf / t_loc
         res["locate_equals_closed_form"] = bool(total == nf and np.array_equal(located, mseq_torch.node_values(starts[:nf])))
