@@ -400,7 +400,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     if(e != hipSuccess) { delete ix; return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(image): ") + hipGetErrorString(e)); }
     e = hipMemcpy(ix->d_base, st.words.data(), ix->bytes, hipMemcpyHostToDevice);
     if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&ix->d_slots), RESULT_SLOTS * 4 * sizeof(unsigned long long)); }
-    if(e != hipSuccess) { (void)hipFree(ix->d_base); delete ix; return fail(GCSA2_ERR_HIP, std::string("hipMemcpy(image): ") + hipGetErrorString(e)); }
+    if(e != hipSuccess) { gcsa2_index_destroy(ix); return fail(GCSA2_ERR_HIP, std::string("hipMemcpy(image): ") + hipGetErrorString(e)); }
 
     const u64* base = static_cast<const u64*>(ix->d_base);
     for(u64 c = 0; c < v->sigma; c++) { img.bwt[c] = resolve(bwt[c], base); }
@@ -431,8 +431,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       }
       if(e != hipSuccess)
       {
-        if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
-        (void)hipFree(ix->d_base); delete ix;
+        gcsa2_index_destroy(ix);       // releases whatever has been allocated so far
         return fail(GCSA2_ERR_HIP, std::string("pred4: ") + hipGetErrorString(e));
       }
       img.pred4 = static_cast<const u64*>(ix->d_pred4);
@@ -479,9 +478,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       }
       if(e != hipSuccess)
       {
-        if(ix->d_kmer) { (void)hipFree(ix->d_kmer); }
-        if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
-        (void)hipFree(ix->d_base); delete ix;
+        gcsa2_index_destroy(ix);
         return fail(GCSA2_ERR_HIP, std::string("k-mer table: ") + hipGetErrorString(e));
       }
       img.kmer_table = static_cast<const u64*>(ix->d_kmer); img.kmer_k = k;
@@ -490,7 +487,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
   }
   catch(const std::bad_alloc&)
   {
-    delete ix; return fail(GCSA2_ERR_OUT_OF_MEMORY, "host staging allocation failed");
+    gcsa2_index_destroy(ix); return fail(GCSA2_ERR_OUT_OF_MEMORY, "host staging allocation failed");
   }
 
   // memoised locate walks: 8 bytes per path node, built with the walk kernel itself.  Optional: skipped
