@@ -155,6 +155,49 @@ __device__ __forceinline__ void lf_fused_lane(const DevImage& img, u32 comp, u64
   b = e_ep - 1; nep = n_ep;
 }
 
+// LF_fast / LF_all (src/gcsa.cpp:742-798) of one range for the N comps c0 .. c0 + N - 1 (those <= limit),
+// one lane per range.  The N first-block loads are issued unconditionally (an inactive comp reads block 0)
+// so that they are all in flight together; children[j] is the node-space range when it is non-empty,
+// otherwise what the reference leaves there: Range::empty_range() = (1, 0) for an empty or single-node
+// input, the edge-space pair in the general case.
+template<int N>
+__device__ __forceinline__ void lf_children(const DevImage& img, u32 c0, u32 limit, bool live, u64 sp0, u64 ep0,
+                                            u64 (&csp)[N], u64 (&cep)[N])
+{
+  const bool nonempty = live && !range_empty(sp0, ep0);
+  const u64 sp = nonempty ? sp0 : 0, e1 = nonempty ? ep0 + 1 : 0;
+  const u64 b_sp = sp / BLOCK_BITS, b_ep = e1 / BLOCK_BITS;
+  ulonglong2 blk[N][8];
+#pragma unroll
+  for(int j = 0; j < N; j++)
+  {
+    const u32 c = c0 + u32(j);
+    const u64 idx = (nonempty && c <= limit ? u64(c) * img.flb_nblocks + b_sp : 0);
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(img.flb + idx * FLB_WORDS);
+#pragma unroll
+    for(u32 k = 0; k < 8; k++) { blk[j][k] = src[k]; }
+  }
+#pragma unroll
+  for(int j = 0; j < N; j++)
+  {
+    const u32 c = c0 + u32(j);
+    csp[j] = 1; cep[j] = 0;
+    if(!(nonempty && c <= limit)) { continue; }
+    u64 a, nsp, e_ep, n_ep;
+    eval_endpoint(blk[j], u32(sp - b_sp * BLOCK_BITS), 0, a, nsp);
+    if(b_ep != b_sp)
+    {
+      const ulonglong2* src = reinterpret_cast<const ulonglong2*>(img.flb + (u64(c) * img.flb_nblocks + b_ep) * FLB_WORDS);
+#pragma unroll
+      for(u32 k = 0; k < 8; k++) { blk[j][k] = src[k]; }
+    }
+    eval_endpoint(blk[j], u32(e1 - b_ep * BLOCK_BITS), 1, e_ep, n_ep);
+    const u64 b = e_ep - 1;
+    if(!range_empty(a, b)) { csp[j] = nsp; cep[j] = n_ep; }
+    else if(sp0 != ep0) { csp[j] = a; cep[j] = b; }
+  }
+}
+
 // wave-cooperative fetch: every lane with need != 0 gets flb block `idx` staged at its slot
 __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane)
 {

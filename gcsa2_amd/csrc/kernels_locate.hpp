@@ -258,47 +258,60 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
 // One lane per search state (a non-empty range at depth d): its children are LF_fast / LF_all of
 // the range (src/gcsa.cpp:742-798) for comps 1..limit; non-empty children are appended to `out`
 // (wave-aggregated atomic slot allocation) or, when out == nullptr, only counted.
+constexpr int KMER_CHUNK = 4;       // comps per batch of independent block loads (the fast characters)
+
+// Output slots for a whole workgroup with ONE atomic: every wave passes the number of slots it wants and
+// gets the index of its first one.  (One atomic per wave and comp on a single counter was what bounded
+// these kernels: ~400 K same-address atomics per level.)  All threads of the workgroup must call it.
+struct WgSlots { u32 count[TPB / 64]; unsigned long long base; };
+
+__device__ __forceinline__ u64 wg_reserve(WgSlots& sh, unsigned long long* counter, u32 wave_count)
+{
+  const u32 wave = threadIdx.x >> 6;
+  if((threadIdx.x & 63) == 0) { sh.count[wave] = wave_count; }
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+    u32 total = 0;
+    for(u32 w = 0; w < TPB / 64; w++) { total += sh.count[w]; }
+    sh.base = (total > 0 ? atomicAdd(counter, (unsigned long long)total) : 0ull);
+  }
+  __syncthreads();
+  u64 first = sh.base;
+  for(u32 w = 0; w < wave; w++) { first += sh.count[w]; }
+  __syncthreads();                     // sh may be reused
+  return first;
+}
+
 __global__ __launch_bounds__(TPB) void k_kmer_expand(DevImage img, const u64* __restrict__ in, u64 n_in, u32 limit,
                                                      u64* __restrict__ out, unsigned long long* __restrict__ counter)
 {
-  __shared__ Tables t;
-  stage_tables(img, t);
+  __shared__ WgSlots slots;
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   const u32 lane = threadIdx.x & 63;
+  const u64 below = (u64(1) << lane) - 1;
   bool live = q < n_in;
   ulonglong2 r = live ? reinterpret_cast<const ulonglong2*>(in)[q] : make_ulonglong2(1, 0);
-  for(u32 c = 1; c <= limit; c++)
+  for(u32 c0 = 1; c0 <= limit; c0 += KMER_CHUNK)
   {
-    u64 sp = 1, ep = 0;
-    if(live)
+    u64 csp[KMER_CHUNK], cep[KMER_CHUNK], mask[KMER_CHUNK];
+    lf_children<KMER_CHUNK>(img, c0, limit, live, r.x, r.y, csp, cep);
+    u32 wave_count = 0;
+#pragma unroll
+    for(int j = 0; j < KMER_CHUNK; j++)
     {
-      DevBV bv = bwt_of(img, c);
-      if(r.x == r.y)      // single path node: bit probe (gcsa.cpp:748-757)
-      {
-        u64 rk;
-        if(bv_get_rank(bv, r.x, rk)) { sp = ep = bv_rank(img.edges, t.C[c] + rk); }
-      }
-      else
-      {
-        u64 ra, rb;
-        bv_rank2(bv, r.x, r.y + 1, ra, rb);
-        sp = t.C[c] + ra; ep = t.C[c] + rb - 1;
-        if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
-      }
+      mask[j] = __ballot(live && c0 + u32(j) <= limit && !range_empty(csp[j], cep[j]));
+      wave_count += u32(__popcll(mask[j]));
     }
-    bool has = live && !range_empty(sp, ep);
-    u64 mask = __ballot(has);
-    if(mask != 0)
+    u64 slot = wg_reserve(slots, counter, wave_count);
+#pragma unroll
+    for(int j = 0; j < KMER_CHUNK; j++)
     {
-      u32 leader = u32(__ffsll((long long)mask)) - 1;
-      unsigned long long base = 0;
-      if(lane == leader) { base = atomicAdd(counter, (unsigned long long)__popcll(mask)); }
-      base = __shfl(base, leader, 64);
-      if(has && out != nullptr)
+      if(out != nullptr && ((mask[j] >> lane) & 1))
       {
-        u64 slot = base + __popcll(mask & ((u64(1) << lane) - 1));
-        reinterpret_cast<ulonglong2*>(out)[slot] = make_ulonglong2(sp, ep);
+        reinterpret_cast<ulonglong2*>(out)[slot + __popcll(mask[j] & below)] = make_ulonglong2(csp[j], cep[j]);
       }
+      slot += __popcll(mask[j]);
     }
   }
 }
@@ -308,25 +321,6 @@ __global__ __launch_bounds__(TPB) void k_kmer_expand(DevImage img, const u64* __
 // index.  The two images are read through pointers (two DevImage values would not fit the 4 KB
 // kernel-argument segment).  final != 0: classify the children instead of storing them:
 // counters[1] += shared, counters[2] += left only, counters[3] += right only.
-__device__ __forceinline__ void lf_child(const DevImage& img, u32 c, u64 sp0, u64 ep0, u64& sp, u64& ep)
-{
-  sp = 1; ep = 0;
-  if(range_empty(sp0, ep0)) { return; }
-  DevBV bv = bwt_of(img, c);
-  if(sp0 == ep0)          // single path node: bit probe (gcsa.cpp:748-757)
-  {
-    u64 rk;
-    if(bv_get_rank(bv, sp0, rk)) { sp = ep = bv_rank(img.edges, img.C[c] + rk); }
-  }
-  else
-  {
-    u64 ra, rb;
-    bv_rank2(bv, sp0, ep0 + 1, ra, rb);
-    sp = img.C[c] + ra; ep = img.C[c] + rb - 1;
-    if(!range_empty(sp, ep)) { path_node_range(img, sp, ep); }
-  }
-}
-
 // KMerComparisonState::set (algorithms.cpp:451-457): comp of extension step i at bits [3i, 3i + 3).
 // (The reference also evaluates `comp >> (64 - bit)` for bit == 0, a shift by the word size; the intended
 // "|= 0 unless the comp straddles two words" is what is restated here.)
@@ -348,6 +342,7 @@ __global__ __launch_bounds__(TPB) void k_kmer_compare(const DevImage* __restrict
                                                       unsigned long long* __restrict__ counters,
                                                       u64* __restrict__ left_records, u64* __restrict__ right_records)
 {
+  __shared__ WgSlots slots;
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   const u32 lane = threadIdx.x & 63;
   const u64 below = (u64(1) << lane) - 1;
@@ -359,52 +354,70 @@ __global__ __launch_bounds__(TPB) void k_kmer_compare(const DevImage* __restrict
     l = reinterpret_cast<const ulonglong2*>(in)[2 * q]; r = reinterpret_cast<const ulonglong2*>(in)[2 * q + 1];
     if(in_keys != nullptr) { key[0] = in_keys[3 * q]; key[1] = in_keys[3 * q + 1]; key[2] = in_keys[3 * q + 2]; }
   }
-  for(u32 c = 1; c <= limit; c++)
+  unsigned long long shared_total = 0;          // mode 1 / 2: k-mers in both indexes, per wave
+  for(u32 c0 = 1; c0 <= limit; c0 += KMER_CHUNK)
   {
-    u64 lsp = 1, lep = 0, rsp = 1, rep = 0;
-    if(live) { lf_child(*left, c, l.x, l.y, lsp, lep); lf_child(*right, c, r.x, r.y, rsp, rep); }
-    const bool lhas = live && !range_empty(lsp, lep), rhas = live && !range_empty(rsp, rep);
-    const bool has = lhas || rhas;
-    u64 child[3] = {key[0], key[1], key[2]};
-    if(has && (out_keys != nullptr || mode == 2)) { kmer_set(child, depth, c); }
-    if(mode != 0)
+    u64 lcsp[KMER_CHUNK], lcep[KMER_CHUNK], rcsp[KMER_CHUNK], rcep[KMER_CHUNK];
+    lf_children<KMER_CHUNK>(*left, c0, limit, live, l.x, l.y, lcsp, lcep);
+    lf_children<KMER_CHUNK>(*right, c0, limit, live, r.x, r.y, rcsp, rcep);
+    u64 lmask[KMER_CHUNK], rmask[KMER_CHUNK];      // children that are non-empty on the left / right
+    u32 any_count = 0, lonly_count = 0, ronly_count = 0;
+#pragma unroll
+    for(int j = 0; j < KMER_CHUNK; j++)
     {
-      const bool lonly = lhas && !rhas, ronly = rhas && !lhas;
-      u64 both = __ballot(lhas && rhas), lmask = __ballot(lonly), rmask = __ballot(ronly);
-      if(lane == 0 && both) { atomicAdd(counters + 1, (unsigned long long)__popcll(both)); }
-      for(int side = 0; side < 2; side++)
+      const bool active = live && c0 + u32(j) <= limit;
+      lmask[j] = __ballot(active && !range_empty(lcsp[j], lcep[j]));
+      rmask[j] = __ballot(active && !range_empty(rcsp[j], rcep[j]));
+      any_count += u32(__popcll(lmask[j] | rmask[j]));
+      lonly_count += u32(__popcll(lmask[j] & ~rmask[j]));
+      ronly_count += u32(__popcll(rmask[j] & ~lmask[j]));
+      shared_total += (unsigned long long)__popcll(lmask[j] & rmask[j]);
+    }
+    if(mode == 0)
+    {
+      u64 slot = wg_reserve(slots, counters, any_count);
+#pragma unroll
+      for(int j = 0; j < KMER_CHUNK; j++)
       {
-        u64 mask = (side == 0 ? lmask : rmask);
-        if(mask == 0) { continue; }
-        u32 leader = u32(__ffsll((long long)mask)) - 1;
-        unsigned long long base = 0;
-        if(lane == leader) { base = atomicAdd(counters + 2 + side, (unsigned long long)__popcll(mask)); }
-        base = __shfl(base, leader, 64);
-        if(mode == 2 && (side == 0 ? lonly : ronly))
+        const u64 mask = lmask[j] | rmask[j];
+        if(out != nullptr && ((mask >> lane) & 1))
         {
-          u64* rec = (side == 0 ? left_records : right_records) + 8 * (base + __popcll(mask & below));
-          rec[0] = lsp; rec[1] = lep; rec[2] = rsp; rec[3] = rep; rec[4] = u64(depth) + 1;
-          rec[5] = child[0]; rec[6] = child[1]; rec[7] = child[2];
+          const u64 at = slot + __popcll(mask & below);
+          reinterpret_cast<ulonglong2*>(out)[2 * at] = make_ulonglong2(lcsp[j], lcep[j]);
+          reinterpret_cast<ulonglong2*>(out)[2 * at + 1] = make_ulonglong2(rcsp[j], rcep[j]);
+          if(out_keys != nullptr)
+          {
+            u64 child[3] = {key[0], key[1], key[2]};
+            kmer_set(child, depth, c0 + u32(j));
+            out_keys[3 * at] = child[0]; out_keys[3 * at + 1] = child[1]; out_keys[3 * at + 2] = child[2];
+          }
         }
+        slot += __popcll(mask);
       }
       continue;
     }
-    u64 mask = __ballot(has);
-    if(mask != 0)
+    u64 lslot = wg_reserve(slots, counters + 2, lonly_count);
+    u64 rslot = wg_reserve(slots, counters + 3, ronly_count);
+    if(mode == 2)
     {
-      u32 leader = u32(__ffsll((long long)mask)) - 1;
-      unsigned long long base = 0;
-      if(lane == leader) { base = atomicAdd(counters, (unsigned long long)__popcll(mask)); }
-      base = __shfl(base, leader, 64);
-      if(has && out != nullptr)
+#pragma unroll
+      for(int j = 0; j < KMER_CHUNK; j++)
       {
-        u64 slot = base + __popcll(mask & below);
-        reinterpret_cast<ulonglong2*>(out)[2 * slot] = make_ulonglong2(lsp, lep);
-        reinterpret_cast<ulonglong2*>(out)[2 * slot + 1] = make_ulonglong2(rsp, rep);
-        if(out_keys != nullptr) { out_keys[3 * slot] = child[0]; out_keys[3 * slot + 1] = child[1]; out_keys[3 * slot + 2] = child[2]; }
+        const u64 lonly = lmask[j] & ~rmask[j], ronly = rmask[j] & ~lmask[j];
+        const bool mine_left = (lonly >> lane) & 1, mine_right = (ronly >> lane) & 1;
+        if(mine_left || mine_right)
+        {
+          u64 child[3] = {key[0], key[1], key[2]};
+          kmer_set(child, depth, c0 + u32(j));
+          u64* rec = (mine_left ? left_records + 8 * (lslot + __popcll(lonly & below)) : right_records + 8 * (rslot + __popcll(ronly & below)));
+          rec[0] = lcsp[j]; rec[1] = lcep[j]; rec[2] = rcsp[j]; rec[3] = rcep[j]; rec[4] = u64(depth) + 1;
+          rec[5] = child[0]; rec[6] = child[1]; rec[7] = child[2];
+        }
+        lslot += __popcll(lonly); rslot += __popcll(ronly);
       }
     }
   }
+  if(mode != 0) { wg_reserve(slots, counters + 1, u32(shared_total)); }
 }
 
 // ---- locate ------------------------------------------------------------------------------
