@@ -236,30 +236,6 @@ __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __r
   while(!bv_get(img.samples, s - 1));
 }
 
-// segments with more than one raw value (the only ones removeDuplicates has to sort)
-// also publishes the two scan totals next to the counter: totals = {nodes, raw values, multi-value segments}
-__global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
-                                                       unsigned long long* __restrict__ totals,
-                                                       u64* __restrict__ seg_begin, u64* __restrict__ seg_end)
-{
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  unsigned long long* counter = totals + 2;
-  if(q == 0) { totals[0] = node_off[nq]; totals[1] = raw_off[nq]; }
-  u64 b = raw_off[q], e = raw_off[q + 1];
-  if(e - b >= 2)
-  {
-    unsigned long long slot = atomicAdd(counter, 1ull);
-    seg_begin[slot] = b; seg_end[slot] = e;
-  }
-}
-
-// ---- countKMers frontier expansion (src/algorithms.cpp:364-421) -------------------------------
-// One lane per search state (a non-empty range at depth d): its children are LF_fast / LF_all of
-// the range (src/gcsa.cpp:742-798) for comps 1..limit; non-empty children are appended to `out`
-// (wave-aggregated atomic slot allocation) or, when out == nullptr, only counted.
-constexpr int KMER_CHUNK = 4;       // comps per batch of independent block loads (the fast characters)
-
 // Output slots for a whole workgroup with ONE atomic: every wave passes the number of slots it wants and
 // gets the index of its first one.  (One atomic per wave and comp on a single counter was what bounded
 // these kernels: ~400 K same-address atomics per level.)  All threads of the workgroup must call it.
@@ -282,6 +258,33 @@ __device__ __forceinline__ u64 wg_reserve(WgSlots& sh, unsigned long long* count
   __syncthreads();                     // sh may be reused
   return first;
 }
+
+// segments with more than one raw value (the only ones removeDuplicates has to sort); also publishes the
+// two scan totals next to the counter: totals = {nodes, raw values, multi-value segments}
+__global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
+                                                       unsigned long long* __restrict__ totals,
+                                                       u64* __restrict__ seg_begin, u64* __restrict__ seg_end)
+{
+  __shared__ WgSlots slots;
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  const u32 lane = threadIdx.x & 63;
+  if(q == 0) { totals[0] = node_off[nq]; totals[1] = raw_off[nq]; }
+  u64 b = 0, e = 0;
+  if(q < nq) { b = raw_off[q]; e = raw_off[q + 1]; }
+  const u64 mask = __ballot(e - b >= 2);
+  u64 slot = wg_reserve(slots, totals + 2, u32(__popcll(mask)));
+  if((mask >> lane) & 1)
+  {
+    slot += __popcll(mask & ((u64(1) << lane) - 1));
+    seg_begin[slot] = b; seg_end[slot] = e;
+  }
+}
+
+// ---- countKMers frontier expansion (src/algorithms.cpp:364-421) -------------------------------
+// One lane per search state (a non-empty range at depth d): its children are LF_fast / LF_all of
+// the range (src/gcsa.cpp:742-798) for comps 1..limit; non-empty children are appended to `out`
+// (wave-aggregated atomic slot allocation) or, when out == nullptr, only counted.
+constexpr int KMER_CHUNK = 4;       // comps per batch of independent block loads (the fast characters)
 
 __global__ __launch_bounds__(TPB) void k_kmer_expand(DevImage img, const u64* __restrict__ in, u64 n_in, u32 limit,
                                                      u64* __restrict__ out, unsigned long long* __restrict__ counter)

@@ -116,7 +116,27 @@ def main():
     d_lv = torch.zeros(max(int(locate_once.total), 1), dtype=torch.int64, device=dev)
     t_into = timed(lambda: gpu.locate_into(sub.data_ptr(), nl, d_lo.data_ptr(), d_lv.data_ptr(), d_lv.shape[0], sp))
     line("locate_into", nl, t_into)
-    res["gpu"] = {"find_qps": nq / t_find, "parent_qps": nh / t_parent, "count_qps": nh / t_count,
+    # ranges spanning several path nodes: duplicates have to be removed (segmented sort + compaction)
+    nw = min(nl, 2_000_000)
+    wide = sub[:nw].clone()
+    wide[:, 1] = torch.clamp(wide[:, 1] + (torch.arange(nw, device=dev) % 16), max=int(ix.n) - 1)
+    d_wo = torch.zeros(nw + 1, dtype=torch.int64, device=dev)
+    try:
+        gpu.locate_into(wide.data_ptr(), nw, d_wo.data_ptr(), d_lv.data_ptr(), 0, sp)
+        need = 0
+    except Exception as e:
+        need = getattr(e, "needed", 0)
+    d_wv = torch.zeros(max(need, 1), dtype=torch.int64, device=dev)
+    t_wide = timed(lambda: gpu.locate_into(wide.data_ptr(), nw, d_wo.data_ptr(), d_wv.data_ptr(), d_wv.shape[0], sp))
+    line("locate wide", nw, t_wide)
+    print(f"{need} occurrences ({t_wide / max(need, 1) * 1e6:.4f} µs/occurrence)")
+    cpu_w = OracleIndex(ix)
+    ns = 20000
+    wo, wv = cpu_w.locate_batch(wide[:ns].cpu().numpy().view(np.uint64), threads=max_threads())
+    wide_ok = bool(np.array_equal(d_wo[:ns + 1].cpu().numpy().view(np.uint64), wo) and
+                   np.array_equal(d_wv[:len(wv)].cpu().numpy().view(np.uint64), wv))
+    print(f"wide ranges equal the oracle on the first {ns}: {wide_ok}")
+    res["gpu"] = {"locate_wide_qps": nw / t_wide, "locate_wide_values": int(need), "locate_wide_parity": wide_ok, "find_qps": nq / t_find, "parent_qps": nh / t_parent, "count_qps": nh / t_count,
                   "locate_qps": nl / t_locate, "locate_values_per_s": locate_once.total / t_locate,
                   "locate_values": int(locate_once.total), "locate_into_qps": nl / t_into}
 
