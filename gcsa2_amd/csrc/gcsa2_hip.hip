@@ -399,7 +399,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     hipError_t e = hipMalloc(&ix->d_base, ix->bytes > 0 ? ix->bytes : 8);
     if(e != hipSuccess) { delete ix; return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(image): ") + hipGetErrorString(e)); }
     e = hipMemcpy(ix->d_base, st.words.data(), ix->bytes, hipMemcpyHostToDevice);
-    if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&ix->d_slots), RESULT_SLOTS * 4 * sizeof(unsigned long long)); }
+    if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&ix->d_slots), RESULT_SLOTS * 8 * sizeof(unsigned long long)); }
     if(e != hipSuccess) { gcsa2_index_destroy(ix); return fail(GCSA2_ERR_HIP, std::string("hipMemcpy(image): ") + hipGetErrorString(e)); }
 
     const u64* base = static_cast<const u64*>(ix->d_base);
@@ -708,7 +708,7 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
   // scan of the raw counts goes straight into the job's offsets (final as they are unless duplicates
   // have to be removed, rewritten in place otherwise)
   u64* sizes = nullptr; u64* segs = nullptr;
-  unsigned long long* d_totals = ix->d_slots + 4 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);   // {nodes, raw, multi, unique}
+  unsigned long long* d_totals = ix->d_slots + 8 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);   // {nodes, raw, large, unique, multi}
   HIP_TRY(scratch.get(sizes, 3 * (nq + 1))); HIP_TRY(scratch.get(segs, 2 * nq));
   u64 *node_counts = sizes, *raw_counts = sizes + (nq + 1), *node_off = sizes + 2 * (nq + 1), *raw_off = d_offsets;
   u64 *seg_begin = segs, *seg_end = segs + nq;
@@ -725,10 +725,10 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
   // segments with more than one raw value: the only ones removeDuplicates has to touch
   hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end);
   LAUNCH_CHECK("k_collect_multi");
-  unsigned long long totals[3] = {0, 0, 0};
+  unsigned long long totals[5] = {0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
-  const u64 total_nodes = totals[0], total_raw = totals[1], multi = totals[2];
+  const u64 total_nodes = totals[0], total_raw = totals[1], large = totals[2], multi = totals[4];
   if(total_raw >= (u64(1) << 31)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate batch produces >= 2^31 values; split the batch"); }
 
   if(total_raw == 0)
@@ -751,21 +751,30 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
   else
   {
     u64 *raw = nullptr, *sorted = nullptr, *flag_scan = nullptr; u32* flags = nullptr;
-    HIP_TRY(scratch.get(raw, total_raw)); HIP_TRY(scratch.get(sorted, total_raw));
+    HIP_TRY(scratch.get(sorted, total_raw));
     HIP_TRY(scratch.get(flags, total_raw + 1)); HIP_TRY(scratch.get(flag_scan, total_raw + 1));
-    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, raw, stream);
+    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, stream);
     LAUNCH_CHECK("k_locate_walk");
 
-    // removeDuplicates: sort only the segments that hold more than one value (single-value
-    // segments are copied through), then flag + scan + compact
-    HIP_TRY(hipMemcpyAsync(sorted, raw, total_raw * sizeof(u64), hipMemcpyDeviceToDevice, stream));
-    size_t sort_bytes = 0;
-    HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw, sorted, int(total_raw), int(multi),
-                                                       seg_begin, seg_end, 0, 64, stream));
-    char* sort_tmp = nullptr;
-    HIP_TRY(scratch.get(sort_tmp, sort_bytes));
-    HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(multi),
-                                                       seg_begin, seg_end, 0, 64, stream));
+    // removeDuplicates: queries with up to SMALL_SEGMENT values are sorted in registers, in place; the
+    // larger ones by hipCUB's segmented radix sort (from a copy); then flag + scan + compact
+    if(large > 0)
+    {
+      HIP_TRY(scratch.get(raw, total_raw));
+      HIP_TRY(hipMemcpyAsync(raw, sorted, total_raw * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    }
+    hipLaunchKernelGGL(k_sort_small, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, sorted);
+    LAUNCH_CHECK("k_sort_small");
+    if(large > 0)
+    {
+      size_t sort_bytes = 0;
+      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw, sorted, int(total_raw), int(large),
+                                                         seg_begin, seg_end, 0, 64, stream));
+      char* sort_tmp = nullptr;
+      HIP_TRY(scratch.get(sort_tmp, sort_bytes));
+      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(large),
+                                                         seg_begin, seg_end, 0, 64, stream));
+    }
     hipLaunchKernelGGL(k_mark_unique, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, raw_off, nq, total_raw, flags);
     LAUNCH_CHECK("k_mark_unique");
     HIP_TRY(hipMemsetAsync(flags + total_raw, 0, sizeof(u32), stream));

@@ -259,8 +259,12 @@ __device__ __forceinline__ u64 wg_reserve(WgSlots& sh, unsigned long long* count
   return first;
 }
 
-// segments with more than one raw value (the only ones removeDuplicates has to sort); also publishes the
-// two scan totals next to the counter: totals = {nodes, raw values, multi-value segments}
+// removeDuplicates (utils.h:350-357) sorts the values of a query.  Queries with one value need nothing,
+// queries with 2..SMALL_SEGMENT values are sorted in registers by one lane each (k_sort_small), the
+// rest goes to hipCUB's segmented radix sort.  k_collect_multi lists the large segments and publishes
+// totals = {nodes, raw values, large segments, (unique values, written later), segments with >= 2 values}.
+constexpr u32 SMALL_SEGMENT = 16;
+
 __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
                                                        unsigned long long* __restrict__ totals,
                                                        u64* __restrict__ seg_begin, u64* __restrict__ seg_end)
@@ -271,13 +275,48 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
   if(q == 0) { totals[0] = node_off[nq]; totals[1] = raw_off[nq]; }
   u64 b = 0, e = 0;
   if(q < nq) { b = raw_off[q]; e = raw_off[q + 1]; }
-  const u64 mask = __ballot(e - b >= 2);
-  u64 slot = wg_reserve(slots, totals + 2, u32(__popcll(mask)));
-  if((mask >> lane) & 1)
+  const u64 multi = __ballot(e - b >= 2), large = __ballot(e - b > SMALL_SEGMENT);
+  wg_reserve(slots, totals + 4, u32(__popcll(multi)));
+  u64 slot = wg_reserve(slots, totals + 2, u32(__popcll(large)));
+  if((large >> lane) & 1)
   {
-    slot += __popcll(mask & ((u64(1) << lane) - 1));
+    slot += __popcll(large & ((u64(1) << lane) - 1));
     seg_begin[slot] = b; seg_end[slot] = e;
   }
+}
+
+// one lane per query with 2..SMALL_SEGMENT values: bitonic network over registers, in place
+__global__ __launch_bounds__(TPB) void k_sort_small(const u64* __restrict__ raw_off, u64 nq, u64* __restrict__ values)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  const u64 b = raw_off[q], len = raw_off[q + 1] - b;
+  if(len < 2 || len > SMALL_SEGMENT) { return; }
+  u64 v[SMALL_SEGMENT];
+#pragma unroll
+  for(u32 i = 0; i < SMALL_SEGMENT; i++) { v[i] = (i < len ? values[b + i] : ~u64(0)); }
+#pragma unroll
+  for(u32 k = 2; k <= SMALL_SEGMENT; k <<= 1)
+  {
+#pragma unroll
+    for(u32 j = k >> 1; j > 0; j >>= 1)
+    {
+#pragma unroll
+      for(u32 i = 0; i < SMALL_SEGMENT; i++)
+      {
+        const u32 l = i ^ j;
+        if(l > i)
+        {
+          const bool up = ((i & k) == 0);
+          const u64 lo = (v[i] < v[l] ? v[i] : v[l]), hi = (v[i] < v[l] ? v[l] : v[i]);
+          v[i] = (up ? lo : hi); v[l] = (up ? hi : lo);
+        }
+      }
+    }
+  }
+  // padding (all ones) sorts to the end; a real value of all ones is then still within the first len slots
+#pragma unroll
+  for(u32 i = 0; i < SMALL_SEGMENT; i++) { if(i < len) { values[b + i] = v[i]; } }
 }
 
 // ---- countKMers frontier expansion (src/algorithms.cpp:364-421) -------------------------------
@@ -433,7 +472,7 @@ __global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* _
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q >= nq) { return; }
-  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; totals[0] = totals[1] = totals[2] = 0; }
+  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; totals[0] = totals[1] = totals[2] = totals[3] = totals[4] = 0; }
   ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
   u64 nodes = 0, raw = 0;
   if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831
@@ -484,14 +523,9 @@ __global__ __launch_bounds__(TPB) void k_mark_unique(const u64* __restrict__ sor
 {
   u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
   if(g >= total) { return; }
-  u64 lo = 0, hi = nq - 1;
-  while(lo < hi)
-  {
-    u64 mid = (lo + hi + 1) >> 1;
-    if(raw_off[mid] <= g) { lo = mid; } else { hi = mid - 1; }
-  }
   // segments of empty queries share their start with the next one; lo is the last of them,
   // which is the only one that can contain g.
+  const u64 lo = owner_of(raw_off, nq, total, g);
   flags[g] = (g == raw_off[lo] || sorted[g] != sorted[g - 1]) ? 1u : 0u;
 }
 
