@@ -63,9 +63,15 @@ class Dist:
         self.active = "RANK" in os.environ and "WORLD_SIZE" in os.environ
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # GCSA2_BENCH_BACKEND=gloo is a control-flow check for boxes with fewer GPUs than ranks (the gather
+        # then goes through host memory and ranks may share a device); the measured configuration is nccl.
+        self.backend = os.environ.get("GCSA2_BENCH_BACKEND", "nccl")
         if self.active:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl", device_id=dev)
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend=self.backend)
 
     def barrier(self):
         if self.active:
@@ -73,13 +79,20 @@ class Dist:
 
     def gather(self, tensor, parts):
         """Asynchronous gather on rank 0; returns the work handle (None when not distributed)."""
+        if self.active and self.backend != "nccl":
+            host = [p.cpu() for p in parts] if self.rank == 0 else None
+            self.dist.gather(tensor.cpu(), host, dst=0)
+            if self.rank == 0:
+                for p, h in zip(parts, host):
+                    p.copy_(h)
+            return None
         if self.active:
             return self.dist.gather(tensor, parts if self.rank == 0 else None, dst=0, async_op=True)
         return None
 
     def max(self, value, dev):
         import torch
-        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        t = torch.tensor([value], dtype=torch.float64, device=dev if self.backend == "nccl" else "cpu")
         if self.active:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
@@ -242,6 +255,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GCSA2_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     D = Dist(dev)
