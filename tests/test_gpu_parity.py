@@ -493,3 +493,36 @@ def test_seed_table_sizes(engine, monkeypatch):
             assert gpu.kmer_table_k() == int(setting)
         assert np.array_equal(gpu.find_batch(data, off), want), setting
     assert len(seen) >= 5
+
+
+def test_fuzz_random_graphs(engine):
+    """150 seeded random graphs (bubbles, indels, cycles, Ns; orders 2..6): every query type equals the
+    oracle, which the CPU suite pins against the definition-level brute force on graphs of this family."""
+    from oracle.oracle import OracleIndex
+    for seed in range(150):
+        rng = SplitMix64(0xF00 + seed)
+        n = 12 + rng.below(50)
+        g = graphs.random_graph(n, 0xF100 + seed, p_branch=0.15 + 0.05 * (seed % 4), p_back=(0.08 if seed % 3 == 0 else 0.0),
+                                p_n=0.05, alphabet=(2 if seed % 5 == 0 else 4))
+        K = 2 + seed % 5
+        ix = build(g, K, sample_period=2 + seed % 7, branching=2 + seed % 5)
+        gpu, lcp = engine.open_index(ix)
+        cpu = OracleIndex(ix)
+        pats = [truncate_at_sink(p) for p in random_patterns(g, K, 0xF200 + seed, 120)]
+        data, off = concat_patterns(pats)
+        ranges = gpu.find_batch(data, off)
+        assert np.array_equal(ranges, cpu.find_batch(data, off)), seed
+        extra = np.array(all_ranges(ix, 0xF300 + seed)[:200], dtype=np.uint64)
+        for arr in (ranges, extra):
+            assert np.array_equal(gpu.count_batch(arr), cpu.count_batch(arr)), seed
+            go, gv = gpu.locate_batch(arr)
+            co, cv = cpu.locate_batch(arr)
+            assert np.array_equal(go, co) and np.array_equal(gv, cv), seed
+            ok = arr[(arr[:, 0] <= arr[:, 1]) & (arr[:, 1] < ix.n)]
+            assert np.array_equal(lcp.parent_batch(ok), cpu.parent_batch(ok)), seed
+            assert np.array_equal(lcp.depth_batch(ok), cpu.depth_batch(ok)), seed
+        for k in (1, K, K + 1):
+            assert gpu.count_kmers(k, force=True) == cpu.count_kmers(k, force=True), (seed, k)
+        m, r, f = gpu.match_stats_batch(data, off)
+        cm, cr, cf = cpu.match_stats_batch(data, off)
+        assert np.array_equal(m, cm) and np.array_equal(r, cr) and np.array_equal(f, cf), seed
