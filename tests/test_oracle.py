@@ -316,3 +316,24 @@ def test_compare_kmers_vs_input_graphs():
             pattern = bytes(b"ACGT"[c - 1] for c in label(r))
             assert (int(r[0]), int(r[1])) == tuple(a.find(pattern))
             assert int(r[2]) == int(r[3]) + 1 and b.find(pattern)[0] > b.find(pattern)[1]
+
+
+def test_fuzz_oracle_vs_input_graph():
+    """The definition-level check of test_find_vs_input_graph on the graph family the GPU fuzz test
+    uses (tests/test_gpu_parity.py::test_fuzz_random_graphs): 60 seeded random graphs with bubbles,
+    indels, cycles and Ns; locate(find(X)) == start positions of paths labelled X, count == their number."""
+    for seed in range(60):
+        rng = SplitMix64(0xF00 + seed)
+        n = 12 + rng.below(50)
+        g = graphs.random_graph(n, 0xF100 + seed, p_branch=0.15 + 0.05 * (seed % 4), p_back=(0.08 if seed % 3 == 0 else 0.0),
+                                p_n=0.05, alphabet=(2 if seed % 5 == 0 else 4))
+        K = 2 + seed % 5
+        ix = build(g, K, sample_period=2 + seed % 7, branching=2 + seed % 5)
+        o, gb = OracleIndex(ix), GraphBrute(g)
+        for p in random_patterns(g, K, 0xF200 + seed, 60):
+            p = truncate_at_sink(p)[:K]
+            comps = [int(ix.char2comp[b]) for b in p]
+            found = o.find(p)
+            expected = gb.occurrences(comps)
+            assert [int(v) for v in o.locate(found)] == expected, (seed, p, found)
+            assert o.count(found) == len(expected), (seed, p)
