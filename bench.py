@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the secondary HBM-resident measurement")
+    ap.add_argument("--no-jump-table", action="store_true", help="skip the secondary measurement with GCSA2_JUMP_TABLE=1")
     ap.add_argument("--variant", type=int, default=2, help="find kernel generation (1 = k_find, 2 = k_find2)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
@@ -316,6 +317,22 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args, ix, flat, offsets, r["d_out"], m)
         if args.workload == "snp" and world == 1:
             result["locate"] = measure_locate(gpu, r["d_out"], dev, max(3, args.steps // 4))
+        if args.workload == "snp" and world == 1 and not args.no_jump_table:
+            # opt-in acceleration structure (GCSA2_JUMP_TABLE=1, 16 bytes per path node): fewer, smaller
+            # memory requests per query; reported beside the headline, which stays the default build
+            os.environ["GCSA2_JUMP_TABLE"] = "1"
+            try:
+                gpu_j = GCSA(ix, device=local_rank, with_samples=False, with_counters=False, with_lcp=False)
+            finally:
+                del os.environ["GCSA2_JUMP_TABLE"]
+            rj = measure(args, D, dev, gpu_j, flat, offsets, nq, m, max(5, args.steps // 2), 2)
+            result["jump_table"] = {
+                "workload": "the headline workload with the jump table (memoised unary LF chains) enabled",
+                "value": nq / (rj["kernel_ms"] * 1e-3), "unit": "queries/s", "kernel_ms": rj["kernel_ms"],
+                "table_bytes": gpu_j.jump_table_bytes(), "blocks_per_query": rj["blocks"] / nq,
+                "algorithmic_GBps": rj["algo_bytes"] / (rj["kernel_ms"] * 1e-3) / 1e9,
+                "equals_default_results": bool(torch.equal(rj["d_out"], r["d_out"]))}
+            del gpu_j, rj
     del r
 
     # secondary measurement: the same kernel on an index far larger than the Infinity Cache

@@ -53,6 +53,7 @@ struct gcsa2_index
   void* d_kmer = nullptr;
   void* d_pred4 = nullptr;
   void* d_locate = nullptr;
+  void* d_jump = nullptr;
   // Small results the host reads back (totals of the locate pipeline) live in plain hipMalloc memory:
   // device-to-host copies out of stream-ordered pool memory were observed to return stale data
   // (about one call in 5000 on ROCm 7.2 / gfx950), copies out of hipMalloc memory never.
@@ -490,6 +491,9 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     gcsa2_index_destroy(ix); return fail(GCSA2_ERR_OUT_OF_MEMORY, "host staging allocation failed");
   }
 
+  DeviceGuard table_guard(device);       // the guard above ended with the try block
+  if(!table_guard.ok) { gcsa2_index_destroy(ix); return fail(GCSA2_ERR_HIP, "hipSetDevice failed"); }
+
   // memoised locate walks: 8 bytes per path node, built with the walk kernel itself.  Optional: skipped
   // when GCSA2_LOCATE_TABLE=0, when it would take more than a quarter of the free memory, or when an
   // entry does not fit (then locate() walks as before).
@@ -529,6 +533,51 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       }
     }
   }
+  // memoised unary LF chains for find(): 16 bytes per path node, opt-in (GCSA2_JUMP_TABLE=1).  Built by
+  // doubling (1 -> 2 -> 4 -> 8 steps) with a second buffer that is released afterwards.
+  ix->img.jump_tab = nullptr;
+  {
+    const char* env = std::getenv("GCSA2_JUMP_TABLE");
+    size_t free_bytes = 0, total_bytes = 0;
+    const u64 n = ix->img.n, bytes = n * sizeof(ulonglong2);
+    if(env != nullptr && std::atoi(env) != 0 && n > 0 && n < JUMP_NODE_MASK && ix->img.sigma >= 5 &&
+       hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && 2 * bytes <= free_bytes / 2)
+    {
+      void* other = nullptr;
+      hipError_t e = hipMalloc(&ix->d_jump, bytes);
+      if(e == hipSuccess) { e = hipMalloc(&other, bytes); }
+      ulonglong2 *a = static_cast<ulonglong2*>(ix->d_jump), *b = static_cast<ulonglong2*>(other);
+      const u64 slice = u64(1) << 30;
+      for(u64 first = 0; first < n && e == hipSuccess; first += slice)
+      {
+        u64 count = (n - first < slice ? n - first : slice);
+        hipLaunchKernelGGL(k_jump_init, dim3(grid_for(count)), dim3(TPB), 0, nullptr, ix->img, first, a);
+        e = hipGetLastError();
+      }
+      for(u32 have = 1; have < JUMP_MAX && e == hipSuccess; have *= 2)
+      {
+        for(u64 first = 0; first < n && e == hipSuccess; first += slice)
+        {
+          u64 count = (n - first < slice ? n - first : slice);
+          hipLaunchKernelGGL(k_jump_double, dim3(grid_for(count)), dim3(TPB), 0, nullptr, a, n, first, have, b);
+          e = hipGetLastError();
+        }
+        std::swap(a, b);
+      }
+      if(e == hipSuccess) { e = hipDeviceSynchronize(); }
+      // three doubling rounds: the result is in the buffer that was `other` at the start
+      if(e == hipSuccess)
+      {
+        (void)hipFree(b); ix->d_jump = a;
+        ix->img.jump_tab = a; ix->bytes += bytes;
+      }
+      else
+      {
+        if(ix->d_jump) { (void)hipFree(ix->d_jump); } if(other) { (void)hipFree(other); }
+        ix->d_jump = nullptr; (void)hipGetLastError();
+      }
+    }
+  }
   *out = ix;
   return GCSA2_OK;
 }
@@ -541,6 +590,7 @@ void gcsa2_index_destroy(gcsa2_index* ix)
   if(ix->d_kmer) { (void)hipFree(ix->d_kmer); }
   if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
   if(ix->d_locate) { (void)hipFree(ix->d_locate); }
+  if(ix->d_jump) { (void)hipFree(ix->d_jump); }
   if(ix->d_slots) { (void)hipFree(ix->d_slots); }
   delete ix;
 }
@@ -565,6 +615,13 @@ int gcsa2_find_device(const gcsa2_index* ix, const uint8_t* d_patterns, const ui
 {
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
+  if(ix->img.jump_tab != nullptr)
+  {
+    hipLaunchKernelGGL((k_find2<false, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
+                       ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr, (unsigned long long*)nullptr);
+    LAUNCH_CHECK("k_find2<jump>");
+    return GCSA2_OK;
+  }
   hipLaunchKernelGGL((k_find2<false, false>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
                      ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr, (unsigned long long*)nullptr);
   LAUNCH_CHECK("k_find2");
@@ -631,6 +688,13 @@ int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, co
   if(d_stats == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null stats buffer"); }
   if(nq == 0) { return GCSA2_OK; }
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64 atomics");
+  if(ix->img.jump_tab != nullptr)
+  {
+    hipLaunchKernelGGL((k_find2<true, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
+                       ix->img, d_patterns, d_offsets, nq, d_ranges, reinterpret_cast<unsigned long long*>(d_stats), (const u32*)nullptr, (unsigned long long*)nullptr);
+    LAUNCH_CHECK("k_find2<stats, jump>");
+    return GCSA2_OK;
+  }
   hipLaunchKernelGGL((k_find2<true, false>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
                      ix->img, d_patterns, d_offsets, nq, d_ranges, reinterpret_cast<unsigned long long*>(d_stats), (const u32*)nullptr, (unsigned long long*)nullptr);
   LAUNCH_CHECK("k_find2<stats>");
@@ -639,6 +703,7 @@ int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, co
 
 uint64_t gcsa2_find_block_bytes(const gcsa2_index*) { return FLB_BYTES; }
 uint64_t gcsa2_kmer_table_k(const gcsa2_index* ix) { return ix->img.kmer_k; }
+uint64_t gcsa2_jump_table_bytes(const gcsa2_index* ix) { return ix->img.jump_tab != nullptr ? ix->img.n * sizeof(ulonglong2) : 0; }
 uint64_t gcsa2_locate_table_bytes(const gcsa2_index* ix) { return ix->img.locate_tab != nullptr ? ix->img.n * sizeof(u64) : 0; }
 
 int gcsa2_lf_device(const gcsa2_index* ix, const uint64_t* d_in, const uint8_t* d_comps, uint64_t nq,

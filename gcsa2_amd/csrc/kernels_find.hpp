@@ -227,7 +227,10 @@ __device__ __forceinline__ void read_block(const ulonglong2* wave_stage, u32 lan
 // new query ids from a global counter (one wave-aggregated atomic) and start them, so that a batch
 // mixing hits and misses keeps all 64 lanes busy.  `queue` points to that counter (zeroed by the
 // host); the grid is sized to the machine, not to the batch.
-template<bool STATS, bool REFILL>
+constexpr u64 JUMP_NODE_MASK = (u64(1) << 56) - 1;
+constexpr u32 JUMP_MAX = 8;
+
+template<bool STATS, bool REFILL, bool JUMP = false>
 __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restrict__ patterns,
                                                const u64* __restrict__ offsets, u64 nq,
                                                u64* __restrict__ out, unsigned long long* __restrict__ stats,
@@ -247,6 +250,9 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
   u64 q = ~u64(0), sp = 0, ep = img.n - 1, i = 0;
   const u8* p = patterns;
   bool done = true;
+  [[maybe_unused]] bool tried = false;     // JUMP: the entry of the current node was examined and does not apply
+  [[maybe_unused]] u64 win_top = ~u64(0), win_code = 0;      // JUMP: packed pattern window (see below)
+  [[maybe_unused]] u32 win_fast = 0;
   u64 word = 0, word_addr = ~u64(0);        // pattern bytes are consumed back to front from aligned 8-byte words
   auto byte_at = [&](u64 pos) -> u32
   {
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
   };
   auto start = [&](u64 query)               // begin the backward search of `query` (< nq)
   {
-    q = query; sp = 0; ep = img.n - 1; i = 0; done = true; word_addr = ~u64(0);
+    q = query; sp = 0; ep = img.n - 1; i = 0; done = true; word_addr = ~u64(0); tried = false; win_top = ~u64(0);
     u64 begin = offsets[q], len = offsets[q + 1] - begin;
     if(len > 0 && img.n > 0)                                   // gcsa.h:99
     {
@@ -328,21 +334,60 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     {
       if(!__any(!done)) { break; }
     }
+    // JUMP: a range of one path node whose next <= 8 predecessors are forced (a single incoming label
+    // each) and spell the next pattern characters moves there with ONE 16-byte lookup.  Same result as
+    // stepping: LF of a single node with a matching label is the single node behind that edge.
+    bool jumping = false;
+    ulonglong2 entry = make_ulonglong2(0, 0);
+    if constexpr(JUMP)
+    {
+      jumping = !done && sp == ep && !tried;
+      entry = img.jump_tab[jumping ? sp : 0];                  // branch-free: all lanes' loads in flight together
+      // The next pattern characters as 2-bit codes: window of the 32 positions below win_top, position
+      // win_top - 1 - r at bits [2r, 2r + 2) of win_code, win_fast bit r = "is a fast character".
+      // Refilled once per 24 consumed characters (five independent word loads), so that neither the
+      // jump test nor a step waits for pattern bytes.
+      if(!done && (win_top == ~u64(0) || win_top - i > 24))
+      {
+        win_top = i; win_code = 0; win_fast = 0;
+        const u64 count = (i < 32 ? i : 32), low = reinterpret_cast<u64>(p) + i - count, base = low & ~u64(7);
+        u64 w[5];
+        const u64 last = (low + count - 1) & ~u64(7);           // never read past the word of the last byte needed
+#pragma unroll
+        for(u32 k = 0; k < 5; k++) { const u64 a = base + 8 * k; w[k] = *reinterpret_cast<const u64*>(a < last ? a : last); }
+        for(u32 r = 0; r < count; r++)
+        {
+          const u64 at = (low - base) + (count - 1 - r);       // byte offset of position win_top - 1 - r
+          u64 word = w[0];                                     // (a clamped slot repeats the last word and is never selected)
+#pragma unroll
+          for(u32 k = 1; k < 5; k++) { if((at >> 3) == k) { word = w[k]; } }
+          const u32 c = u32(t.c2c[u32(word >> ((at & 7) * 8)) & 0xFF]) - 1;
+          win_code |= u64(c & 3) << (2 * r);
+          win_fast |= (c < 4 ? 1u : 0u) << r;
+        }
+      }
+    }
+    const bool stepping = !done && !jumping;
     u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
-    if(!done)
+    if(stepping)
     {
       i--;
-      comp = t.c2c[byte_at(i)];
+      if constexpr(JUMP)
+      {
+        const u32 r = u32(win_top - 1 - i);
+        comp = ((win_fast >> r) & 1) ? 1 + (u32(win_code >> (2 * r)) & 3) : u32(t.c2c[byte_at(i)]);
+      }
+      else { comp = t.c2c[byte_at(i)]; }
       u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
       r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
       idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
     }
     u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
-    const bool need2 = !done && idx_ep != idx_sp;
-    if(STATS && !done) { steps++; blocks += 1 + (need2 ? 1 : 0); }
+    const bool need2 = stepping && idx_ep != idx_sp;
+    if(STATS && stepping) { steps++; blocks += 1 + (need2 ? 1 : 0); }
     ulonglong2 blk[8];
-    fetch_blocks(img.flb, idx_sp, !done, wave_stage, lane);
-    if(!done)
+    fetch_blocks(img.flb, idx_sp, stepping, wave_stage, lane);
+    if(stepping)
     {
       read_block(wave_stage, lane, blk);
       eval_endpoint(blk, r_sp, 0, e_sp, n_sp);                 // gcsa.h:271, then rank(edges, sp')
@@ -359,11 +404,25 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if(!done)
+    if(stepping)
     {
       u64 a = e_sp, b = e_ep - 1;                              // edge space
       if(range_empty(a, b)) { sp = a; ep = b; done = true; }   // gcsa.h:160
       else { sp = n_sp; ep = n_ep; done = (i == 0); }          // gcsa.h:161, 103
+      if constexpr(JUMP) { tried = false; }
+    }
+    if constexpr(JUMP)
+    {
+      if(jumping)
+      {
+        const u32 len = u32(entry.x >> 56), r = u32(win_top - i);
+        const u64 mask = (u64(1) << (2 * len)) - 1;
+        const bool ok = len > 0 && len <= i && ((win_fast >> r) & ((1u << len) - 1)) == ((1u << len) - 1) &&
+                        ((win_code >> (2 * r)) & mask) == (entry.y & mask);
+        if(STATS) { lookups++; }
+        if(ok) { sp = ep = (entry.x & JUMP_NODE_MASK); i -= len; done = (i == 0); if(STATS) { steps += len; } }
+        else { tried = true; }                                 // step normally from this node
+      }
     }
   }
   if(!REFILL && has) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); }
@@ -466,6 +525,41 @@ __global__ __launch_bounds__(TPB) void k_lf_node(DevImage img, const u64* __rest
   if(q >= nq) { return; }
   u64 node = in[q];
   out[q] = (node < img.n ? lf_node(img, t.C, node) : 0);
+}
+
+// ---- jump table: memoised unary LF chains ----------------------------------------------------------
+// Level 1: a node with exactly one incoming label c, c a fast character, gets (LF(node), 1 step, c - 1).
+__global__ __launch_bounds__(TPB) void k_jump_init(DevImage img, u64 first, ulonglong2* __restrict__ table)
+{
+  __shared__ Tables t;
+  stage_tables(img, t);
+  u64 v = first + u64(blockIdx.x) * TPB + threadIdx.x;
+  if(v >= img.n) { return; }
+  u32 labels = 0, comp = 0;
+  for(u32 c = 0; c < u32(img.sigma); c++) { if(bv_get(bwt_of(img, c), v)) { labels++; comp = c; } }
+  ulonglong2 e = make_ulonglong2(0, 0);
+  if(labels == 1 && comp - 1 < 4) { e.x = lf_node(img, t.C, v) | (u64(1) << 56); e.y = comp - 1; }
+  table[v] = e;
+}
+
+// Doubling: an entry that is full at `have` steps is extended by the entry of the node it reaches.
+__global__ __launch_bounds__(TPB) void k_jump_double(const ulonglong2* __restrict__ in, u64 n, u64 first, u32 have,
+                                                     ulonglong2* __restrict__ out)
+{
+  u64 v = first + u64(blockIdx.x) * TPB + threadIdx.x;
+  if(v >= n) { return; }
+  ulonglong2 e = in[v];
+  if(u32(e.x >> 56) == have)
+  {
+    ulonglong2 next = in[e.x & JUMP_NODE_MASK];
+    u32 more = u32(next.x >> 56);
+    if(more > 0)
+    {
+      e.y |= next.y << (2 * have);
+      e.x = (next.x & JUMP_NODE_MASK) | (u64(have + more) << 56);
+    }
+  }
+  out[v] = e;
 }
 
 // LF_fast (all = 0, comps 1..fast_chars) / LF_all (all = 1, comps 1..sigma-2); src/gcsa.cpp:742-798

@@ -162,6 +162,13 @@ uint64_t gcsa2_kmer_table_k(const gcsa2_index* index);
  * one 8-byte entry per path node instead of walking.  Needs samples; skipped when it would take
  * more than a quarter of the free device memory or when GCSA2_LOCATE_TABLE=0. */
 uint64_t gcsa2_locate_table_bytes(const gcsa2_index* index);
+/* Bytes of the jump table (0 = none; built when GCSA2_JUMP_TABLE=1): for every path node the chain of
+ * up to 8 LF steps that is forced because each node on it has a single incoming label (a fast
+ * character), with the node it ends in.  find() on a range of one path node whose next pattern
+ * characters spell that chain moves there with one 16-byte lookup instead of one block fetch per
+ * character; any other case steps as usual, so results (including the edge-space empty ranges of
+ * include/gcsa/gcsa.h:160) are unchanged.  16 bytes per path node. */
+uint64_t gcsa2_jump_table_bytes(const gcsa2_index* index);
 int gcsa2_find_stats_device(const gcsa2_index* index, const uint8_t* d_patterns,
                             const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
                             uint64_t* d_stats, void* stream);

@@ -526,3 +526,38 @@ def test_fuzz_random_graphs(engine):
         m, r, f = gpu.match_stats_batch(data, off)
         cm, cr, cf = cpu.match_stats_batch(data, off)
         assert np.array_equal(m, cm) and np.array_equal(r, cr) and np.array_equal(f, cf), seed
+
+
+def test_jump_table(engine, monkeypatch):
+    """find() with the memoised unary LF chains (GCSA2_JUMP_TABLE=1) equals the oracle: hits, misses at
+    every depth (edge-space empty ranges), patterns with Ns, lengths 1..3 x order; also through the
+    instrumented kernel."""
+    import torch
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    monkeypatch.setenv("GCSA2_JUMP_TABLE", "1")
+    rng = SplitMix64(0x1A0)
+    for case, g in enumerate((graphs.snp_graph(20000, 0x1A1, 0x1A2, snp_period=9, node_len=16),
+                              graphs.linear_graph(5000, 0x1A3, node_len=8),
+                              graphs.random_graph(60, 0x1A4, p_branch=0.2, p_back=0.05))):
+        ix = builder.build(g, 16) if case < 2 else build(g, 4)
+        monkeypatch.setenv("GCSA2_KMER_TABLE", "3" if case == 0 else "0")
+        gpu = engine.GCSA(ix)
+        assert gpu.jump_table_bytes() == 16 * ix.n
+        cpu = OracleIndex(ix)
+        pats = [truncate_at_sink(p) for p in random_patterns(g, 48, 0x1A5 + case, 3000)]
+        for p in list(pats[:600]):                      # substitutions at random positions: misses mid-chain
+            if len(p) > 2:
+                k = rng.below(len(p))
+                pats.append(p[:k] + bytes([b"ACGTN"[rng.below(5)]]) + p[k + 1:])
+        data, off = concat_patterns(pats)
+        want = cpu.find_batch(data, off)
+        assert np.array_equal(gpu.find_batch(data, off), want), case
+        dev = torch.device("cuda", 0)
+        d_pat = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+        d_off = torch.from_numpy(off.view(np.int64).copy()).to(dev)
+        d_out = torch.zeros((len(pats), 2), dtype=torch.int64, device=dev)
+        d_stats = torch.zeros(3, dtype=torch.int64, device=dev)
+        gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), d_stats.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), case

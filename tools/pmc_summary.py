@@ -15,12 +15,17 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def is_default_find(name):
+    """k_find2<STATS=false, REFILL=false[, JUMP=false]>: the timed default kernel."""
+    return "k_find2<false, false>" in name or "k_find2<false, false, false>" in name
+
+
 def counters(directory):
     """counter name -> mean per dispatch of k_find2<false, ...>, summed over the XCD instances of a dispatch."""
     per = defaultdict(lambda: defaultdict(float))
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
-            if "k_find2<false" not in row["Kernel_Name"]:
+            if not is_default_find(row["Kernel_Name"]):
                 continue
             per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
     return {name: sum(d.values()) / len(d) for name, d in per.items()}, max((len(d) for d in per.values()), default=0)
@@ -56,7 +61,7 @@ def main():
     stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_trace", "**", "*kernel_stats.csv"), recursive=True)
     for path in stats:
         for row in csv.DictReader(open(path)):
-            if "k_find2<false" in row["Name"]:
+            if is_default_find(row["Name"]):
                 print(f"kernel trace: k_find2<false> calls={row['Calls']} average={float(row['AverageNs']) / 1e6:.4f} ms")
     if "--write-traffic" in sys.argv and out:
         out["_source"] = (f"tools/pmc_passes.sh {tag} + tools/pmc_summary.py: rocprofv3 --pmc TCC_EA0_RDREQ_{{32B,64B,128B}}_sum passes of bench.py, "
