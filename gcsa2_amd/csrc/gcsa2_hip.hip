@@ -540,7 +540,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     const char* env = std::getenv("GCSA2_JUMP_TABLE");
     size_t free_bytes = 0, total_bytes = 0;
     const u64 n = ix->img.n, bytes = n * sizeof(ulonglong2);
-    if(env != nullptr && std::atoi(env) != 0 && n > 0 && n < JUMP_NODE_MASK && ix->img.sigma >= 5 &&
+    if(env != nullptr && std::atoi(env) != 0 && n > 0 && n <= JUMP_NODE_MASK && ix->img.sigma >= 5 &&
        hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && 2 * bytes <= free_bytes / 2)
     {
       void* other = nullptr;

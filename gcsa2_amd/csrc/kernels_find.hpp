@@ -227,8 +227,23 @@ __device__ __forceinline__ void read_block(const ulonglong2* wave_stage, u32 lan
 // new query ids from a global counter (one wave-aggregated atomic) and start them, so that a batch
 // mixing hits and misses keeps all 64 lanes busy.  `queue` points to that counter (zeroed by the
 // host); the grid is sized to the machine, not to the batch.
-constexpr u64 JUMP_NODE_MASK = (u64(1) << 56) - 1;
+// Jump table entry (16 bytes per path node): the forced chain of up to 8 LF steps out of a node -- every
+// node on it has a single incoming label, a fast character -- with the nodes reached after all `len`
+// steps, after 4 steps (len >= 4) and after 2 steps (len >= 2), so that a pattern with fewer characters
+// left than the chain is long can still take a prefix of it.  Nodes are 36-bit (n < 2^36).
+//   x: [0,36) node after len steps   [36,64) low 28 bits of the node after 4 steps
+//   y: [0,8) its high 8 bits   [8,44) node after 2 steps   [44,60) labels (comp - 1), 2 bits per step   [60,64) len
 constexpr u32 JUMP_MAX = 8;
+constexpr u64 JUMP_NODE_BITS = 36, JUMP_NODE_MASK = (u64(1) << JUMP_NODE_BITS) - 1;
+__device__ __forceinline__ u64 jt_end(ulonglong2 e) { return e.x & JUMP_NODE_MASK; }
+__device__ __forceinline__ u64 jt_after4(ulonglong2 e) { return (e.x >> 36) | ((e.y & 0xFF) << 28); }
+__device__ __forceinline__ u64 jt_after2(ulonglong2 e) { return (e.y >> 8) & JUMP_NODE_MASK; }
+__device__ __forceinline__ u32 jt_labels(ulonglong2 e) { return u32(e.y >> 44) & 0xFFFF; }
+__device__ __forceinline__ u32 jt_len(ulonglong2 e) { return u32(e.y >> 60); }
+__device__ __forceinline__ ulonglong2 jt_make(u64 end, u64 after4, u64 after2, u32 labels, u32 len)
+{
+  return make_ulonglong2(end | (after4 << 36), (after4 >> 28) | (after2 << 8) | (u64(labels) << 44) | (u64(len) << 60));
+}
 
 template<bool STATS, bool REFILL, bool JUMP = false>
 __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restrict__ patterns,
@@ -251,8 +266,9 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
   const u8* p = patterns;
   bool done = true;
   [[maybe_unused]] bool tried = false;     // JUMP: the entry of the current node was examined and does not apply
+  [[maybe_unused]] bool no_jump = false;   // JUMP: no entry can apply for the rest of this pattern
   [[maybe_unused]] u64 win_top = ~u64(0), win_code = 0;      // JUMP: packed pattern window (see below)
-  [[maybe_unused]] u32 win_fast = 0;
+  [[maybe_unused]] u64 win_bad = 0;
   u64 word = 0, word_addr = ~u64(0);        // pattern bytes are consumed back to front from aligned 8-byte words
   auto byte_at = [&](u64 pos) -> u32
   {
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
   };
   auto start = [&](u64 query)               // begin the backward search of `query` (< nq)
   {
-    q = query; sp = 0; ep = img.n - 1; i = 0; done = true; word_addr = ~u64(0); tried = false; win_top = ~u64(0);
+    q = query; sp = 0; ep = img.n - 1; i = 0; done = true; word_addr = ~u64(0); tried = false; no_jump = false; win_top = ~u64(0);
     u64 begin = offsets[q], len = offsets[q + 1] - begin;
     if(len > 0 && img.n > 0)                                   // gcsa.h:99
     {
@@ -341,15 +357,15 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     ulonglong2 entry = make_ulonglong2(0, 0);
     if constexpr(JUMP)
     {
-      jumping = !done && sp == ep && !tried;
+      jumping = !done && sp == ep && !tried && !no_jump;
       entry = img.jump_tab[jumping ? sp : 0];                  // branch-free: all lanes' loads in flight together
       // The next pattern characters as 2-bit codes: window of the 32 positions below win_top, position
-      // win_top - 1 - r at bits [2r, 2r + 2) of win_code, win_fast bit r = "is a fast character".
+      // win_top - 1 - r at bits [2r, 2r + 2) of win_code, bit 2r of win_bad = "not a fast character".
       // Refilled once per 24 consumed characters (five independent word loads), so that neither the
       // jump test nor a step waits for pattern bytes.
       if(!done && (win_top == ~u64(0) || win_top - i > 24))
       {
-        win_top = i; win_code = 0; win_fast = 0;
+        win_top = i; win_code = 0; win_bad = 0;
         const u64 count = (i < 32 ? i : 32), low = reinterpret_cast<u64>(p) + i - count, base = low & ~u64(7);
         u64 w[5];
         const u64 last = (low + count - 1) & ~u64(7);           // never read past the word of the last byte needed
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
           for(u32 k = 1; k < 5; k++) { if((at >> 3) == k) { word = w[k]; } }
           const u32 c = u32(t.c2c[u32(word >> ((at & 7) * 8)) & 0xFF]) - 1;
           win_code |= u64(c & 3) << (2 * r);
-          win_fast |= (c < 4 ? 1u : 0u) << r;
+          win_bad |= u64(c < 4 ? 0 : 1) << (2 * r);
         }
       }
     }
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       if constexpr(JUMP)
       {
         const u32 r = u32(win_top - 1 - i);
-        comp = ((win_fast >> r) & 1) ? 1 + (u32(win_code >> (2 * r)) & 3) : u32(t.c2c[byte_at(i)]);
+        comp = ((win_bad >> (2 * r)) & 1) ? u32(t.c2c[byte_at(i)]) : 1 + (u32(win_code >> (2 * r)) & 3);
       }
       else { comp = t.c2c[byte_at(i)]; }
       u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
@@ -415,13 +431,28 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     {
       if(jumping)
       {
-        const u32 len = u32(entry.x >> 56), r = u32(win_top - i);
-        const u64 mask = (u64(1) << (2 * len)) - 1;
-        const bool ok = len > 0 && len <= i && ((win_fast >> r) & ((1u << len) - 1)) == ((1u << len) - 1) &&
-                        ((win_code >> (2 * r)) & mask) == (entry.y & mask);
+        const u32 len = jt_len(entry), r = u32(win_top - i);
+        // number of leading steps of the chain that the pattern follows
+        const u32 diff = (u32(win_code >> (2 * r)) ^ jt_labels(entry)) & 0xFFFF;
+        const u32 bad = ((diff | (diff >> 1)) & 0x5555) | (u32(win_bad >> (2 * r)) & 0x5555);
+        u32 usable = (bad != 0 ? u32(__ffs(int(bad)) - 1) >> 1 : 8u);
+        usable = (usable < len ? usable : len);
+        usable = (usable < i ? usable : u32(i));
+        u32 take = (usable == len ? len : (usable >= 4 ? 4u : (usable >= 2 ? 2u : 0u)));
         if(STATS) { lookups++; }
-        if(ok) { sp = ep = (entry.x & JUMP_NODE_MASK); i -= len; done = (i == 0); if(STATS) { steps += len; } }
-        else { tried = true; }                                 // step normally from this node
+        if(take > 0)
+        {
+          sp = ep = (take == len ? jt_end(entry) : (take == 4 ? jt_after4(entry) : jt_after2(entry)));
+          i -= take; done = (i == 0);
+          if(STATS) { steps += take; }
+        }
+        else
+        {
+          tried = true;                                        // step normally from this node
+          // A chain the pattern leaves (or outlasts by one character): the nodes the steps will visit lie
+          // on that same chain, so no later entry can apply either.
+          no_jump = (len > 0);
+        }
       }
     }
   }
@@ -538,26 +569,31 @@ __global__ __launch_bounds__(TPB) void k_jump_init(DevImage img, u64 first, ulon
   u32 labels = 0, comp = 0;
   for(u32 c = 0; c < u32(img.sigma); c++) { if(bv_get(bwt_of(img, c), v)) { labels++; comp = c; } }
   ulonglong2 e = make_ulonglong2(0, 0);
-  if(labels == 1 && comp - 1 < 4) { e.x = lf_node(img, t.C, v) | (u64(1) << 56); e.y = comp - 1; }
+  if(labels == 1 && comp - 1 < 4) { e = jt_make(lf_node(img, t.C, v), 0, 0, comp - 1, 1); }
   table[v] = e;
 }
 
-// Doubling: an entry that is full at `have` steps is extended by the entry of the node it reaches.
+// Doubling: an entry that is full at `have` steps is extended by the entry of the node it reaches; the
+// node it reaches is recorded as the 2-step / 4-step landing point when have is 2 / 4.
 __global__ __launch_bounds__(TPB) void k_jump_double(const ulonglong2* __restrict__ in, u64 n, u64 first, u32 have,
                                                      ulonglong2* __restrict__ out)
 {
   u64 v = first + u64(blockIdx.x) * TPB + threadIdx.x;
   if(v >= n) { return; }
   ulonglong2 e = in[v];
-  if(u32(e.x >> 56) == have)
+  if(jt_len(e) == have)
   {
-    ulonglong2 next = in[e.x & JUMP_NODE_MASK];
-    u32 more = u32(next.x >> 56);
-    if(more > 0)
+    const u64 here = jt_end(e);
+    u64 after2 = (have == 2 ? here : jt_after2(e)), after4 = (have == 4 ? here : jt_after4(e));
+    u64 end = here; u32 labels = jt_labels(e), len = have;
+    ulonglong2 next = in[here];
+    if(jt_len(next) > 0)
     {
-      e.y |= next.y << (2 * have);
-      e.x = (next.x & JUMP_NODE_MASK) | (u64(have + more) << 56);
+      labels |= jt_labels(next) << (2 * have);
+      end = jt_end(next); len = have + jt_len(next);
+      if(have == 1) { after2 = end; }                        // 1 + 1 steps
     }
+    e = jt_make(end, after4, after2, labels & 0xFFFF, len);
   }
   out[v] = e;
 }
