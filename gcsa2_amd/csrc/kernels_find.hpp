@@ -245,7 +245,7 @@ __device__ __forceinline__ ulonglong2 jt_make(u64 end, u64 after4, u64 after2, u
   return make_ulonglong2(end | (after4 << 36), (after4 >> 28) | (after2 << 8) | (u64(labels) << 44) | (u64(len) << 60));
 }
 
-template<bool STATS, bool REFILL, bool JUMP = false>
+template<bool STATS, bool REFILL, bool JUMP = false, bool WINDOW = true>
 __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restrict__ patterns,
                                                const u64* __restrict__ offsets, u64 nq,
                                                u64* __restrict__ out, unsigned long long* __restrict__ stats,
@@ -359,6 +359,9 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     {
       jumping = !done && sp == ep && !tried && !no_jump;
       entry = img.jump_tab[jumping ? sp : 0];                  // branch-free: all lanes' loads in flight together
+    }
+    if constexpr(WINDOW)
+    {
       // The next pattern characters as 2-bit codes: window of the 32 positions below win_top, position
       // win_top - 1 - r at bits [2r, 2r + 2) of win_code, bit 2r of win_bad = "not a fast character".
       // Refilled once per 24 consumed characters (five independent word loads), so that neither the
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     if(stepping)
     {
       i--;
-      if constexpr(JUMP)
+      if constexpr(WINDOW)
       {
         const u32 r = u32(win_top - 1 - i);
         comp = ((win_bad >> (2 * r)) & 1) ? u32(t.c2c[byte_at(i)]) : 1 + (u32(win_code >> (2 * r)) & 3);

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def is_default_find(name):
     """k_find2<STATS=false, REFILL=false[, JUMP=false]>: the timed default kernel."""
-    return "k_find2<false, false>" in name or "k_find2<false, false, false>" in name
+    return "k_find2<false, false>" in name or "k_find2<false, false, false" in name
 
 
 def counters(directory):
