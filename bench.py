@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+REQUEST_CEILING_GPS = 58.0   # dependent random 128-byte fetches/s measured by gcsa2_amd/lib/gather_bench (profiles/r01_gather_bench.md)
 LINEAR_SEED = 0x6C5A0040
 
 
@@ -192,7 +193,7 @@ def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup):
     blocks, lf_steps, lookups = (int(x) for x in d_stats.cpu())
     algo_bytes = blocks * gpu.find_block_bytes() + lookups * 16 + nq * (m + 16)
     found = int((d_out[:, 0] <= d_out[:, 1]).sum().item())
-    return dict(elapsed=elapsed, kernel_ms=kernel_ms, blocks=blocks, lf_steps=lf_steps, algo_bytes=algo_bytes,
+    return dict(elapsed=elapsed, kernel_ms=kernel_ms, blocks=blocks, lf_steps=lf_steps, lookups=lookups, algo_bytes=algo_bytes,
                 found=found, d_out=d_out)
 
 
@@ -244,6 +245,11 @@ def roofline(args, r, key, nq, m, kmer_k):
     out = {"bound": "hbm", "kernel": "k_find2" if args.variant == 2 else "k_find", "achieved": achieved,
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
            "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"]}
+    # what actually bounds a random-gather kernel beyond L2 is requests per second (profiles/r01_gather_bench.md:
+    # 50-58 G dependent random 128-byte fetches/s on this GPU); reported beside the byte roofline
+    requests = r["blocks"] + r["lookups"]
+    out["request_rate"] = {"achieved_G_per_s": requests / (r["kernel_ms"] * 1e-3) / 1e9, "ceiling_G_per_s": REQUEST_CEILING_GPS,
+                           "requests_per_query": requests / nq}
     if traffic is not None:
         out["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_*_sum pass of this workload; 128 B x RDREQ_128B + 64 B x RDREQ_64B)"
         out["traffic_GBps"] = traffic / (r["kernel_ms"] * 1e-3) / 1e9
@@ -331,6 +337,8 @@ def main():
                 "value": nq / (rj["kernel_ms"] * 1e-3), "unit": "queries/s", "kernel_ms": rj["kernel_ms"],
                 "table_bytes": gpu_j.jump_table_bytes(), "blocks_per_query": rj["blocks"] / nq,
                 "algorithmic_GBps": rj["algo_bytes"] / (rj["kernel_ms"] * 1e-3) / 1e9,
+                "requests_per_query": (rj["blocks"] + rj["lookups"]) / nq,
+                "request_rate_G_per_s": (rj["blocks"] + rj["lookups"]) / (rj["kernel_ms"] * 1e-3) / 1e9,
                 "equals_default_results": bool(torch.equal(rj["d_out"], r["d_out"]))}
             del gpu_j, rj
     del r
