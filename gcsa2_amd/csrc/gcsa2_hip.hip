@@ -650,8 +650,16 @@ int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t*
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, len_in, len_out, idx_in, idx_out, int(nq), 0, 32, st);
     if(e == hipSuccess)
     {
-      hipLaunchKernelGGL((k_find2<false, false>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)idx_out, (unsigned long long*)nullptr);
+      if(ix->img.jump_tab != nullptr)
+      {
+        hipLaunchKernelGGL((k_find2<false, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
+                           ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)idx_out, (unsigned long long*)nullptr);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_find2<false, false>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
+                           ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)idx_out, (unsigned long long*)nullptr);
+      }
       e = hipGetLastError();
     }
     (void)hipFreeAsync(tmp, st); (void)hipFreeAsync(len_in, st);    // stream-ordered: freed after the kernel
