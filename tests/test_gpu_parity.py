@@ -561,3 +561,7 @@ def test_jump_table(engine, monkeypatch):
         gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), d_stats.data_ptr(), 0)
         torch.cuda.synchronize()
         assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), case
+        d_out.zero_()
+        gpu.find_device_variant(4, d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), 0)     # length-bucketed launch
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), case
