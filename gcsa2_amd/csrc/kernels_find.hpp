@@ -357,7 +357,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     ulonglong2 entry = make_ulonglong2(0, 0);
     if constexpr(JUMP)
     {
-      jumping = !done && sp == ep && !tried && !no_jump;
+      jumping = !done && sp == ep && i >= 2 && !tried && !no_jump;   // the last character is a plain step: same cost, no wasted lookup
       entry = img.jump_tab[jumping ? sp : 0];                  // branch-free: all lanes' loads in flight together
     }
     if constexpr(WINDOW)
