@@ -4,7 +4,9 @@ chr22-like SNP graph 2^22 (6.1 M path nodes); each k run three times, best time 
 import sys
 import time
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from workload import graphs, builder
 from gcsa2_amd.binding import open_index
 from oracle.oracle import OracleIndex, max_threads

@@ -2,7 +2,7 @@
 """SURVEY.md 8(d) config 5 shape on one GPU: long patterns, the LF + parent interplay of vg's MEM
 finder (fused kernel k_match_stats), then locate() on the final ranges.
 
-    python tools/mem_bench.py [--log2-bases 25] [--queries 1000000] [--pattern-len 256]
+    python tests/perf/mem_bench.py [--log2-bases 25] [--queries 1000000] [--pattern-len 256]
 
 Half of the patterns are walks through the graph (full-depth matches), half carry a substitution
 every ~40 bp, so their ranges empty mid-pattern and parent() is taken.
@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -3,7 +3,7 @@
 find -> parent -> depth -> count -> locate over one pattern set, each phase timed on the device
 (inputs and outputs resident in HBM) and, beside it, the CPU oracle on the same host.
 
-    python tools/query_bench.py [--config 1|2] [--queries N] [--pattern-len M] [--locate-queries N]
+    python tests/perf/query_bench.py [--config 1|2] [--queries N] [--pattern-len M] [--locate-queries N]
 
 config 1: 1-Mbp linear graph, order 64, 16-mers (50 % substrings, 50 % uniform random)
 config 2: chr22-like SNP graph 2^25 bases, order 256, 32-mers from walks (set S)
@@ -17,7 +17,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -1,5 +1,6 @@
 import sys, time, json
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from workload import graphs, builder, patterns
 from gcsa2_amd.binding import open_index

@@ -4,7 +4,7 @@ whole-genome indexes, paper.tex:378-380) built without suffix sorting from a deg
 (workload/mseq_torch.py), 10 M 32-mers that are substrings of the text, every result checked against
 its closed-form answer find(T[p..p+32)) = (rank[p], rank[p]).
 
-    python tools/whole_genome_bench.py [--degree 32] [--queries 10000000] [--steps 10]
+    python tests/perf/whole_genome_bench.py [--degree 32] [--queries 10000000] [--steps 10]
 """
 import argparse
 import json
@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
