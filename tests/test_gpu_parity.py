@@ -495,7 +495,7 @@ def test_seed_table_sizes(engine, monkeypatch):
     assert len(seen) >= 5
 
 
-def test_fuzz_random_graphs(engine):
+def test_fuzz_random_graphs(engine, monkeypatch):
     """150 seeded random graphs (bubbles, indels, cycles, Ns; orders 2..6): every query type equals the
     oracle, which the CPU suite pins against the definition-level brute force on graphs of this family."""
     from oracle.oracle import OracleIndex
@@ -512,6 +512,17 @@ def test_fuzz_random_graphs(engine):
         data, off = concat_patterns(pats)
         ranges = gpu.find_batch(data, off)
         assert np.array_equal(ranges, cpu.find_batch(data, off)), seed
+        if seed % 3 == 0:                   # the same index with the opt-in tables switched the other way
+            monkeypatch.setenv("GCSA2_JUMP_TABLE", "1")
+            monkeypatch.setenv("GCSA2_KMER_TABLE", str(seed % 4))
+            monkeypatch.setenv("GCSA2_LOCATE_TABLE", "0")
+            other = engine.GCSA(ix)
+            for name in ("GCSA2_JUMP_TABLE", "GCSA2_KMER_TABLE", "GCSA2_LOCATE_TABLE"):
+                monkeypatch.delenv(name)
+            assert np.array_equal(other.find_batch(data, off), ranges), seed
+            oo, ov = other.locate_batch(ranges)
+            go0, gv0 = gpu.locate_batch(ranges)
+            assert np.array_equal(oo, go0) and np.array_equal(ov, gv0), seed
         extra = np.array(all_ranges(ix, 0xF300 + seed)[:200], dtype=np.uint64)
         for arr in (ranges, extra):
             assert np.array_equal(gpu.count_batch(arr), cpu.count_batch(arr)), seed
