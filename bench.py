@@ -137,7 +137,7 @@ def build_linear_index(args, log2_bases):
     return ix
 
 
-def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup):
+def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup, pack32=False):
     """Warm-up, then `steps` timed find() launches (+ gather when distributed).  Returns timings,
     the device result tensor and the algorithmic traffic of one launch."""
     import torch
@@ -146,7 +146,11 @@ def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup):
     # two result buffers: the RCCL gather of step k (async, on RCCL's own stream) overlaps the
     # find() launch of step k + 1; a buffer is reused only after its gather has completed.
     outs = [torch.zeros((nq, 2), dtype=torch.int64, device=dev) for _ in range(2 if D.active else 1)]
-    parts = [[torch.zeros_like(outs[0]) for _ in range(D.world)] for _ in outs] if (D.active and D.rank == 0) else [None, None]
+    # pack32: every value of a range is below 2^32 for this index, so the gather carries (sp, ep) as u32
+    # pairs (8 bytes per query over xGMI instead of 16); the root keeps the gathered shards in that form
+    pack32 = pack32 and D.active
+    wire = [torch.zeros((nq, 2), dtype=torch.int32, device=dev) for _ in outs] if pack32 else outs
+    parts = [[torch.zeros_like(wire[0]) for _ in range(D.world)] for _ in outs] if (D.active and D.rank == 0) else [None, None]
     pending = [None, None]
     stream = torch.cuda.current_stream()
 
@@ -160,7 +164,9 @@ def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup):
         gpu.find_device_variant(args.variant, d_pat.data_ptr(), d_off.data_ptr(), nq, outs[b].data_ptr(), stream.cuda_stream)
         if record is not None:
             record[1].record(stream)
-        pending[b] = D.gather(outs[b], parts[b])   # the single gather of hit ranges over xGMI (16 B per query)
+        if pack32:
+            wire[b].copy_(outs[b])     # int64 -> int32 keeps the low 32 bits
+        pending[b] = D.gather(wire[b], parts[b])   # the single gather of hit ranges over xGMI
 
     def drain():
         for b in range(len(pending)):
@@ -182,6 +188,10 @@ def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup):
     D.barrier()
     d_out = outs[(steps - 1) % len(outs)] if steps > 0 else outs[0]
     elapsed = D.max(time.perf_counter() - t0, dev)
+    if D.active and D.rank == 0 and steps > 0:       # the root's own shard came back through the gather intact
+        mine = parts[(steps - 1) % len(outs)][0]
+        back = (mine.to(torch.int64) & 0xFFFFFFFF) if pack32 else mine
+        assert torch.equal(back, d_out), "gathered shard differs from the computed ranges"
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     # algorithmic traffic of one launch (instrumented kernel, outside the timed region)
@@ -297,7 +307,8 @@ def main():
     flat, offsets = patterns.as_batch(pats)
     log(f"patterns: {nq} x {m} set {args.set} ({time.time() - t:.1f} s)")
 
-    r = measure(args, D, dev, gpu, flat, offsets, nq, m, args.steps, args.warmup)
+    pack32 = max(int(ix.n), int(ix.e)) + 2 < (1 << 32)
+    r = measure(args, D, dev, gpu, flat, offsets, nq, m, args.steps, args.warmup, pack32=pack32)
 
     result = None
     if rank == 0:
@@ -313,7 +324,8 @@ def main():
                        "found": r["found"], "lf_steps_per_query": r["lf_steps"] / nq,
                        "blocks_per_query": r["blocks"] / nq, "block_bytes": gpu.find_block_bytes(),
                        "kmer_table_k": gpu.kmer_table_k(),
-                       "parallelism": f"replicated index, query shards x{world}, one RCCL gather of ranges per step"},
+                       "parallelism": f"replicated index, query shards x{world}, one RCCL gather of ranges per step"
+                                      + (" ((sp, ep) as u32 pairs: every value of this index is below 2^32)" if (pack32 and world > 1) else "")},
             "roofline": roofline(args, r, f"{args.workload}_{log2_bases}", nq, m, gpu.kmer_table_k()),
         }
         if args.workload == "snp":
