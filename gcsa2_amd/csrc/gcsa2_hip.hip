@@ -614,6 +614,7 @@ int gcsa2_find_device(const gcsa2_index* ix, const uint8_t* d_patterns, const ui
                       uint64_t nq, uint64_t* d_ranges, void* stream)
 {
   CHECK_INDEX(ix);
+  DeviceGuard guard(ix->device);          // the launch goes to the index's device whatever the caller's current one is
   if(nq == 0) { return GCSA2_OK; }
   if(ix->img.jump_tab != nullptr)
   {
@@ -683,6 +684,7 @@ int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t*
     return GCSA2_OK;
   }
   if(variant != 1) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown find variant"); }
+  DeviceGuard guard(ix->device);
   hipLaunchKernelGGL(k_find<false>, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
                      ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr);
   LAUNCH_CHECK("k_find");
@@ -693,6 +695,7 @@ int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, co
                             uint64_t nq, uint64_t* d_ranges, uint64_t* d_stats, void* stream)
 {
   CHECK_INDEX(ix);
+  DeviceGuard guard(ix->device);          // the launch goes to the index's device whatever the caller's current one is
   if(d_stats == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null stats buffer"); }
   if(nq == 0) { return GCSA2_OK; }
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64 atomics");
@@ -718,6 +721,7 @@ int gcsa2_lf_device(const gcsa2_index* ix, const uint64_t* d_in, const uint8_t* 
                     uint64_t* d_out, void* stream)
 {
   CHECK_INDEX(ix);
+  DeviceGuard guard(ix->device);          // the launch goes to the index's device whatever the caller's current one is
   if(nq == 0) { return GCSA2_OK; }
   hipLaunchKernelGGL(k_lf2, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
                      ix->img, d_in, d_comps, nq, d_out);
@@ -728,6 +732,7 @@ int gcsa2_lf_device(const gcsa2_index* ix, const uint64_t* d_in, const uint8_t* 
 int gcsa2_count_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t nq, uint64_t* d_counts, void* stream)
 {
   CHECK_INDEX(ix);
+  DeviceGuard guard(ix->device);          // the launch goes to the index's device whatever the caller's current one is
   if(!ix->img.has_counters) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without counters"); }
   if(nq == 0) { return GCSA2_OK; }
   hipLaunchKernelGGL(k_count, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
@@ -739,6 +744,7 @@ int gcsa2_count_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t
 int gcsa2_parent_device(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t nq, gcsa2_stnode* d_nodes, void* stream)
 {
   CHECK_INDEX(ix);
+  DeviceGuard guard(ix->device);          // the launch goes to the index's device whatever the caller's current one is
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
   if(nq == 0) { return GCSA2_OK; }
   hipLaunchKernelGGL(k_parent, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
@@ -1432,6 +1438,7 @@ extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_
                                         uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
 {
   CHECK_INDEX(ix);
+  DeviceGuard guard(ix->device);
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
   if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
   hipLaunchKernelGGL(k_match_stats, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
