@@ -439,11 +439,14 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       ix->bytes += nwords * 4 * sizeof(u64);
     }
 
-    // k-mer seed table, only if comps 1..4 exist.  Default: the largest k <= 16 whose table (16 * 4^k
-    // bytes) is at most twice the index image itself -- each extra character saves one LF step per query
+    // k-mer seed table, only if comps 1..4 exist.  Default: the largest k <= 16 whose table (4^k entries
+    // of 8 or 16 bytes) is at most twice the index image itself -- each extra character saves one LF step per query
     // (~5 % of a 32-mer) and quadruples the table; HBM capacity is what this GPU has to spare.  GCSA2_KMER_TABLE=k asks for exactly k (<= 16;
     // 0 disables).  Either way the table must fit in a quarter of the free device memory.
     u32 k = 0;
+    // entries are (sp, ep) as two u64, or two u32 when every value fits (path nodes and edges < 2^32 - 2)
+    img.kmer_compact = ((img.n > img.e ? img.n : img.e) + 2 < 0xFFFFFFFFull ? 1 : 0);
+    const u64 entry_bytes = (img.kmer_compact ? 8 : 16);
     const char* env = std::getenv("GCSA2_KMER_TABLE");
     if(env != nullptr)
     {
@@ -451,21 +454,21 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       if(k > 16) { k = 16; }
       size_t free_bytes = 0, total_bytes = 0;
       if(hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { free_bytes = 0; }
-      while(k > 0 && (u64(16) << (2 * k)) > free_bytes / 4) { k--; }
+      while(k > 0 && (entry_bytes << (2 * k)) > free_bytes / 4) { k--; }
     }
     else
     {
       const u64 image_bytes = 2 * st.words.size() * sizeof(u64);
       size_t free_bytes = 0, total_bytes = 0;
       if(hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { free_bytes = 0; }
-      while(k < 16 && (u64(16) << (2 * (k + 1))) <= image_bytes && (u64(16) << (2 * (k + 1))) <= free_bytes / 4) { k++; }
+      while(k < 16 && (entry_bytes << (2 * (k + 1))) <= image_bytes && (entry_bytes << (2 * (k + 1))) <= free_bytes / 4) { k++; }
     }
     if(img.sigma < 5) { k = 0; }
     img.kmer_k = 0; img.kmer_table = nullptr;
     if(k > 0)
     {
       u64 entries = u64(1) << (2 * k);
-      e = hipMalloc(&ix->d_kmer, entries * 2 * sizeof(u64));
+      e = hipMalloc(&ix->d_kmer, entries * entry_bytes);
       if(e == hipSuccess)
       {
         const u64 slice = u64(1) << 30;
@@ -483,7 +486,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
         return fail(GCSA2_ERR_HIP, std::string("k-mer table: ") + hipGetErrorString(e));
       }
       img.kmer_table = static_cast<const u64*>(ix->d_kmer); img.kmer_k = k;
-      ix->bytes += entries * 2 * sizeof(u64);
+      ix->bytes += entries * entry_bytes;
     }
   }
   catch(const std::bad_alloc&)

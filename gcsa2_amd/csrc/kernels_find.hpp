@@ -77,7 +77,8 @@ __global__ __launch_bounds__(TPB) void k_build_kmer_table(DevImage img, u32 k, u
     if(range_empty(sp, ep)) { break; }
     path_node_range(img, sp, ep);
   }
-  reinterpret_cast<ulonglong2*>(table)[tix] = make_ulonglong2(sp, ep);
+  if(img.kmer_compact) { reinterpret_cast<uint2*>(table)[tix] = make_uint2(u32(sp), u32(ep)); }      // ~0 -> 0xFFFFFFFF
+  else { reinterpret_cast<ulonglong2*>(table)[tix] = make_ulonglong2(sp, ep); }
 }
 
 // ---- find, version 2: fused 128-byte LF blocks, wave-cooperative fetch through LDS -----------
@@ -297,8 +298,17 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
         }
         if(fast)
         {
-          ulonglong2 r = reinterpret_cast<const ulonglong2*>(img.kmer_table)[tix];
-          sp = r.x; ep = r.y; i = len - k; seeded = true;
+          if(img.kmer_compact)
+          {
+            uint2 r = reinterpret_cast<const uint2*>(img.kmer_table)[tix];
+            sp = (r.x == 0xFFFFFFFFu ? ~u64(0) : u64(r.x)); ep = (r.y == 0xFFFFFFFFu ? ~u64(0) : u64(r.y));
+          }
+          else
+          {
+            ulonglong2 r = reinterpret_cast<const ulonglong2*>(img.kmer_table)[tix];
+            sp = r.x; ep = r.y;
+          }
+          i = len - k; seeded = true;
           if(STATS) { lookups++; }
         }
       }
