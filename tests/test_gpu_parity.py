@@ -576,3 +576,29 @@ def test_jump_table(engine, monkeypatch):
         gpu.find_device_variant(4, d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), 0)     # length-bucketed launch
         torch.cuda.synchronize()
         assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), case
+
+
+def test_very_long_patterns(engine, monkeypatch):
+    """Patterns far longer than the order and than any window / seed length (a whole 60 kbp backbone,
+    prefixes and suffixes of it, one with a late mismatch): find() equals the oracle, with and without
+    the jump table; the matching-statistics values saturate at 65535 only where the oracle's do."""
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    g = graphs.linear_graph(60000, 0x2A1, node_len=8)
+    ix = builder.build(g, 32)
+    cpu = OracleIndex(ix)
+    text = bytes(b"$ACGTN#"[int(c)] for c in g.comp[1:-1])
+    broken = bytearray(text[:50000]); broken[137] = ord("A") if broken[137] != ord("A") else ord("C")
+    pats = [text, text[:-1], text[1:], text[12345:], text[:40001], bytes(broken), text[-70:], text[:1], b"N" + text[:100]]
+    data, off = concat_patterns(pats)
+    want = cpu.find_batch(data, off)
+    assert want[0][0] <= want[0][1]
+    for jump in ("0", "1"):
+        monkeypatch.setenv("GCSA2_JUMP_TABLE", jump)
+        gpu = engine.GCSA(ix)
+        assert np.array_equal(gpu.find_batch(data, off), want), jump
+    short = [text[:3000], bytes(broken[:3000]), text[20000:20100]]
+    data, off = concat_patterns(short)
+    m, r, f = gpu.match_stats_batch(data, off)
+    cm, cr, cf = cpu.match_stats_batch(data, off)
+    assert np.array_equal(m, cm) and np.array_equal(r, cr) and np.array_equal(f, cf)
