@@ -602,3 +602,22 @@ def test_very_long_patterns(engine, monkeypatch):
     m, r, f = gpu.match_stats_batch(data, off)
     cm, cr, cf = cpu.match_stats_batch(data, off)
     assert np.array_equal(m, cm) and np.array_equal(r, cr) and np.array_equal(f, cf)
+
+
+def test_arbitrary_bytes(engine, monkeypatch):
+    """Patterns over all 256 byte values (lower case, IUPAC codes, control and high bytes): char2comp maps
+    them as the reference's Alphabet does (support.h:150-151) and the ranges equal the oracle's."""
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    g = graphs.snp_graph(3000, 0x2B1, 0x2B2, snp_period=10, node_len=16)
+    ix = builder.build(g, 16)
+    cpu = OracleIndex(ix)
+    rng = SplitMix64(0x2B3)
+    pats = [bytes(rng.below(256) for _ in range(1 + rng.below(20))) for _ in range(2000)]
+    walks = [truncate_at_sink(p) for p in random_patterns(g, 16, 0x2B4, 400)]
+    pats += [p.lower() for p in walks] + [p[:-1] + bytes([rng.below(256)]) for p in walks if len(p) > 1]
+    data, off = concat_patterns(pats)
+    want = cpu.find_batch(data, off)
+    for jump in ("0", "1"):
+        monkeypatch.setenv("GCSA2_JUMP_TABLE", jump)
+        assert np.array_equal(engine.GCSA(ix).find_batch(data, off), want), jump
