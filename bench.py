@@ -397,6 +397,7 @@ def cpu_baseline(args, ix, flat, offsets, d_out, m):
     parity = bool(np.array_equal(got, rall)) and bool(np.array_equal(got[:n1], r1))
     return {"value": nall / tall, "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": f"first {nall} of the {nq} patterns, {m}-mers, OpenMP static split over {cores} threads "
+                      f"= the CPUs this container may use (affinity / cgroup quota; {os.cpu_count()} logical CPUs visible) "
                       f"({tall:.1f} s); single thread: first {n1} patterns ({t1:.1f} s)",
             "single_thread_value": n1 / t1, "single_thread_us_per_query": t1 / n1 * 1e6,
             "gpu_matches_cpu_on_sample": parity}

@@ -302,4 +302,26 @@ class OracleIndex:
 
 
 def max_threads():
-    return int(lib().oracle_max_threads())
+    """Threads the oracle should be timed with: what OpenMP would start, capped by the CPU affinity mask
+    and by the cgroup CPU quota of the container (a box with 256 logical CPUs and a 16-CPU quota runs 128
+    threads slower than 16)."""
+    import math
+    import os
+    n = int(lib().oracle_max_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())           # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
