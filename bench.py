@@ -227,7 +227,14 @@ def measure_locate(gpu, d_ranges, dev, steps):
         gpu.locate_into(d_ranges.data_ptr(), nq, d_off.data_ptr(), d_val.data_ptr(), d_val.shape[0], stream.cuda_stream)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"workload": f"locate() of the {nq} ranges found above, sorted distinct values per range, results into caller-owned HBM buffers",
+    # size-independent check (the query_gcsa consistency test, benchmark/query_gcsa.cpp:160-179): per range,
+    # the number of located values equals count()
+    d_cnt = torch.zeros(nq, dtype=torch.int64, device=dev)
+    gpu.count_device(d_ranges.data_ptr(), nq, d_cnt.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    consistent = bool(torch.equal(d_off[1:] - d_off[:-1], d_cnt)) and int(d_off[-1]) == int(total)
+    return {"count_equals_located": consistent,
+            "workload": f"locate() of the {nq} ranges found above, sorted distinct values per range, results into caller-owned HBM buffers",
             "value": nq / (ms * 1e-3), "unit": "queries/s", "ms_per_step": ms, "values": int(total),
             "locate_table_bytes": gpu.locate_table_bytes()}
 
