@@ -14,7 +14,7 @@ from .hostview import (HostView, STNode, STNODE_DTYPE, UNKNOWN, make_host_view, 
                        u64p, u8p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgcsa2_hip.so")
+LIB_PATH = os.environ.get("GCSA2_HIP_LIB") or os.path.join(_HERE, "lib", "libgcsa2_hip.so")   # override: A/B runs of two builds
 
 STATUS = {0: "OK", -1: "INVALID_ARGUMENT", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY", -4: "HIP",
           -5: "MISSING_COMPONENT", -6: "BUFFER_TOO_SMALL"}
