@@ -1732,7 +1732,8 @@ void load_gcsa_members(const char* path, gcsa2_view_storage& st)
   if(tag != 0x6C5A6C5Au || version != 3 || flags != 0)
   {
     in.error("Invalid header: tag " + std::to_string(tag) + ", version " + std::to_string(version) + ", flags " + std::to_string(flags)
-             + " (expected GCSA version 3)");
+             + " (expected GCSA version 3 as written by GCSA::serialize / sdsl::store_to_file; a file wrapped in another"
+               " container, e.g. a tagged stream, has to be unwrapped first)");
   }
 
   // Alphabet (support.cpp:243-250)
