@@ -24,7 +24,7 @@ EXPORTS = [
     "gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count", "gcsa2_sample_bits",
     "gcsa2_device", "gcsa2_device_bytes", "gcsa2_block_bits",
     "gcsa2_find_batch", "gcsa2_find_device", "gcsa2_find_stats_device", "gcsa2_find_device_variant",
-    "gcsa2_find_block_bytes", "gcsa2_kmer_table_k", "gcsa2_locate_table_bytes", "gcsa2_jump_table_bytes", "gcsa2_lf_batch", "gcsa2_lf_device",
+    "gcsa2_find_block_bytes", "gcsa2_kmer_table_k", "gcsa2_locate_table_bytes", "gcsa2_jump_table_bytes", "gcsa2_pair_block_bytes", "gcsa2_lf_batch", "gcsa2_lf_device",
     "gcsa2_lf_node_batch", "gcsa2_char_range", "gcsa2_lf_all_batch",
     "gcsa2_count_batch", "gcsa2_count_device",
     "gcsa2_locate_run", "gcsa2_locate_fetch", "gcsa2_locate_discard", "gcsa2_locate_device", "gcsa2_locate_into",
@@ -68,7 +68,7 @@ def load_library():
     L.gcsa2_index_destroy.argtypes = [vp]
     L.gcsa2_index_destroy.restype = None
     for name in ("gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count",
-                 "gcsa2_sample_bits", "gcsa2_device_bytes", "gcsa2_block_bits", "gcsa2_find_block_bytes", "gcsa2_kmer_table_k", "gcsa2_locate_table_bytes", "gcsa2_jump_table_bytes",
+                 "gcsa2_sample_bits", "gcsa2_device_bytes", "gcsa2_block_bits", "gcsa2_find_block_bytes", "gcsa2_kmer_table_k", "gcsa2_locate_table_bytes", "gcsa2_jump_table_bytes", "gcsa2_pair_block_bytes",
                  "gcsa2_sampled_positions", "gcsa2_sigma", "gcsa2_fast_chars", "gcsa2_lcp_size",
                  "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching"):
         getattr(L, name).restype = u64
@@ -321,6 +321,9 @@ class GCSA:
 
     def jump_table_bytes(self):
         return int(self._L.gcsa2_jump_table_bytes(self._h))
+
+    def pair_block_bytes(self):
+        return int(self._L.gcsa2_pair_block_bytes(self._h))
 
     def locate_table_bytes(self):
         return int(self._L.gcsa2_locate_table_bytes(self._h))

@@ -54,6 +54,7 @@ struct gcsa2_index
   void* d_pred4 = nullptr;
   void* d_locate = nullptr;
   void* d_jump = nullptr;
+  void* d_pairs = nullptr;
   // Small results the host reads back (totals of the locate pipeline) live in plain hipMalloc memory:
   // device-to-host copies out of stream-ordered pool memory were observed to return stale data
   // (about one call in 5000 on ROCm 7.2 / gfx950), copies out of hipMalloc memory never.
@@ -439,6 +440,35 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       ix->bytes += nwords * 4 * sizeof(u64);
     }
 
+    // FLP128 pair blocks (two characters per step), built on the device: 8 bytes per path node.  Default on;
+    // skipped when GCSA2_PAIR_BLOCKS=0, when comps 1..4 do not exist, or when they would take more than a third
+    // of the free device memory (find() then steps one character at a time, with identical results).
+    img.flp = nullptr; img.flp_nblocks = 0;
+    {
+      const char* penv = std::getenv("GCSA2_PAIR_BLOCKS");
+      const u64 nb = img.n / PAIR_BITS + 1, pair_bytes = 16 * nb * FLB_BYTES;
+      size_t free_bytes = 0, total_bytes = 0;
+      if(!(penv != nullptr && std::atoi(penv) == 0) && img.sigma >= 5 && img.n > 0 && 16 * nb < u64(PAIR_FLAG) &&
+         hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && pair_bytes <= free_bytes / 3)
+      {
+        e = hipMalloc(&ix->d_pairs, pair_bytes);
+        if(e == hipSuccess)
+        {
+          img.flp_nblocks = nb;
+          hipLaunchKernelGGL(k_build_pair_blocks, dim3(unsigned(nb), 4), dim3(256), 0, nullptr, img, static_cast<u64*>(ix->d_pairs));
+          e = hipGetLastError();
+          if(e == hipSuccess) { e = hipDeviceSynchronize(); }
+        }
+        if(e != hipSuccess)
+        {
+          gcsa2_index_destroy(ix);
+          return fail(GCSA2_ERR_HIP, std::string("pair blocks: ") + hipGetErrorString(e));
+        }
+        img.flp = static_cast<const u64*>(ix->d_pairs);
+        ix->bytes += pair_bytes;
+      }
+    }
+
     // k-mer seed table, only if comps 1..4 exist.  Default: the largest k <= 16 whose table (4^k entries
     // of 8 or 16 bytes) is at most twice the index image itself -- each extra character saves one LF step per query
     // (~5 % of a 32-mer) and quadruples the table; HBM capacity is what this GPU has to spare.  GCSA2_KMER_TABLE=k asks for exactly k (<= 16;
@@ -594,6 +624,7 @@ void gcsa2_index_destroy(gcsa2_index* ix)
   if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
   if(ix->d_locate) { (void)hipFree(ix->d_locate); }
   if(ix->d_jump) { (void)hipFree(ix->d_jump); }
+  if(ix->d_pairs) { (void)hipFree(ix->d_pairs); }
   if(ix->d_slots) { (void)hipFree(ix->d_slots); }
   delete ix;
 }
@@ -613,21 +644,37 @@ uint64_t gcsa2_block_bits(const gcsa2_index*) { return BLOCK_BITS; }
 #define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if(e_ != hipSuccess) { \
   return fail(GCSA2_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); } } while(0)
 
+}  // extern "C"
+
+namespace {
+
+// k_find2 instantiation for this image: JUMP with the jump table, PAIR with the pair blocks
+template<bool STATS, bool REFILL>
+void launch_find2(const gcsa2_index* ix, unsigned grid, hipStream_t st, const uint8_t* d_patterns, const uint64_t* d_offsets, u64 nq,
+                  uint64_t* d_ranges, unsigned long long* d_stats, const u32* perm, unsigned long long* queue)
+{
+  const bool jump = ix->img.jump_tab != nullptr, pair = ix->img.flp != nullptr;
+#define G2_FIND2(J, P) hipLaunchKernelGGL((k_find2<STATS, REFILL, J, true, P>), dim3(grid), dim3(TPB2), 0, st, \
+                                          ix->img, d_patterns, d_offsets, nq, d_ranges, d_stats, perm, queue)
+  if(jump && pair) { G2_FIND2(true, true); }
+  else if(jump) { G2_FIND2(true, false); }
+  else if(pair) { G2_FIND2(false, true); }
+  else { G2_FIND2(false, false); }
+#undef G2_FIND2
+}
+
+}  // namespace
+
+extern "C" {
+
 int gcsa2_find_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets,
                       uint64_t nq, uint64_t* d_ranges, void* stream)
 {
   CHECK_INDEX(ix);
   DeviceGuard guard(ix->device);          // the launch goes to the index's device whatever the caller's current one is
   if(nq == 0) { return GCSA2_OK; }
-  if(ix->img.jump_tab != nullptr)
-  {
-    hipLaunchKernelGGL((k_find2<false, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
-                       ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr, (unsigned long long*)nullptr);
-    LAUNCH_CHECK("k_find2<jump>");
-    return GCSA2_OK;
-  }
-  hipLaunchKernelGGL((k_find2<false, false>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
-                     ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr, (unsigned long long*)nullptr);
+  launch_find2<false, false>(ix, unsigned((nq + TPB2 - 1) / TPB2), static_cast<hipStream_t>(stream), d_patterns, d_offsets, nq, d_ranges,
+                             nullptr, nullptr, nullptr);
   LAUNCH_CHECK("k_find2");
   return GCSA2_OK;
 }
@@ -654,16 +701,7 @@ int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t*
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, len_in, len_out, idx_in, idx_out, int(nq), 0, 32, st);
     if(e == hipSuccess)
     {
-      if(ix->img.jump_tab != nullptr)
-      {
-        hipLaunchKernelGGL((k_find2<false, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
-                           ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)idx_out, (unsigned long long*)nullptr);
-      }
-      else
-      {
-        hipLaunchKernelGGL((k_find2<false, false>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
-                           ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)idx_out, (unsigned long long*)nullptr);
-      }
+      launch_find2<false, false>(ix, unsigned((nq + TPB2 - 1) / TPB2), st, d_patterns, d_offsets, nq, d_ranges, nullptr, idx_out, nullptr);
       e = hipGetLastError();
     }
     (void)hipFreeAsync(tmp, st); (void)hipFreeAsync(len_in, st);    // stream-ordered: freed after the kernel
@@ -679,8 +717,7 @@ int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t*
     HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), st));
     u64 resident = u64(ix->compute_units) * 9;                    // workgroups the LDS footprint lets a CU hold
     u64 wanted = (nq + TPB2 - 1) / TPB2;
-    hipLaunchKernelGGL((k_find2<false, true>), dim3(unsigned(wanted < resident ? wanted : resident)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr, queue);
+    launch_find2<false, true>(ix, unsigned(wanted < resident ? wanted : resident), st, d_patterns, d_offsets, nq, d_ranges, nullptr, nullptr, queue);
     hipError_t e = hipGetLastError();
     (void)hipFreeAsync(queue, st);
     if(e != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_find2<refill>: ") + hipGetErrorString(e)); }
@@ -702,19 +739,13 @@ int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, co
   if(d_stats == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null stats buffer"); }
   if(nq == 0) { return GCSA2_OK; }
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64 atomics");
-  if(ix->img.jump_tab != nullptr)
-  {
-    hipLaunchKernelGGL((k_find2<true, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
-                       ix->img, d_patterns, d_offsets, nq, d_ranges, reinterpret_cast<unsigned long long*>(d_stats), (const u32*)nullptr, (unsigned long long*)nullptr);
-    LAUNCH_CHECK("k_find2<stats, jump>");
-    return GCSA2_OK;
-  }
-  hipLaunchKernelGGL((k_find2<true, false>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, static_cast<hipStream_t>(stream),
-                     ix->img, d_patterns, d_offsets, nq, d_ranges, reinterpret_cast<unsigned long long*>(d_stats), (const u32*)nullptr, (unsigned long long*)nullptr);
+  launch_find2<true, false>(ix, unsigned((nq + TPB2 - 1) / TPB2), static_cast<hipStream_t>(stream), d_patterns, d_offsets, nq, d_ranges,
+                            reinterpret_cast<unsigned long long*>(d_stats), nullptr, nullptr);
   LAUNCH_CHECK("k_find2<stats>");
   return GCSA2_OK;
 }
 
+uint64_t gcsa2_pair_block_bytes(const gcsa2_index* ix) { return ix->img.flp != nullptr ? 16 * ix->img.flp_nblocks * FLB_BYTES : 0; }
 uint64_t gcsa2_find_block_bytes(const gcsa2_index*) { return FLB_BYTES; }
 uint64_t gcsa2_kmer_table_k(const gcsa2_index* ix) { return ix->img.kmer_k; }
 uint64_t gcsa2_jump_table_bytes(const gcsa2_index* ix) { return ix->img.jump_tab != nullptr ? ix->img.n * sizeof(ulonglong2) : 0; }

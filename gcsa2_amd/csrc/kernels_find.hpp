@@ -130,6 +130,40 @@ __device__ __forceinline__ void eval_endpoint(const ulonglong2 (&blk)[8], u32 r,
   node = ncnt + cnt;
 }
 
+// lane-private evaluation of one endpoint of a TWO-character step from a staged FLP128 block (layout.hpp):
+//   raw = H(i) = ecnt + rank(P, r);  sp side (ep_side = false): node = N(raw)
+//   ep side: edge b'' = raw - 1 + D[r], node = N(b'')
+__device__ __forceinline__ void eval_pair(const ulonglong2 (&blk)[8], u32 r, bool ep_side, u64& raw, u64& node)
+{
+  const u64 w[16] = { blk[0].x, blk[0].y, blk[1].x, blk[1].y, blk[2].x, blk[2].y, blk[3].x, blk[3].y,
+                      blk[4].x, blk[4].y, blk[5].x, blk[5].y, blk[6].x, blk[6].y, blk[7].x, blk[7].y };
+  const u32 wq = r >> 6;
+  const u64 part = (u64(1) << (r & 63)) - 1;
+  u32 ones = 0;
+  u64 dword = w[6];
+#pragma unroll
+  for(u32 j = 0; j < 4; j++)
+  {
+    u64 m = (j < wq ? ~u64(0) : (j == wq ? part : u64(0)));
+    ones += __popcll(w[2 + j] & m);
+    if(j == wq) { dword = w[6 + j]; }
+  }
+  raw = w[0] + ones;
+  const u64 ncnt = w[1] & ~PREV_BIT;
+  const u32 back = (ep_side ? 1u - u32((dword >> (r & 63)) & 1) : 0u);
+  if(back > ones) { node = ncnt - (w[1] >> 63); return; }    // rank(edges, ecnt - 1)
+  const u32 k = ones - back, kq = k >> 6;
+  const u64 kpart = (u64(1) << (k & 63)) - 1;
+  u32 cnt = 0;
+#pragma unroll
+  for(u32 j = 0; j < 6; j++)
+  {
+    u64 m = (j < kq ? ~u64(0) : (j == kq ? kpart : u64(0)));
+    cnt += __popcll(w[10 + j] & m);
+  }
+  node = ncnt + cnt;
+}
+
 // One lane evaluates LF(range, comp) from the fused blocks on its own (no cooperation): used where
 // lanes run independently (matching statistics).  Returns the edge-space pair (a, b) and, when it is
 // not empty, the node-space range.  One 128-byte block per endpoint instead of two dependent
@@ -199,8 +233,11 @@ __device__ __forceinline__ void lf_children(const DevImage& img, u32 c0, u32 lim
   }
 }
 
-// wave-cooperative fetch: every lane with need != 0 gets flb block `idx` staged at its slot
-__device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane)
+// wave-cooperative fetch: every lane with need != 0 gets flb block `idx` staged at its slot; with PAIR an
+// index carrying PAIR_FLAG selects block idx & ~PAIR_FLAG of the pair array `flp` instead
+template<bool PAIR = false>
+__device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane,
+                                             const u64* __restrict__ flp = nullptr)
 {
   u32 sub = lane & 7;
 #pragma unroll
@@ -211,7 +248,9 @@ __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 id
     // whose owner needs nothing fetch block 0 (one cached line) into a slot nobody reads.
     u32 owner = 8 * j + (lane >> 3);
     u32 oidx = __shfl(need ? idx : 0u, owner, 64);
-    ulonglong2 a = reinterpret_cast<const ulonglong2*>(flb + u64(oidx) * FLB_WORDS)[sub];
+    const u64* base = flb;
+    if constexpr(PAIR) { base = (oidx & PAIR_FLAG) ? flp : flb; oidx &= ~PAIR_FLAG; }
+    ulonglong2 a = reinterpret_cast<const ulonglong2*>(base + u64(oidx) * FLB_WORDS)[sub];
     wave_stage[owner * 8 + (sub ^ (owner & 7))] = a;
   }
   __builtin_amdgcn_wave_barrier();
@@ -246,7 +285,10 @@ __device__ __forceinline__ ulonglong2 jt_make(u64 end, u64 after4, u64 after2, u
   return make_ulonglong2(end | (after4 << 36), (after4 >> 28) | (after2 << 8) | (u64(labels) << 44) | (u64(len) << 60));
 }
 
-template<bool STATS, bool REFILL, bool JUMP = false, bool WINDOW = true>
+// PAIR = true: two characters per step through the FLP128 pair blocks whenever the next two pattern
+// characters are fast characters; a pair that does not prove both steps non-empty is replayed as two
+// single steps (`force_single`), so every returned range is the one the single-step search returns.
+template<bool STATS, bool REFILL, bool JUMP = false, bool WINDOW = true, bool PAIR = false>
 __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restrict__ patterns,
                                                const u64* __restrict__ offsets, u64 nq,
                                                u64* __restrict__ out, unsigned long long* __restrict__ stats,
@@ -270,6 +312,8 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
   [[maybe_unused]] bool no_jump = false;   // JUMP: no entry can apply for the rest of this pattern
   [[maybe_unused]] u64 win_top = ~u64(0), win_code = 0;      // JUMP: packed pattern window (see below)
   [[maybe_unused]] u64 win_bad = 0;
+  [[maybe_unused]] u32 force_single = 0;   // PAIR: characters that must be consumed by single steps (replay)
+  static_assert(!PAIR || WINDOW, "pair steps read the packed pattern window");
   u64 word = 0, word_addr = ~u64(0);        // pattern bytes are consumed back to front from aligned 8-byte words
   auto byte_at = [&](u64 pos) -> u32
   {
@@ -280,6 +324,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
   auto start = [&](u64 query)               // begin the backward search of `query` (< nq)
   {
     q = query; sp = 0; ep = img.n - 1; i = 0; done = true; word_addr = ~u64(0); tried = false; no_jump = false; win_top = ~u64(0);
+    force_single = 0;
     u64 begin = offsets[q], len = offsets[q + 1] - begin;
     if(len > 0 && img.n > 0)                                   // gcsa.h:99
     {
@@ -398,47 +443,93 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     }
     const bool stepping = !done && !jumping;
     u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
+    bool pair = false;
     if(stepping)
     {
-      i--;
-      if constexpr(WINDOW)
+      if constexpr(PAIR)
       {
-        const u32 r = u32(win_top - 1 - i);
-        comp = ((win_bad >> (2 * r)) & 1) ? u32(t.c2c[byte_at(i)]) : 1 + (u32(win_code >> (2 * r)) & 3);
+        if(force_single == 0 && i >= 2)
+        {
+          const u32 r = u32(win_top - i);                      // window slot of position i - 1; i - 2 is slot r + 1
+          pair = ((win_bad >> (2 * r)) & 5) == 0;              // both are fast characters
+          if(pair)
+          {
+            const u32 c2 = u32(win_code >> (2 * r)) & 3, c1 = u32(win_code >> (2 * r + 2)) & 3;
+            const u64 b_sp = sp / PAIR_BITS, b_ep = (ep + 1) / PAIR_BITS;
+            r_sp = u32(sp - b_sp * PAIR_BITS); r_ep = u32(ep + 1 - b_ep * PAIR_BITS);
+            const u64 first = u64(c1 * 4 + c2) * img.flp_nblocks;
+            idx_sp = u32(first + b_sp) | PAIR_FLAG; idx_ep = u32(first + b_ep) | PAIR_FLAG;
+          }
+        }
       }
-      else { comp = t.c2c[byte_at(i)]; }
-      u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
-      r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
-      idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
+      if(!pair)
+      {
+        i--;
+        if constexpr(PAIR) { force_single -= (force_single > 0 ? 1 : 0); }
+        if constexpr(WINDOW)
+        {
+          const u32 r = u32(win_top - 1 - i);
+          comp = ((win_bad >> (2 * r)) & 1) ? u32(t.c2c[byte_at(i)]) : 1 + (u32(win_code >> (2 * r)) & 3);
+        }
+        else { comp = t.c2c[byte_at(i)]; }
+        u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
+        r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
+        idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
+      }
     }
     u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
     const bool need2 = stepping && idx_ep != idx_sp;
-    if(STATS && stepping) { steps++; blocks += 1 + (need2 ? 1 : 0); }
+    if(STATS && stepping) { blocks += 1 + (need2 ? 1 : 0); }
     ulonglong2 blk[8];
-    fetch_blocks(img.flb, idx_sp, stepping, wave_stage, lane);
+    fetch_blocks<PAIR>(img.flb, idx_sp, stepping, wave_stage, lane, img.flp);
     if(stepping)
     {
       read_block(wave_stage, lane, blk);
-      eval_endpoint(blk, r_sp, 0, e_sp, n_sp);                 // gcsa.h:271, then rank(edges, sp')
-      if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
+      if(PAIR && pair)
+      {
+        eval_pair(blk, r_sp, false, e_sp, n_sp);
+        if(idx_ep == idx_sp) { eval_pair(blk, r_ep, true, e_ep, n_ep); }
+      }
+      else
+      {
+        eval_endpoint(blk, r_sp, 0, e_sp, n_sp);               // gcsa.h:271, then rank(edges, sp')
+        if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
+      }
     }
     if(__any(need2))
     {
       __builtin_amdgcn_wave_barrier();
-      fetch_blocks(img.flb, idx_ep, need2, wave_stage, lane);
+      fetch_blocks<PAIR>(img.flb, idx_ep, need2, wave_stage, lane, img.flp);
       if(need2)
       {
         read_block(wave_stage, lane, blk);
-        eval_endpoint(blk, r_ep, 1, e_ep, n_ep);               // gcsa.h:272: LF(ep + 1) - 1
+        if(PAIR && pair) { eval_pair(blk, r_ep, true, e_ep, n_ep); }
+        else { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }      // gcsa.h:272: LF(ep + 1) - 1
       }
     }
     __builtin_amdgcn_wave_barrier();
     if(stepping)
     {
-      u64 a = e_sp, b = e_ep - 1;                              // edge space
-      if(range_empty(a, b)) { sp = a; ep = b; done = true; }   // gcsa.h:160
-      else { sp = n_sp; ep = n_ep; done = (i == 0); }          // gcsa.h:161, 103
-      if constexpr(JUMP) { tried = false; }
+      if(PAIR && pair)
+      {
+        // e_sp = H(sp), e_ep = H(ep + 1).  H(ep + 1) > H(sp) proves that neither of the two steps empties;
+        // anything else is replayed as two single steps from the unchanged (sp, ep).
+        if(e_ep > e_sp)
+        {
+          sp = n_sp; ep = n_ep; i -= 2; done = (i == 0);
+          if(STATS) { steps += 2; }
+          if constexpr(JUMP) { tried = false; }
+        }
+        else { force_single = 2; }
+      }
+      else
+      {
+        if(STATS) { steps++; }
+        u64 a = e_sp, b = e_ep - 1;                            // edge space
+        if(range_empty(a, b)) { sp = a; ep = b; done = true; } // gcsa.h:160
+        else { sp = n_sp; ep = n_ep; done = (i == 0); }        // gcsa.h:161, 103
+        if constexpr(JUMP) { tried = false; }
+      }
     }
     if constexpr(JUMP)
     {
@@ -481,6 +572,50 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps);
       atomicAdd(stats + 2, (unsigned long long)lookups);
     }
+  }
+}
+
+// ---- FLP128 pair blocks (layout.hpp), built on the device from the RB64 vectors -----------------------
+// grid (nblocks, 4): workgroup (b, c2 - 1) of 256 threads writes block b of the four pairs (c1, c2),
+// c1 = 1..4; thread r owns position i = 256 b + r.
+__global__ __launch_bounds__(256) void k_build_pair_blocks(DevImage img, u64* __restrict__ out)
+{
+  __shared__ u64 s_ecnt[4];
+  const u64 b = blockIdx.x, nb = img.flp_nblocks;
+  const u32 c2 = 1 + blockIdx.y, r = threadIdx.x;
+  const u64 i = b * PAIR_BITS + r, n = img.n, e = img.e;
+  const bool valid = i <= n;
+  u64 rk = 0;
+  const bool q = bv_get_rank(bwt_of(img, c2), valid ? (i < n ? i : n) : 0, rk) && i < n;
+  const u64 x = img.C[c2] + rk;                                // E_c2(i)
+  u64 u = 0;
+  const bool ebit = bv_get_rank(img.edges, clampu(x, e), u) && x < e;      // edges[x], u = N(x)
+  const bool split = (x >= 1 && x - 1 < e) && !bv_get(img.edges, x - 1);   // position i splits the out-edges of node u
+#pragma unroll
+  for(u32 c1 = 1; c1 <= 4; c1++)
+  {
+    u64 rc = 0;
+    const bool bc = bv_get_rank(bwt_of(img, c1), clampu(u, n), rc) && u < n;
+    const u64 pw = __ballot(valid && q && ebit && bc), dw = __ballot(valid && split && bc);
+    u64* dst = out + (u64((c1 - 1) * 4 + (c2 - 1)) * nb + b) * FLB_WORDS;
+    if((r & 63) == 0) { dst[2 + (r >> 6)] = pw; dst[6 + (r >> 6)] = dw; }
+    if(r == 0)
+    {
+      const u64 ecnt = img.C[c1] + rc;                         // H(256 b)
+      u64 ncnt = 0;
+      const bool at = bv_get_rank(img.edges, clampu(ecnt, e), ncnt);
+      (void)at;
+      const u64 prev = (ecnt >= 1 && ecnt - 1 < e && bv_get(img.edges, ecnt - 1)) ? PREV_BIT : 0;
+      dst[0] = ecnt; dst[1] = ncnt | prev;
+      s_ecnt[c1 - 1] = ecnt;
+    }
+  }
+  __syncthreads();
+  if(r < 24)
+  {
+    const u32 c1 = 1 + r / 6, k = r % 6;
+    u64* dst = out + (u64((c1 - 1) * 4 + (c2 - 1)) * nb + b) * FLB_WORDS;
+    dst[10 + k] = bv_bits64(img.edges, s_ecnt[c1 - 1] + 64 * k);
   }
 }
 

@@ -29,6 +29,28 @@
 // costs the same as a 64-byte one.  Blocks are fetched cooperatively: 8 adjacent lanes load the
 // 8 x 16 bytes of one block in a single line-coalesced instruction and stage it in LDS.
 //
+// Two characters per step, "FLP128": for every ordered pair (c1, c2) of fast characters (c2 is consumed
+// first by the backward search, then c1) the composition of two LF steps is itself a rank structure.
+// With E_c(i) = C[c] + rank(B_c, i) and N(x) = rank(edges, x):
+//
+//   H(i)  = E_c1(N(E_c2(i)))                 is monotone with increments of 0 or 1, so H(i) = H(0) + rank(P, i),
+//           P[i] = B_c2[i] & edges[x] & B_c1[N(x)],  x = E_c2(i)
+//   sp''  = N(H(sp))                                                  (gcsa.h:271, 161 applied twice)
+//   ep''  = N(H(ep + 1) - 1 + D[ep + 1]),  D[j] = !edges[x - 1] & B_c1[N(x)],  x = E_c2(j)
+//           (D = 1: position j splits the out-edges of one node, which both sides then lead back to)
+//
+//   block b of pair (c1, c2) (16 x u64 = 128 bytes; 256 positions)
+//     word 0        ecnt = H(256 b)
+//     word 1        ncnt = rank(edges, ecnt), bit 63 = edges[ecnt - 1]
+//     words 2..5    P bits [256 b, 256 (b + 1))
+//     words 6..9    D bits of the same positions
+//     words 10..15  edges bits [ecnt, ecnt + 384)
+//
+// so TWO pattern characters cost ONE 128-byte request per endpoint.  The fused pair is used only when it
+// proves that both steps are non-empty (H(ep + 1) > H(sp)); otherwise the two steps are replayed one at a
+// time from the FLB128 blocks, which also yields the edge-space integers the reference returns for a range
+// that empties inside LF (gcsa.h:160).  Results are therefore unchanged.
+//
 // select_1 uses one u32 hint per 448 ones (block holding the (448 j + 1)-th one) followed by a
 // short binary search over block counters and an in-block scan.
 #pragma once
@@ -50,6 +72,8 @@ constexpr u64 SELECT_SAMPLE = 448;
 constexpr u64 FLB_WORDS     = 16;
 constexpr u64 FLB_BYTES     = 128;
 constexpr u64 PREV_BIT      = u64(1) << 63;
+constexpr u64 PAIR_BITS     = 256;           // positions per FLP128 block
+constexpr u32 PAIR_FLAG     = u32(1) << 31;  // block index refers to the FLP128 array
 constexpr int MAX_SIGMA     = 16;
 constexpr int MAX_LCP_LEVELS = 16;
 
@@ -69,6 +93,8 @@ struct DevImage
   DevBV edges;
   const u64* flb;       // fused LF blocks: comp c, block b at flb + (c * flb_nblocks + b) * 16
   u64 flb_nblocks;      // per comp = n / 448 + 1
+  const u64* flp;       // fused pair blocks or nullptr: pair (c1, c2), block b at flp + (((c1 - 1) * 4 + c2 - 1) * flp_nblocks + b) * 16
+  u64 flp_nblocks;      // per pair = n / 256 + 1
   u64 crange[2 * MAX_SIGMA];   // charRange(c) in node space, precomputed (gcsa.h:150-153)
   const u64* pred4;            // 4 bits per path node: bits 0-2 = comp of the first incoming edge
                                // (gcsa.h:165-183 probe order), bit 3 = sampled(node); nullptr if sigma > 8
@@ -207,6 +233,16 @@ __device__ __forceinline__ u64 bv_select(const DevBV& bv, u64 r)
 #pragma unroll
   for(u32 j = 1; j < 7; j++) { if(word == j) { w = b.w[j + 1]; } }
   return pos + (u64(word) << 6) + select_in_word(w, rem);
+}
+
+// 64 bits of the vector starting at bit `pos` (zero past the last block)
+__device__ __forceinline__ u64 bv_bits64(const DevBV& bv, u64 pos)
+{
+  const u64 w = pos >> 6, s = pos & 63, total = bv.nblocks * PAYLOAD_WORDS;
+  const u64 lo = (w < total ? bv.blocks[(w / PAYLOAD_WORDS) * BLOCK_WORDS + 1 + w % PAYLOAD_WORDS] : 0);
+  if(s == 0) { return lo; }
+  const u64 hi = (w + 1 < total ? bv.blocks[((w + 1) / PAYLOAD_WORDS) * BLOCK_WORDS + 1 + (w + 1) % PAYLOAD_WORDS] : 0);
+  return (lo >> s) | (hi << (64 - s));
 }
 
 __device__ __forceinline__ u64 packed_get(const u64* words, u64 width, u64 i)

@@ -621,3 +621,61 @@ def test_arbitrary_bytes(engine, monkeypatch):
     for jump in ("0", "1"):
         monkeypatch.setenv("GCSA2_JUMP_TABLE", jump)
         assert np.array_equal(engine.GCSA(ix).find_batch(data, off), want), jump
+
+
+def test_pair_blocks(engine, monkeypatch):
+    """find() through the two-characters-per-step blocks (default) equals find() with GCSA2_PAIR_BLOCKS=0 and
+    the oracle: SNP bubbles (pairs whose first step takes a non-last out-edge are replayed), cycles, misses at
+    every depth (edge-space empty ranges of gcsa.h:160), Ns between fast characters, odd and even lengths,
+    with and without seed / jump tables, and through the instrumented and length-bucketed launches."""
+    import torch
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    rng = SplitMix64(0x3C0)
+    for case, g in enumerate((graphs.snp_graph(20000, 0x3C1, 0x3C2, snp_period=7, node_len=16),
+                              graphs.linear_graph(3000, 0x3C3, node_len=8),
+                              graphs.random_graph(80, 0x3C4, p_branch=0.25, p_back=0.08, p_n=0.05))):
+        ix = builder.build(g, 16) if case < 2 else build(g, 5)
+        cpu = OracleIndex(ix)
+        pats = [truncate_at_sink(p) for p in random_patterns(g, 40, 0x3C5 + case, 3000)]
+        pats += [p[: 1 + q % 9] for q, p in enumerate(pats[:400])]
+        for p in list(pats[:800]):
+            if len(p) > 2:
+                k = rng.below(len(p))
+                pats.append(p[:k] + bytes([b"ACGTN"[rng.below(5)]]) + p[k + 1:])
+        data, off = concat_patterns(pats)
+        want = cpu.find_batch(data, off)
+        for kmer, jump in (("0", "0"), ("3", "0"), (None, "1")):
+            monkeypatch.setenv("GCSA2_JUMP_TABLE", jump)
+            if kmer is None:
+                monkeypatch.delenv("GCSA2_KMER_TABLE", raising=False)
+            else:
+                monkeypatch.setenv("GCSA2_KMER_TABLE", kmer)
+            monkeypatch.setenv("GCSA2_PAIR_BLOCKS", "0")
+            plain = engine.GCSA(ix, with_samples=False, with_counters=False, with_lcp=False)
+            monkeypatch.delenv("GCSA2_PAIR_BLOCKS")
+            gpu = engine.GCSA(ix, with_samples=False, with_counters=False, with_lcp=False)
+            assert plain.pair_block_bytes() == 0
+            assert gpu.pair_block_bytes() == 16 * (ix.n // 256 + 1) * 128
+            assert np.array_equal(plain.find_batch(data, off), want), (case, kmer, jump)
+            assert np.array_equal(gpu.find_batch(data, off), want), (case, kmer, jump)
+            dev = torch.device("cuda", 0)
+            d_pat = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+            d_off = torch.from_numpy(off.view(np.int64).copy()).to(dev)
+            d_out = torch.zeros((len(pats), 2), dtype=torch.int64, device=dev)
+            stats = []
+            for g_ in (plain, gpu):
+                d_stats = torch.zeros(3, dtype=torch.int64, device=dev)
+                g_.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), d_stats.data_ptr(), 0)
+                torch.cuda.synchronize()
+                assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), (case, kmer, jump)
+                stats.append([int(x) for x in d_stats.cpu()])
+            assert stats[0][1] == stats[1][1]                      # the same LF steps ...
+            if jump == "0":
+                assert stats[1][0] < 0.75 * stats[0][0]            # ... through far fewer blocks
+            for variant in (4, 5):
+                d_out.zero_()
+                gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), 0)
+                torch.cuda.synchronize()
+                assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), (case, kmer, jump, variant)
+    monkeypatch.delenv("GCSA2_JUMP_TABLE")
