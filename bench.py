@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the GCSA2 query hot path on MI355X: batched k-mer find().
 
-One step = one pass of the hot path (`gcsa2_find_device`, kernel k_find2) over one batch of
-synthetic patterns that already sit in HBM; with N > 1 every rank holds a replica of the index,
-searches its own shard (weak scaling) and the hit ranges are gathered on rank 0 with one RCCL
-gather per step.  Prints ONE JSON line on rank 0 (contract: task statement / DESIGN.md section 5).
+Default workload = BASELINE.json configs[3], the configuration the metric is
+quoted on: a whole-human-footprint index (4.29 G path nodes; degree-32 m-sequence text, every answer
+known in closed form), replicated on every GPU, ONE batch of 100 M 32-mers sharded contiguously over
+the N ranks (strong scaling), hit ranges gathered in the root's HBM by the library's single RCCL
+gather (gcsa2_comm_gather: grouped ncclSend / ncclRecv over xGMI).  One step = one pass of the hot
+path (gcsa2_find_device, kernel k_find2) over the rank's shard, inputs resident in HBM, + that gather.
+Prints ONE JSON line on rank 0 (contract: task statement / DESIGN.md section 5).
 
-Primary workload (BASELINE.json configs[1]): "chr22-like" seeded
-SNP-bubble graph, 2^25 backbone bases, one SNP per 32 bp, order-256 maximally pruned de Bruijn graph
-(51 M path nodes), 10 M 32-mers per GPU drawn as random walks through the graph (set S: full-depth
-matches).  Its fused blocks (102 MB) fit the 256 MiB Infinity Cache, so at N = 1 the run also
-measures an HBM-resident index (linear graph, 2^30 bases, 2.1 GB of fused blocks) and reports it
-under "hbm_resident" -- that is where the HBM roofline fraction is meaningful.
+At N = 1 the same run also measures, as secondary objects of that line (never part of `value`):
+  config5  BASELINE configs[4]: 1 M 256-bp patterns on the same index, half of them with a substitution
+           every 41 bp: find() with parent() on failure (fused matching statistics), then locate()
+  chr22    BASELINE configs[1] and [2]: 10 M 32-mer find() and locate() on the chr22-like SNP graph
+
+`--workload chr22 | linear` run those indexes as the primary workload (10 M queries per GPU, weak
+scaling), for the profiles under profiles/.
 """
 import argparse
 import json
@@ -24,9 +28,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
-REQUEST_CEILING_GPS = 58.0   # dependent random 128-byte fetches/s measured by gcsa2_amd/lib/gather_bench (profiles/r01_gather_bench.md)
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+REQUEST_CEILING_GPS = 50.0       # dependent random 128-byte fetches/s at HBM footprints (gather_bench, profiles/r01_gather_bench.md)
 LINEAR_SEED = 0x6C5A0040
+HUMAN_PATTERN_SEED = 0x6C5A0041
+CONFIG5_SEED = 0x6C5A0050
 
 
 def log(msg):
@@ -37,27 +43,29 @@ def log(msg):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["snp", "linear"], default="snp",
-                    help="snp: chr22-like SNP-bubble graph (config 2, Infinity-Cache resident); "
-                         "linear: footprint-scale linear graph = FM-index built on the GPU (HBM resident)")
-    ap.add_argument("--log2-bases", type=int, default=0, help="backbone length (default 25 for snp, 30 for linear)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["human", "chr22", "linear"], default="human",
+                    help="human: whole-human-footprint index, one batch sharded over the GPUs (config 4); "
+                         "chr22: chr22-like SNP-bubble graph (config 2); linear: 2^30-base linear graph built on the GPU")
+    ap.add_argument("--degree", type=int, default=32, help="human: degree of the m-sequence (path nodes = 2^degree - 1)")
+    ap.add_argument("--log2-bases", type=int, default=0, help="chr22 / linear: backbone length (default 25 / 30)")
     ap.add_argument("--order", type=int, default=256)
-    ap.add_argument("--queries", type=int, default=10_000_000, help="patterns per GPU per step")
+    ap.add_argument("--queries", type=int, default=0,
+                    help="human: patterns in the whole batch (default 100 M); chr22 / linear: patterns per GPU (default 10 M)")
     ap.add_argument("--pattern-len", type=int, default=32)
-    ap.add_argument("--set", choices=["S", "U"], default="S")
+    ap.add_argument("--set", choices=["S", "U"], default="S", help="S: patterns that occur (full-depth matches); U: uniform random")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-hbm-resident", action="store_true", help="skip the secondary HBM-resident measurement")
-    ap.add_argument("--no-jump-table", action="store_true", help="skip the secondary measurement with GCSA2_JUMP_TABLE=1")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the config-5 and chr22 measurements")
     ap.add_argument("--variant", type=int, default=2, help="find kernel generation (1 = k_find, 2 = k_find2)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
 
 
 class Dist:
-    """torch.distributed plumbing; a no-op when not launched by torch.distributed.run."""
+    """torch.distributed for the launch contract (rendezvous, barrier, max over ranks); the data-path gather
+    is the library's own RCCL communicator (gcsa2_comm_*), created from an id broadcast through torch."""
 
     def __init__(self, dev):
         import torch.distributed as dist
@@ -68,6 +76,8 @@ class Dist:
         # GCSA2_BENCH_BACKEND=gloo is a control-flow check for boxes with fewer GPUs than ranks (the gather
         # then goes through host memory and ranks may share a device); the measured configuration is nccl.
         self.backend = os.environ.get("GCSA2_BENCH_BACKEND", "nccl")
+        self.comm = None
+        self.dev = dev
         if self.active:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.backend == "nccl":
@@ -75,33 +85,151 @@ class Dist:
             else:
                 dist.init_process_group(backend=self.backend)
 
+    def make_comm(self, binding, device_index):
+        import torch
+        if not self.active or self.backend != "nccl":
+            return
+        uid = torch.zeros(binding.Comm.ID_BYTES, dtype=torch.uint8, device=self.dev)
+        if self.rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(binding.Comm.unique_id()), dtype=torch.uint8))
+        self.dist.broadcast(uid, 0)
+        self.comm = binding.Comm(uid.cpu().numpy().tobytes(), self.rank, self.world, device_index)
+
     def barrier(self):
         if self.active:
             self.dist.barrier()
 
-    def gather(self, tensor, parts):
-        """Asynchronous gather on rank 0; returns the work handle (None when not distributed)."""
-        if self.active and self.backend != "nccl":
-            host = [p.cpu() for p in parts] if self.rank == 0 else None
-            self.dist.gather(tensor.cpu(), host, dst=0)
-            if self.rank == 0:
-                for p, h in zip(parts, host):
-                    p.copy_(h)
-            return None
-        if self.active:
-            return self.dist.gather(tensor, parts if self.rank == 0 else None, dst=0, async_op=True)
-        return None
-
-    def max(self, value, dev):
+    def _reduce(self, value, op):
         import torch
-        t = torch.tensor([value], dtype=torch.float64, device=dev if self.backend == "nccl" else "cpu")
+        t = torch.tensor([value], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
         if self.active:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            self.dist.all_reduce(t, op=op)
         return float(t.item())
 
+    def max(self, value):
+        return self._reduce(value, self.dist.ReduceOp.MAX)
+
+    def all_true(self, flag):
+        return self._reduce(1.0 if flag else 0.0, self.dist.ReduceOp.MIN) > 0.5
+
     def close(self):
+        if self.comm is not None:
+            self.comm.close()
         if self.active:
             self.dist.destroy_process_group()
+
+
+def shard_bounds(n_queries, world):
+    from gcsa2_amd.shard import shard_bounds as sb
+    return sb(n_queries, world)
+
+
+# ---- workloads -------------------------------------------------------------------------------------------
+
+class Workload:
+    """One rank's view: the index image on its GPU, its shard of the batch in HBM, and how to check results."""
+
+    def __init__(self):
+        self.label = ""
+        self.scaling = "weak"
+        self.gpu = None
+        self.ix = None
+        self.d_pat = None
+        self.d_off = None
+        self.nq = 0
+        self.m = 0
+        self.total_queries = 0
+        self.first = 0                      # global id of the shard's first query
+        self.verify = lambda d_ranges, first, count: None     # True / False / None (no closed form)
+
+
+def padded_bytes(t):
+    """Flat uint8 copy with 8 spare bytes (the find kernels read patterns as aligned 8-byte words)."""
+    import torch
+    flat = torch.zeros(t.numel() + 8, dtype=torch.uint8, device=t.device)
+    flat[: t.numel()] = t.reshape(-1)
+    return flat
+
+
+def uniform_patterns_device(first, count, m, seed, dev):
+    """Set U on the device: 2 bits per character from SplitMix64(seed), ceil(m / 32) words per query."""
+    import torch
+    from workload import mseq_torch
+    words = (m + 31) // 32
+    r = mseq_torch.splitmix64_range_torch(seed, first * words, count * words, dev).view(count, words)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    out = torch.empty((count, m), dtype=torch.uint8, device=dev)
+    for i in range(m):
+        out[:, i] = lut[(r[:, i // 32] >> (2 * (i % 32))) & 3]
+    return out
+
+
+def host_memory_ok(bytes_needed):
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) * 1024 >= bytes_needed
+    except OSError:
+        pass
+    return True
+
+
+def setup_human(args, D, dev, local_rank):
+    import torch
+    from workload import mseq_torch
+    from gcsa2_amd.binding import GCSA
+    wl = Workload()
+    wl.scaling = "strong"
+    degree = args.degree
+    # every rank stages its own replica: ~12 bytes of host memory per path node while it does
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", D.world))
+    while degree > 24 and not host_memory_ok(local_world * 12 * (1 << degree)):
+        degree -= 2
+    if degree != args.degree:
+        log(f"warning: host memory too small for {local_world} replicas of degree {args.degree}; using degree {degree}")
+    full = (D.world == 1 and not args.no_secondary)
+    t = time.time()
+    ix, sym_t, rank = mseq_torch.build_mseq(degree, device=dev, verbose=log, full=full)
+    rank_t = torch.from_numpy(rank.view(np.int32)).to(dev)          # rank of every rotation: the closed-form answers
+    del rank
+    log(f"index arrays: n = {ix.n} ({time.time() - t:.1f} s)")
+    t = time.time()
+    wl.gpu = GCSA(ix, device=local_rank, with_samples=full, with_counters=full, with_lcp=full)
+    log(f"device image: {wl.gpu.device_bytes() / 1e9:.2f} GB in HBM, seed table k = {wl.gpu.kmer_table_k()}, "
+        f"pair blocks {wl.gpu.pair_block_bytes() / 1e9:.2f} GB ({time.time() - t:.1f} s)")
+    wl.ix, wl.sym_t, wl.rank_t, wl.full, wl.degree = ix, sym_t, rank_t, full, degree
+    wl.total_queries = args.queries or 100_000_000
+    wl.m = args.pattern_len
+    b, e = shard_bounds(wl.total_queries, D.world)[D.rank]
+    wl.first, wl.nq = b, e - b
+    t = time.time()
+    if args.set == "S":
+        pats, _ = mseq_torch.substring_patterns_device(sym_t, b, e - b, wl.m, HUMAN_PATTERN_SEED)
+    else:
+        pats = uniform_patterns_device(b, e - b, wl.m, HUMAN_PATTERN_SEED, dev)
+    wl.d_pat = padded_bytes(pats)
+    del pats
+    wl.d_off = torch.arange(wl.nq + 1, dtype=torch.int64, device=dev) * wl.m
+    log(f"patterns: shard [{b}, {e}) of {wl.total_queries} x {wl.m}, set {args.set} ({time.time() - t:.1f} s)")
+    wl.label = (f"whole-human-footprint index (degree-{degree} m-sequence text, {ix.n} path nodes), one batch of "
+                f"{wl.total_queries} x {wl.m}-mer find() sharded over {D.world} GPU(s), pattern set {args.set}")
+
+    def verify(d_ranges, first, count):
+        if args.set != "S" or wl.m < degree // 2:
+            return None
+        # find(T[p .. p + m)) = (rank[p], rank[p]): every degree/2-mer occurs exactly once in the cyclic text
+        ok = True
+        chunk = 1 << 25
+        for c in range(0, count, chunk):
+            n = min(chunk, count - c)
+            start = mseq_torch._lsr(mseq_torch.splitmix64_range_torch(HUMAN_PATTERN_SEED, first + c, n, dev), 11) % ix.n
+            exp = rank_t[start].to(torch.int64) & 0xFFFFFFFF
+            got = d_ranges[c:c + n]
+            ok = ok and bool(torch.equal(got[:, 0], exp)) and bool(torch.equal(got[:, 1], exp))
+        return ok
+    wl.verify = verify
+    return wl
 
 
 def build_snp_index(args, log2_bases, rank, barrier):
@@ -125,54 +253,134 @@ def build_snp_index(args, log2_bases, rank, barrier):
     return ix, graph
 
 
-def build_linear_index(args, log2_bases):
-    """Every rank builds its own replica on its own GPU (a few seconds, deterministic)."""
+def setup_chr22(args, D, dev, local_rank, nq=None):
     import torch
-    from workload import linear_torch
+    from workload import patterns
+    from gcsa2_amd.binding import GCSA
+    wl = Workload()
+    log2_bases = args.log2_bases or 25
+    ix, graph = build_snp_index(args, log2_bases, D.rank, D.barrier)
     t = time.time()
-    ix = linear_torch.build_linear(1 << log2_bases, LINEAR_SEED, order=args.order, with_lcp=False,
-                                   with_samples=False, verbose=log)
+    wl.gpu = GCSA(ix, device=local_rank)
+    log(f"device image: {wl.gpu.device_bytes() / 1e6:.1f} MB in HBM ({time.time() - t:.1f} s)")
+    wl.ix = ix
+    wl.nq = nq or args.queries or 10_000_000
+    wl.m = args.pattern_len
+    wl.total_queries = wl.nq * D.world
+    wl.first = wl.nq * D.rank
+    seed = 0x6C5A0012 + 0x1000 * D.rank
+    t = time.time()
+    pats = patterns.walk_patterns(graph, wl.nq, wl.m, seed) if args.set == "S" else patterns.uniform_patterns(wl.nq, wl.m, seed)
+    flat, off = patterns.as_batch(pats)
+    wl.d_pat = padded_bytes(torch.from_numpy(flat).to(dev))
+    wl.d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    log(f"patterns: {wl.nq} x {wl.m} set {args.set} ({time.time() - t:.1f} s)")
+    wl.label = (f"chr22-like SNP graph 2^{log2_bases} bases, order-{args.order} GCSA, {wl.nq} x {wl.m}-mer find() per GPU, "
+                f"pattern set {args.set}")
+    return wl
+
+
+def setup_linear(args, D, dev, local_rank):
+    import torch
+    from workload import linear_torch, patterns
+    from gcsa2_amd.binding import GCSA
+    wl = Workload()
+    log2_bases = args.log2_bases or 30
+    t = time.time()
+    ix = linear_torch.build_linear(1 << log2_bases, LINEAR_SEED, order=args.order, with_lcp=False, with_samples=False, verbose=log)
     torch.cuda.empty_cache()
     log(f"linear index built on the GPU: n={ix.n} ({time.time() - t:.1f} s)")
-    return ix
+    wl.gpu = GCSA(ix, device=local_rank, with_samples=False, with_counters=False, with_lcp=False)
+    wl.ix = ix
+    wl.nq = args.queries or 10_000_000
+    wl.m = args.pattern_len
+    wl.total_queries = wl.nq * D.world
+    wl.first = wl.nq * D.rank
+    seed = 0x6C5A0012 + 0x1000 * D.rank
+    if args.set == "S":
+        pats = linear_torch.substring_patterns_torch(1 << log2_bases, LINEAR_SEED, wl.nq, wl.m, seed, dev)
+    else:
+        pats = patterns.uniform_patterns(wl.nq, wl.m, seed)
+    flat, off = patterns.as_batch(pats)
+    wl.d_pat = padded_bytes(torch.from_numpy(flat).to(dev))
+    wl.d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    wl.label = (f"linear graph 2^{log2_bases} bases (FM-index shaped GCSA, built on the GPU), {wl.nq} x {wl.m}-mer find() per GPU, "
+                f"pattern set {args.set}")
+    return wl
 
 
-def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup, pack32=False):
-    """Warm-up, then `steps` timed find() launches (+ gather when distributed).  Returns timings,
-    the device result tensor and the algorithmic traffic of one launch."""
+# ---- the timed loop ------------------------------------------------------------------------------------------
+
+def gather_via_host(D, mine, counts, wire_bytes):
+    """gloo control-flow check only: torch's gather wants equal sizes, so pad to the largest shard."""
     import torch
-    d_pat = torch.from_numpy(flat).to(dev)
-    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
-    # two result buffers: the RCCL gather of step k (async, on RCCL's own stream) overlaps the
-    # find() launch of step k + 1; a buffer is reused only after its gather has completed.
-    outs = [torch.zeros((nq, 2), dtype=torch.int64, device=dev) for _ in range(2 if D.active else 1)]
-    # pack32: every value of a range is below 2^32 for this index, so the gather carries (sp, ep) as u32
-    # pairs (8 bytes per query over xGMI instead of 16); the root keeps the gathered shards in that form
-    pack32 = pack32 and D.active
-    wire = [torch.zeros((nq, 2), dtype=torch.int32, device=dev) for _ in outs] if pack32 else outs
-    parts = [[torch.zeros_like(wire[0]) for _ in range(D.world)] for _ in outs] if (D.active and D.rank == 0) else [None, None]
-    pending = [None, None]
+    width = max(counts) * wire_bytes
+    padded = torch.zeros(width, dtype=torch.uint8)
+    padded[: mine.numel()] = mine
+    tmp = [torch.zeros(width, dtype=torch.uint8) for _ in counts] if D.rank == 0 else None
+    D.dist.gather(padded, tmp, dst=0)
+    if D.rank != 0:
+        return None
+    return torch.cat([tmp[r][: c * wire_bytes] for r, c in enumerate(counts)])
+
+
+def measure(args, D, dev, wl, steps, warmup):
+    """Warm-up, then `steps` timed passes: find() over the shard (+ the RCCL gather of the ranges on rank 0 when
+    distributed, overlapped with the next pass on a second stream).  Returns timings, the device result tensor and
+    the algorithmic traffic of one launch."""
+    import torch
+    from gcsa2_amd import binding
+    gpu, nq, m = wl.gpu, wl.nq, wl.m
     stream = torch.cuda.current_stream()
+    comm_stream = torch.cuda.Stream(device=dev) if D.active else None
+    nbuf = 2 if D.active else 1
+    outs = [torch.zeros((nq, 2), dtype=torch.int64, device=dev) for _ in range(nbuf)]
+    bounds = shard_bounds(wl.total_queries, D.world) if wl.scaling == "strong" else [(r * nq, (r + 1) * nq) for r in range(D.world)]
+    counts = [e - b for b, e in bounds]
+    total = sum(counts)
+    # wire format: (sp, len) u32 pairs when every path node / edge number is below 2^32, else the u64 pairs
+    pack32 = D.active and max(int(wl.ix.n), int(wl.ix.e)) + 1 < (1 << 32)
+    wire_bytes = 8 if pack32 else 16
+    wire = [torch.zeros((nq, 2), dtype=torch.int32, device=dev) for _ in outs] if pack32 else outs
+    root = D.active and D.rank == 0
+    recv = [torch.zeros(total * wire_bytes, dtype=torch.uint8, device=dev) for _ in outs] if root else [None] * nbuf
+    gathered = torch.zeros((total, 2), dtype=torch.int64, device=dev) if (root and pack32) else None
+    free_ev = [None] * nbuf                  # the gather of the buffer's previous contents has completed
 
     def step(k, record=None):
-        b = k % len(outs)
-        if pending[b] is not None:
-            pending[b].wait()          # stream-level wait, no host sync
-            pending[b] = None
+        b = k % nbuf
+        if free_ev[b] is not None:
+            stream.wait_event(free_ev[b])
         if record is not None:
             record[0].record(stream)
-        gpu.find_device_variant(args.variant, d_pat.data_ptr(), d_off.data_ptr(), nq, outs[b].data_ptr(), stream.cuda_stream)
+        gpu.find_device_variant(args.variant, wl.d_pat.data_ptr(), wl.d_off.data_ptr(), nq, outs[b].data_ptr(), stream.cuda_stream)
         if record is not None:
             record[1].record(stream)
+        if not D.active:
+            return
         if pack32:
-            wire[b].copy_(outs[b])     # int64 -> int32 keeps the low 32 bits
-        pending[b] = D.gather(wire[b], parts[b])   # the single gather of hit ranges over xGMI
+            binding.pack_ranges32_device(outs[b].data_ptr(), nq, wire[b].data_ptr(), stream.cuda_stream)
+        ready = torch.cuda.Event()
+        ready.record(stream)
+        comm_stream.wait_event(ready)
+        if D.comm is not None:               # the single collective of the path: one gather of hit ranges over xGMI
+            D.comm.gather(wire[b].data_ptr(), [c * wire_bytes for c in counts], recv[b].data_ptr() if root else 0, 0,
+                          comm_stream.cuda_stream)
+        else:                                # gloo control-flow check: through host memory
+            comm_stream.synchronize()
+            parts = gather_via_host(D, wire[b].view(torch.uint8).reshape(-1).cpu(), counts, wire_bytes)
+            if root:
+                with torch.cuda.stream(comm_stream):
+                    recv[b].copy_(parts)
+        if root and pack32:
+            binding.unpack_ranges32_device(recv[b].data_ptr(), total, gathered.data_ptr(), comm_stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(comm_stream)
+        free_ev[b] = done
 
     def drain():
-        for b in range(len(pending)):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        if comm_stream is not None:
+            comm_stream.synchronize()
 
     for k in range(warmup):
         step(k)
@@ -186,25 +394,27 @@ def measure(args, D, dev, gpu, flat, offsets, nq, m, steps, warmup, pack32=False
     drain()
     torch.cuda.synchronize()
     D.barrier()
-    d_out = outs[(steps - 1) % len(outs)] if steps > 0 else outs[0]
-    elapsed = D.max(time.perf_counter() - t0, dev)
-    if D.active and D.rank == 0 and steps > 0:       # the root's own shard came back through the gather intact
-        mine = parts[(steps - 1) % len(outs)][0]
-        back = (mine.to(torch.int64) & 0xFFFFFFFF) if pack32 else mine
-        assert torch.equal(back, d_out), "gathered shard differs from the computed ranges"
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    elapsed = D.max(time.perf_counter() - t0)
+    last = (steps - 1) % nbuf if steps > 0 else 0
+    d_out = outs[last]
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if steps > 0 else 0.0
+    result = dict(elapsed=elapsed, kernel_ms=kernel_ms, d_out=d_out, gathered=None, pack32=pack32)
+    if root and steps > 0:
+        result["gathered"] = gathered if pack32 else recv[last].view(torch.int64).view(total, 2)
+        mine = result["gathered"][bounds[0][0]:bounds[0][1]]
+        assert torch.equal(mine, d_out), "gathered shard differs from the computed ranges"
 
     # algorithmic traffic of one launch (instrumented kernel, outside the timed region)
-    d_stats = torch.zeros(3, dtype=torch.int64, device=dev)
+    d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
     d_out2 = torch.zeros_like(d_out)
-    gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out2.data_ptr(), d_stats.data_ptr(), stream.cuda_stream)
+    gpu.find_stats_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), nq, d_out2.data_ptr(), d_stats.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(d_out, d_out2), "instrumented and timed kernels disagree"
-    blocks, lf_steps, lookups = (int(x) for x in d_stats.cpu())
-    algo_bytes = blocks * gpu.find_block_bytes() + lookups * 16 + nq * (m + 16)
-    found = int((d_out[:, 0] <= d_out[:, 1]).sum().item())
-    return dict(elapsed=elapsed, kernel_ms=kernel_ms, blocks=blocks, lf_steps=lf_steps, lookups=lookups, algo_bytes=algo_bytes,
-                found=found, d_out=d_out)
+    blocks, lf_steps, lookups, jumps = (int(x) for x in d_stats.cpu())
+    result.update(blocks=blocks, lf_steps=lf_steps, lookups=lookups, jumps=jumps,
+                  algo_bytes=blocks * gpu.find_block_bytes() + lookups * 8 + jumps * 16 + nq * (m + 16),
+                  found=int((d_out[:, 0] <= d_out[:, 1]).sum().item()))
+    return result
 
 
 def measure_locate(gpu, d_ranges, dev, steps):
@@ -236,41 +446,194 @@ def measure_locate(gpu, d_ranges, dev, steps):
     return {"count_equals_located": consistent,
             "workload": f"locate() of the {nq} ranges found above, sorted distinct values per range, results into caller-owned HBM buffers",
             "value": nq / (ms * 1e-3), "unit": "queries/s", "ms_per_step": ms, "values": int(total),
-            "locate_table_bytes": gpu.locate_table_bytes()}
+            "values_per_s": int(total) / (ms * 1e-3), "locate_table_bytes": gpu.locate_table_bytes()}, d_off, d_val
 
 
-def pmc_traffic(args, key, nq, m, kmer_k):
+def pmc_traffic(args, key, gpu, nq, m):
     """Memory-side read bytes of one launch from the committed rocprofv3 --pmc pass of this exact
-    workload (profiles/traffic.json, derivation in profiles/r01_v5_pmc.md).  PMC counters cannot
-    be read from inside the timed process, so this is looked up, never estimated: any mismatch in
-    workload, batch shape or kernel generation yields None."""
+    workload (profiles/traffic.json).  PMC counters cannot be read from inside the timed process, so this is
+    looked up, never estimated: any mismatch in workload, batch shape, seed table or kernel yields None."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             entry = json.load(f).get(key)
     except (OSError, ValueError):
         return None
-    if not entry or args.variant != 2 or args.set != "S" or entry["queries"] != nq or entry["pattern_len"] != m:
+    if not entry or args.variant != 2 or entry["queries"] != nq or entry["pattern_len"] != m:
         return None
-    if entry.get("kmer_table_k") != kmer_k:        # profiled with another seed table: not this kernel's traffic
+    if entry.get("kmer_table_k") != gpu.kmer_table_k() or entry.get("pair_blocks") != bool(gpu.pair_block_bytes()):
         return None
     return entry["read_bytes_per_launch"]
 
 
-def roofline(args, r, key, nq, m, kmer_k):
+def working_set(gpu, ix):
+    k = gpu.kmer_table_k()
+    blocks = gpu.pair_block_bytes() or int(ix.sigma) * (int(ix.n) // 448 + 1) * 128
+    return int(blocks + ((8 << (2 * k)) if k else 0))
+
+
+def roofline(args, r, wl, key):
+    gpu, nq, m = wl.gpu, wl.nq, wl.m
     achieved = r["algo_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9
-    traffic = pmc_traffic(args, key, nq, m, kmer_k)
-    out = {"bound": "hbm", "kernel": "k_find2" if args.variant == 2 else "k_find", "achieved": achieved,
-           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-           "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"]}
-    # what actually bounds a random-gather kernel beyond L2 is requests per second (profiles/r01_gather_bench.md:
-    # 50-58 G dependent random 128-byte fetches/s on this GPU); reported beside the byte roofline
-    requests = r["blocks"] + r["lookups"]
+    traffic = pmc_traffic(args, key, gpu, nq, m)
+    ws = working_set(gpu, wl.ix)
+    out = {"bound": "hbm", "kernel": ("k_find2<pair>" if gpu.pair_block_bytes() else "k_find2") if args.variant == 2 else "k_find",
+           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+           "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"], "working_set_bytes": ws,
+           "working_set_note": ("blocks + seed table the launch gathers from: far beyond the 256 MiB Infinity Cache, served by HBM" if ws > (2 << 30)
+                                else "within a few multiples of the 256 MiB Infinity Cache: partly served on-die, `frac` is not an HBM fraction here")}
+    # what bounds a random-gather kernel beyond L2 is requests per second (profiles/r01_gather_bench.md:
+    # ~50 G dependent random 128-byte fetches/s at HBM footprints); reported beside the byte roofline
+    requests = r["blocks"] + r["lookups"] + r["jumps"]
     out["request_rate"] = {"achieved_G_per_s": requests / (r["kernel_ms"] * 1e-3) / 1e9, "ceiling_G_per_s": REQUEST_CEILING_GPS,
                            "requests_per_query": requests / nq}
     if traffic is not None:
-        out["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_*_sum pass of this workload; 128 B x RDREQ_128B + 64 B x RDREQ_64B)"
+        out["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_*_sum pass of this workload; "
+                                 "128 B x RDREQ_128B + 64 B x RDREQ_64B + 32 B x RDREQ_32B)")
         out["traffic_GBps"] = traffic / (r["kernel_ms"] * 1e-3) / 1e9
     return out
+
+
+def find_config(wl, r, world):
+    gpu = wl.gpu
+    return {"workload": wl.label, "path_nodes": int(wl.ix.n), "edges": int(wl.ix.e), "queries_total": wl.total_queries,
+            "queries_per_gpu": wl.nq, "pattern_len": wl.m, "index_bytes_hbm": gpu.device_bytes(),
+            "pair_block_bytes": gpu.pair_block_bytes(), "single_block_bytes": int(wl.ix.sigma) * (int(wl.ix.n) // 448 + 1) * 128,
+            "kmer_table_k": gpu.kmer_table_k(), "found": r["found"], "lf_steps_per_query": r["lf_steps"] / wl.nq,
+            "blocks_per_query": r["blocks"] / wl.nq, "block_bytes": gpu.find_block_bytes(),
+            "parallelism": f"replicated index, contiguous query shards x{world}, one RCCL gather of ranges per step (gcsa2_comm_gather)"
+                           + (" as (sp, len) u32 pairs" if r["pack32"] else "")}
+
+
+# ---- N = 1 secondaries ---------------------------------------------------------------------------------------
+
+def config5(args, wl, dev):
+    """BASELINE configs[4] on one GPU: 1 M 256-bp patterns on the whole-human-footprint index, every second one with
+    a substitution every 41 bp.  Backward search with parent() on failure (k_match_stats: LF + LCPArray::parent fused,
+    the MEM-finder interplay of SURVEY.md 8(f)-2), then locate() of the final ranges."""
+    import torch
+    from workload import mseq_torch
+    gpu, ix = wl.gpu, wl.ix
+    nq, m = 1_000_000, 256
+    stream = torch.cuda.current_stream()
+    pats, start = mseq_torch.substring_patterns_device(wl.sym_t, 0, nq, m, CONFIG5_SEED)
+    nxt = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"CGTA"):
+        nxt[a] = b
+    for col in range(37, m, 41):
+        pats[1::2, col] = nxt[pats[1::2, col].to(torch.int64)]
+    d_pat = padded_bytes(pats)
+    d_off = torch.arange(nq + 1, dtype=torch.int64, device=dev) * m
+    d_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev)
+    d_rng = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    d_fb = torch.zeros(nq, dtype=torch.int64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms_time = timed(lambda: gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(),
+                                                   d_fb.data_ptr(), stream.cuda_stream))
+    # closed form for the unmodified half: the range of T[p .. p + 256) is (rank[p], rank[p]), no parent() call,
+    # and the match starting at byte i has length 256 - i
+    exp = wl.rank_t[start[0::2]].to(torch.int64) & 0xFFFFFFFF
+    ms2d = d_ms[: nq * m].view(nq, m)
+    want_ms = (m - torch.arange(m, device=dev)).to(torch.int16).view(1, m)
+    exact_ok = bool(torch.equal(d_rng[0::2, 0], exp)) and bool(torch.equal(d_rng[0::2, 1], exp)) and \
+        bool((d_fb[0::2] == 0).all()) and bool((ms2d[0::2] == want_ms).all())
+    out = {"workload": f"{nq} x {m}-bp patterns on the same index, every second one with a substitution every 41 bp: "
+                       "backward search with parent() on failure (k_match_stats), then locate() and parent() of the final ranges",
+           "match_stats_ms": ms_time, "patterns_per_s": nq / (ms_time * 1e-3), "bases_per_s": nq * m / (ms_time * 1e-3),
+           "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item()),
+           "unmodified_half_equals_closed_form": exact_ok}
+    # plain find() of the same batch (a substituted pattern empties at its first substitution)
+    d_find = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    out["find_ms"] = timed(lambda: gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_find.data_ptr(), stream.cuda_stream))
+    out["find_patterns_per_s"] = nq / (out["find_ms"] * 1e-3)
+    out["find_unmodified_half_equals_closed_form"] = bool(torch.equal(d_find[0::2, 0], exp)) and bool(torch.equal(d_find[0::2, 1], exp))
+    loc, d_loff, d_lval = measure_locate(gpu, d_rng, dev, 3)
+    out["locate"] = loc
+    vals = mseq_torch.node_values(start[0::2].cpu().numpy())
+    out["locate_unmodified_half_equals_closed_form"] = bool(np.array_equal(d_lval[d_loff[:-1][0::2]].cpu().numpy().view(np.uint64), vals))
+    d_nodes = torch.zeros((nq, 5), dtype=torch.int64, device=dev)
+    t_parent = timed(lambda: gpu.parent_device(d_rng.data_ptr(), nq, d_nodes.data_ptr(), stream.cuda_stream))
+    out["parent_queries_per_s"] = nq / (t_parent * 1e-3)
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_match_stats(ix, d_pat, d_ms, d_rng, d_fb, m)
+    return out
+
+
+def chr22_secondary(args, D, dev, local_rank):
+    """BASELINE configs[1] and [2] on one GPU."""
+    wl = setup_chr22(args, D, dev, local_rank, nq=10_000_000)
+    r = measure(args, D, dev, wl, max(5, args.steps), 2)
+    out = {"workload": wl.label, "value": wl.nq / (r["kernel_ms"] * 1e-3), "unit": "queries/s", "kernel_ms": r["kernel_ms"],
+           "config": find_config(wl, r, 1), "roofline": roofline(args, r, wl, f"chr22_{args.log2_bases or 25}_{wl.m}_{args.set}")}
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds / 2)
+    out["locate"], _, _ = measure_locate(wl.gpu, r["d_out"], dev, 3)
+    return out
+
+
+def cpu_baseline(args, wl, d_out, seconds):
+    """The oracle (CPU restatement of the reference path) timed on this host: a bounded sample of
+    the same patterns, all cores with the verifyIndex-style static split, plus one thread."""
+    from oracle.oracle import OracleIndex, max_threads
+    t = time.time()
+    cpu = OracleIndex(wl.ix, with_samples=False, with_counters=False, with_lcp=False)
+    build_s = time.time() - t
+    cores = max_threads()
+    m = wl.m
+    cap = min(wl.nq, 40_000_000)
+    flat = wl.d_pat[: cap * m].cpu().numpy()
+    offsets = np.arange(cap + 1, dtype=np.uint64) * np.uint64(m)
+    probe = min(cap, 20000)
+    cpu.find_batch(flat, offsets[:probe + 1], threads=1)
+    per_query = cpu.last_seconds / probe
+    n1 = int(min(cap, max(probe, 0.25 * seconds / per_query)))
+    r1 = cpu.find_batch(flat, offsets[:n1 + 1], threads=1)
+    t1 = cpu.last_seconds
+    nall = int(min(cap, max(n1, 0.75 * seconds * cores / per_query * 0.5)))
+    rall = cpu.find_batch(flat, offsets[:nall + 1], threads=cores)
+    tall = cpu.last_seconds
+    got = d_out[:nall].cpu().numpy().view(np.uint64)
+    parity = bool(np.array_equal(got, rall)) and bool(np.array_equal(got[:n1], r1))
+    cpu.close()
+    return {"value": nall / tall, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"first {nall} of the {wl.nq} patterns, {m}-mers, OpenMP static split over {cores} threads "
+                      f"= the CPUs this container may use (affinity / cgroup quota; {os.cpu_count()} logical CPUs visible) "
+                      f"({tall:.1f} s); single thread: first {n1} patterns ({t1:.1f} s); oracle index built in {build_s:.1f} s",
+            "single_thread_value": n1 / t1, "single_thread_us_per_query": t1 / n1 * 1e6,
+            "gpu_matches_cpu_on_sample": parity}
+
+
+def cpu_baseline_match_stats(ix, d_pat, d_ms, d_rng, d_fb, m, ns=4000):
+    """config 5's CPU leg: the oracle's LF + parent loop on the first `ns` patterns, timed on all cores, and the
+    GPU results of those patterns checked against it."""
+    from oracle.oracle import OracleIndex, max_threads
+    t = time.time()
+    cpu = OracleIndex(ix, with_samples=False, with_counters=False)
+    build_s = time.time() - t
+    cores = max_threads()
+    flat = d_pat[: ns * m].cpu().numpy()
+    off = np.arange(ns + 1, dtype=np.uint64) * np.uint64(m)
+    cm, cr, cf = cpu.match_stats_batch(flat, off, threads=cores)
+    seconds = cpu.last_seconds
+    got_ms = d_ms[: ns * m].cpu().numpy().view(np.uint16)
+    parity = bool(np.array_equal(got_ms, cm)) and bool(np.array_equal(d_rng[:ns].cpu().numpy().view(np.uint64), cr)) \
+        and bool(np.array_equal(d_fb[:ns].cpu().numpy().view(np.uint64), cf))
+    cpu.close()
+    return {"value": ns / seconds, "unit": "patterns/s", "cores": cores, "kind": "port",
+            "sample": f"first {ns} of the patterns, {m} bp, OpenMP static split over {cores} threads ({seconds:.2f} s); "
+                      f"oracle index built in {build_s:.1f} s",
+            "gpu_matches_cpu_on_sample": parity}
 
 
 def main():
@@ -287,127 +650,50 @@ def main():
     rank, world = D.rank, D.world
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
+    from gcsa2_amd import binding
+    D.make_comm(binding, local_rank)
 
-    from workload import patterns, linear_torch
-    from gcsa2_amd.binding import GCSA
-
-    nq, m = args.queries, args.pattern_len
-    seed = 0x6C5A0012 + 0x1000 * rank
-    log2_bases = args.log2_bases or (25 if args.workload == "snp" else 30)
-    if args.workload == "snp":
-        ix, graph = build_snp_index(args, log2_bases, rank, D.barrier)
-        label = f"chr22-like SNP graph 2^{log2_bases} bases"
+    if args.workload == "human":
+        wl = setup_human(args, D, dev, local_rank)
+    elif args.workload == "chr22":
+        wl = setup_chr22(args, D, dev, local_rank)
     else:
-        ix, graph = build_linear_index(args, log2_bases), None
-        label = f"linear graph 2^{log2_bases} bases (FM-index shaped GCSA)"
-    t = time.time()
-    full = args.workload == "snp"
-    gpu = GCSA(ix, device=local_rank, with_samples=full, with_counters=full, with_lcp=full)
-    log(f"device image: {gpu.device_bytes() / 1e6:.1f} MB in HBM ({time.time() - t:.1f} s)")
-    t = time.time()
-    if args.set == "U":
-        pats = patterns.uniform_patterns(nq, m, seed)
-    elif args.workload == "snp":
-        pats = patterns.walk_patterns(graph, nq, m, seed)
-    else:
-        pats = linear_torch.substring_patterns_torch(1 << log2_bases, LINEAR_SEED, nq, m, seed, dev)
-    flat, offsets = patterns.as_batch(pats)
-    log(f"patterns: {nq} x {m} set {args.set} ({time.time() - t:.1f} s)")
+        wl = setup_linear(args, D, dev, local_rank)
 
-    pack32 = max(int(ix.n), int(ix.e)) + 2 < (1 << 32)
-    r = measure(args, D, dev, gpu, flat, offsets, nq, m, args.steps, args.warmup, pack32=pack32)
+    r = measure(args, D, dev, wl, args.steps, args.warmup)
+    # every rank checks its own shard; the root also checks everything it gathered
+    ok = wl.verify(r["d_out"], wl.first, wl.nq)
+    if rank == 0 and r["gathered"] is not None and ok is not None:
+        ok = ok and wl.verify(r["gathered"], 0, wl.total_queries)
+    checked = None if ok is None else D.all_true(ok)
 
     result = None
     if rank == 0:
+        size = {"human": getattr(wl, "degree", args.degree), "chr22": args.log2_bases or 25, "linear": args.log2_bases or 30}[args.workload]
         result = {
-            "metric": "kmer_find_queries_per_sec", "value": world * nq * args.steps / r["elapsed"], "unit": "queries/s",
+            "metric": "kmer_find_queries_per_sec", "value": wl.total_queries * args.steps / r["elapsed"], "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": r["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": r["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": wl.scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{label}, order-{args.order} GCSA, {nq} x {m}-mer find() per GPU, pattern set {args.set}",
-                       "path_nodes": int(ix.n), "edges": int(ix.e), "queries_per_gpu": nq, "pattern_len": m,
-                       "pattern_set": args.set, "index_bytes_hbm": gpu.device_bytes(),
-                       "find_bytes_hbm": int(ix.sigma) * (int(ix.n) // 448 + 1) * 128,
-                       "found": r["found"], "lf_steps_per_query": r["lf_steps"] / nq,
-                       "blocks_per_query": r["blocks"] / nq, "block_bytes": gpu.find_block_bytes(),
-                       "kmer_table_k": gpu.kmer_table_k(),
-                       "parallelism": f"replicated index, query shards x{world}, one RCCL gather of ranges per step"
-                                      + (" ((sp, ep) as u32 pairs: every value of this index is below 2^32)" if (pack32 and world > 1) else "")},
-            "roofline": roofline(args, r, f"{args.workload}_{log2_bases}", nq, m, gpu.kmer_table_k()),
+            "config": find_config(wl, r, world),
+            "roofline": roofline(args, r, wl, f"{args.workload}_{size}_{wl.m}_{args.set}"),
         }
-        if args.workload == "snp":
-            result["roofline"]["note"] = ("fused blocks of this index fit the 256 MiB Infinity Cache: achieved = algorithmic bytes / "
-                                          "kernel time, served mostly on-die; see hbm_resident for the HBM-bound figure")
-        if not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(args, ix, flat, offsets, r["d_out"], m)
-        if args.workload == "snp" and world == 1:
-            result["locate"] = measure_locate(gpu, r["d_out"], dev, max(3, args.steps // 4))
-        if args.workload == "snp" and world == 1 and not args.no_jump_table:
-            # opt-in acceleration structure (GCSA2_JUMP_TABLE=1, 16 bytes per path node): fewer, smaller
-            # memory requests per query; reported beside the headline, which stays the default build
-            os.environ["GCSA2_JUMP_TABLE"] = "1"
-            try:
-                gpu_j = GCSA(ix, device=local_rank, with_samples=False, with_counters=False, with_lcp=False)
-            finally:
-                del os.environ["GCSA2_JUMP_TABLE"]
-            rj = measure(args, D, dev, gpu_j, flat, offsets, nq, m, max(5, args.steps // 2), 2)
-            result["jump_table"] = {
-                "workload": "the headline workload with the jump table (memoised unary LF chains) enabled",
-                "value": nq / (rj["kernel_ms"] * 1e-3), "unit": "queries/s", "kernel_ms": rj["kernel_ms"],
-                "table_bytes": gpu_j.jump_table_bytes(), "blocks_per_query": rj["blocks"] / nq,
-                "algorithmic_GBps": rj["algo_bytes"] / (rj["kernel_ms"] * 1e-3) / 1e9,
-                "requests_per_query": (rj["blocks"] + rj["lookups"]) / nq,
-                "request_rate_G_per_s": (rj["blocks"] + rj["lookups"]) / (rj["kernel_ms"] * 1e-3) / 1e9,
-                "equals_default_results": bool(torch.equal(rj["d_out"], r["d_out"]))}
-            del gpu_j, rj
+        result["config"]["pattern_set"] = args.set
+        result["config"]["all_ranges_equal_closed_form"] = checked
+        if not args.no_cpu and world == 1:
+            result["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds)
+    secondary = args.workload == "human" and world == 1 and not args.no_secondary
+    if secondary:
+        result["config5"] = config5(args, wl, dev)
     del r
-
-    # secondary measurement: the same kernel on an index far larger than the Infinity Cache
-    if args.workload == "snp" and world == 1 and not args.no_hbm_resident:
-        del gpu, ix, graph
+    if secondary:
+        del wl
         torch.cuda.empty_cache()
-        lb = 30
-        ix2 = build_linear_index(args, lb)
-        gpu2 = GCSA(ix2, device=local_rank, with_samples=False, with_counters=False, with_lcp=False)
-        pats2 = linear_torch.substring_patterns_torch(1 << lb, LINEAR_SEED, nq, m, seed, dev)
-        flat2, off2 = patterns.as_batch(pats2)
-        r2 = measure(args, D, dev, gpu2, flat2, off2, nq, m, max(5, args.steps // 2), 2)
-        result["hbm_resident"] = {
-            "workload": f"linear graph 2^{lb} bases (FM-index shaped GCSA, built on the GPU), {nq} x {m}-mer find(), substrings of the text",
-            "path_nodes": int(ix2.n), "find_bytes_hbm": int(ix2.sigma) * (int(ix2.n) // 448 + 1) * 128,
-            "value": nq / (r2["kernel_ms"] * 1e-3), "unit": "queries/s", "blocks_per_query": r2["blocks"] / nq,
-            "kmer_table_k": gpu2.kmer_table_k(),
-            "roofline": roofline(args, r2, f"linear_{lb}", nq, m, gpu2.kmer_table_k())}
+        result["chr22"] = chr22_secondary(args, D, dev, local_rank)
     if rank == 0:
         print(json.dumps(result), flush=True)
     D.barrier()
     D.close()
-
-
-def cpu_baseline(args, ix, flat, offsets, d_out, m):
-    """The oracle (CPU restatement of the reference path) timed on this host: a bounded sample of
-    the same patterns, all cores with the verifyIndex-style static split, plus one thread."""
-    from oracle.oracle import OracleIndex, max_threads
-    cpu = OracleIndex(ix, with_samples=False, with_counters=False, with_lcp=False)
-    cores = max_threads()
-    nq = offsets.shape[0] - 1
-    probe = min(nq, 20000)
-    cpu.find_batch(flat, offsets[:probe + 1], threads=1)
-    per_query = cpu.last_seconds / probe
-    n1 = int(min(nq, max(probe, 0.25 * args.cpu_seconds / per_query)))
-    r1 = cpu.find_batch(flat, offsets[:n1 + 1], threads=1)
-    t1 = cpu.last_seconds
-    nall = int(min(nq, max(n1, 0.75 * args.cpu_seconds * cores / per_query * 0.5)))
-    rall = cpu.find_batch(flat, offsets[:nall + 1], threads=cores)
-    tall = cpu.last_seconds
-    got = d_out[:nall].cpu().numpy().view(np.uint64)
-    parity = bool(np.array_equal(got, rall)) and bool(np.array_equal(got[:n1], r1))
-    return {"value": nall / tall, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"first {nall} of the {nq} patterns, {m}-mers, OpenMP static split over {cores} threads "
-                      f"= the CPUs this container may use (affinity / cgroup quota; {os.cpu_count()} logical CPUs visible) "
-                      f"({tall:.1f} s); single thread: first {n1} patterns ({t1:.1f} s)",
-            "single_thread_value": n1 / t1, "single_thread_us_per_query": t1 / n1 * 1e6,
-            "gpu_matches_cpu_on_sample": parity}
 
 
 if __name__ == "__main__":

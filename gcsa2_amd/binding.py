@@ -34,7 +34,9 @@ EXPORTS = [
     "gcsa2_lcp_size", "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching",
     "gcsa2_lcp_access_batch",
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
-    "gcsa2_group_find_batch", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device",
+    "gcsa2_group_find_batch", "gcsa2_group_find_device", "gcsa2_group_uses_rccl",
+    "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_gather",
+    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
 ]
@@ -59,6 +61,11 @@ def load_library():
         raise Gcsa2Error(-2, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
     try:
         import torch  # noqa: F401  (plumbing only: one HIP runtime per process)
+        # ... and one RCCL: the gather entry points bind RCCL at run time (csrc/comm.hpp) and are pointed at
+        # the copy torch ships and loads for its own "nccl" backend, when there is one
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(bundled):
+            os.environ.setdefault("GCSA2_RCCL_LIB", bundled)
     except Exception:
         pass
     L = C.CDLL(LIB_PATH)
@@ -124,6 +131,17 @@ def load_library():
     L.gcsa2_group_index.argtypes = [vp, i32]
     L.gcsa2_group_index.restype = vp
     L.gcsa2_group_find_batch.argtypes = [vp, u8p, u64p, u64, u64p]
+    L.gcsa2_group_find_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), u64p, vp]
+    L.gcsa2_group_uses_rccl.argtypes = [vp]
+    L.gcsa2_comm_unique_id.argtypes = [u8p]
+    L.gcsa2_comm_create.argtypes = [u8p, i32, i32, i32, C.POINTER(vp)]
+    L.gcsa2_comm_destroy.argtypes = [vp]
+    L.gcsa2_comm_destroy.restype = None
+    L.gcsa2_comm_rank.argtypes = [vp]
+    L.gcsa2_comm_world.argtypes = [vp]
+    L.gcsa2_comm_gather.argtypes = [vp, vp, u64p, vp, i32, vp]
+    L.gcsa2_pack_ranges32_device.argtypes = [vp, u64, vp, vp]
+    L.gcsa2_unpack_ranges32_device.argtypes = [vp, u64, vp, vp]
     _lib = L
     return L
 
@@ -614,6 +632,51 @@ class LCPArray:
         return (sp, ep, self[sp], right, UNKNOWN)
 
 
+class Comm:
+    """RCCL communicator of the library (`gcsa2_comm_*`): one rank per GPU, one gather of hit ranges on the root.
+    The 128-byte id is made on one rank (`Comm.unique_id()`) and handed to the others by the launcher."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = np.zeros(Comm.ID_BYTES, dtype=np.uint8)
+        _check(load_library().gcsa2_comm_unique_id(_p8(buf)))
+        return buf.tobytes()
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int):
+        self._L = load_library()
+        buf = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        assert buf.shape[0] == Comm.ID_BYTES
+        h = C.c_void_p()
+        _check(self._L.gcsa2_comm_create(_p8(buf), rank, world, device, C.byref(h)))
+        self._h = h
+        self.rank, self.world = rank, world
+
+    def gather(self, d_send, bytes_per_rank, d_recv, root=0, stream=0):
+        """Enqueue the gather: rank r sends bytes_per_rank[r] bytes from device pointer d_send; the root receives
+        all parts back to back at device pointer d_recv."""
+        sizes = np.asarray(bytes_per_rank, dtype=np.uint64)
+        assert sizes.shape[0] == self.world
+        _check(self._L.gcsa2_comm_gather(self._h, d_send, _p64(sizes), d_recv, root, stream))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gcsa2_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def pack_ranges32_device(d_ranges, nq, d_packed, stream=0):
+    _check(load_library().gcsa2_pack_ranges32_device(d_ranges, nq, d_packed, stream))
+
+
+def unpack_ranges32_device(d_packed, nq, d_ranges, stream=0):
+    _check(load_library().gcsa2_unpack_ranges32_device(d_packed, nq, d_ranges, stream))
+
+
 class GCSAGroup:
     """One replica per device; `find_batch` shards the batch contiguously over the replicas
     (single-process multi-GPU, `gcsa2_group_*`)."""
@@ -636,6 +699,19 @@ class GCSAGroup:
         out = np.zeros((nq, 2), dtype=np.uint64)
         _check(self._L.gcsa2_group_find_batch(self._h, _p8(patterns), _p64(offsets), nq, _p64(out)))
         return out
+
+    def uses_rccl(self):
+        return bool(self._L.gcsa2_group_uses_rccl(self._h))
+
+    def find_device(self, d_patterns, d_offsets, counts, d_ranges_root):
+        """Shards already in HBM: d_patterns[r] / d_offsets[r] are device pointers on the device of replica r,
+        d_ranges_root a device pointer on the device of replica 0 (2 x sum(counts) words); complete on return."""
+        G = self.size()
+        assert len(d_patterns) == G and len(d_offsets) == G and len(counts) == G
+        pats = (C.c_void_p * G)(*[C.c_void_p(int(p)) for p in d_patterns])
+        offs = (C.c_void_p * G)(*[C.c_void_p(int(p)) for p in d_offsets])
+        cnt = np.asarray(counts, dtype=np.uint64)
+        _check(self._L.gcsa2_group_find_device(self._h, pats, offs, _p64(cnt), d_ranges_root))
 
     def close(self):
         if getattr(self, "_h", None):

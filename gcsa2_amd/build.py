@@ -7,11 +7,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "gcsa2_hip.hip")
 DEPS = [SRC, os.path.join(os.path.dirname(HERE), "include", "gcsa2_hip.h")] + \
        [os.path.join(HERE, "csrc", f) for f in ("layout.hpp", "kernels_common.hpp", "kernels_find.hpp",
-                                                 "kernels_locate.hpp", "kernels_lcp.hpp", "sdsl_reader.hpp")]
+                                                 "kernels_locate.hpp", "kernels_lcp.hpp", "sdsl_reader.hpp", "comm.hpp")]
 OUT = os.path.join(HERE, "lib", "libgcsa2_hip.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-         "-Wno-unused-result", "-Wno-unused-function"]
+         "-Wno-unused-result", "-Wno-unused-function", "-ldl"]
 
 
 def build(force=False, verbose=False):

@@ -1,0 +1,198 @@
+// comm.hpp -- the one collective of the query path: a gather of hit ranges on a root GPU over RCCL / xGMI.
+// Part of the single translation unit gcsa2_hip.hip.
+//
+// The path shards with no data-path exchange (queries are independent, the index is replicated; the
+// reference's only data-parallel query path is the static split of verifyIndex, src/algorithms.cpp:106-114),
+// so the only inter-GPU traffic is the final gather of (sp, ep) pairs.  It is a true gather, not a ring:
+// every peer owns a direct xGMI link into the root, so grouped ncclSend / ncclRecv pairs use all links at
+// once (a ring all-gather would be bound by one link and move G times the data).
+//
+// RCCL is bound at run time (dlopen) so that the library loads, and every single-GPU entry point works,
+// on hosts without RCCL; the comm entry points fail loudly with GCSA2_ERR_MISSING_COMPONENT there.
+// GCSA2_RCCL_LIB names the library to use (the Python binding points it at the RCCL that torch loaded,
+// so a process has one RCCL); default librccl.so.1, then librccl.so.
+#pragma once
+
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <mutex>
+
+namespace {
+
+struct RcclApi
+{
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+  bool ok = false;
+};
+
+RcclApi& rccl()
+{
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, []()
+  {
+    const char* env = std::getenv("GCSA2_RCCL_LIB");
+    const char* names[3] = { env, "librccl.so.1", "librccl.so" };
+    for(const char* name : names)
+    {
+      if(name == nullptr || *name == 0) { continue; }
+      api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if(api.handle != nullptr) { break; }
+      api.error = dlerror();
+    }
+    if(api.handle == nullptr) { api.error = "RCCL not loadable: " + api.error; return; }
+    bool all = true;
+    auto bind = [&](auto& fn, const char* symbol)
+    {
+      fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(api.handle, symbol));
+      if(fn == nullptr) { all = false; api.error = std::string("RCCL symbol missing: ") + symbol; }
+    };
+    bind(api.GetUniqueId, "ncclGetUniqueId"); bind(api.CommInitRank, "ncclCommInitRank");
+    bind(api.CommInitAll, "ncclCommInitAll"); bind(api.CommDestroy, "ncclCommDestroy");
+    bind(api.GroupStart, "ncclGroupStart"); bind(api.GroupEnd, "ncclGroupEnd");
+    bind(api.Send, "ncclSend"); bind(api.Recv, "ncclRecv"); bind(api.GetErrorString, "ncclGetErrorString");
+    api.ok = all;
+  });
+  return api;
+}
+
+#define RCCL_TRY(expr) do { ncclResult_t r_ = (expr); if(r_ != ncclSuccess) { \
+  return fail(GCSA2_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_)); } } while(0)
+
+// (sp, ep) u64 pairs <-> (sp, ep + 1 - sp) u32 pairs: exact whenever every path node and edge number of the
+// index is below 2^32 (an empty range is (x, x - 1), utils.h:93-96, so its length 0 restores ep = sp - 1 even
+// when that wraps).  Halves the bytes the gather moves over xGMI.
+__global__ __launch_bounds__(TPB) void k_pack_ranges32(const u64* __restrict__ in, u64 nq, uint2* __restrict__ out)
+{
+  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  const ulonglong2 r = reinterpret_cast<const ulonglong2*>(in)[q];
+  out[q] = make_uint2(u32(r.x), u32(r.y + 1 - r.x));
+}
+
+__global__ __launch_bounds__(TPB) void k_unpack_ranges32(const uint2* __restrict__ in, u64 nq, u64* __restrict__ out)
+{
+  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  const uint2 r = in[q];
+  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(u64(r.x), u64(r.x) + u64(r.y) - 1);
+}
+
+// grouped send / recv gather: rank r contributes bytes[r] bytes; the root receives them back to back in rank order
+int gather_bytes(ncclComm_t comm, int rank, int world, const void* d_send, const u64* bytes, void* d_recv, int root, hipStream_t st)
+{
+  RcclApi& api = rccl();
+  RCCL_TRY(api.GroupStart());
+  ncclResult_t r = ncclSuccess;
+  if(rank == root)
+  {
+    u64 at = 0;
+    for(int p = 0; p < world && r == ncclSuccess; p++)
+    {
+      if(p != root && bytes[p] > 0) { r = api.Recv(static_cast<char*>(d_recv) + at, bytes[p], ncclUint8, p, comm, st); }
+      at += bytes[p];
+    }
+  }
+  else if(bytes[rank] > 0) { r = api.Send(d_send, bytes[rank], ncclUint8, root, comm, st); }
+  ncclResult_t g = api.GroupEnd();
+  if(r != ncclSuccess) { return fail(GCSA2_ERR_HIP, std::string("ncclSend / ncclRecv: ") + api.GetErrorString(r)); }
+  if(g != ncclSuccess) { return fail(GCSA2_ERR_HIP, std::string("ncclGroupEnd: ") + api.GetErrorString(g)); }
+  if(rank == root && bytes[root] > 0)       // the root's own shard: a device-to-device copy on the same stream
+  {
+    u64 at = 0;
+    for(int p = 0; p < root; p++) { at += bytes[p]; }
+    if(static_cast<char*>(d_recv) + at != d_send)
+    {
+      HIP_TRY(hipMemcpyAsync(static_cast<char*>(d_recv) + at, d_send, bytes[root], hipMemcpyDeviceToDevice, st));
+    }
+  }
+  return GCSA2_OK;
+}
+
+}  // namespace
+
+struct gcsa2_comm
+{
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+};
+
+extern "C" {
+
+int gcsa2_comm_unique_id(uint8_t* id)
+{
+  if(id == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null id buffer"); }
+  RcclApi& api = rccl();
+  if(!api.ok) { return fail(GCSA2_ERR_MISSING_COMPONENT, api.error); }
+  static_assert(GCSA2_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId uid;
+  RCCL_TRY(api.GetUniqueId(&uid));
+  std::memcpy(id, uid.internal, NCCL_UNIQUE_ID_BYTES);
+  return GCSA2_OK;
+}
+
+int gcsa2_comm_create(const uint8_t* id, int rank, int world, int device, gcsa2_comm** out)
+{
+  if(id == nullptr || out == nullptr || world <= 0 || rank < 0 || rank >= world) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad communicator arguments"); }
+  *out = nullptr;
+  RcclApi& api = rccl();
+  if(!api.ok) { return fail(GCSA2_ERR_MISSING_COMPONENT, api.error); }
+  DeviceGuard guard(device);
+  if(!guard.ok) { return fail(GCSA2_ERR_HIP, "hipSetDevice failed"); }
+  gcsa2_comm* c = new(std::nothrow) gcsa2_comm();
+  if(c == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+  c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId uid;
+  std::memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
+  ncclResult_t r = api.CommInitRank(&c->comm, world, uid, rank);
+  if(r != ncclSuccess) { delete c; return fail(GCSA2_ERR_HIP, std::string("ncclCommInitRank: ") + api.GetErrorString(r)); }
+  *out = c;
+  return GCSA2_OK;
+}
+
+void gcsa2_comm_destroy(gcsa2_comm* c)
+{
+  if(c == nullptr) { return; }
+  if(c->comm != nullptr && rccl().ok) { DeviceGuard guard(c->device); (void)rccl().CommDestroy(c->comm); }
+  delete c;
+}
+
+int gcsa2_comm_rank(const gcsa2_comm* c) { return c == nullptr ? -1 : c->rank; }
+int gcsa2_comm_world(const gcsa2_comm* c) { return c == nullptr ? 0 : c->world; }
+
+int gcsa2_comm_gather(gcsa2_comm* c, const void* d_send, const uint64_t* bytes, void* d_recv, int root, void* stream)
+{
+  if(c == nullptr || bytes == nullptr || root < 0 || root >= c->world) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad gather arguments"); }
+  if(c->rank == root && d_recv == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "the root needs a receive buffer"); }
+  DeviceGuard guard(c->device);
+  return gather_bytes(c->comm, c->rank, c->world, d_send, bytes, d_recv, root, static_cast<hipStream_t>(stream));
+}
+
+int gcsa2_pack_ranges32_device(const uint64_t* d_ranges, uint64_t nq, uint32_t* d_packed, void* stream)
+{
+  if(nq == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_pack_ranges32, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream), d_ranges, nq, reinterpret_cast<uint2*>(d_packed));
+  LAUNCH_CHECK("k_pack_ranges32");
+  return GCSA2_OK;
+}
+
+int gcsa2_unpack_ranges32_device(const uint32_t* d_packed, uint64_t nq, uint64_t* d_ranges, void* stream)
+{
+  if(nq == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_unpack_ranges32, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const uint2*>(d_packed), nq, d_ranges);
+  LAUNCH_CHECK("k_unpack_ranges32");
+  return GCSA2_OK;
+}
+
+}  // extern "C"

@@ -455,8 +455,13 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
         if(e == hipSuccess)
         {
           img.flp_nblocks = nb;
-          hipLaunchKernelGGL(k_build_pair_blocks, dim3(unsigned(nb), 4), dim3(256), 0, nullptr, img, static_cast<u64*>(ix->d_pairs));
-          e = hipGetLastError();
+          const u64 slice = u64(1) << 20;          // blocks per launch: 2^20 x 4 workgroups of 256 threads
+          for(u64 first = 0; first < nb && e == hipSuccess; first += slice)
+          {
+            const u64 count = (nb - first < slice ? nb - first : slice);
+            hipLaunchKernelGGL(k_build_pair_blocks, dim3(unsigned(count), 4), dim3(256), 0, nullptr, img, first, static_cast<u64*>(ix->d_pairs));
+            e = hipGetLastError();
+          }
           if(e == hipSuccess) { e = hipDeviceSynchronize(); }
         }
         if(e != hipSuccess)
@@ -469,47 +474,51 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       }
     }
 
-    // k-mer seed table, only if comps 1..4 exist.  Default: the largest k <= 16 whose table (4^k entries
-    // of 8 or 16 bytes) is at most twice the index image itself -- each extra character saves one LF step per query
-    // (~5 % of a 32-mer) and quadruples the table; HBM capacity is what this GPU has to spare.  GCSA2_KMER_TABLE=k asks for exactly k (<= 16;
-    // 0 disables).  Either way the table must fit in a quarter of the free device memory.
+    // k-mer seed table, only if comps 1..4 exist.  Default: the largest k <= 16 whose table (4^k entries of 8 bytes)
+    // is at most twice the index image (with the pair blocks) -- each extra character saves one LF step per query
+    // and quadruples the table; HBM capacity is what this GPU has to spare.  GCSA2_KMER_TABLE=k asks for exactly
+    // k (<= 16; 0 disables).  Either way the table must fit in a quarter of the free device memory.
     u32 k = 0;
-    // entries are (sp, ep) as two u64, or two u32 when every value fits (path nodes and edges < 2^32 - 2)
-    img.kmer_compact = ((img.n > img.e ? img.n : img.e) + 2 < 0xFFFFFFFFull ? 1 : 0);
-    const u64 entry_bytes = (img.kmer_compact ? 8 : 16);
+    const u64 entry_bytes = 8;
     const char* env = std::getenv("GCSA2_KMER_TABLE");
-    if(env != nullptr)
     {
-      k = u32(std::atoi(env));
-      if(k > 16) { k = 16; }
       size_t free_bytes = 0, total_bytes = 0;
       if(hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { free_bytes = 0; }
-      while(k > 0 && (entry_bytes << (2 * k)) > free_bytes / 4) { k--; }
+      if(env != nullptr)
+      {
+        k = u32(std::atoi(env));
+        if(k > 16) { k = 16; }
+        while(k > 0 && (entry_bytes << (2 * k)) > free_bytes / 4) { k--; }
+      }
+      else
+      {
+        const u64 image_bytes = 2 * ix->bytes;
+        while(k < 16 && (entry_bytes << (2 * (k + 1))) <= image_bytes && (entry_bytes << (2 * (k + 1))) <= free_bytes / 4) { k++; }
+      }
     }
-    else
-    {
-      const u64 image_bytes = 2 * st.words.size() * sizeof(u64);
-      size_t free_bytes = 0, total_bytes = 0;
-      if(hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { free_bytes = 0; }
-      while(k < 16 && (entry_bytes << (2 * (k + 1))) <= image_bytes && (entry_bytes << (2 * (k + 1))) <= free_bytes / 4) { k++; }
-    }
-    if(img.sigma < 5) { k = 0; }
+    if(img.sigma < 5 || (img.n > img.e ? img.n : img.e) + 2 >= (u64(1) << SEED_SP_BITS)) { k = 0; }
     img.kmer_k = 0; img.kmer_table = nullptr;
     if(k > 0)
     {
       u64 entries = u64(1) << (2 * k);
       e = hipMalloc(&ix->d_kmer, entries * entry_bytes);
-      if(e == hipSuccess)
+      const u64 slice = u64(1) << 30;            // a HIP grid holds < 2^32 threads
+      for(u32 j = 0; j < k && e == hipSuccess; j++)
       {
-        const u64 slice = u64(1) << 30;
-        for(u64 first = 0; first < entries && e == hipSuccess; first += slice)
+        // level j + 1 from level j: first the quarters with a non-zero leading code, then level j in place
+        const u64 have = u64(1) << (2 * j), want = have << 2;
+        for(int pass = 0; pass < 2 && e == hipSuccess; pass++)
         {
-          u64 count = (entries - first < slice ? entries - first : slice);
-          hipLaunchKernelGGL(k_build_kmer_table, dim3(grid_for(count)), dim3(TPB), 0, nullptr, img, k, first, entries, static_cast<u64*>(ix->d_kmer));
-          e = hipGetLastError();
+          const u64 lo = (j == 0 ? 0 : (pass == 0 ? have : 0)), hi = (j == 0 ? (pass == 0 ? want : 0) : (pass == 0 ? want : have));
+          for(u64 first = lo; first < hi && e == hipSuccess; first += slice)
+          {
+            u64 count = (hi - first < slice ? hi - first : slice);
+            hipLaunchKernelGGL(k_seed_level, dim3(grid_for(count)), dim3(TPB), 0, nullptr, img, j, first, first + count, static_cast<u64*>(ix->d_kmer));
+            e = hipGetLastError();
+          }
         }
-        if(e == hipSuccess) { e = hipDeviceSynchronize(); }
       }
+      if(e == hipSuccess) { e = hipDeviceSynchronize(); }
       if(e != hipSuccess)
       {
         gcsa2_index_destroy(ix);
@@ -1283,15 +1292,29 @@ int gcsa2_locate_max(const gcsa2_index* ix, uint64_t sp, uint64_t ep, uint64_t m
   } catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_locate_max: ") + e.what()); }
 }
 
+}  // extern "C"
+
+#include "comm.hpp"
+
+extern "C" {
+
 // ---- single-process multi-GPU: replicated index, contiguous query shards ---------------------
 // Queries are independent and the index is read-only (the reference's only data-parallel query
 // path is the static split of verifyIndex, src/algorithms.cpp:106-114), so every device gets a
-// replica and a contiguous shard; one host thread per device stages its shard, runs k_find2 and
-// copies its ranges straight into the caller's buffer.  No device-to-device traffic.
+// replica and a contiguous shard.  gcsa2_group_find_batch (host buffers): one host thread per device
+// stages its shard, runs k_find2 and copies its ranges straight into the caller's buffer.
+// gcsa2_group_find_device (device buffers): every device searches its shard on its own stream and the
+// ranges are gathered in the root's HBM with one grouped RCCL send / recv over xGMI (comm.hpp).
 
 struct gcsa2_group
 {
   std::vector<gcsa2_index*> replicas;
+  std::vector<hipStream_t> streams;        // one per replica, on its device
+  std::vector<ncclComm_t> comms;           // ncclCommInitAll over the device list; empty = peer copies instead
+  std::vector<u64*> scratch;               // per replica: ranges of its shard before the gather (replicas 1..)
+  std::vector<u64> scratch_pairs;
+  bool comm_tried = false;
+  std::mutex lock;                         // group_find_device calls are serialized (they share streams and scratch)
 };
 
 int gcsa2_group_create(const gcsa2_host_view* view, const int* devices, int n_devices, gcsa2_group** out)
@@ -1304,13 +1327,20 @@ int gcsa2_group_create(const gcsa2_host_view* view, const int* devices, int n_de
   {
     gcsa2_index* ix = nullptr;
     int rc = gcsa2_index_create(view, devices[i], &ix);
+    hipStream_t st = nullptr;
+    if(rc == GCSA2_OK)
+    {
+      DeviceGuard guard(devices[i]);
+      if(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rc = fail(GCSA2_ERR_HIP, "hipStreamCreate failed"); gcsa2_index_destroy(ix); }
+    }
     if(rc != GCSA2_OK)
     {
-      for(gcsa2_index* r : g->replicas) { gcsa2_index_destroy(r); }
-      delete g;
-      return rc;
+      std::string msg = g_error;
+      gcsa2_group_destroy(g);
+      return fail(rc, msg);
     }
-    g->replicas.push_back(ix);
+    g->replicas.push_back(ix); g->streams.push_back(st);
+    g->scratch.push_back(nullptr); g->scratch_pairs.push_back(0);
   }
   *out = g;
   return GCSA2_OK;
@@ -1319,8 +1349,103 @@ int gcsa2_group_create(const gcsa2_host_view* view, const int* devices, int n_de
 void gcsa2_group_destroy(gcsa2_group* g)
 {
   if(g == nullptr) { return; }
+  for(size_t i = 0; i < g->comms.size(); i++)
+  {
+    if(g->comms[i] != nullptr) { DeviceGuard guard(g->replicas[i]->device); (void)rccl().CommDestroy(g->comms[i]); }
+  }
+  for(size_t i = 0; i < g->replicas.size(); i++)
+  {
+    DeviceGuard guard(g->replicas[i]->device);
+    if(i < g->streams.size() && g->streams[i] != nullptr) { (void)hipStreamDestroy(g->streams[i]); }
+    if(i < g->scratch.size() && g->scratch[i] != nullptr) { (void)hipFree(g->scratch[i]); }
+  }
   for(gcsa2_index* r : g->replicas) { gcsa2_index_destroy(r); }
   delete g;
+}
+
+int gcsa2_group_uses_rccl(const gcsa2_group* g) { return (g != nullptr && !g->comms.empty()) ? 1 : 0; }
+
+int gcsa2_group_find_device(gcsa2_group* g, const uint8_t* const* d_patterns, const uint64_t* const* d_offsets,
+                            const uint64_t* counts, uint64_t* d_ranges_root)
+{
+  if(g == nullptr || g->replicas.empty()) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null or empty group"); }
+  if(d_patterns == nullptr || d_offsets == nullptr || counts == nullptr || d_ranges_root == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  try {
+  std::lock_guard<std::mutex> hold(g->lock);
+  const int G = int(g->replicas.size());
+  if(!g->comm_tried)
+  {
+    // One communicator per device (ncclCommInitAll).  RCCL needs distinct devices; a group that lists a device
+    // twice (or a host without RCCL) gathers with peer copies instead.
+    g->comm_tried = true;
+    std::vector<int> devs;
+    bool distinct = true;
+    for(int r = 0; r < G; r++)
+    {
+      for(int d : devs) { distinct = distinct && d != g->replicas[r]->device; }
+      devs.push_back(g->replicas[r]->device);
+    }
+    if(G > 1 && distinct && rccl().ok)
+    {
+      g->comms.assign(size_t(G), nullptr);
+      ncclResult_t r = rccl().CommInitAll(g->comms.data(), G, devs.data());
+      if(r != ncclSuccess) { g->comms.clear(); return fail(GCSA2_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(r)); }
+    }
+  }
+  // every replica searches its shard on its own stream; replica 0 writes straight into the result buffer
+  std::vector<u64> first(size_t(G) + 1, 0);
+  for(int r = 0; r < G; r++) { first[size_t(r) + 1] = first[size_t(r)] + counts[r]; }
+  for(int r = 0; r < G; r++)
+  {
+    if(counts[r] == 0) { continue; }
+    u64* dst = d_ranges_root;
+    if(r > 0)
+    {
+      DeviceGuard guard(g->replicas[r]->device);
+      if(g->scratch_pairs[r] < counts[r])
+      {
+        if(g->scratch[r] != nullptr) { (void)hipFree(g->scratch[r]); g->scratch[r] = nullptr; g->scratch_pairs[r] = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->scratch[r]), counts[r] * 2 * sizeof(u64)));
+        g->scratch_pairs[r] = counts[r];
+      }
+      dst = g->scratch[r];
+    }
+    int rc = gcsa2_find_device(g->replicas[r], d_patterns[r], d_offsets[r], counts[r], dst, g->streams[r]);
+    if(rc != GCSA2_OK) { return rc; }
+  }
+  // the gather: ranges of replica r land at d_ranges_root + 2 * first[r]
+  if(!g->comms.empty())
+  {
+    RcclApi& api = rccl();
+    RCCL_TRY(api.GroupStart());
+    ncclResult_t res = ncclSuccess;
+    for(int r = 1; r < G && res == ncclSuccess; r++)
+    {
+      if(counts[r] == 0) { continue; }
+      res = api.Send(g->scratch[r], counts[r] * 2, ncclUint64, 0, g->comms[r], g->streams[r]);
+      if(res == ncclSuccess) { res = api.Recv(d_ranges_root + 2 * first[r], counts[r] * 2, ncclUint64, r, g->comms[0], g->streams[0]); }
+    }
+    ncclResult_t end = api.GroupEnd();
+    if(res != ncclSuccess) { return fail(GCSA2_ERR_HIP, std::string("ncclSend / ncclRecv: ") + api.GetErrorString(res)); }
+    if(end != ncclSuccess) { return fail(GCSA2_ERR_HIP, std::string("ncclGroupEnd: ") + api.GetErrorString(end)); }
+  }
+  else
+  {
+    for(int r = 1; r < G; r++)
+    {
+      if(counts[r] == 0) { continue; }
+      DeviceGuard guard(g->replicas[r]->device);
+      HIP_TRY(hipMemcpyPeerAsync(d_ranges_root + 2 * first[r], g->replicas[0]->device, g->scratch[r], g->replicas[r]->device,
+                                 counts[r] * 2 * sizeof(u64), g->streams[r]));
+    }
+  }
+  for(int r = 0; r < G; r++)
+  {
+    DeviceGuard guard(g->replicas[r]->device);
+    HIP_TRY(hipStreamSynchronize(g->streams[r]));
+  }
+  return GCSA2_OK;
+  } catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_group_find_device: ") + e.what()); }
 }
 
 int gcsa2_group_size(const gcsa2_group* g) { return g == nullptr ? 0 : int(g->replicas.size()); }

@@ -61,24 +61,49 @@ __global__ __launch_bounds__(TPB) void k_find(DevImage img, const u8* __restrict
 // the exact (sp, ep) the backward search returns, including edge-space empty ranges, so that
 // k_find2 can start a pattern whose last k characters are all fast characters at step k.
 // Pure memoisation of gcsa.h:96-110; results are unchanged.
-__global__ __launch_bounds__(TPB) void k_build_kmer_table(DevImage img, u32 k, u64 first, u64 entries, u64* __restrict__ table)
+//
+// One entry = 8 bytes: sp in bits [0, 40), len = ep + 1 - sp in bits [40, 64).  An empty range has
+// len = 0 (LF-produced empties and charRange of an absent character are always (x, x - 1), utils.h:93-96);
+// len = SEED_WIDE marks a range of 2^24 - 1 or more path nodes, which is searched from scratch instead.
+constexpr u64 SEED_SP_BITS = 40, SEED_SP_MASK = (u64(1) << SEED_SP_BITS) - 1, SEED_WIDE = (u64(1) << 24) - 1;
+__device__ __forceinline__ u64 seed_pack(u64 sp, u64 ep)
 {
-  u64 tix = first + u64(blockIdx.x) * TPB + threadIdx.x;     // launched in slices: a grid holds < 2^32 threads
-  if(tix >= entries) { return; }
-  u32 comp = 1 + u32(tix & 3);                               // last character
-  u64 sp = img.crange[2 * comp], ep = img.crange[2 * comp + 1];
-  for(u32 j = 1; j < k && !range_empty(sp, ep); j++)
+  const u64 len = ep + 1 - sp;
+  return (sp & SEED_SP_MASK) | ((len < SEED_WIDE ? len : SEED_WIDE) << SEED_SP_BITS);
+}
+
+// The table is built in place, level by level: the (j + 1)-mer t extends the j-mer t & (4^j - 1) by the character
+// 1 + (t >> 2j) in front, i.e. by one LF step (gcsa.h:103-107).  Launch 1 of a level writes the three quarters
+// with a non-zero leading code (reading level j, untouched), launch 2 extends the entries of level j themselves.
+// A wide entry is recomputed from scratch (only the top levels of a large index have such ranges).
+__global__ __launch_bounds__(TPB) void k_seed_level(DevImage img, u32 j, u64 first, u64 last, u64* __restrict__ table)
+{
+  const u64 tix = first + u64(blockIdx.x) * TPB + threadIdx.x;
+  if(tix >= last) { return; }
+  u64 sp, ep;
+  if(j == 0) { const u32 c = 1 + u32(tix & 3); sp = img.crange[2 * c]; ep = img.crange[2 * c + 1]; }
+  else
   {
-    comp = 1 + u32((tix >> (2 * j)) & 3);
-    DevBV bv = bwt_of(img, comp);
-    u64 ra, rb;
-    bv_rank2(bv, sp, ep + 1, ra, rb);
-    sp = img.C[comp] + ra; ep = img.C[comp] + rb - 1;
-    if(range_empty(sp, ep)) { break; }
-    path_node_range(img, sp, ep);
+    const u64 prev = table[tix & ((u64(1) << (2 * j)) - 1)];
+    u32 from = j;
+    sp = prev & SEED_SP_MASK; ep = sp + (prev >> SEED_SP_BITS) - 1;
+    if((prev >> SEED_SP_BITS) == SEED_WIDE)
+    {
+      const u32 c = 1 + u32(tix & 3);
+      sp = img.crange[2 * c]; ep = img.crange[2 * c + 1]; from = 1;
+    }
+    for(u32 s = from; s <= j && !range_empty(sp, ep); s++)
+    {
+      const u32 comp = 1 + u32((tix >> (2 * s)) & 3);
+      DevBV bv = bwt_of(img, comp);
+      u64 ra, rb;
+      bv_rank2(bv, sp, ep + 1, ra, rb);
+      sp = img.C[comp] + ra; ep = img.C[comp] + rb - 1;
+      if(range_empty(sp, ep)) { break; }
+      path_node_range(img, sp, ep);
+    }
   }
-  if(img.kmer_compact) { reinterpret_cast<uint2*>(table)[tix] = make_uint2(u32(sp), u32(ep)); }      // ~0 -> 0xFFFFFFFF
-  else { reinterpret_cast<ulonglong2*>(table)[tix] = make_ulonglong2(sp, ep); }
+  table[tix] = seed_pack(sp, ep);
 }
 
 // ---- find, version 2: fused 128-byte LF blocks, wave-cooperative fetch through LDS -----------
@@ -303,7 +328,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
 
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  u64 blocks = 0, steps = 0, lookups = 0;
+  u64 blocks = 0, steps = 0, lookups = 0, jumps = 0;
 
   u64 q = ~u64(0), sp = 0, ep = img.n - 1, i = 0;
   const u8* p = patterns;
@@ -343,18 +368,14 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
         }
         if(fast)
         {
-          if(img.kmer_compact)
-          {
-            uint2 r = reinterpret_cast<const uint2*>(img.kmer_table)[tix];
-            sp = (r.x == 0xFFFFFFFFu ? ~u64(0) : u64(r.x)); ep = (r.y == 0xFFFFFFFFu ? ~u64(0) : u64(r.y));
-          }
-          else
-          {
-            ulonglong2 r = reinterpret_cast<const ulonglong2*>(img.kmer_table)[tix];
-            sp = r.x; ep = r.y;
-          }
-          i = len - k; seeded = true;
+          const u64 entry = img.kmer_table[tix];
+          sp = entry & SEED_SP_MASK; ep = sp + (entry >> SEED_SP_BITS) - 1;
+          fast = (entry >> SEED_SP_BITS) != SEED_WIDE;         // a wide range is not in the table
           if(STATS) { lookups++; }
+        }
+        if(fast)
+        {
+          i = len - k; seeded = true;
         }
       }
       if(!seeded)
@@ -543,7 +564,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
         usable = (usable < len ? usable : len);
         usable = (usable < i ? usable : u32(i));
         u32 take = (usable == len ? len : (usable >= 4 ? 4u : (usable >= 2 ? 2u : 0u)));
-        if(STATS) { lookups++; }
+        if(STATS) { jumps++; }
         if(take > 0)
         {
           sp = ep = (take == len ? jt_end(entry) : (take == 4 ? jt_after4(entry) : jt_after2(entry)));
@@ -566,22 +587,23 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     for(int o = 32; o > 0; o >>= 1)
     {
       blocks += __shfl_down(blocks, o, 64); steps += __shfl_down(steps, o, 64); lookups += __shfl_down(lookups, o, 64);
+      jumps += __shfl_down(jumps, o, 64);
     }
     if(lane == 0)
     {
       atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps);
-      atomicAdd(stats + 2, (unsigned long long)lookups);
+      atomicAdd(stats + 2, (unsigned long long)lookups); atomicAdd(stats + 3, (unsigned long long)jumps);
     }
   }
 }
 
 // ---- FLP128 pair blocks (layout.hpp), built on the device from the RB64 vectors -----------------------
-// grid (nblocks, 4): workgroup (b, c2 - 1) of 256 threads writes block b of the four pairs (c1, c2),
-// c1 = 1..4; thread r owns position i = 256 b + r.
-__global__ __launch_bounds__(256) void k_build_pair_blocks(DevImage img, u64* __restrict__ out)
+// grid (blocks, 4), launched in slices of blocks (a HIP grid holds < 2^32 threads): workgroup (b - first, c2 - 1)
+// of 256 threads writes block b of the four pairs (c1, c2), c1 = 1..4; thread r owns position i = 256 b + r.
+__global__ __launch_bounds__(256) void k_build_pair_blocks(DevImage img, u64 first, u64* __restrict__ out)
 {
   __shared__ u64 s_ecnt[4];
-  const u64 b = blockIdx.x, nb = img.flp_nblocks;
+  const u64 b = first + blockIdx.x, nb = img.flp_nblocks;
   const u32 c2 = 1 + blockIdx.y, r = threadIdx.x;
   const u64 i = b * PAIR_BITS + r, n = img.n, e = img.e;
   const bool valid = i <= n;

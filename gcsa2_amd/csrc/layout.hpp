@@ -98,10 +98,9 @@ struct DevImage
   u64 crange[2 * MAX_SIGMA];   // charRange(c) in node space, precomputed (gcsa.h:150-153)
   const u64* pred4;            // 4 bits per path node: bits 0-2 = comp of the first incoming edge
                                // (gcsa.h:165-183 probe order), bit 3 = sampled(node); nullptr if sigma > 8
-  const u64* kmer_table;       // find() of every k-mer over comps 1..4: (sp, ep) pairs, 4^kmer_k entries
+  const u64* kmer_table;       // find() of every k-mer over comps 1..4: 4^kmer_k packed entries (kernels_find.hpp, seed_pack)
   u32 kmer_k;                  // 0 = no table
-  u32 kmer_compact;            // 1: entries are (u32, u32) -- every range value of this index is below 2^32 - 1
-                               // (0xFFFFFFFF stands for the wrapped -1 of an empty range starting at 0)
+  u32 reserved0;
   const ulonglong2* jump_tab;  // memoised unary LF chains, one entry per path node, or nullptr: x = node reached | steps << 56
                                // (0..8 steps), y = the comps (minus 1) of those steps, 2 bits each, first step lowest
   const u64* locate_tab;       // memoised locateInternal walk (gcsa.cpp:880-896), one u64 per path node, or nullptr:

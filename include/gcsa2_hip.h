@@ -149,13 +149,15 @@ int gcsa2_find_device_variant(const gcsa2_index* index, int variant, const uint8
 
 /* Instrumented find for the roofline model (not the timed path): same results in d_ranges, and
  * d_stats[0] += number of distinct fused LF blocks fetched (gcsa2_find_block_bytes() each),
- * d_stats[1] += LF steps executed, d_stats[2] += seed-table lookups (16 bytes each).  A step whose
- * two endpoints fall into one block counts once.  The caller zeroes the three
- * counters of d_stats. */
+ * d_stats[1] += LF steps executed, d_stats[2] += seed-table lookups (8 bytes each), d_stats[3] += jump-table
+ * lookups (16 bytes each).  A step whose two endpoints fall into one block counts once; a
+ * two-character step counts as two LF steps and one block per distinct endpoint block, and a replayed pair
+ * counts every block it fetched.  The caller zeroes the four counters of d_stats. */
 uint64_t gcsa2_find_block_bytes(const gcsa2_index* index);
 /* Length k of the k-mer seed table built at create time (find() of every k-mer over comps 1..4,
  * memoised: a pattern whose last k characters are fast characters starts at step k).  0 = none.
- * Environment variable GCSA2_KMER_TABLE caps k (0 disables). */
+ * One entry is 8 bytes (sp in 40 bits, range length in 24; the few ranges of 2^24 - 1 or more path nodes are
+ * marked and searched from scratch).  Environment variable GCSA2_KMER_TABLE sets k (0 disables). */
 uint64_t gcsa2_kmer_table_k(const gcsa2_index* index);
 /* Bytes of the memoised locate table (0 = none): the walk of locateInternal (src/gcsa.cpp:880-896)
  * depends on the start node only, so it is run once per path node at create time and locate() reads
@@ -346,6 +348,39 @@ int gcsa2_group_size(const gcsa2_group* group);
 const gcsa2_index* gcsa2_group_index(const gcsa2_group* group, int i);
 int gcsa2_group_find_batch(const gcsa2_group* group, const uint8_t* patterns, const uint64_t* offsets,
                            uint64_t n_queries, uint64_t* ranges);
+
+/* The same split with every shard already in the HBM of its device: d_patterns[r] / d_offsets[r] (offsets
+ * rebased to 0, counts[r] + 1 entries) live on the device of replica r, d_ranges_root (2 x sum of counts words)
+ * on the device of replica 0.  Every replica searches its shard on its own stream; the ranges are then gathered
+ * in the root's HBM, in query order, by one grouped RCCL send / recv over xGMI (ncclCommInitAll over the device
+ * list, created at the first call) -- or by peer copies when the group lists a device twice or RCCL is not
+ * available (gcsa2_group_uses_rccl tells which).  Complete on return. */
+int gcsa2_group_find_device(gcsa2_group* group, const uint8_t* const* d_patterns, const uint64_t* const* d_offsets,
+                            const uint64_t* counts, uint64_t* d_ranges_root);
+int gcsa2_group_uses_rccl(const gcsa2_group* group);
+
+/* ---- multi-process multi-GPU: one rank per GPU, one gather of hit ranges ----------------------
+ * The single collective of the path: every rank searches its shard with gcsa2_find_device and
+ * the (sp, ep) pairs are gathered in the root's HBM with grouped ncclSend / ncclRecv -- every peer uses its own
+ * xGMI link into the root.  The communicator is RCCL's (ncclCommInitRank); the 128-byte id is created on one
+ * rank and handed to the others by whatever launcher the application has (bench.py: the torch.distributed store).
+ * RCCL is bound at run time; without it these calls fail with GCSA2_ERR_MISSING_COMPONENT. */
+#define GCSA2_COMM_ID_BYTES 128
+typedef struct gcsa2_comm gcsa2_comm;
+int gcsa2_comm_unique_id(uint8_t* id /* GCSA2_COMM_ID_BYTES */);
+int gcsa2_comm_create(const uint8_t* id, int rank, int world, int device, gcsa2_comm** out);
+void gcsa2_comm_destroy(gcsa2_comm* comm);
+int gcsa2_comm_rank(const gcsa2_comm* comm);
+int gcsa2_comm_world(const gcsa2_comm* comm);
+/* Rank r contributes bytes[r] bytes from d_send (bytes[] has `world` entries and is the same on every rank);
+ * the root receives them back to back in rank order in d_recv (its own part by a device copy; d_recv may be
+ * NULL elsewhere).  Enqueues on `stream` of the communicator's device and does not synchronise. */
+int gcsa2_comm_gather(gcsa2_comm* comm, const void* d_send, const uint64_t* bytes, void* d_recv, int root, void* stream);
+/* Wire format for indexes whose path node and edge numbers are all below 2^32: (sp, ep) u64 pairs <->
+ * (sp, ep + 1 - sp) u32 pairs, exact for every range find() returns (an empty range is (x, x - 1),
+ * include/gcsa/utils.h:93-96).  Halves the bytes of the gather.  Launch on the current device. */
+int gcsa2_pack_ranges32_device(const uint64_t* d_ranges, uint64_t n_queries, uint32_t* d_packed, void* stream);
+int gcsa2_unpack_ranges32_device(const uint32_t* d_packed, uint64_t n_queries, uint64_t* d_ranges, void* stream);
 
 #ifdef __cplusplus
 }

@@ -161,3 +161,31 @@ def substring_patterns(sym_t: torch.Tensor, rank: np.ndarray, nq: int, m: int, s
     pos = start.cpu().numpy()
     exp = rank[pos].astype(np.uint64)
     return out.cpu().numpy(), np.stack([exp, exp], axis=1)
+
+
+def splitmix64_range_torch(seed: int, first: int, count: int, device) -> torch.Tensor:
+    """Outputs first .. first + count - 1 (0-based) of SplitMix64(seed) as int64 bit patterns."""
+    from .linear_torch import _s64
+    idx = torch.arange(first + 1, first + count + 1, dtype=torch.int64, device=device)
+    z = idx * _s64(0x9E3779B97F4A7C15) + _s64(seed)
+    z = (z ^ _lsr(z, 30)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * _s64(0x94D049BB133111EB)
+    return z ^ _lsr(z, 31)
+
+
+def substring_patterns_device(sym_t: torch.Tensor, first: int, count: int, m: int, seed: int):
+    """Queries first .. first + count - 1 of the global batch `seed`, kept on the device: (patterns (count, m)
+    uint8 bytes, start positions int64).  Query q starts at position (splitmix64(seed)[q] >> 11) % N of the
+    cyclic text, so a shard of the batch is the same whichever rank generates it."""
+    device = sym_t.device
+    N = sym_t.shape[0]
+    start = _lsr(splitmix64_range_torch(seed, first, count, device), 11) % N
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    out = torch.empty((count, m), dtype=torch.uint8, device=device)
+    chunk = 1 << 24
+    for b in range(0, count, chunk):
+        e = min(count, b + chunk)
+        idx = (start[b:e].view(-1, 1) + torch.arange(m, dtype=torch.int64, device=device).view(1, -1)) % N
+        out[b:e] = lut[sym_t[idx].to(torch.int64)]
+        del idx
+    return out, start
