@@ -4,7 +4,9 @@
             (find -> parent -> depth -> count -> locate, reference benchmark/query_gcsa.cpp:87-169)
             compared with the oracle on every query.
   config 2  (reduced: 2^21 bases) full parity incl. uniform patterns that die early.
-  config 2  (full: 2^25 bases, 10 M 32-mers) size-independent properties + oracle on a sample.
+  config 2/3 (full: 2^25 bases, 10 M 32-mers) size-independent properties, locate() of all 10 M ranges, oracle on the batch.
+  config 4/5 (whole-human footprint: 4.29 G path nodes) find / locate / parent / 256-bp patterns with parent() on
+            failure against closed-form answers for every query, and against the oracle on samples.
 """
 import numpy as np
 import pytest
@@ -94,8 +96,8 @@ def test_config2_full_size_properties():
     assert bool(np.all(par["sp"] <= sample[:, 0])) and bool(np.all(par["ep"] >= sample[:, 1]))
     assert bool(np.all((par["ep"] - par["sp"]) > (sample[:, 1] - sample[:, 0])))
     assert bool(np.all(par["node_lcp"] < m))
-    # 4. count == |locate| and located values are sorted and distinct (first 200 k queries)
-    sub = ranges[:200_000]
+    # 4. config 3: count == |locate| and located values are sorted and distinct, for ALL 10 M ranges
+    sub = ranges
     loff, lval = gpu.locate_batch(sub)
     assert np.array_equal(np.diff(loff), gpu.count_batch(sub))
     seg = np.repeat(np.arange(sub.shape[0]), np.diff(loff).astype(np.int64))
@@ -153,3 +155,121 @@ def test_mseq_index_closed_form_on_gpu():
     assert np.array_equal(par["sp"].astype(np.int64), np.maximum(lo, 1) - 1)
     assert np.array_equal(par["ep"].astype(np.int64), np.minimum(lo + (np.int64(1) << shift) - 1, ix.n) - 1)
     assert np.array_equal(par["node_lcp"].astype(np.int64), L)
+
+
+def test_whole_human_footprint_closed_form():
+    """BASELINE configs[3] and [4] at their index footprint on one GPU: the degree-32 m-sequence index (4 294 967 295 path
+    nodes, the size of the paper's whole-genome indexes, paper.tex:378-380) with samples, counters and the LCP array.
+    Every find() / locate() / parent() answer is known in closed form; the substituted 256-bp patterns (LF + parent
+    interplay, reference src/algorithms.cpp:146-167 shape) are checked against the oracle on a sample."""
+    import torch
+    from workload import mseq_torch
+    from gcsa2_amd.binding import GCSA
+    from oracle.oracle import OracleIndex
+    dev = torch.device("cuda", 0)
+    degree, k = 32, 16
+    ix, sym_t, rank = mseq_torch.build_mseq(degree, device=dev, full=True)
+    rank_t = torch.from_numpy(rank.view(np.int32)).to(dev)
+    del rank
+    gpu = GCSA(ix, device=0)
+    assert gpu.size() == (1 << 32) - 1 and gpu.pair_block_bytes() > 0 and gpu.locate_table_bytes() > 0
+    st = torch.cuda.current_stream().cuda_stream
+
+    def batch(nq, m, seed):
+        pats, start = mseq_torch.substring_patterns_device(sym_t, 0, nq, m, seed)
+        flat = torch.zeros(nq * m + 8, dtype=torch.uint8, device=dev)
+        flat[: nq * m] = pats.reshape(-1)
+        return pats, flat, torch.arange(nq + 1, dtype=torch.int64, device=dev) * m, start
+
+    # config 4: 20 M 32-mers, every range = (rank[p], rank[p])
+    nq, m = 20_000_000, 32
+    _, d_pat, d_off, start = batch(nq, m, 0x6C5A0041)
+    d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), st)
+    torch.cuda.synchronize()
+    exp = rank_t[start].to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(d_out[:, 0], exp) and torch.equal(d_out[:, 1], exp)
+    # ... also through the single-character kernel (GCSA2_PAIR_BLOCKS=0 path is variant 1's older sibling: k_find)
+    d_out1 = torch.zeros_like(d_out)
+    gpu.find_device_variant(1, d_pat.data_ptr(), d_off.data_ptr(), 2_000_000, d_out1.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out1[:2_000_000], d_out[:2_000_000])
+    # locate: the rotation starting at position p carries exactly the value of p; count = 1
+    d_loff = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
+    d_lval = torch.zeros(nq, dtype=torch.int64, device=dev)
+    assert gpu.locate_into(d_out.data_ptr(), nq, d_loff.data_ptr(), d_lval.data_ptr(), nq, st) == nq
+    torch.cuda.synchronize()
+    assert torch.equal(d_loff, torch.arange(nq + 1, dtype=torch.int64, device=dev))
+    assert np.array_equal(d_lval.cpu().numpy().view(np.uint64), mseq_torch.node_values(start.cpu().numpy()))
+    d_cnt = torch.zeros(nq, dtype=torch.int64, device=dev)
+    gpu.count_device(d_out.data_ptr(), nq, d_cnt.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert bool((d_cnt == 1).all())
+    # parent of a singleton: all k-mer values sharing the first L digits, L = max of the two adjacent LCP values
+    np_q = 4_000_000
+    d_nodes = torch.zeros((np_q, 5), dtype=torch.int64, device=dev)
+    gpu.parent_device(d_out.data_ptr(), np_q, d_nodes.data_ptr(), st)
+    torch.cuda.synchronize()
+    lcpv = torch.from_numpy(ix.lcp_data[: ix.n]).to(dev)
+    r = exp[:np_q]
+    right = torch.where(r + 1 < ix.n, lcpv[torch.clamp(r + 1, max=ix.n - 1)].to(torch.int64), torch.zeros_like(r))
+    L = torch.maximum(lcpv[r].to(torch.int64), right)
+    shift = 2 * (k - L)
+    lo = ((r + 1) >> shift) << shift
+    assert torch.equal(d_nodes[:, 0], torch.clamp(lo, min=1) - 1)
+    assert torch.equal(d_nodes[:, 1], torch.clamp(lo + (torch.ones_like(lo) << shift) - 1, max=ix.n) - 1)
+    assert torch.equal(d_nodes[:, 4], L)
+    del lcpv, d_nodes, d_loff, d_lval, d_cnt, d_out1
+
+    # config 5: 256-bp patterns, every second one with a substitution every 41 bp
+    nq, m = 1_000_000, 256
+    pats, _, d_off, start = batch(nq, m, 0x6C5A0050)
+    nxt = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"CGTA"):
+        nxt[a] = b
+    for col in range(37, m, 41):
+        pats[1::2, col] = nxt[pats[1::2, col].to(torch.int64)]
+    d_pat = torch.zeros(nq * m + 8, dtype=torch.uint8, device=dev)
+    d_pat[: nq * m] = pats.reshape(-1)
+    exp = rank_t[start].to(torch.int64) & 0xFFFFFFFF
+    d_find = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_find.data_ptr(), st)
+    d_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev)
+    d_rng = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    d_fb = torch.zeros(nq, dtype=torch.int64, device=dev)
+    gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(d_find[0::2, 0], exp[0::2]) and torch.equal(d_find[0::2, 1], exp[0::2])
+    assert bool((d_find[1::2, 0] > d_find[1::2, 1]).all())          # a substituted pattern does not occur (every 16-mer is unique)
+    ms2d = d_ms[: nq * m].view(nq, m)
+    assert torch.equal(d_rng[0::2, 0], exp[0::2]) and torch.equal(d_rng[0::2, 1], exp[0::2]) and bool((d_fb[0::2] == 0).all())
+    assert bool((ms2d[0::2] == (m - torch.arange(m, device=dev)).to(torch.int16).view(1, m)).all())
+    assert bool((d_fb[1::2] > 0).all())
+    # locate() of the final ranges: count() values each (query_gcsa.cpp:171-179), closed form for the unmodified half
+    d_loff = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
+    d_cnt = torch.zeros(nq, dtype=torch.int64, device=dev)
+    gpu.count_device(d_rng.data_ptr(), nq, d_cnt.data_ptr(), st)
+    torch.cuda.synchronize()
+    total = int(d_cnt.sum().item())
+    d_lval = torch.zeros(total, dtype=torch.int64, device=dev)
+    assert gpu.locate_into(d_rng.data_ptr(), nq, d_loff.data_ptr(), d_lval.data_ptr(), total, st) == total
+    torch.cuda.synchronize()
+    assert torch.equal(d_loff[1:] - d_loff[:-1], d_cnt)
+    assert np.array_equal(d_lval[d_loff[:-1][0::2]].cpu().numpy().view(np.uint64), mseq_torch.node_values(start[0::2].cpu().numpy()))
+    # the oracle on a sample: find, matching statistics (LF + parent), parent of the final ranges
+    cpu = OracleIndex(ix, with_samples=False, with_counters=False)
+    ns = 3000
+    flat = d_pat[: ns * m].cpu().numpy()
+    off = np.arange(ns + 1, dtype=np.uint64) * np.uint64(m)
+    assert np.array_equal(d_find[:ns].cpu().numpy().view(np.uint64), cpu.find_batch(flat, off, threads=8))
+    cm, cr, cf = cpu.match_stats_batch(flat, off, threads=8)
+    assert np.array_equal(d_ms[: ns * m].cpu().numpy().view(np.uint16), cm)
+    assert np.array_equal(d_rng[:ns].cpu().numpy().view(np.uint64), cr)
+    assert np.array_equal(d_fb[:ns].cpu().numpy().view(np.uint64), cf)
+    d_nodes = torch.zeros((ns, 5), dtype=torch.int64, device=dev)
+    gpu.parent_device(d_rng.data_ptr(), ns, d_nodes.data_ptr(), st)
+    torch.cuda.synchronize()
+    want = cpu.parent_batch(cr, threads=8)
+    got = d_nodes.cpu().numpy().view(np.uint64)
+    for col, name in enumerate(("sp", "ep", "left_lcp", "right_lcp", "node_lcp")):
+        assert np.array_equal(got[:, col], want[name]), name
