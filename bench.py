@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the config-5 and chr22 measurements")
+    ap.add_argument("--secondary", choices=["all", "config5", "chr22"], default="all", help="N = 1: which secondary measurements to run")
     ap.add_argument("--variant", type=int, default=2, help="find kernel generation (1 = k_find, 2 = k_find2)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
@@ -683,10 +684,10 @@ def main():
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds)
     secondary = args.workload == "human" and world == 1 and not args.no_secondary
-    if secondary:
+    if secondary and args.secondary in ("all", "config5"):
         result["config5"] = config5(args, wl, dev)
     del r
-    if secondary:
+    if secondary and args.secondary in ("all", "chr22"):
         del wl
         torch.cuda.empty_cache()
         result["chr22"] = chr22_secondary(args, D, dev, local_rank)

@@ -1600,8 +1600,26 @@ extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_
   DeviceGuard guard(ix->device);
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
   if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
-  hipLaunchKernelGGL(k_match_stats, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
-                     ix->img, d_patterns, d_offsets, nq, reinterpret_cast<unsigned short*>(d_ms), d_ranges, d_fallbacks);
+  // GCSA2_MATCH_STATS=1 runs the first-generation kernel (one lane per pattern, no cooperation) for A/B measurements;
+  // GCSA2_PARENT_BATCH sets how many lanes of a wave must wait for parent() before the wave runs it (default 1)
+  static const int generation = []() { const char* e = std::getenv("GCSA2_MATCH_STATS"); return e != nullptr ? std::atoi(e) : 2; }();
+  static const u32 batch = []() { const char* e = std::getenv("GCSA2_PARENT_BATCH"); int v = (e != nullptr ? std::atoi(e) : int(PARENT_BATCH)); return u32(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+  unsigned short* out = reinterpret_cast<unsigned short*>(d_ms);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if(generation == 1)
+  {
+    hipLaunchKernelGGL(k_match_stats, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks);
+  }
+  else if(ix->img.flp != nullptr)
+  {
+    hipLaunchKernelGGL(k_match_stats2<true>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch);
+  }
+  else
+  {
+    hipLaunchKernelGGL(k_match_stats2<false>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch);
+  }
   LAUNCH_CHECK("k_match_stats");
   return GCSA2_OK;
 }

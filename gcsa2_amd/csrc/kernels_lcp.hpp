@@ -59,10 +59,25 @@ __device__ __forceinline__ bool scan_left(const DevImage& img, u64 from, u64 to,
   {
     const u64 top = (to - 1) >> 3, bottom = from >> 3;
     u64 w[SCAN_WORDS];
+    // the nearest word alone first: the previous smaller value is usually within a few positions, and one
+    // load per lane is one memory request instead of eight
+    w[0] = words[top];
+    {
+      u32 mask = bytes_below(w[0], bound);
+      if(to < (top << 3) + 8) { mask &= (1u << (to - (top << 3))) - 1; }
+      if(from > (top << 3)) { mask &= ~((1u << (from - (top << 3))) - 1); }
+      if(mask != 0)
+      {
+        u32 byte = 31 - __clz(int(mask));
+        rpos = (top << 3) + byte; rval = (w[0] >> (8 * byte)) & 0xFF;
+        return true;
+      }
+      if(top == bottom) { return false; }
+    }
 #pragma unroll
-    for(u32 k = 0; k < SCAN_WORDS; k++) { w[k] = (top >= bottom + k ? words[top - k] : 0); }
+    for(u32 k = 1; k < SCAN_WORDS; k++) { w[k] = (top >= bottom + k ? words[top - k] : 0); }
 #pragma unroll
-    for(u32 k = 0; k < SCAN_WORDS; k++)
+    for(u32 k = 1; k < SCAN_WORDS; k++)
     {
       if(top < bottom + k) { return false; }
       const u64 base = (top - k) << 3;
@@ -90,10 +105,23 @@ __device__ __forceinline__ bool scan_right(const DevImage& img, u64 from, u64 la
   {
     const u64 bottom = from >> 3, top = last >> 3;
     u64 w[SCAN_WORDS];
+    w[0] = words[bottom];                    // the nearest word alone first (see scan_left)
+    {
+      u32 mask = bytes_below(w[0], bound);
+      if(from > (bottom << 3)) { mask &= ~((1u << (from - (bottom << 3))) - 1); }
+      if(last < (bottom << 3) + 7) { mask &= (2u << (last - (bottom << 3))) - 1; }
+      if(mask != 0)
+      {
+        u32 byte = u32(__ffs(int(mask))) - 1;
+        rpos = (bottom << 3) + byte; rval = (w[0] >> (8 * byte)) & 0xFF;
+        return true;
+      }
+      if(top == bottom) { return false; }
+    }
 #pragma unroll
-    for(u32 k = 0; k < SCAN_WORDS; k++) { w[k] = (bottom + k <= top ? words[bottom + k] : 0); }
+    for(u32 k = 1; k < SCAN_WORDS; k++) { w[k] = (bottom + k <= top ? words[bottom + k] : 0); }
 #pragma unroll
-    for(u32 k = 0; k < SCAN_WORDS; k++)
+    for(u32 k = 1; k < SCAN_WORDS; k++)
     {
       if(bottom + k > top) { return false; }
       const u64 base = (bottom + k) << 3;
@@ -366,6 +394,192 @@ __global__ __launch_bounds__(TPB) void k_match_stats(DevImage img, const u8* __r
   }
   reinterpret_cast<ulonglong2*>(ranges)[q] = make_ulonglong2(sp, ep);
   if(fallbacks != nullptr) { fallbacks[q] = calls; }
+}
+
+// ---- matching statistics, version 2: wave-cooperative block fetch, two characters per step, batched parent() ----
+// Same results as k_match_stats.  One lane = one pattern; the LF steps of the 64 patterns of a wave go through the
+// cooperative fetch of k_find2 (one 128-byte request per endpoint, FLP128 pair blocks when the next two
+// characters are fast characters and the block proves that neither step empties -- both matching statistics
+// then follow at once: depth + 1 and depth + 2).  A lane whose step empties waits (need_parent) until PARENT_BATCH
+// lanes of its wave wait or nothing else can step (default 1: at once -- batching more lanes measured slower, profiles/r02_config5.md); the wave then runs LCPArray::parent (lcp.cpp:276-301) for all
+// waiting lanes together, so that the divergent tree walks cost one pass per batch instead of one per step.
+constexpr u32 PARENT_BATCH = 1;
+
+template<bool PAIR>
+__global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* __restrict__ patterns,
+                                                       const u64* __restrict__ offsets, u64 nq,
+                                                       unsigned short* __restrict__ ms, u64* __restrict__ ranges,
+                                                       u64* __restrict__ fallbacks, u32 parent_batch)
+{
+  __shared__ ulonglong2 stage[TPB2 * 8];
+  __shared__ u8 c2c[256];
+  c2c[threadIdx.x] = img.char2comp[threadIdx.x];
+  c2c[threadIdx.x + TPB2] = img.char2comp[threadIdx.x + TPB2];
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63;
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  const u64 q = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  const bool has = q < nq;
+  u64 begin = 0, i = 0;
+  if(has) { begin = offsets[q]; i = offsets[q + 1] - begin; }
+  const u8* p = patterns + begin;
+  u64 sp = 0, ep = img.n - 1, depth = 0, calls = 0;
+  bool need_parent = false;
+  u32 force_single = 0;
+  u64 win_top = ~u64(0), win_code = 0, win_bad = 0;
+  u64 packed = 0; u32 have = 0;             // results: four u16 per aligned 8-byte store
+  auto emit = [&](u64 pos, u64 value)        // ms[begin + pos] = value; positions arrive in descending order
+  {
+    const u64 idx = begin + pos;
+    const u32 slot = u32(idx & 3);
+    packed |= u64(value > 65535 ? 65535 : value) << (16 * slot); have |= 1u << slot;
+    if(slot == 0 || pos == 0)
+    {
+      unsigned short* group = ms + (idx & ~u64(3));
+      if(have == 15u) { *reinterpret_cast<u64*>(group) = packed; }
+      else { for(u32 s = 0; s < 4; s++) { if((have >> s) & 1) { group[s] = (unsigned short)(packed >> (16 * s)); } } }
+      packed = 0; have = 0;
+    }
+  };
+  while(true)
+  {
+    const bool active = has && i > 0;
+    if(!__any(active)) { break; }
+    // packed pattern window, as in k_find2: the 32 positions below win_top as 2-bit codes + "not a fast character" bits
+    if(active && (win_top == ~u64(0) || win_top - i > 24))
+    {
+      win_top = i; win_code = 0; win_bad = 0;
+      const u64 count = (i < 32 ? i : 32), low = reinterpret_cast<u64>(p) + i - count, base = low & ~u64(7);
+      u64 w[5];
+      const u64 last = (low + count - 1) & ~u64(7);
+#pragma unroll
+      for(u32 k = 0; k < 5; k++) { const u64 a = base + 8 * k; w[k] = *reinterpret_cast<const u64*>(a < last ? a : last); }
+      for(u32 r = 0; r < count; r++)
+      {
+        const u64 at = (low - base) + (count - 1 - r);
+        u64 word = w[0];
+#pragma unroll
+        for(u32 k = 1; k < 5; k++) { if((at >> 3) == k) { word = w[k]; } }
+        const u32 c = u32(c2c[u32(word >> ((at & 7) * 8)) & 0xFF]) - 1;
+        win_code |= u64(c & 3) << (2 * r);
+        win_bad |= u64(c < 4 ? 0 : 1) << (2 * r);
+      }
+    }
+    const bool stepping = active && !need_parent;
+    u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
+    bool pair = false;
+    if(stepping)
+    {
+      const u32 r = u32(win_top - i);                          // window slot of position i - 1
+      if constexpr(PAIR)
+      {
+        if(force_single == 0 && i >= 2)
+        {
+          pair = ((win_bad >> (2 * r)) & 5) == 0;
+          if(pair)
+          {
+            const u32 c2 = u32(win_code >> (2 * r)) & 3, c1 = u32(win_code >> (2 * r + 2)) & 3;
+            const u64 b_sp = sp / PAIR_BITS, b_ep = (ep + 1) / PAIR_BITS;
+            r_sp = u32(sp - b_sp * PAIR_BITS); r_ep = u32(ep + 1 - b_ep * PAIR_BITS);
+            const u64 first = u64(c1 * 4 + c2) * img.flp_nblocks;
+            idx_sp = u32(first + b_sp) | PAIR_FLAG; idx_ep = u32(first + b_ep) | PAIR_FLAG;
+          }
+        }
+      }
+      if(!pair)
+      {
+        if((win_bad >> (2 * r)) & 1)
+        {
+          const u64 addr = reinterpret_cast<u64>(p) + i - 1;
+          comp = c2c[u32(*reinterpret_cast<const u64*>(addr & ~u64(7)) >> ((addr & 7) * 8)) & 0xFF];
+        }
+        else { comp = 1 + (u32(win_code >> (2 * r)) & 3); }
+        const u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
+        r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
+        idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
+      }
+    }
+    u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
+    const bool need2 = stepping && idx_ep != idx_sp;
+    ulonglong2 blk[8];
+    if(__any(stepping))
+    {
+      fetch_blocks<PAIR>(img.flb, idx_sp, stepping, wave_stage, lane, img.flp);
+      if(stepping)
+      {
+        read_block(wave_stage, lane, blk);
+        if(PAIR && pair)
+        {
+          eval_pair(blk, r_sp, false, e_sp, n_sp);
+          if(idx_ep == idx_sp) { eval_pair(blk, r_ep, true, e_ep, n_ep); }
+        }
+        else
+        {
+          eval_endpoint(blk, r_sp, 0, e_sp, n_sp);
+          if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
+        }
+      }
+      if(__any(need2))
+      {
+        __builtin_amdgcn_wave_barrier();
+        fetch_blocks<PAIR>(img.flb, idx_ep, need2, wave_stage, lane, img.flp);
+        if(need2)
+        {
+          read_block(wave_stage, lane, blk);
+          if(PAIR && pair) { eval_pair(blk, r_ep, true, e_ep, n_ep); }
+          else { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if(stepping)
+    {
+      if(PAIR && pair)
+      {
+        if(e_ep > e_sp)                                        // neither step empties (layout.hpp)
+        {
+          sp = n_sp; ep = n_ep;
+          emit(i - 1, depth + 1); emit(i - 2, depth + 2);
+          depth += 2; i -= 2;
+        }
+        else { force_single = 2; }
+      }
+      else
+      {
+        const u64 a = e_sp, b = e_ep - 1;                      // gcsa.h:155-162
+        if(!range_empty(a, b))
+        {
+          sp = n_sp; ep = n_ep; depth++;
+          emit(i - 1, depth); i--;
+          force_single -= (force_single > 0 ? 1 : 0);
+        }
+        else if(sp == 0 && ep == img.n - 1)                    // at the root: no such character
+        {
+          depth = 0;
+          emit(i - 1, 0); i--;
+          force_single -= (force_single > 0 ? 1 : 0);
+        }
+        else { need_parent = true; }
+      }
+    }
+    // parent(): for all waiting lanes at once, when enough of them wait or nothing else can move
+    const u64 waiting = __ballot(need_parent);
+    if(waiting != 0 && (u32(__popcll(waiting)) >= parent_batch || !__any(active && !need_parent)))
+    {
+      if(need_parent)
+      {
+        gcsa2_stnode node;
+        lcp_parent(img, sp, ep, node); calls++;
+        sp = node.sp; ep = node.ep; depth = node.node_lcp;
+        need_parent = false;
+      }
+    }
+  }
+  if(has)
+  {
+    reinterpret_cast<ulonglong2*>(ranges)[q] = make_ulonglong2(sp, ep);
+    if(fallbacks != nullptr) { fallbacks[q] = calls; }
+  }
 }
 
 }  // namespace
