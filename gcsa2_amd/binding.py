@@ -39,7 +39,12 @@ EXPORTS = [
     "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
+    "gcsa2_host_view_parse_gcsa", "gcsa2_host_view_parse_lcp", "gcsa2_host_view_serialize_gcsa", "gcsa2_host_view_serialize_lcp",
+    "gcsa2_lcp_create",
 ]
+
+
+SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint64)     # gcsa2_sink
 
 
 class Gcsa2Error(RuntimeError):
@@ -122,6 +127,11 @@ def load_library():
     L.gcsa2_index_create_from_file.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
     L.gcsa2_host_view_load_gcsa.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.gcsa2_index_create_from_gcsa.argtypes = [C.c_char_p, C.c_char_p, i32, C.POINTER(vp)]
+    L.gcsa2_host_view_parse_gcsa.argtypes = [vp, u64, u64p, C.POINTER(vp)]
+    L.gcsa2_host_view_parse_lcp.argtypes = [vp, u64, u64p, C.POINTER(vp)]
+    L.gcsa2_host_view_serialize_gcsa.argtypes = [C.POINTER(HostView), SINK, vp, u64p]
+    L.gcsa2_host_view_serialize_lcp.argtypes = [C.POINTER(HostView), SINK, vp, u64p]
+    L.gcsa2_lcp_create.argtypes = [C.POINTER(HostView), i32, C.POINTER(vp)]
     L.gcsa2_match_stats_batch.argtypes = [vp, u8p, u64p, u64, vp, u64p, u64p]
     L.gcsa2_match_stats_device.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
@@ -723,6 +733,34 @@ class GCSAGroup:
             self.close()
         except Exception:
             pass
+
+
+def serialize_view(view_ref, what="gcsa") -> bytes:
+    """GCSA::serialize / LCPArray::serialize of a host view (`gcsa2_host_view_serialize_*`) as bytes."""
+    L = load_library()
+    chunks = []
+    sink = SINK(lambda ctx, data, n: chunks.append(C.string_at(data, n)))
+    fn = L.gcsa2_host_view_serialize_gcsa if what == "gcsa" else L.gcsa2_host_view_serialize_lcp
+    written = C.c_uint64()
+    _check(fn(view_ref, sink, None, C.byref(written)))
+    out = b"".join(chunks)
+    assert len(out) == written.value
+    return out
+
+
+def parse_view(data: bytes, what="gcsa", exact=True):
+    """`gcsa2_host_view_parse_*`: (storage handle, HostView pointer, bytes consumed); free with free_view()."""
+    L = load_library()
+    buf = C.create_string_buffer(data, len(data))
+    h = C.c_void_p()
+    consumed = C.c_uint64()
+    fn = L.gcsa2_host_view_parse_gcsa if what == "gcsa" else L.gcsa2_host_view_parse_lcp
+    _check(fn(buf, len(data), None if exact else C.byref(consumed), C.byref(h)))
+    return h, L.gcsa2_host_view_get(h), (len(data) if exact else consumed.value)
+
+
+def free_view(h):
+    load_library().gcsa2_host_view_free(h)
 
 
 def open_index(index_arrays, device=0):

@@ -16,6 +16,7 @@
 //   kernels_lcp.hpp     k_parent / k_depth / k_sv / k_rmq   LCPArray     include/gcsa/lcp.h:137-178, src/lcp.cpp:276-519
 #include "layout.hpp"
 #include "sdsl_reader.hpp"
+#include "sdsl_writer.hpp"
 #include "../../include/gcsa2_hip.h"
 
 #include <hipcub/hipcub.hpp>
@@ -323,6 +324,47 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     return fail(GCSA2_ERR_INVALID_ARGUMENT, "host view lacks alphabet / bwt / edges or sigma out of range");
   }
   if(v->lcp_data != nullptr && v->lcp_levels > u64(MAX_LCP_LEVELS)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "too many LCP levels"); }
+  // Consistency of the view itself: the query kernels index device memory with these values and, like the
+  // reference's low-level interface (gcsa.h:133-135), do not check them again.
+  for(int b = 0; b < 256; b++)
+  {
+    if(v->char2comp[b] >= v->sigma) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "alpha.char2comp maps a byte to a comp >= sigma"); }
+  }
+  for(u64 c = 0; c < v->sigma; c++)
+  {
+    if(v->C[c] > v->C[c + 1]) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "alpha.C is not non-decreasing"); }
+  }
+  if(v->C[v->sigma] != v->edges) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "alpha.C[sigma] differs from header.edges"); }
+  if(v->sampled_path_bits != nullptr)
+  {
+    if(v->stored_samples == nullptr || v->sample_bits == nullptr || v->sample_width == 0 || v->sample_width > 64)
+    {
+      return fail(GCSA2_ERR_INVALID_ARGUMENT, "samples: missing array or sample width out of range");
+    }
+  }
+  if(v->extra_filter_bits != nullptr && (v->extra_values_bits == nullptr || v->redundant_bits == nullptr))
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "counters: missing array");
+  }
+  if(v->lcp_data != nullptr)
+  {
+    // LCPArray (src/lcp.cpp:224-259): level 0 = one value per path node, every further level one value per
+    // `branching` values of the level below, up to a single root.  A stale .lcp beside an index (another graph,
+    // another order) would otherwise send parent() outside the index and hang the LF + parent loop.
+    if(v->lcp_offsets == nullptr || v->lcp_levels == 0) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "LCP: missing offsets"); }
+    if(v->lcp_branching < 2) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "LCP: branching factor below 2"); }
+    if(v->path_nodes > 0 && v->lcp_size != v->path_nodes) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "LCP: header.size differs from the number of path nodes (an .lcp file of another index?)"); }
+    u64 level_size = v->lcp_size, at = 0, top_size = 0;
+    for(u64 l = 0; l < v->lcp_levels; l++)
+    {
+      if(v->lcp_offsets[l] != at) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "LCP: offsets do not match the level sizes implied by the branching factor"); }
+      at += level_size; top_size = level_size;
+      if(l + 1 < v->lcp_levels && level_size <= 1) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "LCP: levels above the root"); }
+      level_size = (level_size + v->lcp_branching - 1) / v->lcp_branching;
+    }
+    if(v->lcp_offsets[v->lcp_levels] != at) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "LCP: offsets do not match the level sizes implied by the branching factor"); }
+    if(top_size > 1) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "LCP: the top level is not a single root"); }
+  }
   int count = gcsa2_device_count();
   if(count <= 0) { return fail(GCSA2_ERR_NO_DEVICE, "no HIP device visible: " + g_error); }
   if(device < 0 || device >= count) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "device index out of range"); }
@@ -1771,11 +1813,22 @@ extern "C" int gcsa2_host_view_load(const char* path, gcsa2_view_storage** out)
     v.edge_bits = st->blobs[b++].data();
     if(flags & 1)
     {
-      v.sampled_path_bits = st->blobs[b++].data(); v.stored_samples = st->blobs[b++].data(); v.sample_bits = st->blobs[b++].data();
+      if(v.sample_width == 0 || v.sample_width > 64 || v.sample_count > (u64(1) << 46)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: sample header out of range"); }
+      if(!expect(words_for_bits(v.path_nodes) * 8)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: sampled_paths size"); }
+      v.sampled_path_bits = st->blobs[b++].data();
+      if(!expect(words_for_bits(v.sample_count * v.sample_width) * 8)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: stored_samples size"); }
+      v.stored_samples = st->blobs[b++].data();
+      if(!expect(words_for_bits(v.sample_count) * 8)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: samples size"); }
+      v.sample_bits = st->blobs[b++].data();
     }
     if(flags & 2)
     {
-      v.extra_filter_bits = st->blobs[b++].data(); v.extra_values_bits = st->blobs[b++].data(); v.redundant_bits = st->blobs[b++].data();
+      if(!expect(words_for_bits(v.path_nodes) * 8)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: extra_pointers.filter size"); }
+      v.extra_filter_bits = st->blobs[b++].data();
+      if(!expect(words_for_bits(v.extra_values_len) * 8)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: extra_pointers.values size"); }
+      v.extra_values_bits = st->blobs[b++].data();
+      if(!expect(words_for_bits(v.redundant_len) * 8)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "G2HV: redundant_pointers size"); }
+      v.redundant_bits = st->blobs[b++].data();
     }
     if(flags & 4)
     {
@@ -1892,11 +1945,10 @@ extern "C" int gcsa2_compare_kmers_records(const gcsa2_index* left, const gcsa2_
 
 namespace {
 
-void load_gcsa_members(const char* path, gcsa2_view_storage& st)
+// `exact`: the stream must end with the structure (a file); otherwise trailing bytes are left to the caller
+void load_gcsa_members(sdsl_file::Cursor& in, gcsa2_view_storage& st, bool exact)
 {
   using namespace sdsl_file;
-  Mapping map(path);
-  Cursor in(map, std::string("GCSA::load(") + path + ")");
   gcsa2_host_view& v = st.view;
 
   // GCSAHeader (files.cpp:527-543): tag, version, path_nodes, edges, order, flags
@@ -1966,14 +2018,19 @@ void load_gcsa_members(const char* path, gcsa2_view_storage& st)
   v.redundant_bits = st.blobs[b++].data();
   skip_select_mcl(in, "redundant_pointers.select");
 
-  if(!in.at_end()) { in.error(std::to_string(in.remaining()) + " unaccounted bytes after redundant_pointers"); }
+  if(exact && !in.at_end()) { in.error(std::to_string(in.remaining()) + " unaccounted bytes after redundant_pointers"); }
 }
 
-void load_lcp_members(const char* path, gcsa2_view_storage& st)
+void load_gcsa_members(const char* path, gcsa2_view_storage& st)
+{
+  sdsl_file::Mapping map(path);
+  sdsl_file::Cursor in(map, std::string("GCSA::load(") + path + ")");
+  load_gcsa_members(in, st, true);
+}
+
+void load_lcp_members(sdsl_file::Cursor& in, gcsa2_view_storage& st, bool exact)
 {
   using namespace sdsl_file;
-  Mapping map(path);
-  Cursor in(map, std::string("LCP::load(") + path + ")");
   gcsa2_host_view& v = st.view;
 
   // LCPHeader (files.cpp:595-609): tag, version, size, branching, flags
@@ -1987,7 +2044,7 @@ void load_lcp_members(const char* path, gcsa2_view_storage& st)
   }
   IntVector data = read_int_vector(in, 0, "data");
   IntVector offsets = read_int_vector(in, 64, "offsets");
-  if(!in.at_end()) { in.error(std::to_string(in.remaining()) + " unaccounted bytes after offsets"); }
+  if(exact && !in.at_end()) { in.error(std::to_string(in.remaining()) + " unaccounted bytes after offsets"); }
   if(data.width > 8) { in.error("LCP values wider than 8 bits are not supported"); }
   if(offsets.size() < 2 || offsets.size() - 1 > u64(MAX_LCP_LEVELS)) { in.error("offsets: number of levels out of range"); }
   v.lcp_levels = offsets.size() - 1;
@@ -2001,7 +2058,155 @@ void load_lcp_members(const char* path, gcsa2_view_storage& st)
   v.lcp_offsets = offsets_ptr; v.lcp_data = bytes;
 }
 
+void load_lcp_members(const char* path, gcsa2_view_storage& st)
+{
+  sdsl_file::Mapping map(path);
+  sdsl_file::Cursor in(map, std::string("LCP::load(") + path + ")");
+  load_lcp_members(in, st, true);
+}
+
+template<class Loader>
+int parse_memory(const void* bytes, uint64_t size, uint64_t* consumed, gcsa2_view_storage** out, const char* what, Loader load)
+{
+  if(bytes == nullptr || out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null argument"); }
+  *out = nullptr;
+  try
+  {
+    std::unique_ptr<gcsa2_view_storage> st(new gcsa2_view_storage());
+    std::memset(&st->view, 0, sizeof(st->view));
+    st->blobs.reserve(64);
+    sdsl_file::Cursor in(bytes, size, what);
+    load(in, *st, consumed == nullptr);
+    if(consumed != nullptr) { *consumed = in.consumed(); }
+    *out = st.release();
+    return GCSA2_OK;
+  }
+  catch(const sdsl_file::FormatError& e) { return fail(GCSA2_ERR_INVALID_ARGUMENT, e.what()); }
+  catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string(what) + ": " + e.what()); }
+}
+
 } // namespace
+
+extern "C" int gcsa2_host_view_parse_gcsa(const void* bytes, uint64_t size, uint64_t* consumed, gcsa2_view_storage** out)
+{
+  return parse_memory(bytes, size, consumed, out, "GCSA::load()",
+                      [](sdsl_file::Cursor& in, gcsa2_view_storage& st, bool exact) { load_gcsa_members(in, st, exact); });
+}
+
+extern "C" int gcsa2_host_view_parse_lcp(const void* bytes, uint64_t size, uint64_t* consumed, gcsa2_view_storage** out)
+{
+  return parse_memory(bytes, size, consumed, out, "LCP::load()",
+                      [](sdsl_file::Cursor& in, gcsa2_view_storage& st, bool exact) { load_lcp_members(in, st, exact); });
+}
+
+// GCSA::serialize (src/gcsa.cpp:140-179): header, alphabet, fast_bwt + fast_rank, sparse_bwt + sparse_rank, edges + edge_rank,
+// sampled_paths + rank, stored_samples, samples + select, extra_pointers, redundant_pointers.  The rank supports of
+// bit_vector_il and sd_vector, and the select support of sd_vector, serialize to nothing.
+extern "C" int gcsa2_host_view_serialize_gcsa(const gcsa2_host_view* v, gcsa2_sink sink, void* ctx, uint64_t* written)
+{
+  if(v == nullptr || sink == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null argument"); }
+  if(v->sampled_path_bits == nullptr || v->extra_filter_bits == nullptr)
+  {
+    return fail(GCSA2_ERR_MISSING_COMPONENT, "GCSA::serialize() needs the samples and the counters (a .gcsa file always holds them)");
+  }
+  try
+  {
+    using namespace sdsl_file;
+    Writer out(sink, ctx);
+    out.put<u32>(0x6C5A6C5Au); out.put<u32>(3);                       // GCSAHeader (files.cpp:513-525)
+    out.put<u64>(v->path_nodes); out.put<u64>(v->edges); out.put<u64>(v->order); out.put<u64>(0);
+    // Alphabet (support.cpp:228-241): char2comp, comp2char, C, sigma, fast_chars.  comp2char is not part of the view:
+    // it is rebuilt as the reference's constructors do, the first (upper-case) byte mapped to each comp.
+    out.int_vector8(v->char2comp, 256, false);
+    std::vector<u8> comp2char(v->sigma, 0);
+    for(u64 c = 0; c < v->sigma; c++)
+    {
+      int first = -1, upper = -1;
+      for(int b = 0; b < 256; b++)
+      {
+        if(v->char2comp[b] != c) { continue; }
+        if(first < 0) { first = b; }
+        if(upper < 0 && !(b >= 'a' && b <= 'z')) { upper = b; }
+      }
+      // comp 0 holds both '\0' and '$', comp sigma - 1 is '#', N collects every other byte: print the reference's letters
+      comp2char[c] = u8(upper >= 0 ? upper : (first >= 0 ? first : 0));
+    }
+    if(v->sigma == 7) { const char* dflt = "$ACGTN#"; bool is_default = true;
+      for(u64 c = 0; c < 7; c++) { is_default = is_default && v->char2comp[u8(dflt[c])] == c; }
+      if(is_default) { for(u64 c = 0; c < 7; c++) { comp2char[c] = u8(dflt[c]); } } }
+    out.int_vector8(comp2char.data(), v->sigma, false);
+    out.int_vector64(v->C, v->sigma + 1);
+    out.put<u64>(v->sigma); out.put<u64>(v->fast_chars);
+    for(u64 c = 0; c < v->sigma; c++)
+    {
+      if(c > 0 && c <= v->fast_chars) { write_bit_vector_il(out, v->bwt[c], v->path_nodes); } else { write_empty_bit_vector_il(out); }
+    }
+    for(u64 c = 0; c < v->sigma; c++)
+    {
+      if(c > 0 && c <= v->fast_chars) { write_empty_sd_vector(out); } else { write_sd_vector(out, v->bwt[c], v->path_nodes); }
+    }
+    write_bit_vector_il(out, v->edge_bits, v->edges);
+    write_bit_vector_il(out, v->sampled_path_bits, v->path_nodes);
+    out.int_vector0_words(v->stored_samples, v->sample_count, u8(v->sample_width));
+    out.bit_vector(v->sample_bits, v->sample_count);
+    write_select_mcl(out, v->sample_bits, v->sample_count, true);
+    write_sd_vector(out, v->extra_filter_bits, v->path_nodes);        // SadaSparse (support.cpp:493-503)
+    write_sd_vector(out, v->extra_values_bits, v->extra_values_len);
+    out.bit_vector(v->redundant_bits, v->redundant_len);              // SadaCount (support.cpp:401-408)
+    write_select_mcl(out, v->redundant_bits, v->redundant_len, true);
+    if(written != nullptr) { *written = out.written(); }
+    return GCSA2_OK;
+  }
+  catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("GCSA::serialize(): ") + e.what()); }
+}
+
+// LCPArray::serialize (src/lcp.cpp:116-128): header, data (bit-compressed int_vector<0>, lcp.cpp:258), offsets.
+extern "C" int gcsa2_host_view_serialize_lcp(const gcsa2_host_view* v, gcsa2_sink sink, void* ctx, uint64_t* written)
+{
+  if(v == nullptr || sink == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null argument"); }
+  if(v->lcp_data == nullptr) { return fail(GCSA2_ERR_MISSING_COMPONENT, "the view holds no LCP array"); }
+  try
+  {
+    using namespace sdsl_file;
+    Writer out(sink, ctx);
+    out.put<u32>(0x6C5A7C94u); out.put<u32>(1);                       // LCPHeader (files.cpp:581-593)
+    out.put<u64>(v->lcp_size); out.put<u64>(v->lcp_branching); out.put<u64>(0);
+    const u64 values = v->lcp_offsets[v->lcp_levels];
+    u8 top = 0;
+    for(u64 i = 0; i < values; i++) { top = (v->lcp_data[i] > top ? v->lcp_data[i] : top); }
+    const u8 width = u8(bits_hi(top) + 1);                            // sdsl::util::bit_compress
+    if(width == 8) { out.int_vector8(v->lcp_data, values, true); }
+    else
+    {
+      std::vector<u64> wide(values);
+      for(u64 i = 0; i < values; i++) { wide[i] = v->lcp_data[i]; }
+      out.int_vector0(wide, width);
+    }
+    out.int_vector64(v->lcp_offsets, v->lcp_levels + 1);
+    if(written != nullptr) { *written = out.written(); }
+    return GCSA2_OK;
+  }
+  catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("LCP::serialize(): ") + e.what()); }
+}
+
+// An image that holds only the LCP array: what a default-constructed gcsa::LCPArray becomes after load()
+// (src/lcp.cpp:130-143).  parent / depth / psv / nsv / rmq work on it; everything that needs the GCSA part fails
+// with GCSA2_ERR_MISSING_COMPONENT or returns empty results.
+extern "C" int gcsa2_lcp_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
+{
+  if(v == nullptr || out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null argument"); }
+  *out = nullptr;
+  if(v->lcp_data == nullptr || v->lcp_offsets == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "the view holds no LCP array"); }
+  static const uint8_t c2c[256] = {0};
+  static const uint64_t C[2] = {0, 0}, none[2] = {0, 0};
+  static const uint64_t* const bwt[1] = { none };
+  gcsa2_host_view lcp_only;
+  std::memset(&lcp_only, 0, sizeof(lcp_only));
+  lcp_only.sigma = 1; lcp_only.char2comp = c2c; lcp_only.C = C; lcp_only.bwt = bwt; lcp_only.edge_bits = none;
+  lcp_only.lcp_size = v->lcp_size; lcp_only.lcp_branching = v->lcp_branching; lcp_only.lcp_levels = v->lcp_levels;
+  lcp_only.lcp_offsets = v->lcp_offsets; lcp_only.lcp_data = v->lcp_data;
+  return gcsa2_index_create(&lcp_only, device, out);
+}
 
 extern "C" int gcsa2_host_view_load_gcsa(const char* gcsa_path, const char* lcp_path, gcsa2_view_storage** out)
 {

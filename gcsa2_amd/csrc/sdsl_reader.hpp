@@ -10,7 +10,7 @@
 // this environment, so they follow sdsl-lite 2.1.1 as documented in SURVEY.md section 8(f)-1.  The
 // reader is therefore strict: it checks every internal consistency condition the encodings imply
 // (sizes, block counts, number of ones, monotonicity, exact end of file) and refuses a file it does not
-// fully account for, instead of guessing.
+// fully account for, instead of guessing.  Padding bits past the end of a vector are masked, not judged.
 
 #ifndef GCSA2_SDSL_READER_HPP
 #define GCSA2_SDSL_READER_HPP
@@ -64,6 +64,8 @@ class Cursor
 {
 public:
   Cursor(const Mapping& m, const std::string& what) : base(m.base), bytes(m.bytes), pos(0), what(what) {}
+  Cursor(const void* data, u64 size, const std::string& what) : base(static_cast<const uint8_t*>(data)), bytes(size), pos(0), what(what) {}
+  u64 consumed() const { return pos; }
 
   template<class T> T get(const char* field)
   {
@@ -153,11 +155,10 @@ inline void read_bit_vector_il(Cursor& in, std::vector<u64>& plain, u64& size, c
     if((i & 7) == 0 && data.word(i + i / 8) != cumulative) { in.error(std::string(field) + ": interleaved rank count mismatch"); }
     u64 w = data.word(i + i / 8 + 1);
     cumulative += u64(__builtin_popcountll(w));
-    if(i < (size + 63) / 64) { plain[i] = w; }
-    else if(w != 0) { in.error(std::string(field) + ": set bits past the end"); }
+    if(i < (size + 63) / 64) { plain[i] = w; }       // a spare payload word past the end carries no bits of the vector
   }
   if(data.word(block_num - 1) != cumulative) { in.error(std::string(field) + ": final rank count mismatch"); }
-  if((size & 63) != 0 && (plain[size / 64] >> (size & 63)) != 0) { in.error(std::string(field) + ": set bits past the end"); }
+  if((size & 63) != 0) { plain[size / 64] &= (u64(1) << (size & 63)) - 1; }     // padding bits are not part of the vector
 }
 
 // sdsl::select_support_mcl<b, 1>: u64 arg_cnt; if non-zero: int_vector<0> superblock, bit_vector
@@ -180,7 +181,7 @@ inline void read_bit_vector(Cursor& in, std::vector<u64>& plain, u64& size, cons
   IntVector v = read_int_vector(in, 1, field);
   size = v.bits;
   v.copy_words(plain);
-  if((size & 63) != 0 && (plain[size / 64] >> (size & 63)) != 0) { in.error(std::string(field) + ": set bits past the end"); }
+  if((size & 63) != 0) { plain[size / 64] &= (u64(1) << (size & 63)) - 1; }       // padding bits are not part of the vector
 }
 
 // sdsl::sd_vector<>: u64 size, u8 wl, int_vector<0> low, bit_vector high, select_support_mcl<1>,

@@ -335,6 +335,24 @@ int gcsa2_index_create_from_file(const char* path, int device, gcsa2_index** out
 int gcsa2_host_view_load_gcsa(const char* gcsa_path, const char* lcp_path, gcsa2_view_storage** out);
 int gcsa2_index_create_from_gcsa(const char* gcsa_path, const char* lcp_path, int device, gcsa2_index** out);
 
+/* The same from memory (what GCSA::load(std::istream&) / LCPArray::load(std::istream&) of the facade call after
+ * reading the stream): parses one serialized structure at the start of `bytes`.  consumed != NULL: receives the
+ * number of bytes the structure occupies, trailing bytes are left alone; consumed == NULL: the buffer must end
+ * with the structure.  parse_lcp yields a view in which only the lcp_* fields are set. */
+int gcsa2_host_view_parse_gcsa(const void* bytes, uint64_t size, uint64_t* consumed, gcsa2_view_storage** out);
+int gcsa2_host_view_parse_lcp(const void* bytes, uint64_t size, uint64_t* consumed, gcsa2_view_storage** out);
+/* GCSA::serialize (src/gcsa.cpp:140-179) / LCPArray::serialize (src/lcp.cpp:116-128) of a host view: the byte
+ * stream is handed to `sink` piece by piece (an std::ostream::write in the facade).  Same caveat as for the
+ * reader: the SDSL container encodings are restated from sdsl-lite 2.1.1, format parity is unpinned.
+ * serialize_gcsa needs a view with samples and counters, serialize_lcp one with an LCP array. */
+typedef void (*gcsa2_sink)(void* ctx, const void* data, uint64_t bytes);
+int gcsa2_host_view_serialize_gcsa(const gcsa2_host_view* view, gcsa2_sink sink, void* ctx, uint64_t* written);
+int gcsa2_host_view_serialize_lcp(const gcsa2_host_view* view, gcsa2_sink sink, void* ctx, uint64_t* written);
+/* A device image holding only the LCP array of `view` (its GCSA fields are ignored): a stand-alone
+ * gcsa::LCPArray as LCPArray::load (src/lcp.cpp:130-143) produces it.  Serves gcsa2_parent_* / depth / sv / rmq /
+ * lcp_* ; the GCSA queries find nothing on it. */
+int gcsa2_lcp_create(const gcsa2_host_view* view, int device, gcsa2_index** out);
+
 /* ---- single-process multi-GPU -------------------------------------------------------------
  * A group holds one replica of the index per listed device (a device may be listed more than
  * once).  group_find_batch splits the batch into contiguous shards (sizes differ by at most one,

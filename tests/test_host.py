@@ -256,3 +256,134 @@ def test_sdsl_select_directory_shapes(built, tmp_path):
     kinds = raw[8 + 9 + 8 * ((sb_bits + 63) // 64):]           # after arg_cnt and the superblock vector: mini_or_long
     assert int.from_bytes(kinds[:8], "little") == sb and kinds[8] not in (0, (1 << sb) - 1)      # both kinds present
     loaded.close()
+
+
+def test_serialize_matches_the_file_format_restatement(built):
+    """GCSA::serialize / LCPArray::serialize in C++ (csrc/sdsl_writer.hpp, behind gcsa2_host_view_serialize_*) emit
+    byte for byte what the independent Python restatement of the format (workload/sdsl_format.py) emits, and the
+    in-memory parser (what GCSA::load(std::istream&) of the facade calls) reads them back to the same members,
+    with and without trailing bytes in the stream.  Host only."""
+    from gcsa2_amd.hostview import make_host_view
+    from workload import graphs, sdsl_format, builder
+    from workload.brute_builder import build
+    cases = [build(graphs.paper_graph(), 3, sample_period=2, branching=2),
+             build(graphs.snp_graph(150, 0x52, 0x53, snp_period=8, node_len=8), 6, sample_period=8, branching=4),
+             builder.build(graphs.snp_graph(40000, 0x61, 0x62), 16)]
+    for ix in cases:
+        holder = make_host_view(ix)
+        raw = built.serialize_view(holder.ref(), "gcsa")
+        assert raw == sdsl_format.gcsa_bytes(ix)
+        lcp_raw = built.serialize_view(holder.ref(), "lcp")
+        want_lcp = sdsl_format.lcp_bytes(ix)
+        if int(np.max(ix.lcp_data)) >= 128:            # the Python writer always uses 8 bits; C++ bit-compresses (lcp.cpp:258)
+            assert lcp_raw == want_lcp
+        h, vp, used = built.parse_view(raw, "gcsa")
+        _view_matches(vp.contents, ix)
+        built.free_view(h)
+        h, vp, used = built.parse_view(raw + b"TRAILING", "gcsa", exact=False)
+        assert used == len(raw)
+        _view_matches(vp.contents, ix)
+        built.free_view(h)
+        with pytest.raises(built.Gcsa2Error):
+            built.parse_view(raw + b"TRAILING", "gcsa")
+        h, vp, used = built.parse_view(lcp_raw + b"xx", "lcp", exact=False)
+        v = vp.contents
+        assert used == len(lcp_raw) and (v.lcp_size, v.lcp_branching, v.lcp_levels) == (ix.lcp_size, ix.lcp_branching, len(ix.lcp_offsets) - 1)
+        assert np.ctypeslib.as_array(v.lcp_data, shape=(int(ix.lcp_offsets[-1]),)).tolist() == ix.lcp_data.tolist()
+        assert not v.bwt and v.path_nodes == 0
+        built.free_view(h)
+    # a view without samples / counters cannot become a .gcsa file
+    with pytest.raises(built.Gcsa2Error):
+        built.serialize_view(make_host_view(cases[0], with_counters=False).ref(), "gcsa")
+
+
+def test_header_bytes_from_the_reference_definitions(built, tmp_path):
+    """GCSAHeader / LCPHeader byte layouts hand-assembled from the reference's definitions, not from any writer of
+    this repository: GCSAHeader = u32 tag 0x6C5A6C5A, u32 version 3, u64 path_nodes, edges, order, flags
+    (include/gcsa/files.h:135-156, src/files.cpp:513-537: 40 bytes); LCPHeader = u32 tag 0x6C5A7C94, u32 version 1,
+    u64 size, branching, flags (files.h:169-190, files.cpp:581-603: 32 bytes).  check() accepts exactly
+    tag + version (+ flags == 0); GCSA::load / LCPArray::load throw "Invalid header" otherwise (gcsa.cpp:188-193,
+    lcp.cpp:134-139)."""
+    import struct
+    from workload import graphs, sdsl_format
+    from workload.brute_builder import build
+    ix = build(graphs.paper_graph(), 3, sample_period=2, branching=2)
+    body = sdsl_format.gcsa_bytes(ix)[40:]
+    lcp_body = sdsl_format.lcp_bytes(ix)[32:]
+    good = bytes.fromhex("5a6c5a6c" "03000000") + struct.pack("<QQQQ", 16, 20, 3, 0)       # the paper's example: 16 path nodes, 20 edges, order 3
+    assert len(good) == 40
+    h, vp, _ = built.parse_view(good + body)
+    assert (vp.contents.path_nodes, vp.contents.edges, vp.contents.order) == (16, 20, 3)
+    built.free_view(h)
+    good_lcp = bytes.fromhex("947c5a6c" "01000000") + struct.pack("<QQQ", 16, 2, 0)
+    assert len(good_lcp) == 32
+    h, vp, _ = built.parse_view(good_lcp + lcp_body, "lcp")
+    assert (vp.contents.lcp_size, vp.contents.lcp_branching) == (16, 2)
+    built.free_view(h)
+    bad_headers = {
+        "tag of the LCP file": bytes.fromhex("947c5a6c" "03000000") + good[8:],
+        "byte-swapped tag": bytes.fromhex("6c5a6c5a" "03000000") + good[8:],
+        "version 2 (old format)": good[:4] + struct.pack("<I", 2) + good[8:],
+        "version 4": good[:4] + struct.pack("<I", 4) + good[8:],
+        "flags set": good[:32] + struct.pack("<Q", 1),
+    }
+    for name, head in bad_headers.items():
+        with pytest.raises(built.Gcsa2Error, match="Invalid header"):
+            built.parse_view(head + body)
+    with pytest.raises(built.Gcsa2Error):
+        built.parse_view(good[:39] + body)           # a 39-byte header shifts every member
+    with pytest.raises(built.Gcsa2Error, match="truncated"):
+        built.parse_view(good[:39])
+    for name, head in {"GCSA tag": good[:8] + good_lcp[8:], "version 0": good_lcp[:4] + struct.pack("<I", 0) + good_lcp[8:],
+                       "flags set": good_lcp[:24] + struct.pack("<Q", 2)}.items():
+        with pytest.raises(built.Gcsa2Error, match="Invalid header"):
+            built.parse_view(head + lcp_body, "lcp")
+    # header fields that contradict the members are refused too: one path node too many, one edge too few
+    for head in (good[:8] + struct.pack("<QQQQ", 17, 20, 3, 0), good[:8] + struct.pack("<QQQQ", 16, 19, 3, 0)):
+        with pytest.raises(built.Gcsa2Error):
+            built.parse_view(head + body)
+
+
+def test_create_validates_the_view(built):
+    """gcsa2_index_create refuses inconsistent views before touching a device: char2comp out of range, C not
+    monotone / not ending at `edges`, an LCP array of another index (size, branching, offsets)."""
+    import copy
+    from workload import graphs
+    from workload.brute_builder import build
+    ix = build(graphs.snp_graph(150, 0x52, 0x53, snp_period=8, node_len=8), 6, sample_period=8, branching=4)
+    other = build(graphs.snp_graph(90, 0x54, 0x55, snp_period=8, node_len=8), 6, sample_period=8, branching=4)
+
+    def refuses(mutate, text):
+        bad = copy.copy(ix)
+        mutate(bad)
+        with pytest.raises(built.Gcsa2Error, match=text) as e:
+            built.GCSA(bad)
+        assert e.value.code == -1           # GCSA2_ERR_INVALID_ARGUMENT, not NO_DEVICE: checked before any device work
+
+    def c2c(b):
+        b.char2comp = b.char2comp.copy(); b.char2comp[200] = 7
+    refuses(c2c, "char2comp")
+
+    def cmono(b):
+        b.C = b.C.copy(); b.C[2], b.C[3] = b.C[3], b.C[2] - 1
+    refuses(cmono, "non-decreasing")
+
+    def cend(b):
+        b.C = b.C.copy(); b.C[-1] += 1
+    refuses(cend, "edges")
+
+    def stale_lcp(b):
+        b.lcp_data, b.lcp_offsets, b.lcp_size = other.lcp_data, other.lcp_offsets, other.lcp_size
+    refuses(stale_lcp, "path nodes")
+
+    def branching(b):
+        b.lcp_branching = 1
+    refuses(branching, "branching")
+
+    def offsets(b):
+        b.lcp_offsets = b.lcp_offsets.copy(); b.lcp_offsets[1] -= 1
+    refuses(offsets, "offsets")
+
+    def wrong_branching(b):
+        b.lcp_branching = 8
+    refuses(wrong_branching, "offsets|root")

@@ -168,6 +168,8 @@ def gcsa_bytes(ix):
         # the reference's default alphabet maps both cases to one comp and prints the upper-case one
         upper = [int(h) for h in hits if chr(int(h)).upper() == chr(int(h))]
         comp2char[c] = (upper[0] if upper else (int(hits[0]) if len(hits) else 0))
+    if sigma == 7 and all(int(c2c[b]) == c for c, b in enumerate(b"$ACGTN#")):
+        comp2char[:] = np.frombuffer(b"$ACGTN#", dtype=np.uint8)     # Alphabet::DEFAULT_COMP2CHAR (src/support.cpp:69-92)
     out += [int_vector(c2c, 8, True), int_vector(comp2char, 8, True), int_vector(np.asarray(ix.C, dtype=np.uint64), 64, True),
             struct.pack("<QQ", sigma, int(ix.fast_chars))]                                         # support.cpp:229-240
     fast = [1 <= c <= int(ix.fast_chars) for c in range(sigma)]
