@@ -28,6 +28,7 @@
 #include <functional>
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <random>
 #include <string>
@@ -46,6 +47,16 @@ using namespace g2;
 
 constexpr unsigned RESULT_SLOTS = 1024;     // concurrent locate calls per handle before two share a slot
 
+// Staging of the host-pointer entry points (`*_batch`): a stream, a grow-only device arena and a pinned host arena.
+// A handle keeps a small pool of them, one per concurrent caller, so that a call costs no hipMalloc / hipFree
+// and small transfers go through pinned memory asynchronously on the call's own stream.
+struct Staging
+{
+  hipStream_t stream = nullptr;
+  char* d = nullptr; size_t d_cap = 0;
+  char* h = nullptr; size_t h_cap = 0;       // pinned (hipHostMalloc)
+};
+
 struct gcsa2_index
 {
   int device = 0;
@@ -56,11 +67,15 @@ struct gcsa2_index
   void* d_locate = nullptr;
   void* d_jump = nullptr;
   void* d_pairs = nullptr;
-  // Small results the host reads back (totals of the locate pipeline) live in plain hipMalloc memory:
-  // device-to-host copies out of stream-ordered pool memory were observed to return stale data
-  // (about one call in 5000 on ROCm 7.2 / gfx950), copies out of hipMalloc memory never.
+  hipMemPool_t pool = nullptr;   // stream-ordered scratch of the query pipelines (owned; the default pool is not touched)
+  // Small results the host reads back (totals of the locate pipeline) live in per-handle slots, not in per-call
+  // scratch: no allocation per call.  (Round 1 moved them here after stale read-backs out of pool memory, about one
+  // call in 5000; tools/hip/pool_readback_repro.hip shows the ROCm pool itself delivers 1.1 M such read-backs
+  // correctly in every stream / host-memory combination, so that symptom was this engine's then-code, not ROCm.)
   unsigned long long* d_slots = nullptr;
   mutable std::atomic<unsigned> next_slot{0};
+  mutable std::mutex staging_lock;
+  mutable std::vector<Staging*> staging_pool;
   int compute_units = 256;
   u64 bytes = 0;
   u64 order = 0;
@@ -263,16 +278,114 @@ template<class T> struct DBuf
   ~DBuf() { if(p) { (void)hipFree(p); } }
 };
 
+constexpr size_t PINNED_ARENA = size_t(8) << 20;       // per staging object
+constexpr size_t PINNED_MAX_COPY = size_t(2) << 20;    // larger transfers go straight from / to the caller's memory
+constexpr size_t DEVICE_ARENA_KEEP = size_t(512) << 20; // a larger arena is released with the call that needed it
+
+// One host-pointer call's lease on a Staging object of the handle (see Staging).
+class Lease
+{
+public:
+  explicit Lease(const gcsa2_index* ix) : ix(ix), s(nullptr), d_used(0), h_used(0)
+  {
+    std::lock_guard<std::mutex> hold(ix->staging_lock);
+    if(!ix->staging_pool.empty()) { s = ix->staging_pool.back(); ix->staging_pool.pop_back(); }
+  }
+  ~Lease()
+  {
+    if(s == nullptr) { return; }
+    if(s->d_cap > DEVICE_ARENA_KEEP) { (void)hipFree(s->d); s->d = nullptr; s->d_cap = 0; }
+    std::lock_guard<std::mutex> hold(ix->staging_lock);
+    ix->staging_pool.push_back(s);
+  }
+  Lease(const Lease&) = delete;
+  Lease& operator=(const Lease&) = delete;
+
+  // device bytes this call will carve out of the arena (sum of its buffers, each rounded up to 256 bytes)
+  hipError_t begin(size_t device_bytes)
+  {
+    if(s == nullptr)
+    {
+      s = new(std::nothrow) Staging();
+      if(s == nullptr) { return hipErrorOutOfMemory; }
+      hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+      if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&s->h), PINNED_ARENA, hipHostMallocDefault); }
+      if(e != hipSuccess) { if(s->stream) { (void)hipStreamDestroy(s->stream); } delete s; s = nullptr; return e; }
+      s->h_cap = PINNED_ARENA;
+    }
+    if(device_bytes > s->d_cap)
+    {
+      if(s->d != nullptr) { (void)hipFree(s->d); s->d = nullptr; s->d_cap = 0; }
+      size_t want = device_bytes + (device_bytes >> 2) + 4096;
+      hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d), want);
+      if(e != hipSuccess) { return e; }
+      s->d_cap = want;
+    }
+    d_used = 0; h_used = 0; pending.clear();
+    return hipSuccess;
+  }
+  static size_t need(size_t bytes) { return (bytes + 255) / 256 * 256 + 256; }
+  template<class T> T* dev(u64 count)
+  {
+    char* p = s->d + d_used;
+    d_used += need(count * sizeof(T));
+    return reinterpret_cast<T*>(p);
+  }
+  hipStream_t stream() const { return s->stream; }
+
+  hipError_t up(void* d, const void* h, size_t bytes)
+  {
+    if(bytes == 0) { return hipSuccess; }
+    char* slot = pinned(bytes);
+    if(slot == nullptr) { return hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s->stream); }
+    std::memcpy(slot, h, bytes);
+    return hipMemcpyAsync(d, slot, bytes, hipMemcpyHostToDevice, s->stream);
+  }
+  hipError_t down(void* h, const void* d, size_t bytes)
+  {
+    if(bytes == 0) { return hipSuccess; }
+    char* slot = pinned(bytes);
+    if(slot == nullptr) { return hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s->stream); }
+    pending.push_back(Pending{h, slot, bytes});
+    return hipMemcpyAsync(slot, d, bytes, hipMemcpyDeviceToHost, s->stream);
+  }
+  // wait for everything enqueued on the call's stream and hand the staged results to the caller
+  hipError_t finish()
+  {
+    hipError_t e = hipStreamSynchronize(s->stream);
+    if(e == hipSuccess) { for(const Pending& p : pending) { std::memcpy(p.user, p.slot, p.bytes); } }
+    pending.clear();
+    return e;
+  }
+
+private:
+  char* pinned(size_t bytes)
+  {
+    if(bytes > PINNED_MAX_COPY || h_used + bytes > s->h_cap) { return nullptr; }
+    char* p = s->h + h_used;
+    h_used += (bytes + 63) / 64 * 64;
+    return p;
+  }
+  struct Pending { void* user; const char* slot; size_t bytes; };
+  const gcsa2_index* ix; Staging* s; size_t d_used, h_used;
+  std::vector<Pending> pending;
+};
+
+inline hipError_t pool_alloc(const gcsa2_index* ix, void** p, size_t bytes, hipStream_t stream)
+{
+  return ix->pool != nullptr ? hipMallocFromPoolAsync(p, bytes, ix->pool, stream) : hipMallocAsync(p, bytes, stream);
+}
+
 // stream-ordered scratch: no device-wide synchronisation from allocation or release
 struct Scratch
 {
-  hipStream_t stream; std::vector<void*> held;
-  explicit Scratch(hipStream_t s) : stream(s) {}
+  const gcsa2_index* ix; hipStream_t stream; std::vector<void*> held;
+  Scratch(const gcsa2_index* ix, hipStream_t s) : ix(ix), stream(s) {}
   ~Scratch() { for(void* p : held) { (void)hipFreeAsync(p, stream); } }
   template<class T> hipError_t get(T*& p, u64 count)
   {
     void* raw = nullptr;
-    hipError_t e = hipMallocAsync(&raw, (count > 0 ? count : 1) * sizeof(T), stream);
+    hipError_t e = pool_alloc(ix, &raw, (count > 0 ? count : 1) * sizeof(T), stream);
     if(e == hipSuccess) { held.push_back(raw); p = static_cast<T*>(raw); }
     return e;
   }
@@ -429,14 +542,21 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     {
       int cus = 0;
       if(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) { ix->compute_units = cus; }
-      // Query scratch comes from the device's stream-ordered pool; keep what it has grown to instead
-      // of returning it to the driver at every synchronisation.
-      hipMemPool_t pool = nullptr;
-      if(hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool != nullptr)
+      // Query scratch is stream-ordered memory from a pool OWNED BY THIS HANDLE, which keeps what it has grown to
+      // instead of returning it to the driver at every synchronisation.  The device's default pool (and with it
+      // the caller's own hipMallocAsync behaviour) is left alone.
+      hipMemPoolProps props;
+      std::memset(&props, 0, sizeof(props));
+      props.allocType = hipMemAllocationTypePinned;
+      props.handleTypes = hipMemHandleTypeNone;
+      props.location.type = hipMemLocationTypeDevice;
+      props.location.id = device;
+      if(hipMemPoolCreate(&ix->pool, &props) == hipSuccess && ix->pool != nullptr)
       {
         uint64_t keep = ~uint64_t(0);
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        (void)hipMemPoolSetAttribute(ix->pool, hipMemPoolAttrReleaseThreshold, &keep);
       }
+      else { ix->pool = nullptr; }           // falls back to the default pool with its default threshold
       (void)hipGetLastError();
     }
     ix->bytes = st.words.size() * sizeof(u64);
@@ -677,6 +797,14 @@ void gcsa2_index_destroy(gcsa2_index* ix)
   if(ix->d_jump) { (void)hipFree(ix->d_jump); }
   if(ix->d_pairs) { (void)hipFree(ix->d_pairs); }
   if(ix->d_slots) { (void)hipFree(ix->d_slots); }
+  if(ix->pool) { (void)hipDeviceSynchronize(); (void)hipMemPoolDestroy(ix->pool); }
+  for(Staging* st : ix->staging_pool)
+  {
+    if(st->stream) { (void)hipStreamDestroy(st->stream); }
+    if(st->d) { (void)hipFree(st->d); }
+    if(st->h) { (void)hipHostFree(st->h); }
+    delete st;
+  }
   delete ix;
 }
 
@@ -698,6 +826,22 @@ uint64_t gcsa2_block_bits(const gcsa2_index*) { return BLOCK_BITS; }
 }  // extern "C"
 
 namespace {
+
+// one input array of `in_words` u64 per query, one output array of `out_words` u64 per query, one kernel in between
+template<class Launch>
+int simple_batch(const gcsa2_index* ix, const uint64_t* in, u64 in_words, uint64_t* out, u64 out_words, u64 nq, const char* name, Launch launch)
+{
+  DeviceGuard guard(ix->device);
+  Lease lease(ix);
+  HIP_TRY(lease.begin(Lease::need(in_words * nq * 8) + Lease::need(out_words * nq * 8)));
+  u64* d_in = lease.dev<u64>(in_words * nq); u64* d_out = lease.dev<u64>(out_words * nq);
+  HIP_TRY(lease.up(d_in, in, in_words * nq * sizeof(u64)));
+  launch(d_in, d_out, lease.stream());
+  { hipError_t e_ = hipGetLastError(); if(e_ != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); } }
+  HIP_TRY(lease.down(out, d_out, out_words * nq * sizeof(u64)));
+  HIP_TRY(lease.finish());
+  return GCSA2_OK;
+}
 
 // k_find2 instantiation for this image: JUMP with the jump table, PAIR with the pair blocks
 template<bool STATS, bool REFILL>
@@ -745,8 +889,8 @@ int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t*
     void* tmp = nullptr;
     size_t tmp_bytes = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, len_in, len_out, idx_in, idx_out, int(nq), 0, 32, st));
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&len_in), 4 * nq * sizeof(u32), st));     // four u32 arrays
-    HIP_TRY(hipMallocAsync(&tmp, tmp_bytes, st));
+    HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&len_in), 4 * nq * sizeof(u32), st));     // four u32 arrays
+    HIP_TRY(pool_alloc(ix, &tmp, tmp_bytes, st));
     len_out = len_in + nq; idx_in = len_out + nq; idx_out = idx_in + nq;
     hipLaunchKernelGGL(k_pattern_lengths, dim3(grid_for(nq)), dim3(TPB), 0, st, d_offsets, nq, len_in, idx_in);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, len_in, len_out, idx_in, idx_out, int(nq), 0, 32, st);
@@ -764,7 +908,7 @@ int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t*
     hipStream_t st = static_cast<hipStream_t>(stream);
     DeviceGuard guard(ix->device);
     unsigned long long* queue = nullptr;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st));
+    HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), st));
     u64 resident = u64(ix->compute_units) * 9;                    // workgroups the LDS footprint lets a CU hold
     u64 wanted = (nq + TPB2 - 1) / TPB2;
@@ -866,7 +1010,7 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
     HIP_TRY(hipStreamSynchronize(stream));
     return GCSA2_OK;
   }
-  Scratch scratch(stream);
+  Scratch scratch(ix, stream);
 
   // [node_counts | raw_counts | node_off] (nq + 1 each), [seg_begin | seg_end] (nq each), 3 totals; the
   // scan of the raw counts goes straight into the job's offsets (final as they are unless duplicates
@@ -1037,14 +1181,16 @@ int gcsa2_find_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint6
   if(nq == 0) { return GCSA2_OK; }
   if(offsets == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
   DeviceGuard guard(ix->device);
-  u64 total = offsets[nq];
-  DBuf<u8> d_pat; DBuf<u64> d_off, d_out;
-  HIP_TRY(d_pat.alloc(total + 1)); HIP_TRY(d_off.alloc(nq + 1)); HIP_TRY(d_out.alloc(2 * nq));
-  if(total > 0) { HIP_TRY(hipMemcpy(d_pat.p, patterns, total, hipMemcpyHostToDevice)); }
-  HIP_TRY(hipMemcpy(d_off.p, offsets, (nq + 1) * sizeof(u64), hipMemcpyHostToDevice));
-  int rc = gcsa2_find_device(ix, d_pat.p, d_off.p, nq, d_out.p, nullptr);
+  const u64 total = offsets[nq];
+  Lease lease(ix);
+  HIP_TRY(lease.begin(Lease::need(total + 16) + Lease::need((nq + 1) * 8) + Lease::need(2 * nq * 8)));
+  u8* d_pat = lease.dev<u8>(total + 16); u64* d_off = lease.dev<u64>(nq + 1); u64* d_out = lease.dev<u64>(2 * nq);
+  HIP_TRY(lease.up(d_pat, patterns, total));
+  HIP_TRY(lease.up(d_off, offsets, (nq + 1) * sizeof(u64)));
+  int rc = gcsa2_find_device(ix, d_pat, d_off, nq, d_out, lease.stream());
   if(rc != GCSA2_OK) { return rc; }
-  HIP_TRY(hipMemcpy(ranges, d_out.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
+  HIP_TRY(lease.down(ranges, d_out, 2 * nq * sizeof(u64)));
+  HIP_TRY(lease.finish());
   return GCSA2_OK;
 }
 
@@ -1053,13 +1199,15 @@ int gcsa2_lf_batch(const gcsa2_index* ix, const uint64_t* in, const uint8_t* com
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
-  DBuf<u64> d_in, d_out; DBuf<u8> d_c;
-  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(2 * nq)); HIP_TRY(d_c.alloc(nq));
-  HIP_TRY(hipMemcpy(d_in.p, in, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_c.p, comps, nq, hipMemcpyHostToDevice));
-  int rc = gcsa2_lf_device(ix, d_in.p, d_c.p, nq, d_out.p, nullptr);
+  Lease lease(ix);
+  HIP_TRY(lease.begin(2 * Lease::need(2 * nq * 8) + Lease::need(nq)));
+  u64* d_in = lease.dev<u64>(2 * nq); u64* d_out = lease.dev<u64>(2 * nq); u8* d_c = lease.dev<u8>(nq);
+  HIP_TRY(lease.up(d_in, in, 2 * nq * sizeof(u64)));
+  HIP_TRY(lease.up(d_c, comps, nq));
+  int rc = gcsa2_lf_device(ix, d_in, d_c, nq, d_out, lease.stream());
   if(rc != GCSA2_OK) { return rc; }
-  HIP_TRY(hipMemcpy(out, d_out.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
+  HIP_TRY(lease.down(out, d_out, 2 * nq * sizeof(u64)));
+  HIP_TRY(lease.finish());
   return GCSA2_OK;
 }
 
@@ -1068,12 +1216,14 @@ int gcsa2_lf_node_batch(const gcsa2_index* ix, const uint64_t* in, uint64_t nq, 
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
-  DBuf<u64> d_in, d_out;
-  HIP_TRY(d_in.alloc(nq)); HIP_TRY(d_out.alloc(nq));
-  HIP_TRY(hipMemcpy(d_in.p, in, nq * sizeof(u64), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_lf_node, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
+  Lease lease(ix);
+  HIP_TRY(lease.begin(2 * Lease::need(nq * 8)));
+  u64* d_in = lease.dev<u64>(nq); u64* d_out = lease.dev<u64>(nq);
+  HIP_TRY(lease.up(d_in, in, nq * sizeof(u64)));
+  hipLaunchKernelGGL(k_lf_node, dim3(grid_for(nq)), dim3(TPB), 0, lease.stream(), ix->img, d_in, nq, d_out);
   LAUNCH_CHECK("k_lf_node");
-  HIP_TRY(hipMemcpy(out, d_out.p, nq * sizeof(u64), hipMemcpyDeviceToHost));
+  HIP_TRY(lease.down(out, d_out, nq * sizeof(u64)));
+  HIP_TRY(lease.finish());
   return GCSA2_OK;
 }
 
@@ -1098,13 +1248,15 @@ int gcsa2_lf_all_batch(const gcsa2_index* ix, const uint64_t* in, uint64_t nq, i
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
-  u64 sigma = ix->img.sigma;
-  DBuf<u64> d_in, d_out;
-  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(2 * nq * sigma));
-  HIP_TRY(hipMemcpy(d_in.p, in, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_lf_all, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, all, d_out.p);
+  const u64 sigma = ix->img.sigma;
+  Lease lease(ix);
+  HIP_TRY(lease.begin(Lease::need(2 * nq * 8) + Lease::need(2 * nq * sigma * 8)));
+  u64* d_in = lease.dev<u64>(2 * nq); u64* d_out = lease.dev<u64>(2 * nq * sigma);
+  HIP_TRY(lease.up(d_in, in, 2 * nq * sizeof(u64)));
+  hipLaunchKernelGGL(k_lf_all, dim3(grid_for(nq)), dim3(TPB), 0, lease.stream(), ix->img, d_in, nq, all, d_out);
   LAUNCH_CHECK("k_lf_all");
-  HIP_TRY(hipMemcpy(out, d_out.p, 2 * nq * sigma * sizeof(u64), hipMemcpyDeviceToHost));
+  HIP_TRY(lease.down(out, d_out, 2 * nq * sigma * sizeof(u64)));
+  HIP_TRY(lease.finish());
   return GCSA2_OK;
 }
 
@@ -1113,12 +1265,14 @@ int gcsa2_count_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
-  DBuf<u64> d_in, d_out;
-  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(nq));
-  HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
-  int rc = gcsa2_count_device(ix, d_in.p, nq, d_out.p, nullptr);
+  Lease lease(ix);
+  HIP_TRY(lease.begin(Lease::need(2 * nq * 8) + Lease::need(nq * 8)));
+  u64* d_in = lease.dev<u64>(2 * nq); u64* d_out = lease.dev<u64>(nq);
+  HIP_TRY(lease.up(d_in, ranges, 2 * nq * sizeof(u64)));
+  int rc = gcsa2_count_device(ix, d_in, nq, d_out, lease.stream());
   if(rc != GCSA2_OK) { return rc; }
-  HIP_TRY(hipMemcpy(counts, d_out.p, nq * sizeof(u64), hipMemcpyDeviceToHost));
+  HIP_TRY(lease.down(counts, d_out, nq * sizeof(u64)));
+  HIP_TRY(lease.finish());
   return GCSA2_OK;
 }
 
@@ -1127,14 +1281,15 @@ int gcsa2_locate_run(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq,
   CHECK_INDEX(ix);
   if(offsets == nullptr || job == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
   DeviceGuard guard(ix->device);
-  DBuf<u64> d_in;
-  HIP_TRY(d_in.alloc(2 * nq));
-  if(nq > 0) { HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice)); }
+  Lease lease(ix);
+  HIP_TRY(lease.begin(Lease::need(2 * nq * 8)));
+  u64* d_in = lease.dev<u64>(2 * nq);
+  HIP_TRY(lease.up(d_in, ranges, 2 * nq * sizeof(u64)));
   const u64* d_off = nullptr;
-  int rc = gcsa2_locate_device(ix, d_in.p, nq, sort, job, &d_off, nullptr, nullptr, nullptr);
+  int rc = gcsa2_locate_device(ix, d_in, nq, sort, job, &d_off, nullptr, nullptr, lease.stream());
   if(rc != GCSA2_OK) { return rc; }
-  HIP_TRY(hipMemcpyAsync(offsets, d_off, (nq + 1) * sizeof(u64), hipMemcpyDeviceToHost, nullptr));   // in the job's stream order
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(lease.down(offsets, d_off, (nq + 1) * sizeof(u64)));      // in the job's stream order
+  HIP_TRY(lease.finish());
   return GCSA2_OK;
 }
 
@@ -1157,15 +1312,11 @@ int gcsa2_locate_fetch(gcsa2_locate_job* job, uint64_t* values, uint64_t capacit
 int gcsa2_parent_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, gcsa2_stnode* nodes)
 {
   CHECK_INDEX(ix);
+  if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
   if(nq == 0) { return GCSA2_OK; }
-  DeviceGuard guard(ix->device);
-  DBuf<u64> d_in; DBuf<gcsa2_stnode> d_out;
-  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(nq));
-  HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
-  int rc = gcsa2_parent_device(ix, d_in.p, nq, d_out.p, nullptr);
-  if(rc != GCSA2_OK) { return rc; }
-  HIP_TRY(hipMemcpy(nodes, d_out.p, nq * sizeof(gcsa2_stnode), hipMemcpyDeviceToHost));
-  return GCSA2_OK;
+  static_assert(sizeof(gcsa2_stnode) == 5 * sizeof(u64), "gcsa2_stnode is five packed u64");
+  return simple_batch(ix, ranges, 2, reinterpret_cast<uint64_t*>(nodes), 5, nq, "k_parent", [&](u64* d_in, u64* d_out, hipStream_t st)
+  { hipLaunchKernelGGL(k_parent, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_in, nq, reinterpret_cast<gcsa2_stnode*>(d_out)); });
 }
 
 int gcsa2_depth_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, uint64_t* depths)
@@ -1173,14 +1324,8 @@ int gcsa2_depth_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq
   CHECK_INDEX(ix);
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
   if(nq == 0) { return GCSA2_OK; }
-  DeviceGuard guard(ix->device);
-  DBuf<u64> d_in, d_out;
-  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(nq));
-  HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_depth, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
-  LAUNCH_CHECK("k_depth");
-  HIP_TRY(hipMemcpy(depths, d_out.p, nq * sizeof(u64), hipMemcpyDeviceToHost));
-  return GCSA2_OK;
+  return simple_batch(ix, ranges, 2, depths, 1, nq, "k_depth", [&](u64* d_in, u64* d_out, hipStream_t st)
+  { hipLaunchKernelGGL(k_depth, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_in, nq, d_out); });
 }
 
 int gcsa2_sv_batch(const gcsa2_index* ix, int op, const uint64_t* positions, uint64_t nq, uint64_t* results)
@@ -1189,14 +1334,8 @@ int gcsa2_sv_batch(const gcsa2_index* ix, int op, const uint64_t* positions, uin
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
   if(op < 0 || op > 3) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "op must be 0..3"); }
   if(nq == 0) { return GCSA2_OK; }
-  DeviceGuard guard(ix->device);
-  DBuf<u64> d_in, d_out;
-  HIP_TRY(d_in.alloc(nq)); HIP_TRY(d_out.alloc(2 * nq));
-  HIP_TRY(hipMemcpy(d_in.p, positions, nq * sizeof(u64), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_sv, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, op, d_in.p, nq, d_out.p);
-  LAUNCH_CHECK("k_sv");
-  HIP_TRY(hipMemcpy(results, d_out.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
-  return GCSA2_OK;
+  return simple_batch(ix, positions, 1, results, 2, nq, "k_sv", [&](u64* d_in, u64* d_out, hipStream_t st)
+  { hipLaunchKernelGGL(k_sv, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, op, d_in, nq, d_out); });
 }
 
 int gcsa2_rmq_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, uint64_t* results)
@@ -1204,14 +1343,8 @@ int gcsa2_rmq_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq, 
   CHECK_INDEX(ix);
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
   if(nq == 0) { return GCSA2_OK; }
-  DeviceGuard guard(ix->device);
-  DBuf<u64> d_in, d_out;
-  HIP_TRY(d_in.alloc(2 * nq)); HIP_TRY(d_out.alloc(2 * nq));
-  HIP_TRY(hipMemcpy(d_in.p, ranges, 2 * nq * sizeof(u64), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_rmq, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
-  LAUNCH_CHECK("k_rmq");
-  HIP_TRY(hipMemcpy(results, d_out.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
-  return GCSA2_OK;
+  return simple_batch(ix, ranges, 2, results, 2, nq, "k_rmq", [&](u64* d_in, u64* d_out, hipStream_t st)
+  { hipLaunchKernelGGL(k_rmq, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_in, nq, d_out); });
 }
 
 int gcsa2_sample_range_batch(const gcsa2_index* ix, const uint64_t* nodes, uint64_t nq, uint64_t* out)
@@ -1219,14 +1352,8 @@ int gcsa2_sample_range_batch(const gcsa2_index* ix, const uint64_t* nodes, uint6
   CHECK_INDEX(ix);
   if(!ix->img.has_samples) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without samples"); }
   if(nq == 0) { return GCSA2_OK; }
-  DeviceGuard guard(ix->device);
-  DBuf<u64> d_in, d_out;
-  HIP_TRY(d_in.alloc(nq)); HIP_TRY(d_out.alloc(3 * nq));
-  HIP_TRY(hipMemcpy(d_in.p, nodes, nq * sizeof(u64), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_sample_range, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
-  LAUNCH_CHECK("k_sample_range");
-  HIP_TRY(hipMemcpy(out, d_out.p, 3 * nq * sizeof(u64), hipMemcpyDeviceToHost));
-  return GCSA2_OK;
+  return simple_batch(ix, nodes, 1, out, 3, nq, "k_sample_range", [&](u64* d_in, u64* d_out, hipStream_t st)
+  { hipLaunchKernelGGL(k_sample_range, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_in, nq, d_out); });
 }
 
 int gcsa2_sample_batch(const gcsa2_index* ix, const uint64_t* idx, uint64_t nq, uint64_t* values, uint8_t* last)
@@ -1235,13 +1362,15 @@ int gcsa2_sample_batch(const gcsa2_index* ix, const uint64_t* idx, uint64_t nq, 
   if(!ix->img.has_samples) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without samples"); }
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
-  DBuf<u64> d_in, d_val; DBuf<u8> d_last;
-  HIP_TRY(d_in.alloc(nq)); HIP_TRY(d_val.alloc(nq)); HIP_TRY(d_last.alloc(nq));
-  HIP_TRY(hipMemcpy(d_in.p, idx, nq * sizeof(u64), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_sample, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_val.p, d_last.p);
+  Lease lease(ix);
+  HIP_TRY(lease.begin(2 * Lease::need(nq * 8) + Lease::need(nq)));
+  u64* d_in = lease.dev<u64>(nq); u64* d_val = lease.dev<u64>(nq); u8* d_last = lease.dev<u8>(nq);
+  HIP_TRY(lease.up(d_in, idx, nq * sizeof(u64)));
+  hipLaunchKernelGGL(k_sample, dim3(grid_for(nq)), dim3(TPB), 0, lease.stream(), ix->img, d_in, nq, d_val, d_last);
   LAUNCH_CHECK("k_sample");
-  HIP_TRY(hipMemcpy(values, d_val.p, nq * sizeof(u64), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(last, d_last.p, nq, hipMemcpyDeviceToHost));
+  HIP_TRY(lease.down(values, d_val, nq * sizeof(u64)));
+  HIP_TRY(lease.down(last, d_last, nq));
+  HIP_TRY(lease.finish());
   return GCSA2_OK;
 }
 
@@ -1263,14 +1392,8 @@ int gcsa2_lcp_access_batch(const gcsa2_index* ix, const uint64_t* positions, uin
   CHECK_INDEX(ix);
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
   if(nq == 0) { return GCSA2_OK; }
-  DeviceGuard guard(ix->device);
-  DBuf<u64> d_in, d_out;
-  HIP_TRY(d_in.alloc(nq)); HIP_TRY(d_out.alloc(nq));
-  HIP_TRY(hipMemcpy(d_in.p, positions, nq * sizeof(u64), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_lcp_access, dim3(grid_for(nq)), dim3(TPB), 0, nullptr, ix->img, d_in.p, nq, d_out.p);
-  LAUNCH_CHECK("k_lcp_access");
-  HIP_TRY(hipMemcpy(out, d_out.p, nq * sizeof(u64), hipMemcpyDeviceToHost));
-  return GCSA2_OK;
+  return simple_batch(ix, positions, 1, out, 1, nq, "k_lcp_access", [&](u64* d_in, u64* d_out, hipStream_t st)
+  { hipLaunchKernelGGL(k_lcp_access, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_in, nq, d_out); });
 }
 
 // GCSA::locate(range, max_positions, results) (src/gcsa.cpp:844-878): host control flow with the
@@ -1673,17 +1796,19 @@ extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* pat
   if(nq == 0) { return GCSA2_OK; }
   if(offsets == nullptr || ms == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
   DeviceGuard guard(ix->device);
-  u64 total = offsets[nq];
-  DBuf<u8> d_pat; DBuf<u64> d_off, d_rng, d_fb; DBuf<uint16_t> d_ms;
-  HIP_TRY(d_pat.alloc(total + 8)); HIP_TRY(d_off.alloc(nq + 1)); HIP_TRY(d_rng.alloc(2 * nq)); HIP_TRY(d_fb.alloc(nq));
-  HIP_TRY(d_ms.alloc(total + 1));
-  if(total > 0) { HIP_TRY(hipMemcpy(d_pat.p, patterns, total, hipMemcpyHostToDevice)); }
-  HIP_TRY(hipMemcpy(d_off.p, offsets, (nq + 1) * sizeof(u64), hipMemcpyHostToDevice));
-  int rc = gcsa2_match_stats_device(ix, d_pat.p, d_off.p, nq, d_ms.p, d_rng.p, d_fb.p, nullptr);
+  const u64 total = offsets[nq];
+  Lease lease(ix);
+  HIP_TRY(lease.begin(Lease::need(total + 16) + Lease::need((nq + 1) * 8) + Lease::need(2 * nq * 8) + Lease::need(nq * 8) + Lease::need((total + 8) * 2)));
+  u8* d_pat = lease.dev<u8>(total + 16); u64* d_off = lease.dev<u64>(nq + 1); u64* d_rng = lease.dev<u64>(2 * nq);
+  u64* d_fb = lease.dev<u64>(nq); uint16_t* d_ms = lease.dev<uint16_t>(total + 8);
+  HIP_TRY(lease.up(d_pat, patterns, total));
+  HIP_TRY(lease.up(d_off, offsets, (nq + 1) * sizeof(u64)));
+  int rc = gcsa2_match_stats_device(ix, d_pat, d_off, nq, d_ms, d_rng, d_fb, lease.stream());
   if(rc != GCSA2_OK) { return rc; }
-  if(total > 0) { HIP_TRY(hipMemcpy(ms, d_ms.p, total * sizeof(uint16_t), hipMemcpyDeviceToHost)); }
-  HIP_TRY(hipMemcpy(ranges, d_rng.p, 2 * nq * sizeof(u64), hipMemcpyDeviceToHost));
-  if(fallbacks != nullptr) { HIP_TRY(hipMemcpy(fallbacks, d_fb.p, nq * sizeof(u64), hipMemcpyDeviceToHost)); }
+  HIP_TRY(lease.down(ms, d_ms, total * sizeof(uint16_t)));
+  HIP_TRY(lease.down(ranges, d_rng, 2 * nq * sizeof(u64)));
+  if(fallbacks != nullptr) { HIP_TRY(lease.down(fallbacks, d_fb, nq * sizeof(u64))); }
+  HIP_TRY(lease.finish());
   return GCSA2_OK;
 }
 
