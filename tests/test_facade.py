@@ -11,11 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cpp", "facade_test.cpp")
 
 
-def compile_client(out):
+def compile_client(out, src=SRC):
     import __graft_entry__ as entry
     entry.build()
     libdir = os.path.join(ROOT, "gcsa2_amd", "lib")
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), SRC, "-o", out,
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", out,
            "-L", libdir, "-lgcsa2_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
            "-Wl,--allow-shlib-undefined"]
     subprocess.check_call(cmd)
@@ -199,3 +199,63 @@ def test_count_kmers_cli_matches_oracle(tmp_path):
         assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, want.tolist()))
     bad = subprocess.run([exe, "-k", "9", str(tmp_path / "nothing")], env=_run_env(), capture_output=True, text=True)
     assert bad.returncode != 0 and "Cannot load the index" in bad.stderr
+
+
+REF_CLIENT = os.path.join(ROOT, "tests", "cpp", "ref_api_client.cpp")
+
+
+def test_reference_api_client_compiles_and_links(tmp_path):
+    """A program that includes <gcsa/gcsa.h>, <gcsa/lcp.h>, <gcsa/algorithms.h> and uses the reference's names only
+    (tests/cpp/ref_api_client.cpp) builds against include/ and libgcsa2_hip.so; it mentions nothing of the engine."""
+    text = open(REF_CLIENT).read()
+    code = "\n".join(line.split("//")[0] for line in text.split("\n") if not line.startswith("#define GCSA2_HIP_SDSL_IO"))
+    assert "gcsa2_" not in code and "retainHostView" in code        # one engine knob, for serialize()
+    exe = compile_client(str(tmp_path / "ref_api_client"), REF_CLIENT)
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_reference_api_client_matches_oracle(tmp_path):
+    """The same program run on the GPU against .gcsa / .lcp files: header, alphabet, find (all three overloads and the
+    charRange + LF loop), parent / depth / nodeFor, count, locate, countKMers, copies, serialize() byte-identical to the
+    files it loaded, load() errors, two structures in one stream -- every line compared with the oracle."""
+    from workload import graphs, builder, patterns, sdsl_format
+    from oracle.oracle import OracleIndex
+    g = graphs.snp_graph(3000, 0x81, 0x82, snp_period=10, node_len=16)
+    ix = builder.build(g, 16, sample_period=16, branching=8)
+    cpu = OracleIndex(ix)
+    pats = [bytes(p[: 3 + q % 12]) for q, p in enumerate(patterns.walk_patterns(g, 60, 16, 0x83))]
+    pats += [bytes(p) for p in patterns.uniform_patterns(12, 9, 0x84)] + [b"ACGTN", b"A"]
+    base = str(tmp_path / "index")
+    sdsl_format.write(ix, base)
+    (tmp_path / "patterns.txt").write_text("\n".join(p.decode() for p in pats) + "\n")
+    exe = compile_client(str(tmp_path / "ref_api_client"), REF_CLIENT)
+    out = subprocess.run([exe, base, str(tmp_path / "patterns.txt")], capture_output=True, text=True, env=_run_env(), timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    it = iter(out.stdout.strip().split("\n"))
+    assert next(it) == f"header 1 3 {ix.n} {ix.e} {ix.order} 0"
+    assert next(it) == f"index {ix.n} {ix.e} {ix.order} {ix.sample_count} {ix.sample_width} 0"
+    assert next(it) == f"alpha {ix.sigma} {ix.fast_chars} $ACGTN# " + " ".join(str(int(c)) for c in ix.C)
+    assert next(it) == f"lcp 1 {ix.lcp_size} {int(ix.lcp_offsets[-1])} {len(ix.lcp_offsets) - 1} {ix.lcp_branching}"
+    located = 0
+    for p in pats:
+        sp, ep = cpu.find(p)
+        length = (ep + 1 - sp) % (1 << 64)
+        assert next(it) == f"find {sp} {ep} 1 1 {length} {int(sp > ep)}", p
+        if sp > ep or ep >= ix.n:
+            continue
+        par = cpu.parent((sp, ep))
+        assert next(it) == f"parent {par[0]} {par[1]} {par[4]} {cpu.depth((par[0], par[1]))} 1"
+        vals = cpu.locate((sp, ep))
+        text = " ".join(f"{int(v) >> 11}:{'-' if (int(v) >> 10) & 1 else ''}{int(v) & 1023}" for v in vals)
+        assert next(it) == (f"locate {cpu.count((sp, ep))} {len(vals)} " + text).rstrip()
+        located += len(vals)
+    assert located > 0
+    assert next(it) == f"kmers {cpu.count_kmers(3)}"
+    first = cpu.find(pats[0])
+    assert next(it) == f"copies 0 {ix.n} 1 0 0"          # `copy` was swapped away: an empty index answers (0, size() - 1)
+    assert next(it) == "serialize 1 1 1 1"
+    assert next(it) == "gcsa error 1"
+    assert next(it) == "lcp error 1"
+    assert next(it) == f"stream {ix.n} {ix.lcp_size} 1"
+    assert first[0] <= first[1]

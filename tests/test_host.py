@@ -274,9 +274,7 @@ def test_serialize_matches_the_file_format_restatement(built):
         raw = built.serialize_view(holder.ref(), "gcsa")
         assert raw == sdsl_format.gcsa_bytes(ix)
         lcp_raw = built.serialize_view(holder.ref(), "lcp")
-        want_lcp = sdsl_format.lcp_bytes(ix)
-        if int(np.max(ix.lcp_data)) >= 128:            # the Python writer always uses 8 bits; C++ bit-compresses (lcp.cpp:258)
-            assert lcp_raw == want_lcp
+        assert lcp_raw == sdsl_format.lcp_bytes(ix)
         h, vp, used = built.parse_view(raw, "gcsa")
         _view_matches(vp.contents, ix)
         built.free_view(h)

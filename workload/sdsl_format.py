@@ -187,13 +187,18 @@ def gcsa_bytes(ix):
 
 
 def lcp_bytes(ix):
-    """The `.lcp` byte stream (LCPArray::serialize, src/lcp.cpp:116-128)."""
+    """The `.lcp` byte stream (LCPArray::serialize, src/lcp.cpp:116-128); the data vector is bit-compressed to the
+    width of its largest value, as the reference's constructor leaves it (sdsl::util::bit_compress, src/lcp.cpp:258)."""
     data = np.asarray(ix.lcp_data, dtype=np.uint8)
-    padded = np.zeros(((len(data) + 7) // 8) * 8, dtype=np.uint8)
-    padded[: len(data)] = data
-    return (struct.pack("<IIQQQ", LCP_TAG, LCP_VERSION, int(ix.lcp_size), int(ix.lcp_branching), 0)   # files.cpp:581-593
-            + struct.pack("<QB", len(data) * 8, 8) + padded.tobytes()
-            + int_vector(np.asarray(ix.lcp_offsets, dtype=np.uint64), 64, True))
+    width = _hi(int(data.max()) if len(data) else 0) + 1
+    head = struct.pack("<IIQQQ", LCP_TAG, LCP_VERSION, int(ix.lcp_size), int(ix.lcp_branching), 0)   # files.cpp:581-593
+    if width == 8:
+        padded = np.zeros(((len(data) + 7) // 8) * 8, dtype=np.uint8)
+        padded[: len(data)] = data
+        body = struct.pack("<QB", len(data) * 8, 8) + padded.tobytes()
+    else:
+        body = int_vector(data.astype(np.uint64), width, False)
+    return head + body + int_vector(np.asarray(ix.lcp_offsets, dtype=np.uint64), 64, True)
 
 
 def write(ix, base):
