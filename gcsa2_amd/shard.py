@@ -64,7 +64,8 @@ def gpu_find_compute(gpu, device):
     torch tensors (device memory + current stream are torch plumbing)."""
     def compute(sub_flat, sub_off):
         n = int(sub_off.shape[0]) - 1
-        d_pat = torch.from_numpy(sub_flat).to(device)
+        # 8 spare bytes: the device entry points read patterns in aligned 8-byte words (include/gcsa2_hip.h)
+        d_pat = torch.from_numpy(np.concatenate([sub_flat, np.zeros(8, dtype=np.uint8)])).to(device)
         d_off = torch.from_numpy(sub_off.view(np.int64)).to(device)
         d_out = torch.zeros((n, 2), dtype=torch.int64, device=device)
         if n > 0:

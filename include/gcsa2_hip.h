@@ -19,6 +19,12 @@
  *     synchronise.  `*_device` entry points take DEVICE pointers on the handle's device, only
  *     enqueue work on `stream` (a hipStream_t passed as void*, NULL = default stream) and do
  *     not synchronise -- they are what the benchmark and the multi-GPU driver use.
+ *   - Device buffers of the `*_device` entry points: d_patterns is read in aligned 8-byte words, so the
+ *     allocation must extend to the 8-byte boundary at or after its last pattern byte and start at or before the
+ *     8-byte boundary at or before its first one (any hipMalloc'd buffer of `total bytes + 8` starting with the
+ *     first pattern satisfies both); d_offsets, d_ranges and every other u64 array must be 8-byte aligned, range
+ *     pairs 16-byte aligned; d_ms of gcsa2_match_stats_device must be 8-byte aligned and hold 4 spare entries.
+ *     The host-pointer entry points have no such requirements (they stage into padded buffers).
  *   - Return value: GCSA2_OK (0) or a negative gcsa2_status.  Query entry points do not
  *     validate ranges or comps, exactly like the reference's low-level interface
  *     (include/gcsa/gcsa.h:133-135); count/locate apply the reference's `ep >= size()` guard.

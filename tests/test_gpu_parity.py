@@ -54,6 +54,13 @@ def test_paper_example_on_gpu(engine, paper):
     assert gpu.LF((9, 12), 1) == (2, 4)
     assert gpu.find(b"") == (0, 15)
     assert gpu.size() == 16 and gpu.edgeCount() == 20 and gpu.order() == 3
+    # the LCP family against the answers derived from the figure's keys (tests/golden/make_paper_lcp.py)
+    from test_oracle import check_paper_suffix_tree
+    for branching in (2, 3, 64):
+        ix = build(graphs.paper_graph(), paper["order"], sample_period=1 << 40, branching=branching)
+        gpu, lcp = engine.open_index(ix)
+        check_paper_suffix_tree(paper, [int(x) for x in lcp.access_batch(np.arange(ix.n, dtype=np.uint64))],
+                                lcp.parent, lcp.depth, lcp.psv, lcp.nsv, lcp.rmq, lcp.notFound())
 
 
 def test_find(case):

@@ -62,6 +62,36 @@ def test_oracle_on_paper_example(paper):
     assert o.find(b"") == (0, 15)
 
 
+def check_paper_suffix_tree(paper, lcp_values, parent, depth, psv, nsv, rmq, not_found):
+    """Shared by the oracle (CPU) and the engine (GPU): the answers tests/golden/make_paper_lcp.py derived from
+    the figure's keys by the definitions."""
+    st = paper["suffix_tree"]
+    assert list(lcp_values) == st["lcp"]
+    for i, (p, n) in enumerate(zip(st["psv"], st["nsv"])):
+        assert psv(i) == (tuple(p) if p is not None else not_found), ("psv", i)
+        assert nsv(i) == (tuple(n) if n is not None else not_found), ("nsv", i)
+    for case in st["parent"]:
+        got = parent(tuple(case["range"]))
+        assert got == (case["parent"][0], case["parent"][1], case["left_lcp"], case["right_lcp"], case["node_lcp"]), case
+        if case["parent"][1] > case["parent"][0]:
+            assert depth(tuple(case["parent"])) == case["node_lcp"], case
+    for case in st["depth"]:
+        assert depth(tuple(case["range"])) == case["depth"], case
+    for case in st["rmq"]:
+        assert rmq(*case["range"]) == (case["pos"], case["value"]), case
+
+
+def test_oracle_on_paper_suffix_tree(paper):
+    """LCPArray family pinned on reference-held material: the LCP array of the worked example follows from the
+    figure's sorted keys (definition at paper.tex:600, path_graph.cpp:1204), and parent / depth / psv / nsv / rmq
+    follow from it (paper.tex:600-604) -- for several tree shapes (branching 2, 3, 4, 64)."""
+    for branching in (2, 3, 4, 64):
+        ix = build(graphs.paper_graph(), paper["order"], sample_period=1 << 40, branching=branching)
+        o = OracleIndex(ix)
+        values = int(ix.lcp_offsets[-1])
+        check_paper_suffix_tree(paper, [int(x) for x in ix.lcp_data[: ix.n]], o.parent, o.depth, o.psv, o.nsv, o.rmq, (values, values))
+
+
 # ---------------------------------------------------------------------------------------------
 # 2. differential tests
 
