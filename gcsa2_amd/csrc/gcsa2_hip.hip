@@ -1016,7 +1016,7 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
   // scan of the raw counts goes straight into the job's offsets (final as they are unless duplicates
   // have to be removed, rewritten in place otherwise)
   u64* sizes = nullptr; u64* segs = nullptr;
-  unsigned long long* d_totals = ix->d_slots + 8 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);   // {nodes, raw, large, unique, multi}
+  unsigned long long* d_totals = ix->d_slots + 8 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);   // {nodes, raw, large, unique, multi, medium}
   HIP_TRY(scratch.get(sizes, 3 * (nq + 1))); HIP_TRY(scratch.get(segs, 2 * nq));
   u64 *node_counts = sizes, *raw_counts = sizes + (nq + 1), *node_off = sizes + 2 * (nq + 1), *raw_off = d_offsets;
   u64 *seg_begin = segs, *seg_end = segs + nq;
@@ -1031,12 +1031,14 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, node_counts, node_off, int(nq + 1), stream));
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, raw_counts, raw_off, int(nq + 1), stream));
   // segments with more than one raw value: the only ones removeDuplicates has to touch
-  hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end);
+  // GCSA2_SORT_MEDIUM=0 sends the 17..1024-value segments to the segmented radix sort as well (A/B measurements)
+  static const u32 medium_limit = []() { const char* e = std::getenv("GCSA2_SORT_MEDIUM"); return (e != nullptr && std::atoi(e) == 0) ? SMALL_SEGMENT : MEDIUM_SEGMENT; }();
+  hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, medium_limit);
   LAUNCH_CHECK("k_collect_multi");
-  unsigned long long totals[5] = {0, 0, 0, 0, 0};
+  unsigned long long totals[6] = {0, 0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
-  const u64 total_nodes = totals[0], total_raw = totals[1], large = totals[2], multi = totals[4];
+  const u64 total_nodes = totals[0], total_raw = totals[1], large = totals[2], multi = totals[4], medium = totals[5];
   if(total_raw >= (u64(1) << 31)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate batch produces >= 2^31 values; split the batch"); }
 
   if(total_raw == 0)
@@ -1073,6 +1075,11 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
     }
     hipLaunchKernelGGL(k_sort_small, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, sorted);
     LAUNCH_CHECK("k_sort_small");
+    if(medium > 0)
+    {
+      hipLaunchKernelGGL(k_sort_medium, dim3(unsigned(medium)), dim3(64), 0, stream, seg_begin, seg_end, nq - 1, sorted);
+      LAUNCH_CHECK("k_sort_medium");
+    }
     if(large > 0)
     {
       size_t sort_bytes = 0;

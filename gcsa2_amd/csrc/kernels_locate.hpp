@@ -260,14 +260,17 @@ __device__ __forceinline__ u64 wg_reserve(WgSlots& sh, unsigned long long* count
 }
 
 // removeDuplicates (utils.h:350-357) sorts the values of a query.  Queries with one value need nothing,
-// queries with 2..SMALL_SEGMENT values are sorted in registers by one lane each (k_sort_small), the
-// rest goes to hipCUB's segmented radix sort.  k_collect_multi lists the large segments and publishes
-// totals = {nodes, raw values, large segments, (unique values, written later), segments with >= 2 values}.
+// queries with 2..SMALL_SEGMENT values are sorted in registers by one lane each (k_sort_small), queries with up to
+// MEDIUM_SEGMENT values by one wavefront each in LDS (k_sort_medium), the rest goes to hipCUB's segmented radix sort.
+// k_collect_multi lists the medium segments (from the end of the segment arrays, downwards) and the large ones
+// (from the start) and publishes totals = {nodes, raw values, large segments, (unique values, written later),
+// segments with >= 2 values, medium segments}.
 constexpr u32 SMALL_SEGMENT = 16;
+constexpr u32 MEDIUM_SEGMENT = 1024;
 
 __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
                                                        unsigned long long* __restrict__ totals,
-                                                       u64* __restrict__ seg_begin, u64* __restrict__ seg_end)
+                                                       u64* __restrict__ seg_begin, u64* __restrict__ seg_end, u32 medium_limit)
 {
   __shared__ WgSlots slots;
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
@@ -275,7 +278,8 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
   if(q == 0) { totals[0] = node_off[nq]; totals[1] = raw_off[nq]; }
   u64 b = 0, e = 0;
   if(q < nq) { b = raw_off[q]; e = raw_off[q + 1]; }
-  const u64 multi = __ballot(e - b >= 2), large = __ballot(e - b > SMALL_SEGMENT);
+  const u64 multi = __ballot(e - b >= 2), large = __ballot(e - b > medium_limit);
+  const u64 medium = __ballot(e - b > SMALL_SEGMENT && e - b <= medium_limit);
   wg_reserve(slots, totals + 4, u32(__popcll(multi)));
   u64 slot = wg_reserve(slots, totals + 2, u32(__popcll(large)));
   if((large >> lane) & 1)
@@ -283,6 +287,42 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
     slot += __popcll(large & ((u64(1) << lane) - 1));
     seg_begin[slot] = b; seg_end[slot] = e;
   }
+  slot = wg_reserve(slots, totals + 5, u32(__popcll(medium)));
+  if((medium >> lane) & 1)
+  {
+    slot += __popcll(medium & ((u64(1) << lane) - 1));
+    seg_begin[nq - 1 - slot] = b; seg_end[nq - 1 - slot] = e;        // a query is in at most one of the two lists
+  }
+}
+
+// one wavefront (= one workgroup) per query with SMALL_SEGMENT + 1 .. MEDIUM_SEGMENT values: bitonic sort in LDS,
+// in place.  Segment s of the list is the one at seg_begin / seg_end [last - s].
+__global__ __launch_bounds__(64) void k_sort_medium(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end, u64 last,
+                                                    u64* __restrict__ values)
+{
+  __shared__ u64 buf[MEDIUM_SEGMENT];
+  const u32 lane = threadIdx.x;
+  const u64 b = seg_begin[last - blockIdx.x];
+  const u32 len = u32(seg_end[last - blockIdx.x] - b);
+  u32 n2 = 64;
+  while(n2 < len) { n2 <<= 1; }
+  for(u32 i = lane; i < n2; i += 64) { buf[i] = (i < len ? values[b + i] : ~u64(0)); }    // padding sorts to the end
+  __syncthreads();
+  for(u32 k = 2; k <= n2; k <<= 1)
+  {
+    for(u32 j = k >> 1; j > 0; j >>= 1)
+    {
+      for(u32 t = lane; t < (n2 >> 1); t += 64)
+      {
+        const u32 l = ((t & ~(j - 1)) << 1) | (t & (j - 1)), r = l | j;
+        const u64 x = buf[l], y = buf[r];
+        const bool up = ((l & k) == 0);
+        if((x > y) == up) { buf[l] = y; buf[r] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for(u32 i = lane; i < len; i += 64) { values[b + i] = buf[i]; }
 }
 
 // one lane per query with 2..SMALL_SEGMENT values: bitonic network over registers, in place
@@ -472,7 +512,7 @@ __global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* _
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q >= nq) { return; }
-  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; totals[0] = totals[1] = totals[2] = totals[3] = totals[4] = 0; }
+  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; totals[0] = totals[1] = totals[2] = totals[3] = totals[4] = totals[5] = 0; }
   ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
   u64 nodes = 0, raw = 0;
   if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831

@@ -739,3 +739,37 @@ def test_group_find_device_and_comm(engine):
     engine.unpack_ranges32_device(d_packed.data_ptr(), both.shape[0], d_back.data_ptr(), st)
     torch.cuda.synchronize()
     assert torch.equal(d_in, d_back)
+
+
+def test_locate_segment_sizes(engine):
+    """removeDuplicates at every segment size class: 1 value, 2..16 (registers, one lane), 17..1024 (one wavefront in
+    LDS), more (segmented radix sort), mixed in one batch and in both sort modes; ranges of consecutive path nodes of a
+    repetitive SNP graph (many duplicates per segment)."""
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    g = graphs.snp_graph(30000, 0x4D1, 0x4D2, snp_period=5, node_len=16)
+    ix = builder.build(g, 16, sample_period=16)
+    gpu, lcp = engine.open_index(ix)
+    cpu = OracleIndex(ix)
+    rng = SplitMix64(0x4D3)
+    ranges = []
+    for width in (1, 2, 3, 8, 15, 16, 17, 31, 33, 63, 64, 65, 127, 200, 511, 512, 513, 900, 1023, 1024, 1025, 1500, 3000, 7000):
+        for _ in range(6):
+            a = rng.below(ix.n - width)
+            ranges.append((a, a + width - 1))
+    ranges += [(0, ix.n - 1), (5, 4), (ix.n, ix.n + 3)]
+    order = list(range(len(ranges)))
+    for k in range(len(order) - 1, 0, -1):
+        j = rng.below(k + 1)
+        order[k], order[j] = order[j], order[k]
+    arr = np.array([ranges[k] for k in order], dtype=np.uint64)
+    go, gv = gpu.locate_batch(arr)
+    co, cv = cpu.locate_batch(arr, threads=8)
+    assert np.array_equal(go, co) and np.array_equal(gv, cv)
+    # (count() equals the number of located values only for ranges that are suffix-tree nodes, e.g. find() results --
+    # these are arbitrary node ranges, so count() is compared with the oracle's instead)
+    assert np.array_equal(gpu.count_batch(arr), cpu.count_batch(arr))
+    go, gv = gpu.locate_batch(arr, sort=False)
+    for q, r in enumerate(arr):
+        want = cpu.locate((int(r[0]), int(r[1])), sort=False)
+        assert np.array_equal(gv[int(go[q]):int(go[q + 1])], np.asarray(want, dtype=np.uint64)), r
