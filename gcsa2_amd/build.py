@@ -38,6 +38,18 @@ def build_gather_bench(force=False):
     return BENCH_OUT
 
 
+REPRO_SRC = os.path.join(os.path.dirname(HERE), "tools", "hip", "pool_readback_repro.hip")
+REPRO_OUT = os.path.join(HERE, "lib", "pool_readback_repro")
+
+
+def build_pool_repro(force=False):
+    """Reproducer for read-backs out of stream-ordered pool memory (profiles/r02_pool_repro.md)."""
+    if not force and os.path.exists(REPRO_OUT) and os.path.getmtime(REPRO_OUT) >= os.path.getmtime(REPRO_SRC):
+        return REPRO_OUT
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-o", REPRO_OUT, REPRO_SRC])
+    return REPRO_OUT
+
+
 ROOT = os.path.dirname(HERE)
 CLI_SRC = os.path.join(ROOT, "tools", "cpp", "query_gcsa.cpp")
 CLI_OUT = os.path.join(HERE, "lib", "query_gcsa")
