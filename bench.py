@@ -185,8 +185,12 @@ def setup_human(args, D, dev, local_rank):
     degree = args.degree
     # every rank stages its own replica: ~12 bytes of host memory per path node while it does
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", D.world))
-    while degree > 24 and not host_memory_ok(local_world * 12 * (1 << degree)):
-        degree -= 2
+    available = sorted(d for d in mseq_torch.TAPS if d <= degree)
+    if degree not in available:
+        raise SystemExit(f"--degree must be one of {sorted(mseq_torch.TAPS)}")
+    while len(available) > 1 and available[-1] > 24 and not host_memory_ok(local_world * 12 * (1 << available[-1])):
+        available.pop()
+    degree = available[-1]
     if degree != args.degree:
         log(f"warning: host memory too small for {local_world} replicas of degree {args.degree}; using degree {degree}")
     full = (D.world == 1 and not args.no_secondary)
@@ -339,8 +343,9 @@ def measure(args, D, dev, wl, steps, warmup):
     bounds = shard_bounds(wl.total_queries, D.world) if wl.scaling == "strong" else [(r * nq, (r + 1) * nq) for r in range(D.world)]
     counts = [e - b for b, e in bounds]
     total = sum(counts)
-    # wire format: (sp, len) u32 pairs when every path node / edge number is below 2^32, else the u64 pairs
-    pack32 = D.active and max(int(wl.ix.n), int(wl.ix.e)) + 1 < (1 << 32)
+    # wire format: (sp, len) u32 pairs when every path node / edge number is below 2^32 (sp <= max(n, e), len <= n),
+    # else the u64 pairs
+    pack32 = D.active and max(int(wl.ix.n), int(wl.ix.e)) < (1 << 32)
     wire_bytes = 8 if pack32 else 16
     wire = [torch.zeros((nq, 2), dtype=torch.int32, device=dev) for _ in outs] if pack32 else outs
     root = D.active and D.rank == 0

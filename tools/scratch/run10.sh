@@ -1,0 +1,5 @@
+python __graft_entry__.py smoke 2>&1 | tail -2
+GCSA2_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --degree 26 --queries 4000001 --steps 3 --warmup 1 --no-cpu 2>gpurun_out/two_rank.err | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(d['n_gpus'], d['scaling'], d['value'], d['config']['all_ranges_equal_closed_form'], d['config']['parallelism'])"
+python bench.py > gpurun_out/b3.json 2> gpurun_out/b3.err; echo rc=$?; python -c "
+import json; d=json.load(open('gpurun_out/b3.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['cpu_baseline']['value'], d['config5']['patterns_per_s'], d['chr22']['value'])"
