@@ -45,9 +45,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["human", "chr22", "linear"], default="human",
-                    help="human: whole-human-footprint index, one batch sharded over the GPUs (config 4); "
+    ap.add_argument("--workload", choices=["human", "human_snp", "chr22", "linear"], default="human",
+                    help="human: whole-human-footprint index, one batch sharded over the GPUs (config 4); human_snp: the same text "
+                         "with SNP bubbles (branching index, e = 1.08 n; find() only); "
                          "chr22: chr22-like SNP-bubble graph (config 2); linear: 2^30-base linear graph built on the GPU")
+    ap.add_argument("--snp-period", type=int, default=50, help="human_snp: one SNP per this many positions")
     ap.add_argument("--degree", type=int, default=32, help="human: degree of the m-sequence (path nodes = 2^degree - 1)")
     ap.add_argument("--log2-bases", type=int, default=0, help="chr22 / linear: backbone length (default 25 / 30)")
     ap.add_argument("--order", type=int, default=256)
@@ -58,7 +60,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the config-5 and chr22 measurements")
-    ap.add_argument("--secondary", choices=["all", "config5", "chr22"], default="all", help="N = 1: which secondary measurements to run")
+    ap.add_argument("--secondary", choices=["all", "config5", "chr22", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
     ap.add_argument("--variant", type=int, default=2, help="find kernel generation (1 = k_find, 2 = k_find2)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
@@ -176,7 +178,9 @@ def host_memory_ok(bytes_needed):
     return True
 
 
-def setup_human(args, D, dev, local_rank):
+def setup_human(args, D, dev, local_rank, branching=False, total_queries=None):
+    """branching = False: the plain m-sequence text (every structure in closed form: find, locate, parent);
+    branching = True: the same text with one SNP bubble per --snp-period positions (find() only)."""
     import torch
     from workload import mseq_torch
     from gcsa2_amd.binding import GCSA
@@ -193,9 +197,14 @@ def setup_human(args, D, dev, local_rank):
     degree = available[-1]
     if degree != args.degree:
         log(f"warning: host memory too small for {local_world} replicas of degree {args.degree}; using degree {degree}")
-    full = (D.world == 1 and not args.no_secondary)
+    full = (D.world == 1 and not args.no_secondary and not branching)
     t = time.time()
-    ix, sym_t, rank = mseq_torch.build_mseq(degree, device=dev, verbose=log, full=full)
+    alt_t = None
+    if branching:
+        ix, sym_t, rank, alt_t = mseq_torch.build_mseq_snp(degree, period=args.snp_period, device=dev, verbose=log)
+        torch.cuda.empty_cache()
+    else:
+        ix, sym_t, rank = mseq_torch.build_mseq(degree, device=dev, verbose=log, full=full)
     rank_t = torch.from_numpy(rank.view(np.int32)).to(dev)          # rank of every rotation: the closed-form answers
     del rank
     log(f"index arrays: n = {ix.n} ({time.time() - t:.1f} s)")
@@ -204,12 +213,15 @@ def setup_human(args, D, dev, local_rank):
     log(f"device image: {wl.gpu.device_bytes() / 1e9:.2f} GB in HBM, seed table k = {wl.gpu.kmer_table_k()}, "
         f"pair blocks {wl.gpu.pair_block_bytes() / 1e9:.2f} GB ({time.time() - t:.1f} s)")
     wl.ix, wl.sym_t, wl.rank_t, wl.full, wl.degree = ix, sym_t, rank_t, full, degree
-    wl.total_queries = args.queries or 100_000_000
+    wl.total_queries = total_queries or args.queries or 100_000_000
     wl.m = args.pattern_len
     b, e = shard_bounds(wl.total_queries, D.world)[D.rank]
     wl.first, wl.nq = b, e - b
     t = time.time()
-    if args.set == "S":
+    expected = None
+    if args.set == "S" and branching:
+        pats, expected = mseq_torch.walk_patterns_device(sym_t, alt_t, rank_t, b, e - b, wl.m, HUMAN_PATTERN_SEED)
+    elif args.set == "S":
         pats, _ = mseq_torch.substring_patterns_device(sym_t, b, e - b, wl.m, HUMAN_PATTERN_SEED)
     else:
         pats = uniform_patterns_device(b, e - b, wl.m, HUMAN_PATTERN_SEED, dev)
@@ -217,12 +229,27 @@ def setup_human(args, D, dev, local_rank):
     del pats
     wl.d_off = torch.arange(wl.nq + 1, dtype=torch.int64, device=dev) * wl.m
     log(f"patterns: shard [{b}, {e}) of {wl.total_queries} x {wl.m}, set {args.set} ({time.time() - t:.1f} s)")
-    wl.label = (f"whole-human-footprint index (degree-{degree} m-sequence text, {ix.n} path nodes), one batch of "
-                f"{wl.total_queries} x {wl.m}-mer find() sharded over {D.world} GPU(s), pattern set {args.set}")
+    what = (f"degree-{degree} m-sequence text with one SNP bubble per {args.snp_period} positions: order-{degree // 2} de Bruijn graph, "
+            f"{ix.n} path nodes, {ix.e} edges = {ix.e / ix.n:.3f} n" if branching else f"degree-{degree} m-sequence text, {ix.n} path nodes")
+    wl.label = (f"whole-human-footprint index ({what}), one batch of "
+                f"{wl.total_queries} x {wl.m}-mer find() sharded over {D.world} GPU(s), pattern set {args.set}"
+                + (" (walks through the graph, alternative base taken at half of the SNP sites met)" if branching and args.set == "S" else ""))
 
     def verify(d_ranges, first, count):
         if args.set != "S" or wl.m < degree // 2:
             return None
+        if branching:
+            # find() of a walk = the single node of its first k characters (workload/mseq_torch.py); a shard other than
+            # this rank's own is regenerated
+            exp = expected if (first, count) == (b, e - b) else None
+            ok = True
+            step = 1 << 23
+            for c in range(0, count, step):
+                n = min(step, count - c)
+                ex = exp[c:c + n] if exp is not None else mseq_torch.walk_patterns_device(sym_t, alt_t, rank_t, first + c, n, wl.m, HUMAN_PATTERN_SEED)[1]
+                got = d_ranges[c:c + n]
+                ok = ok and bool(torch.equal(got[:, 0], ex)) and bool(torch.equal(got[:, 1], ex))
+            return ok
         # find(T[p .. p + m)) = (rank[p], rank[p]): every degree/2-mer occurs exactly once in the cyclic text
         ok = True
         chunk = 1 << 25
@@ -588,6 +615,21 @@ def chr22_secondary(args, D, dev, local_rank):
     return out
 
 
+def human_snp_secondary(args, D, dev, local_rank):
+    """The headline workload on a BRANCHING index of the same footprint (e = 1.08 n: out- and in-degrees above one wherever a
+    bubble opens, closes or an alternative k-mer lands), every range checked against its closed form."""
+    import torch
+    wl = setup_human(args, D, dev, local_rank, branching=True, total_queries=args.queries or 100_000_000)
+    r = measure(args, D, dev, wl, max(5, args.steps // 2), 2)
+    ok = wl.verify(r["d_out"], wl.first, wl.nq)
+    out = {"workload": wl.label, "value": wl.nq / (r["kernel_ms"] * 1e-3), "unit": "queries/s", "kernel_ms": r["kernel_ms"],
+           "all_ranges_equal_closed_form": ok, "config": find_config(wl, r, 1),
+           "roofline": roofline(args, r, wl, f"human_snp_{wl.degree}_{wl.m}_{args.set}")}
+    del wl, r
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(args, wl, d_out, seconds):
     """The oracle (CPU restatement of the reference path) timed on this host: a bounded sample of
     the same patterns, all cores with the verifyIndex-style static split, plus one thread."""
@@ -659,8 +701,8 @@ def main():
     from gcsa2_amd import binding
     D.make_comm(binding, local_rank)
 
-    if args.workload == "human":
-        wl = setup_human(args, D, dev, local_rank)
+    if args.workload in ("human", "human_snp"):
+        wl = setup_human(args, D, dev, local_rank, branching=(args.workload == "human_snp"))
     elif args.workload == "chr22":
         wl = setup_chr22(args, D, dev, local_rank)
     else:
@@ -675,7 +717,8 @@ def main():
 
     result = None
     if rank == 0:
-        size = {"human": getattr(wl, "degree", args.degree), "chr22": args.log2_bases or 25, "linear": args.log2_bases or 30}[args.workload]
+        size = {"human": getattr(wl, "degree", args.degree), "human_snp": getattr(wl, "degree", args.degree),
+                "chr22": args.log2_bases or 25, "linear": args.log2_bases or 30}[args.workload]
         result = {
             "metric": "kmer_find_queries_per_sec", "value": wl.total_queries * args.steps / r["elapsed"], "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -692,10 +735,13 @@ def main():
     if secondary and args.secondary in ("all", "config5"):
         result["config5"] = config5(args, wl, dev)
     del r
-    if secondary and args.secondary in ("all", "chr22"):
+    if secondary:
         del wl
         torch.cuda.empty_cache()
+    if secondary and args.secondary in ("all", "chr22"):
         result["chr22"] = chr22_secondary(args, D, dev, local_rank)
+    if secondary and args.secondary in ("all", "human_snp"):
+        result["human_branching"] = human_snp_secondary(args, D, dev, local_rank)
     if rank == 0:
         print(json.dumps(result), flush=True)
     D.barrier()

@@ -602,7 +602,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       ix->bytes += nwords * 4 * sizeof(u64);
     }
 
-    // FLP128 pair blocks (two characters per step), built on the device: 8 bytes per path node.  Default on;
+    // FLP128 pair blocks (two characters per step), built on the device: 10.7 bytes per path node.  Default on;
     // skipped when GCSA2_PAIR_BLOCKS=0, when comps 1..4 do not exist, or when they would take more than a third
     // of the free device memory (find() then steps one character at a time, with identical results).
     img.flp = nullptr; img.flp_nblocks = 0;
@@ -617,11 +617,11 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
         if(e == hipSuccess)
         {
           img.flp_nblocks = nb;
-          const u64 slice = u64(1) << 20;          // blocks per launch: 2^20 x 4 workgroups of 256 threads
+          const u64 slice = u64(1) << 20;          // blocks per launch: 2^20 x 4 workgroups of 192 threads
           for(u64 first = 0; first < nb && e == hipSuccess; first += slice)
           {
             const u64 count = (nb - first < slice ? nb - first : slice);
-            hipLaunchKernelGGL(k_build_pair_blocks, dim3(unsigned(count), 4), dim3(256), 0, nullptr, img, first, static_cast<u64*>(ix->d_pairs));
+            hipLaunchKernelGGL(k_build_pair_blocks, dim3(unsigned(count), 4), dim3(unsigned(PAIR_BITS)), 0, nullptr, img, first, static_cast<u64*>(ix->d_pairs));
             e = hipGetLastError();
           }
           if(e == hipSuccess) { e = hipDeviceSynchronize(); }

@@ -157,36 +157,55 @@ __device__ __forceinline__ void eval_endpoint(const ulonglong2 (&blk)[8], u32 r,
 
 // lane-private evaluation of one endpoint of a TWO-character step from a staged FLP128 block (layout.hpp):
 //   raw = H(i) = ecnt + rank(P, r);  sp side (ep_side = false): node = N(raw)
-//   ep side: edge b'' = raw - 1 + D[r], node = N(b'')
-__device__ __forceinline__ void eval_pair(const ulonglong2 (&blk)[8], u32 r, bool ep_side, u64& raw, u64& node)
+//   ep side: edge b'' = raw - 1 + D[r], node = N(b''), dbit = D[r]
+//   qbefore = rank(Q, r) inside the block, qafter = Q bits at or after r in the block
+struct PairEnd { u64 raw, node; u32 dbit, qbefore, qafter; };
+
+__device__ __forceinline__ PairEnd eval_pair(const ulonglong2 (&blk)[8], u32 r, bool ep_side)
 {
   const u64 w[16] = { blk[0].x, blk[0].y, blk[1].x, blk[1].y, blk[2].x, blk[2].y, blk[3].x, blk[3].y,
                       blk[4].x, blk[4].y, blk[5].x, blk[5].y, blk[6].x, blk[6].y, blk[7].x, blk[7].y };
   const u32 wq = r >> 6;
   const u64 part = (u64(1) << (r & 63)) - 1;
-  u32 ones = 0;
-  u64 dword = w[6];
+  u32 ones = 0, qb = 0, qt = 0;
+  u64 dword = w[5];
 #pragma unroll
-  for(u32 j = 0; j < 4; j++)
+  for(u32 j = 0; j < PAIR_WORDS; j++)
   {
-    u64 m = (j < wq ? ~u64(0) : (j == wq ? part : u64(0)));
+    const u64 m = (j < wq ? ~u64(0) : (j == wq ? part : u64(0)));
     ones += __popcll(w[2 + j] & m);
-    if(j == wq) { dword = w[6 + j]; }
+    qb += __popcll(w[8 + j] & m); qt += __popcll(w[8 + j]);
+    if(j == wq) { dword = w[5 + j]; }
   }
-  raw = w[0] + ones;
+  PairEnd out;
+  out.raw = w[0] + ones; out.qbefore = qb; out.qafter = qt - qb;
+  out.dbit = (ep_side ? u32((dword >> (r & 63)) & 1) : 0u);
   const u64 ncnt = w[1] & ~PREV_BIT;
-  const u32 back = (ep_side ? 1u - u32((dword >> (r & 63)) & 1) : 0u);
-  if(back > ones) { node = ncnt - (w[1] >> 63); return; }    // rank(edges, ecnt - 1)
+  const u32 back = (ep_side ? 1u - out.dbit : 0u);
+  if(back > ones) { out.node = ncnt - (w[1] >> 63); return out; }    // rank(edges, ecnt - 1)
   const u32 k = ones - back, kq = k >> 6;
   const u64 kpart = (u64(1) << (k & 63)) - 1;
   u32 cnt = 0;
 #pragma unroll
-  for(u32 j = 0; j < 6; j++)
+  for(u32 j = 0; j < 4; j++)
   {
-    u64 m = (j < kq ? ~u64(0) : (j == kq ? kpart : u64(0)));
-    cnt += __popcll(w[10 + j] & m);
+    const u64 m = (j < kq ? ~u64(0) : (j == kq ? kpart : u64(0)));
+    cnt += __popcll(w[11 + j] & m);
   }
-  node = ncnt + cnt;
+  out.node = ncnt + cnt;
+  return out;
+}
+
+// What a fused pair of steps decides (layout.hpp): 2 = both steps non-empty, take (node_sp, node_ep);
+// 1 = the second step is empty, (a, b) = its edge-space integers; 0 = replay the two steps singly.
+__device__ __forceinline__ u32 pair_outcome(const PairEnd& s, const PairEnd& e, bool same_block, u64& a, u64& b)
+{
+  if(e.raw > s.raw) { return 2; }
+  const bool first_nonempty = (same_block ? e.qbefore > s.qbefore : (e.qbefore > 0 || s.qafter > 0));
+  if(!first_nonempty) { return 0; }
+  if(e.dbit) { return 2; }
+  a = s.raw; b = s.raw - 1;
+  return 1;
 }
 
 // One lane evaluates LF(range, comp) from the fused blocks on its own (no cooperation): used where
@@ -499,6 +518,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       }
     }
     u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
+    [[maybe_unused]] PairEnd p_sp = {0, 0, 0, 0, 0}, p_ep = {0, 0, 0, 0, 0};
     const bool need2 = stepping && idx_ep != idx_sp;
     if(STATS && stepping) { blocks += 1 + (need2 ? 1 : 0); }
     ulonglong2 blk[8];
@@ -508,8 +528,8 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       read_block(wave_stage, lane, blk);
       if(PAIR && pair)
       {
-        eval_pair(blk, r_sp, false, e_sp, n_sp);
-        if(idx_ep == idx_sp) { eval_pair(blk, r_ep, true, e_ep, n_ep); }
+        p_sp = eval_pair(blk, r_sp, false);
+        if(idx_ep == idx_sp) { p_ep = eval_pair(blk, r_ep, true); }
       }
       else
       {
@@ -524,7 +544,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       if(need2)
       {
         read_block(wave_stage, lane, blk);
-        if(PAIR && pair) { eval_pair(blk, r_ep, true, e_ep, n_ep); }
+        if(PAIR && pair) { p_ep = eval_pair(blk, r_ep, true); }
         else { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }      // gcsa.h:272: LF(ep + 1) - 1
       }
     }
@@ -533,15 +553,20 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     {
       if(PAIR && pair)
       {
-        // e_sp = H(sp), e_ep = H(ep + 1).  H(ep + 1) > H(sp) proves that neither of the two steps empties;
-        // anything else is replayed as two single steps from the unchanged (sp, ep).
-        if(e_ep > e_sp)
+        u64 a = 0, b = 0;
+        const u32 outcome = pair_outcome(p_sp, p_ep, idx_ep == idx_sp, a, b);
+        if(outcome == 2)                                       // neither step empties
         {
-          sp = n_sp; ep = n_ep; i -= 2; done = (i == 0);
+          sp = p_sp.node; ep = p_ep.node; i -= 2; done = (i == 0);
           if(STATS) { steps += 2; }
           if constexpr(JUMP) { tried = false; }
         }
-        else { force_single = 2; }
+        else if(outcome == 1)                                  // the second step empties: its edge-space integers, gcsa.h:160
+        {
+          sp = a; ep = b; i -= 2; done = true;
+          if(STATS) { steps += 2; }
+        }
+        else { force_single = 2; }                             // replayed as two single steps from the unchanged (sp, ep)
       }
       else
       {
@@ -599,8 +624,8 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
 
 // ---- FLP128 pair blocks (layout.hpp), built on the device from the RB64 vectors -----------------------
 // grid (blocks, 4), launched in slices of blocks (a HIP grid holds < 2^32 threads): workgroup (b - first, c2 - 1)
-// of 256 threads writes block b of the four pairs (c1, c2), c1 = 1..4; thread r owns position i = 256 b + r.
-__global__ __launch_bounds__(256) void k_build_pair_blocks(DevImage img, u64 first, u64* __restrict__ out)
+// of 192 threads writes block b of the four pairs (c1, c2), c1 = 1..4; thread r owns position i = 192 b + r.
+__global__ __launch_bounds__(192) void k_build_pair_blocks(DevImage img, u64 first, u64* __restrict__ out)
 {
   __shared__ u64 s_ecnt[4];
   const u64 b = first + blockIdx.x, nb = img.flp_nblocks;
@@ -613,6 +638,7 @@ __global__ __launch_bounds__(256) void k_build_pair_blocks(DevImage img, u64 fir
   u64 u = 0;
   const bool ebit = bv_get_rank(img.edges, clampu(x, e), u) && x < e;      // edges[x], u = N(x)
   const bool split = (x >= 1 && x - 1 < e) && !bv_get(img.edges, x - 1);   // position i splits the out-edges of node u
+  const u64 qw = __ballot(valid && q);
 #pragma unroll
   for(u32 c1 = 1; c1 <= 4; c1++)
   {
@@ -620,24 +646,23 @@ __global__ __launch_bounds__(256) void k_build_pair_blocks(DevImage img, u64 fir
     const bool bc = bv_get_rank(bwt_of(img, c1), clampu(u, n), rc) && u < n;
     const u64 pw = __ballot(valid && q && ebit && bc), dw = __ballot(valid && split && bc);
     u64* dst = out + (u64((c1 - 1) * 4 + (c2 - 1)) * nb + b) * FLB_WORDS;
-    if((r & 63) == 0) { dst[2 + (r >> 6)] = pw; dst[6 + (r >> 6)] = dw; }
+    if((r & 63) == 0) { dst[2 + (r >> 6)] = pw; dst[5 + (r >> 6)] = dw; dst[8 + (r >> 6)] = qw; }
     if(r == 0)
     {
-      const u64 ecnt = img.C[c1] + rc;                         // H(256 b)
+      const u64 ecnt = img.C[c1] + rc;                         // H(192 b)
       u64 ncnt = 0;
-      const bool at = bv_get_rank(img.edges, clampu(ecnt, e), ncnt);
-      (void)at;
+      (void)bv_get_rank(img.edges, clampu(ecnt, e), ncnt);
       const u64 prev = (ecnt >= 1 && ecnt - 1 < e && bv_get(img.edges, ecnt - 1)) ? PREV_BIT : 0;
-      dst[0] = ecnt; dst[1] = ncnt | prev;
+      dst[0] = ecnt; dst[1] = ncnt | prev; dst[15] = 0;
       s_ecnt[c1 - 1] = ecnt;
     }
   }
   __syncthreads();
-  if(r < 24)
+  if(r < 16)
   {
-    const u32 c1 = 1 + r / 6, k = r % 6;
+    const u32 c1 = 1 + r / 4, k = r % 4;
     u64* dst = out + (u64((c1 - 1) * 4 + (c2 - 1)) * nb + b) * FLB_WORDS;
-    dst[10 + k] = bv_bits64(img.edges, s_ecnt[c1 - 1] + 64 * k);
+    dst[11 + k] = bv_bits64(img.edges, s_ecnt[c1 - 1] + 64 * k);
   }
 }
 

@@ -500,6 +500,7 @@ __global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* _
       }
     }
     u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
+    PairEnd p_sp = {0, 0, 0, 0, 0}, p_ep = {0, 0, 0, 0, 0};
     const bool need2 = stepping && idx_ep != idx_sp;
     ulonglong2 blk[8];
     if(__any(stepping))
@@ -510,8 +511,8 @@ __global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* _
         read_block(wave_stage, lane, blk);
         if(PAIR && pair)
         {
-          eval_pair(blk, r_sp, false, e_sp, n_sp);
-          if(idx_ep == idx_sp) { eval_pair(blk, r_ep, true, e_ep, n_ep); }
+          p_sp = eval_pair(blk, r_sp, false);
+          if(idx_ep == idx_sp) { p_ep = eval_pair(blk, r_ep, true); }
         }
         else
         {
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* _
         if(need2)
         {
           read_block(wave_stage, lane, blk);
-          if(PAIR && pair) { eval_pair(blk, r_ep, true, e_ep, n_ep); }
+          if(PAIR && pair) { p_ep = eval_pair(blk, r_ep, true); }
           else { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
         }
       }
@@ -536,13 +537,14 @@ __global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* _
     {
       if(PAIR && pair)
       {
-        if(e_ep > e_sp)                                        // neither step empties (layout.hpp)
+        u64 a = 0, b = 0;
+        if(pair_outcome(p_sp, p_ep, idx_ep == idx_sp, a, b) == 2)          // neither step empties (layout.hpp)
         {
-          sp = n_sp; ep = n_ep;
+          sp = p_sp.node; ep = p_ep.node;
           emit(i - 1, depth + 1); emit(i - 2, depth + 2);
           depth += 2; i -= 2;
         }
-        else { force_single = 2; }
+        else { force_single = 2; }                             // an emptying step needs parent(): one character at a time
       }
       else
       {

@@ -39,17 +39,25 @@
 //   ep''  = N(H(ep + 1) - 1 + D[ep + 1]),  D[j] = !edges[x - 1] & B_c1[N(x)],  x = E_c2(j)
 //           (D = 1: position j splits the out-edges of one node, which both sides then lead back to)
 //
-//   block b of pair (c1, c2) (16 x u64 = 128 bytes; 256 positions)
-//     word 0        ecnt = H(256 b)
+//   block b of pair (c1, c2) (16 x u64 = 128 bytes; 192 positions)
+//     word 0        ecnt = H(192 b)
 //     word 1        ncnt = rank(edges, ecnt), bit 63 = edges[ecnt - 1]
-//     words 2..5    P bits [256 b, 256 (b + 1))
-//     words 6..9    D bits of the same positions
-//     words 10..15  edges bits [ecnt, ecnt + 384)
+//     words 2..4    P bits [192 b, 192 (b + 1))
+//     words 5..7    D bits of the same positions
+//     words 8..10   Q bits of the same positions: Q = B_c2 (is the FIRST of the two steps non-empty?)
+//     words 11..14  edges bits [ecnt, ecnt + 256)
+//     word 15       unused
 //
-// so TWO pattern characters cost ONE 128-byte request per endpoint.  The fused pair is used only when it
-// proves that both steps are non-empty (H(ep + 1) > H(sp)); otherwise the two steps are replayed one at a
-// time from the FLB128 blocks, which also yields the edge-space integers the reference returns for a range
-// that empties inside LF (gcsa.h:160).  Results are therefore unchanged.
+// so TWO pattern characters cost ONE 128-byte request per endpoint.  What the block decides, exactly:
+//   H(ep + 1) > H(sp)                      both steps are non-empty: the range is (N(H(sp)), N(H(ep + 1) - 1 + D))
+//   H(ep + 1) = H(sp), a Q bit in [sp, ep] the first step is non-empty; with D[ep + 1] = 1 the second one is the single edge
+//                                          H(sp) (the walk passes a non-last out-edge of a branching node), with D = 0 it is
+//                                          empty and (H(sp), H(sp) - 1) are the edge-space integers the reference returns
+//                                          (gcsa.h:160)
+//   no Q bit in [sp, ep]                   the first step is empty: its edge-space integers are not in this block, the
+//                                          step is replayed from the FLB128 blocks (so is a range whose endpoints lie in
+//                                          different blocks with no Q bit in either part: undecided)
+// Results are therefore unchanged.
 //
 // select_1 uses one u32 hint per 448 ones (block holding the (448 j + 1)-th one) followed by a
 // short binary search over block counters and an in-block scan.
@@ -72,7 +80,8 @@ constexpr u64 SELECT_SAMPLE = 448;
 constexpr u64 FLB_WORDS     = 16;
 constexpr u64 FLB_BYTES     = 128;
 constexpr u64 PREV_BIT      = u64(1) << 63;
-constexpr u64 PAIR_BITS     = 256;           // positions per FLP128 block
+constexpr u64 PAIR_BITS     = 192;           // positions per FLP128 block (three payload rows of three words)
+constexpr u32 PAIR_WORDS    = 3;
 constexpr u32 PAIR_FLAG     = u32(1) << 31;  // block index refers to the FLP128 array
 constexpr int MAX_SIGMA     = 16;
 constexpr int MAX_LCP_LEVELS = 16;
@@ -94,7 +103,7 @@ struct DevImage
   const u64* flb;       // fused LF blocks: comp c, block b at flb + (c * flb_nblocks + b) * 16
   u64 flb_nblocks;      // per comp = n / 448 + 1
   const u64* flp;       // fused pair blocks or nullptr: pair (c1, c2), block b at flp + (((c1 - 1) * 4 + c2 - 1) * flp_nblocks + b) * 16
-  u64 flp_nblocks;      // per pair = n / 256 + 1
+  u64 flp_nblocks;      // per pair = n / 192 + 1
   u64 crange[2 * MAX_SIGMA];   // charRange(c) in node space, precomputed (gcsa.h:150-153)
   const u64* pred4;            // 4 bits per path node: bits 0-2 = comp of the first incoming edge
                                // (gcsa.h:165-183 probe order), bit 3 = sampled(node); nullptr if sigma > 8

@@ -663,7 +663,7 @@ def test_pair_blocks(engine, monkeypatch):
             monkeypatch.delenv("GCSA2_PAIR_BLOCKS")
             gpu = engine.GCSA(ix, with_samples=False, with_counters=False, with_lcp=False)
             assert plain.pair_block_bytes() == 0
-            assert gpu.pair_block_bytes() == 16 * (ix.n // 256 + 1) * 128
+            assert gpu.pair_block_bytes() == 16 * (ix.n // 192 + 1) * 128
             assert np.array_equal(plain.find_batch(data, off), want), (case, kmer, jump)
             assert np.array_equal(gpu.find_batch(data, off), want), (case, kmer, jump)
             dev = torch.device("cuda", 0)

@@ -273,3 +273,38 @@ def test_whole_human_footprint_closed_form():
     got = d_nodes.cpu().numpy().view(np.uint64)
     for col, name in enumerate(("sp", "ep", "left_lcp", "right_lcp", "node_lcp")):
         assert np.array_equal(got[:, col], want[name]), name
+
+
+def test_branching_footprint_index_closed_form():
+    """The branching variant of the footprint generator (m-sequence text + one SNP bubble per 50 positions: order-k de
+    Bruijn graph, e = 1.08 n; validated against its definition on the CPU in tests/test_workload.py) at 268 M path nodes:
+    every find() of a walk through the graph -- pair steps that go through a non-last out-edge are replayed singly --
+    equals the single node of the walk's first k characters, for 32-mers, 100-mers and k-mers, through the default kernel,
+    the single-character kernel (GCSA2_PAIR_BLOCKS=0 equivalent: variant 1) and the length-bucketed launch."""
+    import torch
+    from workload import mseq_torch
+    from gcsa2_amd.binding import GCSA
+    dev = torch.device("cuda", 0)
+    degree = 28
+    ix, sym_t, rank, alt_t = mseq_torch.build_mseq_snp(degree, device=dev)
+    rank_t = torch.from_numpy(rank.view(np.int32)).to(dev)
+    assert 1.06 * ix.n < ix.e < 1.10 * ix.n
+    gpu = GCSA(ix, device=0, with_samples=False, with_counters=False, with_lcp=False)
+    assert gpu.pair_block_bytes() > 0
+    st = torch.cuda.current_stream().cuda_stream
+    for m, nq in ((32, 4_000_000), (100, 1_000_000), (degree // 2, 2_000_000)):
+        pats, exp = mseq_torch.walk_patterns_device(sym_t, alt_t, rank_t, 0, nq, m, 0x6C5A0041 + m)
+        d_pat = torch.zeros(nq * m + 8, dtype=torch.uint8, device=dev)
+        d_pat[: nq * m] = pats.reshape(-1)
+        d_off = torch.arange(nq + 1, dtype=torch.int64, device=dev) * m
+        for variant in (2, 1, 4):
+            n = nq if variant == 2 else nq // 8
+            d_out = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+            gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), n, d_out.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert torch.equal(d_out[:, 0], exp[:n]) and torch.equal(d_out[:, 1], exp[:n]), (m, variant)
+        d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+        gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), d_stats.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert torch.equal(d_out[:, 0], exp)

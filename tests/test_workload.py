@@ -119,3 +119,77 @@ def test_oracle_locate_parent_closed_form():
     occ = [p for p in range(ix.n) if all(sym[(p + j) % ix.n] == sym[100 + j] for j in range(3))]
     assert rng[1] - rng[0] + 1 == len(occ)
     assert cpu.locate(rng).tolist() == sorted(int(v) for v in mseq_torch.node_values(np.array(occ)))
+
+
+def test_mseq_snp_index_against_the_definition():
+    """The branching footprint-scale generator (workload/mseq_torch.py::build_mseq_snp) at degree 12: the index is
+    the order-6 de Bruijn graph of {text (k + 1)-mers} + {(k + 1)-mers through a SNP's alternative base}.  Checked
+    against that definition, not against any builder: edge counts, out-degrees, and find() of arbitrary patterns
+    through the oracle -- non-empty iff every (k + 1)-mer of the pattern is an edge, and then the single node of the
+    pattern's first k characters; walks through the graph equal their closed form."""
+    import torch
+    from workload import mseq_torch
+    from workload.index_arrays import unpack_bits
+    from workload.rng import SplitMix64
+    from oracle.oracle import OracleIndex
+    degree, k = 12, 6
+    dev = torch.device("cpu")
+    ix, sym_t, rank, alt_t = mseq_torch.build_mseq_snp(degree, period=40, device=dev)
+    N = ix.n
+    sym = sym_t.numpy().astype(np.int64)
+    alt = alt_t.numpy().astype(np.int64)
+    assert N == 4 ** k - 1 and ix.order == k
+    edges = set()
+    for p in range(N):
+        edges.add(tuple(sym[(p + j) % N] for j in range(k + 1)))
+    sites = np.flatnonzero(alt != 255)
+    assert len(sites) >= 90 and np.all(np.diff(sites) >= 2 * (k + 1))
+    for s in sites:
+        for p in range(s - k, s + 1):
+            w = [sym[(p + j) % N] for j in range(k + 1)]
+            w[s - p] = alt[s]
+            edges.add(tuple(w))
+    assert ix.e == len(edges) and 1.05 * N < ix.e < 1.15 * N
+    value = lambda kmer: sum(int(c) * 4 ** (k - 1 - j) for j, c in enumerate(kmer))       # noqa: E731
+    B = [unpack_bits(ix.bwt[c], N) for c in range(7)]
+    for c in (0, 5, 6):
+        assert not B[c].any()
+    preds = sum(int(B[c + 1].sum()) for c in range(4))
+    assert preds == ix.e and [int(x) for x in np.diff(ix.C)] == [0] + [int(B[c + 1].sum()) for c in range(4)] + [0, 0]
+    for w in list(edges)[:3000]:
+        assert B[w[0] + 1][value(w[1:]) - 1]                                               # predecessor label of the target node
+    out = unpack_bits(ix.edges, ix.e)
+    ends = np.flatnonzero(out)
+    assert len(ends) == N
+    outdeg = np.diff(np.concatenate([[-1], ends]))
+    by_source = {}
+    for w in edges:
+        by_source[value(w[:k])] = by_source.get(value(w[:k]), 0) + 1
+    assert all(outdeg[v - 1] == d for v, d in by_source.items()) and len(by_source) == N
+
+    cpu = OracleIndex(ix, with_samples=False, with_counters=False, with_lcp=False)
+    rng = SplitMix64(0x5A1)
+    letters = b"ACGT"
+    pats = []
+    for _ in range(1500):                                     # uniform strings: mostly not in the graph
+        pats.append(tuple(rng.below(4) for _ in range(k + 1 + rng.below(5))))
+    for _ in range(1500):                                     # walks, some with one substitution
+        p, m = rng.below(N), k + 1 + rng.below(12)
+        w = [int(alt[(p + j) % N]) if alt[(p + j) % N] != 255 and rng.below(2) else int(sym[(p + j) % N]) for j in range(m)]
+        if rng.below(3) == 0:
+            w[rng.below(m)] = rng.below(4)
+        pats.append(tuple(w))
+    hits = 0
+    for pat in pats:
+        sp, ep = cpu.find(bytes(letters[c] for c in pat))
+        inside = all(tuple(pat[j:j + k + 1]) in edges for j in range(len(pat) - k))
+        if inside:
+            hits += 1
+            assert (sp, ep) == (value(pat[:k]) - 1, value(pat[:k]) - 1), pat
+        else:
+            assert sp > ep or sp == ep + 1 or (sp + 1) % (1 << 64) > (ep + 1) % (1 << 64), pat
+    assert 800 < hits < 2600
+    rank_t = torch.from_numpy(rank.view(np.int32))
+    walks, exp = mseq_torch.walk_patterns_device(sym_t, alt_t, rank_t, 0, 2000, 20, 0x5A2)
+    got = cpu.find_batch(walks.reshape(-1).numpy(), np.arange(2001, dtype=np.uint64) * np.uint64(20))
+    assert np.array_equal(got[:, 0], exp.numpy().astype(np.uint64)) and np.array_equal(got[:, 1], got[:, 0])
