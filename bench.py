@@ -612,7 +612,22 @@ def chr22_secondary(args, D, dev, local_rank):
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds / 2)
     out["locate"], _, _ = measure_locate(wl.gpu, r["d_out"], dev, 3)
+    del r
+    release(wl)
     return out
+
+
+def release(wl):
+    """Free a workload's device image and tensors now (its `verify` closure refers back to it, so dropping the last
+    name would leave that to the cycle collector)."""
+    import gc
+    import torch
+    if wl.gpu is not None:
+        wl.gpu.close()
+    for name in list(vars(wl)):
+        setattr(wl, name, None)
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
 def human_snp_secondary(args, D, dev, local_rank):
@@ -625,8 +640,8 @@ def human_snp_secondary(args, D, dev, local_rank):
     out = {"workload": wl.label, "value": wl.nq / (r["kernel_ms"] * 1e-3), "unit": "queries/s", "kernel_ms": r["kernel_ms"],
            "all_ranges_equal_closed_form": ok, "config": find_config(wl, r, 1),
            "roofline": roofline(args, r, wl, f"human_snp_{wl.degree}_{wl.m}_{args.set}")}
-    del wl, r
-    torch.cuda.empty_cache()
+    del r
+    release(wl)
     return out
 
 
@@ -736,8 +751,8 @@ def main():
         result["config5"] = config5(args, wl, dev)
     del r
     if secondary:
+        release(wl)
         del wl
-        torch.cuda.empty_cache()
     if secondary and args.secondary in ("all", "chr22"):
         result["chr22"] = chr22_secondary(args, D, dev, local_rank)
     if secondary and args.secondary in ("all", "human_snp"):

@@ -179,10 +179,11 @@ uint64_t gcsa2_locate_table_bytes(const gcsa2_index* index);
 uint64_t gcsa2_jump_table_bytes(const gcsa2_index* index);
 /* Bytes of the two-characters-per-step blocks (0 = none).  For every ordered pair of fast characters the
  * composition of two LF steps (gcsa.h:155-162 applied twice) is stored as one rank structure of 128-byte
- * blocks over 256 path nodes each (gcsa2_amd/csrc/layout.hpp "FLP128"): find() then consumes two pattern
- * characters per memory request whenever the block proves that neither step empties, and replays the two
- * steps one at a time otherwise, so every range (including the edge-space empty ranges of gcsa.h:160) is
- * unchanged.  8 bytes per path node, built on the device at create time; GCSA2_PAIR_BLOCKS=0 disables. */
+ * blocks over 192 path nodes each (gcsa2_amd/csrc/layout.hpp "FLP128"): find() then consumes two pattern
+ * characters per memory request.  A block also tells which of its two steps empties, if any: an emptying second
+ * step yields the edge-space integers of gcsa.h:160 directly, an emptying first step is replayed through the
+ * single-character blocks, so every range is unchanged.  10.7 bytes per path node, built on the device at create
+ * time; GCSA2_PAIR_BLOCKS=0 disables. */
 uint64_t gcsa2_pair_block_bytes(const gcsa2_index* index);
 int gcsa2_find_stats_device(const gcsa2_index* index, const uint8_t* d_patterns,
                             const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,

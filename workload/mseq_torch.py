@@ -285,7 +285,9 @@ def build_mseq_snp(degree: int, period: int = 50, device=None, verbose=None):
         ok = succ > 0
         outdeg[b:e] = (B[c.view(-1, 1).expand(-1, 4), torch.clamp(succ - 1, min=0)] & ok).sum(dim=1).to(torch.uint8)
         del val, c, succ, ok
-    counts = B.sum(dim=1).cpu().numpy().astype(np.uint64)
+    counts = np.zeros(4, dtype=np.uint64)                  # chunked: sum() of a bool tensor materialises int64
+    for b in range(0, N, chunk):
+        counts += B[:, b:b + chunk].sum(dim=1).cpu().numpy().astype(np.uint64)
     e_total = int(counts.sum())
     # edges: the last outgoing edge of every node marked (0^(outdeg - 1) 1)
     edge_bits = torch.zeros(e_total, dtype=torch.bool, device=device)
