@@ -286,7 +286,7 @@ constexpr size_t DEVICE_ARENA_KEEP = size_t(512) << 20; // a larger arena is rel
 class Lease
 {
 public:
-  explicit Lease(const gcsa2_index* ix) : ix(ix), s(nullptr), d_used(0), h_used(0)
+  explicit Lease(const gcsa2_index* ix) : ix(ix), s(nullptr), d_used(0), h_used(0), busy(false)
   {
     std::lock_guard<std::mutex> hold(ix->staging_lock);
     if(!ix->staging_pool.empty()) { s = ix->staging_pool.back(); ix->staging_pool.pop_back(); }
@@ -294,6 +294,7 @@ public:
   ~Lease()
   {
     if(s == nullptr) { return; }
+    if(busy) { (void)hipStreamSynchronize(s->stream); }       // an early error return: nothing of this call may still be in flight
     if(s->d_cap > DEVICE_ARENA_KEEP) { (void)hipFree(s->d); s->d = nullptr; s->d_cap = 0; }
     std::lock_guard<std::mutex> hold(ix->staging_lock);
     ix->staging_pool.push_back(s);
@@ -321,7 +322,7 @@ public:
       if(e != hipSuccess) { return e; }
       s->d_cap = want;
     }
-    d_used = 0; h_used = 0; pending.clear();
+    d_used = 0; h_used = 0; pending.clear(); busy = true;
     return hipSuccess;
   }
   static size_t need(size_t bytes) { return (bytes + 255) / 256 * 256 + 256; }
@@ -354,7 +355,7 @@ public:
   {
     hipError_t e = hipStreamSynchronize(s->stream);
     if(e == hipSuccess) { for(const Pending& p : pending) { std::memcpy(p.user, p.slot, p.bytes); } }
-    pending.clear();
+    pending.clear(); busy = false;
     return e;
   }
 
@@ -367,7 +368,7 @@ private:
     return p;
   }
   struct Pending { void* user; const char* slot; size_t bytes; };
-  const gcsa2_index* ix; Staging* s; size_t d_used, h_used;
+  const gcsa2_index* ix; Staging* s; size_t d_used, h_used; bool busy;
   std::vector<Pending> pending;
 };
 
@@ -2200,14 +2201,14 @@ void load_lcp_members(const char* path, gcsa2_view_storage& st)
 template<class Loader>
 int parse_memory(const void* bytes, uint64_t size, uint64_t* consumed, gcsa2_view_storage** out, const char* what, Loader load)
 {
-  if(bytes == nullptr || out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null argument"); }
+  if((bytes == nullptr && size > 0) || out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null argument"); }
   *out = nullptr;
   try
   {
     std::unique_ptr<gcsa2_view_storage> st(new gcsa2_view_storage());
     std::memset(&st->view, 0, sizeof(st->view));
     st->blobs.reserve(64);
-    sdsl_file::Cursor in(bytes, size, what);
+    sdsl_file::Cursor in(bytes, size, what);          // an empty stream fails as "truncated while reading header.tag"
     load(in, *st, consumed == nullptr);
     if(consumed != nullptr) { *consumed = in.consumed(); }
     *out = st.release();

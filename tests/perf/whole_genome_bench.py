@@ -70,8 +70,8 @@ def main():
     d_out2 = torch.zeros_like(d_out)
     gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out2.data_ptr(), d_stats.data_ptr(), st.cuda_stream)
     torch.cuda.synchronize()
-    blocks, steps, lookups = (int(x) for x in d_stats.cpu())
-    algo = blocks * gpu.find_block_bytes() + lookups * 16 + nq * (m + 16)
+    blocks, steps, lookups, jumps = (int(x) for x in d_stats.cpu())
+    algo = blocks * gpu.find_block_bytes() + lookups * 8 + jumps * 16 + nq * (m + 16)
     res = {"workload": f"degree-{args.degree} m-sequence cyclic text: {ix.n} path nodes, {nq} x {m}-mer find(), substrings of the text",
            "device_image_GB": gpu.device_bytes() / 1e9, "find_bytes_GB": ix.sigma * (ix.n // 448 + 1) * 128 / 1e9,
            "kernel_ms": ms, "queries_per_s": nq / (ms * 1e-3), "blocks_per_query": blocks / nq, "lf_steps_per_query": steps / nq,
