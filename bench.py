@@ -90,13 +90,30 @@ class Dist:
 
     def make_comm(self, binding, device_index):
         import torch
-        if not self.active or self.backend != "nccl":
+        if not self.active or self.backend != "nccl" or os.environ.get("GCSA2_BENCH_NO_COMM"):    # the env knob tests the fallback
             return
-        uid = torch.zeros(binding.Comm.ID_BYTES, dtype=torch.uint8, device=self.dev)
+        # Safety net: if the library's communicator cannot be created on some rank (RCCL not loadable there, ...), every
+        # rank falls back to torch.distributed.gather for the data path and the line says so (config.parallelism).
+        uid = torch.zeros(binding.Comm.ID_BYTES + 1, dtype=torch.uint8, device=self.dev)
         if self.rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(binding.Comm.unique_id()), dtype=torch.uint8))
+            try:
+                uid[: binding.Comm.ID_BYTES].copy_(torch.frombuffer(bytearray(binding.Comm.unique_id()), dtype=torch.uint8))
+                uid[binding.Comm.ID_BYTES] = 1
+            except Exception as e:
+                log(f"warning: gcsa2_comm_unique_id failed ({e}); using torch.distributed.gather")
         self.dist.broadcast(uid, 0)
-        self.comm = binding.Comm(uid.cpu().numpy().tobytes(), self.rank, self.world, device_index)
+        ok = bool(uid[binding.Comm.ID_BYTES].item())
+        if ok:
+            try:
+                self.comm = binding.Comm(uid[: binding.Comm.ID_BYTES].cpu().numpy().tobytes(), self.rank, self.world, device_index)
+            except Exception as e:
+                print(f"[bench] rank {self.rank}: gcsa2_comm_create failed ({e})", file=sys.stderr, flush=True)
+                ok = False
+        if not self.all_true(ok):
+            if self.comm is not None:
+                self.comm.close()
+            self.comm = None
+            log("warning: the library communicator is not available on every rank; using torch.distributed.gather")
 
     def barrier(self):
         if self.active:
@@ -399,6 +416,18 @@ def measure(args, D, dev, wl, steps, warmup):
         if D.comm is not None:               # the single collective of the path: one gather of hit ranges over xGMI
             D.comm.gather(wire[b].data_ptr(), [c * wire_bytes for c in counts], recv[b].data_ptr() if root else 0, 0,
                           comm_stream.cuda_stream)
+        elif D.backend == "nccl":            # fallback (see Dist.make_comm): torch's RCCL gather, shards padded to one size
+            with torch.cuda.stream(comm_stream):
+                width = max(counts) * wire_bytes
+                mine = torch.zeros(width, dtype=torch.uint8, device=dev)
+                mine[: nq * wire_bytes] = wire[b].view(torch.uint8).reshape(-1)
+                parts = [torch.zeros(width, dtype=torch.uint8, device=dev) for _ in counts] if root else None
+                D.dist.gather(mine, parts, dst=0)
+                if root:
+                    at = 0
+                    for p_, c in zip(parts, counts):
+                        recv[b][at: at + c * wire_bytes] = p_[: c * wire_bytes]
+                        at += c * wire_bytes
         else:                                # gloo control-flow check: through host memory
             comm_stream.synchronize()
             parts = gather_via_host(D, wire[b].view(torch.uint8).reshape(-1).cpu(), counts, wire_bytes)
@@ -431,7 +460,10 @@ def measure(args, D, dev, wl, steps, warmup):
     last = (steps - 1) % nbuf if steps > 0 else 0
     d_out = outs[last]
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if steps > 0 else 0.0
-    result = dict(elapsed=elapsed, kernel_ms=kernel_ms, d_out=d_out, gathered=None, pack32=pack32)
+    result = dict(elapsed=elapsed, kernel_ms=kernel_ms, d_out=d_out, gathered=None, pack32=pack32,
+                  gather=("gcsa2_comm_gather (library RCCL communicator)" if D.comm is not None else
+                          ("torch.distributed.gather (fallback)" if D.active and D.backend == "nccl" else
+                           ("host copies (gloo control-flow check)" if D.active else "none (one GPU)"))))
     if root and steps > 0:
         result["gathered"] = gathered if pack32 else recv[last].view(torch.int64).view(total, 2)
         mine = result["gathered"][bounds[0][0]:bounds[0][1]]
@@ -533,7 +565,7 @@ def find_config(wl, r, world):
             "pair_block_bytes": gpu.pair_block_bytes(), "single_block_bytes": int(wl.ix.sigma) * (int(wl.ix.n) // 448 + 1) * 128,
             "kmer_table_k": gpu.kmer_table_k(), "found": r["found"], "lf_steps_per_query": r["lf_steps"] / wl.nq,
             "blocks_per_query": r["blocks"] / wl.nq, "block_bytes": gpu.find_block_bytes(),
-            "parallelism": f"replicated index, contiguous query shards x{world}, one RCCL gather of ranges per step (gcsa2_comm_gather)"
+            "parallelism": f"replicated index, contiguous query shards x{world}, one gather of ranges per step: {r['gather']}"
                            + (" as (sp, len) u32 pairs" if r["pack32"] else "")}
 
 

@@ -1,0 +1,81 @@
+"""bench.py's contract (task statement / DESIGN.md section 5) on small footprints: the JSON line and its objects, the
+strong-sharded multi-rank path through the library's RCCL communicator (world size 1 under torch.distributed.run -- all a
+1-GPU box can hold), its torch.distributed fallback, and two ranks sharing the GPU through the host (gloo: control flow)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run(cmd, env=None, timeout=900):
+    full = dict(os.environ)
+    full.update(env or {})
+    out = subprocess.run(cmd, cwd=ROOT, env=full, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check_line(d, gpus, steps):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["metric"] == "kmer_find_queries_per_sec" and d["unit"] == "queries/s" and d["n_gpus"] == gpus and d["steps"] == steps
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "u64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel_ms"] * d["steps"] <= d["ms_per_step"] * d["steps"] * 1.02 + 0.5
+    assert d["config"]["all_ranges_equal_closed_form"] is True
+
+
+def test_single_gpu_line_with_secondaries():
+    d = run([sys.executable, "bench.py", "--degree", "20", "--queries", "300000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1",
+             "--secondary", "config5"])
+    check_line(d, 1, 3)
+    assert d["scaling"] == "strong" and d["config"]["queries_total"] == 300000
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["gpu_matches_cpu_on_sample"] is True and c["value"] > 0
+    c5 = d["config5"]
+    assert c5["unmodified_half_equals_closed_form"] and c5["find_unmodified_half_equals_closed_form"] and c5["locate"]["count_equals_located"]
+    assert c5["locate_unmodified_half_equals_closed_form"] and c5["cpu_baseline"]["gpu_matches_cpu_on_sample"]
+
+
+def test_branching_workload_line():
+    d = run([sys.executable, "bench.py", "--workload", "human_snp", "--degree", "20", "--queries", "300000", "--steps", "2", "--warmup", "1", "--no-cpu"])
+    check_line(d, 1, 2)
+    assert 1.05 < d["config"]["edges"] / d["config"]["path_nodes"] < 1.12
+
+
+@pytest.mark.parametrize("no_comm", ["", "1"], ids=["library-rccl-gather", "torch-gather-fallback"])
+def test_distributed_path_world_size_1(no_comm):
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+             "--master-port", str(free_port()), "bench.py", "--gpus", "1", "--degree", "24", "--queries", "1000001", "--steps", "3",
+             "--warmup", "1", "--no-cpu"], env={"GCSA2_BENCH_NO_COMM": no_comm})
+    check_line(d, 1, 3)
+    assert ("gcsa2_comm_gather" in d["config"]["parallelism"]) == (no_comm == "")
+    assert "u32 pairs" in d["config"]["parallelism"]
+
+
+def test_two_ranks_share_the_gpu_through_the_host():
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--degree", "24", "--queries", "1000001", "--steps", "2",
+             "--warmup", "1", "--no-cpu"], env={"GCSA2_BENCH_BACKEND": "gloo"})
+    check_line(d, 2, 2)
+    assert d["scaling"] == "strong" and d["config"]["queries_per_gpu"] == 500001 and d["config"]["queries_total"] == 1000001
