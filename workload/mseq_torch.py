@@ -255,11 +255,9 @@ def build_mseq_snp(degree: int, period: int = 50, device=None, verbose=None):
         if w == k:                                     # the window starts AT the alternative base: target = the reference k-mer behind it
             v = value_at(pos + 1)
             label = alt
-        else:                                          # target node = T[p + 1 .. p + k] with the digit of position s replaced
-            digit = k - 1 - (k - w - 1)                # offset of s inside the target k-mer, from the left: k - w - 1 -> weight 4^(k-1-(k-w-1)) = 4^w
-            v = value_at(p + 1) + (alt - ref) * (4 ** w)
+        else:                                          # target node = T[p + 1 .. p + k] with the digit of position s replaced:
+            v = value_at(p + 1) + (alt - ref) * (4 ** w)   # s sits at offset k - w - 1 of the target k-mer, weight 4^w
             label = sym_t[p % N].to(torch.int64)
-            del digit
         keep &= v > 0                                  # A^k does not exist: a bubble that would need it is dropped whole
         targets.append((label, v))
     # the source k-mer of the first window is a reference k-mer; the sources of the others are alternative k-mers
