@@ -1774,9 +1774,11 @@ extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
   if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
   // GCSA2_MATCH_STATS=1 runs the first-generation kernel (one lane per pattern, no cooperation) for A/B measurements;
-  // GCSA2_PARENT_BATCH sets how many lanes of a wave must wait for parent() before the wave runs it (default 1)
+  // GCSA2_PARENT_BATCH sets how many lanes of a wave must wait for parent() before the wave runs it (default 1),
+  // GCSA2_COOL_DOWN how many characters are stepped singly after a step that needed parent() (default 3)
   static const int generation = []() { const char* e = std::getenv("GCSA2_MATCH_STATS"); return e != nullptr ? std::atoi(e) : 2; }();
   static const u32 batch = []() { const char* e = std::getenv("GCSA2_PARENT_BATCH"); int v = (e != nullptr ? std::atoi(e) : int(PARENT_BATCH)); return u32(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+  static const u32 cool = []() { const char* e = std::getenv("GCSA2_COOL_DOWN"); int v = (e != nullptr ? std::atoi(e) : int(COOL_DOWN)); return u32(v < 0 ? 0 : (v > 1000 ? 1000 : v)); }();
   unsigned short* out = reinterpret_cast<unsigned short*>(d_ms);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if(generation == 1)
@@ -1786,12 +1788,12 @@ extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_
   else if(ix->img.flp != nullptr)
   {
     hipLaunchKernelGGL(k_match_stats2<true>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch);
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool);
   }
   else
   {
     hipLaunchKernelGGL(k_match_stats2<false>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch);
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool);
   }
   LAUNCH_CHECK("k_match_stats");
   return GCSA2_OK;

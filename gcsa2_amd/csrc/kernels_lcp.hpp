@@ -404,12 +404,16 @@ __global__ __launch_bounds__(TPB) void k_match_stats(DevImage img, const u8* __r
 // lanes of its wave wait or nothing else can step (default 1: at once -- batching more lanes measured slower, profiles/r02_config5.md); the wave then runs LCPArray::parent (lcp.cpp:276-301) for all
 // waiting lanes together, so that the divergent tree walks cost one pass per batch instead of one per step.
 constexpr u32 PARENT_BATCH = 1;
+// After a step that needed parent() the next COOL_DOWN characters are stepped singly: right after a mismatch the match is
+// short and the following characters fail often, so a pair attempt mostly wastes its round (deep suffix tree, 37 parent()
+// calls per pattern: 60 -> 68 M patterns/s with 6; 3 / 12 / 24 give 67 / 67 / 66; profiles/r02_config5.md).
+constexpr u32 COOL_DOWN = 3;
 
 template<bool PAIR>
 __global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* __restrict__ patterns,
                                                        const u64* __restrict__ offsets, u64 nq,
                                                        unsigned short* __restrict__ ms, u64* __restrict__ ranges,
-                                                       u64* __restrict__ fallbacks, u32 parent_batch)
+                                                       u64* __restrict__ fallbacks, u32 parent_batch, u32 cool_down)
 {
   __shared__ ulonglong2 stage[TPB2 * 8];
   __shared__ u8 c2c[256];
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* _
           emit(i - 1, 0); i--;
           force_single -= (force_single > 0 ? 1 : 0);
         }
-        else { need_parent = true; }
+        else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }
       }
     }
     // parent(): for all waiting lanes at once, when enough of them wait or nothing else can move
