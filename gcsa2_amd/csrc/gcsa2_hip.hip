@@ -1765,38 +1765,76 @@ extern "C" int gcsa2_count_kmers(const gcsa2_index* ix, uint64_t k, int include_
   return GCSA2_OK;
 }
 
-// Matching statistics (LF + parent fused); see k_match_stats.
-extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq,
-                                        uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
+// Matching statistics (LF + parent fused); see k_match_stats2.  variant 0 = default (2), 1 = first generation, 2 = one
+// lane per pattern, 5 = persistent lanes that draw patterns from a counter.
+extern "C" int gcsa2_match_stats_device_variant(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets,
+                                                uint64_t nq, uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
 {
   CHECK_INDEX(ix);
   DeviceGuard guard(ix->device);
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
+  if(variant != 0 && variant != 1 && variant != 2 && variant != 5) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown matching statistics variant"); }
   if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
-  // GCSA2_MATCH_STATS=1 runs the first-generation kernel (one lane per pattern, no cooperation) for A/B measurements;
-  // GCSA2_PARENT_BATCH sets how many lanes of a wave must wait for parent() before the wave runs it (default 1),
-  // GCSA2_COOL_DOWN how many characters are stepped singly after a step that needed parent() (default 3)
-  static const int generation = []() { const char* e = std::getenv("GCSA2_MATCH_STATS"); return e != nullptr ? std::atoi(e) : 2; }();
-  static const u32 batch = []() { const char* e = std::getenv("GCSA2_PARENT_BATCH"); int v = (e != nullptr ? std::atoi(e) : int(PARENT_BATCH)); return u32(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
-  static const u32 cool = []() { const char* e = std::getenv("GCSA2_COOL_DOWN"); int v = (e != nullptr ? std::atoi(e) : int(COOL_DOWN)); return u32(v < 0 ? 0 : (v > 1000 ? 1000 : v)); }();
+  // Tuning knobs, read per call (A/B measurements and the variant tests): GCSA2_MATCH_STATS overrides the variant;
+  // GCSA2_PARENT_BATCH = lanes of a wave that must wait for parent() before the wave runs it; GCSA2_COOL_DOWN =
+  // characters stepped singly after a step that needed parent(); variant 5: GCSA2_MS_REFILL_AT = idle lanes of a wave
+  // that trigger a refill, GCSA2_MS_GRID = most workgroups launched (default: what the device holds at once).
+  auto knob = [](const char* name, long fallback, long lo, long hi) -> long
+  {
+    const char* e = std::getenv(name);
+    long v = (e != nullptr && *e != 0 ? std::atol(e) : fallback);
+    return v < lo ? lo : (v > hi ? hi : v);
+  };
+  int generation = int(knob("GCSA2_MATCH_STATS", variant, 0, 5));
+  if(generation == 0) { generation = 2; }
+  const u32 batch = u32(knob("GCSA2_PARENT_BATCH", PARENT_BATCH, 1, 64));
+  const u32 cool = u32(knob("GCSA2_COOL_DOWN", COOL_DOWN, 0, 1000));
   unsigned short* out = reinterpret_cast<unsigned short*>(d_ms);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const u64 lanes_grid = (nq + TPB2 - 1) / TPB2;
+  const bool pair = ix->img.flp != nullptr;
   if(generation == 1)
   {
     hipLaunchKernelGGL(k_match_stats, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks);
   }
-  else if(ix->img.flp != nullptr)
+  else if(generation == 5)
   {
-    hipLaunchKernelGGL(k_match_stats2<true>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool);
+    const u32 refill_at = u32(knob("GCSA2_MS_REFILL_AT", MS_REFILL_AT, 1, 64));
+    const u64 resident = u64(knob("GCSA2_MS_GRID", long(ix->compute_units) * 8, 1, long(1) << 30));   // 4 waves per SIMD
+    unsigned long long* queue = nullptr;
+    HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), st));
+    const unsigned grid = unsigned(lanes_grid < resident ? lanes_grid : resident);
+    if(pair)
+    {
+      hipLaunchKernelGGL((k_match_stats2<true, true>), dim3(grid), dim3(TPB2), 0, st,
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool, queue, refill_at);
+    }
+    else
+    {
+      hipLaunchKernelGGL((k_match_stats2<false, true>), dim3(grid), dim3(TPB2), 0, st,
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool, queue, refill_at);
+    }
+    (void)hipFreeAsync(queue, st);
+  }
+  else if(pair)
+  {
+    hipLaunchKernelGGL((k_match_stats2<true, false>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool, (unsigned long long*)nullptr, 64u);
   }
   else
   {
-    hipLaunchKernelGGL(k_match_stats2<false>, dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool);
+    hipLaunchKernelGGL((k_match_stats2<false, false>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool, (unsigned long long*)nullptr, 64u);
   }
   LAUNCH_CHECK("k_match_stats");
   return GCSA2_OK;
+}
+
+extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq,
+                                        uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
+{
+  return gcsa2_match_stats_device_variant(ix, 0, d_patterns, d_offsets, nq, d_ms, d_ranges, d_fallbacks, stream);
 }
 
 extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq,
@@ -1813,7 +1851,11 @@ extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* pat
   u64* d_fb = lease.dev<u64>(nq); uint16_t* d_ms = lease.dev<uint16_t>(total + 8);
   HIP_TRY(lease.up(d_pat, patterns, total));
   HIP_TRY(lease.up(d_off, offsets, (nq + 1) * sizeof(u64)));
-  int rc = gcsa2_match_stats_device(ix, d_pat, d_off, nq, d_ms, d_rng, d_fb, lease.stream());
+  // ragged batches (longest pattern > 1.25 x the mean) large enough to fill the device go to the persistent lanes
+  u64 longest = 0;
+  for(u64 q = 0; q < nq; q++) { const u64 len = offsets[q + 1] - offsets[q]; longest = (len > longest ? len : longest); }
+  const bool ragged = nq >= MS_REFILL_MIN && double(longest) * double(nq) > 1.25 * double(total);
+  int rc = gcsa2_match_stats_device_variant(ix, ragged ? 5 : 0, d_pat, d_off, nq, d_ms, d_rng, d_fb, lease.stream());
   if(rc != GCSA2_OK) { return rc; }
   HIP_TRY(lease.down(ms, d_ms, total * sizeof(uint16_t)));
   HIP_TRY(lease.down(ranges, d_rng, 2 * nq * sizeof(u64)));

@@ -408,12 +408,22 @@ constexpr u32 PARENT_BATCH = 1;
 // short and the following characters fail often, so a pair attempt mostly wastes its round (deep suffix tree, 37 parent()
 // calls per pattern: 60 -> 68 M patterns/s with 6; 3 / 12 / 24 give 67 / 67 / 66; profiles/r02_config5.md).
 constexpr u32 COOL_DOWN = 3;
+constexpr u32 MS_REFILL_AT = 8;                         // persistent lanes: idle lanes of a wave that trigger a refill
+constexpr u64 MS_REFILL_MIN = u64(1) << 19;             // host-pointer API: smallest ragged batch sent to the persistent lanes
 
-template<bool PAIR>
-__global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* __restrict__ patterns,
+// REFILL = true (variant 5 of gcsa2_match_stats_device_variant): a lane whose pattern is finished draws the next one from
+// a global counter (`queue`, zeroed by the host) as soon as `refill_at` lanes of its wave are idle, and the grid is what the
+// device holds at once.  For batches of ragged lengths: 2 M patterns of 32..256 bp run at 116 M patterns/s against 85 M/s
+// with a lane per pattern.  Batches of equal lengths lose (174 -> 141 M/s on the 256-bp batch of config 5): starting a
+// pattern costs its wave three dependent loads, paid once per wave with a lane per pattern and ~8 times here; mixing clean
+// and mismatching patterns of one length gains nothing either, a round costs a wave the same whether 32 or 64 lanes take it
+// (profiles/r02_config5.md).
+template<bool PAIR, bool REFILL>
+__global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8* __restrict__ patterns,
                                                        const u64* __restrict__ offsets, u64 nq,
                                                        unsigned short* __restrict__ ms, u64* __restrict__ ranges,
-                                                       u64* __restrict__ fallbacks, u32 parent_batch, u32 cool_down)
+                                                       u64* __restrict__ fallbacks, u32 parent_batch, u32 cool_down,
+                                                       unsigned long long* __restrict__ queue, u32 refill_at)
 {
   __shared__ ulonglong2 stage[TPB2 * 8];
   __shared__ u8 c2c[256];
@@ -422,12 +432,11 @@ __global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* _
   __syncthreads();
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  const u64 q = u64(blockIdx.x) * TPB2 + threadIdx.x;
-  const bool has = q < nq;
-  u64 begin = 0, i = 0;
-  if(has) { begin = offsets[q]; i = offsets[q + 1] - begin; }
-  const u8* p = patterns + begin;
-  u64 sp = 0, ep = img.n - 1, depth = 0, calls = 0;
+  u64 q = 0, begin = 0, i = 0;
+  bool has = false;
+  [[maybe_unused]] bool exhausted = false;
+  u64 sp = 0, ep = img.n - 1, depth = 0;
+  u32 calls = 0;
   bool need_parent = false;
   u32 force_single = 0;
   u64 win_top = ~u64(0), win_code = 0, win_bad = 0;
@@ -445,15 +454,53 @@ __global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* _
       packed = 0; have = 0;
     }
   };
+  auto start = [&](u64 query)
+  {
+    q = query; has = true;
+    begin = offsets[q]; i = offsets[q + 1] - begin;
+    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_top = ~u64(0);
+  };
+  if constexpr(!REFILL)
+  {
+    const u64 gid = u64(blockIdx.x) * TPB2 + threadIdx.x;
+    if(gid < nq) { start(gid); }
+  }
   while(true)
   {
+    if(has && i == 0)                                          // pattern finished (or empty): final range, parent() count
+    {
+      reinterpret_cast<ulonglong2*>(ranges)[q] = make_ulonglong2(sp, ep);
+      if(fallbacks != nullptr) { fallbacks[q] = calls; }
+      has = false;
+    }
+    if constexpr(REFILL)
+    {
+      const u64 idle = __ballot(!has);
+      if(!exhausted && u32(__popcll(idle)) >= refill_at)
+      {
+        const u32 want = u32(__popcll(idle)), leader = u32(__ffsll((long long)idle)) - 1;
+        unsigned long long base = 0;
+        if(lane == leader) { base = atomicAdd(queue, (unsigned long long)want); }
+        base = __shfl(base, leader, 64);
+        if(!has)
+        {
+          const u64 mine = base + __popcll(idle & ((u64(1) << lane) - 1));
+          if(mine < nq) { start(mine); }
+        }
+        exhausted = (base + want >= nq);
+      }
+      if(!__any(has)) { if(exhausted) { break; } continue; }
+    }
+    else
+    {
+      if(!__any(has)) { break; }
+    }
     const bool active = has && i > 0;
-    if(!__any(active)) { break; }
     // packed pattern window, as in k_find2: the 32 positions below win_top as 2-bit codes + "not a fast character" bits
     if(active && (win_top == ~u64(0) || win_top - i > 24))
     {
       win_top = i; win_code = 0; win_bad = 0;
-      const u64 count = (i < 32 ? i : 32), low = reinterpret_cast<u64>(p) + i - count, base = low & ~u64(7);
+      const u64 count = (i < 32 ? i : 32), low = reinterpret_cast<u64>(patterns) + begin + i - count, base = low & ~u64(7);
       u64 w[5];
       const u64 last = (low + count - 1) & ~u64(7);
 #pragma unroll
@@ -494,7 +541,7 @@ __global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* _
       {
         if((win_bad >> (2 * r)) & 1)
         {
-          const u64 addr = reinterpret_cast<u64>(p) + i - 1;
+          const u64 addr = reinterpret_cast<u64>(patterns) + begin + i - 1;
           comp = c2c[u32(*reinterpret_cast<const u64*>(addr & ~u64(7)) >> ((addr & 7) * 8)) & 0xFF];
         }
         else { comp = 1 + (u32(win_code >> (2 * r)) & 3); }
@@ -580,11 +627,6 @@ __global__ __launch_bounds__(TPB2) void k_match_stats2(DevImage img, const u8* _
         need_parent = false;
       }
     }
-  }
-  if(has)
-  {
-    reinterpret_cast<ulonglong2*>(ranges)[q] = make_ulonglong2(sp, ep);
-    if(fallbacks != nullptr) { fallbacks[q] = calls; }
   }
 }
 

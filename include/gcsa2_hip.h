@@ -314,6 +314,13 @@ int gcsa2_match_stats_batch(const gcsa2_index* index, const uint8_t* patterns, c
 int gcsa2_match_stats_device(const gcsa2_index* index, const uint8_t* d_patterns, const uint64_t* d_offsets,
                              uint64_t n_queries, uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks,
                              void* stream);
+/* Kernel selection, same results.  variant 0 or 2 = the default (one lane per pattern, wave-cooperative block fetch,
+ * what gcsa2_match_stats_device runs); variant 5 = the same kernel as persistent wavefronts whose idle lanes draw the
+ * next pattern from a counter, for batches of ragged pattern lengths (gcsa2_match_stats_batch chooses it by itself when
+ * the longest pattern exceeds 1.25 x the mean); variant 1 = the first generation (no cooperation), kept for A/B runs. */
+int gcsa2_match_stats_device_variant(const gcsa2_index* index, int variant, const uint8_t* d_patterns,
+                                     const uint64_t* d_offsets, uint64_t n_queries, uint16_t* d_ms,
+                                     uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream);
 
 /* ---- host-view container file ("G2HV") ---------------------------------------------------
  * Interchange between a process that can read .gcsa / .lcp files (the reference linked with SDSL:

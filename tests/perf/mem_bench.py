@@ -26,6 +26,10 @@ def main():
     ap.add_argument("--pattern-len", type=int, default=256)
     ap.add_argument("--cpu-queries", type=int, default=50_000)
     ap.add_argument("--substituted", type=float, default=0.5, help="fraction of patterns carrying substitutions (0, 0.5 or 1)")
+    ap.add_argument("--ragged", action="store_true", help="pattern lengths uniform in [32, pattern-len] instead of all equal")
+    ap.add_argument("--knobs", default="", help="';'-separated sets of NAME=value,... kernel knobs (gcsa2_match_stats_device reads them "
+                                                "per call); each set is timed on the same index and batch, one JSON line per set")
+    ap.add_argument("--also-queries", type=int, default=0, help="with --knobs: time this (smaller) batch size too")
     args = ap.parse_args()
     import torch
     from workload import graphs, builder, patterns
@@ -41,6 +45,11 @@ def main():
     for col in range(37, m, 41):               # substitutions in every second pattern (default)
         pats[rows, col] = sub[(np.searchsorted(sub, pats[rows, col]) + 1) % 4]
     flat, off = patterns.as_batch(pats)
+    if args.ragged:
+        lengths = np.random.default_rng(0x6C5A0051).integers(32, m + 1, size=nq)
+        keep = np.arange(m)[None, :] < lengths[:, None]
+        flat = np.ascontiguousarray(pats[keep])
+        off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
     dev = torch.device("cuda", 0)
     gpu, lcp = open_index(ix)
     stream = torch.cuda.current_stream()
@@ -52,6 +61,35 @@ def main():
 
     def run():
         gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), stream.cuda_stream)
+    if args.knobs:
+        cpu = OracleIndex(ix)
+        nc = min(nq, args.cpu_queries)
+        cm, cr, cf = cpu.match_stats_batch(flat, off[:nc + 1], threads=max_threads())
+        for spec in [""] + args.knobs.split(";"):
+            names = []
+            for kv in filter(None, spec.split(",")):
+                k, v = kv.split("=")
+                os.environ[k] = v
+                names.append(k)
+            line = {"knobs": spec or "defaults"}
+            for count in filter(None, [nq, args.also_queries]):
+                def go():
+                    gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), count, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), stream.cuda_stream)
+                d_ms.zero_(); go(); torch.cuda.synchronize()
+                ok = bool(np.array_equal(d_ms[: int(off[nc])].cpu().numpy().view(np.uint16), cm)) and \
+                    bool(np.array_equal(d_rng[:nc].cpu().numpy().view(np.uint64), cr)) and \
+                    bool(np.array_equal(d_fb[:nc].cpu().numpy().view(np.uint64), cf))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(3):
+                    go()
+                e1.record(stream); torch.cuda.synchronize()
+                line[f"M_patterns_per_s@{count}"] = round(count / (e0.elapsed_time(e1) * 1e-3 / 3) / 1e6, 1)
+                line[f"parity@{count}"] = ok
+            for k in names:
+                del os.environ[k]
+            print(json.dumps(line), flush=True)
+        return
     run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -73,7 +111,7 @@ def main():
     cores = max_threads()
     cm, cr, cf = cpu.match_stats_batch(flat, off[:nc + 1], threads=cores)
     t_cpu = cpu.last_seconds
-    parity = bool(np.array_equal(d_ms[: nc * m].cpu().numpy().view(np.uint16), cm)) and \
+    parity = bool(np.array_equal(d_ms[: int(off[nc])].cpu().numpy().view(np.uint16), cm)) and \
         bool(np.array_equal(d_rng[:nc].cpu().numpy().view(np.uint64), cr))
     res = {"config": f"config 5 shape: chr22-like SNP graph 2^{args.log2_bases}, {nq} x {m} bp, {int(100 * args.substituted)} % with a substitution every 41 bp",
            "gpu_match_stats_patterns_per_s": nq / t_ms, "gpu_bases_per_s": nq * m / t_ms, "gpu_ms": t_ms * 1e3,

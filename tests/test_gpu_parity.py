@@ -214,6 +214,48 @@ def test_match_stats(case):
     assert np.array_equal(gr, cr) and np.array_equal(gf, cf), name
 
 
+@pytest.mark.parametrize("knobs", [
+    {"GCSA2_MATCH_STATS": "1"},                                                             # first-generation kernel
+    {"GCSA2_MATCH_STATS": "5", "GCSA2_MS_GRID": "2", "GCSA2_MS_REFILL_AT": "1"},            # persistent lanes, eager refill
+    {"GCSA2_MATCH_STATS": "5", "GCSA2_MS_GRID": "3"},
+    {"GCSA2_MATCH_STATS": "5", "GCSA2_MS_GRID": "1", "GCSA2_MS_REFILL_AT": "64"},           # refill only when a wave is empty
+    {"GCSA2_MATCH_STATS": "5"},
+    {"GCSA2_COOL_DOWN": "0", "GCSA2_PARENT_BATCH": "16"},
+    {"GCSA2_MATCH_STATS": "5", "GCSA2_MS_GRID": "2", "GCSA2_COOL_DOWN": "12", "GCSA2_PARENT_BATCH": "64"},
+])
+def test_match_stats_kernel_variants(case, knobs, monkeypatch):
+    """Every launch shape of the matching-statistics kernel (gcsa2_match_stats_device reads its knobs per call) returns
+    the oracle's statistics, ranges and parent() counts -- in particular the persistent lanes that draw patterns from a
+    counter, which small batches do not use by default."""
+    name, g, K, ix, gpu, lcp, cpu = case
+    pats = [p for p in random_patterns(g, 3 * K, 0x95, 1500)] + [b"", b"N", b"", b"ACGTNACGT", b"$", b"#A", b""]
+    data, off = concat_patterns(pats)
+    cm, cr, cf = cpu.match_stats_batch(data, off, threads=2)
+    for key, value in knobs.items():
+        monkeypatch.setenv(key, value)
+    gm, gr, gf = gpu.match_stats_batch(data, off)
+    assert np.array_equal(gm, cm), (name, knobs)
+    assert np.array_equal(gr, cr) and np.array_equal(gf, cf), (name, knobs)
+
+
+def test_match_stats_ragged_host_batch(engine):
+    """A large batch of ragged lengths through the host-pointer entry point, which sends it to the persistent lanes
+    (gcsa2_match_stats_batch: longest pattern > 1.25 x the mean, at least 2^19 patterns)."""
+    from oracle.oracle import OracleIndex, max_threads
+    name, g, K = CASES[-1]
+    ix = build(g, K, sample_period=8, branching=4)
+    gpu, lcp = engine.open_index(ix)
+    cpu = OracleIndex(ix)
+    rng = np.random.default_rng(0x96)
+    nq = (1 << 19) + 77
+    lengths = rng.integers(0, 41, size=nq)
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    data = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.choice(5, size=int(off[-1]), p=[0.245, 0.245, 0.245, 0.245, 0.02])].copy()
+    gm, gr, gf = gpu.match_stats_batch(data, off)
+    cm, cr, cf = cpu.match_stats_batch(data, off, threads=max_threads())
+    assert np.array_equal(gm, cm) and np.array_equal(gr, cr) and np.array_equal(gf, cf)
+
+
 def widen_alphabet(ix):
     """Same index over a 9-letter alphabet: two never-occurring comps are inserted after T, so
     N becomes comp 7 and # comp 8.  Exercises sigma != 7 (sigma > 8 disables the pred4 nibbles and
