@@ -159,7 +159,14 @@ __device__ __forceinline__ void eval_endpoint(const ulonglong2 (&blk)[8], u32 r,
 //   raw = H(i) = ecnt + rank(P, r);  sp side (ep_side = false): node = N(raw)
 //   ep side: edge b'' = raw - 1 + D[r], node = N(b''), dbit = D[r]
 //   qbefore = rank(Q, r) inside the block, qafter = Q bits at or after r in the block
-struct PairEnd { u64 raw, node; u32 dbit, qbefore, qafter; };
+//   (the three small values share one register: qbefore | qafter << 8 | dbit << 16, each count <= 192)
+struct PairEnd
+{
+  u64 raw, node; u32 bits;
+  __device__ __forceinline__ u32 qbefore() const { return bits & 0xFF; }
+  __device__ __forceinline__ u32 qafter() const { return (bits >> 8) & 0xFF; }
+  __device__ __forceinline__ u32 dbit() const { return bits >> 16; }
+};
 
 __device__ __forceinline__ PairEnd eval_pair(const ulonglong2 (&blk)[8], u32 r, bool ep_side)
 {
@@ -178,10 +185,10 @@ __device__ __forceinline__ PairEnd eval_pair(const ulonglong2 (&blk)[8], u32 r, 
     if(j == wq) { dword = w[5 + j]; }
   }
   PairEnd out;
-  out.raw = w[0] + ones; out.qbefore = qb; out.qafter = qt - qb;
-  out.dbit = (ep_side ? u32((dword >> (r & 63)) & 1) : 0u);
+  const u32 dbit = (ep_side ? u32((dword >> (r & 63)) & 1) : 0u);
+  out.raw = w[0] + ones; out.bits = qb | ((qt - qb) << 8) | (dbit << 16);
   const u64 ncnt = w[1] & ~PREV_BIT;
-  const u32 back = (ep_side ? 1u - out.dbit : 0u);
+  const u32 back = (ep_side ? 1u - dbit : 0u);
   if(back > ones) { out.node = ncnt - (w[1] >> 63); return out; }    // rank(edges, ecnt - 1)
   const u32 k = ones - back, kq = k >> 6;
   const u64 kpart = (u64(1) << (k & 63)) - 1;
@@ -201,9 +208,9 @@ __device__ __forceinline__ PairEnd eval_pair(const ulonglong2 (&blk)[8], u32 r, 
 __device__ __forceinline__ u32 pair_outcome(const PairEnd& s, const PairEnd& e, bool same_block, u64& a, u64& b)
 {
   if(e.raw > s.raw) { return 2; }
-  const bool first_nonempty = (same_block ? e.qbefore > s.qbefore : (e.qbefore > 0 || s.qafter > 0));
+  const bool first_nonempty = (same_block ? e.qbefore() > s.qbefore() : (e.qbefore() > 0 || s.qafter() > 0));
   if(!first_nonempty) { return 0; }
-  if(e.dbit) { return 2; }
+  if(e.dbit()) { return 2; }
   a = s.raw; b = s.raw - 1;
   return 1;
 }
@@ -332,8 +339,15 @@ __device__ __forceinline__ ulonglong2 jt_make(u64 end, u64 after4, u64 after2, u
 // PAIR = true: two characters per step through the FLP128 pair blocks whenever the next two pattern
 // characters are fast characters; a pair that does not prove both steps non-empty is replayed as two
 // single steps (`force_single`), so every returned range is the one the single-step search returns.
+// Waves per SIMD the plain instantiations (what gcsa2_find_device runs) are compiled for.  4 = 16 waves per CU (107 VGPRs).
+// -DGCSA2_FIND_WAVES=5 gives 96 VGPRs with only the pattern and output pointers spilled, outside the step loop, and the 18
+// waves per CU that LDS allows -- measured 2-5 % SLOWER (profiles/r02_occupancy.md): at 16 waves the kernel already sits at
+// the memory system's request rate, more resident chains only lengthen each one's round trip.
+#ifndef GCSA2_FIND_WAVES
+#define GCSA2_FIND_WAVES 4
+#endif
 template<bool STATS, bool REFILL, bool JUMP = false, bool WINDOW = true, bool PAIR = false>
-__global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restrict__ patterns,
+__global__ __launch_bounds__(TPB2, (STATS || REFILL || JUMP) ? 4 : GCSA2_FIND_WAVES) void k_find2(DevImage img, const u8* __restrict__ patterns,
                                                const u64* __restrict__ offsets, u64 nq,
                                                u64* __restrict__ out, unsigned long long* __restrict__ stats,
                                                const u32* __restrict__ perm, unsigned long long* __restrict__ queue)
@@ -354,8 +368,8 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
   bool done = true;
   [[maybe_unused]] bool tried = false;     // JUMP: the entry of the current node was examined and does not apply
   [[maybe_unused]] bool no_jump = false;   // JUMP: no entry can apply for the rest of this pattern
-  [[maybe_unused]] u64 win_top = ~u64(0), win_code = 0;      // JUMP: packed pattern window (see below)
-  [[maybe_unused]] u64 win_bad = 0;
+  [[maybe_unused]] u64 win_code = 0;       // packed pattern window (see below)
+  [[maybe_unused]] u32 win_used = ~u32(0), win_bad = 0;      // characters consumed since the window was loaded (~0: no window)
   [[maybe_unused]] u32 force_single = 0;   // PAIR: characters that must be consumed by single steps (replay)
   static_assert(!PAIR || WINDOW, "pair steps read the packed pattern window");
   u64 word = 0, word_addr = ~u64(0);        // pattern bytes are consumed back to front from aligned 8-byte words
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
   };
   auto start = [&](u64 query)               // begin the backward search of `query` (< nq)
   {
-    q = query; sp = 0; ep = img.n - 1; i = 0; done = true; word_addr = ~u64(0); tried = false; no_jump = false; win_top = ~u64(0);
+    q = query; sp = 0; ep = img.n - 1; i = 0; done = true; word_addr = ~u64(0); tried = false; no_jump = false; win_used = ~u32(0);
     force_single = 0;
     u64 begin = offsets[q], len = offsets[q + 1] - begin;
     if(len > 0 && img.n > 0)                                   // gcsa.h:99
@@ -457,13 +471,13 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     }
     if constexpr(WINDOW)
     {
-      // The next pattern characters as 2-bit codes: window of the 32 positions below win_top, position
-      // win_top - 1 - r at bits [2r, 2r + 2) of win_code, bit 2r of win_bad = "not a fast character".
+      // The next pattern characters as 2-bit codes: window of the 32 positions below win_top = i + win_used,
+      // position win_top - 1 - r at bits [2r, 2r + 2) of win_code, bit r of win_bad = "not a fast character".
       // Refilled once per 24 consumed characters (five independent word loads), so that neither the
       // jump test nor a step waits for pattern bytes.
-      if(!done && (win_top == ~u64(0) || win_top - i > 24))
+      if(!done && win_used > 24)
       {
-        win_top = i; win_code = 0; win_bad = 0;
+        win_used = 0; win_code = 0; win_bad = 0;
         const u64 count = (i < 32 ? i : 32), low = reinterpret_cast<u64>(p) + i - count, base = low & ~u64(7);
         u64 w[5];
         const u64 last = (low + count - 1) & ~u64(7);           // never read past the word of the last byte needed
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
           for(u32 k = 1; k < 5; k++) { if((at >> 3) == k) { word = w[k]; } }
           const u32 c = u32(t.c2c[u32(word >> ((at & 7) * 8)) & 0xFF]) - 1;
           win_code |= u64(c & 3) << (2 * r);
-          win_bad |= u64(c < 4 ? 0 : 1) << (2 * r);
+          win_bad |= u32(c < 4 ? 0 : 1) << r;
         }
       }
     }
@@ -490,8 +504,8 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       {
         if(force_single == 0 && i >= 2)
         {
-          const u32 r = u32(win_top - i);                      // window slot of position i - 1; i - 2 is slot r + 1
-          pair = ((win_bad >> (2 * r)) & 5) == 0;              // both are fast characters
+          const u32 r = win_used;                              // window slot of position i - 1; i - 2 is slot r + 1
+          pair = ((win_bad >> r) & 3) == 0;                    // both are fast characters
           if(pair)
           {
             const u32 c2 = u32(win_code >> (2 * r)) & 3, c1 = u32(win_code >> (2 * r + 2)) & 3;
@@ -508,8 +522,13 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
         if constexpr(PAIR) { force_single -= (force_single > 0 ? 1 : 0); }
         if constexpr(WINDOW)
         {
-          const u32 r = u32(win_top - 1 - i);
-          comp = ((win_bad >> (2 * r)) & 1) ? u32(t.c2c[byte_at(i)]) : 1 + (u32(win_code >> (2 * r)) & 3);
+          const u32 r = win_used++;
+          if((win_bad >> r) & 1)                               // rare: read the byte itself (no cached word kept across steps)
+          {
+            const u64 addr = reinterpret_cast<u64>(p) + i;
+            comp = t.c2c[u32(*reinterpret_cast<const u64*>(addr & ~u64(7)) >> ((addr & 7) * 8)) & 0xFF];
+          }
+          else { comp = 1 + (u32(win_code >> (2 * r)) & 3); }
         }
         else { comp = t.c2c[byte_at(i)]; }
         u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
@@ -517,8 +536,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
         idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
       }
     }
-    u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
-    [[maybe_unused]] PairEnd p_sp = {0, 0, 0, 0, 0}, p_ep = {0, 0, 0, 0, 0};
+    PairEnd p_sp = {0, 0, 0}, p_ep = {0, 0, 0};   // a single step keeps (edge, node) in .raw / .node: one set of registers
     const bool need2 = stepping && idx_ep != idx_sp;
     if(STATS && stepping) { blocks += 1 + (need2 ? 1 : 0); }
     ulonglong2 blk[8];
@@ -533,8 +551,8 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       }
       else
       {
-        eval_endpoint(blk, r_sp, 0, e_sp, n_sp);               // gcsa.h:271, then rank(edges, sp')
-        if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
+        eval_endpoint(blk, r_sp, 0, p_sp.raw, p_sp.node);      // gcsa.h:271, then rank(edges, sp')
+        if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, p_ep.raw, p_ep.node); }
       }
     }
     if(__any(need2))
@@ -545,7 +563,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       {
         read_block(wave_stage, lane, blk);
         if(PAIR && pair) { p_ep = eval_pair(blk, r_ep, true); }
-        else { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }      // gcsa.h:272: LF(ep + 1) - 1
+        else { eval_endpoint(blk, r_ep, 1, p_ep.raw, p_ep.node); }   // gcsa.h:272: LF(ep + 1) - 1
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -557,13 +575,13 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
         const u32 outcome = pair_outcome(p_sp, p_ep, idx_ep == idx_sp, a, b);
         if(outcome == 2)                                       // neither step empties
         {
-          sp = p_sp.node; ep = p_ep.node; i -= 2; done = (i == 0);
+          sp = p_sp.node; ep = p_ep.node; i -= 2; win_used += 2; done = (i == 0);
           if(STATS) { steps += 2; }
           if constexpr(JUMP) { tried = false; }
         }
         else if(outcome == 1)                                  // the second step empties: its edge-space integers, gcsa.h:160
         {
-          sp = a; ep = b; i -= 2; done = true;
+          sp = a; ep = b; i -= 2; win_used += 2; done = true;
           if(STATS) { steps += 2; }
         }
         else { force_single = 2; }                             // replayed as two single steps from the unchanged (sp, ep)
@@ -571,9 +589,9 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       else
       {
         if(STATS) { steps++; }
-        u64 a = e_sp, b = e_ep - 1;                            // edge space
+        u64 a = p_sp.raw, b = p_ep.raw - 1;                    // edge space
         if(range_empty(a, b)) { sp = a; ep = b; done = true; } // gcsa.h:160
-        else { sp = n_sp; ep = n_ep; done = (i == 0); }        // gcsa.h:161, 103
+        else { sp = p_sp.node; ep = p_ep.node; done = (i == 0); }   // gcsa.h:161, 103
         if constexpr(JUMP) { tried = false; }
       }
     }
@@ -581,10 +599,12 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
     {
       if(jumping)
       {
-        const u32 len = jt_len(entry), r = u32(win_top - i);
+        const u32 len = jt_len(entry), r = win_used;
+        u32 bad8 = (win_bad >> r) & 0xFF;                      // one bit per slot -> every second bit
+        bad8 = (bad8 | (bad8 << 4)) & 0x0F0F; bad8 = (bad8 | (bad8 << 2)) & 0x3333; bad8 = (bad8 | (bad8 << 1)) & 0x5555;
         // number of leading steps of the chain that the pattern follows
         const u32 diff = (u32(win_code >> (2 * r)) ^ jt_labels(entry)) & 0xFFFF;
-        const u32 bad = ((diff | (diff >> 1)) & 0x5555) | (u32(win_bad >> (2 * r)) & 0x5555);
+        const u32 bad = ((diff | (diff >> 1)) & 0x5555) | bad8;
         u32 usable = (bad != 0 ? u32(__ffs(int(bad)) - 1) >> 1 : 8u);
         usable = (usable < len ? usable : len);
         usable = (usable < i ? usable : u32(i));
@@ -593,7 +613,7 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
         if(take > 0)
         {
           sp = ep = (take == len ? jt_end(entry) : (take == 4 ? jt_after4(entry) : jt_after2(entry)));
-          i -= take; done = (i == 0);
+          i -= take; win_used += take; done = (i == 0);
           if(STATS) { steps += take; }
         }
         else
@@ -606,7 +626,11 @@ __global__ __launch_bounds__(TPB2) void k_find2(DevImage img, const u8* __restri
       }
     }
   }
-  if(!REFILL && has) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); }
+  if constexpr(!REFILL)
+  {
+    const u64 gid = u64(blockIdx.x) * TPB2 + threadIdx.x;     // recomputed: the query id is not held across the loop
+    if(gid < nq) { reinterpret_cast<ulonglong2*>(out)[perm != nullptr ? u64(perm[gid]) : gid] = make_ulonglong2(sp, ep); }
+  }
   if(STATS)
   {
     for(int o = 32; o > 0; o >>= 1)

@@ -439,7 +439,8 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   u32 calls = 0;
   bool need_parent = false;
   u32 force_single = 0;
-  u64 win_top = ~u64(0), win_code = 0, win_bad = 0;
+  u64 win_code = 0;                         // packed pattern window, as in k_find2
+  u32 win_used = ~u32(0), win_bad = 0;
   u64 packed = 0; u32 have = 0;             // results: four u16 per aligned 8-byte store
   auto emit = [&](u64 pos, u64 value)        // ms[begin + pos] = value; positions arrive in descending order
   {
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   {
     q = query; has = true;
     begin = offsets[q]; i = offsets[q + 1] - begin;
-    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_top = ~u64(0);
+    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0);
   };
   if constexpr(!REFILL)
   {
@@ -496,10 +497,10 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       if(!__any(has)) { break; }
     }
     const bool active = has && i > 0;
-    // packed pattern window, as in k_find2: the 32 positions below win_top as 2-bit codes + "not a fast character" bits
-    if(active && (win_top == ~u64(0) || win_top - i > 24))
+    // packed pattern window, as in k_find2: the 32 positions below i + win_used as 2-bit codes + "not a fast character" bits
+    if(active && win_used > 24)
     {
-      win_top = i; win_code = 0; win_bad = 0;
+      win_used = 0; win_code = 0; win_bad = 0;
       const u64 count = (i < 32 ? i : 32), low = reinterpret_cast<u64>(patterns) + begin + i - count, base = low & ~u64(7);
       u64 w[5];
       const u64 last = (low + count - 1) & ~u64(7);
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         for(u32 k = 1; k < 5; k++) { if((at >> 3) == k) { word = w[k]; } }
         const u32 c = u32(c2c[u32(word >> ((at & 7) * 8)) & 0xFF]) - 1;
         win_code |= u64(c & 3) << (2 * r);
-        win_bad |= u64(c < 4 ? 0 : 1) << (2 * r);
+        win_bad |= u32(c < 4 ? 0 : 1) << r;
       }
     }
     const bool stepping = active && !need_parent;
@@ -521,12 +522,12 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     bool pair = false;
     if(stepping)
     {
-      const u32 r = u32(win_top - i);                          // window slot of position i - 1
+      const u32 r = win_used;                                  // window slot of position i - 1
       if constexpr(PAIR)
       {
         if(force_single == 0 && i >= 2)
         {
-          pair = ((win_bad >> (2 * r)) & 5) == 0;
+          pair = ((win_bad >> r) & 3) == 0;
           if(pair)
           {
             const u32 c2 = u32(win_code >> (2 * r)) & 3, c1 = u32(win_code >> (2 * r + 2)) & 3;
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       }
       if(!pair)
       {
-        if((win_bad >> (2 * r)) & 1)
+        if((win_bad >> r) & 1)
         {
           const u64 addr = reinterpret_cast<u64>(patterns) + begin + i - 1;
           comp = c2c[u32(*reinterpret_cast<const u64*>(addr & ~u64(7)) >> ((addr & 7) * 8)) & 0xFF];
@@ -550,8 +551,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
       }
     }
-    u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;
-    PairEnd p_sp = {0, 0, 0, 0, 0}, p_ep = {0, 0, 0, 0, 0};
+    PairEnd p_sp = {0, 0, 0}, p_ep = {0, 0, 0};                // a single step keeps (edge, node) in .raw / .node
     const bool need2 = stepping && idx_ep != idx_sp;
     ulonglong2 blk[8];
     if(__any(stepping))
@@ -567,8 +567,8 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         }
         else
         {
-          eval_endpoint(blk, r_sp, 0, e_sp, n_sp);
-          if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
+          eval_endpoint(blk, r_sp, 0, p_sp.raw, p_sp.node);
+          if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, p_ep.raw, p_ep.node); }
         }
       }
       if(__any(need2))
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         {
           read_block(wave_stage, lane, blk);
           if(PAIR && pair) { p_ep = eval_pair(blk, r_ep, true); }
-          else { eval_endpoint(blk, r_ep, 1, e_ep, n_ep); }
+          else { eval_endpoint(blk, r_ep, 1, p_ep.raw, p_ep.node); }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -593,23 +593,23 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         {
           sp = p_sp.node; ep = p_ep.node;
           emit(i - 1, depth + 1); emit(i - 2, depth + 2);
-          depth += 2; i -= 2;
+          depth += 2; i -= 2; win_used += 2;
         }
         else { force_single = 2; }                             // an emptying step needs parent(): one character at a time
       }
       else
       {
-        const u64 a = e_sp, b = e_ep - 1;                      // gcsa.h:155-162
+        const u64 a = p_sp.raw, b = p_ep.raw - 1;              // gcsa.h:155-162
         if(!range_empty(a, b))
         {
-          sp = n_sp; ep = n_ep; depth++;
-          emit(i - 1, depth); i--;
+          sp = p_sp.node; ep = p_ep.node; depth++;
+          emit(i - 1, depth); i--; win_used++;
           force_single -= (force_single > 0 ? 1 : 0);
         }
         else if(sp == 0 && ep == img.n - 1)                    // at the root: no such character
         {
           depth = 0;
-          emit(i - 1, 0); i--;
+          emit(i - 1, 0); i--; win_used++;
           force_single -= (force_single > 0 ? 1 : 0);
         }
         else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }
