@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+HBM_MEASURED_GBS = 6290.0
 REQUEST_CEILING_GPS = 50.0       # dependent random 128-byte fetches/s at HBM footprints (gather_bench, profiles/r01_gather_bench.md)
 LINEAR_SEED = 0x6C5A0040
 HUMAN_PATTERN_SEED = 0x6C5A0041
@@ -555,6 +556,9 @@ def roofline(args, r, wl, key):
         out["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_*_sum pass of this workload; "
                                  "128 B x RDREQ_128B + 64 B x RDREQ_64B + 32 B x RDREQ_32B)")
         out["traffic_GBps"] = traffic / (r["kernel_ms"] * 1e-3) / 1e9
+        # the guide's measured streaming rate (MI355X_MICROARCH.md: 6.29 TB/s float4 copy = 79 % of the 8 TB/s spec): how close the
+        # launch's memory-side traffic is to what HBM delivers at all
+        out["traffic_frac_of_measured_hbm_rate"] = out["traffic_GBps"] / HBM_MEASURED_GBS
     return out
 
 

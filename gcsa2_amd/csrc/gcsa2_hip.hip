@@ -1183,11 +1183,28 @@ int gcsa2_locate_into(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t 
 
 // ---- host-pointer entry points: copy in, run, copy out, synchronise ----------------------
 
+namespace {
+// pattern offsets handed over by a host caller: non-decreasing, or the kernels would read outside the pattern buffer
+inline bool offsets_ok(const uint64_t* offsets, uint64_t nq, u64* longest = nullptr)
+{
+  u64 bad = 0, most = 0;
+  for(u64 q = 0; q < nq; q++)
+  {
+    const u64 len = offsets[q + 1] - offsets[q];
+    bad |= u64(offsets[q + 1] < offsets[q]);
+    most = (len > most ? len : most);
+  }
+  if(longest != nullptr) { *longest = most; }
+  return bad == 0;
+}
+}
+
 int gcsa2_find_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t* ranges)
 {
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   if(offsets == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  if(!offsets_ok(offsets, nq)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets are not non-decreasing"); }
   DeviceGuard guard(ix->device);
   const u64 total = offsets[nq];
   Lease lease(ix);
@@ -1633,6 +1650,7 @@ int gcsa2_group_find_batch(const gcsa2_group* g, const uint8_t* patterns, const 
   if(g == nullptr || g->replicas.empty()) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null or empty group"); }
   if(nq == 0) { return GCSA2_OK; }
   if(offsets == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  if(!offsets_ok(offsets, nq)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets are not non-decreasing"); }
   try {   // no C++ exception may cross the C boundary
   const u64 G = g->replicas.size(), base = nq / G, rem = nq % G;
   std::vector<int> status(G, GCSA2_OK);
@@ -1843,6 +1861,8 @@ extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* pat
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   if(offsets == nullptr || ms == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  u64 longest = 0;
+  if(!offsets_ok(offsets, nq, &longest)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets are not non-decreasing"); }
   DeviceGuard guard(ix->device);
   const u64 total = offsets[nq];
   Lease lease(ix);
@@ -1852,8 +1872,6 @@ extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* pat
   HIP_TRY(lease.up(d_pat, patterns, total));
   HIP_TRY(lease.up(d_off, offsets, (nq + 1) * sizeof(u64)));
   // ragged batches (longest pattern > 1.25 x the mean) large enough to fill the device go to the persistent lanes
-  u64 longest = 0;
-  for(u64 q = 0; q < nq; q++) { const u64 len = offsets[q + 1] - offsets[q]; longest = (len > longest ? len : longest); }
   const bool ragged = nq >= MS_REFILL_MIN && double(longest) * double(nq) > 1.25 * double(total);
   int rc = gcsa2_match_stats_device_variant(ix, ragged ? 5 : 0, d_pat, d_off, nq, d_ms, d_rng, d_fb, lease.stream());
   if(rc != GCSA2_OK) { return rc; }

@@ -146,6 +146,16 @@ def test_errors(engine):
     assert e.value.code == -5
     with pytest.raises(engine.Gcsa2Error):
         engine.GCSA(ix, device=99)
+    # pattern offsets of the host-pointer entry points must be non-decreasing (they index the pattern buffer)
+    data = np.frombuffer(b"ACGTACGT", dtype=np.uint8).copy()
+    bad = np.array([0, 5, 3, 8], dtype=np.uint64)
+    with pytest.raises(engine.Gcsa2Error) as e:
+        g.find_batch(data, bad)
+    assert e.value.code == -1 and "non-decreasing" in str(e.value)
+    full, lcp = engine.open_index(build(graphs.paper_graph(), 3, sample_period=2, branching=2))
+    with pytest.raises(engine.Gcsa2Error) as e:
+        full.match_stats_batch(data, bad)
+    assert e.value.code == -1
 
 
 def test_locate_modes_and_samples(case):
