@@ -7,10 +7,11 @@
  * Parity pin: the reference (jltsiren/gcsa2 @ v1.3.0) cannot be built in this image -- its one
  * external include <sdsl/wavelet_trees.hpp> (include/gcsa/utils.h:36, vgteam/sdsl-lite, no
  * pinned version, Makefile:1-2) is absent and un-vendored -- and the tree holds no golden
- * vectors.  The only known-answer material is the worked example of the paper (Figures 2-3,
- * paper/gcsa2_graph_dbg.ipe, paper/gcsa2_pruned_index.ipe); this oracle is pinned against it
- * (tests/golden/paper_example.json) and against a definition-level brute force over the input
- * graph (tests/naive.py).  SDSL's rank/select/access are unambiguous integer functions, so any
+ * vectors.  The known-answer material is the paper's two worked examples: the GCSA of Figures 2-3
+ * (paper/gcsa2_graph_dbg.ipe, paper/gcsa2_pruned_index.ipe -> tests/golden/paper_example.json) and the
+ * text index of Figure 1 (paper/gcsa2_text_indexes.ipe: BWT, SA, LCP and LF columns of GCATCATA$ ->
+ * tests/golden/text_example.json); this oracle is pinned against both and against a definition-level
+ * brute force over the input graph (tests/naive.py).  SDSL's rank/select/access are unambiguous integer functions, so any
  * correct bitvector yields bit-identical range_type / node_type results.
  *
  * Memory layout mirrors what libgcsa2 + SDSL touch, so that the CPU baseline has the reference's

@@ -20,6 +20,14 @@ def paper():
         return json.load(f)
 
 
+@pytest.fixture(scope="session")
+def text_figure():
+    """Figure 1 of the paper (text GCATCATA$: BWT, SA, LCP, LF), transcribed by tests/golden/make_text_example.py."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "text_example.json")) as f:
+        return json.load(f)
+
+
 def _gpu_unavailable_reason():
     """None when a GPU and the built HIP library are usable, else why not.  With `-m gpu` selected explicitly (the
     GPU box) nothing is skipped: a missing library or device must fail loudly there, not pass as skipped."""

@@ -28,14 +28,10 @@ def common_prefix(a, b):
     return n
 
 
-def main():
-    with open(PATH) as f:
-        gold = json.load(f)
-    keys = [node["key"] for node in gold["nodes"]]
+def derive_suffix_tree(keys, lcp, ranges):
+    """psv / nsv of every position, parent of every range in `ranges`, depth and rmq cases: from the sorted keys and
+    their LCP array by the definitions in the docstring (string comparisons only)."""
     n = len(keys)
-    order = gold["comp_order"]
-    assert keys == sorted(keys, key=lambda k: [order.index(c) for c in k]), "the figure lists the keys in lexicographic order"
-    lcp = [0] + [common_prefix(keys[i - 1], keys[i]) for i in range(1, n)]
 
     def psv(i):
         return next(([j, lcp[j]] for j in range(i - 1, -1, -1) if lcp[j] < lcp[i]), None) if i > 0 else None
@@ -56,8 +52,6 @@ def main():
         return {"range": [sp, ep], "parent": [lo, hi], "left_lcp": lcp[lo], "right_lcp": (lcp[hi + 1] if hi + 1 < n else 0),
                 "node_lcp": depth}
 
-    ranges = [(i, i) for i in range(n)] + [tuple(q["range"]) for q in gold["find"] if q["range"][0] <= q["range"][1]]
-    ranges += [(2, 4), (2, 3), (9, 12), (10, 11), (13, 15), (14, 15), (1, 4), (5, 6), (7, 8), (0, n - 1), (0, 4), (9, 15)]
     seen, parents = set(), []
     for r in ranges:
         if r not in seen:
@@ -69,15 +63,27 @@ def main():
         for ep in range(sp, n, 3):
             window = lcp[sp: ep + 1]
             rmq.append({"range": [sp, ep], "pos": sp + window.index(min(window)), "value": min(window)})
-    gold["suffix_tree"] = {
-        "_source": "derived from the keys above by tests/golden/make_paper_lcp.py (definitions only; see its docstring)",
-        "lcp": lcp, "psv": [psv(i) for i in range(n)], "nsv": [nsv(i) for i in range(n)],
-        "parent": parents, "depth": depth, "rmq": rmq,
-    }
+    return {"lcp": lcp, "psv": [psv(i) for i in range(n)], "nsv": [nsv(i) for i in range(n)],
+            "parent": parents, "depth": depth, "rmq": rmq}
+
+
+def main():
+    with open(PATH) as f:
+        gold = json.load(f)
+    keys = [node["key"] for node in gold["nodes"]]
+    n = len(keys)
+    order = gold["comp_order"]
+    assert keys == sorted(keys, key=lambda k: [order.index(c) for c in k]), "the figure lists the keys in lexicographic order"
+    lcp = [0] + [common_prefix(keys[i - 1], keys[i]) for i in range(1, n)]
+    ranges = [(i, i) for i in range(n)] + [tuple(q["range"]) for q in gold["find"] if q["range"][0] <= q["range"][1]]
+    ranges += [(2, 4), (2, 3), (9, 12), (10, 11), (13, 15), (14, 15), (1, 4), (5, 6), (7, 8), (0, n - 1), (0, 4), (9, 15)]
+    st = derive_suffix_tree(keys, lcp, ranges)
+    gold["suffix_tree"] = {"_source": "derived from the keys above by tests/golden/make_paper_lcp.py (definitions only; see its docstring)"}
+    gold["suffix_tree"].update(st)
     text = json.dumps(gold, indent=2)
     with open(PATH, "w") as f:
         f.write(text + "\n")
-    print("LCP =", lcp, ";", len(parents), "parent cases,", len(rmq), "rmq cases")
+    print("LCP =", lcp, ";", len(st["parent"]), "parent cases,", len(st["rmq"]), "rmq cases")
 
 
 if __name__ == "__main__":

@@ -63,6 +63,26 @@ def test_paper_example_on_gpu(engine, paper):
                                 lcp.parent, lcp.depth, lcp.psv, lcp.nsv, lcp.rmq, lcp.notFound())
 
 
+def test_text_figure(engine, text_figure):
+    """Figure 1 of the paper (text GCATCATA$: BWT, SA, LCP and LF columns) through the HIP path; the expected values are
+    the figure's, the oracle is not consulted (tests/golden/make_text_example.py)."""
+    from test_oracle import check_text_figure, text_example_index, text_position
+    for branching in (2, 3, 64):
+        ix = text_example_index(text_figure, branching=branching)
+        gpu, lcp = engine.open_index(ix)
+        n = int(ix.n)
+        preds = gpu.lf_all_batch(np.array([[i, i] for i in range(n)], dtype=np.uint64), 1)      # LF_all: every comp's child range
+
+        def pred_char(i):
+            return "".join("$ACGTN#"[c] for c in range(7) if preds[i][c][0] <= preds[i][c][1])
+        check_text_figure(text_figure, gpu.size(), pred_char, [int(x) for x in lcp.access_batch(np.arange(n, dtype=np.uint64))],
+                          lambda i: int(gpu.lf_node_batch(np.array([i], dtype=np.uint64))[0]), gpu.locate, gpu.find,
+                          (lcp.parent, lcp.depth, lcp.psv, lcp.nsv, lcp.rmq, lcp.notFound()))
+    gpu, lcp = engine.open_index(text_example_index(text_figure, sample_period=4))
+    for i in range(9):
+        assert [text_position(v, text_figure) for v in gpu.locate((i, i))] == [text_figure["SA"][i]]
+
+
 def test_find(case):
     name, g, K, ix, gpu, lcp, cpu = case
     pats = [truncate_at_sink(p) for p in random_patterns(g, K, 0x77, 600)]

@@ -93,6 +93,68 @@ def test_oracle_on_paper_suffix_tree(paper):
 
 
 # ---------------------------------------------------------------------------------------------
+# 1b. the paper's text-index figure (GCATCATA$): a GCSA of a text is its FM-index
+
+TEXT_NODE_LEN = 3
+
+
+def text_example_index(fig, sample_period=1 << 40, branching=2):
+    """Index of the path graph of the figure's text: vg-style nodes of 3 bases, order high enough for unique keys."""
+    seq = graphs.default_char2comp()[np.frombuffer(fig["text"][:-1].encode(), dtype=np.uint8)]
+    return build(graphs.linear_graph(len(seq), 0, node_len=TEXT_NODE_LEN, sequence=seq), 16, sample_period=sample_period,
+                 branching=branching)
+
+
+def text_position(value, fig):
+    """Text position of a located node_type: (id, offset) of a base, or the sink node = the final '$'."""
+    node, offset = int(value) >> graphs.ID_OFFSET, int(value) & ((1 << graphs.OFFSET_BITS) - 1)
+    pos = (node - 1) * TEXT_NODE_LEN + offset
+    return pos if pos < len(fig["text"]) - 1 else len(fig["text"]) - 1
+
+
+def check_text_figure(fig, size, pred_char, lcp_values, lf_node, locate, find, suffix_tree_ops):
+    """Shared by the oracle (CPU) and the engine (GPU): every column of the figure, and what follows from them."""
+    g = fig["gcsa"]
+    n = g["path_nodes"]
+    assert size == n == len(fig["suffixes"]) + 1
+    assert [pred_char(i) for i in range(n)] == g["BWT"]                       # BWT column (+ the source-marker row)
+    assert [lf_node(i) for i in range(n)] == g["LF"]                          # LF column
+    assert [lf_node(i) for i in range(9) if fig["SA"][i] != 0] == [fig["LF"][i] for i in range(9) if fig["SA"][i] != 0]
+    for i in range(9):                                                        # SA column
+        assert [text_position(v, fig) for v in locate((i, i))] == [fig["SA"][i]], i
+    for q in g["find"]:                                                       # rows whose suffix starts with the pattern
+        rng = find(q["pattern"].encode())
+        assert list(rng) == q["range"], q
+        assert sorted(text_position(v, fig) for v in locate(rng)) == q["positions"], q
+    for x in g["absent"]:
+        sp, ep = find(x.encode())
+        assert sp + 1 > ep + 1 or sp > ep, x                                  # empty (utils.h:93-96)
+    st = {"suffix_tree": g["suffix_tree"]}
+    assert list(lcp_values)[:9] == fig["LCP"]                                 # LCP column, as printed
+    check_paper_suffix_tree(st, lcp_values, *suffix_tree_ops)
+
+
+def oracle_pred_char(ix):
+    return lambda i: "".join(COMP2CHAR[c] for c in range(int(ix.sigma)) if (int(ix.bwt[c][i >> 6]) >> (i & 63)) & 1)
+
+
+def test_oracle_on_text_figure(text_figure):
+    """Second reference-held known-answer instance: Figure 1 (paper.tex:147-151).  Pins LF, locate and -- the part the
+    GCSA figure does not carry -- a printed LCP array, with parent / depth / psv / nsv / rmq derived from it."""
+    for branching in (2, 3, 64):
+        ix = text_example_index(text_figure, branching=branching)
+        o = OracleIndex(ix)
+        values = int(ix.lcp_offsets[-1])
+        check_text_figure(text_figure, ix.n, oracle_pred_char(ix), [int(x) for x in ix.lcp_data[: ix.n]], o.LF, o.locate, o.find,
+                          (o.parent, o.depth, o.psv, o.nsv, o.rmq, (values, values)))
+    # with samples only every 4th position the located positions are the same
+    ix = text_example_index(text_figure, sample_period=4)
+    o = OracleIndex(ix)
+    for i in range(9):
+        assert [text_position(v, text_figure) for v in o.locate((i, i))] == [text_figure["SA"][i]]
+
+
+# ---------------------------------------------------------------------------------------------
 # 2. differential tests
 
 def small_cases():
