@@ -71,10 +71,11 @@ def test_text_figure(engine, text_figure):
         ix = text_example_index(text_figure, branching=branching)
         gpu, lcp = engine.open_index(ix)
         n = int(ix.n)
-        preds = gpu.lf_all_batch(np.array([[i, i] for i in range(n)], dtype=np.uint64), 1)      # LF_all: every comp's child range
+        singles = np.array([[i, i] for i in range(n)], dtype=np.uint64)
+        steps = [gpu.lf_batch(singles, np.full(n, c, dtype=np.uint8)) for c in range(7)]       # LF((i, i), c) is non-empty iff B_c[i]
 
         def pred_char(i):
-            return "".join("$ACGTN#"[c] for c in range(7) if preds[i][c][0] <= preds[i][c][1])
+            return "".join("$ACGTN#"[c] for c in range(7) if steps[c][i][0] + 1 <= steps[c][i][1] + 1)
         check_text_figure(text_figure, gpu.size(), pred_char, [int(x) for x in lcp.access_batch(np.arange(n, dtype=np.uint64))],
                           lambda i: int(gpu.lf_node_batch(np.array([i], dtype=np.uint64))[0]), gpu.locate, gpu.find,
                           (lcp.parent, lcp.depth, lcp.psv, lcp.nsv, lcp.rmq, lcp.notFound()))
