@@ -1,7 +1,7 @@
 // <gcsa/support.h> of the MI355X engine: node_type / Node and the Alphabet members callers read
-// (reference include/gcsa/support.h:93-155, 441-471).  The construction-time parts of the reference's
-// support.h (ConstructionParameters, KMer, PathNode, the Sadakane counter classes, ...) are out of scope: the
-// counters live inside the device image.
+// (reference include/gcsa/support.h:93-155, 441-471), plus Key / KMer as far as verifyIndex() reads them
+// (support.h:378-497).  The construction-time parts of the reference's support.h (ConstructionParameters, PathNode,
+// the Sadakane counter classes, ...) are out of scope: the counters live inside the device image.
 #ifndef GCSA2_HIP_GCSA_SUPPORT_H
 #define GCSA2_HIP_GCSA_SUPPORT_H
 
@@ -70,6 +70,49 @@ public:
     for(size_type c = 0; is_default && c < sigma; c++) { is_default = (char2comp[std::uint8_t(dflt[c])] == c); }
     if(is_default) { comp2char.assign(dflt.begin(), dflt.end()); }
   }
+};
+
+// A k-mer of the input graph as the reference's constructor and verifyIndex() see it: the label packed 3 bits per
+// character above one byte of predecessor and one byte of successor comps (support.h:378-428).
+typedef std::uint64_t key_type;
+
+struct Key
+{
+  constexpr static size_type GCSA_CHAR_WIDTH = 3;
+  constexpr static key_type  CHAR_MASK = 0x7;
+  constexpr static size_type MAX_LENGTH = 16;
+  constexpr static key_type  PRED_SUCC_MASK = 0xFFFF;
+
+  static key_type encode(const Alphabet& alpha, const std::string& kmer, byte_type pred, byte_type succ)   // support.h:385-396
+  {
+    key_type packed = 0;
+    for(char c : kmer) { packed = (packed << GCSA_CHAR_WIDTH) | alpha.char2comp[std::uint8_t(c)]; }
+    return (((packed << 8) | pred) << 8) | succ;
+  }
+  static std::string decode(key_type key, size_type kmer_length, const Alphabet& alpha)                   // support.cpp:539-553
+  {
+    key_type chars = label(key);
+    const size_type length = (kmer_length < MAX_LENGTH ? kmer_length : MAX_LENGTH);
+    std::string result(length, '\0');
+    for(size_type i = length; i > 0; i--) { result[i - 1] = char(alpha.comp2char[chars & CHAR_MASK]); chars >>= GCSA_CHAR_WIDTH; }
+    return result;
+  }
+  static size_type label(key_type key) { return key >> 16; }
+  static byte_type predecessors(key_type key) { return byte_type((key >> 8) & 0xFF); }
+  static byte_type successors(key_type key) { return byte_type(key & 0xFF); }
+  static comp_type last(key_type key) { return comp_type((key >> 16) & CHAR_MASK); }
+};
+
+struct KMer    // support.h:475-497
+{
+  key_type  key;
+  node_type from, to;
+
+  KMer() : key(0), from(0), to(0) {}
+  KMer(key_type _key, node_type _from, node_type _to) : key(_key), from(_from), to(_to) {}
+  bool operator<(const KMer& another) const { return Key::label(key) < Key::label(another.key); }
+  bool sorted() const { return to == ~node_type(0); }
+  void makeSorted() { to = ~node_type(0); }
 };
 
 } // namespace gcsa
