@@ -259,3 +259,60 @@ def test_reference_api_client_matches_oracle(tmp_path):
     assert next(it) == "lcp error 1"
     assert next(it) == f"stream {ix.n} {ix.lcp_size} 1"
     assert first[0] <= first[1]
+
+
+# ---- verifyIndex() over a k-mer array (include/gcsa/algorithms.h; reference src/algorithms.cpp:101-295) --------------------
+
+VERIFY_SRC = os.path.join(ROOT, "tests", "cpp", "verify_client.cpp")
+
+
+def graph_kmers(g, k):
+    """Every (k-mer label, start node) of the input graph, the reference's verification input: labels are cut after the
+    first endmarker and padded with '$' to k characters, as the k-mer extraction leaves them (paper figure: key `$$$`)."""
+    from workload.brute_builder import k_labels
+    rows = set()
+    for v, labels in enumerate(k_labels(g, k)):
+        for label in labels:
+            text = "".join("$ACGTN#"[c] for c in label)
+            if "$" in text:
+                text = text[: text.index("$") + 1].ljust(k, "$")
+            rows.add((text, int(g.value[v])))
+    return sorted(rows)
+
+
+def test_verify_client_compiles(tmp_path):
+    assert os.path.exists(compile_client(str(tmp_path / "verify_client"), VERIFY_SRC))
+
+
+@pytest.mark.gpu
+def test_verify_index_through_the_reference_api(tmp_path):
+    """The reference's own test of this path: every distinct k-mer of the input graph is searched, located, counted and --
+    with the LCP array -- its parent() compared with re-searching shorter prefixes.  Complete on a correct index; fails,
+    with the reference's messages, when the k-mer array and the index disagree."""
+    from workload import graphs, builder, sdsl_format
+    g = graphs.snp_graph(1500, 0x91, 0x92, snp_period=10, node_len=16)
+    ix = builder.build(g, 16, sample_period=8, branching=4)
+    base = str(tmp_path / "index")
+    sdsl_format.write(ix, base)
+    k = 8
+    rows = graph_kmers(g, k)
+    assert len(rows) > 1500 and any(r[0].endswith("$$") for r in rows) and any(r[0].startswith("#") for r in rows)
+    (tmp_path / "kmers.txt").write_text("".join(f"{label} {value}\n" for label, value in rows))
+    exe = compile_client(str(tmp_path / "verify_client"), VERIFY_SRC)
+
+    def run(*mode):
+        return subprocess.run([exe, base, str(tmp_path / "kmers.txt"), str(k), *mode], env=_run_env(), capture_output=True, text=True,
+                              timeout=600)
+    good = run()
+    assert good.returncode == 0, good.stderr + good.stdout
+    distinct = len({label for label, value in rows})
+    assert f"Queried the index with {distinct} patterns in " in good.stdout
+    assert "Index verification complete" in good.stdout and "result 1" in good.stdout and "verifyIndex()" not in good.stderr
+    plain = run("nolcp")
+    assert plain.returncode == 0 and "Index verification complete" in plain.stdout
+    dropped = run("drop")
+    assert dropped.returncode == 3 and "Index verification failed for 1 patterns" in dropped.stdout
+    assert "verifyIndex(): count(" in dropped.stderr and " occurrences, got " in dropped.stderr
+    altered = run("alter")
+    assert altered.returncode == 3 and "Index verification failed for 1 patterns" in altered.stdout
+    assert "verifyIndex(): locate(" in altered.stderr and "failed: Expected " in altered.stderr
