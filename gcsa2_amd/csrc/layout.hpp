@@ -84,7 +84,7 @@ constexpr u64 PAIR_BITS     = 192;           // positions per FLP128 block (thre
 constexpr u32 PAIR_WORDS    = 3;
 constexpr u32 PAIR_FLAG     = u32(1) << 31;  // block index refers to the FLP128 array
 constexpr int MAX_SIGMA     = 16;
-constexpr int MAX_LCP_LEVELS = 16;
+constexpr int MAX_LCP_LEVELS = 64;      // a binary tree (branching 2, the smallest the reference allows) over 2^63 values
 
 struct DevBV
 {

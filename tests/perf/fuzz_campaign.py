@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Differential campaign on mid-size random graphs (bubbles, indels, cycles, Ns, small alphabets): thousands of path nodes,
+so that ranges straddle the 192-position pair blocks and the 448-position single blocks, steps empty in either character of a
+pair, and locate() meets every segment-size class.  Every query kind of the engine against the CPU oracle.
+
+    python tests/perf/fuzz_campaign.py [--seeds 40] [--first 0]
+
+Prints one line per graph and a final verdict; exits non-zero at the first difference.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=40)
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--cpu-only", action="store_true", help="build the indexes and run the oracle only (timing of the harness)")
+    args = ap.parse_args()
+    from workload import graphs, builder, patterns
+    from workload.rng import SplitMix64
+    from oracle.oracle import OracleIndex, max_threads
+    if not args.cpu_only:
+        from gcsa2_amd.binding import open_index
+    threads = max_threads()
+    t_start = time.time()
+    for seed in range(args.first, args.first + args.seeds):
+        rng = SplitMix64(0xCA11 + seed)
+        n = 1500 + rng.below(30000)
+        alphabet = 2 + rng.below(3)
+        p_back = (0.0, 0.0, 0.001, 0.004)[rng.below(4)]
+        g = graphs.random_graph(n, 0xCA5000 + seed, p_branch=0.03 + 0.01 * rng.below(15), p_back=p_back,
+                                p_n=(0.0, 0.01, 0.03)[rng.below(3)], alphabet=alphabet)
+        K = (4, 8, 16, 32)[rng.below(4)] if p_back == 0.0 else (6, 8)[rng.below(2)]
+        ix = builder.build(g, K, sample_period=(1 << 40 if seed % 7 == 0 else 2 + rng.below(40)), branching=2 + rng.below(63))
+        cpu = OracleIndex(ix)
+        m = 4 + rng.below(60)
+        walks = patterns.walk_patterns(g, 12000, m, 0xCA6000 + seed)
+        mutate = np.random.default_rng(seed)
+        rows = []
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        for q in range(walks.shape[0]):
+            row = walks[q].copy()
+            if q % 3 == 1:                                   # substitutions: steps that empty mid-pattern, parent() in matching statistics
+                for pos in mutate.integers(0, m, size=1 + q % 4):
+                    row[pos] = lut[mutate.integers(0, alphabet)]
+            rows.append(bytes(row[: 1 + mutate.integers(0, m)]) if q % 5 == 2 else bytes(row))
+        rows += [bytes(p) for p in patterns.uniform_patterns(2000, 3 + rng.below(12), 0xCA7000 + seed)]
+        rows += [b"", b"N", b"$", b"#", b"A" * 70]
+        from gcsa2_amd.hostview import concat_patterns
+        data, off = concat_patterns(rows)
+        c_find = cpu.find_batch(data, off, threads=threads)
+        nonempty = c_find[(c_find[:, 0] <= c_find[:, 1]) & (c_find[:, 1] < ix.n)]
+        line = f"seed {seed}: n={ix.n} e={ix.e} K={K} sigma={alphabet} back={p_back} m={m} patterns={len(rows)} hits={len(nonempty)}"
+        if args.cpu_only:
+            print(line, flush=True)
+            continue
+        gpu, lcp = open_index(ix)
+        assert np.array_equal(gpu.find_batch(data, off), c_find), (seed, "find")
+        wide = np.array([[a, min(a + w, ix.n - 1)] for a, w in zip(mutate.integers(0, ix.n, size=3000), mutate.integers(0, 3000, size=3000))],
+                        dtype=np.uint64)
+        for name, arr in (("found", nonempty), ("wide", wide)):
+            assert np.array_equal(gpu.count_batch(arr), cpu.count_batch(arr)), (seed, "count", name)
+            go, gv = gpu.locate_batch(arr)
+            co, cv = cpu.locate_batch(arr)
+            assert np.array_equal(go, co) and np.array_equal(gv, cv), (seed, "locate", name)
+            assert np.array_equal(lcp.parent_batch(arr), cpu.parent_batch(arr)), (seed, "parent", name)
+            assert np.array_equal(lcp.depth_batch(arr), cpu.depth_batch(arr)), (seed, "depth", name)
+        comps = mutate.integers(0, ix.sigma, size=len(wide)).astype(np.uint8)
+        want = np.array([cpu.LF((int(a), int(b)), int(c)) for (a, b), c in zip(wide[:400], comps[:400])], dtype=np.uint64).reshape(-1, 2)
+        assert np.array_equal(gpu.lf_batch(wide[:400], comps[:400]), want), (seed, "lf")
+        gm, gr, gf = gpu.match_stats_batch(data, off)
+        cm, cr, cf = cpu.match_stats_batch(data, off, threads=threads)
+        assert np.array_equal(gm, cm) and np.array_equal(gr, cr) and np.array_equal(gf, cf), (seed, "match_stats")
+        for variant_env in ({"GCSA2_MATCH_STATS": "5", "GCSA2_MS_GRID": "3"}, {"GCSA2_MATCH_STATS": "1"}):
+            os.environ.update(variant_env)
+            vm, vr, vf = gpu.match_stats_batch(data, off)
+            for key in variant_env:
+                del os.environ[key]
+            assert np.array_equal(vm, cm) and np.array_equal(vr, cr) and np.array_equal(vf, cf), (seed, "match_stats", variant_env)
+        print(line + "  ok", flush=True)
+        gpu.close()
+    print(f"campaign of {args.seeds} graphs: no difference ({time.time() - t_start:.0f} s)")
+
+
+if __name__ == "__main__":
+    main()

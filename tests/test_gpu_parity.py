@@ -575,6 +575,29 @@ def test_seed_table_sizes(engine, monkeypatch):
     assert len(seen) >= 5
 
 
+def test_deep_lcp_tree(engine):
+    """A binary range-minimum tree (branching 2, the smallest the reference's constructor accepts) over 70 k values has 18
+    levels: more than the 16 an earlier build admitted.  Every LCP operation equals the oracle."""
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    g = graphs.linear_graph(70000, 0x97, node_len=32)
+    ix = builder.build(g, 16, sample_period=32, branching=2)
+    assert len(ix.lcp_offsets) - 1 > 16
+    gpu, lcp = engine.open_index(ix)
+    cpu = OracleIndex(ix)
+    assert lcp.levels() == len(ix.lcp_offsets) - 1 and lcp.branching() == 2
+    rng = np.random.default_rng(0x98)
+    a = rng.integers(0, ix.n, size=4000)
+    arr = np.stack([a, np.minimum(a + rng.integers(0, 50, size=4000) ** 2, ix.n - 1)], axis=1).astype(np.uint64)
+    assert np.array_equal(lcp.parent_batch(arr), cpu.parent_batch(arr))
+    assert np.array_equal(lcp.depth_batch(arr), cpu.depth_batch(arr))
+    for pos in [0, 1, ix.n - 1] + [int(x) for x in a[:300]]:
+        assert lcp.psv(pos) == cpu.psv(pos) and lcp.nsv(pos) == cpu.nsv(pos), pos
+        assert lcp.psev(pos) == cpu.psev(pos) and lcp.nsev(pos) == cpu.nsev(pos), pos
+    for sp, ep in arr[:300]:
+        assert lcp.rmq(int(sp), int(ep)) == cpu.rmq(int(sp), int(ep))
+
+
 def test_fuzz_random_graphs(engine, monkeypatch):
     """150 seeded random graphs (bubbles, indels, cycles, Ns; orders 2..6): every query type equals the
     oracle, which the CPU suite pins against the definition-level brute force on graphs of this family."""
