@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["human", "human_snp", "chr22", "linear"], default="human",
                     help="human: whole-human-footprint index, one batch sharded over the GPUs (config 4); human_snp: the same text "
-                         "with SNP bubbles (branching index, e = 1.08 n; find() only); "
+                         "with SNP bubbles (branching index, e = 1.08 n; find() and, at N = 1, matching statistics); "
                          "chr22: chr22-like SNP-bubble graph (config 2); linear: 2^30-base linear graph built on the GPU")
     ap.add_argument("--snp-period", type=int, default=50, help="human_snp: one SNP per this many positions")
     ap.add_argument("--degree", type=int, default=32, help="human: degree of the m-sequence (path nodes = 2^degree - 1)")
@@ -198,7 +198,8 @@ def host_memory_ok(bytes_needed):
 
 def setup_human(args, D, dev, local_rank, branching=False, total_queries=None):
     """branching = False: the plain m-sequence text (every structure in closed form: find, locate, parent);
-    branching = True: the same text with one SNP bubble per --snp-period positions (find() only)."""
+    branching = True: the same text with one SNP bubble per --snp-period positions (find(); at N = 1 also the LCP array
+    of the node set, for the matching statistics of config 5)."""
     import torch
     from workload import mseq_torch
     from gcsa2_amd.binding import GCSA
@@ -219,7 +220,8 @@ def setup_human(args, D, dev, local_rank, branching=False, total_queries=None):
     t = time.time()
     alt_t = None
     if branching:
-        ix, sym_t, rank, alt_t = mseq_torch.build_mseq_snp(degree, period=args.snp_period, device=dev, verbose=log)
+        with_lcp = (D.world == 1 and not args.no_secondary)      # N = 1: the matching-statistics leg needs the LCP array
+        ix, sym_t, rank, alt_t = mseq_torch.build_mseq_snp(degree, period=args.snp_period, device=dev, verbose=log, with_lcp=with_lcp)
         torch.cuda.empty_cache()
     else:
         ix, sym_t, rank = mseq_torch.build_mseq(degree, device=dev, verbose=log, full=full)
@@ -227,10 +229,10 @@ def setup_human(args, D, dev, local_rank, branching=False, total_queries=None):
     del rank
     log(f"index arrays: n = {ix.n} ({time.time() - t:.1f} s)")
     t = time.time()
-    wl.gpu = GCSA(ix, device=local_rank, with_samples=full, with_counters=full, with_lcp=full)
+    wl.gpu = GCSA(ix, device=local_rank, with_samples=full, with_counters=full, with_lcp=(full or (branching and ix.lcp_size > 0)))
     log(f"device image: {wl.gpu.device_bytes() / 1e9:.2f} GB in HBM, seed table k = {wl.gpu.kmer_table_k()}, "
         f"pair blocks {wl.gpu.pair_block_bytes() / 1e9:.2f} GB ({time.time() - t:.1f} s)")
-    wl.ix, wl.sym_t, wl.rank_t, wl.full, wl.degree = ix, sym_t, rank_t, full, degree
+    wl.ix, wl.sym_t, wl.rank_t, wl.full, wl.degree, wl.alt_t = ix, sym_t, rank_t, full, degree, alt_t
     wl.total_queries = total_queries or args.queries or 100_000_000
     wl.m = args.pattern_len
     b, e = shard_bounds(wl.total_queries, D.world)[D.rank]
@@ -621,7 +623,10 @@ def config5(args, wl, dev):
                        "backward search with parent() on failure (k_match_stats), then locate() and parent() of the final ranges",
            "match_stats_ms": ms_time, "patterns_per_s": nq / (ms_time * 1e-3), "bases_per_s": nq * m / (ms_time * 1e-3),
            "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item()),
-           "unmodified_half_equals_closed_form": exact_ok}
+           "unmodified_half_equals_closed_form": exact_ok,
+           "note": "on this unbranched index every substituted pattern fails at the same steps (23 parent() calls, 200 rounds each), so "
+                   "the lanes of a wave diverge in lockstep; `human_branching.config5` runs the same kernel on the branching index, "
+                   "where they do not (profiles/r02_config5.md)"}
     # plain find() of the same batch (a substituted pattern empties at its first substitution)
     d_find = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
     out["find_ms"] = timed(lambda: gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_find.data_ptr(), stream.cuda_stream))
@@ -677,7 +682,60 @@ def human_snp_secondary(args, D, dev, local_rank):
            "all_ranges_equal_closed_form": ok, "config": find_config(wl, r, 1),
            "roofline": roofline(args, r, wl, f"human_snp_{wl.degree}_{wl.m}_{args.set}")}
     del r
+    if wl.ix.lcp_size > 0:
+        out["config5"] = config5_branching(args, wl, dev)
     release(wl)
+    return out
+
+
+def config5_branching(args, wl, dev):
+    """BASELINE configs[4]'s backward search with parent() on failure, on the BRANCHING footprint index: 1 M 256-bp walks
+    through the graph (alternative base at half of the SNP sites met), every second one with a substitution every 41 bp.
+    The LCP array is that of the node set (workload/mseq_torch.py::mseq_lcp); locate() needs samples, which this index does
+    not carry, and stays on the unbranched one."""
+    import torch
+    from workload import mseq_torch
+    gpu = wl.gpu
+    nq, m = 1_000_000, 256
+    stream = torch.cuda.current_stream()
+    pats, expected = mseq_torch.walk_patterns_device(wl.sym_t, wl.alt_t, wl.rank_t, 0, nq, m, CONFIG5_SEED)
+    nxt = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"CGTA"):
+        nxt[a] = b
+    for col in range(37, m, 41):
+        pats[1::2, col] = nxt[pats[1::2, col].to(torch.int64)]
+    d_pat = padded_bytes(pats)
+    d_off = torch.arange(nq + 1, dtype=torch.int64, device=dev) * m
+    d_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev)
+    d_rng = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    d_fb = torch.zeros(nq, dtype=torch.int64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+
+    def run():
+        gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), stream.cuda_stream)
+    run()
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms_time = e0.elapsed_time(e1) / reps
+    # closed form for the unmodified half: the walk matches to full depth, so no parent() call, the match starting at byte i
+    # has length 256 - i, and the final range is the single node of the walk's first k characters
+    exp = expected[0::2]
+    ms2d = d_ms[: nq * m].view(nq, m)
+    want_ms = (m - torch.arange(m, device=dev)).to(torch.int16).view(1, m)
+    exact_ok = bool(torch.equal(d_rng[0::2, 0], exp)) and bool(torch.equal(d_rng[0::2, 1], exp)) and \
+        bool((d_fb[0::2] == 0).all()) and bool((ms2d[0::2] == want_ms).all())
+    out = {"workload": f"{nq} x {m}-bp walks through the branching index, every second one with a substitution every 41 bp: "
+                       "backward search with parent() on failure (k_match_stats)",
+           "match_stats_ms": ms_time, "patterns_per_s": nq / (ms_time * 1e-3), "bases_per_s": nq * m / (ms_time * 1e-3),
+           "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item()),
+           "unmodified_half_equals_closed_form": exact_ok}
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_match_stats(wl.ix, d_pat, d_ms, d_rng, d_fb, m)
     return out
 
 

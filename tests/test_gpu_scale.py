@@ -286,10 +286,10 @@ def test_branching_footprint_index_closed_form():
     from gcsa2_amd.binding import GCSA
     dev = torch.device("cuda", 0)
     degree = 28
-    ix, sym_t, rank, alt_t = mseq_torch.build_mseq_snp(degree, device=dev)
+    ix, sym_t, rank, alt_t = mseq_torch.build_mseq_snp(degree, device=dev, with_lcp=True)
     rank_t = torch.from_numpy(rank.view(np.int32)).to(dev)
     assert 1.06 * ix.n < ix.e < 1.10 * ix.n
-    gpu = GCSA(ix, device=0, with_samples=False, with_counters=False, with_lcp=False)
+    gpu = GCSA(ix, device=0, with_samples=False, with_counters=False, with_lcp=True)
     assert gpu.pair_block_bytes() > 0
     st = torch.cuda.current_stream().cuda_stream
     for m, nq in ((32, 4_000_000), (100, 1_000_000), (degree // 2, 2_000_000)):
@@ -308,3 +308,30 @@ def test_branching_footprint_index_closed_form():
         gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), d_stats.data_ptr(), st)
         torch.cuda.synchronize()
         assert torch.equal(d_out[:, 0], exp)
+    # matching statistics (LF + parent) on the branching index: 256-bp walks, every second one with a substitution every
+    # 41 bp.  Unmodified walks: closed form (full-depth match, no parent() call); the first 3000 patterns: the CPU oracle.
+    from oracle.oracle import OracleIndex
+    nq, m = 200_000, 256
+    pats, exp = mseq_torch.walk_patterns_device(sym_t, alt_t, rank_t, 0, nq, m, 0x6C5A0051)
+    nxt = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"CGTA"):
+        nxt[a] = b
+    for col in range(37, m, 41):
+        pats[1::2, col] = nxt[pats[1::2, col].to(torch.int64)]
+    d_pat = torch.zeros(nq * m + 8, dtype=torch.uint8, device=dev)
+    d_pat[: nq * m] = pats.reshape(-1)
+    d_off = torch.arange(nq + 1, dtype=torch.int64, device=dev) * m
+    d_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev)
+    d_rng = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    d_fb = torch.zeros(nq, dtype=torch.int64, device=dev)
+    gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), st)
+    torch.cuda.synchronize()
+    want_ms = (m - torch.arange(m, device=dev)).to(torch.int16).view(1, m)
+    assert torch.equal(d_rng[0::2, 0], exp[0::2]) and torch.equal(d_rng[0::2, 1], exp[0::2])
+    assert bool((d_fb[0::2] == 0).all()) and bool((d_ms[: nq * m].view(nq, m)[0::2] == want_ms).all())
+    assert float(d_fb[1::2].to(torch.float64).mean().item()) > 5            # the substituted half does take parent()
+    ns = 3000
+    cpu = OracleIndex(ix, with_samples=False, with_counters=False)
+    cm, cr, cf = cpu.match_stats_batch(d_pat[: ns * m].cpu().numpy(), np.arange(ns + 1, dtype=np.uint64) * np.uint64(m), threads=8)
+    assert np.array_equal(d_ms[: ns * m].cpu().numpy().view(np.uint16), cm)
+    assert np.array_equal(d_rng[:ns].cpu().numpy().view(np.uint64), cr) and np.array_equal(d_fb[:ns].cpu().numpy().view(np.uint64), cf)

@@ -193,3 +193,42 @@ def test_mseq_snp_index_against_the_definition():
     walks, exp = mseq_torch.walk_patterns_device(sym_t, alt_t, rank_t, 0, 2000, 20, 0x5A2)
     got = cpu.find_batch(walks.reshape(-1).numpy(), np.arange(2001, dtype=np.uint64) * np.uint64(20))
     assert np.array_equal(got[:, 0], exp.numpy().astype(np.uint64)) and np.array_equal(got[:, 1], got[:, 0])
+
+
+def test_mseq_snp_lcp_against_the_definition():
+    """The LCP array the branching generator attaches (the node set is that of the plain text): equal to the common
+    prefixes of the lexicographically adjacent k-mers, and consistent with the index the way verifyIndex demands
+    (src/algorithms.cpp:146-167): parent(find(X)) is the range of the longest proper prefix of X whose range differs,
+    at that prefix's length -- on short patterns, whose ranges are wide, and across SNP bubbles."""
+    import torch
+    from workload import mseq_torch
+    from workload.rng import SplitMix64
+    from oracle.oracle import OracleIndex
+    degree, k = 12, 6
+    ix, sym_t, rank, alt_t = mseq_torch.build_mseq_snp(degree, period=40, device=torch.device("cpu"), with_lcp=True, branching=4)
+    N = ix.n
+    keys = [tuple((v >> (2 * (k - 1 - j))) & 3 for j in range(k)) for v in range(1, N + 1)]
+    assert keys == sorted(keys)
+    want = [0] + [next(j for j in range(k) if keys[i - 1][j] != keys[i][j]) for i in range(1, N)]
+    assert [int(x) for x in ix.lcp_data[:N]] == want and ix.lcp_size == N
+    cpu = OracleIndex(ix, with_samples=False, with_counters=False, with_lcp=True)
+    rng = SplitMix64(0x5A3)
+    sym, alt = sym_t.numpy(), alt_t.numpy()
+    checked = 0
+    for _ in range(600):
+        p, m = rng.below(N), 1 + rng.below(k)
+        w = [int(alt[(p + j) % N]) if alt[(p + j) % N] != 255 and rng.below(2) else int(sym[(p + j) % N]) for j in range(m)]
+        pat = bytes(b"ACGT"[c] for c in w)
+        rng_x = cpu.find(pat)
+        if rng_x[0] > rng_x[1] or rng_x == (0, N - 1):
+            continue
+        end = m
+        shorter = rng_x
+        while shorter == rng_x:
+            end -= 1
+            shorter = cpu.find(pat[:end])
+        parent = cpu.parent(rng_x)
+        assert (parent[0], parent[1]) == shorter and parent[4] == end, (pat, rng_x, parent, shorter, end)
+        assert cpu.depth(shorter) == end or shorter == (0, N - 1)
+        checked += 1
+    assert checked > 400

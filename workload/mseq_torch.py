@@ -109,19 +109,7 @@ def build_mseq(degree: int, device=None, verbose=None, full: bool = False, branc
         lib.gcsa_pack_ints(stored.ctypes.data, S, width, packed.ctypes.data)
         sampled = torch.zeros(N, dtype=torch.bool, device=device)
         sampled[torch.from_numpy(srank).to(device)] = True
-        # LCP bytes in closed form
-        lcp = torch.empty(N, dtype=torch.uint8, device=device)
-        for b in range(0, N, chunk):
-            e = min(N, b + chunk)
-            j = torch.arange(b, e, dtype=torch.int64, device=device)
-            q = torch.zeros(e - b, dtype=torch.int64, device=device)
-            run = torch.ones(e - b, dtype=torch.bool, device=device)
-            for m in range(k):
-                run &= ((j >> (2 * m)) & 3) == 3
-                q += run.to(torch.int64)
-            lcp[b:e] = (k - 1 - q).clamp(min=0).to(torch.uint8)
-        lcp[0] = 0
-        lcp_data, lcp_offsets = build_lcp_tree(lcp.cpu().numpy(), branching)
+        lcp_data, lcp_offsets = mseq_lcp(degree, device, branching)
         extras = dict(sampled_paths=pack_bits_torch(sampled), sample_count=S, sample_width=width,
                       stored_samples=packed, stored_samples_plain=stored,
                       samples=pack_bits_torch(torch.ones(S, dtype=torch.bool, device=device)),
@@ -129,12 +117,33 @@ def build_mseq(degree: int, device=None, verbose=None, full: bool = False, branc
                       redundant_len=N - 1, redundant=pack_bits_torch(torch.ones(N - 1, dtype=torch.bool, device=device)),
                       lcp_size=N, lcp_branching=branching, lcp_offsets=lcp_offsets,
                       lcp_data=np.ascontiguousarray(lcp_data))
-        del sampled, lcp
+        del sampled
         if verbose:
             verbose(f"samples ({S}), counters and LCP derived in closed form")
     ix = IndexArrays(n=N, e=N, order=degree // 2, sigma=SIGMA, fast_chars=FAST_CHARS, char2comp=default_char2comp(),
                      C=Carr, bwt=bwt, edges=edges, table=None, **extras)
     return ix, sym_t, rank
+
+
+def mseq_lcp(degree: int, device, branching: int = 64):
+    """(LCP bytes + range-minimum tree, level offsets) of the path nodes = all k-mers but A^k in lexicographic order:
+    adjacent nodes j - 1, j hold the k-mer values j, j + 1, whose common prefix is k - 1 - (number of trailing base-4
+    digits of j equal to 3).  Depends on the node set only, so the branching variant (same nodes, more edges) shares it."""
+    k = degree // 2
+    N = (1 << degree) - 1
+    chunk = 1 << 27
+    lcp = torch.empty(N, dtype=torch.uint8, device=device)
+    for b in range(0, N, chunk):
+        e = min(N, b + chunk)
+        j = torch.arange(b, e, dtype=torch.int64, device=device)
+        q = torch.zeros(e - b, dtype=torch.int64, device=device)
+        run = torch.ones(e - b, dtype=torch.bool, device=device)
+        for m in range(k):
+            run &= ((j >> (2 * m)) & 3) == 3
+            q += run.to(torch.int64)
+        lcp[b:e] = (k - 1 - q).clamp(min=0).to(torch.uint8)
+    lcp[0] = 0
+    return build_lcp_tree(lcp.cpu().numpy(), branching)
 
 
 def cycle_graph(degree: int):
@@ -219,9 +228,10 @@ def snp_sites(N: int, k: int, period: int, device):
     return pos, shift.to(torch.uint8)
 
 
-def build_mseq_snp(degree: int, period: int = 50, device=None, verbose=None):
-    """Returns (IndexArrays [find() only: no samples / counters / LCP], sym tensor, rank numpy uint32,
-    alt tensor uint8[N]: the alternative symbol at a SNP site, 255 elsewhere)."""
+def build_mseq_snp(degree: int, period: int = 50, device=None, verbose=None, with_lcp: bool = False, branching: int = 64):
+    """Returns (IndexArrays [no samples / counters; the LCP array with with_lcp -- the path nodes are those of the plain
+    text, so it is mseq_lcp()], sym tensor, rank numpy uint32, alt tensor uint8[N]: the alternative symbol at a SNP
+    site, 255 elsewhere)."""
     if device is None:
         device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
     sym, rank = mseq_text(degree)
@@ -312,8 +322,13 @@ def build_mseq_snp(degree: int, period: int = 50, device=None, verbose=None):
                   stored_samples=np.zeros(2, dtype=np.uint64), stored_samples_plain=np.zeros(0, dtype=np.uint64),
                   samples=np.zeros(2, dtype=np.uint64), extra_filter=zero, extra_values_len=0,
                   extra_values=np.zeros(2, dtype=np.uint64), redundant_len=0, redundant=np.zeros(2, dtype=np.uint64),
-                  lcp_size=0, lcp_branching=64, lcp_offsets=np.zeros(2, dtype=np.uint64),
+                  lcp_size=0, lcp_branching=branching, lcp_offsets=np.zeros(2, dtype=np.uint64),
                   lcp_data=np.zeros(1, dtype=np.uint8))
+    if with_lcp:
+        lcp_data, lcp_offsets = mseq_lcp(degree, device, branching)
+        extras.update(lcp_size=N, lcp_offsets=lcp_offsets, lcp_data=np.ascontiguousarray(lcp_data))
+        if verbose:
+            verbose("LCP array of the node set in closed form")
     ix = IndexArrays(n=N, e=e_total, order=k, sigma=SIGMA, fast_chars=FAST_CHARS, char2comp=default_char2comp(),
                      C=Carr, bwt=bwt, edges=edges, table=None, **extras)
     return ix, sym_t, rank, alt_t
