@@ -535,7 +535,7 @@ def pmc_traffic(args, key, gpu, nq, m):
 
 def working_set(gpu, ix):
     k = gpu.kmer_table_k()
-    blocks = gpu.pair_block_bytes() or int(ix.sigma) * (int(ix.n) // 448 + 1) * 128
+    blocks = gpu.pair_block_bytes() or int(ix.sigma) * (int(ix.n) // 384 + 1) * 128
     return int(blocks + ((8 << (2 * k)) if k else 0))
 
 
@@ -568,7 +568,7 @@ def find_config(wl, r, world):
     gpu = wl.gpu
     return {"workload": wl.label, "path_nodes": int(wl.ix.n), "edges": int(wl.ix.e), "queries_total": wl.total_queries,
             "queries_per_gpu": wl.nq, "pattern_len": wl.m, "index_bytes_hbm": gpu.device_bytes(),
-            "pair_block_bytes": gpu.pair_block_bytes(), "single_block_bytes": int(wl.ix.sigma) * (int(wl.ix.n) // 448 + 1) * 128,
+            "pair_block_bytes": gpu.pair_block_bytes(), "single_block_bytes": int(wl.ix.sigma) * (int(wl.ix.n) // 384 + 1) * 128,
             "kmer_table_k": gpu.kmer_table_k(), "found": r["found"], "lf_steps_per_query": r["lf_steps"] / wl.nq,
             "blocks_per_query": r["blocks"] / wl.nq, "block_bytes": gpu.find_block_bytes(),
             "parallelism": f"replicated index, contiguous query shards x{world}, one gather of ranges per step: {r['gather']}"

@@ -218,31 +218,42 @@ u64 stage_flb(Stager& st, const gcsa2_host_view* v, DevImage& img, const std::ve
     img.crange[2 * c + 1] = erank(v->C[c + 1] - 1);
   }
 
-  const u64 nblocks = n / BLOCK_BITS + 1;
+  const u64 nblocks = n / FLB_BITS + 1;
   img.flb_nblocks = nblocks;
   u64 off = st.reserve(sigma * nblocks * FLB_WORDS, FLB_WORDS);
   u64* words = st.words.data();
+  const u64 rb_blocks = n / BLOCK_BITS + 1;      // RB64 blocks of every B_c staged just before: payload words and cumulative counts
   for(u64 c = 0; c < sigma; c++)
   {
-    // the RB64 copy of B_c staged just before holds payload words and cumulative counts already
     const u64* rb = words + bwt_blocks_off[c];
     u64* dst_base = words + off + c * nblocks * FLB_WORDS;
     const u64 Cc = v->C[c];
     parallel_ranges(nblocks, [=, &ew](u64 b0, u64 b1)
     {
+      auto payload = [&](u64 w) -> u64          // plain word w of B_c (zero past the vector)
+      {
+        const u64 blk = w / PAYLOAD_WORDS;
+        return blk < rb_blocks ? rb[blk * BLOCK_WORDS + 1 + w % PAYLOAD_WORDS] : 0;
+      };
       for(u64 b = b0; b < b1; b++)
       {
-        const u64* src = rb + b * BLOCK_WORDS;
         u64* dst = dst_base + b * FLB_WORDS;
-        u64 ecnt = Cc + src[0];
-        u64 prev = (ecnt > 0 && ecnt - 1 < e) ? ((ew[(ecnt - 1) >> 6] >> ((ecnt - 1) & 63)) & 1) : 0;
+        const u64 w0 = b * FLB_PAYLOAD, rblk = w0 / PAYLOAD_WORDS;          // rank(B_c, 384 b): the RB64 count + the words before w0
+        u64 rank = rb[rblk * BLOCK_WORDS];                                  // 384 b <= n, so rblk < rb_blocks
+        for(u64 w = rblk * PAYLOAD_WORDS; w < w0; w++) { rank += u64(__builtin_popcountll(payload(w))); }
+        const u64 ecnt = Cc + rank;
+        const u64 prev = (ecnt > 0 && ecnt - 1 < e) ? ((ew[(ecnt - 1) >> 6] >> ((ecnt - 1) & 63)) & 1) : 0;
         dst[0] = ecnt;
         dst[1] = erank(ecnt) | (prev << 63);
-        for(u64 j = 0; j < PAYLOAD_WORDS; j++)
+        u64 cum_b = 0, cum_e = 0, run_b = 0, run_e = 0;
+        for(u64 j = 0; j < FLB_PAYLOAD; j++)
         {
-          dst[2 + j] = src[1 + j];
-          dst[9 + j] = ebits(ecnt + 64 * j);
+          dst[2 + j] = payload(w0 + j);
+          dst[8 + j] = ebits(ecnt + 64 * j);
+          run_b += u64(__builtin_popcountll(dst[2 + j])); run_e += u64(__builtin_popcountll(dst[8 + j]));
+          cum_b |= run_b << (10 * j); cum_e |= run_e << (10 * j);
         }
+        dst[14] = cum_b; dst[15] = cum_e;
       }
     });
   }
@@ -534,7 +545,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       img.lcp_size = v->lcp_size; img.lcp_branching = v->lcp_branching; img.lcp_levels = v->lcp_levels;
       for(u64 l = 0; l <= v->lcp_levels; l++) { img.lcp_offsets[l] = v->lcp_offsets[l]; }
       img.lcp_values = v->lcp_offsets[v->lcp_levels];
-      lcp_off = st.reserve((img.lcp_values + 7) / 8 + 1);
+      lcp_off = st.reserve((img.lcp_values + 7) / 8 + 2);   // 16-byte chunk reads of the last values stay inside (parent_from_chunks)
       std::memcpy(st.words.data() + lcp_off, v->lcp_data, img.lcp_values);
     }
 

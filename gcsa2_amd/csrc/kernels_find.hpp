@@ -124,35 +124,31 @@ struct Tables2
 
 struct Endpoint { u64 edge; u64 node; u32 ones; };
 
-// lane-private evaluation of one LF endpoint from a staged fused block
-//   blk = 8 x ulonglong2 (w0..w15), r = bit offset inside the block
+// A word of the staged block as an opaque register value: selecting among such values compiles to v_cndmask.  Without
+// it LLVM folds a select of array elements into a dynamically indexed load, and the block array moves to scratch memory
+// (measured: find() 2.1x slower).
+__device__ __forceinline__ u64 in_register(u64 x) { asm volatile("" : "+v"(x)); return x; }
+
+// lane-private evaluation of one LF endpoint from a staged fused block (FLB128, layout.hpp)
+//   blk = 8 x ulonglong2 (w0..w15), r = bit offset inside the block (< 384)
 //   edge = C[c] + rank(B_c, i);  node = rank(edges, edge - back) with back = 0 (sp) or 1 (ep)
 __device__ __forceinline__ void eval_endpoint(const ulonglong2 (&blk)[8], u32 r, u32 back, u64& edge, u64& node)
 {
-  const u64 w[16] = { blk[0].x, blk[0].y, blk[1].x, blk[1].y, blk[2].x, blk[2].y, blk[3].x, blk[3].y,
-                      blk[4].x, blk[4].y, blk[5].x, blk[5].y, blk[6].x, blk[6].y, blk[7].x, blk[7].y };
-  u32 wq = r >> 6;
-  u64 part = (u64(1) << (r & 63)) - 1;
-  u32 ones = 0;
-#pragma unroll
-  for(u32 j = 0; j < 7; j++)
-  {
-    u64 m = (j < wq ? ~u64(0) : (j == wq ? part : u64(0)));
-    ones += __popcll(w[2 + j] & m);
-  }
-  edge = w[0] + ones;
-  u64 ncnt = w[1] & ~PREV_BIT;
-  if(back > ones) { node = ncnt - (w[1] >> 63); return; }    // rank(edges, ecnt - 1)
-  u32 k = ones - back, kq = k >> 6;
-  u64 kpart = (u64(1) << (k & 63)) - 1;
-  u32 cnt = 0;
-#pragma unroll
-  for(u32 j = 0; j < 7; j++)
-  {
-    u64 m = (j < kq ? ~u64(0) : (j == kq ? kpart : u64(0)));
-    cnt += __popcll(w[9 + j] & m);
-  }
-  node = ncnt + cnt;
+  const u32 wq = r >> 6;                                                                   // 0..5
+  const u64 part = (u64(1) << (r & 63)) - 1;
+  const u64 b0 = in_register(blk[1].x), b1 = in_register(blk[1].y), b2 = in_register(blk[2].x),
+            b3 = in_register(blk[2].y), b4 = in_register(blk[3].x), b5 = in_register(blk[3].y);           // w2..w7
+  const u64 bword = (wq < 3 ? (wq == 0 ? b0 : (wq == 1 ? b1 : b2)) : (wq == 3 ? b3 : (wq == 4 ? b4 : b5)));
+  const u32 ones = (wq == 0 ? 0u : u32(blk[7].x >> (10 * (wq - 1))) & 0x3FF) + u32(__popcll(bword & part));
+  edge = blk[0].x + ones;
+  const u64 ncnt = blk[0].y & ~PREV_BIT;
+  if(back > ones) { node = ncnt - (blk[0].y >> 63); return; }                              // rank(edges, ecnt - 1)
+  const u32 k = ones - back, kq = k >> 6;                                                  // 0..6 (6: the whole slice)
+  const u64 kpart = (u64(1) << (k & 63)) - 1;
+  const u64 e0 = in_register(blk[4].x), e1 = in_register(blk[4].y), e2 = in_register(blk[5].x),
+            e3 = in_register(blk[5].y), e4 = in_register(blk[6].x), e5 = in_register(blk[6].y);           // w8..w13
+  const u64 eword = (kq < 3 ? (kq == 0 ? e0 : (kq == 1 ? e1 : e2)) : (kq == 3 ? e3 : (kq == 4 ? e4 : (kq == 5 ? e5 : u64(0)))));
+  node = ncnt + (kq == 0 ? 0u : u32(blk[7].y >> (10 * (kq - 1))) & 0x3FF) + u32(__popcll(eword & kpart));
 }
 
 // lane-private evaluation of one endpoint of a TWO-character step from a staged FLP128 block (layout.hpp):
@@ -223,21 +219,21 @@ __device__ __forceinline__ void lf_fused_lane(const DevImage& img, u32 comp, u64
                                               u64& a, u64& b, u64& nsp, u64& nep)
 {
   const u64 e1 = ep + 1;
-  const u64 b_sp = sp / BLOCK_BITS, b_ep = e1 / BLOCK_BITS;
+  const u64 b_sp = sp / FLB_BITS, b_ep = e1 / FLB_BITS;
   const u64* base = img.flb + u64(comp) * img.flb_nblocks * FLB_WORDS;
   ulonglong2 blk[8];
   const ulonglong2* src = reinterpret_cast<const ulonglong2*>(base + b_sp * FLB_WORDS);
 #pragma unroll
   for(u32 k = 0; k < 8; k++) { blk[k] = src[k]; }
   u64 e_ep, n_ep;
-  eval_endpoint(blk, u32(sp - b_sp * BLOCK_BITS), 0, a, nsp);
+  eval_endpoint(blk, u32(sp - b_sp * FLB_BITS), 0, a, nsp);
   if(b_ep != b_sp)
   {
     src = reinterpret_cast<const ulonglong2*>(base + b_ep * FLB_WORDS);
 #pragma unroll
     for(u32 k = 0; k < 8; k++) { blk[k] = src[k]; }
   }
-  eval_endpoint(blk, u32(e1 - b_ep * BLOCK_BITS), 1, e_ep, n_ep);
+  eval_endpoint(blk, u32(e1 - b_ep * FLB_BITS), 1, e_ep, n_ep);
   b = e_ep - 1; nep = n_ep;
 }
 
@@ -252,7 +248,7 @@ __device__ __forceinline__ void lf_children(const DevImage& img, u32 c0, u32 lim
 {
   const bool nonempty = live && !range_empty(sp0, ep0);
   const u64 sp = nonempty ? sp0 : 0, e1 = nonempty ? ep0 + 1 : 0;
-  const u64 b_sp = sp / BLOCK_BITS, b_ep = e1 / BLOCK_BITS;
+  const u64 b_sp = sp / FLB_BITS, b_ep = e1 / FLB_BITS;
   ulonglong2 blk[N][8];
 #pragma unroll
   for(int j = 0; j < N; j++)
@@ -270,14 +266,14 @@ __device__ __forceinline__ void lf_children(const DevImage& img, u32 c0, u32 lim
     csp[j] = 1; cep[j] = 0;
     if(!(nonempty && c <= limit)) { continue; }
     u64 a, nsp, e_ep, n_ep;
-    eval_endpoint(blk[j], u32(sp - b_sp * BLOCK_BITS), 0, a, nsp);
+    eval_endpoint(blk[j], u32(sp - b_sp * FLB_BITS), 0, a, nsp);
     if(b_ep != b_sp)
     {
       const ulonglong2* src = reinterpret_cast<const ulonglong2*>(img.flb + (u64(c) * img.flb_nblocks + b_ep) * FLB_WORDS);
 #pragma unroll
       for(u32 k = 0; k < 8; k++) { blk[j][k] = src[k]; }
     }
-    eval_endpoint(blk[j], u32(e1 - b_ep * BLOCK_BITS), 1, e_ep, n_ep);
+    eval_endpoint(blk[j], u32(e1 - b_ep * FLB_BITS), 1, e_ep, n_ep);
     const u64 b = e_ep - 1;
     if(!range_empty(a, b)) { csp[j] = nsp; cep[j] = n_ep; }
     else if(sp0 != ep0) { csp[j] = a; cep[j] = b; }
@@ -311,6 +307,48 @@ __device__ __forceinline__ void read_block(const ulonglong2* wave_stage, u32 lan
 {
 #pragma unroll
   for(u32 k = 0; k < 8; k++) { blk[k] = wave_stage[lane * 8 + (k ^ (lane & 7))]; }
+}
+
+// ---- one evaluator for both block kinds, straight from the staged block in LDS ------------------------------------
+// Both layouts keep the rank vector in words 2.. and running popcounts of it and of the edges slice (layout.hpp), so an
+// endpoint is: header, the word that holds the position, one masked popcount, the word of the slice that holds the
+// resulting edge, one masked popcount -- the SAME instructions for a single-character step (FLB128) and a two-character
+// step (FLP128; its Q and D rows are read on top), with the differences in per-lane values.  A wave whose lanes mix the two
+// kinds therefore runs one evaluation per round, not two (profiles/r02_config5.md: the matching statistics are bound by
+// instruction issue once the lanes of a wave diverge).
+__device__ __forceinline__ u64 staged_word(const ulonglong2* wave_stage, u32 lane, u32 w)
+{
+  return reinterpret_cast<const u64*>(wave_stage)[(lane * 8 + ((w >> 1) ^ (lane & 7))) * 2 + (w & 1)];
+}
+
+__device__ __forceinline__ PairEnd eval_staged(const ulonglong2* wave_stage, u32 lane, bool pair, u32 r, bool ep_side)
+{
+  const ulonglong2 head = wave_stage[lane * 8 + (lane & 7)];             // w0, w1
+  const ulonglong2 tail = wave_stage[lane * 8 + (7 ^ (lane & 7))];       // w14, w15
+  const u32 wq = r >> 6, width = (pair ? 8u : 10u), mask = (pair ? 0xFFu : 0x3FFu);
+  const u64 part = (u64(1) << (r & 63)) - 1;
+  const u64 cum_rank = (pair ? tail.y : tail.x), cum_edges = (pair ? tail.y >> 40 : tail.y);
+  const u64 bword = staged_word(wave_stage, lane, 2 + wq);
+  const u32 ones = (wq == 0 ? 0u : u32(cum_rank >> (width * (wq - 1))) & mask) + u32(__popcll(bword & part));
+  PairEnd out;
+  out.raw = head.x + ones; out.bits = 0;
+  u32 back = (ep_side ? 1u : 0u);
+  if(pair)
+  {
+    const u64 dword = staged_word(wave_stage, lane, 5 + wq), qword = staged_word(wave_stage, lane, 8 + wq);
+    const u32 qb = (wq == 0 ? 0u : u32(tail.y >> (16 + 8 * (wq - 1))) & 0xFF) + u32(__popcll(qword & part));
+    const u32 qt = u32(tail.y >> 32) & 0xFF;
+    const u32 dbit = (ep_side ? u32((dword >> (r & 63)) & 1) : 0u);
+    out.bits = qb | ((qt - qb) << 8) | (dbit << 16);
+    back = (ep_side ? 1u - dbit : 0u);
+  }
+  const u64 ncnt = head.y & ~PREV_BIT;
+  if(back > ones) { out.node = ncnt - (head.y >> 63); return out; }      // rank(edges, ecnt - 1)
+  const u32 k = ones - back, kq = k >> 6;          // kq may name the word after the slice, only with k & 63 == 0: an empty mask
+  const u64 kpart = (u64(1) << (k & 63)) - 1;
+  const u64 eword = staged_word(wave_stage, lane, (pair ? 11u : 8u) + kq);
+  out.node = ncnt + (kq == 0 ? 0u : u32(cum_edges >> (width * (kq - 1))) & mask) + u32(__popcll(eword & kpart));
+  return out;
 }
 
 // REFILL = true: persistent waves.  Lanes do not own a fixed query; whenever at least half of a
@@ -531,8 +569,8 @@ __global__ __launch_bounds__(TPB2, (STATS || REFILL || JUMP) ? 4 : GCSA2_FIND_WA
           else { comp = 1 + (u32(win_code >> (2 * r)) & 3); }
         }
         else { comp = t.c2c[byte_at(i)]; }
-        u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
-        r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
+        u64 b_sp = sp / FLB_BITS, b_ep = (ep + 1) / FLB_BITS;
+        r_sp = u32(sp - b_sp * FLB_BITS); r_ep = u32(ep + 1 - b_ep * FLB_BITS);
         idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
       }
     }
@@ -651,7 +689,7 @@ __global__ __launch_bounds__(TPB2, (STATS || REFILL || JUMP) ? 4 : GCSA2_FIND_WA
 // of 192 threads writes block b of the four pairs (c1, c2), c1 = 1..4; thread r owns position i = 192 b + r.
 __global__ __launch_bounds__(192) void k_build_pair_blocks(DevImage img, u64 first, u64* __restrict__ out)
 {
-  __shared__ u64 s_ecnt[4];
+  __shared__ u64 s_ecnt[4], s_p[4][3], s_q[3], s_e[4][4];
   const u64 b = first + blockIdx.x, nb = img.flp_nblocks;
   const u32 c2 = 1 + blockIdx.y, r = threadIdx.x;
   const u64 i = b * PAIR_BITS + r, n = img.n, e = img.e;
@@ -670,14 +708,14 @@ __global__ __launch_bounds__(192) void k_build_pair_blocks(DevImage img, u64 fir
     const bool bc = bv_get_rank(bwt_of(img, c1), clampu(u, n), rc) && u < n;
     const u64 pw = __ballot(valid && q && ebit && bc), dw = __ballot(valid && split && bc);
     u64* dst = out + (u64((c1 - 1) * 4 + (c2 - 1)) * nb + b) * FLB_WORDS;
-    if((r & 63) == 0) { dst[2 + (r >> 6)] = pw; dst[5 + (r >> 6)] = dw; dst[8 + (r >> 6)] = qw; }
+    if((r & 63) == 0) { dst[2 + (r >> 6)] = pw; dst[5 + (r >> 6)] = dw; dst[8 + (r >> 6)] = qw; s_p[c1 - 1][r >> 6] = pw; s_q[r >> 6] = qw; }
     if(r == 0)
     {
       const u64 ecnt = img.C[c1] + rc;                         // H(192 b)
       u64 ncnt = 0;
       (void)bv_get_rank(img.edges, clampu(ecnt, e), ncnt);
       const u64 prev = (ecnt >= 1 && ecnt - 1 < e && bv_get(img.edges, ecnt - 1)) ? PREV_BIT : 0;
-      dst[0] = ecnt; dst[1] = ncnt | prev; dst[15] = 0;
+      dst[0] = ecnt; dst[1] = ncnt | prev;
       s_ecnt[c1 - 1] = ecnt;
     }
   }
@@ -686,7 +724,17 @@ __global__ __launch_bounds__(192) void k_build_pair_blocks(DevImage img, u64 fir
   {
     const u32 c1 = 1 + r / 4, k = r % 4;
     u64* dst = out + (u64((c1 - 1) * 4 + (c2 - 1)) * nb + b) * FLB_WORDS;
-    dst[11 + k] = bv_bits64(img.edges, s_ecnt[c1 - 1] + 64 * k);
+    const u64 slice = bv_bits64(img.edges, s_ecnt[c1 - 1] + 64 * k);
+    dst[11 + k] = slice; s_e[c1 - 1][k] = slice;
+  }
+  __syncthreads();
+  if(r < 4)                                                    // word 15: running popcounts, one byte each (layout.hpp)
+  {
+    u64* dst = out + (u64(r * 4 + (c2 - 1)) * nb + b) * FLB_WORDS;
+    const u64 p0 = __popcll(s_p[r][0]), p1 = p0 + __popcll(s_p[r][1]);
+    const u64 q0 = __popcll(s_q[0]), q1 = q0 + __popcll(s_q[1]), q2 = q1 + __popcll(s_q[2]);
+    const u64 e0 = __popcll(s_e[r][0]), e1 = e0 + __popcll(s_e[r][1]), e2 = e1 + __popcll(s_e[r][2]);
+    dst[15] = p0 | (p1 << 8) | (q0 << 16) | (q1 << 24) | (q2 << 32) | (e0 << 40) | (e1 << 48) | (e2 << 56);
   }
 }
 
@@ -720,8 +768,8 @@ __global__ __launch_bounds__(TPB2) void k_lf2(DevImage img, const u64* __restric
     if(comp >= img.sigma) { comp = u32(img.sigma - 1); }     // memory safety only
     sp = clampu(r.x, img.n);
     u64 e1 = clampu(r.y + 1, img.n);
-    u64 b_sp = sp / BLOCK_BITS, b_ep = e1 / BLOCK_BITS;
-    r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(e1 - b_ep * BLOCK_BITS);
+    u64 b_sp = sp / FLB_BITS, b_ep = e1 / FLB_BITS;
+    r_sp = u32(sp - b_sp * FLB_BITS); r_ep = u32(e1 - b_ep * FLB_BITS);
     idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
   }
   ulonglong2 blk[8];

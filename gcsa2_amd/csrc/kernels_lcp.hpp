@@ -396,6 +396,42 @@ __global__ __launch_bounds__(TPB) void k_match_stats(DevImage img, const u8* __r
   if(fallbacks != nullptr) { fallbacks[q] = calls; }
 }
 
+// parent() of (sp, ep) from the two aligned 16-byte chunks of the LCP array that hold LCP[sp] and LCP[ep + 1]
+// (lcp_parent's first loads, widened): node_lcp = max of the two values; the previous / next smaller value on the
+// side(s) that attain it is the nearest smaller byte of the flat array, which is what the tree walks of lcp_psv /
+// lcp_nsv return, so whenever it lies inside the chunk the answer is complete -- one round trip and a few dozen
+// instructions instead of three dependent ones and two tree walks.  false: not decidable from the chunks (a bound
+// at the chunk's edge, a wider interval, the array's ends) -- the caller runs lcp_parent.
+__device__ __forceinline__ bool parent_from_chunks(const DevImage& img, u64 sp, u64 ep, gcsa2_stnode& out)
+{
+  if(ep + 2 >= img.lcp_size || sp == 0) { return false; }
+  const ulonglong2* chunks = reinterpret_cast<const ulonglong2*>(img.lcp);
+  const ulonglong2 left = chunks[sp >> 4], right = chunks[(ep + 1) >> 4];
+  const u32 lo = u32(sp & 15), ro = u32((ep + 1) & 15);
+  const u64 left_lcp = ((lo < 8 ? left.x : left.y) >> (8 * (lo & 7))) & 0xFF;
+  const u64 right_lcp = ((ro < 8 ? right.x : right.y) >> (8 * (ro & 7))) & 0xFF;
+  const u64 node_lcp = (left_lcp > right_lcp ? left_lcp : right_lcp);
+  u64 lpos = sp, lval = left_lcp, rpos = ep + 1, rval = right_lcp;
+  if(left_lcp == node_lcp)
+  {
+    const u32 mask = (bytes_below(left.x, left_lcp) | (bytes_below(left.y, left_lcp) << 8)) & ((1u << lo) - 1);
+    if(mask == 0) { return false; }
+    const u32 byte = 31 - __clz(int(mask));
+    lpos = (sp & ~u64(15)) + byte; lval = ((byte < 8 ? left.x : left.y) >> (8 * (byte & 7))) & 0xFF;
+  }
+  if(right_lcp == node_lcp)
+  {
+    const u64 base = (ep + 1) & ~u64(15);
+    u32 mask = (bytes_below(right.x, right_lcp) | (bytes_below(right.y, right_lcp) << 8)) & ~((2u << ro) - 1) & 0xFFFF;
+    if(base + 16 > img.lcp_size) { mask &= (1u << (img.lcp_size - base)) - 1; }      // bytes past the array belong to the tree
+    if(mask == 0) { return false; }
+    const u32 byte = u32(__ffs(int(mask))) - 1;
+    rpos = base + byte; rval = ((byte < 8 ? right.x : right.y) >> (8 * (byte & 7))) & 0xFF;
+  }
+  out = gcsa2_stnode{lpos, rpos - 1, lval, rval, node_lcp};
+  return true;
+}
+
 // ---- matching statistics, version 2: wave-cooperative block fetch, two characters per step, batched parent() ----
 // Same results as k_match_stats.  One lane = one pattern; the LF steps of the 64 patterns of a wave go through the
 // cooperative fetch of k_find2 (one 128-byte request per endpoint, FLP128 pair blocks when the next two
@@ -546,41 +582,26 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
           comp = c2c[u32(*reinterpret_cast<const u64*>(addr & ~u64(7)) >> ((addr & 7) * 8)) & 0xFF];
         }
         else { comp = 1 + (u32(win_code >> (2 * r)) & 3); }
-        const u64 b_sp = sp / BLOCK_BITS, b_ep = (ep + 1) / BLOCK_BITS;
-        r_sp = u32(sp - b_sp * BLOCK_BITS); r_ep = u32(ep + 1 - b_ep * BLOCK_BITS);
+        const u64 b_sp = sp / FLB_BITS, b_ep = (ep + 1) / FLB_BITS;
+        r_sp = u32(sp - b_sp * FLB_BITS); r_ep = u32(ep + 1 - b_ep * FLB_BITS);
         idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
       }
     }
     PairEnd p_sp = {0, 0, 0}, p_ep = {0, 0, 0};                // a single step keeps (edge, node) in .raw / .node
     const bool need2 = stepping && idx_ep != idx_sp;
-    ulonglong2 blk[8];
     if(__any(stepping))
     {
       fetch_blocks<PAIR>(img.flb, idx_sp, stepping, wave_stage, lane, img.flp);
-      if(stepping)
+      if(stepping)                               // one evaluation for single and pair steps alike (eval_staged)
       {
-        read_block(wave_stage, lane, blk);
-        if(PAIR && pair)
-        {
-          p_sp = eval_pair(blk, r_sp, false);
-          if(idx_ep == idx_sp) { p_ep = eval_pair(blk, r_ep, true); }
-        }
-        else
-        {
-          eval_endpoint(blk, r_sp, 0, p_sp.raw, p_sp.node);
-          if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, p_ep.raw, p_ep.node); }
-        }
+        p_sp = eval_staged(wave_stage, lane, PAIR && pair, r_sp, false);
+        if(idx_ep == idx_sp) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
       }
       if(__any(need2))
       {
         __builtin_amdgcn_wave_barrier();
         fetch_blocks<PAIR>(img.flb, idx_ep, need2, wave_stage, lane, img.flp);
-        if(need2)
-        {
-          read_block(wave_stage, lane, blk);
-          if(PAIR && pair) { p_ep = eval_pair(blk, r_ep, true); }
-          else { eval_endpoint(blk, r_ep, 1, p_ep.raw, p_ep.node); }
-        }
+        if(need2) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -622,7 +643,8 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       if(need_parent)
       {
         gcsa2_stnode node;
-        lcp_parent(img, sp, ep, node); calls++;
+        if(!parent_from_chunks(img, sp, ep, node)) { lcp_parent(img, sp, ep, node); }
+        calls++;
         sp = node.sp; ep = node.ep; depth = node.node_lcp;
         need_parent = false;
       }

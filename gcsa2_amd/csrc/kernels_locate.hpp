@@ -139,8 +139,8 @@ __device__ __forceinline__ void walk_to_sample(const DevImage& img, u64& node, u
       if(nib & 8) { walking = false; }                       // sampled(node), gcsa.cpp:883
       else
       {
-        u64 b = node / BLOCK_BITS;
-        r = u32(node - b * BLOCK_BITS);
+        u64 b = node / FLB_BITS;
+        r = u32(node - b * FLB_BITS);
         idx = u32(u64(nib & 7) * img.flb_nblocks + b);
       }
     }

@@ -18,10 +18,14 @@
 // For find() / LF(range) every B_c is ALSO stored in a fused 128-byte form, "FLB128":
 //
 //   block b of comp c (16 x u64 = 128 bytes, 128-byte aligned)
-//     word 0       ecnt = C[c] + rank(B_c, 448 b)                  edge-space position of the block
+//     word 0       ecnt = C[c] + rank(B_c, 384 b)                  edge-space position of the block
 //     word 1       ncnt = rank(edges, ecnt), bit 63 = edges[ecnt - 1]
-//     words 2..8   B_c payload bits [448 b, 448 (b + 1))
-//     words 9..15  edges bits [ecnt, ecnt + 448)                   the slice those ones map into
+//     words 2..7   B_c payload bits [384 b, 384 (b + 1))
+//     words 8..13  edges bits [ecnt, ecnt + 384)                   the slice those ones map into
+//     word 14      running popcounts of words 2..7, 10 bits each: w2, w2 + w3, ... (six fields, low to high)
+//     word 15      the same for words 8..13
+//   (the running popcounts make a rank inside the block ONE masked popcount, of the word that holds the position,
+//   instead of one per payload word: round 2 found the matching-statistics kernel bound by instruction issue)
 //
 // so one LF endpoint, C[c] + rank(B_c, i) followed by rank(edges, .) (gcsa.h:262-274, 253-258), is
 // ONE 128-byte fetch instead of two dependent 64-byte fetches: beyond L2 the memory system is
@@ -46,7 +50,7 @@
 //     words 5..7    D bits of the same positions
 //     words 8..10   Q bits of the same positions: Q = B_c2 (is the FIRST of the two steps non-empty?)
 //     words 11..14  edges bits [ecnt, ecnt + 256)
-//     word 15       unused
+//     word 15       running popcounts, one byte each: P0, P0+P1 | Q0, Q0+Q1, Q0+Q1+Q2 | E0, E0+E1, E0+E1+E2 (low to high)
 //
 // so TWO pattern characters cost ONE 128-byte request per endpoint.  What the block decides, exactly:
 //   H(ep + 1) > H(sp)                      both steps are non-empty: the range is (N(H(sp)), N(H(ep + 1) - 1 + D))
@@ -78,6 +82,8 @@ constexpr u64 BLOCK_BITS    = 448;
 constexpr u64 BLOCK_BYTES   = 64;
 constexpr u64 SELECT_SAMPLE = 448;
 constexpr u64 FLB_WORDS     = 16;
+constexpr u64 FLB_BITS      = 384;           // positions per FLB128 block (six payload words)
+constexpr u64 FLB_PAYLOAD   = 6;
 constexpr u64 FLB_BYTES     = 128;
 constexpr u64 PREV_BIT      = u64(1) << 63;
 constexpr u64 PAIR_BITS     = 192;           // positions per FLP128 block (three payload rows of three words)

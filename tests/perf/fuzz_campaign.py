@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential campaign on mid-size random graphs (bubbles, indels, cycles, Ns, small alphabets): thousands of path nodes,
-so that ranges straddle the 192-position pair blocks and the 448-position single blocks, steps empty in either character of a
+so that ranges straddle the 192-position pair blocks and the 384-position single blocks, steps empty in either character of a
 pair, and locate() meets every segment-size class.  Every query kind of the engine against the CPU oracle.
 
     python tests/perf/fuzz_campaign.py [--seeds 40] [--first 0]

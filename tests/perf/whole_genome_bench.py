@@ -73,7 +73,7 @@ def main():
     blocks, steps, lookups, jumps = (int(x) for x in d_stats.cpu())
     algo = blocks * gpu.find_block_bytes() + lookups * 8 + jumps * 16 + nq * (m + 16)
     res = {"workload": f"degree-{args.degree} m-sequence cyclic text: {ix.n} path nodes, {nq} x {m}-mer find(), substrings of the text",
-           "device_image_GB": gpu.device_bytes() / 1e9, "find_bytes_GB": ix.sigma * (ix.n // 448 + 1) * 128 / 1e9,
+           "device_image_GB": gpu.device_bytes() / 1e9, "find_bytes_GB": ix.sigma * (ix.n // 384 + 1) * 128 / 1e9,
            "kernel_ms": ms, "queries_per_s": nq / (ms * 1e-3), "blocks_per_query": blocks / nq, "lf_steps_per_query": steps / nq,
            "algorithmic_GBps": algo / (ms * 1e-3) / 1e9, "frac_of_8TBps": algo / (ms * 1e-3) / 8e12,
            "all_results_equal_closed_form": exact}
