@@ -232,3 +232,253 @@ def test_mseq_snp_lcp_against_the_definition():
         assert cpu.depth(shorter) == end or shorter == (0, N - 1)
         checked += 1
     assert checked > 400
+
+
+# ---- indexes beyond 2^32 path nodes: workload/dbg_torch.py at small degrees --------------------------------------
+
+@pytest.mark.parametrize("degree", [8, 10, 12, 16])
+def test_dbg_plain_equals_general_builder(degree):
+    """The non-maximal LFSR cycle (a third of the k-mers present, ranks through the universe bitmap): the plain index
+    with its closed-form samples, counters and LCP array is exactly what the general builder produces for the cycle
+    graph of the same text."""
+    import torch
+    from workload import dbg_torch
+    a = builder.build(dbg_torch.cycle_graph(degree), degree // 2)
+    b, wl = dbg_torch.build_dbg(degree, device=torch.device("cpu"), full=True, chunk_bits=10)
+    assert b.n == dbg_torch.text_length(degree) == ((1 << degree) - 1) // 3
+    assert (a.n, a.e, a.order, a.sample_count, a.sample_width) == (b.n, b.e, b.order, b.sample_count, b.sample_width)
+    assert np.array_equal(a.C, b.C)
+    w = (a.n + 63) // 64
+    for c in range(a.sigma):
+        assert np.array_equal(a.bwt[c][:w], b.bwt[c][:w]), c
+    assert np.array_equal(a.edges[:w], b.edges[:w])
+    assert np.array_equal(a.sampled_paths[:w], b.sampled_paths[:w])
+    assert np.array_equal(a.stored_samples_plain, b.stored_samples_plain)
+    assert np.array_equal(a.lcp_data, b.lcp_data) and np.array_equal(a.lcp_offsets, b.lcp_offsets)
+    assert a.extra_values_len == b.extra_values_len == 0 and a.redundant_len == b.redundant_len
+    assert np.array_equal(a.redundant[: (a.redundant_len + 63) // 64], b.redundant[: (b.redundant_len + 63) // 64])
+    # the closed form the full-size tests rely on: find() of a substring = the bitmap rank of its first k-mer
+    pats, start, exp = dbg_torch.walk_patterns_device(wl, 0, 300, degree // 2 + 5, 0xD1)
+    sym = wl.sym_t.numpy().astype(np.int64)
+    k = degree // 2
+    values = sorted(sum(int(sym[(p + j) % b.n]) << (2 * (k - 1 - j)) for j in range(k)) for p in range(b.n))
+    for q in range(300):
+        p = int(start[q])
+        v = sum(int(sym[(p + j) % b.n]) << (2 * (k - 1 - j)) for j in range(k))
+        assert values[int(exp[q])] == v
+
+
+@pytest.mark.parametrize("degree,period", [(12, 40), (16, 54)])
+def test_dbg_snp_index_against_the_definition(degree, period):
+    """The branching generator (workload/dbg_torch.py::build_dbg with SNP bubbles): the index is the order-k de Bruijn
+    graph of {text (k + 1)-mers} + {(k + 1)-mers through a SNP's alternative base}; its path nodes are ALL k-mers of
+    those, text and alternative ones, in lexicographic order.  Checked against that definition, not against any
+    builder: node and edge sets, predecessor labels, out-degrees, the LCP array, find() of arbitrary patterns through the
+    oracle, and the closed form of walks."""
+    import torch
+    from workload import dbg_torch
+    from workload.index_arrays import unpack_bits
+    from workload.rng import SplitMix64
+    from oracle.oracle import OracleIndex
+    k = degree // 2
+    ix, wl = dbg_torch.build_dbg(degree, period=period, device=torch.device("cpu"), with_lcp=True, branching=4, chunk_bits=11)
+    P = wl.P
+    sym = wl.sym_t.numpy().astype(np.int64)
+    alt = wl.alt_t.numpy().astype(np.int64)
+    edges = set()
+    for p in range(P):
+        edges.add(tuple(sym[(p + j) % P] for j in range(k + 1)))
+    sites = np.flatnonzero(alt != 255)
+    assert len(sites) >= P // period - 2 and np.all(np.diff(sites) >= 2 * (k + 1))
+    for s in sites:
+        for p in range(s - k, s + 1):
+            w = [sym[(p + j) % P] for j in range(k + 1)]
+            w[s - p] = alt[s]
+            edges.add(tuple(w))
+    value = lambda kmer: sum(int(c) * 4 ** (k - 1 - j) for j, c in enumerate(kmer))       # noqa: E731
+    node_values = sorted({value(w[:k]) for w in edges} | {value(w[1:]) for w in edges})
+    node_id = {v: i for i, v in enumerate(node_values)}
+    N = len(node_values)
+    assert ix.n == N and ix.e == len(edges) and ix.order == k
+    assert N > 1.05 * P and 1.03 * N < ix.e < 1.12 * N                 # alternative k-mers are new path nodes; e / n grows with k (1.08 at k = 17)
+    B = [unpack_bits(ix.bwt[c], N) for c in range(7)]
+    for c in (0, 5, 6):
+        assert not B[c].any()
+    assert sum(int(B[c + 1].sum()) for c in range(4)) == ix.e
+    assert [int(x) for x in np.diff(ix.C)] == [0] + [int(B[c + 1].sum()) for c in range(4)] + [0, 0]
+    for w in edges:
+        assert B[w[0] + 1][node_id[value(w[1:])]]
+    out = unpack_bits(ix.edges, ix.e)
+    ends = np.flatnonzero(out)
+    assert len(ends) == N
+    outdeg = np.diff(np.concatenate([[-1], ends]))
+    by_source = {}
+    for w in edges:
+        by_source[value(w[:k])] = by_source.get(value(w[:k]), 0) + 1
+    assert len(by_source) == N and all(outdeg[node_id[v]] == d for v, d in by_source.items())
+    keys = [tuple((v >> (2 * (k - 1 - j))) & 3 for j in range(k)) for v in node_values]
+    want = [0] + [next(j for j in range(k) if keys[i - 1][j] != keys[i][j]) for i in range(1, N)]
+    assert [int(x) for x in ix.lcp_data[:N]] == want and ix.lcp_size == N
+
+    cpu = OracleIndex(ix, with_samples=False, with_counters=False, with_lcp=True)
+    rng = SplitMix64(0x5A1 + degree)
+    letters = b"ACGT"
+    pats = []
+    for _ in range(1000):                                     # uniform strings: mostly not in the graph
+        pats.append(tuple(rng.below(4) for _ in range(k + 1 + rng.below(5))))
+    for _ in range(1500):                                     # walks, some with one substitution
+        p, m = rng.below(P), k + 1 + rng.below(12)
+        w = [int(alt[(p + j) % P]) if alt[(p + j) % P] != 255 and rng.below(2) else int(sym[(p + j) % P]) for j in range(m)]
+        if rng.below(3) == 0:
+            w[rng.below(m)] = rng.below(4)
+        pats.append(tuple(w))
+    hits = 0
+    for pat in pats:
+        sp, ep = cpu.find(bytes(letters[c] for c in pat))
+        inside = all(tuple(pat[j:j + k + 1]) in edges for j in range(len(pat) - k))
+        if inside:
+            hits += 1
+            assert (sp, ep) == (node_id[value(pat[:k])], node_id[value(pat[:k])]), pat
+        else:
+            assert (sp + 1) % (1 << 64) > (ep + 1) % (1 << 64), pat
+    assert 700 < hits < 2400
+    walks, start, exp = dbg_torch.walk_patterns_device(wl, 0, 2000, k + 9, 0x5A2)
+    got = cpu.find_batch(walks.reshape(-1).numpy(), np.arange(2001, dtype=np.uint64) * np.uint64(k + 9))
+    assert np.array_equal(got[:, 0], exp.numpy().astype(np.uint64)) and np.array_equal(got[:, 1], got[:, 0])
+    took_alt = sum(1 for q in range(2000) if any(walks[q, j] != letters[sym[(int(start[q]) + j) % P]] for j in range(k + 9)))
+    assert took_alt > 100
+    # parent(find(X)) = the range of the longest proper prefix of X with a different range, at that prefix's length
+    # (the invariant verifyIndex asserts, src/algorithms.cpp:146-167)
+    checked = 0
+    for _ in range(400):
+        p, m = rng.below(P), 1 + rng.below(k)
+        w = [int(alt[(p + j) % P]) if alt[(p + j) % P] != 255 and rng.below(2) else int(sym[(p + j) % P]) for j in range(m)]
+        pat = bytes(letters[c] for c in w)
+        rng_x = cpu.find(pat)
+        if rng_x[0] > rng_x[1] or rng_x == (0, N - 1):
+            continue
+        end, shorter = m, rng_x
+        while shorter == rng_x:
+            end -= 1
+            shorter = cpu.find(pat[:end])
+        parent = cpu.parent(rng_x)
+        assert (parent[0], parent[1]) == shorter and parent[4] == end, (pat, rng_x, parent, shorter, end)
+        checked += 1
+    assert checked > 250
+
+
+@pytest.mark.parametrize("degree", [12, 16])
+def test_dbg_junction_index_against_the_definition(degree):
+    """The whole-human-sized branching index (workload/dbg_torch.py::build_dbg with junction edges), at small degrees:
+    path nodes = the k-mers of the cyclic text, edges = the text's (k + 1)-mers + the selected junctions u -> u[1..k) x
+    between existing nodes.  Checked against that definition through the arrays and through the oracle: predecessor
+    labels, out-degrees, find() of arbitrary patterns, the closed forms of walks (find, locate, count), the sampling rule
+    of src/gcsa.cpp:621-646 (a node with several predecessors, or whose value is not its predecessor's + 1, is sampled),
+    and the parent() invariant of verifyIndex."""
+    import torch
+    from workload import dbg_torch, mseq_torch
+    from workload.index_arrays import unpack_bits
+    from workload.rng import SplitMix64
+    from oracle.oracle import OracleIndex
+    k = degree // 2
+    ix, wl = dbg_torch.build_dbg(degree, junctions=80, device=torch.device("cpu"), full=True, branching=4, chunk_bits=11)
+    P = wl.P
+    sym = wl.sym_t.numpy().astype(np.int64)
+    def value(symbols):                                      # base-4 value of a string of any length
+        v = 0
+        for c in symbols:
+            v = v * 4 + int(c)
+        return v
+    kmer_at = [value([sym[(p + j) % P] for j in range(k)]) for p in range(P)]
+    node_values = sorted(kmer_at)
+    node_id = {v: i for i, v in enumerate(node_values)}
+    pos_of = {v: p for p, v in enumerate(kmer_at)}
+    assert ix.n == P == len(node_id) and ix.order == k
+    edges = set()
+    junctions = 0
+    for p in range(P):
+        u, succ = kmer_at[p], kmer_at[(p + 1) % P]
+        edges.add((u, succ))
+        for x in range(4):
+            cand = ((u & (4 ** (k - 1) - 1)) << 2) + x
+            if cand != succ and cand in node_id and bool(dbg_torch.junction_selected(torch.tensor([(u << 2) + x]), 80)[0]):
+                edges.add((u, cand))
+                junctions += 1
+    assert ix.e == len(edges) == P + junctions and 1.06 * P < ix.e < 1.10 * P
+    B = [unpack_bits(ix.bwt[c], P) for c in range(7)]
+    for c in (0, 5, 6):
+        assert not B[c].any()
+    assert sum(int(B[c + 1].sum()) for c in range(4)) == ix.e
+    assert [int(x) for x in np.diff(ix.C)] == [0] + [int(B[c + 1].sum()) for c in range(4)] + [0, 0]
+    indeg = np.zeros(P, dtype=np.int64)
+    outdeg_want = np.zeros(P, dtype=np.int64)
+    for u, v in edges:
+        assert B[(u >> (2 * (k - 1))) + 1][node_id[v]]
+        indeg[node_id[v]] += 1
+        outdeg_want[node_id[u]] += 1
+    ends = np.flatnonzero(unpack_bits(ix.edges, ix.e))
+    assert len(ends) == P and np.array_equal(np.diff(np.concatenate([[-1], ends])), outdeg_want)
+    assert int((indeg > 1).sum()) > 0.05 * P and int((outdeg_want > 1).sum()) > 0.05 * P
+    # sampling rule
+    sampled = unpack_bits(ix.sampled_paths, P)
+    want_sampled = np.zeros(P, dtype=bool)
+    for p in range(P):
+        want_sampled[node_id[kmer_at[p]]] = (p % 32 == 0) or indeg[node_id[kmer_at[p]]] > 1
+    assert np.array_equal(sampled, want_sampled) and ix.sample_count == int(want_sampled.sum())
+
+    cpu = OracleIndex(ix)
+    # locate / count of every node: its single value
+    r = np.arange(P, dtype=np.uint64)
+    offs, vals = cpu.locate_batch(np.stack([r, r], axis=1))
+    assert np.array_equal(np.diff(offs), np.ones(P, dtype=np.uint64))
+    assert np.array_equal(vals, mseq_torch.node_values(np.array([pos_of[v] for v in node_values])))
+    assert np.array_equal(cpu.count_batch(np.stack([r, r], axis=1)), np.ones(P, dtype=np.uint64))
+    rng = SplitMix64(0x5B1 + degree)
+    letters = b"ACGT"
+    edge_kmers = {(u << 2) | (v & 3) for u, v in edges}
+    pats = [tuple(rng.below(4) for _ in range(k + 1 + rng.below(5))) for _ in range(1000)]
+    walks, start, exp = dbg_torch.walk_patterns_device(wl, 0, 2500, k + 14, 0x5B2)
+    walks_np = walks.numpy()
+    for q in range(1500):                                     # walks, some with one substitution
+        w = [letters.index(int(c)) for c in walks_np[q, : k + 1 + rng.below(13)]]
+        if rng.below(3) == 0:
+            w[rng.below(len(w))] = rng.below(4)
+        pats.append(tuple(w))
+    hits = 0
+    for pat in pats:
+        sp, ep = cpu.find(bytes(letters[c] for c in pat))
+        inside = value(pat[:k]) in node_id and all(value(pat[j:j + k + 1]) in edge_kmers for j in range(len(pat) - k))
+        if inside:
+            hits += 1
+            assert (sp, ep) == (node_id[value(pat[:k])], node_id[value(pat[:k])]), pat
+        else:
+            assert (sp + 1) % (1 << 64) > (ep + 1) % (1 << 64), pat
+    assert 700 < hits < 2400
+    got = cpu.find_batch(walks_np.reshape(-1), np.arange(2501, dtype=np.uint64) * np.uint64(k + 14))
+    assert np.array_equal(got[:, 0], exp.numpy().astype(np.uint64)) and np.array_equal(got[:, 1], got[:, 0])
+    left_text = sum(1 for q in range(2500)
+                    if any(walks_np[q, j] != letters[sym[(int(start[q]) + j) % P]] for j in range(k + 14)))
+    assert left_text > 400                                    # the walks do cross junctions
+    offs, vals = cpu.locate_batch(got)
+    assert np.array_equal(vals, mseq_torch.node_values(start.numpy()))
+    # a wide range: every node whose k-mer starts with a 3-mer; its values are the start positions of that 3-mer
+    pat = bytes(letters[s] for s in sym[100:103])
+    rng3 = cpu.find(pat)
+    occ = [p for p in range(P) if all(sym[(p + j) % P] == sym[100 + j] for j in range(3))]
+    assert rng3[1] - rng3[0] + 1 == len(occ) == cpu.count(rng3)
+    assert cpu.locate(rng3).tolist() == sorted(int(v) for v in mseq_torch.node_values(np.array(occ)))
+    checked = 0
+    for _ in range(400):
+        p, m = rng.below(P), 1 + rng.below(k)
+        pat = bytes(letters[sym[(p + j) % P]] for j in range(m))
+        rng_x = cpu.find(pat)
+        if rng_x == (0, P - 1):
+            continue
+        end, shorter = m, rng_x
+        while shorter == rng_x:
+            end -= 1
+            shorter = cpu.find(pat[:end])
+        parent = cpu.parent(rng_x)
+        assert (parent[0], parent[1]) == shorter and parent[4] == end, (pat, rng_x, parent, shorter, end)
+        checked += 1
+    assert checked > 250

@@ -486,5 +486,67 @@ int gcsa_mseq_text(int degree, const int* taps, int ntaps, u8* sym, u32* rank)
   return 0;
 }
 
-}  // extern "C"
+// Cyclic text of an LFSR cycle that is NOT maximal: the cycle through state 1 of the recurrence a[n + d] = XOR of
+// a[n + d - tap] must have exactly `period` states (odd), e.g. (2^d - 1) / 3 for a suitable irreducible polynomial of even
+// degree d.  Symbol i consumes output bits 2i, 2i + 1, so the d/2-mer at position i is the state before them: the
+// `period` d/2-mers of the cyclic text are the states of the cycle, all distinct -- but, unlike gcsa_mseq_text, not
+// all d/2-mers exist, so ranks are not closed-form values (workload/dbg_torch.py ranks them through a bitmap of the
+// k-mer universe).  degree <= 62.  Returns 0, -1 if the cycle length is not `period`, -2 on bad arguments.
+int gcsa_lfsr_text(int degree, const int* taps, int ntaps, u64 period, u8* sym)
+{
+  if(degree < 4 || degree > 62 || (degree & 1) || (period & 1) == 0) { return -2; }
+  const u64 mask = (u64(1) << degree) - 1;
+  auto step = [&](u64 st) -> u64
+  {
+    u64 fb = 0;
+    for(int t = 0; t < ntaps; t++) { fb ^= (st >> (taps[t] - 1)) & 1; }
+    return ((st << 1) | fb) & mask;
+  };
+  typedef std::vector<u64> Mat;
+  auto mat_vec = [&](const Mat& M, u64 v) -> u64
+  {
+    u64 r = 0;
+    while(v) { int c = __builtin_ctzll(v); v &= v - 1; r ^= M[size_t(c)]; }
+    return r;
+  };
+  std::vector<Mat> power(size_t(degree) + 2, Mat(size_t(degree), 0));
+  for(int c = 0; c < degree; c++) { power[0][size_t(c)] = step(u64(1) << c); }
+  for(size_t j = 1; j < power.size(); j++)
+  {
+    for(int c = 0; c < degree; c++) { power[j][size_t(c)] = mat_vec(power[j - 1], power[j - 1][size_t(c)]); }
+  }
+  auto jump = [&](u64 st, u64 steps) -> u64
+  {
+    for(size_t j = 0; steps != 0; j++, steps >>= 1) { if(steps & 1) { st = mat_vec(power[j], st); } }
+    return st;
+  };
+  const u64 start = 1;
+  if(jump(start, period) != start) { return -1; }
+  {
+    u64 rest = period;
+    for(u64 p = 3; p * p <= rest; p += 2)
+    {
+      if(rest % p != 0) { continue; }
+      while(rest % p == 0) { rest /= p; }
+      if(jump(start, period / p) == start) { return -1; }
+    }
+    if(rest > 1 && rest != period && jump(start, period / rest) == start) { return -1; }
+  }
+  const int threads = omp_get_max_threads();
+  const u64 chunks = u64(threads) * 4, per = (period + chunks - 1) / chunks;
+  #pragma omp parallel for schedule(dynamic, 1)
+  for(u64 ch = 0; ch < chunks; ch++)
+  {
+    u64 begin = ch * per, end = begin + per < period ? begin + per : period;
+    if(begin >= end) { continue; }
+    u64 state = jump(start, 2 * begin);
+    for(u64 i = begin; i < end; i++)
+    {
+      sym[i] = u8((state >> (degree - 2)) & 3);
+      state = step(step(state));
+    }
+  }
+  return 0;
+}
 
+}  // extern "C"
