@@ -2,10 +2,12 @@
 """Benchmark of the GCSA2 query hot path on MI355X: batched k-mer find().
 
 Default workload = BASELINE.json configs[3], the configuration the metric is
-quoted on: a whole-human-footprint index (4.29 G path nodes; degree-32 m-sequence text, every answer
-known in closed form), replicated on every GPU, ONE batch of 100 M 32-mers sharded contiguously over
-the N ranks (strong scaling), hit ranges gathered in the root's HBM by the library's single RCCL
-gather (gcsa2_comm_gather: grouped ncclSend / ncclRecv over xGMI).  One step = one pass of the hot
+quoted on: a whole-human-pangenome-sized BRANCHING index -- 5 726 623 061 path nodes, e = 1.08 n, the
+figures of the paper's whole-human index (paper.tex:380); order-17 de Bruijn graph of a degree-34 LFSR
+cycle plus junction edges, every answer known in closed form (workload/dbg_torch.py) -- replicated on
+every GPU, ONE batch of 100 M 32-mers sharded contiguously over the N ranks (strong scaling), hit ranges
+gathered in the root's HBM by the library's single RCCL gather (gcsa2_comm_gather: grouped ncclSend /
+ncclRecv over xGMI; u64 pairs on the wire, the path nodes do not fit 32 bits).  One step = one pass of the hot
 path (gcsa2_find_device, kernel k_find2) over the rank's shard, inputs resident in HBM, + that gather.
 Prints ONE JSON line on rank 0 (contract: task statement / DESIGN.md section 5).
 
@@ -13,6 +15,7 @@ At N = 1 the same run also measures, as secondary objects of that line (never pa
   config5  BASELINE configs[4]: 1 M 256-bp patterns on the same index, half of them with a substitution
            every 41 bp: find() with parent() on failure (fused matching statistics), then locate()
   chr22    BASELINE configs[1] and [2]: 10 M 32-mer find() and locate() on the chr22-like SNP graph
+  human32  rounds 1-2's headline for continuity: the 2^32 - 1 node index of the degree-32 m-sequence text
 
 `--workload chr22 | linear` run those indexes as the primary workload (10 M queries per GPU, weak
 scaling), for the profiles under profiles/.
@@ -46,12 +49,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["human", "human_snp", "chr22", "linear"], default="human",
-                    help="human: whole-human-footprint index, one batch sharded over the GPUs (config 4); human_snp: the same text "
-                         "with SNP bubbles (branching index, e = 1.08 n; find() and, at N = 1, matching statistics); "
+    ap.add_argument("--workload", choices=["pangenome", "pangenome_plain", "pangenome_snp", "human", "human_snp", "chr22", "linear"], default="pangenome",
+                    help="pangenome: whole-human-pangenome-sized branching index (5.73 G path nodes, e = 1.08 n), one batch sharded over "
+                         "the GPUs (config 4); pangenome_plain / pangenome_snp: the same text without junction edges / with SNP bubbles "
+                         "(6.9 G path nodes); human: rounds 1-2's 2^32 - 1 node index; human_snp: that text with SNP bubbles; "
                          "chr22: chr22-like SNP-bubble graph (config 2); linear: 2^30-base linear graph built on the GPU")
+    ap.add_argument("--junctions", type=int, default=80, help="pangenome: junction edges, per mille of the candidates (80 -> e = 1.08 n)")
     ap.add_argument("--snp-period", type=int, default=50, help="human_snp: one SNP per this many positions")
-    ap.add_argument("--degree", type=int, default=32, help="human: degree of the m-sequence (path nodes = 2^degree - 1)")
+    ap.add_argument("--degree", type=int, default=0, help="pangenome: degree of the LFSR (default 34: (2^34 - 1) / 3 path nodes); "
+                                                            "human: degree of the m-sequence (default 32: 2^degree - 1 path nodes)")
     ap.add_argument("--log2-bases", type=int, default=0, help="chr22 / linear: backbone length (default 25 / 30)")
     ap.add_argument("--order", type=int, default=256)
     ap.add_argument("--queries", type=int, default=0,
@@ -61,7 +67,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the config-5 and chr22 measurements")
-    ap.add_argument("--secondary", choices=["all", "config5", "chr22", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
+    ap.add_argument("--secondary", choices=["all", "config5", "chr22", "human32", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
     ap.add_argument("--variant", type=int, default=2, help="find kernel generation (1 = k_find, 2 = k_find2)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
@@ -205,7 +211,7 @@ def setup_human(args, D, dev, local_rank, branching=False, total_queries=None):
     from gcsa2_amd.binding import GCSA
     wl = Workload()
     wl.scaling = "strong"
-    degree = args.degree
+    degree = args.degree or 32
     # every rank stages its own replica: ~12 bytes of host memory per path node while it does
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", D.world))
     available = sorted(d for d in mseq_torch.TAPS if d <= degree)
@@ -214,8 +220,8 @@ def setup_human(args, D, dev, local_rank, branching=False, total_queries=None):
     while len(available) > 1 and available[-1] > 24 and not host_memory_ok(local_world * 12 * (1 << available[-1])):
         available.pop()
     degree = available[-1]
-    if degree != args.degree:
-        log(f"warning: host memory too small for {local_world} replicas of degree {args.degree}; using degree {degree}")
+    if degree != (args.degree or 32):
+        log(f"warning: host memory too small for {local_world} replicas of degree {args.degree or 32}; using degree {degree}")
     full = (D.world == 1 and not args.no_secondary and not branching)
     t = time.time()
     alt_t = None
@@ -233,6 +239,14 @@ def setup_human(args, D, dev, local_rank, branching=False, total_queries=None):
     log(f"device image: {wl.gpu.device_bytes() / 1e9:.2f} GB in HBM, seed table k = {wl.gpu.kmer_table_k()}, "
         f"pair blocks {wl.gpu.pair_block_bytes() / 1e9:.2f} GB ({time.time() - t:.1f} s)")
     wl.ix, wl.sym_t, wl.rank_t, wl.full, wl.degree, wl.alt_t = ix, sym_t, rank_t, full, degree, alt_t
+
+    def long_patterns(first, count, m, seed):          # (patterns, start positions, closed-form node) for config 5
+        if branching:
+            pats, exp = mseq_torch.walk_patterns_device(sym_t, alt_t, rank_t, first, count, m, seed)
+            return pats, None, exp
+        pats, start = mseq_torch.substring_patterns_device(sym_t, first, count, m, seed)
+        return pats, start, rank_t[start].to(torch.int64) & 0xFFFFFFFF
+    wl.long_patterns = long_patterns
     wl.total_queries = total_queries or args.queries or 100_000_000
     wl.m = args.pattern_len
     b, e = shard_bounds(wl.total_queries, D.world)[D.rank]
@@ -281,6 +295,77 @@ def setup_human(args, D, dev, local_rank, branching=False, total_queries=None):
             ok = ok and bool(torch.equal(got[:, 0], exp)) and bool(torch.equal(got[:, 1], exp))
         return ok
     wl.verify = verify
+    return wl
+
+
+def setup_pangenome(args, D, dev, local_rank, total_queries=None):
+    """BASELINE configs[3] as SURVEY 8(d) wrote it: n = 5.73 G path nodes, e = 1.08 n (workload/dbg_torch.py).  The same
+    index serves config 5 at N = 1 (samples, counters and LCP array in closed form)."""
+    import torch
+    from workload import dbg_torch, mseq_torch
+    from gcsa2_amd.binding import GCSA
+    wl = Workload()
+    wl.scaling = "strong"
+    degree = args.degree or 34
+    if degree not in dbg_torch.LFSR:
+        raise SystemExit(f"--degree must be one of {sorted(dbg_torch.LFSR)}")
+    kind = {"pangenome": "junction", "pangenome_plain": "plain", "pangenome_snp": "snp"}[args.workload if args.workload.startswith("pangenome") else "pangenome"]
+    full = (D.world == 1 and not args.no_secondary and kind != "snp")
+    # every rank stages its own replica on the host: ~5 bytes per path node for find() alone, ~9 with samples and LCP
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", D.world))
+    need = local_world * (9 if full else 5) * dbg_torch.text_length(degree) * (1.25 if kind == "snp" else 1.0)
+    if degree > 20 and not host_memory_ok(need):
+        log(f"warning: host memory too small for {local_world} replicas of the degree-{degree} index ({need / 1e9:.0f} GB); "
+            f"falling back to the 2^32 - 1 node index of rounds 1-2")
+        args.degree = 0
+        return setup_human(args, D, dev, local_rank, total_queries=total_queries)
+    t = time.time()
+    ix, dbg = dbg_torch.build_dbg(degree, period=(args.snp_period if kind == "snp" else 0),
+                                  junctions=(args.junctions if kind == "junction" else 0), device=dev, verbose=log,
+                                  full=full, with_lcp=(kind == "snp" and D.world == 1 and not args.no_secondary))
+    torch.cuda.empty_cache()
+    log(f"index arrays: n = {ix.n}, e = {ix.e} ({time.time() - t:.1f} s)")
+    t = time.time()
+    wl.gpu = GCSA(ix, device=local_rank, with_samples=full, with_counters=full, with_lcp=ix.lcp_size > 0)
+    log(f"device image: {wl.gpu.device_bytes() / 1e9:.2f} GB in HBM, seed table k = {wl.gpu.kmer_table_k()}, "
+        f"pair blocks {wl.gpu.pair_block_bytes() / 1e9:.2f} GB, locate table {wl.gpu.locate_table_bytes() / 1e9:.2f} GB ({time.time() - t:.1f} s)")
+    wl.ix, wl.dbg, wl.full, wl.degree = ix, dbg, full, degree
+    wl.total_queries = total_queries or args.queries or 100_000_000
+    wl.m = args.pattern_len
+    b, e = shard_bounds(wl.total_queries, D.world)[D.rank]
+    wl.first, wl.nq = b, e - b
+    t = time.time()
+    expected = None
+    if args.set == "S":
+        pats, _, expected = dbg_torch.walk_patterns_device(dbg, b, e - b, wl.m, HUMAN_PATTERN_SEED)
+    else:
+        pats = uniform_patterns_device(b, e - b, wl.m, HUMAN_PATTERN_SEED, dev)
+    wl.d_pat = padded_bytes(pats)
+    del pats
+    wl.d_off = torch.arange(wl.nq + 1, dtype=torch.int64, device=dev) * wl.m
+    log(f"patterns: shard [{b}, {e}) of {wl.total_queries} x {wl.m}, set {args.set} ({time.time() - t:.1f} s)")
+    graph = {"junction": f"+ junction edges between existing nodes ({args.junctions} per mille of the candidates)",
+             "plain": "(no branching)", "snp": f"+ one SNP bubble per {args.snp_period} positions"}[kind]
+    wl.label = (f"whole-human-pangenome-sized index: order-{degree // 2} de Bruijn graph of a degree-{degree} LFSR cycle of "
+                f"{dbg.P} positions {graph}: {ix.n} path nodes, {ix.e} edges = {ix.e / ix.n:.3f} n; one batch of "
+                f"{wl.total_queries} x {wl.m}-mer find() sharded over {D.world} GPU(s), pattern set {args.set}"
+                + (" (walks through the graph)" if args.set == "S" else ""))
+
+    def verify(d_ranges, first, count):
+        # find() of a walk of >= k characters = the single node of its first k characters, in closed form (the bitmap
+        # rank of that k-mer); a shard other than this rank's own is regenerated
+        if args.set != "S" or wl.m < degree // 2:
+            return None
+        ok = True
+        step = 1 << 23
+        for c in range(0, count, step):
+            n = min(step, count - c)
+            ex = expected[c:c + n] if (first, count) == (b, e - b) else dbg_torch.walk_patterns_device(dbg, first + c, n, wl.m, HUMAN_PATTERN_SEED)[2]
+            got = d_ranges[c:c + n]
+            ok = ok and bool(torch.equal(got[:, 0], ex)) and bool(torch.equal(got[:, 1], ex))
+        return ok
+    wl.verify = verify
+    wl.long_patterns = lambda first, count, m, seed: dbg_torch.walk_patterns_device(dbg, first, count, m, seed)
     return wl
 
 
@@ -578,21 +663,23 @@ def find_config(wl, r, world):
 # ---- N = 1 secondaries ---------------------------------------------------------------------------------------
 
 def config5(args, wl, dev):
-    """BASELINE configs[4] on one GPU: 1 M 256-bp patterns on the whole-human-footprint index, every second one with
-    a substitution every 41 bp.  Backward search with parent() on failure (k_match_stats: LF + LCPArray::parent fused,
-    the MEM-finder interplay of SURVEY.md 8(f)-2), then locate() of the final ranges."""
+    """BASELINE configs[4] on one GPU: 1 M 256-bp walks through the index of the headline, every second one with a
+    substitution every 41 bp.  Backward search with parent() on failure (k_match_stats2: LF + LCPArray::parent fused, the
+    MEM-finder interplay of SURVEY.md 8(f)-2), plain find(), then -- when the index carries samples -- locate() and
+    parent() of the final ranges.  Closed forms for the unmodified half, the CPU oracle on a sample of everything."""
     import torch
     from workload import mseq_torch
     gpu, ix = wl.gpu, wl.ix
     nq, m = 1_000_000, 256
     stream = torch.cuda.current_stream()
-    pats, start = mseq_torch.substring_patterns_device(wl.sym_t, 0, nq, m, CONFIG5_SEED)
+    pats, start, expected = wl.long_patterns(0, nq, m, CONFIG5_SEED)
     nxt = torch.zeros(256, dtype=torch.uint8, device=dev)
     for a, b in zip(b"ACGT", b"CGTA"):
         nxt[a] = b
     for col in range(37, m, 41):
         pats[1::2, col] = nxt[pats[1::2, col].to(torch.int64)]
     d_pat = padded_bytes(pats)
+    del pats
     d_off = torch.arange(nq + 1, dtype=torch.int64, device=dev) * m
     d_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev)
     d_rng = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
@@ -612,30 +699,30 @@ def config5(args, wl, dev):
 
     ms_time = timed(lambda: gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(),
                                                    d_fb.data_ptr(), stream.cuda_stream))
-    # closed form for the unmodified half: the range of T[p .. p + 256) is (rank[p], rank[p]), no parent() call,
-    # and the match starting at byte i has length 256 - i
-    exp = wl.rank_t[start[0::2]].to(torch.int64) & 0xFFFFFFFF
+    # closed form for the unmodified half: the walk matches to full depth, so no parent() call, the match starting at
+    # byte i has length 256 - i, and the final range is the single node of the walk's first k characters
+    exp = expected[0::2]
     ms2d = d_ms[: nq * m].view(nq, m)
     want_ms = (m - torch.arange(m, device=dev)).to(torch.int16).view(1, m)
     exact_ok = bool(torch.equal(d_rng[0::2, 0], exp)) and bool(torch.equal(d_rng[0::2, 1], exp)) and \
         bool((d_fb[0::2] == 0).all()) and bool((ms2d[0::2] == want_ms).all())
-    out = {"workload": f"{nq} x {m}-bp patterns on the same index, every second one with a substitution every 41 bp: "
-                       "backward search with parent() on failure (k_match_stats), then locate() and parent() of the final ranges",
+    out = {"workload": f"{nq} x {m}-bp walks through the same index, every second one with a substitution every 41 bp: "
+                       "backward search with parent() on failure (k_match_stats2), find(), then locate() and parent() of the final ranges",
+           "path_nodes": int(ix.n), "edges": int(ix.e),
            "match_stats_ms": ms_time, "patterns_per_s": nq / (ms_time * 1e-3), "bases_per_s": nq * m / (ms_time * 1e-3),
            "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item()),
-           "unmodified_half_equals_closed_form": exact_ok,
-           "note": "on this unbranched index every substituted pattern fails at the same steps (23 parent() calls, 200 rounds each), so "
-                   "the lanes of a wave diverge in lockstep; `human_branching.config5` runs the same kernel on the branching index, "
-                   "where they do not (profiles/r02_config5.md)"}
-    # plain find() of the same batch (a substituted pattern empties at its first substitution)
+           "unmodified_half_equals_closed_form": exact_ok}
+    # plain find() of the same batch (a substituted pattern usually empties at its first substitution)
     d_find = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
     out["find_ms"] = timed(lambda: gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_find.data_ptr(), stream.cuda_stream))
     out["find_patterns_per_s"] = nq / (out["find_ms"] * 1e-3)
     out["find_unmodified_half_equals_closed_form"] = bool(torch.equal(d_find[0::2, 0], exp)) and bool(torch.equal(d_find[0::2, 1], exp))
-    loc, d_loff, d_lval = measure_locate(gpu, d_rng, dev, 3)
-    out["locate"] = loc
-    vals = mseq_torch.node_values(start[0::2].cpu().numpy())
-    out["locate_unmodified_half_equals_closed_form"] = bool(np.array_equal(d_lval[d_loff[:-1][0::2]].cpu().numpy().view(np.uint64), vals))
+    if gpu.sampleCount() > 0:
+        loc, d_loff, d_lval = measure_locate(gpu, d_rng, dev, 3)
+        out["locate"] = loc
+        if start is not None:
+            vals = mseq_torch.node_values(start[0::2].cpu().numpy())
+            out["locate_unmodified_half_equals_closed_form"] = bool(np.array_equal(d_lval[d_loff[:-1][0::2]].cpu().numpy().view(np.uint64), vals))
     d_nodes = torch.zeros((nq, 5), dtype=torch.int64, device=dev)
     t_parent = timed(lambda: gpu.parent_device(d_rng.data_ptr(), nq, d_nodes.data_ptr(), stream.cuda_stream))
     out["parent_queries_per_s"] = nq / (t_parent * 1e-3)
@@ -671,6 +758,22 @@ def release(wl):
     torch.cuda.empty_cache()
 
 
+def human32_secondary(args, D, dev, local_rank):
+    """Rounds 1-2's headline, for continuity: the 2^32 - 1 node index of the degree-32 m-sequence text (e = n), find() only."""
+    saved = (args.degree, args.no_secondary)
+    args.degree, args.no_secondary = 32, True              # no samples / LCP: the find() leg only
+    wl = setup_human(args, D, dev, local_rank, total_queries=args.queries or 100_000_000)
+    args.degree, args.no_secondary = saved
+    r = measure(args, D, dev, wl, max(5, args.steps // 2), 2)
+    ok = wl.verify(r["d_out"], wl.first, wl.nq)
+    out = {"workload": wl.label, "value": wl.nq / (r["kernel_ms"] * 1e-3), "unit": "queries/s", "kernel_ms": r["kernel_ms"],
+           "all_ranges_equal_closed_form": ok, "config": find_config(wl, r, 1),
+           "roofline": roofline(args, r, wl, f"human_{wl.degree}_{wl.m}_{args.set}")}
+    del r
+    release(wl)
+    return out
+
+
 def human_snp_secondary(args, D, dev, local_rank):
     """The headline workload on a BRANCHING index of the same footprint (e = 1.08 n: out- and in-degrees above one wherever a
     bubble opens, closes or an alternative k-mer lands), every range checked against its closed form."""
@@ -683,59 +786,8 @@ def human_snp_secondary(args, D, dev, local_rank):
            "roofline": roofline(args, r, wl, f"human_snp_{wl.degree}_{wl.m}_{args.set}")}
     del r
     if wl.ix.lcp_size > 0:
-        out["config5"] = config5_branching(args, wl, dev)
+        out["config5"] = config5(args, wl, dev)
     release(wl)
-    return out
-
-
-def config5_branching(args, wl, dev):
-    """BASELINE configs[4]'s backward search with parent() on failure, on the BRANCHING footprint index: 1 M 256-bp walks
-    through the graph (alternative base at half of the SNP sites met), every second one with a substitution every 41 bp.
-    The LCP array is that of the node set (workload/mseq_torch.py::mseq_lcp); locate() needs samples, which this index does
-    not carry, and stays on the unbranched one."""
-    import torch
-    from workload import mseq_torch
-    gpu = wl.gpu
-    nq, m = 1_000_000, 256
-    stream = torch.cuda.current_stream()
-    pats, expected = mseq_torch.walk_patterns_device(wl.sym_t, wl.alt_t, wl.rank_t, 0, nq, m, CONFIG5_SEED)
-    nxt = torch.zeros(256, dtype=torch.uint8, device=dev)
-    for a, b in zip(b"ACGT", b"CGTA"):
-        nxt[a] = b
-    for col in range(37, m, 41):
-        pats[1::2, col] = nxt[pats[1::2, col].to(torch.int64)]
-    d_pat = padded_bytes(pats)
-    d_off = torch.arange(nq + 1, dtype=torch.int64, device=dev) * m
-    d_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev)
-    d_rng = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
-    d_fb = torch.zeros(nq, dtype=torch.int64, device=dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
-
-    def run():
-        gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), stream.cuda_stream)
-    run()
-    torch.cuda.synchronize()
-    e0.record(stream)
-    for _ in range(reps):
-        run()
-    e1.record(stream)
-    torch.cuda.synchronize()
-    ms_time = e0.elapsed_time(e1) / reps
-    # closed form for the unmodified half: the walk matches to full depth, so no parent() call, the match starting at byte i
-    # has length 256 - i, and the final range is the single node of the walk's first k characters
-    exp = expected[0::2]
-    ms2d = d_ms[: nq * m].view(nq, m)
-    want_ms = (m - torch.arange(m, device=dev)).to(torch.int16).view(1, m)
-    exact_ok = bool(torch.equal(d_rng[0::2, 0], exp)) and bool(torch.equal(d_rng[0::2, 1], exp)) and \
-        bool((d_fb[0::2] == 0).all()) and bool((ms2d[0::2] == want_ms).all())
-    out = {"workload": f"{nq} x {m}-bp walks through the branching index, every second one with a substitution every 41 bp: "
-                       "backward search with parent() on failure (k_match_stats)",
-           "match_stats_ms": ms_time, "patterns_per_s": nq / (ms_time * 1e-3), "bases_per_s": nq * m / (ms_time * 1e-3),
-           "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item()),
-           "unmodified_half_equals_closed_form": exact_ok}
-    if not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline_match_stats(wl.ix, d_pat, d_ms, d_rng, d_fb, m)
     return out
 
 
@@ -810,7 +862,9 @@ def main():
     from gcsa2_amd import binding
     D.make_comm(binding, local_rank)
 
-    if args.workload in ("human", "human_snp"):
+    if args.workload.startswith("pangenome"):
+        wl = setup_pangenome(args, D, dev, local_rank)
+    elif args.workload in ("human", "human_snp"):
         wl = setup_human(args, D, dev, local_rank, branching=(args.workload == "human_snp"))
     elif args.workload == "chr22":
         wl = setup_chr22(args, D, dev, local_rank)
@@ -826,8 +880,7 @@ def main():
 
     result = None
     if rank == 0:
-        size = {"human": getattr(wl, "degree", args.degree), "human_snp": getattr(wl, "degree", args.degree),
-                "chr22": args.log2_bases or 25, "linear": args.log2_bases or 30}[args.workload]
+        size = {"chr22": args.log2_bases or 25, "linear": args.log2_bases or 30}.get(args.workload, getattr(wl, "degree", args.degree))
         result = {
             "metric": "kmer_find_queries_per_sec", "value": wl.total_queries * args.steps / r["elapsed"], "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -840,8 +893,8 @@ def main():
         result["config"]["all_ranges_equal_closed_form"] = checked
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds)
-    secondary = args.workload == "human" and world == 1 and not args.no_secondary
-    if secondary and args.secondary in ("all", "config5"):
+    secondary = args.workload in ("pangenome", "pangenome_plain", "human") and world == 1 and not args.no_secondary
+    if secondary and args.secondary in ("all", "config5") and wl.ix.lcp_size > 0:
         result["config5"] = config5(args, wl, dev)
     del r
     if secondary:
@@ -849,7 +902,9 @@ def main():
         del wl
     if secondary and args.secondary in ("all", "chr22"):
         result["chr22"] = chr22_secondary(args, D, dev, local_rank)
-    if secondary and args.secondary in ("all", "human_snp"):
+    if secondary and args.workload != "human" and args.secondary in ("all", "human32"):
+        result["human32"] = human32_secondary(args, D, dev, local_rank)
+    if secondary and args.secondary == "human_snp":
         result["human_branching"] = human_snp_secondary(args, D, dev, local_rank)
     if rank == 0:
         print(json.dumps(result), flush=True)

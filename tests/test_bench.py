@@ -50,6 +50,7 @@ def test_single_gpu_line_with_secondaries():
              "--secondary", "config5"])
     check_line(d, 1, 3)
     assert d["scaling"] == "strong" and d["config"]["queries_total"] == 300000
+    assert d["config"]["path_nodes"] == ((1 << 20) - 1) // 3 and 1.06 < d["config"]["edges"] / d["config"]["path_nodes"] < 1.10
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["gpu_matches_cpu_on_sample"] is True and c["value"] > 0
     c5 = d["config5"]

@@ -5,8 +5,9 @@
             compared with the oracle on every query.
   config 2  (reduced: 2^21 bases) full parity incl. uniform patterns that die early.
   config 2/3 (full: 2^25 bases, 10 M 32-mers) size-independent properties, locate() of all 10 M ranges, oracle on the batch.
-  config 4/5 (whole-human footprint: 4.29 G path nodes) find / locate / parent / 256-bp patterns with parent() on
-            failure against closed-form answers for every query, and against the oracle on samples.
+  config 4/5 (whole-human pangenome size: 5.73 G path nodes, e = 1.08 n -- beyond 2^32) find / locate / count / parent /
+            256-bp patterns with parent() on failure against closed-form answers for every query, and against the oracle
+            on samples; the u64 wire format of the gather.
 """
 import numpy as np
 import pytest
@@ -157,44 +158,99 @@ def test_mseq_index_closed_form_on_gpu():
     assert np.array_equal(par["node_lcp"].astype(np.int64), L)
 
 
-def test_whole_human_footprint_closed_form():
-    """BASELINE configs[3] and [4] at their index footprint on one GPU: the degree-32 m-sequence index (4 294 967 295 path
-    nodes, the size of the paper's whole-genome indexes, paper.tex:378-380) with samples, counters and the LCP array.
-    Every find() / locate() / parent() answer is known in closed form; the substituted 256-bp patterns (LF + parent
-    interplay, reference src/algorithms.cpp:146-167 shape) are checked against the oracle on a sample."""
+def dbg_parent_closed_form(dbg, lcpv, ranks, values):
+    """parent() of the singleton ranges (r, r) on a de Bruijn index of workload/dbg_torch.py: the nodes sharing the first
+    L characters with node r, L = max of the two adjacent LCP values -- the k-mer values [lo, lo + 4^(k - L)), whose
+    path node ids follow from the bitmap rank.  Returns (sp, ep, L)."""
     import torch
-    from workload import mseq_torch
+    n, k = dbg.nodes.n, dbg.k
+    right = torch.where(ranks + 1 < n, lcpv[torch.clamp(ranks + 1, max=n - 1)].to(torch.int64), torch.zeros_like(ranks))
+    L = torch.maximum(lcpv[ranks].to(torch.int64), right)
+    L = torch.where(ranks == 0, right, L)                   # LCP[0] = 0 by definition
+    shift = 2 * (k - L)
+    lo = (values >> shift) << shift
+    hi = lo + (torch.ones_like(lo) << shift)                # exclusive; may equal 4^k, one past the universe
+    top = torch.full_like(hi, n)
+    inside = hi < dbg.nodes.universe
+    top[inside] = dbg.nodes.rank(hi[inside])
+    return dbg.nodes.rank(lo), top - 1, L
+
+
+def test_pangenome_index_beyond_32_bits():
+    """BASELINE configs[3] and [4] as SURVEY 8(d) wrote them, on one GPU: 5 726 623 061 path nodes and e = 1.08 n
+    (paper.tex:380), i.e. path node, edge and LCP positions beyond 2^32 -- the 64-bit side of every kernel: block
+    indices, 40-bit seed and locate-table fields, the u64 wire format of the gather.  The index is the order-17 de Bruijn
+    graph of a degree-34 LFSR cycle plus junction edges (workload/dbg_torch.py; validated against its definition at small
+    degrees in tests/test_workload.py) with samples, counters and LCP array; every find() / locate() / count() /
+    parent() answer is known in closed form, the substituted 256-bp patterns (LF + parent interplay, reference
+    src/algorithms.cpp:146-167 shape) are checked against the oracle on a sample."""
+    import torch
+    from workload import dbg_torch, mseq_torch
+    from gcsa2_amd import binding
     from gcsa2_amd.binding import GCSA
     from oracle.oracle import OracleIndex
     dev = torch.device("cuda", 0)
-    degree, k = 32, 16
-    ix, sym_t, rank = mseq_torch.build_mseq(degree, device=dev, full=True)
-    rank_t = torch.from_numpy(rank.view(np.int32)).to(dev)
-    del rank
+    degree, k = 34, 17
+    ix, dbg = dbg_torch.build_dbg(degree, junctions=80, device=dev, full=True)
+    torch.cuda.empty_cache()
+    assert ix.n == 5_726_623_061 and 1.07 * ix.n < ix.e < 1.09 * ix.n and ix.sample_width > 32
     gpu = GCSA(ix, device=0)
-    assert gpu.size() == (1 << 32) - 1 and gpu.pair_block_bytes() > 0 and gpu.locate_table_bytes() > 0
+    assert gpu.size() == ix.n and gpu.pair_block_bytes() > 0 and gpu.locate_table_bytes() > 0 and gpu.kmer_table_k() >= 15
     st = torch.cuda.current_stream().cuda_stream
 
     def batch(nq, m, seed):
-        pats, start = mseq_torch.substring_patterns_device(sym_t, 0, nq, m, seed)
+        pats, start, exp = dbg_torch.walk_patterns_device(dbg, 0, nq, m, seed)
         flat = torch.zeros(nq * m + 8, dtype=torch.uint8, device=dev)
         flat[: nq * m] = pats.reshape(-1)
-        return pats, flat, torch.arange(nq + 1, dtype=torch.int64, device=dev) * m, start
+        return pats, flat, torch.arange(nq + 1, dtype=torch.int64, device=dev) * m, start, exp
 
-    # config 4: 20 M 32-mers, every range = (rank[p], rank[p])
+    # config 4: 20 M 32-mers, every range = the single node of the walk's first 17 characters
     nq, m = 20_000_000, 32
-    _, d_pat, d_off, start = batch(nq, m, 0x6C5A0041)
+    _, d_pat, d_off, start, exp = batch(nq, m, 0x6C5A0041)
+    assert int(exp.max().item()) > (1 << 32) and int((exp > (1 << 32)).sum().item()) > nq // 8      # sp beyond 32 bits
     d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
     gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), st)
     torch.cuda.synchronize()
-    exp = rank_t[start].to(torch.int64) & 0xFFFFFFFF
     assert torch.equal(d_out[:, 0], exp) and torch.equal(d_out[:, 1], exp)
-    # ... also through the single-character kernel (GCSA2_PAIR_BLOCKS=0 path is variant 1's older sibling: k_find)
-    d_out1 = torch.zeros_like(d_out)
-    gpu.find_device_variant(1, d_pat.data_ptr(), d_off.data_ptr(), 2_000_000, d_out1.data_ptr(), st)
+    # ... also through the first-generation kernel (64-byte rank blocks, no seed table, no pair blocks) and the
+    # length-bucketed launch
+    for variant in (1, 4):
+        d_out1 = torch.zeros((2_000_000, 2), dtype=torch.int64, device=dev)
+        gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), 2_000_000, d_out1.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert torch.equal(d_out1, d_out[:2_000_000]), variant
+    # k-mers exactly as long as the order, and uniform random 32-mers (mostly absent: edge-space empty ranges beyond 2^32)
+    # against the oracle
+    cpu = OracleIndex(ix, with_samples=False, with_counters=False)
+    _, d_patk, d_offk, _, expk = batch(1_000_000, k, 0x6C5A0042)
+    d_outk = torch.zeros((1_000_000, 2), dtype=torch.int64, device=dev)
+    gpu.find_device(d_patk.data_ptr(), d_offk.data_ptr(), 1_000_000, d_outk.data_ptr(), st)
     torch.cuda.synchronize()
-    assert torch.equal(d_out1[:2_000_000], d_out[:2_000_000])
-    # locate: the rotation starting at position p carries exactly the value of p; count = 1
+    assert torch.equal(d_outk[:, 0], expk) and torch.equal(d_outk[:, 1], expk)
+    ns = 200_000
+    uni = torch.from_numpy(patterns.uniform_patterns(ns, 32, 0x6C5A0043)).to(dev)
+    d_patu = torch.zeros(ns * 32 + 8, dtype=torch.uint8, device=dev)
+    d_patu[: ns * 32] = uni.reshape(-1)
+    d_outu = torch.zeros((ns, 2), dtype=torch.int64, device=dev)
+    gpu.find_device(d_patu.data_ptr(), d_off.data_ptr(), ns, d_outu.data_ptr(), st)
+    torch.cuda.synchronize()
+    want = cpu.find_batch(d_patu[: ns * 32].cpu().numpy(), np.arange(ns + 1, dtype=np.uint64) * np.uint64(32), threads=8)
+    got = d_outu.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want) and int((want[:, 0] > np.uint64(1 << 32)).sum()) > ns // 8
+    # the u64 wire format of the gather (these ranges do not fit the (sp, len) u32 pairs): world-size-1 communicator
+    try:
+        comm = binding.Comm(binding.Comm.unique_id(), 0, 1, 0)
+    except binding.Gcsa2Error as e:
+        comm = None
+        assert e.code == -5, e                          # RCCL not loadable on this host
+    if comm is not None:
+        d_recv = torch.zeros_like(d_out)
+        comm.gather(d_out.data_ptr(), [nq * 16], d_recv.data_ptr(), 0, st)
+        torch.cuda.synchronize()
+        assert torch.equal(d_recv, d_out)
+        comm.close()
+        del d_recv
+    # locate: the node of position p carries exactly the value of p (39-bit values); count = 1
     d_loff = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
     d_lval = torch.zeros(nq, dtype=torch.int64, device=dev)
     assert gpu.locate_into(d_out.data_ptr(), nq, d_loff.data_ptr(), d_lval.data_ptr(), nq, st) == nq
@@ -205,25 +261,36 @@ def test_whole_human_footprint_closed_form():
     gpu.count_device(d_out.data_ptr(), nq, d_cnt.data_ptr(), st)
     torch.cuda.synchronize()
     assert bool((d_cnt == 1).all())
-    # parent of a singleton: all k-mer values sharing the first L digits, L = max of the two adjacent LCP values
+    # ... and a batch of WIDE ranges (the first 8..12 characters of walks: thousands of nodes each) against the oracle:
+    # locate with sort + unique over the big segments, count == |locate|
+    nw = 2000
+    wide_pats = [bytes(uni[q, : 8 + q % 5].cpu().numpy()) for q in range(nw)]
+    from gcsa2_amd.hostview import concat_patterns
+    wdata, woff = concat_patterns(wide_pats)
+    wr = gpu.find_batch(wdata, woff)
+    assert np.array_equal(wr, cpu.find_batch(wdata, woff, threads=8))
+    hit = wr[(wr[:, 0] <= wr[:, 1]) & (wr[:, 1] < ix.n)][:300]
+    assert hit.shape[0] > 100 and int((hit[:, 1] - hit[:, 0]).max()) > 5000
+    go, gv = gpu.locate_batch(hit)
+    full_cpu = OracleIndex(ix, with_lcp=False)
+    co, cv = full_cpu.locate_batch(hit, threads=8)
+    assert np.array_equal(go, co) and np.array_equal(gv, cv)
+    assert np.array_equal(np.diff(go), gpu.count_batch(hit)) and np.array_equal(np.diff(go), full_cpu.count_batch(hit, threads=8))
+    full_cpu.close()
+    # parent of a singleton: all nodes sharing the first L characters, L = max of the two adjacent LCP values
     np_q = 4_000_000
     d_nodes = torch.zeros((np_q, 5), dtype=torch.int64, device=dev)
     gpu.parent_device(d_out.data_ptr(), np_q, d_nodes.data_ptr(), st)
     torch.cuda.synchronize()
     lcpv = torch.from_numpy(ix.lcp_data[: ix.n]).to(dev)
-    r = exp[:np_q]
-    right = torch.where(r + 1 < ix.n, lcpv[torch.clamp(r + 1, max=ix.n - 1)].to(torch.int64), torch.zeros_like(r))
-    L = torch.maximum(lcpv[r].to(torch.int64), right)
-    shift = 2 * (k - L)
-    lo = ((r + 1) >> shift) << shift
-    assert torch.equal(d_nodes[:, 0], torch.clamp(lo, min=1) - 1)
-    assert torch.equal(d_nodes[:, 1], torch.clamp(lo + (torch.ones_like(lo) << shift) - 1, max=ix.n) - 1)
-    assert torch.equal(d_nodes[:, 4], L)
-    del lcpv, d_nodes, d_loff, d_lval, d_cnt, d_out1
+    psp, pep, L = dbg_parent_closed_form(dbg, lcpv, exp[:np_q], dbg.values_at(start[:np_q]))
+    assert torch.equal(d_nodes[:, 0], psp) and torch.equal(d_nodes[:, 1], pep) and torch.equal(d_nodes[:, 4], L)
+    assert int(d_nodes[:, 1].max().item()) > (1 << 32)
+    del lcpv, d_nodes, d_loff, d_lval, d_cnt, d_out1, d_out, d_pat
 
-    # config 5: 256-bp patterns, every second one with a substitution every 41 bp
+    # config 5: 256-bp walks, every second one with a substitution every 41 bp
     nq, m = 1_000_000, 256
-    pats, _, d_off, start = batch(nq, m, 0x6C5A0050)
+    pats, _, d_off, start, exp = batch(nq, m, 0x6C5A0050)
     nxt = torch.zeros(256, dtype=torch.uint8, device=dev)
     for a, b in zip(b"ACGT", b"CGTA"):
         nxt[a] = b
@@ -231,7 +298,6 @@ def test_whole_human_footprint_closed_form():
         pats[1::2, col] = nxt[pats[1::2, col].to(torch.int64)]
     d_pat = torch.zeros(nq * m + 8, dtype=torch.uint8, device=dev)
     d_pat[: nq * m] = pats.reshape(-1)
-    exp = rank_t[start].to(torch.int64) & 0xFFFFFFFF
     d_find = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
     gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_find.data_ptr(), st)
     d_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev)
@@ -240,11 +306,12 @@ def test_whole_human_footprint_closed_form():
     gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), st)
     torch.cuda.synchronize()
     assert torch.equal(d_find[0::2, 0], exp[0::2]) and torch.equal(d_find[0::2, 1], exp[0::2])
-    assert bool((d_find[1::2, 0] > d_find[1::2, 1]).all())          # a substituted pattern does not occur (every 16-mer is unique)
+    # (a substituted walk is found only if its changed 18-mers happen to be junction edges of the graph: almost never)
+    assert float((d_find[1::2, 0] > d_find[1::2, 1]).to(torch.float64).mean().item()) > 0.95
     ms2d = d_ms[: nq * m].view(nq, m)
     assert torch.equal(d_rng[0::2, 0], exp[0::2]) and torch.equal(d_rng[0::2, 1], exp[0::2]) and bool((d_fb[0::2] == 0).all())
     assert bool((ms2d[0::2] == (m - torch.arange(m, device=dev)).to(torch.int16).view(1, m)).all())
-    assert bool((d_fb[1::2] > 0).all())
+    assert float(d_fb[1::2].to(torch.float64).mean().item()) > 5
     # locate() of the final ranges: count() values each (query_gcsa.cpp:171-179), closed form for the unmodified half
     d_loff = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
     d_cnt = torch.zeros(nq, dtype=torch.int64, device=dev)
@@ -257,7 +324,6 @@ def test_whole_human_footprint_closed_form():
     assert torch.equal(d_loff[1:] - d_loff[:-1], d_cnt)
     assert np.array_equal(d_lval[d_loff[:-1][0::2]].cpu().numpy().view(np.uint64), mseq_torch.node_values(start[0::2].cpu().numpy()))
     # the oracle on a sample: find, matching statistics (LF + parent), parent of the final ranges
-    cpu = OracleIndex(ix, with_samples=False, with_counters=False)
     ns = 3000
     flat = d_pat[: ns * m].cpu().numpy()
     off = np.arange(ns + 1, dtype=np.uint64) * np.uint64(m)

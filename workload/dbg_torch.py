@@ -38,13 +38,14 @@ import numpy as np
 import torch
 
 from .graphs import SIGMA, FAST_CHARS, default_char2comp
-from .index_arrays import IndexArrays, bit_length, build_lcp_tree
+from .index_arrays import IndexArrays, bit_length
 from .linear_torch import pack_bits_torch, _lsr, _s64
 from .mseq_torch import NODE_LEN, node_values, splitmix64_range_torch
 
 # tap lists of a[n + d] = XOR a[n + d - tap] whose cycle through state 1 has (2^d - 1) / 3 states (verified at run time
 # by gcsa_lfsr_text; found by exhaustive search over 2- and 4-tap recurrences)
-LFSR = {8: [8, 7, 3, 1], 10: [10, 3, 2, 1], 12: [12, 11, 2, 1], 16: [16, 6, 2, 1], 20: [20, 3, 2, 1], 34: [34, 7]}
+LFSR = {8: [8, 7, 3, 1], 10: [10, 3, 2, 1], 12: [12, 11, 2, 1], 16: [16, 6, 2, 1], 20: [20, 3, 2, 1], 24: [24, 22, 11, 1],
+        28: [28, 3, 2, 1], 34: [34, 7]}
 
 SNP_SEED = 0x6C5A0043
 
@@ -204,7 +205,33 @@ def dbg_lcp(nodes: NodeSet, k: int, device, branching: int = 64, chunk_bits: int
         prev = vals[-1:].clone()
         del vals, left, x, q
     lcp[0] = 0
-    return build_lcp_tree(lcp.cpu().numpy(), branching)
+    return lcp_tree_torch(lcp, branching)
+
+
+def lcp_tree_torch(lcp: torch.Tensor, branching: int):
+    """== index_arrays.build_lcp_tree (levels and data as LCPArray::LCPArray lays them out, src/lcp.cpp:224-259), with the
+    level minima taken on the device; returns host arrays."""
+    n = int(lcp.shape[0])
+    sizes = [n]
+    while sizes[-1] > 1:
+        sizes.append((sizes[-1] + branching - 1) // branching)
+    offsets = np.zeros(len(sizes) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(sizes)
+    data = np.empty(int(offsets[-1]), dtype=np.uint8)
+    level = lcp
+    at = 0
+    for size in sizes:
+        assert int(level.shape[0]) == size
+        data[at: at + size] = level.cpu().numpy()
+        at += size
+        if size == 1:
+            break
+        whole = size // branching
+        parts = [level[: whole * branching].view(whole, branching).amin(dim=1)]
+        if whole * branching < size:
+            parts.append(level[whole * branching:].amin().view(1))
+        level = torch.cat(parts)
+    return data, offsets
 
 
 def _empty_extras(zero, branching):
