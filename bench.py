@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the config-5 and chr22 measurements")
     ap.add_argument("--secondary", choices=["all", "config5", "chr22", "human32", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
-    ap.add_argument("--variant", type=int, default=2, help="find kernel generation (1 = k_find, 2 = k_find2)")
+    ap.add_argument("--variant", type=int, default=2, help="find launch shape (2 = one lane per query in batch order, 4 = queries ordered by length first)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
 
@@ -629,7 +629,7 @@ def roofline(args, r, wl, key):
     achieved = r["algo_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9
     traffic = pmc_traffic(args, key, gpu, nq, m)
     ws = working_set(gpu, wl.ix)
-    out = {"bound": "hbm", "kernel": ("k_find2<pair>" if gpu.pair_block_bytes() else "k_find2") if args.variant == 2 else "k_find",
+    out = {"bound": "hbm", "kernel": "k_find2<pair>" if gpu.pair_block_bytes() else "k_find2",
            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
            "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"], "working_set_bytes": ws,
            "working_set_note": ("blocks + seed table the launch gathers from: far beyond the 256 MiB Infinity Cache, served by HBM" if ws > (2 << 30)
@@ -698,7 +698,7 @@ def config5(args, wl, dev):
         return e0.elapsed_time(e1) / reps
 
     ms_time = timed(lambda: gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(),
-                                                   d_fb.data_ptr(), stream.cuda_stream))
+                                                   d_fb.data_ptr(), stream.cuda_stream, total_bytes=nq * m))
     # closed form for the unmodified half: the walk matches to full depth, so no parent() call, the match starting at
     # byte i has length 256 - i, and the final range is the single node of the walk's first k characters
     exp = expected[0::2]

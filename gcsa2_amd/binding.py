@@ -36,7 +36,7 @@ EXPORTS = [
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
     "gcsa2_group_find_batch", "gcsa2_group_find_device", "gcsa2_group_uses_rccl",
     "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_gather",
-    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant",
+    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
     "gcsa2_host_view_parse_gcsa", "gcsa2_host_view_parse_lcp", "gcsa2_host_view_serialize_gcsa", "gcsa2_host_view_serialize_lcp",
@@ -135,6 +135,7 @@ def load_library():
     L.gcsa2_match_stats_batch.argtypes = [vp, u8p, u64p, u64, vp, u64p, u64p]
     L.gcsa2_match_stats_device.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.gcsa2_match_stats_device_variant.argtypes = [vp, C.c_int, vp, vp, u64, vp, vp, vp, vp]
+    L.gcsa2_match_stats_device_sized.argtypes = [vp, C.c_int, vp, vp, u64, u64, vp, vp, vp, vp]
     L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
     L.gcsa2_group_destroy.argtypes = [vp]
     L.gcsa2_group_destroy.restype = None
@@ -468,8 +469,14 @@ class GCSA:
                                                _p64(ranges), _p64(fallbacks)))
         return ms[: int(offsets[nq])], ranges, fallbacks
 
-    def match_stats_device(self, d_patterns, d_offsets, nq, d_ms, d_ranges, d_fallbacks=0, stream=0, variant=0):
-        _check(self._L.gcsa2_match_stats_device_variant(self._h, variant, d_patterns, d_offsets, nq, d_ms, d_ranges, d_fallbacks, stream))
+    def match_stats_device(self, d_patterns, d_offsets, nq, d_ms, d_ranges, d_fallbacks=0, stream=0, variant=0, total_bytes=None):
+        """total_bytes = offsets[nq] when the caller knows it: the call then only enqueues (otherwise it reads that
+        value back from the device, which waits for the stream once)."""
+        if total_bytes is None:
+            _check(self._L.gcsa2_match_stats_device_variant(self._h, variant, d_patterns, d_offsets, nq, d_ms, d_ranges, d_fallbacks, stream))
+        else:
+            _check(self._L.gcsa2_match_stats_device_sized(self._h, variant, d_patterns, d_offsets, nq, int(total_bytes), d_ms, d_ranges,
+                                                          d_fallbacks, stream))
 
     def count_kmers(self, k, include_Ns=False, force=False):
         """`countKMers` (reference src/algorithms.cpp:387-421)."""

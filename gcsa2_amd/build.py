@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "gcsa2_hip.hip")
 DEPS = [SRC, os.path.join(os.path.dirname(HERE), "include", "gcsa2_hip.h")] + \
        [os.path.join(HERE, "csrc", f) for f in ("layout.hpp", "kernels_common.hpp", "kernels_find.hpp",
-                                                 "kernels_locate.hpp", "kernels_lcp.hpp", "sdsl_reader.hpp", "comm.hpp")]
+                                                 "kernels_locate.hpp", "kernels_lcp.hpp", "sdsl_reader.hpp", "sdsl_writer.hpp", "comm.hpp")]
 OUT = os.path.join(HERE, "lib", "libgcsa2_hip.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",

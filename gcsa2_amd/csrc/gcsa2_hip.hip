@@ -79,6 +79,14 @@ struct gcsa2_index
   int compute_units = 256;
   u64 bytes = 0;
   u64 order = 0;
+  // tuning knobs, read from the environment ONCE, when the index is created (A/B measurements; results never depend on them)
+  struct Tuning
+  {
+    u32 cool_down = COOL_DOWN;         // GCSA2_COOL_DOWN: characters stepped singly after a step that needed parent()
+    u32 ms_refill_at = MS_REFILL_AT;   // GCSA2_MS_REFILL_AT: persistent matching statistics, idle lanes of a wave that trigger a refill
+    u64 ms_grid = 0;                   // GCSA2_MS_GRID: ... most workgroups launched (0: what the device holds at once)
+    u32 sort_medium_limit = 0;         // GCSA2_SORT_MEDIUM=0 sends the 17..1024-value locate segments to the segmented radix sort
+  } tune;
 };
 
 struct gcsa2_locate_job
@@ -494,9 +502,25 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
   if(count <= 0) { return fail(GCSA2_ERR_NO_DEVICE, "no HIP device visible: " + g_error); }
   if(device < 0 || device >= count) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "device index out of range"); }
 
+  if(v->path_nodes > MAX_PATH_NODES || v->edges > 2 * MAX_PATH_NODES)
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "index of more than 2^38 path nodes: beyond what one device holds and what the block indices of this build address");
+  }
   gcsa2_index* ix = new(std::nothrow) gcsa2_index();
   if(ix == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
   ix->device = device; ix->order = v->order;
+  {
+    auto knob = [](const char* name, long fallback, long lo, long hi) -> long
+    {
+      const char* e = std::getenv(name);
+      long val = (e != nullptr && *e != 0 ? std::atol(e) : fallback);
+      return val < lo ? lo : (val > hi ? hi : val);
+    };
+    ix->tune.cool_down = u32(knob("GCSA2_COOL_DOWN", COOL_DOWN, 0, 1000));
+    ix->tune.ms_refill_at = u32(knob("GCSA2_MS_REFILL_AT", MS_REFILL_AT, 1, 64));
+    ix->tune.ms_grid = u64(knob("GCSA2_MS_GRID", 0, 0, long(1) << 30));
+    ix->tune.sort_medium_limit = (knob("GCSA2_SORT_MEDIUM", 1, 0, 1) == 0 ? SMALL_SEGMENT : MEDIUM_SEGMENT);
+  }
   std::memset(&ix->img, 0, sizeof(DevImage));
   DevImage& img = ix->img;
   img.n = v->path_nodes; img.e = v->edges; img.sigma = v->sigma; img.fast_chars = v->fast_chars;
@@ -711,14 +735,14 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
   if(!table_guard.ok) { gcsa2_index_destroy(ix); return fail(GCSA2_ERR_HIP, "hipSetDevice failed"); }
 
   // memoised locate walks: 8 bytes per path node, built with the walk kernel itself.  Optional: skipped
-  // when GCSA2_LOCATE_TABLE=0, when it would take more than a quarter of the free memory, or when an
+  // when GCSA2_LOCATE_TABLE=0, when it would take more than a third of the free memory, or when an
   // entry does not fit (then locate() walks as before).
   ix->img.locate_tab = nullptr;
   {
     const char* env = std::getenv("GCSA2_LOCATE_TABLE");
     size_t free_bytes = 0, total_bytes = 0;
     bool wanted = ix->img.has_samples && ix->img.pred4 != nullptr && ix->img.n > 0 && !(env != nullptr && std::atoi(env) == 0);
-    if(wanted && hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && ix->img.n * sizeof(u64) <= free_bytes / 4)
+    if(wanted && hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && ix->img.n * sizeof(u64) <= free_bytes / 3)
     {
       u32* d_overflow = nullptr; u32 overflow = 1;
       hipError_t e = hipMalloc(&ix->d_locate, ix->img.n * sizeof(u64));
@@ -856,13 +880,13 @@ int simple_batch(const gcsa2_index* ix, const uint64_t* in, u64 in_words, uint64
 }
 
 // k_find2 instantiation for this image: JUMP with the jump table, PAIR with the pair blocks
-template<bool STATS, bool REFILL>
+template<bool STATS>
 void launch_find2(const gcsa2_index* ix, unsigned grid, hipStream_t st, const uint8_t* d_patterns, const uint64_t* d_offsets, u64 nq,
-                  uint64_t* d_ranges, unsigned long long* d_stats, const u32* perm, unsigned long long* queue)
+                  uint64_t* d_ranges, unsigned long long* d_stats, const u32* perm)
 {
   const bool jump = ix->img.jump_tab != nullptr, pair = ix->img.flp != nullptr;
-#define G2_FIND2(J, P) hipLaunchKernelGGL((k_find2<STATS, REFILL, J, true, P>), dim3(grid), dim3(TPB2), 0, st, \
-                                          ix->img, d_patterns, d_offsets, nq, d_ranges, d_stats, perm, queue)
+#define G2_FIND2(J, P) hipLaunchKernelGGL((k_find2<STATS, J, P>), dim3(grid), dim3(TPB2), 0, st, \
+                                          ix->img, d_patterns, d_offsets, nq, d_ranges, d_stats, perm)
   if(jump && pair) { G2_FIND2(true, true); }
   else if(jump) { G2_FIND2(true, false); }
   else if(pair) { G2_FIND2(false, true); }
@@ -880,8 +904,8 @@ int gcsa2_find_device(const gcsa2_index* ix, const uint8_t* d_patterns, const ui
   CHECK_INDEX(ix);
   DeviceGuard guard(ix->device);          // the launch goes to the index's device whatever the caller's current one is
   if(nq == 0) { return GCSA2_OK; }
-  launch_find2<false, false>(ix, unsigned((nq + TPB2 - 1) / TPB2), static_cast<hipStream_t>(stream), d_patterns, d_offsets, nq, d_ranges,
-                             nullptr, nullptr, nullptr);
+  launch_find2<false>(ix, unsigned((nq + TPB2 - 1) / TPB2), static_cast<hipStream_t>(stream), d_patterns, d_offsets, nq, d_ranges,
+                      nullptr, nullptr);
   LAUNCH_CHECK("k_find2");
   return GCSA2_OK;
 }
@@ -908,34 +932,14 @@ int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t*
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, len_in, len_out, idx_in, idx_out, int(nq), 0, 32, st);
     if(e == hipSuccess)
     {
-      launch_find2<false, false>(ix, unsigned((nq + TPB2 - 1) / TPB2), st, d_patterns, d_offsets, nq, d_ranges, nullptr, idx_out, nullptr);
+      launch_find2<false>(ix, unsigned((nq + TPB2 - 1) / TPB2), st, d_patterns, d_offsets, nq, d_ranges, nullptr, idx_out);
       e = hipGetLastError();
     }
     (void)hipFreeAsync(tmp, st); (void)hipFreeAsync(len_in, st);    // stream-ordered: freed after the kernel
     if(e != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("length-bucketed find: ") + hipGetErrorString(e)); }
     return GCSA2_OK;
   }
-  if(variant == 5)   // persistent waves with work refill
-  {
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    DeviceGuard guard(ix->device);
-    unsigned long long* queue = nullptr;
-    HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), st));
-    u64 resident = u64(ix->compute_units) * 9;                    // workgroups the LDS footprint lets a CU hold
-    u64 wanted = (nq + TPB2 - 1) / TPB2;
-    launch_find2<false, true>(ix, unsigned(wanted < resident ? wanted : resident), st, d_patterns, d_offsets, nq, d_ranges, nullptr, nullptr, queue);
-    hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(queue, st);
-    if(e != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_find2<refill>: ") + hipGetErrorString(e)); }
-    return GCSA2_OK;
-  }
-  if(variant != 1) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown find variant"); }
-  DeviceGuard guard(ix->device);
-  hipLaunchKernelGGL(k_find<false>, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
-                     ix->img, d_patterns, d_offsets, nq, d_ranges, (unsigned long long*)nullptr);
-  LAUNCH_CHECK("k_find");
-  return GCSA2_OK;
+  return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown find variant (2: default, 4: queries ordered by pattern length first)");
 }
 
 int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets,
@@ -946,8 +950,8 @@ int gcsa2_find_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, co
   if(d_stats == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null stats buffer"); }
   if(nq == 0) { return GCSA2_OK; }
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64 atomics");
-  launch_find2<true, false>(ix, unsigned((nq + TPB2 - 1) / TPB2), static_cast<hipStream_t>(stream), d_patterns, d_offsets, nq, d_ranges,
-                            reinterpret_cast<unsigned long long*>(d_stats), nullptr, nullptr);
+  launch_find2<true>(ix, unsigned((nq + TPB2 - 1) / TPB2), static_cast<hipStream_t>(stream), d_patterns, d_offsets, nq, d_ranges,
+                     reinterpret_cast<unsigned long long*>(d_stats), nullptr);
   LAUNCH_CHECK("k_find2<stats>");
   return GCSA2_OK;
 }
@@ -1043,8 +1047,7 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, node_counts, node_off, int(nq + 1), stream));
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, raw_counts, raw_off, int(nq + 1), stream));
   // segments with more than one raw value: the only ones removeDuplicates has to touch
-  // GCSA2_SORT_MEDIUM=0 sends the 17..1024-value segments to the segmented radix sort as well (A/B measurements)
-  static const u32 medium_limit = []() { const char* e = std::getenv("GCSA2_SORT_MEDIUM"); return (e != nullptr && std::atoi(e) == 0) ? SMALL_SEGMENT : MEDIUM_SEGMENT; }();
+  const u32 medium_limit = ix->tune.sort_medium_limit;
   hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, medium_limit);
   LAUNCH_CHECK("k_collect_multi");
   unsigned long long totals[6] = {0, 0, 0, 0, 0, 0};
@@ -1794,76 +1797,87 @@ extern "C" int gcsa2_count_kmers(const gcsa2_index* ix, uint64_t k, int include_
   return GCSA2_OK;
 }
 
-// Matching statistics (LF + parent fused); see k_match_stats2.  variant 0 = default (2), 1 = first generation, 2 = one
-// lane per pattern, 5 = persistent lanes that draw patterns from a counter.
-extern "C" int gcsa2_match_stats_device_variant(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets,
-                                                uint64_t nq, uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
+// Matching statistics (LF + parent fused); see k_match_stats2.  variant 0 / 2 = one lane per pattern, 5 = persistent lanes
+// that draw patterns from a counter.  total_bytes = offsets[nq] when the caller knows it (GCSA2_UNKNOWN: read back from the
+// device, which waits for the stream once).
+namespace {
+int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, u64 total_bytes,
+                       uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st)
 {
   CHECK_INDEX(ix);
   DeviceGuard guard(ix->device);
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
-  if(variant != 0 && variant != 1 && variant != 2 && variant != 5) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown matching statistics variant"); }
+  if(variant != 0 && variant != 2 && variant != 5) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown matching statistics variant (0 / 2: one lane per pattern, 5: persistent lanes)"); }
   if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
-  // Tuning knobs, read per call (A/B measurements and the variant tests): GCSA2_MATCH_STATS overrides the variant;
-  // GCSA2_PARENT_BATCH = lanes of a wave that must wait for parent() before the wave runs it; GCSA2_COOL_DOWN =
-  // characters stepped singly after a step that needed parent(); variant 5: GCSA2_MS_REFILL_AT = idle lanes of a wave
-  // that trigger a refill, GCSA2_MS_GRID = most workgroups launched (default: what the device holds at once).
-  auto knob = [](const char* name, long fallback, long lo, long hi) -> long
+  if(total_bytes == GCSA2_UNKNOWN)
   {
-    const char* e = std::getenv(name);
-    long v = (e != nullptr && *e != 0 ? std::atol(e) : fallback);
-    return v < lo ? lo : (v > hi ? hi : v);
-  };
-  int generation = int(knob("GCSA2_MATCH_STATS", variant, 0, 5));
-  if(generation == 0) { generation = 2; }
-  const u32 batch = u32(knob("GCSA2_PARENT_BATCH", PARENT_BATCH, 1, 64));
-  const u32 cool = u32(knob("GCSA2_COOL_DOWN", COOL_DOWN, 0, 1000));
+    HIP_TRY(hipMemcpyAsync(&total_bytes, d_offsets + nq, sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  // pre-pass: the patterns as 2-bit codes, last character first (k_pack_patterns); stream-ordered scratch
+  const u64 words = (total_bytes >> 5) + nq + 2;
+  u64* codes = nullptr; u32* bad = nullptr;
+  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&codes), words * sizeof(u64), st));
+  hipError_t pe = pool_alloc(ix, reinterpret_cast<void**>(&bad), words * sizeof(u32), st);
+  if(pe != hipSuccess) { (void)hipFreeAsync(codes, st); return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("matching statistics scratch: ") + hipGetErrorString(pe)); }
+  hipLaunchKernelGGL(k_pack_patterns, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, codes, bad);
+  const u32 cool = ix->tune.cool_down;
   unsigned short* out = reinterpret_cast<unsigned short*>(d_ms);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   const u64 lanes_grid = (nq + TPB2 - 1) / TPB2;
   const bool pair = ix->img.flp != nullptr;
-  if(generation == 1)
+  unsigned long long* queue = nullptr;
+  if(variant == 5)
   {
-    hipLaunchKernelGGL(k_match_stats, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks);
-  }
-  else if(generation == 5)
-  {
-    const u32 refill_at = u32(knob("GCSA2_MS_REFILL_AT", MS_REFILL_AT, 1, 64));
-    const u64 resident = u64(knob("GCSA2_MS_GRID", long(ix->compute_units) * 8, 1, long(1) << 30));   // 4 waves per SIMD
-    unsigned long long* queue = nullptr;
-    HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), st));
+    const u64 resident = ix->tune.ms_grid != 0 ? ix->tune.ms_grid : u64(ix->compute_units) * 8;   // 4 waves per SIMD
+    hipError_t qe = pool_alloc(ix, reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st);
+    if(qe == hipSuccess) { qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st); }
+    if(qe != hipSuccess) { (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st); return fail(GCSA2_ERR_HIP, std::string("matching statistics queue: ") + hipGetErrorString(qe)); }
     const unsigned grid = unsigned(lanes_grid < resident ? lanes_grid : resident);
     if(pair)
     {
       hipLaunchKernelGGL((k_match_stats2<true, true>), dim3(grid), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool, queue, refill_at);
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad);
     }
     else
     {
       hipLaunchKernelGGL((k_match_stats2<false, true>), dim3(grid), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool, queue, refill_at);
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad);
     }
-    (void)hipFreeAsync(queue, st);
   }
   else if(pair)
   {
     hipLaunchKernelGGL((k_match_stats2<true, false>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool, (unsigned long long*)nullptr, 64u);
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, codes, bad);
   }
   else
   {
     hipLaunchKernelGGL((k_match_stats2<false, false>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, batch, cool, (unsigned long long*)nullptr, 64u);
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, codes, bad);
   }
-  LAUNCH_CHECK("k_match_stats");
+  hipError_t le = hipGetLastError();
+  if(queue != nullptr) { (void)hipFreeAsync(queue, st); }
+  (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st);         // stream-ordered: released after the kernel
+  if(le != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats2: ") + hipGetErrorString(le)); }
   return GCSA2_OK;
+}
+}  // namespace
+
+extern "C" int gcsa2_match_stats_device_variant(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets,
+                                                uint64_t nq, uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
+{
+  return match_stats_launch(ix, variant, d_patterns, d_offsets, nq, GCSA2_UNKNOWN, d_ms, d_ranges, d_fallbacks, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq,
                                         uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
 {
-  return gcsa2_match_stats_device_variant(ix, 0, d_patterns, d_offsets, nq, d_ms, d_ranges, d_fallbacks, stream);
+  return match_stats_launch(ix, 0, d_patterns, d_offsets, nq, GCSA2_UNKNOWN, d_ms, d_ranges, d_fallbacks, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gcsa2_match_stats_device_sized(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq,
+                                              uint64_t total_pattern_bytes, uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
+{
+  return match_stats_launch(ix, variant, d_patterns, d_offsets, nq, total_pattern_bytes, d_ms, d_ranges, d_fallbacks, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq,
@@ -1884,7 +1898,7 @@ extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* pat
   HIP_TRY(lease.up(d_off, offsets, (nq + 1) * sizeof(u64)));
   // ragged batches (longest pattern > 1.25 x the mean) large enough to fill the device go to the persistent lanes
   const bool ragged = nq >= MS_REFILL_MIN && double(longest) * double(nq) > 1.25 * double(total);
-  int rc = gcsa2_match_stats_device_variant(ix, ragged ? 5 : 0, d_pat, d_off, nq, d_ms, d_rng, d_fb, lease.stream());
+  int rc = match_stats_launch(ix, ragged ? 5 : 0, d_pat, d_off, nq, total, d_ms, d_rng, d_fb, lease.stream());
   if(rc != GCSA2_OK) { return rc; }
   HIP_TRY(lease.down(ms, d_ms, total * sizeof(uint16_t)));
   HIP_TRY(lease.down(ranges, d_rng, 2 * nq * sizeof(u64)));

@@ -28,6 +28,23 @@ __device__ __forceinline__ void stage_tables(const DevImage& img, Tables& t)
 
 __device__ __forceinline__ u64 clampu(u64 x, u64 hi) { return x < hi ? x : hi; }
 
+// Block and in-block offset of a position in the FLP128 (192 positions) / FLB128 (384 positions) arrays.  192 = 3 x 64 and
+// 384 = 3 x 128, and positions stay below 2^38 (gcsa2_index_create refuses larger indexes: the blocks of one would not fit
+// any GPU's memory), so the division is ONE 32-bit multiply-high instead of the 64-bit magic multiplication the compiler
+// emits for `pos / 192` -- four of those per LF step were a tenth of the step's instructions.
+constexpr u64 MAX_PATH_NODES = (u64(1) << 38) - 2;
+__device__ __forceinline__ u32 div3_u32(u32 x) { return __umulhi(x, 0xAAAAAAABu) >> 1; }
+__device__ __forceinline__ void pair_block_of(u64 pos, u32& block, u32& offset)
+{
+  const u32 hi = u32(pos >> 6);
+  block = div3_u32(hi); offset = ((hi - 3 * block) << 6) | (u32(pos) & 63);
+}
+__device__ __forceinline__ void flb_block_of(u64 pos, u32& block, u32& offset)
+{
+  const u32 hi = u32(pos >> 7);
+  block = div3_u32(hi); offset = ((hi - 3 * block) << 7) | (u32(pos) & 127);
+}
+
 // pathNodeRange (gcsa.h:253-258)
 __device__ __forceinline__ void path_node_range(const DevImage& img, u64& sp, u64& ep)
 {

@@ -1,4 +1,4 @@
-// kernels_find.hpp -- find() / LF: k_find (v1), the k-mer seed table, k_find2 and k_lf2 over fused 128-byte blocks, LF(path_node), LF_fast / LF_all.
+// kernels_find.hpp -- find() / LF: the k-mer seed table, k_find2 and k_lf2 over fused 128-byte blocks, LF(path_node), LF_fast / LF_all.
 // Part of the single translation unit gcsa2_hip.hip (device code, anonymous namespace).
 #pragma once
 
@@ -7,54 +7,6 @@
 using namespace g2;
 
 namespace {
-
-// STATS = true additionally counts, per launch, the distinct rank blocks fetched and the LF steps
-// executed (the "algorithmic bytes" of the roofline model): stats[0] += blocks,
-// stats[1] += steps.  The timed path is the STATS = false instantiation.
-template<bool STATS>
-__global__ __launch_bounds__(TPB) void k_find(DevImage img, const u8* __restrict__ patterns,
-                                              const u64* __restrict__ offsets, u64 nq,
-                                              u64* __restrict__ out, unsigned long long* __restrict__ stats)
-{
-  __shared__ Tables t;
-  stage_tables(img, t);
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  u64 blocks = 0, steps = 0;
-  if(q < nq)
-  {
-    u64 begin = offsets[q], len = offsets[q + 1] - begin;
-    u64 sp = 0, ep = img.n - 1;
-    if(len > 0 && img.n > 0)                                  // gcsa.h:99
-    {
-      const u8* p = patterns + begin;
-      u64 i = len - 1;
-      u32 comp = t.c2c[p[i]];
-      sp = t.C[comp]; ep = t.C[comp + 1] - 1;                 // charRange, utils.h:414-419
-      if(STATS) { blocks += 1 + (block_of(clampu(sp, img.e)) != block_of(clampu(ep, img.e))); }
-      path_node_range(img, sp, ep);                           // gcsa.h:150-153 (no emptiness check)
-      while(!range_empty(sp, ep) && i > 0)                    // gcsa.h:103
-      {
-        i--;
-        comp = t.c2c[p[i]];
-        DevBV bv = bwt_of(img, comp);
-        u64 ra, rb;
-        if(STATS) { steps++; blocks += 1 + (block_of(sp) != block_of(ep + 1)); }
-        bv_rank2(bv, sp, ep + 1, ra, rb);                     // gcsa.h:271-272
-        sp = t.C[comp] + ra; ep = t.C[comp] + rb - 1;
-        if(range_empty(sp, ep)) { break; }                    // gcsa.h:160: edge-space integers
-        if(STATS) { blocks += 1 + (block_of(sp) != block_of(ep)); }
-        path_node_range(img, sp, ep);                         // gcsa.h:161
-      }
-    }
-    reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep);
-  }
-  if(STATS)
-  {
-    // wave reduction, one atomic per wave
-    for(int o = 32; o > 0; o >>= 1) { blocks += __shfl_down(blocks, o, 64); steps += __shfl_down(steps, o, 64); }
-    if((threadIdx.x & 63) == 0) { atomicAdd(stats, (unsigned long long)blocks); atomicAdd(stats + 1, (unsigned long long)steps); }
-  }
-}
 
 // ---- k-mer seed table ----------------------------------------------------------------------
 // table[t] = find() of the k-mer whose j-th character FROM THE END has comp 1 + ((t >> 2j) & 3):
@@ -211,32 +163,6 @@ __device__ __forceinline__ u32 pair_outcome(const PairEnd& s, const PairEnd& e, 
   return 1;
 }
 
-// One lane evaluates LF(range, comp) from the fused blocks on its own (no cooperation): used where
-// lanes run independently (matching statistics).  Returns the edge-space pair (a, b) and, when it is
-// not empty, the node-space range.  One 128-byte block per endpoint instead of two dependent
-// 64-byte fetches (B_c, then edges).
-__device__ __forceinline__ void lf_fused_lane(const DevImage& img, u32 comp, u64 sp, u64 ep,
-                                              u64& a, u64& b, u64& nsp, u64& nep)
-{
-  const u64 e1 = ep + 1;
-  const u64 b_sp = sp / FLB_BITS, b_ep = e1 / FLB_BITS;
-  const u64* base = img.flb + u64(comp) * img.flb_nblocks * FLB_WORDS;
-  ulonglong2 blk[8];
-  const ulonglong2* src = reinterpret_cast<const ulonglong2*>(base + b_sp * FLB_WORDS);
-#pragma unroll
-  for(u32 k = 0; k < 8; k++) { blk[k] = src[k]; }
-  u64 e_ep, n_ep;
-  eval_endpoint(blk, u32(sp - b_sp * FLB_BITS), 0, a, nsp);
-  if(b_ep != b_sp)
-  {
-    src = reinterpret_cast<const ulonglong2*>(base + b_ep * FLB_WORDS);
-#pragma unroll
-    for(u32 k = 0; k < 8; k++) { blk[k] = src[k]; }
-  }
-  eval_endpoint(blk, u32(e1 - b_ep * FLB_BITS), 1, e_ep, n_ep);
-  b = e_ep - 1; nep = n_ep;
-}
-
 // LF_fast / LF_all (src/gcsa.cpp:742-798) of one range for the N comps c0 .. c0 + N - 1 (those <= limit),
 // one lane per range.  The N first-block loads are issued unconditionally (an inactive comp reads block 0)
 // so that they are all in flight together; children[j] is the node-space range when it is non-empty,
@@ -351,11 +277,6 @@ __device__ __forceinline__ PairEnd eval_staged(const ulonglong2* wave_stage, u32
   return out;
 }
 
-// REFILL = true: persistent waves.  Lanes do not own a fixed query; whenever at least half of a
-// wave's lanes are idle (their chains ended early: mismatches, short patterns) the idle lanes draw
-// new query ids from a global counter (one wave-aggregated atomic) and start them, so that a batch
-// mixing hits and misses keeps all 64 lanes busy.  `queue` points to that counter (zeroed by the
-// host); the grid is sized to the machine, not to the batch.
 // Jump table entry (16 bytes per path node): the forced chain of up to 8 LF steps out of a node -- every
 // node on it has a single incoming label, a fast character -- with the nodes reached after all `len`
 // steps, after 4 steps (len >= 4) and after 2 steps (len >= 2), so that a pattern with fewer characters
@@ -384,12 +305,13 @@ __device__ __forceinline__ ulonglong2 jt_make(u64 end, u64 after4, u64 after2, u
 #ifndef GCSA2_FIND_WAVES
 #define GCSA2_FIND_WAVES 4
 #endif
-template<bool STATS, bool REFILL, bool JUMP = false, bool WINDOW = true, bool PAIR = false>
-__global__ __launch_bounds__(TPB2, (STATS || REFILL || JUMP) ? 4 : GCSA2_FIND_WAVES) void k_find2(DevImage img, const u8* __restrict__ patterns,
+template<bool STATS, bool JUMP = false, bool PAIR = false>
+__global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void k_find2(DevImage img, const u8* __restrict__ patterns,
                                                const u64* __restrict__ offsets, u64 nq,
                                                u64* __restrict__ out, unsigned long long* __restrict__ stats,
-                                               const u32* __restrict__ perm, unsigned long long* __restrict__ queue)
+                                               const u32* __restrict__ perm)
 {
+  constexpr bool WINDOW = true;               // the packed pattern window (below); the byte-at-a-time path is kept for reference only
   __shared__ ulonglong2 stage[TPB2 * 8];
   __shared__ Tables2 t;
   if(threadIdx.x < 2 * MAX_SIGMA) { t.crange[threadIdx.x] = img.crange[threadIdx.x]; }
@@ -409,7 +331,6 @@ __global__ __launch_bounds__(TPB2, (STATS || REFILL || JUMP) ? 4 : GCSA2_FIND_WA
   [[maybe_unused]] u64 win_code = 0;       // packed pattern window (see below)
   [[maybe_unused]] u32 win_used = ~u32(0), win_bad = 0;      // characters consumed since the window was loaded (~0: no window)
   [[maybe_unused]] u32 force_single = 0;   // PAIR: characters that must be consumed by single steps (replay)
-  static_assert(!PAIR || WINDOW, "pair steps read the packed pattern window");
   u64 word = 0, word_addr = ~u64(0);        // pattern bytes are consumed back to front from aligned 8-byte words
   auto byte_at = [&](u64 pos) -> u32
   {
@@ -459,44 +380,16 @@ __global__ __launch_bounds__(TPB2, (STATS || REFILL || JUMP) ? 4 : GCSA2_FIND_WA
     }
   };
 
-  bool has = false, exhausted = false;      // REFILL: lane holds a query / the queue is empty
-  if constexpr(!REFILL)
   {
     // perm != nullptr: lane g works on query perm[g] (queries ordered by length, so that the 64
     // chains of a wave finish together); results still go to out[query].
     const u64 gid = u64(blockIdx.x) * TPB2 + threadIdx.x;
-    if(gid < nq) { start(perm != nullptr ? u64(perm[gid]) : gid); has = true; }
+    if(gid < nq) { start(perm != nullptr ? u64(perm[gid]) : gid); }
   }
 
   while(true)
   {
-    if constexpr(REFILL)
-    {
-      if(has && done) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); has = false; }
-      const u64 idle = __ballot(!has);
-      if(!exhausted && __popcll(idle) >= 32)
-      {
-        const u32 want = u32(__popcll(idle)), leader = u32(__ffsll((long long)idle)) - 1;
-        unsigned long long base = 0;
-        if(lane == leader) { base = atomicAdd(queue, (unsigned long long)want); }
-        base = __shfl(base, leader, 64);
-        if(!has)
-        {
-          const u64 mine = base + __popcll(idle & ((u64(1) << lane) - 1));
-          if(mine < nq) { start(mine); has = true; }
-        }
-        exhausted = (base + want >= nq);
-      }
-      if(!__any(has && !done))
-      {
-        if(exhausted && !__any(has)) { break; }
-        if(!exhausted || __any(has)) { continue; }            // retire / refill in the next round
-      }
-    }
-    else
-    {
-      if(!__any(!done)) { break; }
-    }
+    if(!__any(!done)) { break; }
     // JUMP: a range of one path node whose next <= 8 predecessors are forced (a single incoming label
     // each) and spell the next pattern characters moves there with ONE 16-byte lookup.  Same result as
     // stepping: LF of a single node with a matching label is the single node behind that edge.
@@ -547,10 +440,10 @@ __global__ __launch_bounds__(TPB2, (STATS || REFILL || JUMP) ? 4 : GCSA2_FIND_WA
           if(pair)
           {
             const u32 c2 = u32(win_code >> (2 * r)) & 3, c1 = u32(win_code >> (2 * r + 2)) & 3;
-            const u64 b_sp = sp / PAIR_BITS, b_ep = (ep + 1) / PAIR_BITS;
-            r_sp = u32(sp - b_sp * PAIR_BITS); r_ep = u32(ep + 1 - b_ep * PAIR_BITS);
-            const u64 first = u64(c1 * 4 + c2) * img.flp_nblocks;
-            idx_sp = u32(first + b_sp) | PAIR_FLAG; idx_ep = u32(first + b_ep) | PAIR_FLAG;
+            u32 b_sp, b_ep;
+            pair_block_of(sp, b_sp, r_sp); pair_block_of(ep + 1, b_ep, r_ep);
+            const u32 first = (c1 * 4 + c2) * u32(img.flp_nblocks);
+            idx_sp = (first + b_sp) | PAIR_FLAG; idx_ep = (first + b_ep) | PAIR_FLAG;
           }
         }
       }
@@ -569,9 +462,9 @@ __global__ __launch_bounds__(TPB2, (STATS || REFILL || JUMP) ? 4 : GCSA2_FIND_WA
           else { comp = 1 + (u32(win_code >> (2 * r)) & 3); }
         }
         else { comp = t.c2c[byte_at(i)]; }
-        u64 b_sp = sp / FLB_BITS, b_ep = (ep + 1) / FLB_BITS;
-        r_sp = u32(sp - b_sp * FLB_BITS); r_ep = u32(ep + 1 - b_ep * FLB_BITS);
-        idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
+        u32 b_sp, b_ep;
+        flb_block_of(sp, b_sp, r_sp); flb_block_of(ep + 1, b_ep, r_ep);
+        idx_sp = comp * u32(img.flb_nblocks) + b_sp; idx_ep = comp * u32(img.flb_nblocks) + b_ep;
       }
     }
     PairEnd p_sp = {0, 0, 0}, p_ep = {0, 0, 0};   // a single step keeps (edge, node) in .raw / .node: one set of registers
@@ -664,7 +557,6 @@ __global__ __launch_bounds__(TPB2, (STATS || REFILL || JUMP) ? 4 : GCSA2_FIND_WA
       }
     }
   }
-  if constexpr(!REFILL)
   {
     const u64 gid = u64(blockIdx.x) * TPB2 + threadIdx.x;     // recomputed: the query id is not held across the loop
     if(gid < nq) { reinterpret_cast<ulonglong2*>(out)[perm != nullptr ? u64(perm[gid]) : gid] = make_ulonglong2(sp, ep); }
@@ -768,9 +660,9 @@ __global__ __launch_bounds__(TPB2) void k_lf2(DevImage img, const u64* __restric
     if(comp >= img.sigma) { comp = u32(img.sigma - 1); }     // memory safety only
     sp = clampu(r.x, img.n);
     u64 e1 = clampu(r.y + 1, img.n);
-    u64 b_sp = sp / FLB_BITS, b_ep = e1 / FLB_BITS;
-    r_sp = u32(sp - b_sp * FLB_BITS); r_ep = u32(e1 - b_ep * FLB_BITS);
-    idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
+    u32 b_sp, b_ep;
+    flb_block_of(sp, b_sp, r_sp); flb_block_of(e1, b_ep, r_ep);
+    idx_sp = comp * u32(img.flb_nblocks) + b_sp; idx_ep = comp * u32(img.flb_nblocks) + b_ep;
   }
   ulonglong2 blk[8];
   u64 e_sp = 0, n_sp = 0, e_ep = 0, n_ep = 0;

@@ -348,52 +348,46 @@ __global__ __launch_bounds__(TPB) void k_lcp_access(DevImage img, const u64* __r
 // empty, replace the range by its parent (lcp.cpp:276-301) and retry; at the root the character is
 // skipped.  ms[offset + i] = length of the longest match starting at i (capped at 65535), the final
 // range is the one of position 0.  Paper: paper.tex:344 (after Ohlebusch et al. 2010).
-__global__ __launch_bounds__(TPB) void k_match_stats(DevImage img, const u8* __restrict__ patterns,
-                                                     const u64* __restrict__ offsets, u64 nq,
-                                                     unsigned short* __restrict__ ms, u64* __restrict__ ranges,
-                                                     u64* __restrict__ fallbacks)
+
+// Pre-pass of k_match_stats2: every pattern as 2-bit codes, LAST character first.  Code word j of pattern q lives at
+// index (offsets[q] >> 5) + q + j (consecutive patterns never overlap: floor((o + len) / 32) + 1 - floor(o / 32) >=
+// ceil(len / 32)) and holds the characters at distance t = 32 j .. 32 j + 31 from the pattern's end, t at bits
+// [2 (t & 31), 2 (t & 31) + 2) = comp - 1 of a fast character; bit (t & 31) of `bad` word j marks any other character
+// and the positions past the pattern's first character.  The step loop then refills its 32-character window with two
+// word loads and a funnel shift.  Round 2's kernel translated the bytes itself, a 32-iteration loop per refill; once
+// the lanes of a wave diverge some lane refills in nearly every round and the whole wave pays for the loop -- it was
+// about a third of the VALU instructions on a branching index (profiles/r03_match_stats.md).
+__global__ __launch_bounds__(TPB) void k_pack_patterns(DevImage img, const u8* __restrict__ patterns, const u64* __restrict__ offsets,
+                                                      u64 nq, u64* __restrict__ codes, u32* __restrict__ bad)
 {
-  __shared__ Tables t;
-  stage_tables(img, t);
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  __shared__ u8 c2c[256];
+  c2c[threadIdx.x] = img.char2comp[threadIdx.x];
+  __syncthreads();
+  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q >= nq) { return; }
-  u64 begin = offsets[q], len = offsets[q + 1] - begin;
-  const u8* p = patterns + begin;
-  u64 sp = 0, ep = img.n - 1, depth = 0, calls = 0;
-  u64 word = 0, word_addr = ~u64(0);        // pattern bytes: back to front from aligned 8-byte words (one load per 8 steps)
-  u64 packed = 0; u32 have = 0;             // results: four u16 per aligned 8-byte store
-  for(u64 i = len; i-- > 0; )
+  const u64 begin = offsets[q], len = offsets[q + 1] - begin;
+  const u64 first_word = (begin >> 5) + q, words = (len + 31) >> 5;
+  for(u64 j = 0; j < words; j++)
   {
-    u64 addr = reinterpret_cast<u64>(p) + i, aligned = addr & ~u64(7);
-    if(aligned != word_addr) { word = *reinterpret_cast<const u64*>(aligned); word_addr = aligned; }
-    u32 comp = t.c2c[u32(word >> ((addr & 7) * 8)) & 0xFF];
-    while(true)
+    const u64 high = len - 32 * j;                              // one past the pattern position of t = 32 j
+    const u64 count = (high < 32 ? high : 32), low = reinterpret_cast<u64>(patterns) + begin + high - count;
+    const u64 base = low & ~u64(7), last = (low + count - 1) & ~u64(7);
+    u64 w[5];
+#pragma unroll
+    for(u32 k = 0; k < 5; k++) { const u64 a = base + 8 * k; w[k] = *reinterpret_cast<const u64*>(a < last ? a : last); }
+    u64 code = 0; u32 flags = (count < 32 ? ~u32(0) << count : 0u);
+    for(u32 r = 0; r < count; r++)
     {
-      u64 a, b, nsp, nep;
-      lf_fused_lane(img, comp, sp, ep, a, b, nsp, nep);          // gcsa.h:155-162
-      if(!range_empty(a, b))
-      {
-        sp = nsp; ep = nep; depth++;
-        break;
-      }
-      if(sp == 0 && ep == img.n - 1) { depth = 0; break; }     // at the root: no such character
-      gcsa2_stnode node;
-      lcp_parent(img, sp, ep, node); calls++;
-      sp = node.sp; ep = node.ep; depth = node.node_lcp;
+      const u64 at = (low - base) + (count - 1 - r);           // byte offset of the character at distance 32 j + r from the end
+      u64 word = w[0];
+#pragma unroll
+      for(u32 k = 1; k < 5; k++) { if((at >> 3) == k) { word = w[k]; } }
+      const u32 c = u32(c2c[u32(word >> ((at & 7) * 8)) & 0xFF]) - 1;
+      code |= u64(c & 3) << (2 * r);
+      flags |= u32(c < 4 ? 0 : 1) << r;
     }
-    const u64 idx = begin + i;
-    const u32 slot = u32(idx & 3);
-    packed |= u64(depth > 65535 ? 65535 : depth) << (16 * slot); have |= 1u << slot;
-    if(slot == 0 || i == 0)                   // the group of four is complete, or the pattern ends inside it
-    {
-      unsigned short* group = ms + (idx & ~u64(3));
-      if(have == 15u) { *reinterpret_cast<u64*>(group) = packed; }
-      else { for(u32 s = 0; s < 4; s++) { if((have >> s) & 1) { group[s] = (unsigned short)(packed >> (16 * s)); } } }
-      packed = 0; have = 0;
-    }
+    codes[first_word + j] = code; bad[first_word + j] = flags;
   }
-  reinterpret_cast<ulonglong2*>(ranges)[q] = make_ulonglong2(sp, ep);
-  if(fallbacks != nullptr) { fallbacks[q] = calls; }
 }
 
 // parent() of (sp, ep) from the two aligned 16-byte chunks of the LCP array that hold LCP[sp] and LCP[ep + 1]
@@ -436,10 +430,8 @@ __device__ __forceinline__ bool parent_from_chunks(const DevImage& img, u64 sp, 
 // Same results as k_match_stats.  One lane = one pattern; the LF steps of the 64 patterns of a wave go through the
 // cooperative fetch of k_find2 (one 128-byte request per endpoint, FLP128 pair blocks when the next two
 // characters are fast characters and the block proves that neither step empties -- both matching statistics
-// then follow at once: depth + 1 and depth + 2).  A lane whose step empties waits (need_parent) until PARENT_BATCH
-// lanes of its wave wait or nothing else can step (default 1: at once -- batching more lanes measured slower, profiles/r02_config5.md); the wave then runs LCPArray::parent (lcp.cpp:276-301) for all
-// waiting lanes together, so that the divergent tree walks cost one pass per batch instead of one per step.
-constexpr u32 PARENT_BATCH = 1;
+// then follow at once: depth + 1 and depth + 2).  A lane whose step empties runs LCPArray::parent (lcp.cpp:276-301) in the
+// same round and retries the character in the next one.
 // After a step that needed parent() the next COOL_DOWN characters are stepped singly: right after a mismatch the match is
 // short and the following characters fail often, so a pair attempt mostly wastes its round (deep suffix tree, 37 parent()
 // calls per pattern: 60 -> 68 M patterns/s with 6; 3 / 12 / 24 give 67 / 67 / 66; profiles/r02_config5.md).
@@ -458,8 +450,9 @@ template<bool PAIR, bool REFILL>
 __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8* __restrict__ patterns,
                                                        const u64* __restrict__ offsets, u64 nq,
                                                        unsigned short* __restrict__ ms, u64* __restrict__ ranges,
-                                                       u64* __restrict__ fallbacks, u32 parent_batch, u32 cool_down,
-                                                       unsigned long long* __restrict__ queue, u32 refill_at)
+                                                       u64* __restrict__ fallbacks, u32 cool_down,
+                                                       unsigned long long* __restrict__ queue, u32 refill_at,
+                                                       const u64* __restrict__ codes, const u32* __restrict__ bad)
 {
   __shared__ ulonglong2 stage[TPB2 * 8];
   __shared__ u8 c2c[256];
@@ -468,7 +461,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   __syncthreads();
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  u64 q = 0, begin = 0, i = 0;
+  u64 q = 0, begin = 0, i = 0, total = 0;
   bool has = false;
   [[maybe_unused]] bool exhausted = false;
   u64 sp = 0, ep = img.n - 1, depth = 0;
@@ -494,7 +487,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   auto start = [&](u64 query)
   {
     q = query; has = true;
-    begin = offsets[q]; i = offsets[q + 1] - begin;
+    begin = offsets[q]; i = total = offsets[q + 1] - begin;
     sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0);
   };
   if constexpr(!REFILL)
@@ -533,25 +526,17 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       if(!__any(has)) { break; }
     }
     const bool active = has && i > 0;
-    // packed pattern window, as in k_find2: the 32 positions below i + win_used as 2-bit codes + "not a fast character" bits
+    // packed pattern window, as in k_find2: the 32 positions below i as 2-bit codes + "not a fast character" bits, slot r =
+    // position i - 1 - r; refilled from the pre-packed codes (k_pack_patterns): two words and a funnel shift, no loop
     if(active && win_used > 24)
     {
-      win_used = 0; win_code = 0; win_bad = 0;
-      const u64 count = (i < 32 ? i : 32), low = reinterpret_cast<u64>(patterns) + begin + i - count, base = low & ~u64(7);
-      u64 w[5];
-      const u64 last = (low + count - 1) & ~u64(7);
-#pragma unroll
-      for(u32 k = 0; k < 5; k++) { const u64 a = base + 8 * k; w[k] = *reinterpret_cast<const u64*>(a < last ? a : last); }
-      for(u32 r = 0; r < count; r++)
-      {
-        const u64 at = (low - base) + (count - 1 - r);
-        u64 word = w[0];
-#pragma unroll
-        for(u32 k = 1; k < 5; k++) { if((at >> 3) == k) { word = w[k]; } }
-        const u32 c = u32(c2c[u32(word >> ((at & 7) * 8)) & 0xFF]) - 1;
-        win_code |= u64(c & 3) << (2 * r);
-        win_bad |= u32(c < 4 ? 0 : 1) << r;
-      }
+      const u64 t0 = total - i, word = (begin >> 5) + q + (t0 >> 5);
+      const u32 s = u32(t0) & 31;
+      const u64 c0 = codes[word], c1 = codes[word + 1];
+      const u32 b0 = bad[word], b1 = bad[word + 1];
+      win_code = (s == 0 ? c0 : (c0 >> (2 * s)) | (c1 << (64 - 2 * s)));
+      win_bad = (s == 0 ? b0 : (b0 >> s) | (b1 << (32 - s)));
+      win_used = 0;
     }
     const bool stepping = active && !need_parent;
     u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
@@ -567,10 +552,10 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
           if(pair)
           {
             const u32 c2 = u32(win_code >> (2 * r)) & 3, c1 = u32(win_code >> (2 * r + 2)) & 3;
-            const u64 b_sp = sp / PAIR_BITS, b_ep = (ep + 1) / PAIR_BITS;
-            r_sp = u32(sp - b_sp * PAIR_BITS); r_ep = u32(ep + 1 - b_ep * PAIR_BITS);
-            const u64 first = u64(c1 * 4 + c2) * img.flp_nblocks;
-            idx_sp = u32(first + b_sp) | PAIR_FLAG; idx_ep = u32(first + b_ep) | PAIR_FLAG;
+            u32 b_sp, b_ep;
+            pair_block_of(sp, b_sp, r_sp); pair_block_of(ep + 1, b_ep, r_ep);
+            const u32 first = (c1 * 4 + c2) * u32(img.flp_nblocks);
+            idx_sp = (first + b_sp) | PAIR_FLAG; idx_ep = (first + b_ep) | PAIR_FLAG;
           }
         }
       }
@@ -582,9 +567,9 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
           comp = c2c[u32(*reinterpret_cast<const u64*>(addr & ~u64(7)) >> ((addr & 7) * 8)) & 0xFF];
         }
         else { comp = 1 + (u32(win_code >> (2 * r)) & 3); }
-        const u64 b_sp = sp / FLB_BITS, b_ep = (ep + 1) / FLB_BITS;
-        r_sp = u32(sp - b_sp * FLB_BITS); r_ep = u32(ep + 1 - b_ep * FLB_BITS);
-        idx_sp = u32(comp * img.flb_nblocks + b_sp); idx_ep = u32(comp * img.flb_nblocks + b_ep);
+        u32 b_sp, b_ep;
+        flb_block_of(sp, b_sp, r_sp); flb_block_of(ep + 1, b_ep, r_ep);
+        idx_sp = comp * u32(img.flb_nblocks) + b_sp; idx_ep = comp * u32(img.flb_nblocks) + b_ep;
       }
     }
     PairEnd p_sp = {0, 0, 0}, p_ep = {0, 0, 0};                // a single step keeps (edge, node) in .raw / .node
@@ -636,18 +621,14 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }
       }
     }
-    // parent(): for all waiting lanes at once, when enough of them wait or nothing else can move
-    const u64 waiting = __ballot(need_parent);
-    if(waiting != 0 && (u32(__popcll(waiting)) >= parent_batch || !__any(active && !need_parent)))
+    // parent() as soon as a lane needs it (deferring it until more lanes of the wave wait measured slower, profiles/r02_config5.md)
+    if(need_parent)
     {
-      if(need_parent)
-      {
-        gcsa2_stnode node;
-        if(!parent_from_chunks(img, sp, ep, node)) { lcp_parent(img, sp, ep, node); }
-        calls++;
-        sp = node.sp; ep = node.ep; depth = node.node_lcp;
-        need_parent = false;
-      }
+      gcsa2_stnode node;
+      if(!parent_from_chunks(img, sp, ep, node)) { lcp_parent(img, sp, ep, node); }
+      calls++;
+      sp = node.sp; ep = node.ep; depth = node.node_lcp;
+      need_parent = false;
     }
   }
 }

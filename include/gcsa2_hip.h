@@ -142,13 +142,12 @@ int gcsa2_find_device(const gcsa2_index* index, const uint8_t* d_patterns,
                       const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
                       void* stream);
 
-/* Kernel selection.  variant 2 = the default (k_find2, fused 128-byte blocks, what
+/* Launch shape.  variant 2 = the default (k_find2, fused 128-byte blocks, what
  * gcsa2_find_device runs); variant 4 = the same kernel behind a device-side sort of the queries by
  * pattern length, for batches of very uneven lengths (the 64 chains of a wavefront then finish
- * together; results are written in query order as always; stream-ordered scratch, no host sync);
- * variant 5 = k_find2 as persistent wavefronts that refill idle lanes from a global queue, for
- * batches mixing hits and early misses; variant 1 = the first generation (k_find, one lane per
- * query over 64-byte rank blocks), kept for A/B measurements. */
+ * together; results are written in query order as always; stream-ordered scratch, no host sync).
+ * Any other value is refused (rounds 1-2 also shipped a first-generation kernel and persistent
+ * wavefronts as variants 1 and 5; neither won anywhere, both are gone). */
 int gcsa2_find_device_variant(const gcsa2_index* index, int variant, const uint8_t* d_patterns,
                               const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
                               void* stream);
@@ -168,7 +167,7 @@ uint64_t gcsa2_kmer_table_k(const gcsa2_index* index);
 /* Bytes of the memoised locate table (0 = none): the walk of locateInternal (src/gcsa.cpp:880-896)
  * depends on the start node only, so it is run once per path node at create time and locate() reads
  * one 8-byte entry per path node instead of walking.  Needs samples; skipped when it would take
- * more than a quarter of the free device memory or when GCSA2_LOCATE_TABLE=0. */
+ * more than a third of the free device memory or when GCSA2_LOCATE_TABLE=0. */
 uint64_t gcsa2_locate_table_bytes(const gcsa2_index* index);
 /* Bytes of the jump table (0 = none; built when GCSA2_JUMP_TABLE=1): for every path node the chain of
  * up to 8 LF steps that is forced because each node on it has a single incoming label (a fast
@@ -314,13 +313,19 @@ int gcsa2_match_stats_batch(const gcsa2_index* index, const uint8_t* patterns, c
 int gcsa2_match_stats_device(const gcsa2_index* index, const uint8_t* d_patterns, const uint64_t* d_offsets,
                              uint64_t n_queries, uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks,
                              void* stream);
-/* Kernel selection, same results.  variant 0 or 2 = the default (one lane per pattern, wave-cooperative block fetch,
+/* Launch shape, same results.  variant 0 or 2 = the default (one lane per pattern, wave-cooperative block fetch,
  * what gcsa2_match_stats_device runs); variant 5 = the same kernel as persistent wavefronts whose idle lanes draw the
  * next pattern from a counter, for batches of ragged pattern lengths (gcsa2_match_stats_batch chooses it by itself when
- * the longest pattern exceeds 1.25 x the mean); variant 1 = the first generation (no cooperation), kept for A/B runs. */
+ * the longest pattern exceeds 1.25 x the mean).  Any other value is refused.
+ * The kernel reads the patterns as 2-bit codes prepared by a pre-pass into stream-ordered scratch, whose size depends on
+ * d_offsets[n_queries]: gcsa2_match_stats_device and _variant read that value back (ONE wait for `stream` per call);
+ * gcsa2_match_stats_device_sized takes it from the caller (total_pattern_bytes) and only enqueues. */
 int gcsa2_match_stats_device_variant(const gcsa2_index* index, int variant, const uint8_t* d_patterns,
                                      const uint64_t* d_offsets, uint64_t n_queries, uint16_t* d_ms,
                                      uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream);
+int gcsa2_match_stats_device_sized(const gcsa2_index* index, int variant, const uint8_t* d_patterns,
+                                   const uint64_t* d_offsets, uint64_t n_queries, uint64_t total_pattern_bytes,
+                                   uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream);
 
 /* ---- host-view container file ("G2HV") ---------------------------------------------------
  * Interchange between a process that can read .gcsa / .lcp files (the reference linked with SDSL:

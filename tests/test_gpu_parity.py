@@ -245,28 +245,41 @@ def test_match_stats(case):
     assert np.array_equal(gr, cr) and np.array_equal(gf, cf), name
 
 
-@pytest.mark.parametrize("knobs", [
-    {"GCSA2_MATCH_STATS": "1"},                                                             # first-generation kernel
-    {"GCSA2_MATCH_STATS": "5", "GCSA2_MS_GRID": "2", "GCSA2_MS_REFILL_AT": "1"},            # persistent lanes, eager refill
-    {"GCSA2_MATCH_STATS": "5", "GCSA2_MS_GRID": "3"},
-    {"GCSA2_MATCH_STATS": "5", "GCSA2_MS_GRID": "1", "GCSA2_MS_REFILL_AT": "64"},           # refill only when a wave is empty
-    {"GCSA2_MATCH_STATS": "5"},
-    {"GCSA2_COOL_DOWN": "0", "GCSA2_PARENT_BATCH": "16"},
-    {"GCSA2_MATCH_STATS": "5", "GCSA2_MS_GRID": "2", "GCSA2_COOL_DOWN": "12", "GCSA2_PARENT_BATCH": "64"},
+@pytest.mark.parametrize("variant,knobs", [
+    (5, {"GCSA2_MS_GRID": "2", "GCSA2_MS_REFILL_AT": "1"}),             # persistent lanes, eager refill
+    (5, {"GCSA2_MS_GRID": "3"}),
+    (5, {"GCSA2_MS_GRID": "1", "GCSA2_MS_REFILL_AT": "64"}),            # refill only when a wave is empty
+    (5, {}),
+    (0, {"GCSA2_COOL_DOWN": "0"}),
+    (5, {"GCSA2_MS_GRID": "2", "GCSA2_COOL_DOWN": "12"}),
 ])
-def test_match_stats_kernel_variants(case, knobs, monkeypatch):
-    """Every launch shape of the matching-statistics kernel (gcsa2_match_stats_device reads its knobs per call) returns
-    the oracle's statistics, ranges and parent() counts -- in particular the persistent lanes that draw patterns from a
-    counter, which small batches do not use by default."""
+def test_match_stats_kernel_variants(case, engine, variant, knobs, monkeypatch):
+    """Every launch shape of the matching-statistics kernel returns the oracle's statistics, ranges and parent() counts --
+    in particular the persistent lanes that draw patterns from a counter, which small batches do not use by default.  The
+    tuning knobs are read once, when an index is created; the variant is an argument."""
+    import torch
     name, g, K, ix, gpu, lcp, cpu = case
     pats = [p for p in random_patterns(g, 3 * K, 0x95, 1500)] + [b"", b"N", b"", b"ACGTNACGT", b"$", b"#A", b""]
     data, off = concat_patterns(pats)
     cm, cr, cf = cpu.match_stats_batch(data, off, threads=2)
     for key, value in knobs.items():
         monkeypatch.setenv(key, value)
-    gm, gr, gf = gpu.match_stats_batch(data, off)
-    assert np.array_equal(gm, cm), (name, knobs)
-    assert np.array_equal(gr, cr) and np.array_equal(gf, cf), (name, knobs)
+    tuned, _ = engine.open_index(ix, device=0)
+    dev = torch.device("cuda", 0)
+    nq, total = len(pats), int(off[-1])
+    d_pat = torch.zeros(total + 16, dtype=torch.uint8, device=dev)
+    d_pat[:total] = torch.from_numpy(data[:total]).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    for sized in (False, True):
+        d_ms = torch.full((total + 8,), -3, dtype=torch.int16, device=dev)
+        d_rng = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+        d_fb = torch.zeros(nq, dtype=torch.int64, device=dev)
+        tuned.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), 0,
+                                 variant=variant, total_bytes=(total if sized else None))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_ms[:total].cpu().numpy().view(np.uint16), cm), (name, variant, knobs)
+        assert np.array_equal(d_rng.cpu().numpy().view(np.uint64), cr) and np.array_equal(d_fb.cpu().numpy().view(np.uint64), cf), (name, variant, knobs)
+    tuned.close()
 
 
 def test_match_stats_ragged_host_batch(engine):
@@ -342,8 +355,8 @@ def test_other_alphabet_size(engine):
 
 
 def test_find_variants_on_device(case):
-    """All kernel generations (1 = k_find, 2 = k_find2, 4 = length-bucketed, 5 = persistent waves with refill) through the
-    device-pointer entry point, ragged pattern lengths."""
+    """Both launch shapes of k_find2 (2 = one lane per query in batch order, 4 = queries ordered by pattern length first)
+    through the device-pointer entry point, ragged pattern lengths; the variants dropped in round 3 are refused."""
     import torch
     name, g, K, ix, gpu, lcp, cpu = case
     pats = [truncate_at_sink(p) for p in random_patterns(g, 3 * K, 0x94, 500)] + [b"", b"N", b"$"]
@@ -352,12 +365,16 @@ def test_find_variants_on_device(case):
     dev = torch.device("cuda", 0)
     d_pat = torch.from_numpy(data).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)
-    for variant in (1, 2, 4, 5):
+    for variant in (2, 4):
         d_out = torch.full((len(pats), 2), -7, dtype=torch.int64, device=dev)
         gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(),
                                 torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), (name, variant)
+    from gcsa2_amd.binding import Gcsa2Error
+    for variant in (1, 5, 7):
+        with pytest.raises(Gcsa2Error):
+            gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), 0)
 
 
 def test_create_from_container_file(engine, tmp_path):
@@ -777,7 +794,7 @@ def test_pair_blocks(engine, monkeypatch):
                 assert stats[0][1] == stats[1][1]                  # the same LF steps ...
             if jump == "0":
                 assert stats[1][0] < 0.75 * stats[0][0]            # ... through far fewer blocks
-            for variant in (4, 5):
+            for variant in (4,):
                 d_out.zero_()
                 gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), 0)
                 torch.cuda.synchronize()

@@ -104,12 +104,12 @@ def test_config2_full_size_properties():
     seg = np.repeat(np.arange(sub.shape[0]), np.diff(loff).astype(np.int64))
     same = seg[1:] == seg[:-1]
     assert bool(np.all(lval[1:][same] > lval[:-1][same]))
-    # 4b. both kernel generations agree on the whole batch (device-resident entry points)
+    # 4b. both launch shapes agree on the whole batch (device-resident entry points)
     dev = torch.device("cuda", 0)
     d_pat = torch.from_numpy(flat).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)
     outs = []
-    for variant in (1, 2):
+    for variant in (4, 2):
         d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
         gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(),
                                 torch.cuda.current_stream().cuda_stream)
@@ -212,9 +212,8 @@ def test_pangenome_index_beyond_32_bits():
     gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), st)
     torch.cuda.synchronize()
     assert torch.equal(d_out[:, 0], exp) and torch.equal(d_out[:, 1], exp)
-    # ... also through the first-generation kernel (64-byte rank blocks, no seed table, no pair blocks) and the
-    # length-bucketed launch
-    for variant in (1, 4):
+    # ... also through the length-bucketed launch
+    for variant in (4,):
         d_out1 = torch.zeros((2_000_000, 2), dtype=torch.int64, device=dev)
         gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), 2_000_000, d_out1.data_ptr(), st)
         torch.cuda.synchronize()
@@ -345,8 +344,8 @@ def test_branching_footprint_index_closed_form():
     """The branching variant of the footprint generator (m-sequence text + one SNP bubble per 50 positions: order-k de
     Bruijn graph, e = 1.08 n; validated against its definition on the CPU in tests/test_workload.py) at 268 M path nodes:
     every find() of a walk through the graph -- pair steps that go through a non-last out-edge are replayed singly --
-    equals the single node of the walk's first k characters, for 32-mers, 100-mers and k-mers, through the default kernel,
-    the single-character kernel (GCSA2_PAIR_BLOCKS=0 equivalent: variant 1) and the length-bucketed launch."""
+    equals the single node of the walk's first k characters, for 32-mers, 100-mers and k-mers, through the default and
+    the length-bucketed launch."""
     import torch
     from workload import mseq_torch
     from gcsa2_amd.binding import GCSA
@@ -363,7 +362,7 @@ def test_branching_footprint_index_closed_form():
         d_pat = torch.zeros(nq * m + 8, dtype=torch.uint8, device=dev)
         d_pat[: nq * m] = pats.reshape(-1)
         d_off = torch.arange(nq + 1, dtype=torch.int64, device=dev) * m
-        for variant in (2, 1, 4):
+        for variant in (2, 4):
             n = nq if variant == 2 else nq // 8
             d_out = torch.zeros((n, 2), dtype=torch.int64, device=dev)
             gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), n, d_out.data_ptr(), st)
