@@ -310,9 +310,11 @@ def setup_pangenome(args, D, dev, local_rank, total_queries=None):
     if degree not in dbg_torch.LFSR:
         raise SystemExit(f"--degree must be one of {sorted(dbg_torch.LFSR)}")
     kind = {"pangenome": "junction", "pangenome_plain": "plain", "pangenome_snp": "snp"}[args.workload if args.workload.startswith("pangenome") else "pangenome"]
-    full = (D.world == 1 and not args.no_secondary and kind != "snp")
     # every rank stages its own replica on the host: ~5 bytes per path node for find() alone, ~9 with samples and LCP
+    # (config 5 runs sharded at N > 1, so every rank needs them)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", D.world))
+    full = (not args.no_secondary and kind != "snp" and args.secondary in ("all", "config5")
+            and (degree <= 20 or host_memory_ok(local_world * 9 * dbg_torch.text_length(degree))))
     need = local_world * (9 if full else 5) * dbg_torch.text_length(degree) * (1.25 if kind == "snp" else 1.0)
     if degree > 20 and not host_memory_ok(need):
         log(f"warning: host memory too small for {local_world} replicas of the degree-{degree} index ({need / 1e9:.0f} GB); "
@@ -731,6 +733,134 @@ def config5(args, wl, dev):
     return out
 
 
+def config5_sharded(args, D, wl, dev):
+    """BASELINE configs[4] as written: the 1 M 256-bp batch sharded contiguously over the ranks (index replicated), every rank
+    runs the fused LF + parent kernel and locate() on its shard, the root receives the matching statistics, ranges, parent()
+    counts and the CSR of located values in query order (gcsa2_comm_match_stats / gcsa2_comm_locate: per-rank totals, then
+    offsets and values through the grouped send / recv gather).  The root checks the gathered batch: closed
+    form for the unmodified half, count() == located values for every range (benchmark/query_gcsa.cpp:171-179)."""
+    import torch
+    from workload import mseq_torch
+    from gcsa2_amd import shard
+    gpu, ix = wl.gpu, wl.ix
+    nq_total, m = 1_000_000, 256
+    bounds = shard_bounds(nq_total, D.world)
+    b, e = bounds[D.rank]
+    nq = e - b
+    counts = [hi - lo for lo, hi in bounds]
+    stream = torch.cuda.current_stream()
+    pats, start, expected = wl.long_patterns(b, nq, m, CONFIG5_SEED)
+    nxt = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a_, b_ in zip(b"ACGT", b"CGTA"):
+        nxt[a_] = b_
+    odd = (torch.arange(b, e, device=dev) % 2) == 1                # global parity: the batch is the same for every N
+    for col in range(37, m, 41):
+        pats[odd, col] = nxt[pats[odd, col].to(torch.int64)]
+    d_pat = padded_bytes(pats)
+    del pats
+    d_off = torch.arange(nq + 1, dtype=torch.int64, device=dev) * m
+    root = D.rank == 0
+    d_ms = torch.zeros((nq_total if root else 1) * m + 8, dtype=torch.int16, device=dev)
+    d_rng = torch.zeros((nq_total if root else 1, 2), dtype=torch.int64, device=dev)
+    d_fb = torch.zeros(nq_total if root else 1, dtype=torch.int64, device=dev)
+    use_comm = D.comm is not None
+
+    def run_match_stats():
+        if use_comm:
+            D.comm.match_stats(gpu, d_pat.data_ptr(), d_off.data_ptr(), counts, [c * m for c in counts], d_ms.data_ptr(), d_rng.data_ptr(),
+                               d_fb.data_ptr(), 0, stream.cuda_stream)
+            return
+        # control-flow check without the library communicator (gloo, or the torch fallback): through host memory
+        l_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev)
+        l_rng = torch.zeros((max(nq, 1), 2), dtype=torch.int64, device=dev)
+        l_fb = torch.zeros(max(nq, 1), dtype=torch.int64, device=dev)
+        gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, l_ms.data_ptr(), l_rng.data_ptr(), l_fb.data_ptr(), stream.cuda_stream,
+                               total_bytes=nq * m)
+        torch.cuda.synchronize()
+        g_ms = shard.gather_variable(l_ms[: nq * m].cpu().numpy().view(np.uint16), [c * m for c in counts])
+        g_rng = shard.gather_variable(l_rng[:nq].cpu().numpy().view(np.uint64).reshape(-1), [2 * c for c in counts])
+        g_fb = shard.gather_variable(l_fb[:nq].cpu().numpy().view(np.uint64), counts)
+        if root:
+            d_ms[: nq_total * m] = torch.from_numpy(g_ms.view(np.int16)).to(dev)
+            d_rng.copy_(torch.from_numpy(g_rng.view(np.int64).reshape(-1, 2)).to(dev))
+            d_fb.copy_(torch.from_numpy(g_fb.view(np.int64)).to(dev))
+
+    run_match_stats()
+    torch.cuda.synchronize()
+    reps = 5
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run_match_stats()
+    torch.cuda.synchronize()
+    D.barrier()
+    ms_time = D.max(time.perf_counter() - t0) / reps * 1e3
+    # locate() of the final ranges of every shard, CSR gathered on the root
+    if root:
+        my_rng = d_rng[b:e].contiguous()
+    else:
+        my_rng = torch.zeros((max(nq, 1), 2), dtype=torch.int64, device=dev)
+        l_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev)
+        gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, l_ms.data_ptr(), my_rng.data_ptr(), 0, stream.cuda_stream, total_bytes=nq * m)
+        torch.cuda.synchronize()
+        del l_ms
+    d_loff = torch.zeros((nq_total if root else 1) + 1, dtype=torch.int64, device=dev)
+    loc_total, loc_vals = 0, None
+
+    def run_locate():
+        nonlocal loc_total, loc_vals
+        if use_comm:
+            res = D.comm.locate(gpu, my_rng.data_ptr(), counts, d_loff.data_ptr(), 0, stream.cuda_stream)
+            if root:
+                job, d_val, loc_total = res
+                from gcsa2_amd.binding import fetch_job
+                loc_vals = fetch_job(job, loc_total) if loc_vals is None else (gpu.locate_discard(job) or loc_vals)
+            return
+        job, d_o, d_v, tot = gpu.locate_device(my_rng.data_ptr(), nq, stream.cuda_stream)
+        l_off = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
+        l_val = torch.zeros(max(tot, 1), dtype=torch.int64, device=dev)
+        gpu.locate_discard(job)
+        gpu.locate_into(my_rng.data_ptr(), nq, l_off.data_ptr(), l_val.data_ptr(), max(tot, 1), stream.cuda_stream)
+        torch.cuda.synchronize()
+        res = shard.locate_sharded(lambda r: (l_off.cpu().numpy().view(np.uint64), l_val[:tot].cpu().numpy().view(np.uint64)),
+                                   np.zeros((nq_total, 2), dtype=np.uint64))
+        if root:
+            d_loff.copy_(torch.from_numpy(res[0].view(np.int64)).to(dev))
+            loc_total, loc_vals = int(res[0][-1]), res[1]
+
+    run_locate()
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        run_locate()
+    torch.cuda.synchronize()
+    D.barrier()
+    loc_ms = D.max(time.perf_counter() - t0) / 3 * 1e3
+    out = None
+    if root:
+        pats_all, start_all, exp_all = wl.long_patterns(0, nq_total, m, CONFIG5_SEED)
+        del pats_all
+        exp = exp_all[0::2]
+        ms2d = d_ms[: nq_total * m].view(nq_total, m)
+        want_ms = (m - torch.arange(m, device=dev)).to(torch.int16).view(1, m)
+        exact_ok = bool(torch.equal(d_rng[0::2, 0], exp)) and bool(torch.equal(d_rng[0::2, 1], exp)) and \
+            bool((d_fb[0::2] == 0).all()) and bool((ms2d[0::2] == want_ms).all())
+        d_cnt = torch.zeros(nq_total, dtype=torch.int64, device=dev)
+        gpu.count_device(d_rng.data_ptr(), nq_total, d_cnt.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        consistent = bool(torch.equal(d_loff[1:] - d_loff[:-1], d_cnt)) and int(d_loff[-1]) == loc_total
+        first_vals = loc_vals[d_loff[:-1][0::2].cpu().numpy()]
+        located_ok = bool(np.array_equal(first_vals, mseq_torch.node_values(start_all[0::2].cpu().numpy()))) if start_all is not None else None
+        out = {"workload": f"{nq_total} x {m}-bp walks, every second one with a substitution every 41 bp, sharded contiguously over {D.world} GPU(s): "
+                           "backward search with parent() on failure + locate() of the final ranges on every shard, results gathered on the root "
+                           + ("(gcsa2_comm_match_stats / gcsa2_comm_locate: grouped RCCL send / recv)" if use_comm else "(through host memory: control-flow check)"),
+               "n_gpus": D.world, "match_stats_ms": ms_time, "patterns_per_s": nq_total / (ms_time * 1e-3), "bases_per_s": nq_total * m / (ms_time * 1e-3),
+               "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item()), "unmodified_half_equals_closed_form": exact_ok,
+               "locate": {"ms_per_step": loc_ms, "value": nq_total / (loc_ms * 1e-3), "unit": "queries/s", "values": loc_total,
+                          "count_equals_located": consistent, "unmodified_half_equals_closed_form": located_ok}}
+    return out
+
+
 def chr22_secondary(args, D, dev, local_rank):
     """BASELINE configs[1] and [2] on one GPU."""
     wl = setup_chr22(args, D, dev, local_rank, nq=10_000_000)
@@ -896,13 +1026,18 @@ def main():
     secondary = args.workload in ("pangenome", "pangenome_plain", "human") and world == 1 and not args.no_secondary
     if secondary and args.secondary in ("all", "config5") and wl.ix.lcp_size > 0:
         result["config5"] = config5(args, wl, dev)
+    if world > 1 and not args.no_secondary and args.secondary in ("all", "config5") and D.all_true(wl.ix.lcp_size > 0 and wl.gpu.sampleCount() > 0):
+        c5 = config5_sharded(args, D, wl, dev)
+        if rank == 0:
+            result["config5"] = c5
     del r
+    full_size = getattr(wl, "degree", 0) >= 32
     if secondary:
         release(wl)
         del wl
     if secondary and args.secondary in ("all", "chr22"):
         result["chr22"] = chr22_secondary(args, D, dev, local_rank)
-    if secondary and args.workload != "human" and args.secondary in ("all", "human32"):
+    if secondary and args.workload != "human" and args.secondary in ("all", "human32") and full_size:
         result["human32"] = human32_secondary(args, D, dev, local_rank)
     if secondary and args.secondary == "human_snp":
         result["human_branching"] = human_snp_secondary(args, D, dev, local_rank)

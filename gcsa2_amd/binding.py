@@ -35,8 +35,9 @@ EXPORTS = [
     "gcsa2_lcp_access_batch",
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
     "gcsa2_group_find_batch", "gcsa2_group_find_device", "gcsa2_group_uses_rccl",
+    "gcsa2_group_match_stats_device", "gcsa2_group_locate_device", "gcsa2_comm_match_stats", "gcsa2_comm_locate",
     "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_gather",
-    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized",
+    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
     "gcsa2_host_view_parse_gcsa", "gcsa2_host_view_parse_lcp", "gcsa2_host_view_serialize_gcsa", "gcsa2_host_view_serialize_lcp",
@@ -136,6 +137,7 @@ def load_library():
     L.gcsa2_match_stats_device.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.gcsa2_match_stats_device_variant.argtypes = [vp, C.c_int, vp, vp, u64, vp, vp, vp, vp]
     L.gcsa2_match_stats_device_sized.argtypes = [vp, C.c_int, vp, vp, u64, u64, vp, vp, vp, vp]
+    L.gcsa2_match_stats_profile_device.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp, vp, vp]
     L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
     L.gcsa2_group_destroy.argtypes = [vp]
     L.gcsa2_group_destroy.restype = None
@@ -145,6 +147,10 @@ def load_library():
     L.gcsa2_group_find_batch.argtypes = [vp, u8p, u64p, u64, u64p]
     L.gcsa2_group_find_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), u64p, vp]
     L.gcsa2_group_uses_rccl.argtypes = [vp]
+    L.gcsa2_group_match_stats_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), u64p, u64p, vp, vp, vp]
+    L.gcsa2_group_locate_device.argtypes = [vp, C.POINTER(vp), u64p, i32, vp, C.POINTER(vp), C.POINTER(vp), u64p]
+    L.gcsa2_comm_match_stats.argtypes = [vp, vp, vp, vp, u64p, u64p, i32, vp, vp, vp, vp]
+    L.gcsa2_comm_locate.argtypes = [vp, vp, vp, u64p, i32, i32, vp, C.POINTER(vp), C.POINTER(vp), u64p, vp]
     L.gcsa2_comm_unique_id.argtypes = [u8p]
     L.gcsa2_comm_create.argtypes = [u8p, i32, i32, i32, C.POINTER(vp)]
     L.gcsa2_comm_destroy.argtypes = [vp]
@@ -478,6 +484,10 @@ class GCSA:
             _check(self._L.gcsa2_match_stats_device_sized(self._h, variant, d_patterns, d_offsets, nq, int(total_bytes), d_ms, d_ranges,
                                                           d_fallbacks, stream))
 
+    def match_stats_profile_device(self, d_patterns, d_offsets, nq, total_bytes, d_ms, d_ranges, d_fallbacks, d_prof, stream=0):
+        """Diagnostic: the instrumented matching-statistics kernel (cycles per phase and event counts into d_prof[16])."""
+        _check(self._L.gcsa2_match_stats_profile_device(self._h, d_patterns, d_offsets, nq, int(total_bytes), d_ms, d_ranges, d_fallbacks, d_prof, stream))
+
     def count_kmers(self, k, include_Ns=False, force=False):
         """`countKMers` (reference src/algorithms.cpp:387-421)."""
         res = C.c_uint64()
@@ -678,6 +688,24 @@ class Comm:
         assert sizes.shape[0] == self.world
         _check(self._L.gcsa2_comm_gather(self._h, d_send, _p64(sizes), d_recv, root, stream))
 
+    def match_stats(self, gcsa, d_patterns, d_offsets, counts, pattern_bytes, d_ms_root, d_ranges_root, d_fallbacks_root, root=0, stream=0):
+        """Matching statistics of this rank's shard, gathered on the root in query order (enqueue-only).  counts[r] /
+        pattern_bytes[r] = patterns / pattern bytes of rank r's shard; the *_root pointers are read on the root only."""
+        cnt, pb = np.asarray(counts, dtype=np.uint64), np.asarray(pattern_bytes, dtype=np.uint64)
+        assert cnt.shape[0] == self.world and pb.shape[0] == self.world
+        _check(self._L.gcsa2_comm_match_stats(self._h, gcsa.handle, d_patterns, d_offsets, _p64(cnt), _p64(pb), root, d_ms_root, d_ranges_root,
+                                              d_fallbacks_root, stream))
+
+    def locate(self, gcsa, d_ranges, counts, d_offsets_root, root=0, stream=0, sort=True):
+        """locate() of this rank's shard; on the root returns (job, d_values, total) for the whole batch in query order
+        (offsets written to d_offsets_root: sum(counts) + 1 entries; free the job with gcsa.locate_discard), None elsewhere."""
+        cnt = np.asarray(counts, dtype=np.uint64)
+        assert cnt.shape[0] == self.world
+        job, d_val, total = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(self._L.gcsa2_comm_locate(self._h, gcsa.handle, d_ranges, _p64(cnt), int(sort), root, d_offsets_root, C.byref(job), C.byref(d_val),
+                                         C.byref(total), stream))
+        return (job, d_val.value, total.value) if self.rank == root else None
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.gcsa2_comm_destroy(self._h)
@@ -685,6 +713,13 @@ class Comm:
 
     def __del__(self):
         self.close()
+
+
+def fetch_job(job, total: int) -> np.ndarray:
+    """The values of a locate job (gcsa2_locate_device / group / comm locate) on the host; frees the job (gcsa2_locate_fetch)."""
+    values = np.zeros(max(int(total), 1), dtype=np.uint64)
+    _check(load_library().gcsa2_locate_fetch(job, _p64(values), values.shape[0]))
+    return values[: int(total)]
 
 
 def pack_ranges32_device(d_ranges, nq, d_packed, stream=0):
@@ -730,6 +765,28 @@ class GCSAGroup:
         offs = (C.c_void_p * G)(*[C.c_void_p(int(p)) for p in d_offsets])
         cnt = np.asarray(counts, dtype=np.uint64)
         _check(self._L.gcsa2_group_find_device(self._h, pats, offs, _p64(cnt), d_ranges_root))
+
+    def match_stats_device(self, d_patterns, d_offsets, counts, pattern_bytes, d_ms_root, d_ranges_root, d_fallbacks_root=0):
+        """Matching statistics of a batch sharded over the replicas (shards in HBM as for find_device; pattern_bytes[r] =
+        pattern bytes of shard r); statistics, ranges and parent() counts gathered on replica 0's device.  Complete on return."""
+        G = self.size()
+        pats = (C.c_void_p * G)(*[C.c_void_p(int(p)) for p in d_patterns])
+        offs = (C.c_void_p * G)(*[C.c_void_p(int(p)) for p in d_offsets])
+        cnt, pb = np.asarray(counts, dtype=np.uint64), np.asarray(pattern_bytes, dtype=np.uint64)
+        _check(self._L.gcsa2_group_match_stats_device(self._h, pats, offs, _p64(cnt), _p64(pb), d_ms_root, d_ranges_root, d_fallbacks_root))
+
+    def locate_device(self, d_ranges, counts, d_offsets_root, sort=True):
+        """locate() of a batch of ranges sharded over the replicas; returns (job, d_values, total) on replica 0's device,
+        offsets of the whole batch in d_offsets_root (sum(counts) + 1 entries).  Free with locate_discard(job)."""
+        G = self.size()
+        rng = (C.c_void_p * G)(*[C.c_void_p(int(p)) for p in d_ranges])
+        cnt = np.asarray(counts, dtype=np.uint64)
+        job, d_val, total = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(self._L.gcsa2_group_locate_device(self._h, rng, _p64(cnt), int(sort), d_offsets_root, C.byref(job), C.byref(d_val), C.byref(total)))
+        return job, d_val.value, total.value
+
+    def locate_discard(self, job):
+        self._L.gcsa2_locate_discard(job)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1329,6 +1329,7 @@ int gcsa2_locate_run(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq,
   if(rc != GCSA2_OK) { return rc; }
   HIP_TRY(lease.down(offsets, d_off, (nq + 1) * sizeof(u64)));      // in the job's stream order
   HIP_TRY(lease.finish());
+  (*job)->stream = nullptr;       // the lease's stream belongs to the index; the job is complete and may outlive it
   return GCSA2_OK;
 }
 
@@ -1498,6 +1499,12 @@ int gcsa2_locate_max(const gcsa2_index* ix, uint64_t sp, uint64_t ep, uint64_t m
 
 }  // extern "C"
 
+namespace {
+int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, u64 total_bytes,
+                       uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st);
+int group_comm_init(gcsa2_group* g);
+}  // namespace
+
 #include "comm.hpp"
 
 extern "C" {
@@ -1577,25 +1584,7 @@ int gcsa2_group_find_device(gcsa2_group* g, const uint8_t* const* d_patterns, co
   try {
   std::lock_guard<std::mutex> hold(g->lock);
   const int G = int(g->replicas.size());
-  if(!g->comm_tried)
-  {
-    // One communicator per device (ncclCommInitAll).  RCCL needs distinct devices; a group that lists a device
-    // twice (or a host without RCCL) gathers with peer copies instead.
-    g->comm_tried = true;
-    std::vector<int> devs;
-    bool distinct = true;
-    for(int r = 0; r < G; r++)
-    {
-      for(int d : devs) { distinct = distinct && d != g->replicas[r]->device; }
-      devs.push_back(g->replicas[r]->device);
-    }
-    if(G > 1 && distinct && rccl().ok)
-    {
-      g->comms.assign(size_t(G), nullptr);
-      ncclResult_t r = rccl().CommInitAll(g->comms.data(), G, devs.data());
-      if(r != ncclSuccess) { g->comms.clear(); return fail(GCSA2_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(r)); }
-    }
-  }
+  { int rc = group_comm_init(g); if(rc != GCSA2_OK) { return rc; } }
   // every replica searches its shard on its own stream; replica 0 writes straight into the result buffer
   std::vector<u64> first(size_t(G) + 1, 0);
   for(int r = 0; r < G; r++) { first[size_t(r) + 1] = first[size_t(r)] + counts[r]; }
@@ -1650,6 +1639,334 @@ int gcsa2_group_find_device(gcsa2_group* g, const uint8_t* const* d_patterns, co
   }
   return GCSA2_OK;
   } catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_group_find_device: ") + e.what()); }
+}
+
+}  // extern "C"
+
+namespace {
+
+// The gather of the group entry points: src[r] (bytes[r] bytes, on the device of replica r, produced on streams[r]) lands at
+// dst_root + at[r] on the device of replica 0.  One grouped RCCL send / recv when the group has a communicator, peer copies
+// otherwise.  Replica 0's own part is a device copy on its stream (skipped when it is already in place).
+int group_gather(gcsa2_group* g, const std::vector<const void*>& src, const std::vector<u64>& bytes, char* dst_root, const std::vector<u64>& at)
+{
+  const int G = int(g->replicas.size());
+  if(bytes[0] > 0 && src[0] != dst_root + at[0])
+  {
+    DeviceGuard guard(g->replicas[0]->device);
+    HIP_TRY(hipMemcpyAsync(dst_root + at[0], src[0], bytes[0], hipMemcpyDeviceToDevice, g->streams[0]));
+  }
+  if(!g->comms.empty())
+  {
+    RcclApi& api = rccl();
+    RCCL_TRY(api.GroupStart());
+    ncclResult_t res = ncclSuccess;
+    for(int r = 1; r < G && res == ncclSuccess; r++)
+    {
+      if(bytes[size_t(r)] == 0) { continue; }
+      res = api.Send(src[size_t(r)], bytes[size_t(r)], ncclUint8, 0, g->comms[size_t(r)], g->streams[size_t(r)]);
+      if(res == ncclSuccess) { res = api.Recv(dst_root + at[size_t(r)], bytes[size_t(r)], ncclUint8, r, g->comms[0], g->streams[0]); }
+    }
+    ncclResult_t end = api.GroupEnd();
+    if(res != ncclSuccess) { return fail(GCSA2_ERR_HIP, std::string("ncclSend / ncclRecv: ") + api.GetErrorString(res)); }
+    if(end != ncclSuccess) { return fail(GCSA2_ERR_HIP, std::string("ncclGroupEnd: ") + api.GetErrorString(end)); }
+  }
+  else
+  {
+    for(int r = 1; r < G; r++)
+    {
+      if(bytes[size_t(r)] == 0) { continue; }
+      DeviceGuard guard(g->replicas[size_t(r)]->device);
+      HIP_TRY(hipMemcpyPeerAsync(dst_root + at[size_t(r)], g->replicas[0]->device, src[size_t(r)], g->replicas[size_t(r)]->device,
+                                 bytes[size_t(r)], g->streams[size_t(r)]));
+    }
+  }
+  return GCSA2_OK;
+}
+
+int group_sync(gcsa2_group* g)
+{
+  for(size_t r = 0; r < g->replicas.size(); r++)
+  {
+    DeviceGuard guard(g->replicas[r]->device);
+    HIP_TRY(hipStreamSynchronize(g->streams[r]));
+  }
+  return GCSA2_OK;
+}
+
+// One communicator per device (ncclCommInitAll), made at the first device-resident group call.  RCCL needs distinct
+// devices; a group that lists a device twice (or a host without RCCL) gathers with peer copies instead.
+int group_comm_init(gcsa2_group* g)
+{
+  if(g->comm_tried) { return GCSA2_OK; }
+  g->comm_tried = true;
+  const int G = int(g->replicas.size());
+  std::vector<int> devs;
+  bool distinct = true;
+  for(int r = 0; r < G; r++)
+  {
+    for(int d : devs) { distinct = distinct && d != g->replicas[size_t(r)]->device; }
+    devs.push_back(g->replicas[size_t(r)]->device);
+  }
+  if(G > 1 && distinct && rccl().ok)
+  {
+    g->comms.assign(size_t(G), nullptr);
+    ncclResult_t r = rccl().CommInitAll(g->comms.data(), G, devs.data());
+    if(r != ncclSuccess) { g->comms.clear(); return fail(GCSA2_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(r)); }
+  }
+  return GCSA2_OK;
+}
+
+__global__ __launch_bounds__(TPB) void k_rebase_offsets(u64* __restrict__ offsets, u64 count, u64 base)
+{
+  const u64 i = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(i < count) { offsets[i] += base; }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Matching statistics of a batch sharded over the group (BASELINE configs[4] on N GPUs): replica r runs its shard
+// (d_patterns[r], d_offsets[r] rebased to 0, counts[r] patterns of pattern_bytes[r] bytes in all) and the three result arrays
+// are gathered on replica 0's device in query order.  Complete on return.
+int gcsa2_group_match_stats_device(gcsa2_group* g, const uint8_t* const* d_patterns, const uint64_t* const* d_offsets, const uint64_t* counts,
+                                   const uint64_t* pattern_bytes, uint16_t* d_ms_root, uint64_t* d_ranges_root, uint64_t* d_fallbacks_root)
+{
+  if(g == nullptr || g->replicas.empty()) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null or empty group"); }
+  if(d_patterns == nullptr || d_offsets == nullptr || counts == nullptr || pattern_bytes == nullptr || d_ms_root == nullptr || d_ranges_root == nullptr)
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer");
+  }
+  try {
+  std::lock_guard<std::mutex> hold(g->lock);
+  const size_t G = g->replicas.size();
+  int rc = group_comm_init(g);
+  if(rc != GCSA2_OK) { return rc; }
+  std::vector<const void*> ms(G, nullptr), rng(G, nullptr), fb(G, nullptr);
+  std::vector<u64> ms_bytes(G, 0), rng_bytes(G, 0), fb_bytes(G, 0), ms_at(G, 0), rng_at(G, 0), fb_at(G, 0);
+  std::vector<void*> scratch;
+  struct Release { gcsa2_group* g; std::vector<void*>& p; std::vector<int> dev; ~Release() { for(size_t i = 0; i < p.size(); i++) { DeviceGuard guard(dev[i]); (void)hipFree(p[i]); } } } release{g, scratch, {}};
+  u64 q_before = 0, b_before = 0;
+  for(size_t r = 0; r < G; r++)
+  {
+    ms_at[r] = 2 * b_before; rng_at[r] = 16 * q_before; fb_at[r] = 8 * q_before;
+    ms_bytes[r] = 2 * pattern_bytes[r]; rng_bytes[r] = 16 * counts[r]; fb_bytes[r] = 8 * counts[r];
+    q_before += counts[r]; b_before += pattern_bytes[r];
+    if(counts[r] == 0) { continue; }
+    const gcsa2_index* ix = g->replicas[r];
+    DeviceGuard guard(ix->device);
+    // the kernel wants an 8-byte aligned statistics array with 4 spare entries: a scratch copy per replica (replica 0's
+    // slice of the result starts at 0 and is used in place)
+    char* buf = nullptr;
+    const u64 ms_room = (2 * pattern_bytes[r] + 8 * sizeof(uint16_t) + 15) / 16 * 16;
+    uint16_t* my_ms = d_ms_root; u64* my_rng = d_ranges_root; u64* my_fb = d_fallbacks_root;
+    if(r > 0)
+    {
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), ms_room + 24 * counts[r]));
+      scratch.push_back(buf); release.dev.push_back(ix->device);
+      my_ms = reinterpret_cast<uint16_t*>(buf); my_rng = reinterpret_cast<u64*>(buf + ms_room); my_fb = my_rng + 2 * counts[r];
+    }
+    else if(d_fallbacks_root == nullptr) { fb_bytes[0] = 0; }
+    rc = match_stats_launch(ix, 0, d_patterns[r], d_offsets[r], counts[r], pattern_bytes[r], my_ms, my_rng, my_fb, g->streams[r]);
+    if(rc != GCSA2_OK) { return rc; }
+    ms[r] = my_ms; rng[r] = my_rng; fb[r] = my_fb;
+  }
+  if(d_fallbacks_root == nullptr) { for(size_t r = 0; r < G; r++) { fb_bytes[r] = 0; } }
+  rc = group_gather(g, ms, ms_bytes, reinterpret_cast<char*>(d_ms_root), ms_at);
+  if(rc == GCSA2_OK) { rc = group_gather(g, rng, rng_bytes, reinterpret_cast<char*>(d_ranges_root), rng_at); }
+  if(rc == GCSA2_OK && d_fallbacks_root != nullptr) { rc = group_gather(g, fb, fb_bytes, reinterpret_cast<char*>(d_fallbacks_root), fb_at); }
+  int sc = group_sync(g);
+  return rc != GCSA2_OK ? rc : sc;
+  } catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_group_match_stats_device: ") + e.what()); }
+}
+
+// locate() of a batch of ranges sharded over the group: replica r locates d_ranges[r] (counts[r] ranges); the root receives the
+// CSR of the whole batch in query order -- per-rank totals first, then the offsets (rebased) and the values (SURVEY.md 8(e):
+// "all-gather of per-rank counts, then gatherv of the CSR values").  *job owns the values on replica 0's device.
+int gcsa2_group_locate_device(gcsa2_group* g, const uint64_t* const* d_ranges, const uint64_t* counts, int sort, uint64_t* d_offsets_root,
+                              gcsa2_locate_job** job_out, const uint64_t** d_values_root, uint64_t* total_values)
+{
+  if(g == nullptr || g->replicas.empty()) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null or empty group"); }
+  if(d_ranges == nullptr || counts == nullptr || d_offsets_root == nullptr || job_out == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  *job_out = nullptr;
+  try {
+  std::lock_guard<std::mutex> hold(g->lock);
+  const size_t G = g->replicas.size();
+  int rc = group_comm_init(g);
+  if(rc != GCSA2_OK) { return rc; }
+  // every replica locates its shard from its own host thread (the locate pipeline synchronises its stream)
+  std::vector<gcsa2_locate_job*> jobs(G, nullptr);
+  std::vector<int> status(G, GCSA2_OK);
+  std::vector<std::string> messages(G);
+  struct Discard { std::vector<gcsa2_locate_job*>& j; ~Discard() { for(gcsa2_locate_job* x : j) { gcsa2_locate_discard(x); } } } discard{jobs};
+  {
+    std::vector<std::thread> workers;
+    for(size_t r = 0; r < G; r++)
+    {
+      workers.emplace_back([&, r]()
+      {
+        status[r] = gcsa2_locate_device(g->replicas[r], d_ranges[r], counts[r], sort, &jobs[r], nullptr, nullptr, nullptr, g->streams[r]);
+        if(status[r] != GCSA2_OK) { messages[r] = g_error; }
+      });
+    }
+    for(std::thread& t : workers) { t.join(); }
+  }
+  for(size_t r = 0; r < G; r++) { if(status[r] != GCSA2_OK) { return fail(status[r], "shard " + std::to_string(r) + ": " + messages[r]); } }
+  u64 total = 0, q_before = 0;
+  std::vector<const void*> off(G, nullptr), val(G, nullptr);
+  std::vector<u64> off_bytes(G, 0), val_bytes(G, 0), off_at(G, 0), val_at(G, 0), base(G, 0);
+  for(size_t r = 0; r < G; r++)
+  {
+    base[r] = total; off_at[r] = 8 * q_before; val_at[r] = 8 * total;
+    off[r] = jobs[r]->d_offsets; off_bytes[r] = 8 * counts[r];
+    val[r] = jobs[r]->d_values; val_bytes[r] = 8 * jobs[r]->total;
+    total += jobs[r]->total; q_before += counts[r];
+  }
+  const gcsa2_index* root = g->replicas[0];
+  gcsa2_locate_job* result = new(std::nothrow) gcsa2_locate_job();
+  if(result == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+  result->device = root->device; result->nq = q_before; result->total = total;
+  {
+    DeviceGuard guard(root->device);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&result->d_values), (total > 0 ? total : 1) * sizeof(u64));
+    if(e != hipSuccess) { delete result; return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(values): ") + hipGetErrorString(e)); }
+  }
+  rc = group_gather(g, off, off_bytes, reinterpret_cast<char*>(d_offsets_root), off_at);
+  if(rc == GCSA2_OK) { rc = group_gather(g, val, val_bytes, reinterpret_cast<char*>(result->d_values), val_at); }
+  if(rc == GCSA2_OK) { rc = group_sync(g); }
+  if(rc == GCSA2_OK)
+  {
+    DeviceGuard guard(root->device);
+    u64 at = 0;
+    for(size_t r = 0; r < G; r++)
+    {
+      if(counts[r] > 0 && base[r] > 0)
+      {
+        hipLaunchKernelGGL(k_rebase_offsets, dim3(grid_for(counts[r])), dim3(TPB), 0, g->streams[0], d_offsets_root + at, counts[r], base[r]);
+      }
+      at += counts[r];
+    }
+    hipError_t e = hipMemcpyAsync(d_offsets_root + q_before, &total, sizeof(u64), hipMemcpyHostToDevice, g->streams[0]);
+    if(e == hipSuccess) { e = hipStreamSynchronize(g->streams[0]); }
+    if(e != hipSuccess) { rc = fail(GCSA2_ERR_HIP, std::string("offsets of the gathered batch: ") + hipGetErrorString(e)); }
+  }
+  if(rc != GCSA2_OK) { gcsa2_locate_discard(result); return rc; }
+  *job_out = result;
+  if(d_values_root) { *d_values_root = result->d_values; }
+  if(total_values) { *total_values = total; }
+  return GCSA2_OK;
+  } catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_group_locate_device: ") + e.what()); }
+}
+
+// ---- the same two queries with one process per GPU (gcsa2_comm): every rank works on its contiguous shard, the results are
+// gathered on the root through gcsa2_comm_gather's grouped send / recv ----------------------------------------------------------
+
+// counts[r] / pattern_bytes[r]: patterns and pattern bytes of rank r's shard (the same arrays on every rank).  Enqueue-only on
+// `stream` (the scratch of the shard's results is stream-ordered); the root's arrays are complete when the stream is.
+int gcsa2_comm_match_stats(gcsa2_comm* c, const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets, const uint64_t* counts,
+                           const uint64_t* pattern_bytes, int root, uint16_t* d_ms_root, uint64_t* d_ranges_root, uint64_t* d_fallbacks_root,
+                           void* stream)
+{
+  CHECK_INDEX(ix);
+  if(c == nullptr || counts == nullptr || pattern_bytes == nullptr || root < 0 || root >= c->world) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad arguments"); }
+  if(c->rank == root && (d_ms_root == nullptr || d_ranges_root == nullptr || d_fallbacks_root == nullptr)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "the root needs all three result buffers"); }
+  if(ix->device != c->device) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "index and communicator are on different devices"); }
+  DeviceGuard guard(c->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const u64 nq = counts[c->rank], bytes = pattern_bytes[c->rank];
+  const u64 ms_room = (2 * bytes + 8 * sizeof(uint16_t) + 15) / 16 * 16;
+  char* buf = nullptr;
+  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&buf), ms_room + 24 * nq + 16, st));
+  uint16_t* my_ms = reinterpret_cast<uint16_t*>(buf); u64* my_rng = reinterpret_cast<u64*>(buf + ms_room); u64* my_fb = my_rng + 2 * nq;
+  int rc = (nq > 0 ? match_stats_launch(ix, 0, d_patterns, d_offsets, nq, bytes, my_ms, my_rng, my_fb, st) : GCSA2_OK);
+  std::vector<u64> sizes(size_t(c->world));
+  if(rc == GCSA2_OK)
+  {
+    for(int r = 0; r < c->world; r++) { sizes[size_t(r)] = 2 * pattern_bytes[r]; }
+    rc = gather_bytes(c->comm, c->rank, c->world, my_ms, sizes.data(), d_ms_root, root, st);
+  }
+  if(rc == GCSA2_OK)
+  {
+    for(int r = 0; r < c->world; r++) { sizes[size_t(r)] = 16 * counts[r]; }
+    rc = gather_bytes(c->comm, c->rank, c->world, my_rng, sizes.data(), d_ranges_root, root, st);
+  }
+  if(rc == GCSA2_OK)
+  {
+    for(int r = 0; r < c->world; r++) { sizes[size_t(r)] = 8 * counts[r]; }
+    rc = gather_bytes(c->comm, c->rank, c->world, my_fb, sizes.data(), d_fallbacks_root, root, st);
+  }
+  (void)hipFreeAsync(buf, st);
+  return rc;
+}
+
+// locate() of this rank's shard (counts[rank] ranges); on the root: d_offsets_root (sum of counts + 1 entries) and a job that owns
+// the values of the whole batch in query order.  Per-rank totals travel first (8 bytes each), then the offsets and the values
+// (SURVEY.md 8(e)).  Complete on return (the sizes of the second gather are read on the host).
+int gcsa2_comm_locate(gcsa2_comm* c, const gcsa2_index* ix, const uint64_t* d_ranges, const uint64_t* counts, int sort, int root,
+                      uint64_t* d_offsets_root, gcsa2_locate_job** job_root, const uint64_t** d_values_root, uint64_t* total_values, void* stream)
+{
+  CHECK_INDEX(ix);
+  if(c == nullptr || counts == nullptr || root < 0 || root >= c->world) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad arguments"); }
+  if(c->rank == root && (d_offsets_root == nullptr || job_root == nullptr)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "the root needs result buffers"); }
+  if(ix->device != c->device) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "index and communicator are on different devices"); }
+  if(job_root != nullptr) { *job_root = nullptr; }
+  try {
+  DeviceGuard guard(c->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t W = size_t(c->world);
+  const bool is_root = (c->rank == root);
+  gcsa2_locate_job* mine = nullptr;
+  int rc = gcsa2_locate_device(ix, d_ranges, counts[c->rank], sort, &mine, nullptr, nullptr, nullptr, st);
+  if(rc != GCSA2_OK) { return rc; }
+  struct Discard { gcsa2_locate_job*& j; ~Discard() { gcsa2_locate_discard(j); } } discard{mine};
+  // 1. per-rank totals: the last entry of every rank's offsets
+  std::vector<u64> eight(W, sizeof(u64)), totals(W, 0);
+  u64* d_totals = nullptr;
+  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&d_totals), W * sizeof(u64), st));
+  rc = gather_bytes(c->comm, c->rank, c->world, mine->d_offsets + counts[c->rank], eight.data(), d_totals, root, st);
+  if(rc == GCSA2_OK && is_root) { HIP_TRY(hipMemcpyAsync(totals.data(), d_totals, W * sizeof(u64), hipMemcpyDeviceToHost, st)); }
+  if(rc == GCSA2_OK) { HIP_TRY(hipStreamSynchronize(st)); }
+  (void)hipFreeAsync(d_totals, st);
+  if(rc != GCSA2_OK) { return rc; }
+  if(!is_root) { totals[size_t(c->rank)] = mine->total; }
+  // 2. offsets (counts[r] entries each) and values (totals[r] each); a peer only needs its own sizes
+  std::vector<u64> off_bytes(W), val_bytes(W);
+  u64 total = 0, queries = 0;
+  for(size_t r = 0; r < W; r++) { off_bytes[r] = 8 * counts[r]; val_bytes[r] = 8 * totals[r]; total += totals[r]; queries += counts[r]; }
+  gcsa2_locate_job* result = nullptr;
+  if(is_root)
+  {
+    result = new(std::nothrow) gcsa2_locate_job();
+    if(result == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    result->device = c->device; result->nq = queries; result->total = total;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&result->d_values), (total > 0 ? total : 1) * sizeof(u64));
+    if(e != hipSuccess) { delete result; return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(values): ") + hipGetErrorString(e)); }
+  }
+  rc = gather_bytes(c->comm, c->rank, c->world, mine->d_offsets, off_bytes.data(), d_offsets_root, root, st);
+  if(rc == GCSA2_OK) { rc = gather_bytes(c->comm, c->rank, c->world, mine->d_values, val_bytes.data(), is_root ? result->d_values : nullptr, root, st); }
+  if(rc == GCSA2_OK && is_root)
+  {
+    u64 at = 0, base = 0;
+    for(size_t r = 0; r < W; r++)
+    {
+      if(counts[r] > 0 && base > 0) { hipLaunchKernelGGL(k_rebase_offsets, dim3(grid_for(counts[r])), dim3(TPB), 0, st, d_offsets_root + at, counts[r], base); }
+      at += counts[r]; base += totals[r];
+    }
+    hipError_t e = hipMemcpyAsync(d_offsets_root + queries, &total, sizeof(u64), hipMemcpyHostToDevice, st);
+    if(e != hipSuccess) { rc = fail(GCSA2_ERR_HIP, std::string("offsets of the gathered batch: ") + hipGetErrorString(e)); }
+  }
+  hipError_t se = hipStreamSynchronize(st);
+  if(rc == GCSA2_OK && se != hipSuccess) { rc = fail(GCSA2_ERR_HIP, std::string("gather: ") + hipGetErrorString(se)); }
+  if(rc != GCSA2_OK) { gcsa2_locate_discard(result); return rc; }
+  if(is_root)
+  {
+    *job_root = result;
+    if(d_values_root) { *d_values_root = result->d_values; }
+    if(total_values) { *total_values = total; }
+  }
+  return GCSA2_OK;
+  } catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_comm_locate: ") + e.what()); }
 }
 
 int gcsa2_group_size(const gcsa2_group* g) { return g == nullptr ? 0 : int(g->replicas.size()); }
@@ -1872,6 +2189,33 @@ extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_
                                         uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
 {
   return match_stats_launch(ix, 0, d_patterns, d_offsets, nq, GCSA2_UNKNOWN, d_ms, d_ranges, d_fallbacks, static_cast<hipStream_t>(stream));
+}
+
+// Diagnostic: the default kernel instrumented with shader-clock counters per phase of its round (k_match_stats2<.., PROF>),
+// same results; d_prof[0..15] (zeroed by the caller) receives the cycle sums and event counts listed at the kernel.
+extern "C" int gcsa2_match_stats_profile_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq,
+                                                uint64_t total_bytes, uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks,
+                                                uint64_t* d_prof, void* stream)
+{
+  CHECK_INDEX(ix);
+  DeviceGuard guard(ix->device);
+  if(!ix->img.has_lcp || ix->img.flp == nullptr) { return fail(GCSA2_ERR_MISSING_COMPONENT, "the profiled kernel needs the LCP array and the pair blocks"); }
+  if(d_prof == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null profile buffer"); }
+  if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const u64 words = (total_bytes >> 5) + nq + 2;
+  u64* codes = nullptr; u32* bad = nullptr;
+  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&codes), words * sizeof(u64), st));
+  hipError_t pe = pool_alloc(ix, reinterpret_cast<void**>(&bad), words * sizeof(u32), st);
+  if(pe != hipSuccess) { (void)hipFreeAsync(codes, st); return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("matching statistics scratch: ") + hipGetErrorString(pe)); }
+  hipLaunchKernelGGL(k_pack_patterns, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, codes, bad);
+  hipLaunchKernelGGL((k_match_stats2<true, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
+                     ix->img, d_patterns, d_offsets, nq, reinterpret_cast<unsigned short*>(d_ms), d_ranges, d_fallbacks, ix->tune.cool_down,
+                     (unsigned long long*)nullptr, 64u, codes, bad, reinterpret_cast<unsigned long long*>(d_prof));
+  hipError_t le = hipGetLastError();
+  (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st);
+  if(le != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats2<prof>: ") + hipGetErrorString(le)); }
+  return GCSA2_OK;
 }
 
 extern "C" int gcsa2_match_stats_device_sized(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq,

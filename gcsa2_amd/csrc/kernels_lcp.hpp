@@ -446,14 +446,25 @@ constexpr u64 MS_REFILL_MIN = u64(1) << 19;             // host-pointer API: sma
 // pattern costs its wave three dependent loads, paid once per wave with a lane per pattern and ~8 times here; mixing clean
 // and mismatching patterns of one length gains nothing either, a round costs a wave the same whether 32 or 64 lanes take it
 // (profiles/r02_config5.md).
-template<bool PAIR, bool REFILL>
+// PROF = true (gcsa2_match_stats_profile_device, a diagnostic): shader-clock cycles per phase of the round, summed over the
+// waves, and event counts, added to prof[0..15]: 0 loop head / window, 1 step setup, 2 first fetch, 3 first evaluation,
+// 4 second fetch + evaluation, 5 outcome + statistics, 6 parent() from the chunks, 7 parent() tree walk; 8 rounds (per wave),
+// 9 rounds with a second fetch, 10 lane steps, 11 lane pair attempts, 12 failed pair attempts, 13 parent() calls, 14 tree walks,
+// 15 lane second fetches.
+template<bool PAIR, bool REFILL, bool PROF = false>
 __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8* __restrict__ patterns,
                                                        const u64* __restrict__ offsets, u64 nq,
                                                        unsigned short* __restrict__ ms, u64* __restrict__ ranges,
                                                        u64* __restrict__ fallbacks, u32 cool_down,
                                                        unsigned long long* __restrict__ queue, u32 refill_at,
-                                                       const u64* __restrict__ codes, const u32* __restrict__ bad)
+                                                       const u64* __restrict__ codes, const u32* __restrict__ bad,
+                                                       unsigned long long* __restrict__ prof = nullptr)
 {
+  [[maybe_unused]] u64 prof_t = 0, prof_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] u32 prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr(PROF) { prof_t = clock64(); }
+#define G2_TICK(phase) do { if constexpr(PROF) { const u64 now_ = clock64(); prof_c[phase] += now_ - prof_t; prof_t = now_; } } while(0)
+#define G2_COUNT(slot, value) do { if constexpr(PROF) { prof_n[slot] += u32(value); } } while(0)
   __shared__ ulonglong2 stage[TPB2 * 8];
   __shared__ u8 c2c[256];
   c2c[threadIdx.x] = img.char2comp[threadIdx.x];
@@ -538,6 +549,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       win_bad = (s == 0 ? b0 : (b0 >> s) | (b1 << (32 - s)));
       win_used = 0;
     }
+    G2_TICK(0);
     const bool stepping = active && !need_parent;
     u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
     bool pair = false;
@@ -574,21 +586,28 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     }
     PairEnd p_sp = {0, 0, 0}, p_ep = {0, 0, 0};                // a single step keeps (edge, node) in .raw / .node
     const bool need2 = stepping && idx_ep != idx_sp;
+    G2_TICK(1);
+    G2_COUNT(0, lane == 0); G2_COUNT(2, stepping); G2_COUNT(3, pair); G2_COUNT(7, need2);
     if(__any(stepping))
     {
       fetch_blocks<PAIR>(img.flb, idx_sp, stepping, wave_stage, lane, img.flp);
+      if constexpr(PROF) { if(stepping) { asm volatile("" :: "v"(wave_stage[lane * 8 + (lane & 7)].x)); } }     // the fetch has landed
+      G2_TICK(2);
       if(stepping)                               // one evaluation for single and pair steps alike (eval_staged)
       {
         p_sp = eval_staged(wave_stage, lane, PAIR && pair, r_sp, false);
         if(idx_ep == idx_sp) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
       }
+      G2_TICK(3);
       if(__any(need2))
       {
+        G2_COUNT(1, lane == 0);
         __builtin_amdgcn_wave_barrier();
         fetch_blocks<PAIR>(img.flb, idx_ep, need2, wave_stage, lane, img.flp);
         if(need2) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
       }
       __builtin_amdgcn_wave_barrier();
+      G2_TICK(4);
     }
     if(stepping)
     {
@@ -601,7 +620,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
           emit(i - 1, depth + 1); emit(i - 2, depth + 2);
           depth += 2; i -= 2; win_used += 2;
         }
-        else { force_single = 2; }                             // an emptying step needs parent(): one character at a time
+        else { force_single = 2; G2_COUNT(4, 1); }             // an emptying step needs parent(): one character at a time
       }
       else
       {
@@ -621,16 +640,34 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }
       }
     }
+    G2_TICK(5);
     // parent() as soon as a lane needs it (deferring it until more lanes of the wave wait measured slower, profiles/r02_config5.md)
+    bool walk = false;
+    gcsa2_stnode node;
+    if(need_parent) { walk = !parent_from_chunks(img, sp, ep, node); G2_COUNT(5, 1); }
+    if constexpr(PROF) { if(need_parent && !walk) { asm volatile("" :: "v"(node.sp)); } }
+    G2_TICK(6);
+    if(walk) { lcp_parent(img, sp, ep, node); G2_COUNT(6, 1); }
     if(need_parent)
     {
-      gcsa2_stnode node;
-      if(!parent_from_chunks(img, sp, ep, node)) { lcp_parent(img, sp, ep, node); }
       calls++;
       sp = node.sp; ep = node.ep; depth = node.node_lcp;
       need_parent = false;
     }
+    G2_TICK(7);
   }
+  if constexpr(PROF)
+  {
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+    {
+      u64 events = prof_n[k];
+      for(int o = 32; o > 0; o >>= 1) { events += __shfl_down(events, o, 64); }
+      if(lane == 0) { atomicAdd(prof + k, (unsigned long long)prof_c[k]); atomicAdd(prof + 8 + k, (unsigned long long)events); }
+    }
+  }
+#undef G2_TICK
+#undef G2_COUNT
 }
 
 }  // namespace

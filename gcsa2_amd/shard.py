@@ -73,3 +73,69 @@ def gpu_find_compute(gpu, device):
                             torch.cuda.current_stream(device).cuda_stream)
         return d_out
     return compute
+
+
+def gather_variable(local: np.ndarray, sizes, group=None):
+    """Gather 1-D numpy arrays of per-rank lengths `sizes` (known on every rank) on rank 0, concatenated in rank order.
+    The parts travel as bytes, padded to the longest (torch's gather wants equal shapes; the library's own gather,
+    gcsa2_comm_gather, sends exact sizes)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    item = local.dtype.itemsize
+    width = max(max(sizes), 1) * item
+    padded = torch.zeros(width, dtype=torch.uint8)
+    raw = np.ascontiguousarray(local).view(np.uint8).reshape(-1)
+    padded[: raw.shape[0]] = torch.from_numpy(raw.copy())
+    parts = [torch.zeros_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    return np.concatenate([parts[r][: sizes[r] * item].numpy() for r in range(world)]).view(local.dtype)
+
+
+def locate_sharded(compute, ranges: np.ndarray, group=None):
+    """locate() of a batch of ranges split contiguously over the ranks, the CSR result gathered on rank 0 in query order
+    -- the control flow of gcsa2_comm_locate: per-rank totals first, then the offsets of every shard
+    (rebased by the totals of the shards before it) and the values.  `compute(sub_ranges) -> (offsets uint64[n + 1],
+    values uint64[offsets[n]])`.  Returns (offsets, values) on rank 0, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nq = int(ranges.shape[0])
+    bounds = shard_bounds(nq, world)
+    b, e = bounds[rank]
+    off, val = compute(ranges[b:e])
+    totals = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(totals, torch.tensor([int(off[-1])], dtype=torch.int64), group=group)
+    totals = [int(t.item()) for t in totals]
+    offsets = gather_variable(off[:-1].astype(np.uint64), [hi - lo for lo, hi in bounds], group)
+    values = gather_variable(val.astype(np.uint64), totals, group)
+    if rank != 0:
+        return None
+    out = np.zeros(nq + 1, dtype=np.uint64)
+    base = 0
+    for r, (lo, hi) in enumerate(bounds):
+        out[lo:hi] = offsets[lo:hi] + np.uint64(base)
+        base += totals[r]
+    out[nq] = base
+    return out, values
+
+
+def match_stats_sharded(compute, flat: np.ndarray, offsets: np.ndarray, group=None):
+    """Matching statistics of a batch split contiguously over the ranks (the control flow of gcsa2_comm_match_stats):
+    `compute(flat_r, offsets_r) -> (ms uint16[bytes_r], ranges (n_r, 2) uint64, fallbacks uint64[n_r])`; rank 0 receives
+    the three arrays of the whole batch in query order."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nq = int(offsets.shape[0]) - 1
+    bounds = shard_bounds(nq, world)
+    b, e = bounds[rank]
+    sub_flat, sub_off = slice_batch(flat, offsets, b, e)
+    ms, rng, fb = compute(sub_flat, sub_off)
+    counts = [hi - lo for lo, hi in bounds]
+    nbytes = [int(offsets[hi] - offsets[lo]) for lo, hi in bounds]
+    g_ms = gather_variable(ms.astype(np.uint16), nbytes, group)
+    g_rng = gather_variable(rng.astype(np.uint64).reshape(-1), [2 * c for c in counts], group)
+    g_fb = gather_variable(fb.astype(np.uint64), counts, group)
+    if rank != 0:
+        return None
+    return g_ms, g_rng.reshape(-1, 2), g_fb

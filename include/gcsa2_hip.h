@@ -326,6 +326,14 @@ int gcsa2_match_stats_device_variant(const gcsa2_index* index, int variant, cons
 int gcsa2_match_stats_device_sized(const gcsa2_index* index, int variant, const uint8_t* d_patterns,
                                    const uint64_t* d_offsets, uint64_t n_queries, uint64_t total_pattern_bytes,
                                    uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream);
+/* Diagnostic (not the timed path): the default kernel instrumented with shader-clock counters, same results.  d_prof[16],
+ * zeroed by the caller: [0..7] cycles summed over the wavefronts for the phases of a round (loop head / pattern window, step
+ * setup, first block fetch, first evaluation, second fetch + evaluation, outcome + statistics, parent() from the LCP chunks,
+ * parent() tree walk); [8..15] events: rounds, rounds with a second fetch, lane steps, pair attempts, failed pair attempts,
+ * parent() calls, tree walks, second fetches of lanes.  Needs the pair blocks. */
+int gcsa2_match_stats_profile_device(const gcsa2_index* index, const uint8_t* d_patterns, const uint64_t* d_offsets,
+                                     uint64_t n_queries, uint64_t total_pattern_bytes, uint16_t* d_ms, uint64_t* d_ranges,
+                                     uint64_t* d_fallbacks, uint64_t* d_prof, void* stream);
 
 /* ---- host-view container file ("G2HV") ---------------------------------------------------
  * Interchange between a process that can read .gcsa / .lcp files (the reference linked with SDSL:
@@ -396,6 +404,21 @@ int gcsa2_group_find_device(gcsa2_group* group, const uint8_t* const* d_patterns
                             const uint64_t* counts, uint64_t* d_ranges_root);
 int gcsa2_group_uses_rccl(const gcsa2_group* group);
 
+/* BASELINE configs[4] over the group -- the two queries of benchmark/query_gcsa.cpp:143-179 whose results are ragged or
+ * long -- with the same contiguous split.  Both are complete on return.
+ * group_match_stats_device: replica r computes the matching statistics of its shard (d_patterns[r], d_offsets[r] rebased
+ *   to 0, counts[r] patterns of pattern_bytes[r] bytes in all); the statistics (sum of pattern_bytes entries + 4 spare,
+ *   8-byte aligned), ranges and parent() counts (may be NULL) are gathered on replica 0's device in query order.
+ * group_locate_device: replica r locates d_ranges[r] (counts[r] ranges); the per-replica totals come first, then the CSR
+ *   offsets (rebased; d_offsets_root has sum of counts + 1 entries) and the values are gathered.  *job owns
+ *   the values on replica 0's device (gcsa2_locate_discard). */
+int gcsa2_group_match_stats_device(gcsa2_group* group, const uint8_t* const* d_patterns, const uint64_t* const* d_offsets,
+                                   const uint64_t* counts, const uint64_t* pattern_bytes, uint16_t* d_ms_root,
+                                   uint64_t* d_ranges_root, uint64_t* d_fallbacks_root);
+int gcsa2_group_locate_device(gcsa2_group* group, const uint64_t* const* d_ranges, const uint64_t* counts, int sort,
+                              uint64_t* d_offsets_root, gcsa2_locate_job** job, const uint64_t** d_values_root,
+                              uint64_t* total_values);
+
 /* ---- multi-process multi-GPU: one rank per GPU, one gather of hit ranges ----------------------
  * The single collective of the path: every rank searches its shard with gcsa2_find_device and
  * the (sp, ep) pairs are gathered in the root's HBM with grouped ncclSend / ncclRecv -- every peer uses its own
@@ -413,6 +436,18 @@ int gcsa2_comm_world(const gcsa2_comm* comm);
  * the root receives them back to back in rank order in d_recv (its own part by a device copy; d_recv may be
  * NULL elsewhere).  Enqueues on `stream` of the communicator's device and does not synchronise. */
 int gcsa2_comm_gather(gcsa2_comm* comm, const void* d_send, const uint64_t* bytes, void* d_recv, int root, void* stream);
+/* The same two queries with one rank per GPU: every rank passes its shard and the per-rank sizes (counts[r] queries and, for
+ * the matching statistics, pattern_bytes[r] pattern bytes of rank r: the same arrays on every rank); the results land on
+ * `root` in query order through gcsa2_comm_gather's grouped send / recv.  The *_root arguments are read on the root only.
+ * comm_match_stats only enqueues on `stream` (all three result arrays are required on the root); comm_locate is complete on
+ * return: the per-rank totals travel first, the root sizes the value buffer from them ("all-gather of
+ * per-rank counts, then gatherv of the CSR values"). */
+int gcsa2_comm_match_stats(gcsa2_comm* comm, const gcsa2_index* index, const uint8_t* d_patterns, const uint64_t* d_offsets,
+                           const uint64_t* counts, const uint64_t* pattern_bytes, int root, uint16_t* d_ms_root,
+                           uint64_t* d_ranges_root, uint64_t* d_fallbacks_root, void* stream);
+int gcsa2_comm_locate(gcsa2_comm* comm, const gcsa2_index* index, const uint64_t* d_ranges, const uint64_t* counts, int sort,
+                      int root, uint64_t* d_offsets_root, gcsa2_locate_job** job_root, const uint64_t** d_values_root,
+                      uint64_t* total_values, void* stream);
 /* Wire format for indexes whose path node and edge numbers are all below 2^32: (sp, ep) u64 pairs <->
  * (sp, ep + 1 - sp) u32 pairs, exact for every range find() returns (an empty range is (x, x - 1),
  * include/gcsa/utils.h:93-96).  Halves the bytes of the gather.  Launch on the current device. */

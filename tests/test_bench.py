@@ -68,7 +68,7 @@ def test_branching_workload_line():
 def test_distributed_path_world_size_1(no_comm):
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
              "--master-port", str(free_port()), "bench.py", "--gpus", "1", "--degree", "24", "--queries", "1000001", "--steps", "3",
-             "--warmup", "1", "--no-cpu"], env={"GCSA2_BENCH_NO_COMM": no_comm})
+             "--warmup", "1", "--no-cpu", "--secondary", "config5"], env={"GCSA2_BENCH_NO_COMM": no_comm})
     check_line(d, 1, 3)
     assert ("gcsa2_comm_gather" in d["config"]["parallelism"]) == (no_comm == "")
     assert "u32 pairs" in d["config"]["parallelism"]
@@ -77,6 +77,10 @@ def test_distributed_path_world_size_1(no_comm):
 def test_two_ranks_share_the_gpu_through_the_host():
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
              "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--degree", "24", "--queries", "1000001", "--steps", "2",
-             "--warmup", "1", "--no-cpu"], env={"GCSA2_BENCH_BACKEND": "gloo"})
+             "--warmup", "1", "--no-cpu", "--secondary", "config5"], env={"GCSA2_BENCH_BACKEND": "gloo"})
     check_line(d, 2, 2)
     assert d["scaling"] == "strong" and d["config"]["queries_per_gpu"] == 500001 and d["config"]["queries_total"] == 1000001
+    # config 5 sharded over the two ranks: matching statistics and the CSR of located values gathered on the root
+    c5 = d["config5"]
+    assert c5["n_gpus"] == 2 and c5["unmodified_half_equals_closed_form"] is True
+    assert c5["locate"]["count_equals_located"] is True and c5["locate"]["unmodified_half_equals_closed_form"] is True

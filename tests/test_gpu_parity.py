@@ -854,6 +854,88 @@ def test_group_find_device_and_comm(engine):
     assert torch.equal(d_in, d_back)
 
 
+def test_sharded_match_stats_and_locate(engine):
+    """BASELINE configs[4] sharded: matching statistics and locate() of a batch split contiguously over
+    replicas, results gathered on the root in query order -- the CSR offsets rebased by the per-shard totals.  On a 1-GPU box
+    the replicas of a group share device 0 (peer copies) and the communicator has world size 1; ragged shards, an empty
+    shard, and ranges of every width.  Must equal the unsharded oracle, and count == |locate| on the gathered result
+    (benchmark/query_gcsa.cpp:171-179)."""
+    import torch
+    from oracle.oracle import OracleIndex
+    from gcsa2_amd.shard import shard_bounds, slice_batch
+    name, g, K = CASES[-1]
+    ix = build(g, K, sample_period=8, branching=4)
+    cpu = OracleIndex(ix)
+    pats = [p for p in random_patterns(g, 3 * K, 0x7B, 301)] + [b"", b"N", b"ACGTTTTTT", b"A", b"C"]
+    data, off = concat_patterns(pats)
+    cm, cr, cf = cpu.match_stats_batch(data, off, threads=2)
+    ranges = np.array([r for r in all_ranges(ix, 0x7C, 150) if r[0] <= r[1]], dtype=np.uint64)
+    lo, lv = cpu.locate_batch(ranges)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    total = int(off[-1])
+
+    def shards(bounds):
+        keep, d_pat, d_off, nbytes = [], [], [], []
+        for b, e in bounds:
+            sub, so = slice_batch(data, off, b, e)
+            tp = torch.from_numpy(np.concatenate([sub, np.zeros(16, dtype=np.uint8)])).to(dev)
+            to = torch.from_numpy(so.view(np.int64).copy()).to(dev)
+            keep += [tp, to]; d_pat.append(tp.data_ptr()); d_off.append(to.data_ptr()); nbytes.append(int(so[-1]))
+        return keep, d_pat, d_off, nbytes
+
+    for devices in ([0], [0, 0, 0], [0] * 4):
+        G = len(devices)
+        grp = engine.GCSAGroup(ix, devices)
+        bounds = shard_bounds(len(pats), G)
+        if G == 4:                                                # ragged: an empty shard in the middle
+            bounds = [(0, 7), (7, 7), (7, 200), (200, len(pats))]
+        keep, d_pat, d_off, nbytes = shards(bounds)
+        d_ms = torch.full((total + 8,), -5, dtype=torch.int16, device=dev)
+        d_rng = torch.zeros((len(pats), 2), dtype=torch.int64, device=dev)
+        d_fb = torch.zeros(len(pats), dtype=torch.int64, device=dev)
+        grp.match_stats_device(d_pat, d_off, [e - b for b, e in bounds], nbytes, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr())
+        assert np.array_equal(d_ms[:total].cpu().numpy().view(np.uint16), cm), devices
+        assert np.array_equal(d_rng.cpu().numpy().view(np.uint64), cr) and np.array_equal(d_fb.cpu().numpy().view(np.uint64), cf), devices
+        rb = shard_bounds(ranges.shape[0], G) if G != 4 else [(0, 1), (1, 1), (1, 90), (90, ranges.shape[0])]
+        parts = [torch.from_numpy(ranges[b:e].view(np.int64).copy()).to(dev) if e > b else torch.zeros((1, 2), dtype=torch.int64, device=dev) for b, e in rb]
+        d_loff = torch.full((ranges.shape[0] + 1,), -1, dtype=torch.int64, device=dev)
+        for sort in (True, False):
+            job, d_val, nval = grp.locate_device([p_.data_ptr() for p_ in parts], [e - b for b, e in rb], d_loff.data_ptr(), sort=sort)
+            if sort:
+                want_o, want_v = lo, lv
+            else:                                                 # path order, duplicates kept
+                parts = [cpu.locate((int(a), int(b)), sort=False) for a, b in ranges]
+                want_o = np.concatenate([[0], np.cumsum([len(p_) for p_ in parts])]).astype(np.uint64)
+                want_v = np.concatenate(parts).astype(np.uint64) if parts else np.zeros(0, dtype=np.uint64)
+            assert nval == int(want_o[-1]) and np.array_equal(d_loff.cpu().numpy().view(np.uint64), want_o), (devices, sort)
+            assert np.array_equal(engine.fetch_job(job, nval), want_v), (devices, sort)
+        counts = cpu.count_batch(ranges)
+        assert np.array_equal(np.diff(lo), counts)
+        grp.close()
+    # one rank per GPU: the RCCL communicator with world size 1 (the gathers are the root's own device copies)
+    gpu, _ = engine.open_index(ix, device=0)
+    try:
+        comm = engine.Comm(engine.Comm.unique_id(), 0, 1, 0)
+    except engine.Gcsa2Error as e:
+        assert e.code == -5
+        return
+    keep, d_pat, d_off, nbytes = shards([(0, len(pats))])
+    d_ms = torch.full((total + 8,), -5, dtype=torch.int16, device=dev)
+    d_rng = torch.zeros((len(pats), 2), dtype=torch.int64, device=dev)
+    d_fb = torch.zeros(len(pats), dtype=torch.int64, device=dev)
+    comm.match_stats(gpu, d_pat[0], d_off[0], [len(pats)], nbytes, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ms[:total].cpu().numpy().view(np.uint16), cm)
+    assert np.array_equal(d_rng.cpu().numpy().view(np.uint64), cr) and np.array_equal(d_fb.cpu().numpy().view(np.uint64), cf)
+    d_r = torch.from_numpy(ranges.view(np.int64).copy()).to(dev)
+    d_loff = torch.zeros(ranges.shape[0] + 1, dtype=torch.int64, device=dev)
+    job, d_val, nval = comm.locate(gpu, d_r.data_ptr(), [ranges.shape[0]], d_loff.data_ptr(), 0, st)
+    assert nval == int(lo[-1]) and np.array_equal(d_loff.cpu().numpy().view(np.uint64), lo)
+    assert np.array_equal(engine.fetch_job(job, nval), lv)
+    comm.close()
+
+
 def test_locate_segment_sizes(engine):
     """removeDuplicates at every segment size class: 1 value, 2..16 (registers, one lane), 17..1024 (one wavefront in
     LDS), more (segmented radix sort), mixed in one batch and in both sort modes; ranges of consecutive path nodes of a

@@ -117,6 +117,48 @@ def test_sharded_find_gloo_world2(tmp_path, nq):
     assert out.read_text() == "ok"
 
 
+def _worker_config5(rank, world, port, nq, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from workload import graphs
+    from workload.brute_builder import build
+    from workload.rng import SplitMix64
+    from gcsa2_amd.hostview import concat_patterns
+    from gcsa2_amd.shard import locate_sharded, match_stats_sharded
+    from oracle.oracle import OracleIndex
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ix = build(graphs.snp_graph(120, 0x52, 0x53, snp_period=8, node_len=8), 6, sample_period=8, branching=4)
+    cpu = OracleIndex(ix)   # stands in for the GPU engine: this test covers the sharding and the CSR gather only
+    rng = SplitMix64(11)
+    pats = ["".join("ACGTN"[rng.below(5)] for _ in range(rng.below(9))).encode() for _ in range(nq)]
+    flat, off = concat_patterns(pats)
+    res = match_stats_sharded(lambda f, o: cpu.match_stats_batch(f, o), flat, off)
+    ranges = cpu.find_batch(flat, off)
+    ranges = ranges[(ranges[:, 0] <= ranges[:, 1]) & (ranges[:, 1] < ix.n)]
+    loc = locate_sharded(lambda r: cpu.locate_batch(r), ranges)
+    if rank == 0:
+        cm, cr, cf = cpu.match_stats_batch(flat, off)
+        assert np.array_equal(res[0], cm) and np.array_equal(res[1], cr) and np.array_equal(res[2], cf)
+        lo, lv = cpu.locate_batch(ranges)
+        assert np.array_equal(loc[0], lo) and np.array_equal(loc[1], lv)
+        assert np.array_equal(np.diff(loc[0]), cpu.count_batch(ranges))          # benchmark/query_gcsa.cpp:171-179
+        open(out_path, "w").write("ok")
+    else:
+        assert res is None and loc is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nq", [(2, 101), (3, 2), (2, 1)])
+def test_sharded_config5_gloo(tmp_path, world, nq):
+    """The control flow of the sharded matching statistics and locate (gcsa2_comm_match_stats / gcsa2_comm_locate):
+    contiguous shards, per-rank totals, CSR offsets rebased on the root -- with the oracle standing in for the engine."""
+    import torch.multiprocessing as mp
+    out = tmp_path / "ok.txt"
+    mp.spawn(_worker_config5, args=(world, _free_port(), nq, str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
+
+
 def test_host_view_file_round_trip(built, tmp_path):
     """G2HV container: save -> load -> identical arrays (host only, no device)."""
     import ctypes as C
