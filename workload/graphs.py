@@ -242,3 +242,56 @@ def random_graph(n: int, seed: int, p_branch: float = 0.25, p_back: float = 0.0,
             off = 0
         value[i] = encode_node(node_id, off)
     return _from_adj(comp, value, adj, 0, N - 1)
+
+
+# ---- a repeat-rich backbone: the range widths of real genomes -------------------------------------------------------
+# The paper's human indexes answer a found 32-mer with 336 path nodes on average and a 16-mer with 7129
+# (paper/paper.tex:403,408): interspersed repeat families and tandem arrays.  A uniform random backbone has unique
+# 16-mers, so every range of the other workloads is a singleton after a few steps.  This backbone plants, in blocks of
+# REPEAT_BLOCK bases: an Alu-like family (a 300-bp consensus, one copy per block, 10 % of the bases of every copy
+# substituted independently), a younger family (a 1000-bp consensus filling one block in 16, 2 % divergence) and short
+# tandem arrays (unit of 2..7 bases repeated over 150..400 bases in one block in 16).
+REPEAT_BLOCK = 1000
+
+
+def repeat_bases(n: int, seed: int, alu_divergence: float = 0.10, young_divergence: float = 0.02) -> np.ndarray:
+    """n comp codes (1..4): random bases with the planted repeat families described above."""
+    seq = random_bases(n, seed)
+    blocks = n // REPEAT_BLOCK
+    if blocks == 0:
+        return seq
+    h = splitmix64_array(seed ^ 0x5EED5EED, blocks)
+    alu = random_bases(300, seed ^ 0xA1)
+    young = random_bases(REPEAT_BLOCK, seed ^ 0xA2)
+    base = np.arange(blocks, dtype=np.int64) * REPEAT_BLOCK
+    kind = (h >> np.uint64(4)) % np.uint64(16)                    # 0: young family, 1: tandem array, else: Alu-like copy
+
+    def mutate(copy_positions, consensus_bases, divergence, salt):
+        r = splitmix64_array(seed ^ salt, copy_positions.size).reshape(copy_positions.shape)
+        hit = (r >> np.uint64(11)) % np.uint64(10000) < np.uint64(int(divergence * 10000))
+        shift = ((r >> np.uint64(40)) % np.uint64(3)).astype(np.uint8) + 1
+        return np.where(hit, (consensus_bases - 1 + shift) % 4 + 1, consensus_bases).astype(np.uint8)
+
+    sel = np.flatnonzero(kind >= 2)
+    if sel.size:
+        off = ((h[sel] >> np.uint64(20)) % np.uint64(REPEAT_BLOCK - 300)).astype(np.int64)
+        pos = (base[sel] + off)[:, None] + np.arange(300, dtype=np.int64)[None, :]
+        seq[pos] = mutate(pos, np.broadcast_to(alu, pos.shape), alu_divergence, 0xB1)
+    sel = np.flatnonzero(kind == 0)
+    if sel.size:
+        pos = base[sel][:, None] + np.arange(REPEAT_BLOCK, dtype=np.int64)[None, :]
+        seq[pos] = mutate(pos, np.broadcast_to(young, pos.shape), young_divergence, 0xB2)
+    sel = np.flatnonzero(kind == 1)
+    for j in sel:                                                 # one block in 16: a loop over ~n / 16000 arrays
+        hj = int(h[j])
+        unit_len = 2 + (hj >> 24) % 6
+        length = 150 + (hj >> 32) % 251
+        start = int(base[j]) + (hj >> 44) % (REPEAT_BLOCK - length)
+        unit = random_bases(unit_len, (seed ^ hj) & 0xFFFFFFFFFFFFFFFF)
+        seq[start:start + length] = np.resize(unit, length)
+    return seq
+
+
+def repeat_graph(n: int, seed: int, snp_seed, snp_period: int = 32, node_len: int = 32) -> Graph:
+    """The chr22-like SNP graph over a repeat-rich backbone (repeat_bases)."""
+    return snp_graph(n, seed, snp_seed, snp_period=snp_period, node_len=node_len, sequence=repeat_bases(n, seed))
