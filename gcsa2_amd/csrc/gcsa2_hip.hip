@@ -502,6 +502,10 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
   if(count <= 0) { return fail(GCSA2_ERR_NO_DEVICE, "no HIP device visible: " + g_error); }
   if(device < 0 || device >= count) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "device index out of range"); }
 
+  if(v->sigma * (v->path_nodes / FLB_BITS + 1) >= u64(PAIR_FLAG) || v->lcp_size / 16 + 16 >= u64(PAIR_FLAG))
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "index too large: the block and LCP-window indices of the fetch keep two flag bits");
+  }
   if(v->path_nodes > MAX_PATH_NODES || v->edges > 2 * MAX_PATH_NODES)
   {
     return fail(GCSA2_ERR_INVALID_ARGUMENT, "index of more than 2^38 path nodes: beyond what one device holds and what the block indices of this build address");
@@ -567,9 +571,11 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     if(img.has_lcp)
     {
       img.lcp_size = v->lcp_size; img.lcp_branching = v->lcp_branching; img.lcp_levels = v->lcp_levels;
+      img.lcp_shift = 0;
+      if((v->lcp_branching & (v->lcp_branching - 1)) == 0) { while((u64(1) << img.lcp_shift) < v->lcp_branching) { img.lcp_shift++; } }
       for(u64 l = 0; l <= v->lcp_levels; l++) { img.lcp_offsets[l] = v->lcp_offsets[l]; }
       img.lcp_values = v->lcp_offsets[v->lcp_levels];
-      lcp_off = st.reserve((img.lcp_values + 7) / 8 + 2);   // 16-byte chunk reads of the last values stay inside (parent_from_chunks)
+      lcp_off = st.reserve((img.lcp_values + 7) / 8 + 18);  // 128-byte window reads around the last values stay inside (parent_from_window)
       std::memcpy(st.words.data() + lcp_off, v->lcp_data, img.lcp_values);
     }
 

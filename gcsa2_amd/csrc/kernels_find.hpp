@@ -207,10 +207,11 @@ __device__ __forceinline__ void lf_children(const DevImage& img, u32 c0, u32 lim
 }
 
 // wave-cooperative fetch: every lane with need != 0 gets flb block `idx` staged at its slot; with PAIR an
-// index carrying PAIR_FLAG selects block idx & ~PAIR_FLAG of the pair array `flp` instead
-template<bool PAIR = false>
+// index carrying PAIR_FLAG selects block idx & ~PAIR_FLAG of the pair array `flp` instead; with LCPW an index carrying
+// LCP_FLAG selects the 128 bytes of the LCP array that start at byte 16 * (idx & ~LCP_FLAG)
+template<bool PAIR = false, bool LCPW = false>
 __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane,
-                                             const u64* __restrict__ flp = nullptr)
+                                             const u64* __restrict__ flp = nullptr, const u8* __restrict__ lcp = nullptr)
 {
   u32 sub = lane & 7;
 #pragma unroll
@@ -222,8 +223,11 @@ __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 id
     u32 owner = 8 * j + (lane >> 3);
     u32 oidx = __shfl(need ? idx : 0u, owner, 64);
     const u64* base = flb;
-    if constexpr(PAIR) { base = (oidx & PAIR_FLAG) ? flp : flb; oidx &= ~PAIR_FLAG; }
-    ulonglong2 a = reinterpret_cast<const ulonglong2*>(base + u64(oidx) * FLB_WORDS)[sub];
+    u32 unit = FLB_WORDS;                                     // u64 words per index step
+    if constexpr(PAIR) { base = (oidx & PAIR_FLAG) ? flp : flb; }
+    if constexpr(LCPW) { if(oidx & LCP_FLAG) { base = reinterpret_cast<const u64*>(lcp); unit = 2; } }
+    oidx &= ~(PAIR_FLAG | LCP_FLAG);
+    ulonglong2 a = reinterpret_cast<const ulonglong2*>(base + u64(oidx) * unit)[sub];
     wave_stage[owner * 8 + (sub ^ (owner & 7))] = a;
   }
   __builtin_amdgcn_wave_barrier();

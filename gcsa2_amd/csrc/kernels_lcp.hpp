@@ -15,10 +15,17 @@ struct Lcp
   const DevImage& img;
   __device__ __forceinline__ u64 at(u64 i) const { return img.lcp[i]; }
   __device__ __forceinline__ u64 root() const { return img.lcp_values - 1; }
+  // (a 64-bit division by a run-time value is ~150 instructions; the reference's default branching factor is a power of two)
   __device__ __forceinline__ u64 parent(u64 node, u64 level) const
-  { return img.lcp_offsets[level + 1] + (node - img.lcp_offsets[level]) / img.lcp_branching; }
+  {
+    const u64 d = node - img.lcp_offsets[level];
+    return img.lcp_offsets[level + 1] + (img.lcp_shift != 0 ? d >> img.lcp_shift : d / img.lcp_branching);
+  }
   __device__ __forceinline__ u64 first_sibling(u64 node, u64 level) const
-  { return node - (node - img.lcp_offsets[level]) % img.lcp_branching; }
+  {
+    const u64 d = node - img.lcp_offsets[level];
+    return node - (img.lcp_shift != 0 ? d & (img.lcp_branching - 1) : d % img.lcp_branching);
+  }
   __device__ __forceinline__ u64 last_sibling(u64 first_child, u64 level) const
   {
     u64 a = img.lcp_offsets[level + 1], b = first_child + img.lcp_branching;
@@ -390,48 +397,57 @@ __global__ __launch_bounds__(TPB) void k_pack_patterns(DevImage img, const u8* _
   }
 }
 
-// parent() of (sp, ep) from the two aligned 16-byte chunks of the LCP array that hold LCP[sp] and LCP[ep + 1]
-// (lcp_parent's first loads, widened): node_lcp = max of the two values; the previous / next smaller value on the
-// side(s) that attain it is the nearest smaller byte of the flat array, which is what the tree walks of lcp_psv /
-// lcp_nsv return, so whenever it lies inside the chunk the answer is complete -- one round trip and a few dozen
-// instructions instead of three dependent ones and two tree walks.  false: not decidable from the chunks (a bound
-// at the chunk's edge, a wider interval, the array's ends) -- the caller runs lcp_parent.
-__device__ __forceinline__ bool parent_from_chunks(const DevImage& img, u64 sp, u64 ep, gcsa2_stnode& out)
+// parent() of (sp, ep) from a 128-byte window of the LCP array staged in the lane's LDS slot (fetch_blocks with LCP_FLAG): the
+// window starts at byte `wstart` (a multiple of 16), 48..63 positions before sp.  node_lcp = max(LCP[sp], LCP[ep + 1]); the
+// previous / next smaller value on the side(s) that attain it is the nearest smaller byte of the flat array, which is what
+// the tree walks of lcp_psv / lcp_nsv return, so whenever both lie inside the window the answer is complete.  false: not
+// decidable from the window (the interval reaches beyond it, or touches the array's ends) -- the caller runs lcp_parent.
+// After a failed LF step the climb rarely passes intervals of a few dozen path nodes (a range of w nodes extends with
+// probability 1 - 0.73^w on a whole-genome index), so the window decides nearly every call; round 2's two 16-byte chunks left
+// 39 % of the calls to the tree walk, which then was 44 % of the kernel's time (profiles/r03_match_stats.md).
+__device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage, u32 lane, u64 wstart, u64 lcp_size, u64 sp, u64 ep,
+                                                   gcsa2_stnode& out)
 {
-  if(ep + 2 >= img.lcp_size || sp == 0) { return false; }
-  const ulonglong2* chunks = reinterpret_cast<const ulonglong2*>(img.lcp);
-  const ulonglong2 left = chunks[sp >> 4], right = chunks[(ep + 1) >> 4];
-  const u32 lo = u32(sp & 15), ro = u32((ep + 1) & 15);
-  const u64 left_lcp = ((lo < 8 ? left.x : left.y) >> (8 * (lo & 7))) & 0xFF;
-  const u64 right_lcp = ((ro < 8 ? right.x : right.y) >> (8 * (ro & 7))) & 0xFF;
+  if(sp == 0 || ep + 2 >= lcp_size || ep + 1 >= wstart + 128) { return false; }
+  const u32 lo = u32(sp - wstart), ro = u32(ep + 1 - wstart);              // byte offsets of LCP[sp], LCP[ep + 1] in the window
+  const u64 lw = staged_word(wave_stage, lane, lo >> 3), rw = staged_word(wave_stage, lane, ro >> 3);
+  const u64 left_lcp = (lw >> (8 * (lo & 7))) & 0xFF, right_lcp = (rw >> (8 * (ro & 7))) & 0xFF;
   const u64 node_lcp = (left_lcp > right_lcp ? left_lcp : right_lcp);
   u64 lpos = sp, lval = left_lcp, rpos = ep + 1, rval = right_lcp;
+  bool decided = true;
   if(left_lcp == node_lcp)
   {
-    const u32 mask = (bytes_below(left.x, left_lcp) | (bytes_below(left.y, left_lcp) << 8)) & ((1u << lo) - 1);
-    if(mask == 0) { return false; }
-    const u32 byte = 31 - __clz(int(mask));
-    lpos = (sp & ~u64(15)) + byte; lval = ((byte < 8 ? left.x : left.y) >> (8 * (byte & 7))) & 0xFF;
+    u32 w = lo >> 3;
+    u64 word = lw;
+    u32 mask = bytes_below(word, left_lcp) & ((1u << (lo & 7)) - 1);
+    while(mask == 0 && w > 0) { w--; word = staged_word(wave_stage, lane, w); mask = bytes_below(word, left_lcp); }
+    if(mask == 0) { decided = false; }
+    else { const u32 byte = 31 - __clz(int(mask)); lpos = wstart + 8 * w + byte; lval = (word >> (8 * byte)) & 0xFF; }
   }
   if(right_lcp == node_lcp)
   {
-    const u64 base = (ep + 1) & ~u64(15);
-    u32 mask = (bytes_below(right.x, right_lcp) | (bytes_below(right.y, right_lcp) << 8)) & ~((2u << ro) - 1) & 0xFFFF;
-    if(base + 16 > img.lcp_size) { mask &= (1u << (img.lcp_size - base)) - 1; }      // bytes past the array belong to the tree
-    if(mask == 0) { return false; }
-    const u32 byte = u32(__ffs(int(mask))) - 1;
-    rpos = base + byte; rval = ((byte < 8 ? right.x : right.y) >> (8 * (byte & 7))) & 0xFF;
+    // (the positions up to ep + 2 exist; bytes at or past lcp_size belong to the tree and are masked)
+    const u32 last = (wstart + 128 <= lcp_size ? 15u : u32((lcp_size - 1 - wstart) >> 3));
+    u32 w = ro >> 3;
+    u64 word = rw;
+    u32 mask = bytes_below(word, right_lcp) & ~((2u << (ro & 7)) - 1) & 0xFF;
+    while(mask == 0 && w < last) { w++; word = staged_word(wave_stage, lane, w); mask = bytes_below(word, right_lcp); }
+    if(w == last && wstart + 8 * w + 8 > lcp_size) { mask &= (1u << (lcp_size - wstart - 8 * w)) - 1; }
+    if(mask == 0) { decided = false; }
+    else { const u32 byte = u32(__ffs(int(mask))) - 1; rpos = wstart + 8 * w + byte; rval = (word >> (8 * byte)) & 0xFF; }
   }
   out = gcsa2_stnode{lpos, rpos - 1, lval, rval, node_lcp};
-  return true;
+  return decided;
 }
 
 // ---- matching statistics, version 2: wave-cooperative block fetch, two characters per step, batched parent() ----
 // Same results as k_match_stats.  One lane = one pattern; the LF steps of the 64 patterns of a wave go through the
 // cooperative fetch of k_find2 (one 128-byte request per endpoint, FLP128 pair blocks when the next two
 // characters are fast characters and the block proves that neither step empties -- both matching statistics
-// then follow at once: depth + 1 and depth + 2).  A lane whose step empties runs LCPArray::parent (lcp.cpp:276-301) in the
-// same round and retries the character in the next one.
+// then follow at once: depth + 1 and depth + 2).  A lane whose step empties spends its next round on LCPArray::parent
+// (lcp.cpp:276-301) -- the 128 bytes of the LCP array around its range travel through the same cooperative fetch as the other
+// lanes' blocks and decide the call in all but a few per cent of the cases (parent_from_window) -- and retries the character
+// in the round after that.
 // After a step that needed parent() the next COOL_DOWN characters are stepped singly: right after a mismatch the match is
 // short and the following characters fail often, so a pair attempt mostly wastes its round (deep suffix tree, 37 parent()
 // calls per pattern: 60 -> 68 M patterns/s with 6; 3 / 12 / 24 give 67 / 67 / 66; profiles/r02_config5.md).
@@ -448,7 +464,7 @@ constexpr u64 MS_REFILL_MIN = u64(1) << 19;             // host-pointer API: sma
 // (profiles/r02_config5.md).
 // PROF = true (gcsa2_match_stats_profile_device, a diagnostic): shader-clock cycles per phase of the round, summed over the
 // waves, and event counts, added to prof[0..15]: 0 loop head / window, 1 step setup, 2 first fetch, 3 first evaluation,
-// 4 second fetch + evaluation, 5 outcome + statistics, 6 parent() from the chunks, 7 parent() tree walk; 8 rounds (per wave),
+// 4 second fetch + evaluation, 5 outcome + statistics, 6 parent() from the LCP window, 7 parent() tree walk; 8 rounds (per wave),
 // 9 rounds with a second fetch, 10 lane steps, 11 lane pair attempts, 12 failed pair attempts, 13 parent() calls, 14 tree walks,
 // 15 lane second fetches.
 template<bool PAIR, bool REFILL, bool PROF = false>
@@ -550,9 +566,17 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       win_used = 0;
     }
     G2_TICK(0);
-    const bool stepping = active && !need_parent;
+    const bool stepping = active && !need_parent, parenting = active && need_parent;
     u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
     bool pair = false;
+    u64 wstart = 0;
+    if(parenting)
+    {
+      // parent(): the 128 bytes of the LCP array around the range, through the same cooperative fetch as the blocks
+      const u64 unit = sp >> 4;
+      wstart = (unit >= 3 ? unit - 3 : 0) << 4;
+      idx_sp = idx_ep = u32(wstart >> 4) | LCP_FLAG;
+    }
     if(stepping)
     {
       const u32 r = win_used;                                  // window slot of position i - 1
@@ -586,12 +610,13 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     }
     PairEnd p_sp = {0, 0, 0}, p_ep = {0, 0, 0};                // a single step keeps (edge, node) in .raw / .node
     const bool need2 = stepping && idx_ep != idx_sp;
+    gcsa2_stnode node;
+    bool decided = false;
     G2_TICK(1);
     G2_COUNT(0, lane == 0); G2_COUNT(2, stepping); G2_COUNT(3, pair); G2_COUNT(7, need2);
-    if(__any(stepping))
     {
-      fetch_blocks<PAIR>(img.flb, idx_sp, stepping, wave_stage, lane, img.flp);
-      if constexpr(PROF) { if(stepping) { asm volatile("" :: "v"(wave_stage[lane * 8 + (lane & 7)].x)); } }     // the fetch has landed
+      fetch_blocks<PAIR, true>(img.flb, idx_sp, active, wave_stage, lane, img.flp, img.lcp);
+      if constexpr(PROF) { if(active) { asm volatile("" :: "v"(wave_stage[lane * 8 + (lane & 7)].x)); } }     // the fetch has landed
       G2_TICK(2);
       if(stepping)                               // one evaluation for single and pair steps alike (eval_staged)
       {
@@ -599,6 +624,9 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         if(idx_ep == idx_sp) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
       }
       G2_TICK(3);
+      if(parenting) { decided = parent_from_window(wave_stage, lane, wstart, img.lcp_size, sp, ep, node); G2_COUNT(5, 1); }
+      if constexpr(PROF) { if(parenting && decided) { asm volatile("" :: "v"(node.sp)); } }
+      G2_TICK(6);
       if(__any(need2))
       {
         G2_COUNT(1, lane == 0);
@@ -637,19 +665,13 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
           emit(i - 1, 0); i--; win_used++;
           force_single -= (force_single > 0 ? 1 : 0);
         }
-        else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }
+        else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }   // parent() in the next round
       }
     }
     G2_TICK(5);
-    // parent() as soon as a lane needs it (deferring it until more lanes of the wave wait measured slower, profiles/r02_config5.md)
-    bool walk = false;
-    gcsa2_stnode node;
-    if(need_parent) { walk = !parent_from_chunks(img, sp, ep, node); G2_COUNT(5, 1); }
-    if constexpr(PROF) { if(need_parent && !walk) { asm volatile("" :: "v"(node.sp)); } }
-    G2_TICK(6);
-    if(walk) { lcp_parent(img, sp, ep, node); G2_COUNT(6, 1); }
-    if(need_parent)
+    if(parenting)
     {
+      if(!decided) { lcp_parent(img, sp, ep, node); G2_COUNT(6, 1); }      // the interval reaches beyond the window: tree walk (lcp.cpp:276-301)
       calls++;
       sp = node.sp; ep = node.ep; depth = node.node_lcp;
       need_parent = false;

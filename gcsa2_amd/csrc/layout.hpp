@@ -88,7 +88,8 @@ constexpr u64 FLB_BYTES     = 128;
 constexpr u64 PREV_BIT      = u64(1) << 63;
 constexpr u64 PAIR_BITS     = 192;           // positions per FLP128 block (three payload rows of three words)
 constexpr u32 PAIR_WORDS    = 3;
-constexpr u32 PAIR_FLAG     = u32(1) << 31;  // block index refers to the FLP128 array
+constexpr u32 PAIR_FLAG     = u32(1) << 30;  // block index refers to the FLP128 array
+constexpr u32 LCP_FLAG      = u32(1) << 31;  // "block" index refers to the LCP array, in 16-byte units (a 128-byte window of it)
 constexpr int MAX_SIGMA     = 16;
 constexpr int MAX_LCP_LEVELS = 64;      // a binary tree (branching 2, the smallest the reference allows) over 2^63 values
 
@@ -115,7 +116,7 @@ struct DevImage
                                // (gcsa.h:165-183 probe order), bit 3 = sampled(node); nullptr if sigma > 8
   const u64* kmer_table;       // find() of every k-mer over comps 1..4: 4^kmer_k packed entries (kernels_find.hpp, seed_pack)
   u32 kmer_k;                  // 0 = no table
-  u32 reserved0;
+  u32 lcp_shift;               // log2(lcp_branching) when that is a power of two (the reference's default 64), else 0
   const ulonglong2* jump_tab;  // memoised unary LF chains, one entry per path node, or nullptr: x = node reached | steps << 56
                                // (0..8 steps), y = the comps (minus 1) of those steps, 2 bits each, first step lowest
   const u64* locate_tab;       // memoised locateInternal walk (gcsa.cpp:880-896), one u64 per path node, or nullptr:
