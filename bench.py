@@ -560,7 +560,7 @@ def measure(args, D, dev, wl, steps, warmup):
         assert torch.equal(mine, d_out), "gathered shard differs from the computed ranges"
 
     # algorithmic traffic of one launch (instrumented kernel, outside the timed region)
-    d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+    d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
     d_out2 = torch.zeros_like(d_out)
     gpu.find_stats_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), nq, d_out2.data_ptr(), d_stats.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()

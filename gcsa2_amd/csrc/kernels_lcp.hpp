@@ -481,13 +481,15 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   if constexpr(PROF) { prof_t = clock64(); }
 #define G2_TICK(phase) do { if constexpr(PROF) { const u64 now_ = clock64(); prof_c[phase] += now_ - prof_t; prof_t = now_; } } while(0)
 #define G2_COUNT(slot, value) do { if constexpr(PROF) { prof_n[slot] += u32(value); } } while(0)
-  __shared__ ulonglong2 stage[TPB2 * 8];
+  __shared__ ulonglong2 stage[(TPB2 / 64) * STAGE_SLOTS * 8];
+  __shared__ u32 extra_table[TPB2 / 64][EXTRA_SLOTS];
   __shared__ u8 c2c[256];
   c2c[threadIdx.x] = img.char2comp[threadIdx.x];
   c2c[threadIdx.x + TPB2] = img.char2comp[threadIdx.x + TPB2];
   __syncthreads();
   const u32 lane = threadIdx.x & 63;
-  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  ulonglong2* wave_stage = stage + (threadIdx.x >> 6) * (STAGE_SLOTS * 8);
+  u32* wave_extra = extra_table[threadIdx.x >> 6];
   u64 q = 0, begin = 0, i = 0, total = 0;
   bool has = false;
   [[maybe_unused]] bool exhausted = false;
@@ -516,6 +518,25 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     q = query; has = true;
     begin = offsets[q]; i = total = offsets[q + 1] - begin;
     sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0);
+    // The k-mer seed table (find() of every k-mer over the fast characters, kernels_find.hpp): when the pattern's last k
+    // characters are fast characters and occur, the search starts behind them -- all k suffixes match, so their statistics
+    // are 1 .. k -- and skips the steps on the widest ranges, whose endpoints lie in different blocks.  An empty or wide
+    // entry starts from scratch.
+    const u32 k = img.kmer_k;
+    if(k > 0 && total >= k && img.n > 0)
+    {
+      const u64 word = (begin >> 5) + q;
+      const u64 tix = codes[word] & ((u64(1) << (2 * k)) - 1);
+      const bool fast = (bad[word] & ((1u << k) - 1)) == 0;
+      const u64 entry = img.kmer_table[fast ? tix : 0];
+      const u64 width = entry >> SEED_SP_BITS;
+      if(fast && width != 0 && width != SEED_WIDE)
+      {
+        sp = entry & SEED_SP_MASK; ep = sp + width - 1;
+        for(u32 j = 0; j < k; j++) { emit(total - 1 - j, j + 1); }
+        depth = k; i = total - k;
+      }
+    }
   };
   if constexpr(!REFILL)
   {
@@ -615,19 +636,22 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     G2_TICK(1);
     G2_COUNT(0, lane == 0); G2_COUNT(2, stepping); G2_COUNT(3, pair); G2_COUNT(7, need2);
     {
-      fetch_blocks<PAIR, true>(img.flb, idx_sp, active, wave_stage, lane, img.flp, img.lcp);
+      u32 count2, my_extra, group_idx;
+      const bool extra = plan_extra(need2, idx_ep, wave_extra, lane, count2, my_extra, group_idx);
+      fetch_blocks<PAIR, true>(img.flb, idx_sp, active, wave_stage, lane, img.flp, img.lcp, group_idx, extra);
       if constexpr(PROF) { if(active) { asm volatile("" :: "v"(wave_stage[lane * 8 + (lane & 7)].x)); } }     // the fetch has landed
       G2_TICK(2);
       if(stepping)                               // one evaluation for single and pair steps alike (eval_staged)
       {
         p_sp = eval_staged(wave_stage, lane, PAIR && pair, r_sp, false);
         if(idx_ep == idx_sp) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
+        else if(extra) { p_ep = eval_staged(wave_stage, 64 + my_extra, PAIR && pair, r_ep, true); }   // the second block came along
       }
       G2_TICK(3);
       if(parenting) { decided = parent_from_window(wave_stage, lane, wstart, img.lcp_size, sp, ep, node); G2_COUNT(5, 1); }
       if constexpr(PROF) { if(parenting && decided) { asm volatile("" :: "v"(node.sp)); } }
       G2_TICK(6);
-      if(__any(need2))
+      if(!extra && count2 != 0)
       {
         G2_COUNT(1, lane == 0);
         __builtin_amdgcn_wave_barrier();

@@ -157,7 +157,10 @@ int gcsa2_find_device_variant(const gcsa2_index* index, int variant, const uint8
  * d_stats[1] += LF steps executed, d_stats[2] += seed-table lookups (8 bytes each), d_stats[3] += jump-table
  * lookups (16 bytes each).  A step whose two endpoints fall into one block counts once; a
  * two-character step counts as two LF steps and one block per distinct endpoint block, and a replayed pair
- * counts every block it fetched.  The caller zeroes the four counters of d_stats. */
+ * counts every block it fetched.  d_stats[4] += fetch rounds taken by lanes (one per single or pair step attempted),
+ * d_stats[5] += those whose two endpoints lay in different blocks (a second fetch round for the whole wavefront),
+ * d_stats[6] += seed-table entries that were marked "wide" (the range is then searched from scratch).
+ * d_stats holds EIGHT counters (rounds 1-2: four; an ABI change of round 3), zeroed by the caller. */
 uint64_t gcsa2_find_block_bytes(const gcsa2_index* index);
 /* Length k of the k-mer seed table built at create time (find() of every k-mer over comps 1..4,
  * memoised: a pattern whose last k characters are fast characters starts at step k).  0 = none.

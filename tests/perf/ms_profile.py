@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--substituted", type=float, default=0.5, help="fraction of the patterns that get a substitution every 41 bp")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="0: one lane per pattern; 5: persistent lanes")
     args = ap.parse_args()
     import torch
     from workload import dbg_torch
@@ -58,7 +59,7 @@ def main():
 
     def run():
         gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), st.cuda_stream,
-                               total_bytes=nq * m)
+                               variant=args.variant, total_bytes=nq * m)
     run()
     torch.cuda.synchronize()
     e0.record(st)
@@ -67,7 +68,7 @@ def main():
     e1.record(st)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.reps
-    out = {"degree": args.degree, "path_nodes": int(ix.n), "edges": int(ix.e), "patterns": nq, "pattern_len": m,
+    out = {"variant": args.variant, "degree": args.degree, "path_nodes": int(ix.n), "edges": int(ix.e), "patterns": nq, "pattern_len": m,
            "substituted_fraction": (1 / every if every else 0), "ms": ms, "patterns_per_s": nq / (ms * 1e-3),
            "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item())}
     if not args.no_profile:

@@ -66,7 +66,7 @@ def main():
     ms = e0.elapsed_time(e1) / args.steps
     got = d_out.cpu().numpy().view(np.uint64)
     exact = bool(np.array_equal(got, exp))
-    d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+    d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
     d_out2 = torch.zeros_like(d_out)
     gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out2.data_ptr(), d_stats.data_ptr(), st.cuda_stream)
     torch.cuda.synchronize()

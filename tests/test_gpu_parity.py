@@ -688,7 +688,7 @@ def test_jump_table(engine, monkeypatch):
         d_pat = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
         d_off = torch.from_numpy(off.view(np.int64).copy()).to(dev)
         d_out = torch.zeros((len(pats), 2), dtype=torch.int64, device=dev)
-        d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
         gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), d_stats.data_ptr(), 0)
         torch.cuda.synchronize()
         assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), case
@@ -785,7 +785,7 @@ def test_pair_blocks(engine, monkeypatch):
             d_out = torch.zeros((len(pats), 2), dtype=torch.int64, device=dev)
             stats = []
             for g_ in (plain, gpu):
-                d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+                d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
                 g_.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), d_stats.data_ptr(), 0)
                 torch.cuda.synchronize()
                 assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), (case, kmer, jump)

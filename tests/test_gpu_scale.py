@@ -368,7 +368,7 @@ def test_branching_footprint_index_closed_form():
             gpu.find_device_variant(variant, d_pat.data_ptr(), d_off.data_ptr(), n, d_out.data_ptr(), st)
             torch.cuda.synchronize()
             assert torch.equal(d_out[:, 0], exp[:n]) and torch.equal(d_out[:, 1], exp[:n]), (m, variant)
-        d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
         d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
         gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), d_stats.data_ptr(), st)
         torch.cuda.synchronize()
