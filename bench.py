@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["pangenome", "pangenome_plain", "pangenome_snp", "human", "human_snp", "chr22", "linear"], default="pangenome",
+    ap.add_argument("--workload", choices=["pangenome", "pangenome_plain", "pangenome_snp", "human", "human_snp", "chr22", "repeats", "linear"], default="pangenome",
                     help="pangenome: whole-human-pangenome-sized branching index (5.73 G path nodes, e = 1.08 n), one batch sharded over "
                          "the GPUs (config 4); pangenome_plain / pangenome_snp: the same text without junction edges / with SNP bubbles "
                          "(6.9 G path nodes); human: rounds 1-2's 2^32 - 1 node index; human_snp: that text with SNP bubbles; "
@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the config-5 and chr22 measurements")
-    ap.add_argument("--secondary", choices=["all", "config5", "chr22", "human32", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
+    ap.add_argument("--secondary", choices=["all", "config5", "chr22", "repeats", "human32", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
     ap.add_argument("--variant", type=int, default=2, help="find launch shape (2 = one lane per query in batch order, 4 = queries ordered by length first)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
@@ -149,6 +149,48 @@ class Dist:
 def shard_bounds(n_queries, world):
     from gcsa2_amd.shard import shard_bounds as sb
     return sb(n_queries, world)
+
+
+def measured_request_ceiling():
+    """Dependent random 128-byte fetches per second on THIS box (gather_bench's lds128 mode, the fetch pattern of k_find2, on a
+    32 GB buffer): the ceiling the headline's request rate is held against.  Boxes differ by a few per cent; the constant of
+    rounds 1-2 (50 G/s) was one box's figure.  Run before the index takes the memory.  None if the tool is missing."""
+    import subprocess
+    tool = os.path.join(ROOT, "gcsa2_amd", "lib", "gather_bench")
+    if not os.path.exists(tool):
+        return None
+    try:
+        out = subprocess.run([tool, "--mode", "lds128", "35"], capture_output=True, text=True, timeout=120)
+        for line in out.stdout.splitlines():
+            parts = line.split()
+            if len(parts) >= 4 and parts[1] == "lds128":
+                return float(parts[2])
+    except (OSError, subprocess.SubprocessError, ValueError):
+        pass
+    return None
+
+
+def device_telemetry(under_load):
+    """Clocks, power and temperatures from rocm-smi while `under_load()` keeps the GPU busy (it enqueues ~1 s of the timed kernel
+    and returns); explains box-to-box differences of the headline.  Whatever rocm-smi reports for device 0, verbatim."""
+    import subprocess
+    import torch
+    info = {}
+    try:
+        under_load()
+        out = subprocess.run(["rocm-smi", "-d", str(torch.cuda.current_device()), "--showclocks", "--showpower", "--showtemp", "--showperflevel",
+                              "--json"], capture_output=True, text=True, timeout=60)
+        torch.cuda.synchronize()
+        try:
+            data = json.loads(out.stdout)
+            card = next(iter(data.values())) if isinstance(data, dict) and data else {}
+            info = {k: v for k, v in card.items() if any(w in k.lower() for w in ("sclk", "mclk", "fclk", "socclk", "power", "temperature", "performance"))}
+        except ValueError:
+            info = {"raw": out.stdout[-600:]}
+    except (OSError, subprocess.SubprocessError) as e:
+        info = {"error": str(e)}
+    torch.cuda.synchronize()
+    return info
 
 
 # ---- workloads -------------------------------------------------------------------------------------------
@@ -565,8 +607,9 @@ def measure(args, D, dev, wl, steps, warmup):
     gpu.find_stats_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), nq, d_out2.data_ptr(), d_stats.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(d_out, d_out2), "instrumented and timed kernels disagree"
-    blocks, lf_steps, lookups, jumps = (int(x) for x in d_stats.cpu())
-    result.update(blocks=blocks, lf_steps=lf_steps, lookups=lookups, jumps=jumps,
+    blocks, lf_steps, lookups, jumps, fetch_steps, second_fetches, wide_seeds, _ = (int(x) for x in d_stats.cpu())
+    result.update(blocks=blocks, lf_steps=lf_steps, lookups=lookups, jumps=jumps, fetch_steps=fetch_steps, second_fetches=second_fetches,
+                  wide_seeds=wide_seeds,
                   algo_bytes=blocks * gpu.find_block_bytes() + lookups * 8 + jumps * 16 + nq * (m + 16),
                   found=int((d_out[:, 0] <= d_out[:, 1]).sum().item()))
     return result
@@ -657,6 +700,7 @@ def find_config(wl, r, world):
             "queries_per_gpu": wl.nq, "pattern_len": wl.m, "index_bytes_hbm": gpu.device_bytes(),
             "pair_block_bytes": gpu.pair_block_bytes(), "single_block_bytes": int(wl.ix.sigma) * (int(wl.ix.n) // 384 + 1) * 128,
             "kmer_table_k": gpu.kmer_table_k(), "found": r["found"], "lf_steps_per_query": r["lf_steps"] / wl.nq,
+            "second_fetch_fraction_of_steps": r["second_fetches"] / max(r["fetch_steps"], 1), "wide_seed_entries_hit": r["wide_seeds"],
             "blocks_per_query": r["blocks"] / wl.nq, "block_bytes": gpu.find_block_bytes(),
             "parallelism": f"replicated index, contiguous query shards x{world}, one gather of ranges per step: {r['gather']}"
                            + (" as (sp, len) u32 pairs" if r["pack32"] else "")}
@@ -861,6 +905,73 @@ def config5_sharded(args, D, wl, dev):
     return out
 
 
+def setup_repeats(args, D, dev, local_rank, nq=None, m=None):
+    """A repeat-rich index: the chr22-like SNP graph over a backbone with planted repeat families (an Alu-like family in every
+    600-bp block at 7 % divergence, a younger 600-bp family, short tandem arrays; workload/graphs.py::repeat_bases), so that
+    found 32-mers match hundreds of path nodes on average and 16-mers thousands, as on the paper's human indexes
+    (paper.tex:403,408) -- the other workloads have unique seed-length k-mers, i.e. singleton ranges."""
+    import torch
+    from workload import graphs, builder, cache, patterns
+    from gcsa2_amd.binding import GCSA
+    wl = Workload()
+    log2_bases = args.log2_bases or 23
+    path = os.path.join(args.cache_dir, f"repeats_{log2_bases}_{args.order}_v1.npz")
+    t = time.time()
+    graph = graphs.repeat_graph(1 << log2_bases, 0x6C5A0020, 0x6C5A0021)
+    ix = None
+    if D.rank == 0 and not os.path.exists(path):
+        os.makedirs(args.cache_dir, exist_ok=True)
+        ix = builder.build(graph, args.order, keep_table=False)
+        cache.save(path + ".tmp.npz", ix)
+        os.replace(path + ".tmp.npz", path)
+    D.barrier()
+    if ix is None:
+        ix = cache.load(path)
+    log(f"repeat-rich index: n={ix.n} e={ix.e} samples={ix.sample_count} ({time.time() - t:.1f} s)")
+    wl.gpu = GCSA(ix, device=local_rank)
+    wl.ix, wl.graph = ix, graph
+    wl.nq = nq or args.queries or 4_000_000
+    wl.m = m or args.pattern_len
+    wl.total_queries = wl.nq * D.world
+    wl.first = wl.nq * D.rank
+    pats = patterns.walk_patterns(graph, wl.nq, wl.m, 0x6C5A0022 + wl.m + 0x1000 * D.rank)
+    flat, off = patterns.as_batch(pats)
+    wl.d_pat = padded_bytes(torch.from_numpy(flat).to(dev))
+    wl.d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    wl.label = (f"repeat-rich SNP graph 2^{log2_bases} bases (planted interspersed and tandem repeats), order-{args.order} GCSA, "
+                f"{wl.nq} x {wl.m}-mer find() per GPU, walks through the graph")
+    return wl
+
+
+def repeats_secondary(args, D, dev, local_rank):
+    """The hot path on WIDE ranges: find() of 32-mers and 16-mers on the repeat-rich index, with the share of steps that need a
+    second block, the seed-table entries marked wide, and locate() of the ranges with its segment-size classes."""
+    import torch
+    out = {}
+    for m in (32, 16):
+        wl = setup_repeats(args, D, dev, local_rank, nq=4_000_000, m=m)
+        r = measure(args, D, dev, wl, max(5, args.steps), 2)
+        d_out = r["d_out"]
+        width = (d_out[:, 1] - d_out[:, 0] + 1).to(torch.float64)
+        leg = {"workload": wl.label, "value": wl.nq / (r["kernel_ms"] * 1e-3), "unit": "queries/s", "kernel_ms": r["kernel_ms"],
+               "mean_range_width_path_nodes": float(width.mean().item()), "ranges_wider_than_one": float((width > 1).to(torch.float64).mean().item()),
+               "config": find_config(wl, r, 1), "roofline": roofline(args, r, wl, f"repeats_{args.log2_bases or 23}_{m}_S")}
+        if not args.no_cpu:
+            leg["cpu_baseline"] = cpu_baseline(args, wl, d_out, args.cpu_seconds / 4)
+        # locate() of the first ranges (the whole batch would be billions of values), with the sizes the sort has to handle
+        nloc = 400_000 if m == 32 else 100_000
+        loc, d_loff, _ = measure_locate(wl.gpu, d_out[:nloc].contiguous(), dev, 3)
+        sizes = d_loff[1:] - d_loff[:-1]
+        loc["segments"] = {"one value": int((sizes == 1).sum().item()), "2..16": int(((sizes >= 2) & (sizes <= 16)).sum().item()),
+                           "17..1024": int(((sizes >= 17) & (sizes <= 1024)).sum().item()), "more than 1024": int((sizes > 1024).sum().item()),
+                           "largest": int(sizes.max().item())}
+        leg["locate"] = loc
+        out[f"{m}-mers"] = leg
+        del r, d_out
+        release(wl)
+    return out
+
+
 def chr22_secondary(args, D, dev, local_rank):
     """BASELINE configs[1] and [2] on one GPU."""
     wl = setup_chr22(args, D, dev, local_rank, nq=10_000_000)
@@ -991,6 +1102,9 @@ def main():
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
     from gcsa2_amd import binding
     D.make_comm(binding, local_rank)
+    ceiling = measured_request_ceiling() if (rank == 0 and world == 1) else None
+    if ceiling is not None:
+        log(f"request-rate ceiling of this box: {ceiling:.1f} G dependent random 128-byte fetches/s (gather_bench lds128, 32 GB)")
 
     if args.workload.startswith("pangenome"):
         wl = setup_pangenome(args, D, dev, local_rank)
@@ -998,6 +1112,8 @@ def main():
         wl = setup_human(args, D, dev, local_rank, branching=(args.workload == "human_snp"))
     elif args.workload == "chr22":
         wl = setup_chr22(args, D, dev, local_rank)
+    elif args.workload == "repeats":
+        wl = setup_repeats(args, D, dev, local_rank)
     else:
         wl = setup_linear(args, D, dev, local_rank)
 
@@ -1010,7 +1126,7 @@ def main():
 
     result = None
     if rank == 0:
-        size = {"chr22": args.log2_bases or 25, "linear": args.log2_bases or 30}.get(args.workload, getattr(wl, "degree", args.degree))
+        size = {"chr22": args.log2_bases or 25, "repeats": args.log2_bases or 23, "linear": args.log2_bases or 30}.get(args.workload, getattr(wl, "degree", args.degree))
         result = {
             "metric": "kmer_find_queries_per_sec", "value": wl.total_queries * args.steps / r["elapsed"], "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1021,6 +1137,19 @@ def main():
         }
         result["config"]["pattern_set"] = args.set
         result["config"]["all_ranges_equal_closed_form"] = checked
+        if ceiling is not None:
+            rr = result["roofline"]["request_rate"]
+            rr["ceiling_G_per_s"] = ceiling
+            rr["ceiling_source"] = "gather_bench --mode lds128 35 on this box, before the index was loaded"
+            rr["frac_of_ceiling"] = rr["achieved_G_per_s"] / ceiling
+        if world == 1:
+            st = torch.cuda.current_stream()
+
+            def under_load():
+                d_tmp = torch.zeros((wl.nq, 2), dtype=torch.int64, device=dev)
+                for _ in range(max(1, int(1000 / max(r["kernel_ms"], 0.1)))):
+                    wl.gpu.find_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), wl.nq, d_tmp.data_ptr(), st.cuda_stream)
+            result["device"] = device_telemetry(under_load)
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds)
     secondary = args.workload in ("pangenome", "pangenome_plain", "human") and world == 1 and not args.no_secondary
@@ -1037,6 +1166,8 @@ def main():
         del wl
     if secondary and args.secondary in ("all", "chr22"):
         result["chr22"] = chr22_secondary(args, D, dev, local_rank)
+    if secondary and args.secondary in ("all", "repeats"):
+        result["repeats"] = repeats_secondary(args, D, dev, local_rank)
     if secondary and args.workload != "human" and args.secondary in ("all", "human32") and full_size:
         result["human32"] = human32_secondary(args, D, dev, local_rank)
     if secondary and args.secondary == "human_snp":

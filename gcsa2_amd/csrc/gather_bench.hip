@@ -15,11 +15,13 @@
 // The next block index depends on the fetched data, so chains cannot be overlapped by the
 // hardware; parallelism comes only from resident lanes, exactly as in k_find.
 //
-//   gather_bench [log2_bytes ...]      prints one line per (size, mode)
+//   gather_bench [log2_bytes ...]                  prints one line per (size, mode)
+//   gather_bench --mode lds128 [log2_bytes ...]    that mode only (bench.py: the request-rate ceiling of THIS box)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef uint64_t u64;
@@ -153,9 +155,18 @@ double run(const u64* buf, u64 nblocks, u64 chains, int steps, u64* out, int rep
 int main(int argc, char** argv)
 {
   std::vector<int> sizes;
-  for(int i = 1; i < argc; i++) { sizes.push_back(atoi(argv[i])); }
-  if(sizes.empty()) { sizes = {21, 27, 33}; }   // 2 MB (L2), 128 MB (Infinity Cache), 8 GB (HBM)
   const char* names[7] = {"lane64", "lane16", "lane8x2", "quad", "lds", "lane128", "lds128"};
+  int only = -1;
+  for(int i = 1; i < argc; i++)
+  {
+    if(std::string(argv[i]) == "--mode" && i + 1 < argc)
+    {
+      for(int m = 0; m < 7; m++) { if(std::string(argv[i + 1]) == names[m]) { only = m; } }
+      i++;
+    }
+    else { sizes.push_back(atoi(argv[i])); }
+  }
+  if(sizes.empty()) { sizes = {21, 27, 33}; }   // 2 MB (L2), 128 MB (Infinity Cache), 8 GB (HBM)
   u64* out; CHECK(hipMalloc(&out, 64));
   printf("%-10s %-8s %12s %12s %10s\n", "bytes", "mode", "Gfetch/s", "GB/s(64B)", "chains");
   for(int lg : sizes)
@@ -167,16 +178,17 @@ int main(int argc, char** argv)
     const int steps = 64;
     for(u64 chains : {u64(1) << 22})
     {
-      double r[7];
-      r[0] = run<0>(buf, nblocks, chains, steps, out, 3);
-      r[1] = run<1>(buf, nblocks, chains, steps, out, 3);
-      r[2] = run<2>(buf, nblocks, chains, steps, out, 3);
-      r[3] = run<3>(buf, nblocks, chains, steps, out, 3);
-      r[4] = run<4>(buf, nblocks, chains, steps, out, 3);
-      r[5] = run<5>(buf, nblocks, chains, steps, out, 3);
-      r[6] = run<6>(buf, nblocks, chains, steps, out, 3);
+      double r[7] = {0, 0, 0, 0, 0, 0, 0};
+      if(only < 0 || only == 0) { r[0] = run<0>(buf, nblocks, chains, steps, out, 3); }
+      if(only < 0 || only == 1) { r[1] = run<1>(buf, nblocks, chains, steps, out, 3); }
+      if(only < 0 || only == 2) { r[2] = run<2>(buf, nblocks, chains, steps, out, 3); }
+      if(only < 0 || only == 3) { r[3] = run<3>(buf, nblocks, chains, steps, out, 3); }
+      if(only < 0 || only == 4) { r[4] = run<4>(buf, nblocks, chains, steps, out, 3); }
+      if(only < 0 || only == 5) { r[5] = run<5>(buf, nblocks, chains, steps, out, 3); }
+      if(only < 0 || only == 6) { r[6] = run<6>(buf, nblocks, chains, steps, out, only == 6 ? 10 : 3); }
       for(int m = 0; m < 7; m++)
       {
+        if(only >= 0 && m != only) { continue; }
         printf("2^%-8d %-8s %12.2f %12.1f %10llu\n", lg, names[m], r[m] / 1e9, r[m] * (m >= 5 ? 128 : 64) / 1e9, (unsigned long long)chains);
       }
     }

@@ -256,6 +256,10 @@ __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 id
 // group of 8 lanes picks up the one it loads.  Returns whether the extra slots are used; *mine = this lane's extra slot.
 __device__ __forceinline__ bool plan_extra(bool need2, u32 idx_ep, u32* table, u32 lane, u32& count, u32& mine, u32& group_idx)
 {
+#ifdef GCSA2_AB_NO_EXTRA
+  count = (__any(need2) ? EXTRA_SLOTS + 1 : 0); mine = 0; group_idx = 0;
+  return false;
+#endif
   const u64 wanted = __ballot(need2);
   count = u32(__popcll(wanted));
   mine = u32(__popcll(wanted & ((u64(1) << lane) - 1)));

@@ -522,7 +522,11 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     // characters are fast characters and occur, the search starts behind them -- all k suffixes match, so their statistics
     // are 1 .. k -- and skips the steps on the widest ranges, whose endpoints lie in different blocks.  An empty or wide
     // entry starts from scratch.
+#ifdef GCSA2_AB_NO_MS_SEED
+    const u32 k = 0;
+#else
     const u32 k = img.kmer_k;
+#endif
     if(k > 0 && total >= k && img.n > 0)
     {
       const u64 word = (begin >> 5) + q;

@@ -73,6 +73,42 @@ def test_config2_reduced_full_parity():
     phases(gpu, lcp, cpu, flat, off, ix.n)
 
 
+def test_repeat_rich_index_parity():
+    """Wide ranges on the hot path: the SNP graph over a repeat-rich backbone (workload/graphs.py::repeat_bases: interspersed
+    families and tandem arrays, so that found k-mers match many path nodes, paper.tex:403,408).  The whole query_gcsa phase
+    sequence against the oracle -- find() with endpoints in different blocks at most steps, seed-table entries of wide ranges,
+    locate() with segments of every size class incl. the segmented radix sort, count == |locate|."""
+    import torch
+    from gcsa2_amd.binding import open_index
+    from oracle.oracle import OracleIndex
+    g = graphs.repeat_graph(1 << 19, 0x6C5A0020, 0x6C5A0021)
+    ix = builder.build(g, 256)
+    gpu, lcp = open_index(ix)
+    cpu = OracleIndex(ix)
+    widths = {}
+    for m, nq in ((32, 60_000), (16, 30_000), (8, 2_000)):
+        pats = np.concatenate([patterns.walk_patterns(g, nq, m, 0x6C5A0022 + m), patterns.uniform_patterns(nq // 4, m, 0x6C5A0023 + m)])
+        flat, off = patterns.as_batch(pats)
+        ranges, hit = phases(gpu, lcp, cpu, flat, off, ix.n)
+        widths[m] = float((hit[:, 1] - hit[:, 0] + 1).mean())
+    assert widths[32] > 5 and widths[16] > 50 and widths[8] > 1000            # the ranges are wide (x16 at the bench's 2^23 bases)
+    # the device-resident instrumented kernel sees second blocks and agrees with the default one
+    dev = torch.device("cuda", 0)
+    pats = patterns.walk_patterns(g, 100_000, 16, 0x6C5A0024)
+    flat, off = patterns.as_batch(pats)
+    d_pat = torch.from_numpy(np.concatenate([flat, np.zeros(8, dtype=np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_a = torch.zeros((100_000, 2), dtype=torch.int64, device=dev)
+    d_b = torch.zeros_like(d_a)
+    d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
+    gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), 100_000, d_a.data_ptr(), 0)
+    gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), 100_000, d_b.data_ptr(), d_stats.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(d_a, d_b) and np.array_equal(d_a.cpu().numpy().view(np.uint64), cpu.find_batch(flat, off, threads=8))
+    blocks, steps, lookups, jumps, fetch_steps, second, wide, _ = (int(x) for x in d_stats.cpu())
+    assert blocks == fetch_steps + second and 0 < second < fetch_steps and lookups > 0
+
+
 def test_config2_full_size_properties():
     import torch
     from gcsa2_amd.binding import open_index

@@ -482,3 +482,20 @@ def test_dbg_junction_index_against_the_definition(degree):
         assert (parent[0], parent[1]) == shorter and parent[4] == end, (pat, rng_x, parent, shorter, end)
         checked += 1
     assert checked > 250
+
+
+def test_repeat_rich_backbone():
+    """workload/graphs.py::repeat_bases: seeded, over {A, C, G, T}, and repeat-rich -- sampled 16-mers occur many times
+    (a uniform random backbone of this length has essentially unique 16-mers)."""
+    n = 1 << 18
+    a, b = graphs.repeat_bases(n, 0x6C5A0020), graphs.repeat_bases(n, 0x6C5A0020)
+    assert np.array_equal(a, b) and a.shape == (n,) and int(a.min()) >= 1 and int(a.max()) <= 4
+    assert not np.array_equal(a, graphs.repeat_bases(n, 0x6C5A0021))
+
+    def mean_occurrences(seq):
+        v = np.zeros(n - 15, dtype=np.uint64)
+        for j in range(16):
+            v = (v << np.uint64(2)) | (seq[j: n - 15 + j].astype(np.uint64) - np.uint64(1))
+        uniq, inv, counts = np.unique(v, return_inverse=True, return_counts=True)
+        return float(counts[inv[:: 97]].mean())
+    assert mean_occurrences(a) > 20 and mean_occurrences(graphs.random_bases(n, 0x6C5A0020)) < 1.01

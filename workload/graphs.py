@@ -248,13 +248,14 @@ def random_graph(n: int, seed: int, p_branch: float = 0.25, p_back: float = 0.0,
 # The paper's human indexes answer a found 32-mer with 336 path nodes on average and a 16-mer with 7129
 # (paper/paper.tex:403,408): interspersed repeat families and tandem arrays.  A uniform random backbone has unique
 # 16-mers, so every range of the other workloads is a singleton after a few steps.  This backbone plants, in blocks of
-# REPEAT_BLOCK bases: an Alu-like family (a 300-bp consensus, one copy per block, 10 % of the bases of every copy
-# substituted independently), a younger family (a 1000-bp consensus filling one block in 16, 2 % divergence) and short
-# tandem arrays (unit of 2..7 bases repeated over 150..400 bases in one block in 16).
-REPEAT_BLOCK = 1000
+# REPEAT_BLOCK bases: an Alu-like family (a 300-bp consensus, one copy per block, 7 % of the bases of every copy
+# substituted independently), a younger family (a consensus filling one block in 16, 2 % divergence) and short
+# tandem arrays (unit of 2..7 bases repeated over 150..400 bases in one block in 16).  At 2^23 bases a found 32-mer
+# matches ~300 path nodes on average and a 16-mer ~1300 (the means are carried by the repeats: the median is 1).
+REPEAT_BLOCK = 600
 
 
-def repeat_bases(n: int, seed: int, alu_divergence: float = 0.10, young_divergence: float = 0.02) -> np.ndarray:
+def repeat_bases(n: int, seed: int, alu_divergence: float = 0.07, young_divergence: float = 0.02) -> np.ndarray:
     """n comp codes (1..4): random bases with the planted repeat families described above."""
     seq = random_bases(n, seed)
     blocks = n // REPEAT_BLOCK
