@@ -615,6 +615,27 @@ def measure(args, D, dev, wl, steps, warmup):
     return result
 
 
+def host_batch_rate(wl, d_out, nq=10_000_000):
+    """The PCIe-inclusive rate (never `value`): the first `nq` patterns of the batch in pageable host memory through
+    gcsa2_find_batch -- chunked and double-buffered over pinned staging on several streams (csrc: find_pipelined) -- results
+    back in host memory; checked against the device-resident run."""
+    nq = min(nq, wl.nq)
+    m = wl.m
+    flat = wl.d_pat[: nq * m].cpu().numpy().copy()
+    offsets = np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)
+    wl.gpu.find_batch(flat[: 1_000_000 * m], offsets[:1_000_001])             # first call: the pipeline's pinned and device buffers
+    best, got = None, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got = wl.gpu.find_batch(flat, offsets)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    same = bool(np.array_equal(got, d_out[:nq].cpu().numpy().view(np.uint64)))
+    return {"workload": f"{nq} x {m}-mers in pageable host memory -> gcsa2_find_batch -> ranges in host memory (best of 3)",
+            "value": nq / best, "unit": "queries/s", "ms": best * 1e3, "bytes_per_query_over_pcie": m + 8 + 16,
+            "GB_per_s_end_to_end": nq * (m + 24) / best / 1e9, "equals_device_resident_run": same}
+
+
 def measure_locate(gpu, d_ranges, dev, steps):
     """Secondary figure (BASELINE configs[2]): locate() of the ranges the timed find() returned, into
     caller-owned device buffers (gcsa2_locate_into); reported beside the headline, never part of `value`."""
@@ -1150,6 +1171,7 @@ def main():
                 for _ in range(max(1, int(1000 / max(r["kernel_ms"], 0.1)))):
                     wl.gpu.find_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), wl.nq, d_tmp.data_ptr(), st.cuda_stream)
             result["device"] = device_telemetry(under_load)
+            result["host_batch"] = host_batch_rate(wl, r["d_out"])
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds)
     secondary = args.workload in ("pangenome", "pangenome_plain", "human") and world == 1 and not args.no_secondary

@@ -210,17 +210,13 @@ __device__ __forceinline__ void lf_children(const DevImage& img, u32 c0, u32 lim
 // index carrying PAIR_FLAG selects block idx & ~PAIR_FLAG of the pair array `flp` instead; with LCPW an index carrying
 // LCP_FLAG selects the 128 bytes of the LCP array that start at byte 16 * (idx & ~LCP_FLAG)
 //
-// Extra slots: a step whose two endpoints lie in different blocks needs a second block.  Per lane that is rare once the range
-// is narrow (1 step in 192), per WAVE it is not -- 28 % of the rounds have such a lane, and a second fetch round for it costs
-// the whole wave a memory round trip.  So up to EXTRA_SLOTS second blocks ride along with the first round: slot 64 + s of the
-// wave's stage holds block `extra_idx` of the lanes 8 s .. 8 s + 7 (the caller hands every group the index of the s-th lane
-// that needs one), loaded by a ninth instruction that is in flight together with the eight others.
-constexpr u32 EXTRA_SLOTS = 8;
-constexpr u32 STAGE_SLOTS = 64 + EXTRA_SLOTS;          // 128-byte slots per wave
+// (Round 3 also tried to let up to eight second blocks -- endpoints in different blocks: rare per lane, 28 % of the rounds per
+// wave -- ride along in extra LDS slots of the first round instead of costing the wave a second round trip.  find() did not
+// move, it is bound by the request rate, not by rounds (5.03 G queries/s either way); the matching statistics lost a third
+// to the planning step in front of every fetch.  Dropped; profiles/r03_match_stats.md.)
 template<bool PAIR = false, bool LCPW = false>
 __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane,
-                                             const u64* __restrict__ flp = nullptr, const u8* __restrict__ lcp = nullptr,
-                                             u32 extra_idx = 0, bool extra = false)
+                                             const u64* __restrict__ flp = nullptr, const u8* __restrict__ lcp = nullptr)
 {
   u32 sub = lane & 7;
 #pragma unroll
@@ -239,37 +235,7 @@ __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 id
     ulonglong2 a = reinterpret_cast<const ulonglong2*>(base + u64(oidx) * unit)[sub];
     wave_stage[owner * 8 + (sub ^ (owner & 7))] = a;
   }
-  if(extra)                                                   // wave-uniform
-  {
-    const u32 owner = 64 + (lane >> 3);
-    const u64* base = flb;
-    if constexpr(PAIR) { base = (extra_idx & PAIR_FLAG) ? flp : flb; }
-    const u32 oidx = extra_idx & ~(PAIR_FLAG | LCP_FLAG);
-    ulonglong2 a = reinterpret_cast<const ulonglong2*>(base + u64(oidx) * FLB_WORDS)[sub];
-    wave_stage[owner * 8 + (sub ^ (owner & 7))] = a;
-  }
   __builtin_amdgcn_wave_barrier();
-}
-
-// The lanes that need a second block this round: their number, and for every lane its rank among them.  With 1..EXTRA_SLOTS
-// of them the second blocks use the extra slots: each such lane posts its index in `table` (8 words of LDS per wave) and every
-// group of 8 lanes picks up the one it loads.  Returns whether the extra slots are used; *mine = this lane's extra slot.
-__device__ __forceinline__ bool plan_extra(bool need2, u32 idx_ep, u32* table, u32 lane, u32& count, u32& mine, u32& group_idx)
-{
-#ifdef GCSA2_AB_NO_EXTRA
-  count = (__any(need2) ? EXTRA_SLOTS + 1 : 0); mine = 0; group_idx = 0;
-  return false;
-#endif
-  const u64 wanted = __ballot(need2);
-  count = u32(__popcll(wanted));
-  mine = u32(__popcll(wanted & ((u64(1) << lane) - 1)));
-  group_idx = 0;
-  if(count == 0 || count > EXTRA_SLOTS) { return false; }
-  if(need2) { table[mine] = idx_ep; }
-  __builtin_amdgcn_wave_barrier();
-  group_idx = ((lane >> 3) < count ? table[lane >> 3] : 0u);
-  __builtin_amdgcn_wave_barrier();
-  return true;
 }
 
 __device__ __forceinline__ void read_block(const ulonglong2* wave_stage, u32 lane, ulonglong2 (&blk)[8])
@@ -355,8 +321,7 @@ __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void 
                                                const u32* __restrict__ perm)
 {
   constexpr bool WINDOW = true;               // the packed pattern window (below); the byte-at-a-time path is kept for reference only
-  __shared__ ulonglong2 stage[(TPB2 / 64) * STAGE_SLOTS * 8];
-  __shared__ u32 extra_table[TPB2 / 64][EXTRA_SLOTS];
+  __shared__ ulonglong2 stage[TPB2 * 8];
   __shared__ Tables2 t;
   if(threadIdx.x < 2 * MAX_SIGMA) { t.crange[threadIdx.x] = img.crange[threadIdx.x]; }
   t.c2c[threadIdx.x] = img.char2comp[threadIdx.x];
@@ -364,8 +329,7 @@ __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void 
   __syncthreads();
 
   const u32 lane = threadIdx.x & 63;
-  ulonglong2* wave_stage = stage + (threadIdx.x >> 6) * (STAGE_SLOTS * 8);
-  u32* wave_extra = extra_table[threadIdx.x >> 6];
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
   u64 blocks = 0, steps = 0, lookups = 0, jumps = 0;
   [[maybe_unused]] u64 fetch_steps = 0, second_fetches = 0, wide_seeds = 0;     // STATS only
 
@@ -517,9 +481,7 @@ __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void 
     const bool need2 = stepping && idx_ep != idx_sp;
     if(STATS && stepping) { blocks += 1 + (need2 ? 1 : 0); fetch_steps++; second_fetches += (need2 ? 1 : 0); }
     ulonglong2 blk[8];
-    u32 count2, my_extra, group_idx;
-    const bool extra = plan_extra(need2, idx_ep, wave_extra, lane, count2, my_extra, group_idx);
-    fetch_blocks<PAIR>(img.flb, idx_sp, stepping, wave_stage, lane, img.flp, nullptr, group_idx, extra);
+    fetch_blocks<PAIR>(img.flb, idx_sp, stepping, wave_stage, lane, img.flp);
     if(stepping)
     {
       read_block(wave_stage, lane, blk);
@@ -533,14 +495,8 @@ __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void 
         eval_endpoint(blk, r_sp, 0, p_sp.raw, p_sp.node);      // gcsa.h:271, then rank(edges, sp')
         if(idx_ep == idx_sp) { eval_endpoint(blk, r_ep, 1, p_ep.raw, p_ep.node); }
       }
-      if(extra && need2)                                       // the second block came along in an extra slot
-      {
-        read_block(wave_stage, 64 + my_extra, blk);
-        if(PAIR && pair) { p_ep = eval_pair(blk, r_ep, true); }
-        else { eval_endpoint(blk, r_ep, 1, p_ep.raw, p_ep.node); }
-      }
     }
-    if(!extra && count2 != 0)
+    if(__any(need2))
     {
       __builtin_amdgcn_wave_barrier();
       fetch_blocks<PAIR>(img.flb, idx_ep, need2, wave_stage, lane, img.flp);

@@ -440,6 +440,28 @@ __device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage,
   return decided;
 }
 
+// Zone of a failed single step (FLB128 block staged in the lane's slot, both endpoints at offsets r_sp <= r_ep in it, no B_c
+// one in [r_sp, r_ep)): distance from sp down to the nearest one below it (bits 0-15; 0 = none in the block) and from ep up to
+// the nearest one above it (bits 16-31; 0 = none in the block).
+constexpr u32 ZONE_NONE = ~u32(0);
+__device__ __forceinline__ u32 ones_around(const ulonglong2* wave_stage, u32 lane, u32 r_sp, u32 r_ep)
+{
+  u32 dl = 0, dr = 0;
+  {
+    u32 w = r_sp >> 6;
+    u64 word = staged_word(wave_stage, lane, 2 + w) & ((u64(1) << (r_sp & 63)) - 1);
+    while(word == 0 && w > 0) { w--; word = staged_word(wave_stage, lane, 2 + w); }
+    if(word != 0) { dl = r_sp - (64 * w + 63 - u32(__clzll((long long)word))); }
+  }
+  {
+    u32 w = r_ep >> 6;
+    u64 word = staged_word(wave_stage, lane, 2 + w) & ~((u64(1) << (r_ep & 63)) - 1);
+    while(word == 0 && w < 5) { w++; word = staged_word(wave_stage, lane, 2 + w); }
+    if(word != 0) { dr = 64 * w + u32(__ffsll((long long)word)) - 1 - r_ep + 1; }
+  }
+  return dl | (dr << 16);
+}
+
 // ---- matching statistics, version 2: wave-cooperative block fetch, two characters per step, batched parent() ----
 // Same results as k_match_stats.  One lane = one pattern; the LF steps of the 64 patterns of a wave go through the
 // cooperative fetch of k_find2 (one 128-byte request per endpoint, FLP128 pair blocks when the next two
@@ -481,15 +503,13 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   if constexpr(PROF) { prof_t = clock64(); }
 #define G2_TICK(phase) do { if constexpr(PROF) { const u64 now_ = clock64(); prof_c[phase] += now_ - prof_t; prof_t = now_; } } while(0)
 #define G2_COUNT(slot, value) do { if constexpr(PROF) { prof_n[slot] += u32(value); } } while(0)
-  __shared__ ulonglong2 stage[(TPB2 / 64) * STAGE_SLOTS * 8];
-  __shared__ u32 extra_table[TPB2 / 64][EXTRA_SLOTS];
+  __shared__ ulonglong2 stage[TPB2 * 8];
   __shared__ u8 c2c[256];
   c2c[threadIdx.x] = img.char2comp[threadIdx.x];
   c2c[threadIdx.x + TPB2] = img.char2comp[threadIdx.x + TPB2];
   __syncthreads();
   const u32 lane = threadIdx.x & 63;
-  ulonglong2* wave_stage = stage + (threadIdx.x >> 6) * (STAGE_SLOTS * 8);
-  u32* wave_extra = extra_table[threadIdx.x >> 6];
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
   u64 q = 0, begin = 0, i = 0, total = 0;
   bool has = false;
   [[maybe_unused]] bool exhausted = false;
@@ -497,6 +517,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   u32 calls = 0;
   bool need_parent = false;
   u32 force_single = 0;
+  u32 zone = ZONE_NONE;                     // where the nearest B_c ones around the range of a failed step are (below)
   u64 win_code = 0;                         // packed pattern window, as in k_find2
   u32 win_used = ~u32(0), win_bad = 0;
   u64 packed = 0; u32 have = 0;             // results: four u16 per aligned 8-byte store
@@ -508,6 +529,9 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     if(slot == 0 || pos == 0)
     {
       unsigned short* group = ms + (idx & ~u64(3));
+#ifdef GCSA2_AB_NO_MS_STORE
+      if(packed == 0x123456789ABCDEFull)        // (A/B build: the statistics are not written)
+#endif
       if(have == 15u) { *reinterpret_cast<u64*>(group) = packed; }
       else { for(u32 s = 0; s < 4; s++) { if((have >> s) & 1) { group[s] = (unsigned short)(packed >> (16 * s)); } } }
       packed = 0; have = 0;
@@ -517,16 +541,12 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   {
     q = query; has = true;
     begin = offsets[q]; i = total = offsets[q + 1] - begin;
-    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0);
+    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0); zone = ZONE_NONE;
     // The k-mer seed table (find() of every k-mer over the fast characters, kernels_find.hpp): when the pattern's last k
     // characters are fast characters and occur, the search starts behind them -- all k suffixes match, so their statistics
     // are 1 .. k -- and skips the steps on the widest ranges, whose endpoints lie in different blocks.  An empty or wide
     // entry starts from scratch.
-#ifdef GCSA2_AB_NO_MS_SEED
-    const u32 k = 0;
-#else
     const u32 k = img.kmer_k;
-#endif
     if(k > 0 && total >= k && img.n > 0)
     {
       const u64 word = (begin >> 5) + q;
@@ -640,22 +660,51 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     G2_TICK(1);
     G2_COUNT(0, lane == 0); G2_COUNT(2, stepping); G2_COUNT(3, pair); G2_COUNT(7, need2);
     {
-      u32 count2, my_extra, group_idx;
-      const bool extra = plan_extra(need2, idx_ep, wave_extra, lane, count2, my_extra, group_idx);
-      fetch_blocks<PAIR, true>(img.flb, idx_sp, active, wave_stage, lane, img.flp, img.lcp, group_idx, extra);
+      fetch_blocks<PAIR, true>(img.flb, idx_sp, active, wave_stage, lane, img.flp, img.lcp);
       if constexpr(PROF) { if(active) { asm volatile("" :: "v"(wave_stage[lane * 8 + (lane & 7)].x)); } }     // the fetch has landed
       G2_TICK(2);
       if(stepping)                               // one evaluation for single and pair steps alike (eval_staged)
       {
         p_sp = eval_staged(wave_stage, lane, PAIR && pair, r_sp, false);
         if(idx_ep == idx_sp) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
-        else if(extra) { p_ep = eval_staged(wave_stage, 64 + my_extra, PAIR && pair, r_ep, true); }   // the second block came along
+        // A single step that empties with both endpoints in one block: the block's B_c bits tell how far the nearest ones
+        // lie on either side of [sp, ep] -- LF(range', comp) stays empty for every range' that holds neither (zone, below).
+        // (Taken here: a second fetch round of the wave overwrites the staged blocks.)
+        zone = ZONE_NONE;
+        if(!(PAIR && pair) && idx_ep == idx_sp && range_empty(p_sp.raw, p_ep.raw - 1)) { zone = ones_around(wave_stage, lane, r_sp, r_ep); }
       }
       G2_TICK(3);
-      if(parenting) { decided = parent_from_window(wave_stage, lane, wstart, img.lcp_size, sp, ep, node); G2_COUNT(5, 1); }
+      if(parenting)
+      {
+        // parent() from the staged window -- and again, for as long as the retry is KNOWN to fail: the new range lies inside the
+        // positions the failed step's block covered and reaches neither of the nearest B_c ones (LF(range, comp) is non-empty iff
+        // B_c has a one inside the range, gcsa.h:155-162).  The same parent() calls the reference's loop makes between two
+        // failing LF calls, without the rounds of those LF calls.
+        u32 known_l = 0, known_r = 0, dl = 0, dr = 0;
+        if(zone != ZONE_NONE)
+        {
+          u32 blk_sp, off_sp, blk_ep, off_ep;
+          flb_block_of(sp, blk_sp, off_sp); flb_block_of(ep + 1, blk_ep, off_ep);
+          known_l = off_sp; known_r = u32(FLB_BITS) - off_ep; dl = zone & 0xFFFF; dr = zone >> 16;
+        }
+        u64 csp = sp, cep = ep;
+        decided = true;
+        while(true)
+        {
+          gcsa2_stnode up;
+          if(!parent_from_window(wave_stage, lane, wstart, img.lcp_size, csp, cep, up)) { decided = false; break; }    // tree walk below
+          G2_COUNT(5, 1);
+          calls++; node = up; csp = up.sp; cep = up.ep;
+          if(zone == ZONE_NONE || (csp == 0 && cep == img.n - 1)) { break; }
+          const u64 grow_l = sp - csp, grow_r = cep - ep;
+          if((dl != 0 && grow_l >= dl) || (dr != 0 && grow_r >= dr)) { break; }       // holds a one: the retry succeeds
+          if(grow_l > known_l || grow_r > known_r) { break; }                         // beyond the block: not known
+        }
+        if(!decided && (csp != sp || cep != ep)) { decided = true; }                  // some levels were climbed: retry from there
+      }
       if constexpr(PROF) { if(parenting && decided) { asm volatile("" :: "v"(node.sp)); } }
       G2_TICK(6);
-      if(!extra && count2 != 0)
+      if(__any(need2))
       {
         G2_COUNT(1, lane == 0);
         __builtin_amdgcn_wave_barrier();
@@ -699,8 +748,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     G2_TICK(5);
     if(parenting)
     {
-      if(!decided) { lcp_parent(img, sp, ep, node); G2_COUNT(6, 1); }      // the interval reaches beyond the window: tree walk (lcp.cpp:276-301)
-      calls++;
+      if(!decided) { lcp_parent(img, sp, ep, node); calls++; G2_COUNT(6, 1); G2_COUNT(5, 1); }   // the interval reaches beyond the window: tree walk (lcp.cpp:276-301)
       sp = node.sp; ep = node.ep; depth = node.node_lcp;
       need_parent = false;
     }
