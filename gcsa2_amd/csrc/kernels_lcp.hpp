@@ -440,28 +440,6 @@ __device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage,
   return decided;
 }
 
-// Zone of a failed single step (FLB128 block staged in the lane's slot, both endpoints at offsets r_sp <= r_ep in it, no B_c
-// one in [r_sp, r_ep)): distance from sp down to the nearest one below it (bits 0-15; 0 = none in the block) and from ep up to
-// the nearest one above it (bits 16-31; 0 = none in the block).
-constexpr u32 ZONE_NONE = ~u32(0);
-__device__ __forceinline__ u32 ones_around(const ulonglong2* wave_stage, u32 lane, u32 r_sp, u32 r_ep)
-{
-  u32 dl = 0, dr = 0;
-  {
-    u32 w = r_sp >> 6;
-    u64 word = staged_word(wave_stage, lane, 2 + w) & ((u64(1) << (r_sp & 63)) - 1);
-    while(word == 0 && w > 0) { w--; word = staged_word(wave_stage, lane, 2 + w); }
-    if(word != 0) { dl = r_sp - (64 * w + 63 - u32(__clzll((long long)word))); }
-  }
-  {
-    u32 w = r_ep >> 6;
-    u64 word = staged_word(wave_stage, lane, 2 + w) & ~((u64(1) << (r_ep & 63)) - 1);
-    while(word == 0 && w < 5) { w++; word = staged_word(wave_stage, lane, 2 + w); }
-    if(word != 0) { dr = 64 * w + u32(__ffsll((long long)word)) - 1 - r_ep + 1; }
-  }
-  return dl | (dr << 16);
-}
-
 // ---- matching statistics, version 2: wave-cooperative block fetch, two characters per step, batched parent() ----
 // Same results as k_match_stats.  One lane = one pattern; the LF steps of the 64 patterns of a wave go through the
 // cooperative fetch of k_find2 (one 128-byte request per endpoint, FLP128 pair blocks when the next two
@@ -510,18 +488,22 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   __syncthreads();
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  u64 q = 0, begin = 0, i = 0, total = 0;
+  u64 q = 0, begin = 0;
+  u32 i = 0, total = 0;                     // characters left / in all (a pattern is shorter than 2^32 characters)
   bool has = false;
   [[maybe_unused]] bool exhausted = false;
-  u64 sp = 0, ep = img.n - 1, depth = 0;
-  u32 calls = 0;
+  u64 sp = 0, ep = img.n - 1;
+  u32 depth = 0, calls = 0;
   bool need_parent = false;
   u32 force_single = 0;
-  u32 zone = ZONE_NONE;                     // where the nearest B_c ones around the range of a failed step are (below)
   u64 win_code = 0;                         // packed pattern window, as in k_find2
   u32 win_used = ~u32(0), win_bad = 0;
-  u64 packed = 0; u32 have = 0;             // results: four u16 per aligned 8-byte store
-  auto emit = [&](u64 pos, u64 value)        // ms[begin + pos] = value; positions arrive in descending order
+  // results: eight u16 per 16-byte store (`ms` is 8-byte aligned, the hardware takes the 16-byte store at any dword).  The
+  // statistics are a third of the kernel's memory requests -- every lane writes into its own pattern's 512 bytes, nothing
+  // coalesces across lanes -- so the only lever is fewer, wider stores per lane (8-byte stores: 64 per 256-bp pattern).
+#ifdef GCSA2_AB_STORE8
+  u64 packed = 0; u32 have = 0;
+  auto emit = [&](u32 pos, u32 value)        // ms[begin + pos] = value; positions arrive in descending order
   {
     const u64 idx = begin + pos;
     const u32 slot = u32(idx & 3);
@@ -529,24 +511,53 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     if(slot == 0 || pos == 0)
     {
       unsigned short* group = ms + (idx & ~u64(3));
-#ifdef GCSA2_AB_NO_MS_STORE
-      if(packed == 0x123456789ABCDEFull)        // (A/B build: the statistics are not written)
-#endif
       if(have == 15u) { *reinterpret_cast<u64*>(group) = packed; }
       else { for(u32 s = 0; s < 4; s++) { if((have >> s) & 1) { group[s] = (unsigned short)(packed >> (16 * s)); } } }
       packed = 0; have = 0;
     }
   };
+#else
+  u64 packed_lo = 0, packed_hi = 0; u32 have = 0;
+  auto emit = [&](u32 pos, u32 value)        // ms[begin + pos] = value; positions arrive in descending order
+  {
+    const u64 idx = begin + pos;
+    const u32 slot = u32(idx & 7);
+    const u64 field = u64(value > 65535 ? 65535 : value) << (16 * (slot & 3));
+    if(slot < 4) { packed_lo |= field; } else { packed_hi |= field; }
+    have |= 1u << slot;
+    if(slot == 0 || pos == 0)
+    {
+      unsigned short* group = ms + (idx & ~u64(7));
+      if(have == 0xFFu)
+      {
+        typedef unsigned long long ull2 __attribute__((ext_vector_type(2), aligned(8)));
+        *reinterpret_cast<ull2*>(group) = ull2{packed_lo, packed_hi};
+      }
+      else
+      {
+        if((have & 0x0Fu) == 0x0Fu) { *reinterpret_cast<u64*>(group) = packed_lo; }
+        else { for(u32 s = 0; s < 4; s++) { if((have >> s) & 1) { group[s] = (unsigned short)(packed_lo >> (16 * s)); } } }
+        if((have & 0xF0u) == 0xF0u) { *reinterpret_cast<u64*>(group + 4) = packed_hi; }
+        else { for(u32 s = 0; s < 4; s++) { if((have >> (4 + s)) & 1) { group[4 + s] = (unsigned short)(packed_hi >> (16 * s)); } } }
+      }
+      packed_lo = 0; packed_hi = 0; have = 0;
+    }
+  };
+#endif
   auto start = [&](u64 query)
   {
     q = query; has = true;
-    begin = offsets[q]; i = total = offsets[q + 1] - begin;
-    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0); zone = ZONE_NONE;
+    begin = offsets[q]; i = total = u32(offsets[q + 1] - begin);
+    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0);
     // The k-mer seed table (find() of every k-mer over the fast characters, kernels_find.hpp): when the pattern's last k
     // characters are fast characters and occur, the search starts behind them -- all k suffixes match, so their statistics
     // are 1 .. k -- and skips the steps on the widest ranges, whose endpoints lie in different blocks.  An empty or wide
     // entry starts from scratch.
+#ifdef GCSA2_AB_NO_MS_SEED
+    const u32 k = 0;
+#else
     const u32 k = img.kmer_k;
+#endif
     if(k > 0 && total >= k && img.n > 0)
     {
       const u64 word = (begin >> 5) + q;
@@ -602,8 +613,8 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     // position i - 1 - r; refilled from the pre-packed codes (k_pack_patterns): two words and a funnel shift, no loop
     if(active && win_used > 24)
     {
-      const u64 t0 = total - i, word = (begin >> 5) + q + (t0 >> 5);
-      const u32 s = u32(t0) & 31;
+      const u32 t0 = total - i, s = t0 & 31;
+      const u64 word = (begin >> 5) + q + (t0 >> 5);
       const u64 c0 = codes[word], c1 = codes[word + 1];
       const u32 b0 = bad[word], b1 = bad[word + 1];
       win_code = (s == 0 ? c0 : (c0 >> (2 * s)) | (c1 << (64 - 2 * s)));
@@ -667,41 +678,9 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       {
         p_sp = eval_staged(wave_stage, lane, PAIR && pair, r_sp, false);
         if(idx_ep == idx_sp) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
-        // A single step that empties with both endpoints in one block: the block's B_c bits tell how far the nearest ones
-        // lie on either side of [sp, ep] -- LF(range', comp) stays empty for every range' that holds neither (zone, below).
-        // (Taken here: a second fetch round of the wave overwrites the staged blocks.)
-        zone = ZONE_NONE;
-        if(!(PAIR && pair) && idx_ep == idx_sp && range_empty(p_sp.raw, p_ep.raw - 1)) { zone = ones_around(wave_stage, lane, r_sp, r_ep); }
       }
       G2_TICK(3);
-      if(parenting)
-      {
-        // parent() from the staged window -- and again, for as long as the retry is KNOWN to fail: the new range lies inside the
-        // positions the failed step's block covered and reaches neither of the nearest B_c ones (LF(range, comp) is non-empty iff
-        // B_c has a one inside the range, gcsa.h:155-162).  The same parent() calls the reference's loop makes between two
-        // failing LF calls, without the rounds of those LF calls.
-        u32 known_l = 0, known_r = 0, dl = 0, dr = 0;
-        if(zone != ZONE_NONE)
-        {
-          u32 blk_sp, off_sp, blk_ep, off_ep;
-          flb_block_of(sp, blk_sp, off_sp); flb_block_of(ep + 1, blk_ep, off_ep);
-          known_l = off_sp; known_r = u32(FLB_BITS) - off_ep; dl = zone & 0xFFFF; dr = zone >> 16;
-        }
-        u64 csp = sp, cep = ep;
-        decided = true;
-        while(true)
-        {
-          gcsa2_stnode up;
-          if(!parent_from_window(wave_stage, lane, wstart, img.lcp_size, csp, cep, up)) { decided = false; break; }    // tree walk below
-          G2_COUNT(5, 1);
-          calls++; node = up; csp = up.sp; cep = up.ep;
-          if(zone == ZONE_NONE || (csp == 0 && cep == img.n - 1)) { break; }
-          const u64 grow_l = sp - csp, grow_r = cep - ep;
-          if((dl != 0 && grow_l >= dl) || (dr != 0 && grow_r >= dr)) { break; }       // holds a one: the retry succeeds
-          if(grow_l > known_l || grow_r > known_r) { break; }                         // beyond the block: not known
-        }
-        if(!decided && (csp != sp || cep != ep)) { decided = true; }                  // some levels were climbed: retry from there
-      }
+      if(parenting) { decided = parent_from_window(wave_stage, lane, wstart, img.lcp_size, sp, ep, node); G2_COUNT(5, 1); }
       if constexpr(PROF) { if(parenting && decided) { asm volatile("" :: "v"(node.sp)); } }
       G2_TICK(6);
       if(__any(need2))
@@ -748,8 +727,9 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     G2_TICK(5);
     if(parenting)
     {
-      if(!decided) { lcp_parent(img, sp, ep, node); calls++; G2_COUNT(6, 1); G2_COUNT(5, 1); }   // the interval reaches beyond the window: tree walk (lcp.cpp:276-301)
-      sp = node.sp; ep = node.ep; depth = node.node_lcp;
+      if(!decided) { lcp_parent(img, sp, ep, node); G2_COUNT(6, 1); }      // the interval reaches beyond the window: tree walk (lcp.cpp:276-301)
+      calls++;
+      sp = node.sp; ep = node.ep; depth = u32(node.node_lcp);
       need_parent = false;
     }
     G2_TICK(7);

@@ -91,7 +91,7 @@ def test_repeat_rich_index_parity():
         flat, off = patterns.as_batch(pats)
         ranges, hit = phases(gpu, lcp, cpu, flat, off, ix.n)
         widths[m] = float((hit[:, 1] - hit[:, 0] + 1).mean())
-    assert widths[32] > 5 and widths[16] > 50 and widths[8] > 1000            # the ranges are wide (x16 at the bench's 2^23 bases)
+    assert widths[32] > 5 and widths[16] > 50 and widths[8] > 100             # the ranges are wide (x16 at the bench's 2^23 bases)
     # the device-resident instrumented kernel sees second blocks and agrees with the default one
     dev = torch.device("cuda", 0)
     pats = patterns.walk_patterns(g, 100_000, 16, 0x6C5A0024)
