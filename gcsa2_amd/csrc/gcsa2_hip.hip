@@ -1249,6 +1249,7 @@ namespace {
 constexpr unsigned PIPE_LANES = 8;
 constexpr u64 PIPE_CHUNK_QUERIES = u64(1) << 17, PIPE_CHUNK_BYTES = u64(8) << 20;     // per chunk: at most this many patterns and pattern bytes
 constexpr u64 PIPE_MIN_QUERIES = u64(1) << 19;                                       // smaller batches take the single-copy path
+constexpr int PIPE_PATTERN_TOO_LONG = 1;                                             // internal: not a gcsa2_status
 
 inline u64 pipe_set_bytes() { return (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8 + PIPE_CHUNK_QUERIES * 16; }
 
@@ -1288,16 +1289,21 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
   std::lock_guard<std::mutex> hold(ix->pipe_lock);
   int rc = pipe_prepare(ix);
   if(rc != GCSA2_OK) { return rc; }
-  // chunk boundaries: at most PIPE_CHUNK_QUERIES patterns and PIPE_CHUNK_BYTES pattern bytes each
+  // chunk boundaries: at most PIPE_CHUNK_QUERIES patterns and PIPE_CHUNK_BYTES pattern bytes each.  The offsets are validated
+  // by the lanes, chunk by chunk, while they rebase them (a serial pass over 10 M offsets costs as much as the whole batch);
+  // here only the boundaries are looked at, defensively.
   std::vector<u64> cut(1, 0);
   while(cut.back() < nq)
   {
     const u64 b = cut.back();
     u64 e = (nq - b < PIPE_CHUNK_QUERIES ? nq : b + PIPE_CHUNK_QUERIES);
+    if(offsets[e] < offsets[b]) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets are not non-decreasing"); }
     if(offsets[e] - offsets[b] > PIPE_CHUNK_BYTES)
     {
-      e = u64(std::upper_bound(offsets + b, offsets + e + 1, offsets[b] + PIPE_CHUNK_BYTES) - offsets) - 1;
-      if(e == b) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "a single pattern exceeds the pipeline's chunk size"); }   // (callers route such batches elsewhere)
+      u64 lo = b, hi = e;                                    // largest e' with offsets[e'] - offsets[b] <= PIPE_CHUNK_BYTES
+      while(lo < hi) { const u64 mid = (lo + hi + 1) / 2; if(offsets[mid] >= offsets[b] && offsets[mid] - offsets[b] <= PIPE_CHUNK_BYTES) { lo = mid; } else { hi = mid - 1; } }
+      e = lo;
+      if(e == b) { return PIPE_PATTERN_TOO_LONG; }           // the caller takes the single-copy path
     }
     cut.push_back(e);
   }
@@ -1327,8 +1333,10 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
       const u64 b = cut[c], e = cut[c + 1], count = e - b, base = offsets[b], bytes = offsets[e] - base;
       char* h_pat = set.h; u64* h_off = reinterpret_cast<u64*>(set.h + (PIPE_CHUNK_BYTES + 64));
       char* h_out = reinterpret_cast<char*>(h_off + PIPE_CHUNK_QUERIES + 8);
+      u64 bad = 0;
+      for(u64 i = 0; i <= count; i++) { const u64 o = offsets[b + i]; h_off[i] = o - base; bad |= u64(i > 0 && o < offsets[b + i - 1]); }
+      if(bad != 0 || bytes > PIPE_CHUNK_BYTES) { status[t] = GCSA2_ERR_INVALID_ARGUMENT; messages[t] = "pattern offsets are not non-decreasing"; break; }
       std::memcpy(h_pat, patterns + base, bytes);
-      for(u64 i = 0; i <= count; i++) { h_off[i] = offsets[b + i] - base; }
       char* d_pat = set.d; u64* d_off = reinterpret_cast<u64*>(set.d + (PIPE_CHUNK_BYTES + 64));
       u64* d_out = d_off + PIPE_CHUNK_QUERIES + 8;
       hipError_t err = hipMemcpyAsync(d_pat, h_pat, (bytes + 7) / 8 * 8, hipMemcpyHostToDevice, lane.stream);
@@ -1366,13 +1374,16 @@ int gcsa2_find_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint6
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   if(offsets == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
-  u64 longest = 0;
-  if(!offsets_ok(offsets, nq, &longest)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets are not non-decreasing"); }
-  if(nq >= PIPE_MIN_QUERIES && longest <= PIPE_CHUNK_BYTES)
+  if(nq >= PIPE_MIN_QUERIES)
   {
-    try { return find_pipelined(ix, patterns, offsets, nq, ranges); }
+    try
+    {
+      const int rc = find_pipelined(ix, patterns, offsets, nq, ranges);
+      if(rc != PIPE_PATTERN_TOO_LONG) { return rc; }
+    }
     catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_find_batch: ") + e.what()); }
   }
+  if(!offsets_ok(offsets, nq)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets are not non-decreasing"); }
   DeviceGuard guard(ix->device);
   const u64 total = offsets[nq];
   Lease lease(ix);

@@ -14,8 +14,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# k_find2<STATS = false, REFILL = false, JUMP = false, WINDOW = true, PAIR = *>: the timed default kernel
-TIMED = re.compile(r"k_find2<false, false, false, true, (true|false)>")
+# k_find2<STATS = false, JUMP = false, PAIR = *>: the timed default kernel (rounds 1-2: <false, false, false, true, PAIR>)
+TIMED = re.compile(r"k_find2<false, false, (true|false)>|k_find2<false, false, false, true, (true|false)>")
 
 
 def counters(directory):
