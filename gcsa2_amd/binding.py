@@ -30,7 +30,7 @@ EXPORTS = [
     "gcsa2_locate_run", "gcsa2_locate_fetch", "gcsa2_locate_discard", "gcsa2_locate_device", "gcsa2_locate_into",
     "gcsa2_parent_batch", "gcsa2_parent_device", "gcsa2_depth_batch", "gcsa2_sv_batch",
     "gcsa2_rmq_batch", "gcsa2_locate_max", "gcsa2_sample_range_batch", "gcsa2_sample_batch",
-    "gcsa2_sampled_positions", "gcsa2_sigma", "gcsa2_fast_chars", "gcsa2_alphabet",
+    "gcsa2_sampled_positions", "gcsa2_sigma", "gcsa2_fast_chars", "gcsa2_alphabet", "gcsa2_derive_comp2char",
     "gcsa2_lcp_size", "gcsa2_lcp_values", "gcsa2_lcp_levels", "gcsa2_lcp_branching",
     "gcsa2_lcp_access_batch",
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",

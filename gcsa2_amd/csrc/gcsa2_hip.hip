@@ -1586,6 +1586,29 @@ uint64_t gcsa2_lcp_levels(const gcsa2_index* ix) { return ix->img.lcp_levels; }
 uint64_t gcsa2_lcp_branching(const gcsa2_index* ix) { return ix->img.lcp_branching; }
 uint64_t gcsa2_sigma(const gcsa2_index* ix) { return ix->img.sigma; }
 uint64_t gcsa2_fast_chars(const gcsa2_index* ix) { return ix->img.fast_chars; }
+void gcsa2_derive_comp2char(const uint8_t* char2comp, uint64_t sigma, uint8_t* comp2char)
+{
+  if(char2comp == nullptr || comp2char == nullptr) { return; }
+  for(u64 c = 0; c < sigma; c++)
+  {
+    int first = -1, upper = -1;
+    for(int b = 0; b < 256; b++)
+    {
+      if(char2comp[b] != c) { continue; }
+      if(first < 0) { first = b; }
+      if(upper < 0 && !(b >= 'a' && b <= 'z') && b != 0) { upper = b; }
+    }
+    comp2char[c] = u8(upper >= 0 ? upper : (first >= 0 ? first : 0));
+  }
+  if(sigma == 7)
+  {
+    const char* dflt = "$ACGTN#";
+    bool is_default = true;
+    for(u64 c = 0; c < 7; c++) { is_default = is_default && char2comp[u8(dflt[c])] == c; }
+    if(is_default) { for(u64 c = 0; c < 7; c++) { comp2char[c] = u8(dflt[c]); } }
+  }
+}
+
 void gcsa2_alphabet(const gcsa2_index* ix, uint8_t* char2comp, uint64_t* C)
 {
   if(char2comp) { std::memcpy(char2comp, ix->img.char2comp, 256); }
@@ -2428,6 +2451,7 @@ struct gcsa2_view_storage
   gcsa2_host_view view;
   std::vector<std::vector<u64>> blobs;    // 8-byte aligned backing store
   std::vector<const u64*> bwt;
+  std::vector<uint8_t> comp2char;         // alpha.comp2char as the file had it (GCSA::load keeps it, so serialize() must too)
 };
 
 namespace {
@@ -2693,12 +2717,19 @@ void load_gcsa_members(sdsl_file::Cursor& in, gcsa2_view_storage& st, bool exact
 
   // Alphabet (support.cpp:243-250)
   IntVector char2comp = read_int_vector(in, 8, "alpha.char2comp");
-  read_int_vector(in, 8, "alpha.comp2char");
+  IntVector comp2char = read_int_vector(in, 8, "alpha.comp2char");
   IntVector C = read_int_vector(in, 64, "alpha.C");
   v.sigma = in.get<u64>("alpha.sigma"); v.fast_chars = in.get<u64>("alpha.fast_chars");
   if(char2comp.size() != 256) { in.error("alpha.char2comp must have 256 entries"); }
   if(v.sigma == 0 || v.sigma > GCSA2_MAX_SIGMA || C.size() != v.sigma + 1) { in.error("alphabet size out of range or alpha.C of the wrong length"); }
   if(v.fast_chars >= v.sigma) { in.error("alpha.fast_chars out of range"); }
+  if(comp2char.size() == v.sigma)
+  {
+    std::vector<u64> words;
+    comp2char.copy_words(words);
+    st.comp2char.assign(reinterpret_cast<const uint8_t*>(words.data()), reinterpret_cast<const uint8_t*>(words.data()) + v.sigma);
+    v.comp2char = st.comp2char.data();
+  }
 
   st.blobs.resize(2 + v.sigma + 9);
   u64 b = 0;
@@ -2844,25 +2875,12 @@ extern "C" int gcsa2_host_view_serialize_gcsa(const gcsa2_host_view* v, gcsa2_si
     Writer out(sink, ctx);
     out.put<u32>(0x6C5A6C5Au); out.put<u32>(3);                       // GCSAHeader (files.cpp:513-525)
     out.put<u64>(v->path_nodes); out.put<u64>(v->edges); out.put<u64>(v->order); out.put<u64>(0);
-    // Alphabet (support.cpp:228-241): char2comp, comp2char, C, sigma, fast_chars.  comp2char is not part of the view:
-    // it is rebuilt as the reference's constructors do, the first (upper-case) byte mapped to each comp.
+    // Alphabet (support.cpp:228-241): char2comp, comp2char, C, sigma, fast_chars.  comp2char travels in the view when
+    // it came from a file; otherwise it is derived by the one rule the facade's Alphabet uses too.
     out.int_vector8(v->char2comp, 256, false);
     std::vector<u8> comp2char(v->sigma, 0);
-    for(u64 c = 0; c < v->sigma; c++)
-    {
-      int first = -1, upper = -1;
-      for(int b = 0; b < 256; b++)
-      {
-        if(v->char2comp[b] != c) { continue; }
-        if(first < 0) { first = b; }
-        if(upper < 0 && !(b >= 'a' && b <= 'z')) { upper = b; }
-      }
-      // comp 0 holds both '\0' and '$', comp sigma - 1 is '#', N collects every other byte: print the reference's letters
-      comp2char[c] = u8(upper >= 0 ? upper : (first >= 0 ? first : 0));
-    }
-    if(v->sigma == 7) { const char* dflt = "$ACGTN#"; bool is_default = true;
-      for(u64 c = 0; c < 7; c++) { is_default = is_default && v->char2comp[u8(dflt[c])] == c; }
-      if(is_default) { for(u64 c = 0; c < 7; c++) { comp2char[c] = u8(dflt[c]); } } }
+    if(v->comp2char != nullptr) { std::memcpy(comp2char.data(), v->comp2char, v->sigma); }      // as loaded (or as the caller's Alphabet has it)
+    else { gcsa2_derive_comp2char(v->char2comp, v->sigma, comp2char.data()); }
     out.int_vector8(comp2char.data(), v->sigma, false);
     out.int_vector64(v->C, v->sigma + 1);
     out.put<u64>(v->sigma); out.put<u64>(v->fast_chars);

@@ -28,6 +28,7 @@ class HostView(C.Structure):
         ("redundant_len", C.c_uint64), ("redundant_bits", u64p),
         ("lcp_size", C.c_uint64), ("lcp_branching", C.c_uint64), ("lcp_levels", C.c_uint64),
         ("lcp_offsets", u64p), ("lcp_data", u8p),
+        ("comp2char", u8p),
     ]
 
 

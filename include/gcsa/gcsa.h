@@ -56,6 +56,11 @@ public:
   // GCSA::serialize (gcsa.cpp:140-179): the reference's byte stream.  The device image does not keep the host-side
   // arrays, so this works on an index whose host view was retained (retainHostView(true) before it was loaded or
   // created); otherwise it throws.  Returns the number of bytes written; the structure tree is not filled in.
+  // EXPERIMENTAL: the SDSL container encodings inside the stream (bit_vector_il rank samples, sd_vector, the stored
+  // select_support_mcl directories) are restated from sdsl-lite and have never met a file written by the real library.
+  // The reference LOADS stored select directories without checking them, so a mismatch there would surface as wrong
+  // select() / locate() answers in reference tools, not as a load error: do not feed files written here to reference tools
+  // before one has been compared with the real library's output for the same index.
   size_type serialize(std::ostream& out, sdsl::structure_tree_node* = nullptr, std::string = "") const
   {
     if(!host) { throw std::runtime_error("GCSA::serialize(): the host view of this index was not retained (GCSA::retainHostView)"); }

@@ -46,29 +46,15 @@ public:
   std::vector<size_type>    C;
   size_type                 sigma, fast_chars;
 
-  // from a handle: char2comp and C are the image's; comp2char is the first (upper-case) byte of every comp, which
-  // gives "$ACGTN#" for the reference's default alphabet (support.cpp:69-92)
+  // from a handle: char2comp and C are the image's; comp2char is derived from char2comp by the rule GCSA::serialize uses too
+  // (gcsa2_derive_comp2char: "$ACGTN#" for the reference's default alphabet, support.cpp:69-92)
   void read(const gcsa2_index* handle)
   {
     sigma = gcsa2_sigma(handle); fast_chars = gcsa2_fast_chars(handle);
     char2comp.assign(256, 0); C.assign(sigma + 1, 0);
     gcsa2_alphabet(handle, char2comp.data(), C.data());
     comp2char.assign(sigma, 0);
-    for(size_type c = 0; c < sigma; c++)
-    {
-      int first = -1, upper = -1;
-      for(int b = 0; b < 256; b++)
-      {
-        if(char2comp[b] != c) { continue; }
-        if(first < 0) { first = b; }
-        if(upper < 0 && !(b >= 'a' && b <= 'z') && b != 0) { upper = b; }
-      }
-      comp2char[c] = std::uint8_t(upper >= 0 ? upper : (first >= 0 ? first : 0));
-    }
-    const std::string dflt = "$ACGTN#";
-    bool is_default = (sigma == dflt.size());
-    for(size_type c = 0; is_default && c < sigma; c++) { is_default = (char2comp[std::uint8_t(dflt[c])] == c); }
-    if(is_default) { comp2char.assign(dflt.begin(), dflt.end()); }
+    gcsa2_derive_comp2char(char2comp.data(), sigma, comp2char.data());
   }
 };
 

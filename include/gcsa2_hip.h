@@ -91,6 +91,10 @@ typedef struct gcsa2_host_view {
   uint64_t lcp_levels;            /* offsets.size() - 1 */
   const uint64_t* lcp_offsets;    /* lcp_levels + 1 entries */
   const uint8_t*  lcp_data;       /* data widened to bytes, lcp_offsets[lcp_levels] entries */
+
+  /* alpha.comp2char, sigma entries, or NULL (round 3; appended).  The query path never reads it; it is kept so that
+   * load + serialize reproduces a file's alphabet.  NULL = derived from char2comp (gcsa2_derive_comp2char). */
+  const uint8_t*  comp2char;
 } gcsa2_host_view;
 
 #define GCSA2_MAX_SIGMA 16
@@ -255,6 +259,10 @@ uint64_t gcsa2_sampled_positions(const gcsa2_index* index);
 uint64_t gcsa2_sigma(const gcsa2_index* index);
 uint64_t gcsa2_fast_chars(const gcsa2_index* index);
 void gcsa2_alphabet(const gcsa2_index* index, uint8_t* char2comp /* 256 */, uint64_t* C /* sigma + 1 */);
+/* comp2char of an alphabet given by char2comp alone: per comp the first byte that is not a lower-case letter and not NUL
+ * (else the first byte), and the reference's "$ACGTN#" for its default alphabet (src/support.cpp:69-92).  The one rule behind
+ * the facade's Alphabet and GCSA::serialize when a view carries no comp2char.  Host only. */
+void gcsa2_derive_comp2char(const uint8_t* char2comp /* 256 */, uint64_t sigma, uint8_t* comp2char /* sigma */);
 
 /* ---- suffix-tree operations: LCPArray::parent / depth / psv / psev / nsv / nsev / rmq
  *      (include/gcsa/lcp.h:137-178, src/lcp.cpp:276-519) -------------------------------------- */

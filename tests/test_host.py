@@ -335,6 +335,26 @@ def test_serialize_matches_the_file_format_restatement(built):
     # a view without samples / counters cannot become a .gcsa file
     with pytest.raises(built.Gcsa2Error):
         built.serialize_view(make_host_view(cases[0], with_counters=False).ref(), "gcsa")
+    # alpha.comp2char survives load + serialize (GCSA::load keeps the file's): a file whose comp2char differs
+    # from what char2comp would give -- here lower-case letters -- is reproduced byte for byte
+    raw = built.serialize_view(make_host_view(cases[1]).ref(), "gcsa")
+    at = raw.index(b"$ACGTN#")
+    custom = raw[:at] + b"$acgtn#" + raw[at + 7:]
+    h, vp, used = built.parse_view(custom, "gcsa")
+    assert bytes(vp.contents.comp2char[:7]) == b"$acgtn#"
+    assert built.serialize_view(vp, "gcsa") == custom
+    built.free_view(h)
+    # ... and the one derivation rule (facade Alphabet::read and the serializer of a view without comp2char)
+    import ctypes as C
+    out = (C.c_uint8 * 7)()
+    c2c = np.ascontiguousarray(cases[1].char2comp, dtype=np.uint8)
+    built.load_library().gcsa2_derive_comp2char(c2c.ctypes.data_as(C.POINTER(C.c_uint8)), 7, out)
+    assert bytes(out) == b"$ACGTN#"
+    odd = np.full(256, 2, dtype=np.uint8)
+    odd[0] = 0; odd[ord("x")] = 1; odd[ord("X")] = 1
+    out3 = (C.c_uint8 * 3)()
+    built.load_library().gcsa2_derive_comp2char(odd.ctypes.data_as(C.POINTER(C.c_uint8)), 3, out3)
+    assert bytes(out3) == bytes([0, ord("X"), 1])          # comp 0 holds only NUL; comp 2's first byte that is not NUL / lower case
 
 
 def test_header_bytes_from_the_reference_definitions(built, tmp_path):
