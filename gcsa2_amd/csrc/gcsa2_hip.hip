@@ -92,6 +92,7 @@ struct gcsa2_index
     u32 ms_refill_at = MS_REFILL_AT;   // GCSA2_MS_REFILL_AT: persistent matching statistics, idle lanes of a wave that trigger a refill
     u64 ms_grid = 0;                   // GCSA2_MS_GRID: ... most workgroups launched (0: what the device holds at once)
     u32 sort_medium_limit = 0;         // GCSA2_SORT_MEDIUM=0 sends the 17..1024-value locate segments to the segmented radix sort
+    u64 locate_split = (u64(1) << 31) - 1;   // GCSA2_LOCATE_SPLIT: most values (before deduplication) one pass of the locate pipeline handles
   } tune;
 };
 
@@ -530,6 +531,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.ms_refill_at = u32(knob("GCSA2_MS_REFILL_AT", MS_REFILL_AT, 1, 64));
     ix->tune.ms_grid = u64(knob("GCSA2_MS_GRID", 0, 0, long(1) << 30));
     ix->tune.sort_medium_limit = (knob("GCSA2_SORT_MEDIUM", 1, 0, 1) == 0 ? SMALL_SEGMENT : MEDIUM_SEGMENT);
+    ix->tune.locate_split = u64(knob("GCSA2_LOCATE_SPLIT", (long(1) << 31) - 1, 2, (long(1) << 31) - 1));
   }
   std::memset(&ix->img, 0, sizeof(DevImage));
   DevImage& img = ix->img;
@@ -1038,8 +1040,13 @@ typedef std::function<u64*(u64)> ValuesProvider;
 
 namespace {
 
-int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u64* d_offsets,
-                const ValuesProvider& values_for, u64* total_out, hipStream_t stream)
+constexpr int LOCATE_NEEDS_SPLIT = 1;      // internal: not a gcsa2_status
+
+// One pass of the locate pipeline.  The library calls inside (hipCUB scans and the segmented sort) count in `int`, so a pass
+// takes fewer than 2^31 values before deduplication; a larger batch returns LOCATE_NEEDS_SPLIT (allow_split) with the
+// exclusive scan of the per-query raw counts left in d_offsets, and locate_core below cuts it.
+int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u64* d_offsets,
+                 const ValuesProvider& values_for, u64* total_out, hipStream_t stream, bool allow_split)
 {
   *total_out = 0;
   if(nq == 0)
@@ -1076,7 +1083,11 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
   HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   const u64 total_nodes = totals[0], total_raw = totals[1], large = totals[2], multi = totals[4], medium = totals[5];
-  if(total_raw >= (u64(1) << 31)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate batch produces >= 2^31 values; split the batch"); }
+  if(total_raw > ix->tune.locate_split)
+  {
+    if(allow_split) { return LOCATE_NEEDS_SPLIT; }
+    return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate: one range alone has 2^31 or more values before deduplication");
+  }
 
   if(total_raw == 0)
   {
@@ -1150,6 +1161,82 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
     HIP_TRY(hipStreamSynchronize(stream));
   }
 
+  return GCSA2_OK;
+}
+
+// largest q1 in (q0, nq] with raw_off[q1] - raw_off[q0] <= limit (q0 if even the first query exceeds it); one thread
+__global__ void k_locate_cut(const u64* __restrict__ raw_off, u64 nq, u64 q0, u64 limit, unsigned long long* __restrict__ out)
+{
+  u64 lo = q0, hi = nq;
+  const u64 base = raw_off[q0];
+  while(lo < hi)
+  {
+    const u64 mid = (lo + hi + 1) >> 1;
+    if(raw_off[mid] - base <= limit) { lo = mid; } else { hi = mid - 1; }
+  }
+  *out = lo;
+}
+
+__global__ __launch_bounds__(TPB) void k_shift_offsets(const u64* __restrict__ src, u64 count, u64 base, u64* __restrict__ dst)
+{
+  const u64 i = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(i < count) { dst[i] = src[i] + base; }
+}
+
+// The locate pipeline for batches of any size: one pass when the batch has fewer than 2^31 values before deduplication (the
+// paper's 16-mer batch has 2.5 G, paper.tex:403), otherwise consecutive sub-batches of queries, each below that, whose value
+// arrays are concatenated and whose offsets are shifted -- the same CSR a single pass would give.
+int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u64* d_offsets,
+                const ValuesProvider& values_for, u64* total_out, hipStream_t stream)
+{
+  int rc = locate_chunk(ix, d_ranges, nq, sort, d_offsets, values_for, total_out, stream, true);
+  if(rc != LOCATE_NEEDS_SPLIT) { return rc; }
+  struct Part { u64 q0 = 0, q1 = 0, total = 0; u64* d_off = nullptr; u64* d_val = nullptr; };
+  std::vector<Part> parts;
+  struct Release { std::vector<Part>& p; ~Release() { for(Part& x : p) { if(x.d_off) { (void)hipFree(x.d_off); } if(x.d_val) { (void)hipFree(x.d_val); } } } } release{parts};
+  unsigned long long* d_cut = ix->d_slots + 8 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);
+  u64 q0 = 0;
+  while(q0 < nq)                                   // d_offsets still holds the scan of the raw counts
+  {
+    unsigned long long q1 = 0;
+    hipLaunchKernelGGL(k_locate_cut, dim3(1), dim3(1), 0, stream, d_offsets, nq, q0, ix->tune.locate_split, d_cut);
+    HIP_TRY(hipMemcpyAsync(&q1, d_cut, sizeof(q1), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if(q1 <= q0) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate: one range alone has 2^31 or more values before deduplication"); }
+    Part part; part.q0 = q0; part.q1 = q1;
+    parts.push_back(part);
+    q0 = q1;
+  }
+  u64 total = 0;
+  for(Part& part : parts)
+  {
+    const u64 count = part.q1 - part.q0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&part.d_off), (count + 1) * sizeof(u64)));
+    Part* self = &part;
+    ValuesProvider own = [self](u64 values) -> u64*
+    {
+      hipError_t e = hipMalloc(reinterpret_cast<void**>(&self->d_val), (values > 0 ? values : 1) * sizeof(u64));
+      if(e != hipSuccess) { fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(values of a sub-batch): ") + hipGetErrorString(e)); return nullptr; }
+      return self->d_val;
+    };
+    g_error.clear();
+    rc = locate_chunk(ix, d_ranges + 2 * part.q0, count, sort, part.d_off, own, &part.total, stream, false);
+    if(rc != GCSA2_OK) { return rc; }
+    total += part.total;
+  }
+  *total_out = total;
+  u64* out = values_for(total);
+  if(out == nullptr) { return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
+  u64 base = 0;
+  for(Part& part : parts)
+  {
+    const u64 count = part.q1 - part.q0;
+    if(part.total > 0) { HIP_TRY(hipMemcpyAsync(out + base, part.d_val, part.total * sizeof(u64), hipMemcpyDeviceToDevice, stream)); }
+    hipLaunchKernelGGL(k_shift_offsets, dim3(grid_for(count)), dim3(TPB), 0, stream, part.d_off, count, base, d_offsets + part.q0);
+    base += part.total;
+  }
+  HIP_TRY(hipMemcpyAsync(d_offsets + nq, &total, sizeof(u64), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
   return GCSA2_OK;
 }
 

@@ -221,7 +221,11 @@ int gcsa2_count_device(const gcsa2_index* index, const uint64_t* d_ranges, uint6
  * inside `*job`; locate_fetch copies the values (offsets[n_queries] of them) and frees the job.
  * sort != 0: sorted distinct values per query (removeDuplicates, utils.h:350-357), so
  *            offsets[q+1] - offsets[q] == count(range q).
- * sort == 0: values in path order, duplicates kept, exactly as the reference pushes them. */
+ * sort == 0: values in path order, duplicates kept, exactly as the reference pushes them.
+ * A batch of any size: one pass of the pipeline takes fewer than 2^31 values before deduplication (its library scans and
+ * segmented sort count in int); a larger batch -- the paper's 16-mer batch has 2.5 G values -- is cut into consecutive
+ * sub-batches of queries whose results are concatenated.  Only a single range with that many values is refused
+ * (GCSA2_ERR_BUFFER_TOO_SMALL). */
 typedef struct gcsa2_locate_job gcsa2_locate_job;
 int gcsa2_locate_run(const gcsa2_index* index, const uint64_t* ranges, uint64_t n_queries,
                      int sort, uint64_t* offsets /* n_queries + 1 */, gcsa2_locate_job** job);

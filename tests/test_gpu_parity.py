@@ -934,6 +934,42 @@ def test_sharded_match_stats_and_locate(engine):
     comm.close()
 
 
+def test_locate_splits_large_batches(case, engine, monkeypatch):
+    """A locate batch with 2^31 or more values before deduplication (the paper's 16-mer batch has 2.5 G) is cut into
+    consecutive sub-batches whose CSRs are concatenated.  The limit is a tuning knob read at create time
+    (GCSA2_LOCATE_SPLIT), so the splitting runs here on small batches: same offsets and values as the oracle, in both sort
+    modes, through the host and the device entry points; only a single range above the limit is refused."""
+    import torch
+    name, g, K, ix, gpu, lcp, cpu = case
+    ranges = np.array([r for r in all_ranges(ix, 0x7D, 120) if r[0] <= r[1]], dtype=np.uint64)
+    widest = int((ranges[:, 1] - ranges[:, 0] + 1).max())
+    want_o, want_v = cpu.locate_batch(ranges)
+    raw = [cpu.locate((int(a), int(b)), sort=False) for a, b in ranges]
+    limit = max(len(r) for r in raw) + 3                     # every range fits alone, few fit together
+    monkeypatch.setenv("GCSA2_LOCATE_SPLIT", str(limit))
+    small, _ = engine.open_index(ix, device=0)
+    go, gv = small.locate_batch(ranges)
+    assert np.array_equal(go, want_o) and np.array_equal(gv, want_v), name
+    go, gv = small.locate_batch(ranges, sort=False)
+    assert np.array_equal(go, np.concatenate([[0], np.cumsum([len(r) for r in raw])]).astype(np.uint64)), name
+    assert np.array_equal(gv, np.concatenate(raw).astype(np.uint64)), name
+    dev = torch.device("cuda", 0)
+    d_r = torch.from_numpy(ranges.view(np.int64).copy()).to(dev)
+    d_off = torch.zeros(ranges.shape[0] + 1, dtype=torch.int64, device=dev)
+    d_val = torch.zeros(max(int(want_o[-1]), 1), dtype=torch.int64, device=dev)
+    assert small.locate_into(d_r.data_ptr(), ranges.shape[0], d_off.data_ptr(), d_val.data_ptr(), d_val.shape[0], 0) == int(want_o[-1])
+    torch.cuda.synchronize()
+    assert np.array_equal(d_off.cpu().numpy().view(np.uint64), want_o) and np.array_equal(d_val[: int(want_o[-1])].cpu().numpy().view(np.uint64), want_v)
+    small.close()
+    if widest > 3:
+        monkeypatch.setenv("GCSA2_LOCATE_SPLIT", "2")
+        tiny, _ = engine.open_index(ix, device=0)
+        with pytest.raises(engine.Gcsa2Error) as err:
+            tiny.locate_batch(ranges)
+        assert err.value.code == -6
+        tiny.close()
+
+
 def test_locate_segment_sizes(engine):
     """removeDuplicates at every segment size class: 1 value, 2..16 (registers, one lane), 17..1024 (one wavefront in
     LDS), more (segmented radix sort), mixed in one batch and in both sort modes; ranges of consecutive path nodes of a
