@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the config-5 and chr22 measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the request-rate ceiling, the device telemetry and the host-batch leg "
+                                                               "(profiler passes: only the timed kernel and its instrumented twin run)")
     ap.add_argument("--secondary", choices=["all", "config5", "chr22", "repeats", "human32", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
     ap.add_argument("--variant", type=int, default=2, help="find launch shape (2 = one lane per query in batch order, 4 = queries ordered by length first)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
@@ -1124,7 +1126,7 @@ def main():
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
     from gcsa2_amd import binding
     D.make_comm(binding, local_rank)
-    ceiling = measured_request_ceiling() if (rank == 0 and world == 1) else None
+    ceiling = measured_request_ceiling() if (rank == 0 and world == 1 and not args.no_extras) else None
     if ceiling is not None:
         log(f"request-rate ceiling of this box: {ceiling:.1f} G dependent random 128-byte fetches/s (gather_bench lds128, 32 GB)")
 
@@ -1164,7 +1166,7 @@ def main():
             rr["ceiling_G_per_s"] = ceiling
             rr["ceiling_source"] = "gather_bench --mode lds128 35 on this box, before the index was loaded"
             rr["frac_of_ceiling"] = rr["achieved_G_per_s"] / ceiling
-        if world == 1:
+        if world == 1 and not args.no_extras:
             st = torch.cuda.current_stream()
 
             def under_load():

@@ -1079,10 +1079,10 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   const u32 medium_limit = ix->tune.sort_medium_limit;
   hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, medium_limit);
   LAUNCH_CHECK("k_collect_multi");
-  unsigned long long totals[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long totals[7] = {0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
-  const u64 total_nodes = totals[0], total_raw = totals[1], large = totals[2], multi = totals[4], medium = totals[5];
+  const u64 total_nodes = totals[0], total_raw = totals[1], large = totals[2], multi = totals[4], medium = totals[5], huge = totals[6];
   if(total_raw > ix->tune.locate_split)
   {
     if(allow_split) { return LOCATE_NEEDS_SPLIT; }
@@ -1114,9 +1114,10 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, stream);
     LAUNCH_CHECK("k_locate_walk");
 
-    // removeDuplicates: queries with up to SMALL_SEGMENT values are sorted in registers, in place; the
-    // larger ones by hipCUB's segmented radix sort (from a copy); then flag + scan + compact
-    if(large > 0)
+    // removeDuplicates: queries with up to SMALL_SEGMENT values are sorted in registers, up to MEDIUM_SEGMENT by a wavefront
+    // and up to BIG_SEGMENT by a workgroup in LDS, all in place; only longer ones by hipCUB's segmented radix sort (from a
+    // copy: it then runs over the whole list of large segments, the sorted ones included); then flag + scan + compact
+    if(huge > 0)
     {
       HIP_TRY(scratch.get(raw, total_raw));
       HIP_TRY(hipMemcpyAsync(raw, sorted, total_raw * sizeof(u64), hipMemcpyDeviceToDevice, stream));
@@ -1129,6 +1130,11 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
       LAUNCH_CHECK("k_sort_medium");
     }
     if(large > 0)
+    {
+      hipLaunchKernelGGL(k_sort_big, dim3(unsigned(large)), dim3(BIG_THREADS), 0, stream, seg_begin, seg_end, sorted);
+      LAUNCH_CHECK("k_sort_big");
+    }
+    if(huge > 0)
     {
       size_t sort_bytes = 0;
       HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw, sorted, int(total_raw), int(large),
@@ -1333,7 +1339,7 @@ namespace {
 // H2D + k_find2 + D2H on the lane's own stream, and while that runs prepare the next chunk in the lane's other staging set;
 // a set's results are copied to the caller's array when its event has fired.  Both PCIe directions, the kernel and the host
 // copies overlap; what bounds the batch is the host's memcpy rate (56 bytes per 32-mer query through pinned memory).
-constexpr unsigned PIPE_LANES = 8;
+constexpr unsigned PIPE_LANES = 12;
 constexpr u64 PIPE_CHUNK_QUERIES = u64(1) << 17, PIPE_CHUNK_BYTES = u64(8) << 20;     // per chunk: at most this many patterns and pattern bytes
 constexpr u64 PIPE_MIN_QUERIES = u64(1) << 19;                                       // smaller batches take the single-copy path
 constexpr int PIPE_PATTERN_TOO_LONG = 1;                                             // internal: not a gcsa2_status
@@ -2389,8 +2395,8 @@ extern "C" int gcsa2_count_kmers(const gcsa2_index* ix, uint64_t k, int include_
   return GCSA2_OK;
 }
 
-// Matching statistics (LF + parent fused); see k_match_stats2.  variant 0 / 2 = one lane per pattern, 5 = persistent lanes
-// that draw patterns from a counter.  total_bytes = offsets[nq] when the caller knows it (GCSA2_UNKNOWN: read back from the
+// Matching statistics (LF + parent fused); see k_match_stats2.  variant 2 = one lane per pattern, 5 = persistent lanes that draw
+// patterns from a counter, 0 = the library chooses by batch size.  total_bytes = offsets[nq] when the caller knows it (GCSA2_UNKNOWN: read back from the
 // device, which waits for the stream once).
 namespace {
 int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, u64 total_bytes,
@@ -2418,9 +2424,13 @@ int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patt
   const u64 lanes_grid = (nq + TPB2 - 1) / TPB2;
   const bool pair = ix->img.flp != nullptr;
   unsigned long long* queue = nullptr;
+  const u64 resident = ix->tune.ms_grid != 0 ? ix->tune.ms_grid : u64(ix->compute_units) * 8;     // workgroups the device holds at 4 waves per SIMD
+  // variant 0 chooses: a batch of more than two generations of workgroups goes to the persistent lanes -- patterns that need
+  // parent() take three times the rounds of those that do not, and a wave whose lanes own fixed patterns waits for its slowest
+  // (1 M x 256 bp, half with mismatches: 114 -> 128 M patterns/s; without mismatches 242 -> 236; profiles/r03_match_stats.md)
+  if(variant == 0) { variant = (lanes_grid > 2 * resident ? 5 : 2); }
   if(variant == 5)
   {
-    const u64 resident = ix->tune.ms_grid != 0 ? ix->tune.ms_grid : u64(ix->compute_units) * 8;   // 4 waves per SIMD
     hipError_t qe = pool_alloc(ix, reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st);
     if(qe == hipSuccess) { qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st); }
     if(qe != hipSuccess) { (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st); return fail(GCSA2_ERR_HIP, std::string("matching statistics queue: ") + hipGetErrorString(qe)); }

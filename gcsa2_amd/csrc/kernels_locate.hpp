@@ -261,12 +261,14 @@ __device__ __forceinline__ u64 wg_reserve(WgSlots& sh, unsigned long long* count
 
 // removeDuplicates (utils.h:350-357) sorts the values of a query.  Queries with one value need nothing,
 // queries with 2..SMALL_SEGMENT values are sorted in registers by one lane each (k_sort_small), queries with up to
-// MEDIUM_SEGMENT values by one wavefront each in LDS (k_sort_medium), the rest goes to hipCUB's segmented radix sort.
-// k_collect_multi lists the medium segments (from the end of the segment arrays, downwards) and the large ones
-// (from the start) and publishes totals = {nodes, raw values, large segments, (unique values, written later),
-// segments with >= 2 values, medium segments}.
+// MEDIUM_SEGMENT values by one wavefront each in LDS (k_sort_medium), queries with up to BIG_SEGMENT values by one workgroup
+// each in 64 KB of LDS (k_sort_big: the paper's 16-mers average 7129 values, paper.tex:403), anything longer goes to hipCUB's
+// segmented radix sort.  k_collect_multi lists the medium segments (from the end of the segment arrays, downwards) and the
+// large ones (from the start) and publishes totals = {nodes, raw values, large segments, (unique values, written later),
+// segments with >= 2 values, medium segments, segments beyond BIG_SEGMENT}.
 constexpr u32 SMALL_SEGMENT = 16;
 constexpr u32 MEDIUM_SEGMENT = 1024;
+constexpr u32 BIG_SEGMENT = 8192;
 
 __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
                                                        unsigned long long* __restrict__ totals,
@@ -280,7 +282,9 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
   if(q < nq) { b = raw_off[q]; e = raw_off[q + 1]; }
   const u64 multi = __ballot(e - b >= 2), large = __ballot(e - b > medium_limit);
   const u64 medium = __ballot(e - b > SMALL_SEGMENT && e - b <= medium_limit);
+  const u64 huge = __ballot(e - b > BIG_SEGMENT);
   wg_reserve(slots, totals + 4, u32(__popcll(multi)));
+  if(huge != 0) { wg_reserve(slots, totals + 6, u32(__popcll(huge))); }
   u64 slot = wg_reserve(slots, totals + 2, u32(__popcll(large)));
   if((large >> lane) & 1)
   {
@@ -323,6 +327,40 @@ __global__ __launch_bounds__(64) void k_sort_medium(const u64* __restrict__ seg_
     }
   }
   for(u32 i = lane; i < len; i += 64) { values[b + i] = buf[i]; }
+}
+
+// one workgroup per LARGE segment (list from the start of the segment arrays) with at most BIG_SEGMENT values: bitonic sort in
+// 64 KB of LDS, in place; longer segments are left to the segmented radix sort.  Round 2 sent everything above 1024 values
+// there: on a repeat-rich index that library call was 80 % of locate() (profiles/r03_locate.md).
+constexpr int BIG_THREADS = 256;
+__global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end,
+                                                        u64* __restrict__ values)
+{
+  __shared__ u64 buf[BIG_SEGMENT];
+  const u32 tid = threadIdx.x;
+  const u64 b = seg_begin[blockIdx.x];
+  const u64 full = seg_end[blockIdx.x] - b;
+  if(full > BIG_SEGMENT) { return; }                       // (uniform per workgroup)
+  const u32 len = u32(full);
+  u32 n2 = 2048;
+  while(n2 < len) { n2 <<= 1; }
+  for(u32 i = tid; i < n2; i += BIG_THREADS) { buf[i] = (i < len ? values[b + i] : ~u64(0)); }    // padding sorts to the end
+  __syncthreads();
+  for(u32 k = 2; k <= n2; k <<= 1)
+  {
+    for(u32 j = k >> 1; j > 0; j >>= 1)
+    {
+      for(u32 t = tid; t < (n2 >> 1); t += BIG_THREADS)
+      {
+        const u32 l = ((t & ~(j - 1)) << 1) | (t & (j - 1)), r = l | j;
+        const u64 x = buf[l], y = buf[r];
+        const bool up = ((l & k) == 0);
+        if((x > y) == up) { buf[l] = y; buf[r] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for(u32 i = tid; i < len; i += BIG_THREADS) { values[b + i] = buf[i]; }
 }
 
 // one lane per query with 2..SMALL_SEGMENT values: bitonic network over registers, in place
@@ -512,7 +550,7 @@ __global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* _
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q >= nq) { return; }
-  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; totals[0] = totals[1] = totals[2] = totals[3] = totals[4] = totals[5] = 0; }
+  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; totals[0] = totals[1] = totals[2] = totals[3] = totals[4] = totals[5] = totals[6] = 0; }
   ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
   u64 nodes = 0, raw = 0;
   if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831

@@ -328,10 +328,12 @@ int gcsa2_match_stats_batch(const gcsa2_index* index, const uint8_t* patterns, c
 int gcsa2_match_stats_device(const gcsa2_index* index, const uint8_t* d_patterns, const uint64_t* d_offsets,
                              uint64_t n_queries, uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks,
                              void* stream);
-/* Launch shape, same results.  variant 0 or 2 = the default (one lane per pattern, wave-cooperative block fetch,
- * what gcsa2_match_stats_device runs); variant 5 = the same kernel as persistent wavefronts whose idle lanes draw the
- * next pattern from a counter, for batches of ragged pattern lengths (gcsa2_match_stats_batch chooses it by itself when
- * the longest pattern exceeds 1.25 x the mean).  Any other value is refused.
+/* Launch shape, same results.  variant 2 = one lane per pattern (wave-cooperative block fetch); variant 5 = the same kernel
+ * as persistent wavefronts whose idle lanes draw the next pattern from a counter -- for batches of ragged pattern lengths
+ * or of uneven difficulty (a pattern with mismatches takes three times the rounds of one without); variant 0 = the
+ * library chooses (what gcsa2_match_stats_device runs): persistent lanes when the batch is more than two generations of
+ * resident workgroups, and gcsa2_match_stats_batch also when the longest pattern exceeds 1.25 x the mean.  Any other
+ * value is refused.
  * The kernel reads the patterns as 2-bit codes prepared by a pre-pass into stream-ordered scratch, whose size depends on
  * d_offsets[n_queries]: gcsa2_match_stats_device and _variant read that value back (ONE wait for `stream` per call);
  * gcsa2_match_stats_device_sized takes it from the caller (total_pattern_bytes) and only enqueues. */

@@ -972,8 +972,9 @@ def test_locate_splits_large_batches(case, engine, monkeypatch):
 
 def test_locate_segment_sizes(engine):
     """removeDuplicates at every segment size class: 1 value, 2..16 (registers, one lane), 17..1024 (one wavefront in
-    LDS), more (segmented radix sort), mixed in one batch and in both sort modes; ranges of consecutive path nodes of a
-    repetitive SNP graph (many duplicates per segment)."""
+    LDS), 1025..8192 (one workgroup in LDS), more (segmented radix sort), mixed in one batch and in both sort modes; ranges of
+    consecutive path nodes of a repetitive SNP graph (many duplicates per segment).  A second batch has no segment beyond
+    8192 values: the library sort is then not called at all."""
     from oracle.oracle import OracleIndex
     from workload import builder
     g = graphs.snp_graph(30000, 0x4D1, 0x4D2, snp_period=5, node_len=16)
@@ -982,7 +983,8 @@ def test_locate_segment_sizes(engine):
     cpu = OracleIndex(ix)
     rng = SplitMix64(0x4D3)
     ranges = []
-    for width in (1, 2, 3, 8, 15, 16, 17, 31, 33, 63, 64, 65, 127, 200, 511, 512, 513, 900, 1023, 1024, 1025, 1500, 3000, 7000):
+    for width in (1, 2, 3, 8, 15, 16, 17, 31, 33, 63, 64, 65, 127, 200, 511, 512, 513, 900, 1023, 1024, 1025, 1500, 2047, 2048, 2049, 3000,
+                  4096, 4097, 7000, 8191, 8192, 8193, 9000, 20000):
         for _ in range(6):
             a = rng.below(ix.n - width)
             ranges.append((a, a + width - 1))
@@ -1002,3 +1004,7 @@ def test_locate_segment_sizes(engine):
     for q, r in enumerate(arr):
         want = cpu.locate((int(r[0]), int(r[1])), sort=False)
         assert np.array_equal(gv[int(go[q]):int(go[q + 1])], np.asarray(want, dtype=np.uint64)), r
+    modest = arr[(arr[:, 1] - arr[:, 0] < 5000) | (arr[:, 0] > arr[:, 1])]
+    go, gv = gpu.locate_batch(modest)
+    co, cv = cpu.locate_batch(modest, threads=8)
+    assert np.array_equal(go, co) and np.array_equal(gv, cv) and int(np.diff(co).max()) > 1024
