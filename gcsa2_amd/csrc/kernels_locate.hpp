@@ -284,7 +284,7 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
   const u64 medium = __ballot(e - b > SMALL_SEGMENT && e - b <= medium_limit);
   const u64 huge = __ballot(e - b > BIG_SEGMENT);
   wg_reserve(slots, totals + 4, u32(__popcll(multi)));
-  if(huge != 0) { wg_reserve(slots, totals + 6, u32(__popcll(huge))); }
+  wg_reserve(slots, totals + 6, u32(__popcll(huge)));           // (every wave of the workgroup: wg_reserve synchronises it)
   u64 slot = wg_reserve(slots, totals + 2, u32(__popcll(large)));
   if((large >> lane) & 1)
   {
