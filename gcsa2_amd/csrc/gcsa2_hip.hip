@@ -1062,9 +1062,9 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   // have to be removed, rewritten in place otherwise)
   u64* sizes = nullptr; u64* segs = nullptr;
   unsigned long long* d_totals = ix->d_slots + 8 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);   // {nodes, raw, large, unique, multi, medium}
-  HIP_TRY(scratch.get(sizes, 3 * (nq + 1))); HIP_TRY(scratch.get(segs, 2 * nq));
+  HIP_TRY(scratch.get(sizes, 3 * (nq + 1))); HIP_TRY(scratch.get(segs, 4 * nq));
   u64 *node_counts = sizes, *raw_counts = sizes + (nq + 1), *node_off = sizes + 2 * (nq + 1), *raw_off = d_offsets;
-  u64 *seg_begin = segs, *seg_end = segs + nq;
+  u64 *seg_begin = segs, *seg_end = segs + nq, *huge_begin = segs + 2 * nq, *huge_end = segs + 3 * nq;
   hipLaunchKernelGGL(k_locate_sizes, dim3(grid_for(nq)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_counts, raw_counts, d_totals);
   LAUNCH_CHECK("k_locate_sizes");
 
@@ -1077,7 +1077,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, raw_counts, raw_off, int(nq + 1), stream));
   // segments with more than one raw value: the only ones removeDuplicates has to touch
   const u32 medium_limit = ix->tune.sort_medium_limit;
-  hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, medium_limit);
+  hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, huge_begin, huge_end, medium_limit);
   LAUNCH_CHECK("k_collect_multi");
   unsigned long long totals[7] = {0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
@@ -1116,7 +1116,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
 
     // removeDuplicates: queries with up to SMALL_SEGMENT values are sorted in registers, up to MEDIUM_SEGMENT by a wavefront
     // and up to BIG_SEGMENT by a workgroup in LDS, all in place; only longer ones by hipCUB's segmented radix sort (from a
-    // copy: it then runs over the whole list of large segments, the sorted ones included); then flag + scan + compact
+    // copy); then flag + scan + compact
     if(huge > 0)
     {
       HIP_TRY(scratch.get(raw, total_raw));
@@ -1137,12 +1137,12 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     if(huge > 0)
     {
       size_t sort_bytes = 0;
-      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw, sorted, int(total_raw), int(large),
-                                                         seg_begin, seg_end, 0, 64, stream));
+      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw, sorted, int(total_raw), int(huge),
+                                                         huge_begin, huge_end, 0, 64, stream));
       char* sort_tmp = nullptr;
       HIP_TRY(scratch.get(sort_tmp, sort_bytes));
-      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(large),
-                                                         seg_begin, seg_end, 0, 64, stream));
+      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(huge),
+                                                         huge_begin, huge_end, 0, 64, stream));
     }
     hipLaunchKernelGGL(k_mark_unique, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, raw_off, nq, total_raw, flags);
     LAUNCH_CHECK("k_mark_unique");

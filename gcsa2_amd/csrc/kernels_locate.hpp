@@ -263,16 +263,18 @@ __device__ __forceinline__ u64 wg_reserve(WgSlots& sh, unsigned long long* count
 // queries with 2..SMALL_SEGMENT values are sorted in registers by one lane each (k_sort_small), queries with up to
 // MEDIUM_SEGMENT values by one wavefront each in LDS (k_sort_medium), queries with up to BIG_SEGMENT values by one workgroup
 // each in 64 KB of LDS (k_sort_big: the paper's 16-mers average 7129 values, paper.tex:403), anything longer goes to hipCUB's
-// segmented radix sort.  k_collect_multi lists the medium segments (from the end of the segment arrays, downwards) and the
-// large ones (from the start) and publishes totals = {nodes, raw values, large segments, (unique values, written later),
-// segments with >= 2 values, medium segments, segments beyond BIG_SEGMENT}.
+// segmented radix sort.  k_collect_multi lists the medium segments (from the end of the segment arrays, downwards), the
+// large ones (from the start; MEDIUM_SEGMENT + 1 .. BIG_SEGMENT values) and the huge ones (arrays of their own) and publishes
+// totals = {nodes, raw values, large segments, (unique values, written later), segments with >= 2 values, medium segments,
+// huge segments}.
 constexpr u32 SMALL_SEGMENT = 16;
 constexpr u32 MEDIUM_SEGMENT = 1024;
 constexpr u32 BIG_SEGMENT = 8192;
 
 __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
                                                        unsigned long long* __restrict__ totals,
-                                                       u64* __restrict__ seg_begin, u64* __restrict__ seg_end, u32 medium_limit)
+                                                       u64* __restrict__ seg_begin, u64* __restrict__ seg_end,
+                                                       u64* __restrict__ huge_begin, u64* __restrict__ huge_end, u32 medium_limit)
 {
   __shared__ WgSlots slots;
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
@@ -280,11 +282,10 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
   if(q == 0) { totals[0] = node_off[nq]; totals[1] = raw_off[nq]; }
   u64 b = 0, e = 0;
   if(q < nq) { b = raw_off[q]; e = raw_off[q + 1]; }
-  const u64 multi = __ballot(e - b >= 2), large = __ballot(e - b > medium_limit);
+  const u64 multi = __ballot(e - b >= 2), large = __ballot(e - b > medium_limit && e - b <= BIG_SEGMENT);
   const u64 medium = __ballot(e - b > SMALL_SEGMENT && e - b <= medium_limit);
   const u64 huge = __ballot(e - b > BIG_SEGMENT);
-  wg_reserve(slots, totals + 4, u32(__popcll(multi)));
-  wg_reserve(slots, totals + 6, u32(__popcll(huge)));           // (every wave of the workgroup: wg_reserve synchronises it)
+  wg_reserve(slots, totals + 4, u32(__popcll(multi)));           // (every wave of the workgroup: wg_reserve synchronises it)
   u64 slot = wg_reserve(slots, totals + 2, u32(__popcll(large)));
   if((large >> lane) & 1)
   {
@@ -296,6 +297,12 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
   {
     slot += __popcll(medium & ((u64(1) << lane) - 1));
     seg_begin[nq - 1 - slot] = b; seg_end[nq - 1 - slot] = e;        // a query is in at most one of the two lists
+  }
+  slot = wg_reserve(slots, totals + 6, u32(__popcll(huge)));
+  if((huge >> lane) & 1)
+  {
+    slot += __popcll(huge & ((u64(1) << lane) - 1));
+    huge_begin[slot] = b; huge_end[slot] = e;
   }
 }
 
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(64) void k_sort_medium(const u64* __restrict__ seg_
 }
 
 // one workgroup per LARGE segment (list from the start of the segment arrays) with at most BIG_SEGMENT values: bitonic sort in
-// 64 KB of LDS, in place; longer segments are left to the segmented radix sort.  Round 2 sent everything above 1024 values
+// 64 KB of LDS, in place (longer segments are on the list of the segmented radix sort).  Round 2 sent everything above 1024 values
 // there: on a repeat-rich index that library call was 80 % of locate() (profiles/r03_locate.md).
 constexpr int BIG_THREADS = 256;
 __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end,
@@ -339,9 +346,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict_
   __shared__ u64 buf[BIG_SEGMENT];
   const u32 tid = threadIdx.x;
   const u64 b = seg_begin[blockIdx.x];
-  const u64 full = seg_end[blockIdx.x] - b;
-  if(full > BIG_SEGMENT) { return; }                       // (uniform per workgroup)
-  const u32 len = u32(full);
+  const u32 len = u32(seg_end[blockIdx.x] - b);            // <= BIG_SEGMENT: k_collect_multi
   u32 n2 = 2048;
   while(n2 < len) { n2 <<= 1; }
   for(u32 i = tid; i < n2; i += BIG_THREADS) { buf[i] = (i < len ? values[b + i] : ~u64(0)); }    // padding sorts to the end
