@@ -1177,6 +1177,9 @@ def main():
             result["host_batch"] = host_batch_rate(wl, r["d_out"])
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds)
+    if rank == 0 and world == 1 and args.workload in ("repeats", "chr22") and wl.gpu.sampleCount() > 0:
+        nloc = min(wl.nq, 400_000 if args.workload == "repeats" else wl.nq)
+        result["locate"], _, _ = measure_locate(wl.gpu, r["d_out"][:nloc].contiguous(), dev, 3)
     secondary = args.workload in ("pangenome", "pangenome_plain", "human") and world == 1 and not args.no_secondary
     if secondary and args.secondary in ("all", "config5") and wl.ix.lcp_size > 0:
         result["config5"] = config5(args, wl, dev)
