@@ -440,6 +440,60 @@ __device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage,
   return decided;
 }
 
+// The statistics from the breaks k_match_stats2 wrote (see there): MS at distance t from the pattern's end = value of the
+// last break at or before t, plus the distance to it; before the first break t + 1.  Eight lanes per pattern take its 32-position
+// words round-robin (the lanes of a group write 8 x 64 contiguous bytes), break counts and the last break carried by scans
+// within the group.
+__global__ __launch_bounds__(TPB) void k_expand_stats(const u64* __restrict__ offsets, u64 nq, const u32* __restrict__ marks,
+                                                     const unsigned short* __restrict__ vals, unsigned short* __restrict__ ms)
+{
+  const u64 q = (u64(blockIdx.x) * TPB + threadIdx.x) >> 3;
+  const u32 sub = threadIdx.x & 7;
+  if(q >= nq) { return; }                                   // (whole groups of 8 lanes)
+  const u64 begin = offsets[q], len = offsets[q + 1] - begin;
+  const u64 words = (len + 31) >> 5, mbase = (begin >> 5) + q;
+  const unsigned short* list = vals + 8 * ((begin >> 3) + q);
+  u64 carry_count = 0;
+  long long carry_last = -1;                                // t of the last break so far (-1: none)
+  for(u64 w0 = 0; w0 < words; w0 += 8)
+  {
+    const u64 w = w0 + sub;
+    const u32 m = (w < words ? marks[mbase + w] : 0u);
+    const u32 c = u32(__popc(m));
+    u32 incl = c;
+    long long last = (m != 0 ? (long long)(32 * w + 31 - u32(__clz(int(m)))) : -1), best = last;
+#pragma unroll
+    for(u32 d = 1; d < 8; d <<= 1)
+    {
+      const u32 vi = __shfl_up(incl, d, 8);
+      const long long vb = __shfl_up(best, d, 8);
+      if(sub >= d) { incl += vi; best = (vb > best ? vb : best); }
+    }
+    // exclusive values for this lane: breaks before its word, last break before its word
+    u32 before = __shfl_up(incl, 1, 8);
+    long long prev = __shfl_up(best, 1, 8);
+    if(sub == 0) { before = 0; prev = -1; }
+    u64 k = carry_count + before;
+    long long from = (prev > carry_last ? prev : carry_last);
+    u64 value = (k > 0 ? u64(list[k - 1]) : 0);
+    if(w < words)
+    {
+      for(u32 b = 0; b < 32; b++)
+      {
+        const u64 t = 32 * w + b;
+        if(t >= len) { break; }
+        if((m >> b) & 1) { value = list[k]; k++; from = (long long)t; }
+        const u64 out = value + u64((long long)t - from);
+        ms[begin + (len - 1 - t)] = (unsigned short)(out > 65535 ? 65535 : out);
+      }
+    }
+    const u32 total_breaks = __shfl(incl, 7, 8);
+    const long long group_best = __shfl(best, 7, 8);
+    carry_count += total_breaks;
+    carry_last = (group_best > carry_last ? group_best : carry_last);
+  }
+}
+
 // ---- matching statistics, version 2: wave-cooperative block fetch, two characters per step, batched parent() ----
 // Same results as k_match_stats.  One lane = one pattern; the LF steps of the 64 patterns of a wave go through the
 // cooperative fetch of k_find2 (one 128-byte request per endpoint, FLP128 pair blocks when the next two
@@ -474,6 +528,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
                                                        u64* __restrict__ fallbacks, u32 cool_down,
                                                        unsigned long long* __restrict__ queue, u32 refill_at,
                                                        const u64* __restrict__ codes, const u32* __restrict__ bad,
+                                                       u32* __restrict__ marks, unsigned short* __restrict__ vals,
                                                        unsigned long long* __restrict__ prof = nullptr)
 {
   [[maybe_unused]] u64 prof_t = 0, prof_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -498,27 +553,16 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   u32 force_single = 0;
   u64 win_code = 0;                         // packed pattern window, as in k_find2
   u32 win_used = ~u32(0), win_bad = 0;
-  // results: eight u16 per 16-byte store (`ms` is 8-byte aligned, the hardware takes the 16-byte store at any dword).  The
-  // statistics are a third of the kernel's memory requests -- every lane writes into its own pattern's 512 bytes, nothing
-  // coalesces across lanes -- so the only lever is fewer, wider stores per lane (8-byte stores: 64 per 256-bp pattern).
-#ifdef GCSA2_AB_STORE8
-  u64 packed = 0; u32 have = 0;
-  auto emit = [&](u32 pos, u32 value)        // ms[begin + pos] = value; positions arrive in descending order
-  {
-    const u64 idx = begin + pos;
-    const u32 slot = u32(idx & 3);
-    packed |= u64(value > 65535 ? 65535 : value) << (16 * slot); have |= 1u << slot;
-    if(slot == 0 || pos == 0)
-    {
-      unsigned short* group = ms + (idx & ~u64(3));
-      if(have == 15u) { *reinterpret_cast<u64*>(group) = packed; }
-      else { for(u32 s = 0; s < 4; s++) { if((have >> s) & 1) { group[s] = (unsigned short)(packed >> (16 * s)); } } }
-      packed = 0; have = 0;
-    }
-  };
-#else
+  // Results.  The statistics are MS[i] = MS[i + 1] + 1 wherever the search simply extended; only the positions where it did
+  // not -- after parent(), or a character absent at the root -- carry information ("breaks").  Writing every value cost a
+  // third of the kernel's memory requests (every lane writes into its own pattern's bytes, nothing coalesces across lanes):
+  // not writing them at all ran 22 % (half the patterns with mismatches) to 40 % (none) faster.  So the kernel writes the
+  // break values only, eight per 16-byte store, into a compact list per pattern (`vals`, at entry 8 ((begin >> 3) + q)) and
+  // one bit per break into `marks` (pre-zeroed; word (begin >> 5) + q + (t >> 5), t = distance from the pattern's end);
+  // k_expand_stats turns both into the statistics with coalesced stores.  A pattern without mismatches writes nothing.
+#ifdef GCSA2_AB_DENSE_STATS
   u64 packed_lo = 0, packed_hi = 0; u32 have = 0;
-  auto emit = [&](u32 pos, u32 value)        // ms[begin + pos] = value; positions arrive in descending order
+  auto emit = [&](u32 pos, u32 value, bool)  // ms[begin + pos] = value; positions arrive in descending order
   {
     const u64 idx = begin + pos;
     const u32 slot = u32(idx & 7);
@@ -543,21 +587,44 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       packed_lo = 0; packed_hi = 0; have = 0;
     }
   };
+  auto finish_stats = [&]() {};
+#else
+  u64 packed_lo = 0, packed_hi = 0;
+  u32 breaks = 0, mark_bits = 0, mark_word = 0;
+  auto emit = [&](u32 pos, u32 value, bool is_break)
+  {
+    if(!is_break) { return; }
+    const u32 t = total - 1 - pos, word = t >> 5;
+    if(word != mark_word && mark_bits != 0) { marks[(begin >> 5) + q + mark_word] = mark_bits; mark_bits = 0; }
+    mark_word = word; mark_bits |= 1u << (t & 31);
+    const u32 slot = breaks & 7;
+    const u64 field = u64(value > 65535 ? 65535 : value) << (16 * (slot & 3));
+    if(slot < 4) { packed_lo |= field; } else { packed_hi |= field; }
+    breaks++;
+    if(slot == 7)
+    {
+      reinterpret_cast<ulonglong2*>(vals + 8 * ((begin >> 3) + q))[(breaks >> 3) - 1] = make_ulonglong2(packed_lo, packed_hi);
+      packed_lo = 0; packed_hi = 0;
+    }
+  };
+  auto finish_stats = [&]()                   // the pattern is done: the open mark word and the open group of values
+  {
+    if(mark_bits != 0) { marks[(begin >> 5) + q + mark_word] = mark_bits; }
+    if((breaks & 7) != 0) { reinterpret_cast<ulonglong2*>(vals + 8 * ((begin >> 3) + q))[breaks >> 3] = make_ulonglong2(packed_lo, packed_hi); }
+    packed_lo = 0; packed_hi = 0; breaks = 0; mark_bits = 0; mark_word = 0;
+  };
 #endif
+  bool broke = false;                         // parent() was taken since the last statistic: the next one is a break
   auto start = [&](u64 query)
   {
     q = query; has = true;
     begin = offsets[q]; i = total = u32(offsets[q + 1] - begin);
-    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0);
+    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0); broke = false;
     // The k-mer seed table (find() of every k-mer over the fast characters, kernels_find.hpp): when the pattern's last k
     // characters are fast characters and occur, the search starts behind them -- all k suffixes match, so their statistics
     // are 1 .. k -- and skips the steps on the widest ranges, whose endpoints lie in different blocks.  An empty or wide
     // entry starts from scratch.
-#ifdef GCSA2_AB_NO_MS_SEED
-    const u32 k = 0;
-#else
     const u32 k = img.kmer_k;
-#endif
     if(k > 0 && total >= k && img.n > 0)
     {
       const u64 word = (begin >> 5) + q;
@@ -568,7 +635,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       if(fast && width != 0 && width != SEED_WIDE)
       {
         sp = entry & SEED_SP_MASK; ep = sp + width - 1;
-        for(u32 j = 0; j < k; j++) { emit(total - 1 - j, j + 1); }
+        for(u32 j = 0; j < k; j++) { emit(total - 1 - j, j + 1, false); }
         depth = k; i = total - k;
       }
     }
@@ -584,6 +651,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     {
       reinterpret_cast<ulonglong2*>(ranges)[q] = make_ulonglong2(sp, ep);
       if(fallbacks != nullptr) { fallbacks[q] = calls; }
+      finish_stats();
       has = false;
     }
     if constexpr(REFILL)
@@ -701,7 +769,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         if(pair_outcome(p_sp, p_ep, idx_ep == idx_sp, a, b) == 2)          // neither step empties (layout.hpp)
         {
           sp = p_sp.node; ep = p_ep.node;
-          emit(i - 1, depth + 1); emit(i - 2, depth + 2);
+          emit(i - 1, depth + 1, false); emit(i - 2, depth + 2, false);
           depth += 2; i -= 2; win_used += 2;
         }
         else { force_single = 2; G2_COUNT(4, 1); }             // an emptying step needs parent(): one character at a time
@@ -712,13 +780,13 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         if(!range_empty(a, b))
         {
           sp = p_sp.node; ep = p_ep.node; depth++;
-          emit(i - 1, depth); i--; win_used++;
+          emit(i - 1, depth, broke); broke = false; i--; win_used++;
           force_single -= (force_single > 0 ? 1 : 0);
         }
         else if(sp == 0 && ep == img.n - 1)                    // at the root: no such character
         {
           depth = 0;
-          emit(i - 1, 0); i--; win_used++;
+          emit(i - 1, 0, true); broke = false; i--; win_used++;
           force_single -= (force_single > 0 ? 1 : 0);
         }
         else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }   // parent() in the next round
@@ -730,7 +798,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       if(!decided) { lcp_parent(img, sp, ep, node); G2_COUNT(6, 1); }      // the interval reaches beyond the window: tree walk (lcp.cpp:276-301)
       calls++;
       sp = node.sp; ep = node.ep; depth = u32(node.node_lcp);
-      need_parent = false;
+      need_parent = false; broke = true;
     }
     G2_TICK(7);
   }

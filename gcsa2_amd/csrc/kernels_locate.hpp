@@ -339,14 +339,18 @@ __global__ __launch_bounds__(64) void k_sort_medium(const u64* __restrict__ seg_
 // one workgroup per LARGE segment (list from the start of the segment arrays) with at most BIG_SEGMENT values: bitonic sort in
 // 64 KB of LDS, in place (longer segments are on the list of the segmented radix sort).  Round 2 sent everything above 1024 values
 // there: on a repeat-rich index that library call was 80 % of locate() (profiles/r03_locate.md).
+// Two instantiations share the list: CAPACITY 4096 takes the segments of up to 4096 values in 32 KB of LDS (five workgroups
+// per CU), CAPACITY 8192 the rest in 64 KB (two per CU); a workgroup whose segment belongs to the other one exits at once.
 constexpr int BIG_THREADS = 256;
+template<u32 CAPACITY, u32 ABOVE>
 __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end,
                                                         u64* __restrict__ values)
 {
-  __shared__ u64 buf[BIG_SEGMENT];
+  __shared__ u64 buf[CAPACITY];
   const u32 tid = threadIdx.x;
   const u64 b = seg_begin[blockIdx.x];
   const u32 len = u32(seg_end[blockIdx.x] - b);            // <= BIG_SEGMENT: k_collect_multi
+  if(len > CAPACITY || len <= ABOVE) { return; }            // the other instantiation's segment (uniform per workgroup)
   u32 n2 = 2048;
   while(n2 < len) { n2 <<= 1; }
   for(u32 i = tid; i < n2; i += BIG_THREADS) { buf[i] = (i < len ? values[b + i] : ~u64(0)); }    // padding sorts to the end
