@@ -2469,7 +2469,9 @@ int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patt
     hipLaunchKernelGGL((k_match_stats2<false, false>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
                        ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, codes, bad, marks, vals);
   }
-  hipLaunchKernelGGL(k_expand_stats, dim3(grid_for(8 * nq)), dim3(TPB), 0, st, d_offsets, nq, marks, vals, out);
+#ifndef GCSA2_AB_DENSE_STATS
+  hipLaunchKernelGGL(k_expand_stats, dim3(grid_for(64 * nq)), dim3(TPB), 0, st, d_offsets, nq, marks, vals, out);
+#endif
   hipError_t le = hipGetLastError();
   if(queue != nullptr) { (void)hipFreeAsync(queue, st); }
   (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st);         // stream-ordered: released after the kernels
@@ -2517,7 +2519,9 @@ extern "C" int gcsa2_match_stats_profile_device(const gcsa2_index* ix, const uin
   hipLaunchKernelGGL((k_match_stats2<true, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
                      ix->img, d_patterns, d_offsets, nq, reinterpret_cast<unsigned short*>(d_ms), d_ranges, d_fallbacks, ix->tune.cool_down,
                      (unsigned long long*)nullptr, 64u, codes, bad, marks, vals, reinterpret_cast<unsigned long long*>(d_prof));
-  hipLaunchKernelGGL(k_expand_stats, dim3(grid_for(8 * nq)), dim3(TPB), 0, st, d_offsets, nq, marks, vals, reinterpret_cast<unsigned short*>(d_ms));
+#ifndef GCSA2_AB_DENSE_STATS
+  hipLaunchKernelGGL(k_expand_stats, dim3(grid_for(64 * nq)), dim3(TPB), 0, st, d_offsets, nq, marks, vals, reinterpret_cast<unsigned short*>(d_ms));
+#endif
   hipError_t le = hipGetLastError();
   (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st); (void)hipFreeAsync(marks, st); (void)hipFreeAsync(vals, st);
   if(le != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats2<prof>: ") + hipGetErrorString(le)); }

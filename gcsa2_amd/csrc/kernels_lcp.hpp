@@ -441,56 +441,59 @@ __device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage,
 }
 
 // The statistics from the breaks k_match_stats2 wrote (see there): MS at distance t from the pattern's end = value of the
-// last break at or before t, plus the distance to it; before the first break t + 1.  Eight lanes per pattern take its 32-position
-// words round-robin (the lanes of a group write 8 x 64 contiguous bytes), break counts and the last break carried by scans
-// within the group.
+// last break at or before t, plus the distance to it; before the first break t + 1.  One wavefront per pattern: a round takes
+// 64 mark words (2048 positions) -- one per lane, break counts and the last break so far by scans over the wave -- and then
+// writes the positions 64 at a time, consecutive lanes consecutive addresses.
 __global__ __launch_bounds__(TPB) void k_expand_stats(const u64* __restrict__ offsets, u64 nq, const u32* __restrict__ marks,
                                                      const unsigned short* __restrict__ vals, unsigned short* __restrict__ ms)
 {
-  const u64 q = (u64(blockIdx.x) * TPB + threadIdx.x) >> 3;
-  const u32 sub = threadIdx.x & 7;
-  if(q >= nq) { return; }                                   // (whole groups of 8 lanes)
+  const u64 q = (u64(blockIdx.x) * TPB + threadIdx.x) >> 6;
+  const u32 lane = threadIdx.x & 63;
+  if(q >= nq) { return; }                                   // (whole wavefronts)
   const u64 begin = offsets[q], len = offsets[q + 1] - begin;
   const u64 words = (len + 31) >> 5, mbase = (begin >> 5) + q;
   const unsigned short* list = vals + 8 * ((begin >> 3) + q);
-  u64 carry_count = 0;
-  long long carry_last = -1;                                // t of the last break so far (-1: none)
-  for(u64 w0 = 0; w0 < words; w0 += 8)
+  u64 carry_count = 0;                                      // breaks in the rounds before
+  long long carry_last = -1;                                // t of the last of them (-1: none)
+  for(u64 w0 = 0; w0 < words; w0 += 64)
   {
-    const u64 w = w0 + sub;
+    const u64 w = w0 + lane;
     const u32 m = (w < words ? marks[mbase + w] : 0u);
-    const u32 c = u32(__popc(m));
-    u32 incl = c;
-    long long last = (m != 0 ? (long long)(32 * w + 31 - u32(__clz(int(m)))) : -1), best = last;
+    u32 incl = u32(__popc(m));
+    long long best = (m != 0 ? (long long)(32 * w + 31 - u32(__clz(int(m)))) : -1);
 #pragma unroll
-    for(u32 d = 1; d < 8; d <<= 1)
+    for(u32 d = 1; d < 64; d <<= 1)
     {
-      const u32 vi = __shfl_up(incl, d, 8);
-      const long long vb = __shfl_up(best, d, 8);
-      if(sub >= d) { incl += vi; best = (vb > best ? vb : best); }
+      const u32 vi = __shfl_up(incl, d, 64);
+      const long long vb = __shfl_up(best, d, 64);
+      if(lane >= d) { incl += vi; best = (vb > best ? vb : best); }
     }
-    // exclusive values for this lane: breaks before its word, last break before its word
-    u32 before = __shfl_up(incl, 1, 8);
-    long long prev = __shfl_up(best, 1, 8);
-    if(sub == 0) { before = 0; prev = -1; }
-    u64 k = carry_count + before;
-    long long from = (prev > carry_last ? prev : carry_last);
-    u64 value = (k > 0 ? u64(list[k - 1]) : 0);
-    if(w < words)
+    u32 before = __shfl_up(incl, 1, 64);                    // breaks of this round before the lane's word, last break before it
+    long long prev = __shfl_up(best, 1, 64);
+    if(lane == 0) { before = 0; prev = -1; }
+    const u64 word_before = carry_count + before;
+    const long long word_prev = (prev > carry_last ? prev : carry_last);
+    const u64 round_positions = (words - w0 < 64 ? len - 32 * w0 : 2048);
+    for(u64 p0 = 0; p0 < round_positions; p0 += 64)
     {
-      for(u32 b = 0; b < 32; b++)
+      const u64 t = 32 * w0 + p0 + lane;
+      const u32 owner = u32((p0 + lane) >> 5);              // the lane that holds this position's word
+      const u32 wm = __shfl(m, owner, 64);
+      const u64 wb = __shfl(word_before, owner, 64);
+      const long long wp = __shfl(word_prev, owner, 64);
+      if(t < len)
       {
-        const u64 t = 32 * w + b;
-        if(t >= len) { break; }
-        if((m >> b) & 1) { value = list[k]; k++; from = (long long)t; }
-        const u64 out = value + u64((long long)t - from);
+        const u32 upto = wm & u32((u64(2) << (t & 31)) - 1);  // breaks of the word at or before t
+        long long from = wp;
+        u64 k = wb;                                         // number of breaks at or before t
+        if(upto != 0) { from = (long long)((t & ~u64(31)) + 31 - u32(__clz(int(upto)))); k += u32(__popc(upto)); }
+        const u64 out = (k > 0 ? u64(list[k - 1]) : 0) + u64((long long)t - from);
         ms[begin + (len - 1 - t)] = (unsigned short)(out > 65535 ? 65535 : out);
       }
     }
-    const u32 total_breaks = __shfl(incl, 7, 8);
-    const long long group_best = __shfl(best, 7, 8);
-    carry_count += total_breaks;
-    carry_last = (group_best > carry_last ? group_best : carry_last);
+    carry_count += __shfl(incl, 63, 64);
+    const long long round_best = __shfl(best, 63, 64);
+    carry_last = (round_best > carry_last ? round_best : carry_last);
   }
 }
 
@@ -769,7 +772,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         if(pair_outcome(p_sp, p_ep, idx_ep == idx_sp, a, b) == 2)          // neither step empties (layout.hpp)
         {
           sp = p_sp.node; ep = p_ep.node;
-          emit(i - 1, depth + 1, false); emit(i - 2, depth + 2, false);
+          emit(i - 1, depth + 1, broke); emit(i - 2, depth + 2, false); broke = false;     // (a pair right after parent(): cool_down = 0)
           depth += 2; i -= 2; win_used += 2;
         }
         else { force_single = 2; G2_COUNT(4, 1); }             // an emptying step needs parent(): one character at a time
