@@ -2420,18 +2420,6 @@ int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patt
   hipError_t pe = pool_alloc(ix, reinterpret_cast<void**>(&bad), words * sizeof(u32), st);
   if(pe != hipSuccess) { (void)hipFreeAsync(codes, st); return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("matching statistics scratch: ") + hipGetErrorString(pe)); }
   hipLaunchKernelGGL(k_pack_patterns, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, codes, bad);
-  // the kernel writes break marks and break values (k_match_stats2), k_expand_stats the statistics
-  const u64 mark_words = words, val_entries = total_bytes + 8 * nq + 16;
-  u32* marks = nullptr; unsigned short* vals = nullptr;
-  hipError_t me = pool_alloc(ix, reinterpret_cast<void**>(&marks), mark_words * sizeof(u32), st);
-  if(me == hipSuccess) { me = pool_alloc(ix, reinterpret_cast<void**>(&vals), val_entries * sizeof(unsigned short), st); }
-  if(me == hipSuccess) { me = hipMemsetAsync(marks, 0, mark_words * sizeof(u32), st); }
-  if(me != hipSuccess)
-  {
-    (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st);
-    if(marks != nullptr) { (void)hipFreeAsync(marks, st); }
-    return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("matching statistics scratch: ") + hipGetErrorString(me));
-  }
   const u32 cool = ix->tune.cool_down;
   unsigned short* out = reinterpret_cast<unsigned short*>(d_ms);
   const u64 lanes_grid = (nq + TPB2 - 1) / TPB2;
@@ -2451,31 +2439,27 @@ int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patt
     if(pair)
     {
       hipLaunchKernelGGL((k_match_stats2<true, true>), dim3(grid), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad, marks, vals);
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad);
     }
     else
     {
       hipLaunchKernelGGL((k_match_stats2<false, true>), dim3(grid), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad, marks, vals);
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad);
     }
   }
   else if(pair)
   {
     hipLaunchKernelGGL((k_match_stats2<true, false>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, codes, bad, marks, vals);
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, codes, bad);
   }
   else
   {
     hipLaunchKernelGGL((k_match_stats2<false, false>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, codes, bad, marks, vals);
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, codes, bad);
   }
-#ifndef GCSA2_AB_DENSE_STATS
-  hipLaunchKernelGGL(k_expand_stats, dim3(grid_for(64 * nq)), dim3(TPB), 0, st, d_offsets, nq, marks, vals, out);
-#endif
   hipError_t le = hipGetLastError();
   if(queue != nullptr) { (void)hipFreeAsync(queue, st); }
-  (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st);         // stream-ordered: released after the kernels
-  (void)hipFreeAsync(marks, st); (void)hipFreeAsync(vals, st);
+  (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st);         // stream-ordered: released after the kernel
   if(le != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats2: ") + hipGetErrorString(le)); }
   return GCSA2_OK;
 }
@@ -2511,19 +2495,11 @@ extern "C" int gcsa2_match_stats_profile_device(const gcsa2_index* ix, const uin
   hipError_t pe = pool_alloc(ix, reinterpret_cast<void**>(&bad), words * sizeof(u32), st);
   if(pe != hipSuccess) { (void)hipFreeAsync(codes, st); return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("matching statistics scratch: ") + hipGetErrorString(pe)); }
   hipLaunchKernelGGL(k_pack_patterns, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, codes, bad);
-  u32* marks = nullptr; unsigned short* vals = nullptr;
-  hipError_t me = pool_alloc(ix, reinterpret_cast<void**>(&marks), words * sizeof(u32), st);
-  if(me == hipSuccess) { me = pool_alloc(ix, reinterpret_cast<void**>(&vals), (total_bytes + 8 * nq + 16) * sizeof(unsigned short), st); }
-  if(me == hipSuccess) { me = hipMemsetAsync(marks, 0, words * sizeof(u32), st); }
-  if(me != hipSuccess) { (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st); return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("matching statistics scratch: ") + hipGetErrorString(me)); }
   hipLaunchKernelGGL((k_match_stats2<true, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
                      ix->img, d_patterns, d_offsets, nq, reinterpret_cast<unsigned short*>(d_ms), d_ranges, d_fallbacks, ix->tune.cool_down,
-                     (unsigned long long*)nullptr, 64u, codes, bad, marks, vals, reinterpret_cast<unsigned long long*>(d_prof));
-#ifndef GCSA2_AB_DENSE_STATS
-  hipLaunchKernelGGL(k_expand_stats, dim3(grid_for(64 * nq)), dim3(TPB), 0, st, d_offsets, nq, marks, vals, reinterpret_cast<unsigned short*>(d_ms));
-#endif
+                     (unsigned long long*)nullptr, 64u, codes, bad, reinterpret_cast<unsigned long long*>(d_prof));
   hipError_t le = hipGetLastError();
-  (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st); (void)hipFreeAsync(marks, st); (void)hipFreeAsync(vals, st);
+  (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st);
   if(le != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats2<prof>: ") + hipGetErrorString(le)); }
   return GCSA2_OK;
 }

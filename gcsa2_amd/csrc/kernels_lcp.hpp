@@ -440,63 +440,6 @@ __device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage,
   return decided;
 }
 
-// The statistics from the breaks k_match_stats2 wrote (see there): MS at distance t from the pattern's end = value of the
-// last break at or before t, plus the distance to it; before the first break t + 1.  One wavefront per pattern: a round takes
-// 64 mark words (2048 positions) -- one per lane, break counts and the last break so far by scans over the wave -- and then
-// writes the positions 64 at a time, consecutive lanes consecutive addresses.
-__global__ __launch_bounds__(TPB) void k_expand_stats(const u64* __restrict__ offsets, u64 nq, const u32* __restrict__ marks,
-                                                     const unsigned short* __restrict__ vals, unsigned short* __restrict__ ms)
-{
-  const u64 q = (u64(blockIdx.x) * TPB + threadIdx.x) >> 6;
-  const u32 lane = threadIdx.x & 63;
-  if(q >= nq) { return; }                                   // (whole wavefronts)
-  const u64 begin = offsets[q], len = offsets[q + 1] - begin;
-  const u64 words = (len + 31) >> 5, mbase = (begin >> 5) + q;
-  const unsigned short* list = vals + 8 * ((begin >> 3) + q);
-  u64 carry_count = 0;                                      // breaks in the rounds before
-  long long carry_last = -1;                                // t of the last of them (-1: none)
-  for(u64 w0 = 0; w0 < words; w0 += 64)
-  {
-    const u64 w = w0 + lane;
-    const u32 m = (w < words ? marks[mbase + w] : 0u);
-    u32 incl = u32(__popc(m));
-    long long best = (m != 0 ? (long long)(32 * w + 31 - u32(__clz(int(m)))) : -1);
-#pragma unroll
-    for(u32 d = 1; d < 64; d <<= 1)
-    {
-      const u32 vi = __shfl_up(incl, d, 64);
-      const long long vb = __shfl_up(best, d, 64);
-      if(lane >= d) { incl += vi; best = (vb > best ? vb : best); }
-    }
-    u32 before = __shfl_up(incl, 1, 64);                    // breaks of this round before the lane's word, last break before it
-    long long prev = __shfl_up(best, 1, 64);
-    if(lane == 0) { before = 0; prev = -1; }
-    const u64 word_before = carry_count + before;
-    const long long word_prev = (prev > carry_last ? prev : carry_last);
-    const u64 round_positions = (words - w0 < 64 ? len - 32 * w0 : 2048);
-    for(u64 p0 = 0; p0 < round_positions; p0 += 64)
-    {
-      const u64 t = 32 * w0 + p0 + lane;
-      const u32 owner = u32((p0 + lane) >> 5);              // the lane that holds this position's word
-      const u32 wm = __shfl(m, owner, 64);
-      const u64 wb = __shfl(word_before, owner, 64);
-      const long long wp = __shfl(word_prev, owner, 64);
-      if(t < len)
-      {
-        const u32 upto = wm & u32((u64(2) << (t & 31)) - 1);  // breaks of the word at or before t
-        long long from = wp;
-        u64 k = wb;                                         // number of breaks at or before t
-        if(upto != 0) { from = (long long)((t & ~u64(31)) + 31 - u32(__clz(int(upto)))); k += u32(__popc(upto)); }
-        const u64 out = (k > 0 ? u64(list[k - 1]) : 0) + u64((long long)t - from);
-        ms[begin + (len - 1 - t)] = (unsigned short)(out > 65535 ? 65535 : out);
-      }
-    }
-    carry_count += __shfl(incl, 63, 64);
-    const long long round_best = __shfl(best, 63, 64);
-    carry_last = (round_best > carry_last ? round_best : carry_last);
-  }
-}
-
 // ---- matching statistics, version 2: wave-cooperative block fetch, two characters per step, batched parent() ----
 // Same results as k_match_stats.  One lane = one pattern; the LF steps of the 64 patterns of a wave go through the
 // cooperative fetch of k_find2 (one 128-byte request per endpoint, FLP128 pair blocks when the next two
@@ -531,7 +474,6 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
                                                        u64* __restrict__ fallbacks, u32 cool_down,
                                                        unsigned long long* __restrict__ queue, u32 refill_at,
                                                        const u64* __restrict__ codes, const u32* __restrict__ bad,
-                                                       u32* __restrict__ marks, unsigned short* __restrict__ vals,
                                                        unsigned long long* __restrict__ prof = nullptr)
 {
   [[maybe_unused]] u64 prof_t = 0, prof_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -556,16 +498,11 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   u32 force_single = 0;
   u64 win_code = 0;                         // packed pattern window, as in k_find2
   u32 win_used = ~u32(0), win_bad = 0;
-  // Results.  The statistics are MS[i] = MS[i + 1] + 1 wherever the search simply extended; only the positions where it did
-  // not -- after parent(), or a character absent at the root -- carry information ("breaks").  Writing every value cost a
-  // third of the kernel's memory requests (every lane writes into its own pattern's bytes, nothing coalesces across lanes):
-  // not writing them at all ran 22 % (half the patterns with mismatches) to 40 % (none) faster.  So the kernel writes the
-  // break values only, eight per 16-byte store, into a compact list per pattern (`vals`, at entry 8 ((begin >> 3) + q)) and
-  // one bit per break into `marks` (pre-zeroed; word (begin >> 5) + q + (t >> 5), t = distance from the pattern's end);
-  // k_expand_stats turns both into the statistics with coalesced stores.  A pattern without mismatches writes nothing.
-#ifdef GCSA2_AB_DENSE_STATS
+  // results: eight u16 per 16-byte store (`ms` is 8-byte aligned, the hardware takes the 16-byte store at any dword).  The
+  // statistics are a third of the kernel's memory requests -- every lane writes into its own pattern's 512 bytes, nothing
+  // coalesces across lanes -- so the only lever is fewer, wider stores per lane (8-byte stores: 64 per 256-bp pattern).
   u64 packed_lo = 0, packed_hi = 0; u32 have = 0;
-  auto emit = [&](u32 pos, u32 value, bool)  // ms[begin + pos] = value; positions arrive in descending order
+  auto emit = [&](u32 pos, u32 value)        // ms[begin + pos] = value; positions arrive in descending order
   {
     const u64 idx = begin + pos;
     const u32 slot = u32(idx & 7);
@@ -590,39 +527,11 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       packed_lo = 0; packed_hi = 0; have = 0;
     }
   };
-  auto finish_stats = [&]() {};
-#else
-  u64 packed_lo = 0, packed_hi = 0;
-  u32 breaks = 0, mark_bits = 0, mark_word = 0;
-  auto emit = [&](u32 pos, u32 value, bool is_break)
-  {
-    if(!is_break) { return; }
-    const u32 t = total - 1 - pos, word = t >> 5;
-    if(word != mark_word && mark_bits != 0) { marks[(begin >> 5) + q + mark_word] = mark_bits; mark_bits = 0; }
-    mark_word = word; mark_bits |= 1u << (t & 31);
-    const u32 slot = breaks & 7;
-    const u64 field = u64(value > 65535 ? 65535 : value) << (16 * (slot & 3));
-    if(slot < 4) { packed_lo |= field; } else { packed_hi |= field; }
-    breaks++;
-    if(slot == 7)
-    {
-      reinterpret_cast<ulonglong2*>(vals + 8 * ((begin >> 3) + q))[(breaks >> 3) - 1] = make_ulonglong2(packed_lo, packed_hi);
-      packed_lo = 0; packed_hi = 0;
-    }
-  };
-  auto finish_stats = [&]()                   // the pattern is done: the open mark word and the open group of values
-  {
-    if(mark_bits != 0) { marks[(begin >> 5) + q + mark_word] = mark_bits; }
-    if((breaks & 7) != 0) { reinterpret_cast<ulonglong2*>(vals + 8 * ((begin >> 3) + q))[breaks >> 3] = make_ulonglong2(packed_lo, packed_hi); }
-    packed_lo = 0; packed_hi = 0; breaks = 0; mark_bits = 0; mark_word = 0;
-  };
-#endif
-  bool broke = false;                         // parent() was taken since the last statistic: the next one is a break
   auto start = [&](u64 query)
   {
     q = query; has = true;
     begin = offsets[q]; i = total = u32(offsets[q + 1] - begin);
-    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0); broke = false;
+    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0);
     // The k-mer seed table (find() of every k-mer over the fast characters, kernels_find.hpp): when the pattern's last k
     // characters are fast characters and occur, the search starts behind them -- all k suffixes match, so their statistics
     // are 1 .. k -- and skips the steps on the widest ranges, whose endpoints lie in different blocks.  An empty or wide
@@ -638,7 +547,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       if(fast && width != 0 && width != SEED_WIDE)
       {
         sp = entry & SEED_SP_MASK; ep = sp + width - 1;
-        for(u32 j = 0; j < k; j++) { emit(total - 1 - j, j + 1, false); }
+        for(u32 j = 0; j < k; j++) { emit(total - 1 - j, j + 1); }
         depth = k; i = total - k;
       }
     }
@@ -654,7 +563,6 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     {
       reinterpret_cast<ulonglong2*>(ranges)[q] = make_ulonglong2(sp, ep);
       if(fallbacks != nullptr) { fallbacks[q] = calls; }
-      finish_stats();
       has = false;
     }
     if constexpr(REFILL)
@@ -772,7 +680,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         if(pair_outcome(p_sp, p_ep, idx_ep == idx_sp, a, b) == 2)          // neither step empties (layout.hpp)
         {
           sp = p_sp.node; ep = p_ep.node;
-          emit(i - 1, depth + 1, broke); emit(i - 2, depth + 2, false); broke = false;     // (a pair right after parent(): cool_down = 0)
+          emit(i - 1, depth + 1); emit(i - 2, depth + 2);
           depth += 2; i -= 2; win_used += 2;
         }
         else { force_single = 2; G2_COUNT(4, 1); }             // an emptying step needs parent(): one character at a time
@@ -783,13 +691,13 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         if(!range_empty(a, b))
         {
           sp = p_sp.node; ep = p_ep.node; depth++;
-          emit(i - 1, depth, broke); broke = false; i--; win_used++;
+          emit(i - 1, depth); i--; win_used++;
           force_single -= (force_single > 0 ? 1 : 0);
         }
         else if(sp == 0 && ep == img.n - 1)                    // at the root: no such character
         {
           depth = 0;
-          emit(i - 1, 0, true); broke = false; i--; win_used++;
+          emit(i - 1, 0); i--; win_used++;
           force_single -= (force_single > 0 ? 1 : 0);
         }
         else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }   // parent() in the next round
@@ -801,7 +709,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       if(!decided) { lcp_parent(img, sp, ep, node); G2_COUNT(6, 1); }      // the interval reaches beyond the window: tree walk (lcp.cpp:276-301)
       calls++;
       sp = node.sp; ep = node.ep; depth = u32(node.node_lcp);
-      need_parent = false; broke = true;
+      need_parent = false;
     }
     G2_TICK(7);
   }
