@@ -41,6 +41,7 @@ using namespace g2;
 #include "kernels_find.hpp"
 #include "kernels_locate.hpp"
 #include "kernels_lcp.hpp"
+#include "kernels_build.hpp"
 
 // ==========================================================================================
 // host code
@@ -122,157 +123,80 @@ inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, cons
 
 // host-side staging of the device image --------------------------------------------------
 
-struct Stager
+// The image is laid out first (offsets only), allocated once, and filled by the kernels of kernels_build.hpp.
+struct Planner
 {
-  std::vector<u64> words;      // image, in u64 units; every piece starts on a 64-byte boundary
+  u64 words = 0;               // image size so far, in u64 units; every piece starts on a 64-byte boundary
   u64 reserve(u64 nwords, u64 align_words = 8)
   {
-    u64 off = (words.size() + align_words - 1) / align_words * align_words;
-    words.resize(off + nwords, 0);
+    u64 off = (words + align_words - 1) / align_words * align_words;
+    words = off + nwords;
     return off;
   }
 };
 
-struct BVPlan { u64 blocks_off = 0, hints_off = 0, size = 0, nblocks = 0, ones = 0; bool hints = false; };
+struct BVPlan { u64 blocks_off = 0, hints_off = 0, size = 0, nblocks = 0, ones = 0, nhints = 0; bool hints = false; };
 
-// Run fn(begin, end) over [0, n) on several host threads (image staging of multi-GB indexes).
-template<class F> void parallel_ranges(u64 n, F fn)
-{
-  unsigned hw = std::thread::hardware_concurrency();
-  u64 threads = (hw == 0 ? 4 : (hw > 32 ? 32 : hw));
-  if(n < (u64(1) << 16)) { threads = 1; }
-  if(threads <= 1) { fn(u64(0), n); return; }
-  std::vector<std::thread> pool;
-  u64 per = (n + threads - 1) / threads;
-  for(u64 t = 0; t < threads; t++)
-  {
-    u64 b = t * per, e = (b + per < n ? b + per : n);
-    if(b >= e) { break; }
-    pool.emplace_back([=]() { fn(b, e); });
-  }
-  for(std::thread& t : pool) { t.join(); }
-}
-
-BVPlan stage_bv(Stager& st, const u64* plain, u64 size, bool with_select)
+BVPlan plan_bv(Planner& pl, u64 size, bool with_select)
 {
   BVPlan p;
   p.size = size; p.nblocks = size / BLOCK_BITS + 1; p.hints = with_select;
-  p.blocks_off = st.reserve(p.nblocks * BLOCK_WORDS);
-  const u64 total_words = (size + 63) / 64;
-  u64* base = st.words.data() + p.blocks_off;
-  // pass 1: payload words and per-block popcounts (kept in word 0 for the moment)
-  parallel_ranges(p.nblocks, [=](u64 b0, u64 b1)
-  {
-    for(u64 b = b0; b < b1; b++)
-    {
-      u64* dst = base + b * BLOCK_WORDS;
-      u64 ones = 0;
-      for(u64 j = 0; j < PAYLOAD_WORDS; j++)
-      {
-        u64 w = b * PAYLOAD_WORDS + j, val = 0;
-        if(w < total_words)
-        {
-          val = plain[w];
-          if(w == (size >> 6) && (size & 63)) { val &= (u64(1) << (size & 63)) - 1; }
-        }
-        dst[1 + j] = val; ones += u64(__builtin_popcountll(val));
-      }
-      dst[0] = ones;
-    }
-  });
-  // pass 2: exclusive prefix sum over the blocks
-  u64 cumul = 0;
-  for(u64 b = 0; b < p.nblocks; b++) { u64 ones = base[b * BLOCK_WORDS]; base[b * BLOCK_WORDS] = cumul; cumul += ones; }
-  p.ones = cumul;
+  p.blocks_off = pl.reserve(p.nblocks * BLOCK_WORDS);
   if(with_select)
   {
-    u64 nh = p.ones / SELECT_SAMPLE + 2;
-    p.hints_off = st.reserve((nh + 1) / 2);
-    u32* h = reinterpret_cast<u32*>(st.words.data() + p.hints_off);
-    const u64* blk = st.words.data() + p.blocks_off;
-    for(u64 j = 0, b = 0; j < nh; j++)
-    {
-      u64 target = j * SELECT_SAMPLE + 1;    // largest block whose counter is < target
-      while(b + 1 < p.nblocks && blk[(b + 1) * BLOCK_WORDS] < target) { b++; }
-      h[j] = u32(b);
-    }
+    p.nhints = size / SELECT_SAMPLE + 2;      // ones / SELECT_SAMPLE + 2 are read (bv_select); ones <= size is known after the build
+    p.hints_off = pl.reserve((p.nhints + 1) / 2);
   }
   return p;
 }
 
-// Fused LF blocks (layout.hpp "FLB128") and the charRange table, built on the host from the plain
-// B_c and edges bits.
-u64 stage_flb(Stager& st, const gcsa2_host_view* v, DevImage& img, const std::vector<u64>& bwt_blocks_off)
+// Device scratch of one image build: a plain bit array in flight, the per-block popcounts and their prefix sums.
+struct BuildScratch
 {
-  const u64 n = v->path_nodes, e = v->edges, sigma = v->sigma;
-  const u64 ewords = (e + 63) / 64;
-  std::vector<u64> ew(ewords + 9, 0), ecum(ewords + 10, 0);
-  for(u64 w = 0; w < ewords; w++)
+  u64 *plain = nullptr, *counts = nullptr, *before = nullptr;
+  void* cub = nullptr;
+  size_t cub_bytes = 0;
+  hipError_t alloc(u64 max_bits)
   {
-    u64 val = v->edge_bits[w];
-    if(w == (e >> 6) && (e & 63)) { val &= (u64(1) << (e & 63)) - 1; }
-    ew[w] = val;
+    const u64 words = (max_bits + 63) / 64 + 1, blocks = max_bits / BLOCK_BITS + 1 + 2 * MAX_SIGMA;   // `before` also receives the charRange table
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&plain), words * sizeof(u64));
+    if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&counts), blocks * sizeof(u64)); }
+    if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&before), blocks * sizeof(u64)); }
+    if(e == hipSuccess) { e = hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, counts, before, int(blocks)); }
+    if(e == hipSuccess) { e = hipMalloc(&cub, cub_bytes > 0 ? cub_bytes : 8); }
+    return e;
   }
-  for(u64 w = 0; w < ewords + 9; w++) { ecum[w + 1] = ecum[w] + u64(__builtin_popcountll(ew[w])); }
-  auto erank = [&](u64 x) -> u64   // ones in edges[0, x), x clamped to e
+  ~BuildScratch()
   {
-    if(x > e) { x = e; }
-    u64 w = x >> 6, r = x & 63;
-    return ecum[w] + (r ? u64(__builtin_popcountll(ew[w] & ((u64(1) << r) - 1))) : 0);
-  };
-  auto ebits = [&](u64 pos) -> u64  // 64 edges bits starting at bit pos (zero past the end)
-  {
-    if(pos >= e) { return 0; }
-    u64 w = pos >> 6, r = pos & 63;
-    return r ? ((ew[w] >> r) | (ew[w + 1] << (64 - r))) : ew[w];
-  };
+    if(plain) { (void)hipFree(plain); } if(counts) { (void)hipFree(counts); }
+    if(before) { (void)hipFree(before); } if(cub) { (void)hipFree(cub); }
+  }
+};
 
-  for(u64 c = 0; c < sigma; c++)   // charRange(c): pathNodeRange of (C[c], C[c+1] - 1), gcsa.h:150-153
+// RB64 form of one plain bit array (`plain` in host OR device memory) at its planned place in the image; fills p.ones.
+hipError_t build_bv(u64* d_base, BVPlan& p, const u64* plain, BuildScratch& s)
+{
+  const u64 words = (p.size + 63) / 64;
+  hipError_t e = hipSuccess;
+  if(words > 0) { e = hipMemcpy(s.plain, plain, words * sizeof(u64), hipMemcpyDefault); }
+  if(e != hipSuccess) { return e; }
+  u64* blocks = d_base + p.blocks_off;
+  hipLaunchKernelGGL(k_rb64_fill, dim3(grid_for(p.nblocks)), dim3(TPB), 0, nullptr, s.plain, p.size, p.nblocks, blocks, s.counts);
+  size_t bytes = s.cub_bytes;
+  e = hipcub::DeviceScan::ExclusiveSum(s.cub, bytes, s.counts, s.before, int(p.nblocks));
+  if(e != hipSuccess) { return e; }
+  hipLaunchKernelGGL(k_rb64_counts, dim3(grid_for(p.nblocks)), dim3(TPB), 0, nullptr, s.before, p.nblocks, blocks);
+  u64 last[2] = { 0, 0 };
+  e = hipMemcpy(&last[0], s.before + (p.nblocks - 1), sizeof(u64), hipMemcpyDeviceToHost);
+  if(e == hipSuccess) { e = hipMemcpy(&last[1], s.counts + (p.nblocks - 1), sizeof(u64), hipMemcpyDeviceToHost); }
+  if(e != hipSuccess) { return e; }
+  p.ones = last[0] + last[1];
+  if(p.hints)
   {
-    img.crange[2 * c] = erank(v->C[c]);
-    img.crange[2 * c + 1] = erank(v->C[c + 1] - 1);
+    hipLaunchKernelGGL(k_select_hints, dim3(grid_for(p.nhints)), dim3(TPB), 0, nullptr, blocks, p.nblocks, p.nhints,
+                       reinterpret_cast<u32*>(d_base + p.hints_off));
   }
-
-  const u64 nblocks = n / FLB_BITS + 1;
-  img.flb_nblocks = nblocks;
-  u64 off = st.reserve(sigma * nblocks * FLB_WORDS, FLB_WORDS);
-  u64* words = st.words.data();
-  const u64 rb_blocks = n / BLOCK_BITS + 1;      // RB64 blocks of every B_c staged just before: payload words and cumulative counts
-  for(u64 c = 0; c < sigma; c++)
-  {
-    const u64* rb = words + bwt_blocks_off[c];
-    u64* dst_base = words + off + c * nblocks * FLB_WORDS;
-    const u64 Cc = v->C[c];
-    parallel_ranges(nblocks, [=, &ew](u64 b0, u64 b1)
-    {
-      auto payload = [&](u64 w) -> u64          // plain word w of B_c (zero past the vector)
-      {
-        const u64 blk = w / PAYLOAD_WORDS;
-        return blk < rb_blocks ? rb[blk * BLOCK_WORDS + 1 + w % PAYLOAD_WORDS] : 0;
-      };
-      for(u64 b = b0; b < b1; b++)
-      {
-        u64* dst = dst_base + b * FLB_WORDS;
-        const u64 w0 = b * FLB_PAYLOAD, rblk = w0 / PAYLOAD_WORDS;          // rank(B_c, 384 b): the RB64 count + the words before w0
-        u64 rank = rb[rblk * BLOCK_WORDS];                                  // 384 b <= n, so rblk < rb_blocks
-        for(u64 w = rblk * PAYLOAD_WORDS; w < w0; w++) { rank += u64(__builtin_popcountll(payload(w))); }
-        const u64 ecnt = Cc + rank;
-        const u64 prev = (ecnt > 0 && ecnt - 1 < e) ? ((ew[(ecnt - 1) >> 6] >> ((ecnt - 1) & 63)) & 1) : 0;
-        dst[0] = ecnt;
-        dst[1] = erank(ecnt) | (prev << 63);
-        u64 cum_b = 0, cum_e = 0, run_b = 0, run_e = 0;
-        for(u64 j = 0; j < FLB_PAYLOAD; j++)
-        {
-          dst[2 + j] = payload(w0 + j);
-          dst[8 + j] = ebits(ecnt + 64 * j);
-          run_b += u64(__builtin_popcountll(dst[2 + j])); run_e += u64(__builtin_popcountll(dst[8 + j]));
-          cum_b |= run_b << (10 * j); cum_e |= run_e << (10 * j);
-        }
-        dst[14] = cum_b; dst[15] = cum_e;
-      }
-    });
-  }
-  return off;
+  return hipGetLastError();
 }
 
 DevBV resolve(const BVPlan& p, const u64* d_base)
@@ -539,41 +463,42 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
   for(u64 c = 0; c <= v->sigma; c++) { img.C[c] = v->C[c]; }
   std::memcpy(img.char2comp, v->char2comp, 256);
 
-  Stager st;
   try
   {
-    // all B_c back to back with identical geometry (k_find selects by base + comp * stride)
+    // Layout first.  All B_c back to back with identical geometry (k_find selects by base + comp * stride).
+    Planner pl;
     std::vector<BVPlan> bwt(v->sigma);
     for(u64 c = 0; c < v->sigma; c++)
     {
-      bwt[c] = stage_bv(st, v->bwt[c], img.n, false);
+      bwt[c] = plan_bv(pl, img.n, false);
       if(c > 0 && bwt[c].blocks_off != bwt[0].blocks_off + c * (bwt[0].nblocks * BLOCK_WORDS))
       {
         delete ix; return fail(GCSA2_ERR_INVALID_ARGUMENT, "internal: B_c stride mismatch");
       }
     }
-    BVPlan edges = stage_bv(st, v->edge_bits, img.e, false);
-    std::vector<u64> bwt_blocks_off(v->sigma);
-    for(u64 c = 0; c < v->sigma; c++) { bwt_blocks_off[c] = bwt[c].blocks_off; }
-    u64 flb_off = stage_flb(st, v, img, bwt_blocks_off);
+    BVPlan edges = plan_bv(pl, img.e, false);
+    img.flb_nblocks = img.n / FLB_BITS + 1;
+    const u64 flb_off = pl.reserve(v->sigma * img.flb_nblocks * FLB_WORDS, FLB_WORDS);
     BVPlan sampled, samples, xfilter, xvalues, redundant;
-    u64 stored_off = 0, lcp_off = 0;
+    u64 stored_off = 0, lcp_off = 0, stored_words = 0, max_bits = (img.n > img.e ? img.n : img.e);
     img.has_samples = (v->sampled_path_bits != nullptr);
     if(img.has_samples)
     {
-      sampled = stage_bv(st, v->sampled_path_bits, img.n, false);
-      samples = stage_bv(st, v->sample_bits, v->sample_count, true);
-      u64 nw = (v->sample_count * v->sample_width + 63) / 64;
-      stored_off = st.reserve(nw + 2);
-      std::memcpy(st.words.data() + stored_off, v->stored_samples, nw * sizeof(u64));
+      sampled = plan_bv(pl, img.n, false);
+      samples = plan_bv(pl, v->sample_count, true);
+      stored_words = (v->sample_count * v->sample_width + 63) / 64;
+      stored_off = pl.reserve(stored_words + 2);
       img.sample_count = v->sample_count; img.sample_width = v->sample_width;
+      if(v->sample_count > max_bits) { max_bits = v->sample_count; }
     }
     img.has_counters = (v->extra_filter_bits != nullptr);
     if(img.has_counters)
     {
-      xfilter = stage_bv(st, v->extra_filter_bits, img.n, false);
-      xvalues = stage_bv(st, v->extra_values_bits, v->extra_values_len, true);
-      redundant = stage_bv(st, v->redundant_bits, v->redundant_len, true);
+      xfilter = plan_bv(pl, img.n, false);
+      xvalues = plan_bv(pl, v->extra_values_len, true);
+      redundant = plan_bv(pl, v->redundant_len, true);
+      if(v->extra_values_len > max_bits) { max_bits = v->extra_values_len; }
+      if(v->redundant_len > max_bits) { max_bits = v->redundant_len; }
     }
     img.has_lcp = (v->lcp_data != nullptr);
     if(img.has_lcp)
@@ -583,8 +508,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       if((v->lcp_branching & (v->lcp_branching - 1)) == 0) { while((u64(1) << img.lcp_shift) < v->lcp_branching) { img.lcp_shift++; } }
       for(u64 l = 0; l <= v->lcp_levels; l++) { img.lcp_offsets[l] = v->lcp_offsets[l]; }
       img.lcp_values = v->lcp_offsets[v->lcp_levels];
-      lcp_off = st.reserve((img.lcp_values + 7) / 8 + 18);  // 128-byte window reads around the last values stay inside (parent_from_window)
-      std::memcpy(st.words.data() + lcp_off, v->lcp_data, img.lcp_values);
+      lcp_off = pl.reserve((img.lcp_values + 7) / 8 + 18);  // 128-byte window reads around the last values stay inside (parent_from_window)
     }
 
     DeviceGuard guard(device);
@@ -609,27 +533,72 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       else { ix->pool = nullptr; }           // falls back to the default pool with its default threshold
       (void)hipGetLastError();
     }
-    ix->bytes = st.words.size() * sizeof(u64);
+    ix->bytes = pl.words * sizeof(u64);
     hipError_t e = hipMalloc(&ix->d_base, ix->bytes > 0 ? ix->bytes : 8);
     if(e != hipSuccess) { delete ix; return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(image): ") + hipGetErrorString(e)); }
-    e = hipMemcpy(ix->d_base, st.words.data(), ix->bytes, hipMemcpyHostToDevice);
+    e = hipMemset(ix->d_base, 0, ix->bytes > 0 ? ix->bytes : 8);       // alignment gaps, the words behind the samples and the LCP values
     if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&ix->d_slots), RESULT_SLOTS * 8 * sizeof(unsigned long long)); }
-    if(e != hipSuccess) { gcsa2_index_destroy(ix); return fail(GCSA2_ERR_HIP, std::string("hipMemcpy(image): ") + hipGetErrorString(e)); }
+    if(e != hipSuccess) { gcsa2_index_destroy(ix); return fail(GCSA2_ERR_HIP, std::string("image allocation: ") + hipGetErrorString(e)); }
 
-    const u64* base = static_cast<const u64*>(ix->d_base);
-    for(u64 c = 0; c < v->sigma; c++) { img.bwt[c] = resolve(bwt[c], base); }
-    img.edges = resolve(edges, base);
-    img.flb = base + flb_off;
-    if(img.has_samples)
+    // The image is built on the device from the plain arrays of the view, each of them copied once (they may already be in
+    // device memory): rank blocks, select hints, the fused FLB128 blocks and the charRange table (kernels_build.hpp).
+    u64* wbase = static_cast<u64*>(ix->d_base);
+    const u64* base = wbase;
     {
-      img.sampled = resolve(sampled, base); img.samples = resolve(samples, base);
-      img.stored = base + stored_off;
+      BuildScratch scratch;
+      const char* step = "scratch";
+      auto run = [&](const char* name, BVPlan& plan, const u64* plain, DevBV& dst)
+      {
+        if(e != hipSuccess) { return; }
+        step = name;
+        e = build_bv(wbase, plan, plain, scratch);
+        dst = resolve(plan, base);
+      };
+      auto copy = [&](const char* name, u64 word_off, const void* src, u64 bytes)
+      {
+        if(e != hipSuccess || bytes == 0) { return; }
+        step = name;
+        e = hipMemcpy(wbase + word_off, src, bytes, hipMemcpyDefault);
+      };
+      e = scratch.alloc(max_bits);
+      for(u64 c = 0; c < v->sigma; c++) { run("bwt", bwt[c], v->bwt[c], img.bwt[c]); }
+      run("edges", edges, v->edge_bits, img.edges);
+      if(e == hipSuccess)
+      {
+        step = "fused blocks";
+        hipLaunchKernelGGL(k_build_flb, dim3(grid_for(img.flb_nblocks), unsigned(v->sigma)), dim3(TPB), 0, nullptr, img, wbase + flb_off);
+        hipLaunchKernelGGL(k_crange, dim3(1), dim3(64), 0, nullptr, img, scratch.before);
+        e = hipGetLastError();
+        if(e == hipSuccess) { e = hipMemcpy(img.crange, scratch.before, 2 * v->sigma * sizeof(u64), hipMemcpyDeviceToHost); }
+        img.flb = base + flb_off;
+      }
+      if(img.has_samples)
+      {
+        run("sampled_paths", sampled, v->sampled_path_bits, img.sampled);
+        run("samples", samples, v->sample_bits, img.samples);
+        copy("stored_samples", stored_off, v->stored_samples, stored_words * sizeof(u64));
+        img.stored = base + stored_off;
+      }
+      if(img.has_counters)
+      {
+        run("extra_pointers.filter", xfilter, v->extra_filter_bits, img.xfilter);
+        run("extra_pointers.values", xvalues, v->extra_values_bits, img.xvalues);
+        run("redundant_pointers", redundant, v->redundant_bits, img.redundant);
+      }
+      if(img.has_lcp)
+      {
+        copy("lcp", lcp_off, v->lcp_data, img.lcp_values);
+        img.lcp = reinterpret_cast<const u8*>(base + lcp_off);
+      }
+      if(e == hipSuccess) { step = "synchronize"; e = hipDeviceSynchronize(); }
+      if(e != hipSuccess) { g_error = step; }
     }
-    if(img.has_counters)
+    if(e != hipSuccess)
     {
-      img.xfilter = resolve(xfilter, base); img.xvalues = resolve(xvalues, base); img.redundant = resolve(redundant, base);
+      const std::string step = g_error;
+      gcsa2_index_destroy(ix);
+      return fail(GCSA2_ERR_HIP, "image build (" + step + "): " + hipGetErrorString(e));
     }
-    if(img.has_lcp) { img.lcp = reinterpret_cast<const u8*>(base + lcp_off); }
 
     // pred4 nibbles (first predecessor comp + sampled flag), built on the device
     img.pred4 = nullptr;
@@ -742,7 +711,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
   }
   catch(const std::bad_alloc&)
   {
-    gcsa2_index_destroy(ix); return fail(GCSA2_ERR_OUT_OF_MEMORY, "host staging allocation failed");
+    gcsa2_index_destroy(ix); return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed");
   }
 
   DeviceGuard table_guard(device);       // the guard above ended with the try block
