@@ -4,7 +4,9 @@ A host view describes the data members of `gcsa::GCSA` (reference `include/gcsa/
 and `gcsa::LCPArray` (`include/gcsa/lcp.h:188-190`) as plain LSB-first bit arrays and integer
 arrays.  `make_host_view()` accepts any object with the attribute names used by
 `workload.index_arrays.IndexArrays`; the numpy arrays it references are kept alive by the
-returned holder.
+returned holder.  The bulk arrays (bwt[c], edges, the sample / counter bit arrays, stored_samples,
+lcp_data) may also be torch tensors in device memory: the image is built on the device and reads
+them from wherever they are.  char2comp, C and lcp_offsets are read by the host.
 """
 import ctypes as C
 import numpy as np
@@ -51,12 +53,23 @@ STNODE_DTYPE = np.dtype([("sp", "<u8"), ("ep", "<u8"), ("left_lcp", "<u8"), ("ri
                          ("node_lcp", "<u8")])
 
 
+def _is_device_tensor(a):
+    return hasattr(a, "data_ptr") and hasattr(a, "is_cuda")
+
+
 def _u64(a):
+    if _is_device_tensor(a):
+        # a bulk array already in device (or pinned host) memory: gcsa2_index_create copies it with hipMemcpyDefault
+        assert a.is_contiguous() and a.element_size() == 8, "device arrays must be contiguous 64-bit words"
+        return a, C.cast(a.data_ptr(), u64p)
     a = np.ascontiguousarray(a, dtype=np.uint64)
     return a, a.ctypes.data_as(u64p)
 
 
 def _u8(a):
+    if _is_device_tensor(a):
+        assert a.is_contiguous() and a.element_size() == 1, "device byte arrays must be contiguous"
+        return a, C.cast(a.data_ptr(), u8p)
     a = np.ascontiguousarray(a, dtype=np.uint8)
     return a, a.ctypes.data_as(u8p)
 

@@ -116,7 +116,11 @@ typedef struct gcsa2_stnode {
 int gcsa2_device_count(void);
 
 /* Build the device image of `view` on HIP device `device`.  Replaces GCSA::load + LCPArray::load
- * followed by nothing: the reference queries host RAM in place (benchmark/query_gcsa.cpp:55,63). */
+ * followed by nothing: the reference queries host RAM in place (benchmark/query_gcsa.cpp:55,63).
+ * The image (rank blocks, select hints, fused LF blocks) is built ON the device: every bulk array of the view (bwt[c],
+ * edge_bits, the sample and counter bit arrays, stored_samples, lcp_data) is copied to HBM once, 1/8 byte per bit, and
+ * may itself be in host, pinned or device memory (hipMemcpyDefault).  char2comp, C, lcp_offsets, comp2char and the
+ * pointer table `bwt` are read by the host.  No host copy of the image is made. */
 int gcsa2_index_create(const gcsa2_host_view* view, int device, gcsa2_index** out);
 void gcsa2_index_destroy(gcsa2_index* index);
 

@@ -1008,3 +1008,36 @@ def test_locate_segment_sizes(engine):
     go, gv = gpu.locate_batch(modest)
     co, cv = cpu.locate_batch(modest, threads=8)
     assert np.array_equal(go, co) and np.array_equal(gv, cv) and int(np.diff(co).max()) > 1024
+
+
+def test_index_from_device_resident_arrays(case, engine):
+    """gcsa2_index_create builds the image on the device and reads the bulk arrays of the view from wherever they are: an
+    index whose bit arrays, samples and LCP bytes already sit in HBM answers exactly like the one built from host arrays
+    (and like the oracle), and both report the same image size."""
+    import types
+    import torch
+    name, g, K, ix, gpu, lcp, cpu = case
+    dev = torch.device("cuda", 0)
+
+    def words(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64).copy()).to(dev)
+
+    fields = dict(vars(ix))
+    fields["bwt"] = [words(b) for b in ix.bwt]
+    for key in ("edges", "sampled_paths", "stored_samples", "samples", "extra_filter", "extra_values", "redundant"):
+        fields[key] = words(fields[key])
+    fields["lcp_data"] = torch.from_numpy(np.ascontiguousarray(ix.lcp_data, dtype=np.uint8).copy()).to(dev)
+    resident, rlcp = engine.open_index(types.SimpleNamespace(**fields), device=0)
+    assert resident.device_bytes() == gpu.device_bytes() and resident.sampleCount() == gpu.sampleCount()
+    pats = random_patterns(g, K, 0xD1CE, 300)
+    cat, off = concat_patterns(pats)
+    got = resident.find_batch(cat, off)
+    assert np.array_equal(got, gpu.find_batch(cat, off)), name
+    for p, r in zip(pats[:60], got):
+        assert tuple(int(x) for x in r) == tuple(cpu.find(p)), (name, p)
+    ranges = np.array([r for r in all_ranges(ix, 0x5EED, 60) if r[0] <= r[1]], dtype=np.uint64)
+    for a, b in zip(resident.locate_batch(ranges), gpu.locate_batch(ranges)):
+        assert np.array_equal(a, b), name
+    assert np.array_equal(resident.count_batch(ranges), gpu.count_batch(ranges)), name
+    assert np.array_equal(rlcp.parent_batch(ranges), lcp.parent_batch(ranges)), name
+    resident.close()
