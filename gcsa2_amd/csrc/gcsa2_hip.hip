@@ -56,6 +56,7 @@ struct Staging
   hipStream_t stream = nullptr;
   char* d = nullptr; size_t d_cap = 0;
   char* h = nullptr; size_t h_cap = 0;       // pinned (hipHostMalloc)
+  char* z = nullptr;                         // pinned, coherent, ZERO_COPY_ARENA bytes: kernels of small calls read and write it directly
 };
 
 struct gcsa2_index
@@ -94,6 +95,8 @@ struct gcsa2_index
     u64 ms_grid = 0;                   // GCSA2_MS_GRID: ... most workgroups launched (0: what the device holds at once)
     u32 sort_medium_limit = 0;         // GCSA2_SORT_MEDIUM=0 sends the 17..1024-value locate segments to the segmented radix sort
     u64 locate_split = (u64(1) << 31) - 1;   // GCSA2_LOCATE_SPLIT: most values (before deduplication) one pass of the locate pipeline handles
+    bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the segmented radix sort
+    bool zero_copy = true;             // GCSA2_ZERO_COPY=0: small host-pointer calls copy through the arenas like large ones
   } tune;
 };
 
@@ -231,12 +234,16 @@ template<class T> struct DBuf
 constexpr size_t PINNED_ARENA = size_t(8) << 20;       // per staging object
 constexpr size_t PINNED_MAX_COPY = size_t(2) << 20;    // larger transfers go straight from / to the caller's memory
 constexpr size_t DEVICE_ARENA_KEEP = size_t(512) << 20; // a larger arena is released with the call that needed it
+// A call that moves at most this much (the scalar find() / LF() / count() / parent() of the facade, batches of a few hundred
+// queries) makes no copies at all: its buffers are carved out of pinned host memory that the kernel reads and writes over the
+// bus, so the call is one launch and one stream synchronisation instead of two or three copies around them.
+constexpr size_t ZERO_COPY_ARENA = size_t(32) << 10;
 
 // One host-pointer call's lease on a Staging object of the handle (see Staging).
 class Lease
 {
 public:
-  explicit Lease(const gcsa2_index* ix) : ix(ix), s(nullptr), d_used(0), h_used(0), busy(false)
+  explicit Lease(const gcsa2_index* ix) : ix(ix), s(nullptr), d_used(0), h_used(0), busy(false), zero(false)
   {
     std::lock_guard<std::mutex> hold(ix->staging_lock);
     if(!ix->staging_pool.empty()) { s = ix->staging_pool.back(); ix->staging_pool.pop_back(); }
@@ -253,7 +260,8 @@ public:
   Lease& operator=(const Lease&) = delete;
 
   // device bytes this call will carve out of the arena (sum of its buffers, each rounded up to 256 bytes)
-  hipError_t begin(size_t device_bytes)
+  // zero_copy_ok: every buffer of the call is only ever touched by kernels and by up() / down()
+  hipError_t begin(size_t device_bytes, bool zero_copy_ok = false)
   {
     if(s == nullptr)
     {
@@ -261,9 +269,16 @@ public:
       if(s == nullptr) { return hipErrorOutOfMemory; }
       hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
       if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&s->h), PINNED_ARENA, hipHostMallocDefault); }
-      if(e != hipSuccess) { if(s->stream) { (void)hipStreamDestroy(s->stream); } delete s; s = nullptr; return e; }
+      if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&s->z), ZERO_COPY_ARENA, hipHostMallocMapped | hipHostMallocCoherent); }
+      if(e != hipSuccess)
+      {
+        if(s->stream) { (void)hipStreamDestroy(s->stream); } if(s->h) { (void)hipHostFree(s->h); }
+        delete s; s = nullptr; return e;
+      }
       s->h_cap = PINNED_ARENA;
     }
+    zero = (zero_copy_ok && ix->tune.zero_copy && device_bytes <= ZERO_COPY_ARENA);
+    if(zero) { d_used = 0; h_used = 0; pending.clear(); busy = true; return hipSuccess; }
     if(device_bytes > s->d_cap)
     {
       if(s->d != nullptr) { (void)hipFree(s->d); s->d = nullptr; s->d_cap = 0; }
@@ -278,7 +293,7 @@ public:
   static size_t need(size_t bytes) { return (bytes + 255) / 256 * 256 + 256; }
   template<class T> T* dev(u64 count)
   {
-    char* p = s->d + d_used;
+    char* p = (zero ? s->z : s->d) + d_used;
     d_used += need(count * sizeof(T));
     return reinterpret_cast<T*>(p);
   }
@@ -287,6 +302,7 @@ public:
   hipError_t up(void* d, const void* h, size_t bytes)
   {
     if(bytes == 0) { return hipSuccess; }
+    if(in_zero_arena(d)) { std::memcpy(d, h, bytes); return hipSuccess; }
     char* slot = pinned(bytes);
     if(slot == nullptr) { return hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s->stream); }
     std::memcpy(slot, h, bytes);
@@ -295,6 +311,7 @@ public:
   hipError_t down(void* h, const void* d, size_t bytes)
   {
     if(bytes == 0) { return hipSuccess; }
+    if(in_zero_arena(d)) { pending.push_back(Pending{h, static_cast<const char*>(d), bytes}); return hipSuccess; }
     char* slot = pinned(bytes);
     if(slot == nullptr) { return hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s->stream); }
     pending.push_back(Pending{h, slot, bytes});
@@ -310,6 +327,11 @@ public:
   }
 
 private:
+  bool in_zero_arena(const void* p) const
+  {
+    const char* c = static_cast<const char*>(p);
+    return zero && c >= s->z && c < s->z + ZERO_COPY_ARENA;
+  }
   char* pinned(size_t bytes)
   {
     if(bytes > PINNED_MAX_COPY || h_used + bytes > s->h_cap) { return nullptr; }
@@ -318,7 +340,7 @@ private:
     return p;
   }
   struct Pending { void* user; const char* slot; size_t bytes; };
-  const gcsa2_index* ix; Staging* s; size_t d_used, h_used; bool busy;
+  const gcsa2_index* ix; Staging* s; size_t d_used, h_used; bool busy, zero;
   std::vector<Pending> pending;
 };
 
@@ -456,6 +478,8 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.ms_grid = u64(knob("GCSA2_MS_GRID", 0, 0, long(1) << 30));
     ix->tune.sort_medium_limit = (knob("GCSA2_SORT_MEDIUM", 1, 0, 1) == 0 ? SMALL_SEGMENT : MEDIUM_SEGMENT);
     ix->tune.locate_split = u64(knob("GCSA2_LOCATE_SPLIT", (long(1) << 31) - 1, 2, (long(1) << 31) - 1));
+    ix->tune.zero_copy = (knob("GCSA2_ZERO_COPY", 1, 0, 1) != 0);
+    ix->tune.dedup_huge = (knob("GCSA2_DEDUP_HUGE", 1, 0, 1) != 0);
   }
   std::memset(&ix->img, 0, sizeof(DevImage));
   DevImage& img = ix->img;
@@ -832,6 +856,7 @@ void gcsa2_index_destroy(gcsa2_index* ix)
     if(st->stream) { (void)hipStreamDestroy(st->stream); }
     if(st->d) { (void)hipFree(st->d); }
     if(st->h) { (void)hipHostFree(st->h); }
+    if(st->z) { (void)hipHostFree(st->z); }
     delete st;
   }
   delete ix;
@@ -862,7 +887,7 @@ int simple_batch(const gcsa2_index* ix, const uint64_t* in, u64 in_words, uint64
 {
   DeviceGuard guard(ix->device);
   Lease lease(ix);
-  HIP_TRY(lease.begin(Lease::need(in_words * nq * 8) + Lease::need(out_words * nq * 8)));
+  HIP_TRY(lease.begin(Lease::need(in_words * nq * 8) + Lease::need(out_words * nq * 8), true));
   u64* d_in = lease.dev<u64>(in_words * nq); u64* d_out = lease.dev<u64>(out_words * nq);
   HIP_TRY(lease.up(d_in, in, in_words * nq * sizeof(u64)));
   launch(d_in, d_out, lease.stream());
@@ -1031,9 +1056,9 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   // have to be removed, rewritten in place otherwise)
   u64* sizes = nullptr; u64* segs = nullptr;
   unsigned long long* d_totals = ix->d_slots + 8 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);   // {nodes, raw, large, unique, multi, medium}
-  HIP_TRY(scratch.get(sizes, 3 * (nq + 1))); HIP_TRY(scratch.get(segs, 4 * nq));
+  HIP_TRY(scratch.get(sizes, 3 * (nq + 1))); HIP_TRY(scratch.get(segs, 6 * nq));
   u64 *node_counts = sizes, *raw_counts = sizes + (nq + 1), *node_off = sizes + 2 * (nq + 1), *raw_off = d_offsets;
-  u64 *seg_begin = segs, *seg_end = segs + nq, *huge_begin = segs + 2 * nq, *huge_end = segs + 3 * nq;
+  u64 *seg_begin = segs, *seg_end = segs + nq, *huge_begin = segs + 2 * nq, *huge_end = segs + 3 * nq, *over_begin = segs + 4 * nq, *over_end = segs + 5 * nq;
   hipLaunchKernelGGL(k_locate_sizes, dim3(grid_for(nq)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_counts, raw_counts, d_totals);
   LAUNCH_CHECK("k_locate_sizes");
 
@@ -1048,10 +1073,11 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   const u32 medium_limit = ix->tune.sort_medium_limit;
   hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, huge_begin, huge_end, medium_limit);
   LAUNCH_CHECK("k_collect_multi");
-  unsigned long long totals[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
-  const u64 total_nodes = totals[0], total_raw = totals[1], large = totals[2], multi = totals[4], medium = totals[5], huge = totals[6];
+  const u64 total_nodes = totals[0], total_raw = totals[1], multi = totals[4], huge = totals[6];
+  u64 large = totals[2], medium = totals[5], over = 0;
   if(total_raw > ix->tune.locate_split)
   {
     if(allow_split) { return LOCATE_NEEDS_SPLIT; }
@@ -1084,9 +1110,20 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     LAUNCH_CHECK("k_locate_walk");
 
     // removeDuplicates: queries with up to SMALL_SEGMENT values are sorted in registers, up to MEDIUM_SEGMENT by a wavefront
-    // and up to BIG_SEGMENT by a workgroup in LDS, all in place; only longer ones by hipCUB's segmented radix sort (from a
-    // copy); then flag + scan + compact
-    if(huge > 0)
+    // and up to BIG_SEGMENT by a workgroup in LDS, all in place.  Longer ones first lose their duplicates (k_dedup_huge) and
+    // join those lists with their distinct values; only a segment with more than BIG_SEGMENT distinct values goes to hipCUB's
+    // segmented radix sort (from a copy).  Then flag + scan + compact.
+    if(huge > 0 && !ix->tune.dedup_huge) { over = huge; over_begin = huge_begin; over_end = huge_end; }
+    else if(huge > 0)
+    {
+      hipLaunchKernelGGL(k_dedup_huge, dim3(unsigned(huge)), dim3(HUGE_THREADS), 0, stream, huge_begin, huge_end, sorted, nq, medium_limit,
+                         d_totals, seg_begin, seg_end, over_begin, over_end);
+      LAUNCH_CHECK("k_dedup_huge");
+      HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      large = totals[2]; medium = totals[5]; over = totals[7];
+    }
+    if(over > 0)
     {
       HIP_TRY(scratch.get(raw, total_raw));
       HIP_TRY(hipMemcpyAsync(raw, sorted, total_raw * sizeof(u64), hipMemcpyDeviceToDevice, stream));
@@ -1104,15 +1141,15 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
       hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(large)), dim3(BIG_THREADS), 0, stream, seg_begin, seg_end, sorted);
       LAUNCH_CHECK("k_sort_big");
     }
-    if(huge > 0)
+    if(over > 0)
     {
       size_t sort_bytes = 0;
-      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw, sorted, int(total_raw), int(huge),
-                                                         huge_begin, huge_end, 0, 64, stream));
+      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw, sorted, int(total_raw), int(over),
+                                                         over_begin, over_end, 0, 64, stream));
       char* sort_tmp = nullptr;
       HIP_TRY(scratch.get(sort_tmp, sort_bytes));
-      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(huge),
-                                                         huge_begin, huge_end, 0, 64, stream));
+      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(over),
+                                                         over_begin, over_end, 0, 64, stream));
     }
     hipLaunchKernelGGL(k_mark_unique, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, raw_off, nq, total_raw, flags);
     LAUNCH_CHECK("k_mark_unique");
@@ -1450,7 +1487,7 @@ int gcsa2_find_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint6
   DeviceGuard guard(ix->device);
   const u64 total = offsets[nq];
   Lease lease(ix);
-  HIP_TRY(lease.begin(Lease::need(total + 16) + Lease::need((nq + 1) * 8) + Lease::need(2 * nq * 8)));
+  HIP_TRY(lease.begin(Lease::need(total + 16) + Lease::need((nq + 1) * 8) + Lease::need(2 * nq * 8), true));
   u8* d_pat = lease.dev<u8>(total + 16); u64* d_off = lease.dev<u64>(nq + 1); u64* d_out = lease.dev<u64>(2 * nq);
   HIP_TRY(lease.up(d_pat, patterns, total));
   HIP_TRY(lease.up(d_off, offsets, (nq + 1) * sizeof(u64)));
@@ -1467,7 +1504,7 @@ int gcsa2_lf_batch(const gcsa2_index* ix, const uint64_t* in, const uint8_t* com
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
   Lease lease(ix);
-  HIP_TRY(lease.begin(2 * Lease::need(2 * nq * 8) + Lease::need(nq)));
+  HIP_TRY(lease.begin(2 * Lease::need(2 * nq * 8) + Lease::need(nq), true));
   u64* d_in = lease.dev<u64>(2 * nq); u64* d_out = lease.dev<u64>(2 * nq); u8* d_c = lease.dev<u8>(nq);
   HIP_TRY(lease.up(d_in, in, 2 * nq * sizeof(u64)));
   HIP_TRY(lease.up(d_c, comps, nq));
@@ -1484,7 +1521,7 @@ int gcsa2_lf_node_batch(const gcsa2_index* ix, const uint64_t* in, uint64_t nq, 
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
   Lease lease(ix);
-  HIP_TRY(lease.begin(2 * Lease::need(nq * 8)));
+  HIP_TRY(lease.begin(2 * Lease::need(nq * 8), true));
   u64* d_in = lease.dev<u64>(nq); u64* d_out = lease.dev<u64>(nq);
   HIP_TRY(lease.up(d_in, in, nq * sizeof(u64)));
   hipLaunchKernelGGL(k_lf_node, dim3(grid_for(nq)), dim3(TPB), 0, lease.stream(), ix->img, d_in, nq, d_out);
@@ -1517,7 +1554,7 @@ int gcsa2_lf_all_batch(const gcsa2_index* ix, const uint64_t* in, uint64_t nq, i
   DeviceGuard guard(ix->device);
   const u64 sigma = ix->img.sigma;
   Lease lease(ix);
-  HIP_TRY(lease.begin(Lease::need(2 * nq * 8) + Lease::need(2 * nq * sigma * 8)));
+  HIP_TRY(lease.begin(Lease::need(2 * nq * 8) + Lease::need(2 * nq * sigma * 8), true));
   u64* d_in = lease.dev<u64>(2 * nq); u64* d_out = lease.dev<u64>(2 * nq * sigma);
   HIP_TRY(lease.up(d_in, in, 2 * nq * sizeof(u64)));
   hipLaunchKernelGGL(k_lf_all, dim3(grid_for(nq)), dim3(TPB), 0, lease.stream(), ix->img, d_in, nq, all, d_out);
@@ -1533,7 +1570,7 @@ int gcsa2_count_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
   Lease lease(ix);
-  HIP_TRY(lease.begin(Lease::need(2 * nq * 8) + Lease::need(nq * 8)));
+  HIP_TRY(lease.begin(Lease::need(2 * nq * 8) + Lease::need(nq * 8), true));
   u64* d_in = lease.dev<u64>(2 * nq); u64* d_out = lease.dev<u64>(nq);
   HIP_TRY(lease.up(d_in, ranges, 2 * nq * sizeof(u64)));
   int rc = gcsa2_count_device(ix, d_in, nq, d_out, lease.stream());
@@ -1631,7 +1668,7 @@ int gcsa2_sample_batch(const gcsa2_index* ix, const uint64_t* idx, uint64_t nq, 
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
   Lease lease(ix);
-  HIP_TRY(lease.begin(2 * Lease::need(nq * 8) + Lease::need(nq)));
+  HIP_TRY(lease.begin(2 * Lease::need(nq * 8) + Lease::need(nq), true));
   u64* d_in = lease.dev<u64>(nq); u64* d_val = lease.dev<u64>(nq); u8* d_last = lease.dev<u8>(nq);
   HIP_TRY(lease.up(d_in, idx, nq * sizeof(u64)));
   hipLaunchKernelGGL(k_sample, dim3(grid_for(nq)), dim3(TPB), 0, lease.stream(), ix->img, d_in, nq, d_val, d_last);

@@ -262,7 +262,8 @@ __device__ __forceinline__ u64 wg_reserve(WgSlots& sh, unsigned long long* count
 // removeDuplicates (utils.h:350-357) sorts the values of a query.  Queries with one value need nothing,
 // queries with 2..SMALL_SEGMENT values are sorted in registers by one lane each (k_sort_small), queries with up to
 // MEDIUM_SEGMENT values by one wavefront each in LDS (k_sort_medium), queries with up to BIG_SEGMENT values by one workgroup
-// each in 64 KB of LDS (k_sort_big: the paper's 16-mers average 7129 values, paper.tex:403), anything longer goes to hipCUB's
+// each in 64 KB of LDS (k_sort_big: the paper's 16-mers average 7129 values, paper.tex:403); longer ones lose their duplicates
+// first (k_dedup_huge) and join those lists, and only what still has more than BIG_SEGMENT DISTINCT values goes to hipCUB's
 // segmented radix sort.  k_collect_multi lists the medium segments (from the end of the segment arrays, downwards), the
 // large ones (from the start; MEDIUM_SEGMENT + 1 .. BIG_SEGMENT values) and the huge ones (arrays of their own) and publishes
 // totals = {nodes, raw values, large segments, (unique values, written later), segments with >= 2 values, medium segments,
@@ -370,6 +371,95 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict_
     }
   }
   for(u32 i = tid; i < len; i += BIG_THREADS) { values[b + i] = buf[i]; }
+}
+
+// one workgroup per HUGE segment (more than BIG_SEGMENT values before deduplication): on a repeat-rich index such a segment
+// holds a few distinct values many times over (five raw values per distinct one in profiles/r03_locate.md), so the duplicates
+// are removed BEFORE sorting, through a hash set in 128 KB of LDS.  A segment with at most BIG_SEGMENT distinct values leaves
+// as: its distinct values (unsorted) at the front, the rest of the segment filled with its largest value (duplicates that
+// k_mark_unique drops), and the front appended to the medium or large list for the LDS sorts that run next.  A segment with
+// more distinct values is left untouched and listed for the segmented radix sort (over_begin / over_end, counted in totals[7]).
+constexpr int HUGE_THREADS = 512;
+constexpr u32 HUGE_SLOTS = 2 * BIG_SEGMENT;          // 16384 x 8 bytes
+constexpr u64 HUGE_EMPTY = ~u64(0);
+
+__global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restrict__ huge_begin, const u64* __restrict__ huge_end,
+                                                            u64* __restrict__ values, u64 nq, u32 medium_limit,
+                                                            unsigned long long* __restrict__ totals,
+                                                            u64* __restrict__ seg_begin, u64* __restrict__ seg_end,
+                                                            u64* __restrict__ over_begin, u64* __restrict__ over_end)
+{
+  __shared__ unsigned long long table[HUGE_SLOTS];
+  __shared__ u32 distinct, has_ones, placed;
+  __shared__ unsigned long long largest;
+  const u32 tid = threadIdx.x;
+  const u64 b = huge_begin[blockIdx.x], e = huge_end[blockIdx.x], len = e - b;
+  for(u32 i = tid; i < HUGE_SLOTS; i += HUGE_THREADS) { table[i] = HUGE_EMPTY; }
+  if(tid == 0) { distinct = 0; has_ones = 0; placed = 0; largest = 0; }
+  __syncthreads();
+  bool overflow = false;
+  for(u64 base = 0; base < len; base += HUGE_THREADS)
+  {
+    const u64 i = base + tid;
+    if(i < len)
+    {
+      const u64 v = values[b + i];
+      if(v == HUGE_EMPTY) { has_ones = 1; }
+      else
+      {
+        u32 slot = u32((v * 0x9E3779B97F4A7C15ull) >> 50);          // 14 bits
+        while(true)
+        {
+          const unsigned long long prev = atomicCAS(&table[slot], HUGE_EMPTY, (unsigned long long)v);
+          if(prev == HUGE_EMPTY) { atomicAdd(&distinct, 1u); break; }
+          if(prev == v) { break; }
+          slot = (slot + 1) & (HUGE_SLOTS - 1);
+        }
+      }
+    }
+    __syncthreads();
+    // at most BIG_SEGMENT + HUGE_THREADS of the 2 x BIG_SEGMENT slots are ever taken: the probing always ends
+    if(distinct + has_ones > BIG_SEGMENT) { overflow = true; break; }          // uniform: read after the barrier
+    __syncthreads();
+  }
+  if(overflow)
+  {
+    if(tid == 0)
+    {
+      const u64 slot = atomicAdd(totals + 7, 1ull);
+      over_begin[slot] = b; over_end[slot] = e;
+    }
+    return;
+  }
+  unsigned long long mine = 0;
+  for(u32 i = tid; i < HUGE_SLOTS; i += HUGE_THREADS)
+  {
+    const unsigned long long v = table[i];
+    if(v != HUGE_EMPTY)
+    {
+      values[b + atomicAdd(&placed, 1u)] = v;
+      mine = (v > mine ? v : mine);
+    }
+  }
+  atomicMax(&largest, mine);
+  __syncthreads();
+  u32 count = distinct;
+  unsigned long long top = largest;
+  if(has_ones) { if(tid == 0) { values[b + count] = HUGE_EMPTY; } count++; top = HUGE_EMPTY; }
+  for(u64 i = count + tid; i < len; i += HUGE_THREADS) { values[b + i] = top; }
+  if(tid == 0 && count >= 2)
+  {
+    if(count <= medium_limit && medium_limit > SMALL_SEGMENT)
+    {
+      const u64 slot = atomicAdd(totals + 5, 1ull);
+      seg_begin[nq - 1 - slot] = b; seg_end[nq - 1 - slot] = b + count;
+    }
+    else
+    {
+      const u64 slot = atomicAdd(totals + 2, 1ull);
+      seg_begin[slot] = b; seg_end[slot] = b + count;
+    }
+  }
 }
 
 // one lane per query with 2..SMALL_SEGMENT values: bitonic network over registers, in place
@@ -559,7 +649,7 @@ __global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* _
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q >= nq) { return; }
-  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; totals[0] = totals[1] = totals[2] = totals[3] = totals[4] = totals[5] = totals[6] = 0; }
+  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; totals[0] = totals[1] = totals[2] = totals[3] = totals[4] = totals[5] = totals[6] = totals[7] = 0; }
   ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
   u64 nodes = 0, raw = 0;
   if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831

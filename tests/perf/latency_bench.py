@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2-bases", type=int, default=22)
+    ap.add_argument("--sizes", default="1,64,4096,262144,10000000", help="queries per call, comma separated")
     args = ap.parse_args()
     from workload import graphs, builder, patterns
     from gcsa2_amd.binding import open_index
@@ -27,7 +28,7 @@ def main():
     ix = builder.build(g, 256, keep_table=False)
     gpu, lcp = open_index(ix)
     rows = []
-    for nq in (1, 64, 4096, 262144, 10_000_000):
+    for nq in [int(x) for x in args.sizes.split(",")]:
         pats = patterns.walk_patterns(g, nq, 32, 0x6C5A0012)
         flat, off = patterns.as_batch(pats)
         gpu.find_batch(flat, off)                                   # warm-up (arena growth)

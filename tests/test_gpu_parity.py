@@ -970,15 +970,18 @@ def test_locate_splits_large_batches(case, engine, monkeypatch):
         tiny.close()
 
 
-def test_locate_segment_sizes(engine):
+@pytest.mark.parametrize("dedup_huge", [1, 0])
+def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
     """removeDuplicates at every segment size class: 1 value, 2..16 (registers, one lane), 17..1024 (one wavefront in
-    LDS), 1025..8192 (one workgroup in LDS), more (segmented radix sort), mixed in one batch and in both sort modes; ranges of
-    consecutive path nodes of a repetitive SNP graph (many duplicates per segment).  A second batch has no segment beyond
-    8192 values: the library sort is then not called at all."""
+    LDS), 1025..8192 (one workgroup in LDS), more (duplicates removed through an LDS hash set, then the LDS sorts; the
+    segmented radix sort when more than 8192 values are distinct -- the whole-index range here -- or, with GCSA2_DEDUP_HUGE=0,
+    always), mixed in one batch and in both sort modes; ranges of consecutive path nodes of a repetitive SNP graph (many
+    duplicates per segment).  A second batch has no segment beyond 8192 values: the library sort is then not called at all."""
     from oracle.oracle import OracleIndex
     from workload import builder
     g = graphs.snp_graph(30000, 0x4D1, 0x4D2, snp_period=5, node_len=16)
     ix = builder.build(g, 16, sample_period=16)
+    monkeypatch.setenv("GCSA2_DEDUP_HUGE", str(dedup_huge))
     gpu, lcp = engine.open_index(ix)
     cpu = OracleIndex(ix)
     rng = SplitMix64(0x4D3)
