@@ -1071,7 +1071,10 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, raw_counts, raw_off, int(nq + 1), stream));
   // segments with more than one raw value: the only ones removeDuplicates has to touch
   const u32 medium_limit = ix->tune.sort_medium_limit;
-  hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, huge_begin, huge_end, medium_limit);
+  // with the duplicate filter every segment beyond the medium class goes through it first (listed as huge), without it only
+  // the ones the workgroup sort cannot hold
+  const u32 big_limit = (ix->tune.dedup_huge && sort ? (medium_limit > SMALL_SEGMENT ? medium_limit : SMALL_SEGMENT) : BIG_SEGMENT);
+  hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, huge_begin, huge_end, medium_limit, big_limit);
   LAUNCH_CHECK("k_collect_multi");
   unsigned long long totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
@@ -1103,7 +1106,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   }
   else
   {
-    u64 *raw = nullptr, *sorted = nullptr, *flag_scan = nullptr; u32* flags = nullptr;
+    u64 *raw = nullptr, *sorted = nullptr; u32 *flags = nullptr, *flag_scan = nullptr;
     HIP_TRY(scratch.get(sorted, total_raw));
     HIP_TRY(scratch.get(flags, total_raw + 1)); HIP_TRY(scratch.get(flag_scan, total_raw + 1));
     launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, stream);
@@ -1116,8 +1119,10 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     if(huge > 0 && !ix->tune.dedup_huge) { over = huge; over_begin = huge_begin; over_end = huge_end; }
     else if(huge > 0)
     {
-      hipLaunchKernelGGL(k_dedup_huge, dim3(unsigned(huge)), dim3(HUGE_THREADS), 0, stream, huge_begin, huge_end, sorted, nq, medium_limit,
-                         d_totals, seg_begin, seg_end, over_begin, over_end);
+      hipLaunchKernelGGL((k_dedup_huge<BIG_SEGMENT, 0, BIG_SEGMENT / 2>), dim3(unsigned(huge)), dim3(HUGE_THREADS), 0, stream, huge_begin, huge_end, sorted, nq,
+                         medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end);
+      hipLaunchKernelGGL((k_dedup_huge<2 * BIG_SEGMENT, BIG_SEGMENT / 2, ~u32(0)>), dim3(unsigned(huge)), dim3(HUGE_THREADS), 0, stream, huge_begin, huge_end, sorted, nq,
+                         medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end);
       LAUNCH_CHECK("k_dedup_huge");
       HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
@@ -1151,9 +1156,9 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
       HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(over),
                                                          over_begin, over_end, 0, 64, stream));
     }
-    hipLaunchKernelGGL(k_mark_unique, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, raw_off, nq, total_raw, flags);
-    LAUNCH_CHECK("k_mark_unique");
-    HIP_TRY(hipMemsetAsync(flags + total_raw, 0, sizeof(u32), stream));
+    hipLaunchKernelGGL(k_mark_changes, dim3(grid_for(total_raw + 1)), dim3(TPB), 0, stream, sorted, total_raw, flags);
+    hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, flags);
+    LAUNCH_CHECK("k_mark_changes / k_mark_starts");
     size_t scan_bytes = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, flag_scan, int(total_raw + 1), stream));
     char* scan_tmp = nullptr;
@@ -1167,7 +1172,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     *total_out = total_unique;
     u64* out = values_for(total_unique);
     if(out == nullptr) { return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
-    hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, flags, flag_scan, total_raw, out);
+    hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, flag_scan, total_raw, out);
     LAUNCH_CHECK("k_compact");
     hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, flag_scan, nq, total_raw, total_unique, d_offsets);
     LAUNCH_CHECK("k_final_offsets");

@@ -79,17 +79,19 @@ __device__ __forceinline__ u32 pred4_get(const u64* pred4, u64 node)
   return u32(pred4[node >> 4] >> ((node & 15) * 4)) & 15;
 }
 
-// Query owning flattened node g: the last q with node_off[q] <= g.  Starts from the proportional
-// guess and gallops, so batches of similar-sized ranges cost O(1) probes instead of log2(nq).
-__device__ __forceinline__ u64 owner_of(const u64* __restrict__ node_off, u64 nq, u64 total_nodes, u64 g)
+// Query owning flattened node g: the last q with node_off[q] <= g, known to lie in [qa, qb]; ga / gb = the first flattened
+// node of the bracket and the one behind its last.  Starts from the proportional guess and gallops, so runs of similar-sized
+// ranges cost O(1) probes instead of log2 of their number.
+__device__ __forceinline__ u64 owner_between(const u64* __restrict__ node_off, u64 qa, u64 qb, u64 ga, u64 gb, u64 g)
 {
-  u64 q = u64(double(g) / double(total_nodes) * double(nq));
-  if(q >= nq) { q = nq - 1; }
+  if(qa >= qb) { return qa; }
+  u64 q = qa + u64(double(g - ga) / double(gb - ga) * double(qb - qa + 1));
+  if(q > qb) { q = qb; }
   u64 lo, hi;
   if(node_off[q] <= g)
   {
-    lo = q; hi = nq - 1;
-    for(u64 step = 1; lo + step < nq; step <<= 1)
+    lo = q; hi = qb;
+    for(u64 step = 1; lo + step <= qb; step <<= 1)
     {
       if(node_off[lo + step] > g) { hi = lo + step - 1; break; }
       lo += step;
@@ -97,8 +99,8 @@ __device__ __forceinline__ u64 owner_of(const u64* __restrict__ node_off, u64 nq
   }
   else
   {
-    hi = q - 1; lo = 0;                    // node_off[0] == 0 <= g
-    for(u64 step = 1; step <= hi; step <<= 1)
+    hi = q - 1; lo = qa;                    // node_off[qa] <= g
+    for(u64 step = 1; step <= hi - qa; step <<= 1)
     {
       if(node_off[hi - step] <= g) { lo = hi - step; break; }
       hi -= step;
@@ -112,11 +114,30 @@ __device__ __forceinline__ u64 owner_of(const u64* __restrict__ node_off, u64 nq
   return lo;
 }
 
-__device__ __forceinline__ void locate_item(const DevImage& img, const u64* __restrict__ ranges, u64 nq,
-                                            const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
-                                            u64 total_nodes, u64 g, u64& node, u64& dest)
+__device__ __forceinline__ u64 owner_of(const u64* __restrict__ node_off, u64 nq, u64 total_nodes, u64 g)
 {
-  u64 q = owner_of(node_off, nq, total_nodes, g);
+  return owner_between(node_off, 0, nq - 1, 0, total_nodes, g);
+}
+
+// The owners of a workgroup's consecutive flattened nodes lie between the owners of its first and its last one: two full
+// searches per workgroup, then every lane searches that bracket only (a single query when the ranges are wide: no probe at
+// all).  All threads of the workgroup must call it.
+struct OwnerBracket { u64 q[2]; };
+
+__device__ __forceinline__ u64 owner_in_workgroup(OwnerBracket& sh, const u64* __restrict__ node_off, u64 nq, u64 total_nodes,
+                                                  u64 g_first, u32 threads, u64 g, bool live)
+{
+  const u64 g_last = (g_first + threads <= total_nodes ? g_first + threads : total_nodes) - 1;      // g_first < total_nodes
+  if(threadIdx.x == 0) { sh.q[0] = owner_of(node_off, nq, total_nodes, g_first); }
+  if(threadIdx.x == 64) { sh.q[1] = owner_of(node_off, nq, total_nodes, g_last); }
+  __syncthreads();
+  return live ? owner_between(node_off, sh.q[0], sh.q[1], g_first, g_last + 1, g) : 0;
+}
+
+__device__ __forceinline__ void locate_item(const DevImage& img, const u64* __restrict__ ranges, u64 q,
+                                            const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
+                                            u64 g, u64& node, u64& dest)
+{
   u64 sp = ranges[2 * q];
   node = sp + (g - node_off[q]);
   dest = raw_off[q] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0);
@@ -172,10 +193,12 @@ __global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* 
   __shared__ ulonglong2 stage[TPB2 * 8];
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  __shared__ OwnerBracket bracket;
   u64 g = u64(blockIdx.x) * TPB2 + threadIdx.x;
   bool live = g < total_nodes;
   u64 node = 0, dest = 0, steps = 0;
-  if(live) { locate_item(img, ranges, nq, node_off, raw_off, total_nodes, g, node, dest); }
+  const u64 q = owner_in_workgroup(bracket, node_off, nq, total_nodes, u64(blockIdx.x) * TPB2, TPB2, g, live);
+  if(live) { locate_item(img, ranges, q, node_off, raw_off, g, node, dest); }
   walk_to_sample(img, node, steps, live, wave_stage, lane);
   if(live)
   {
@@ -221,10 +244,12 @@ __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __r
                                                     const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
                                                     u64 total_nodes, u64* __restrict__ values)
 {
+  __shared__ OwnerBracket bracket;
   u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
+  const u64 q = owner_in_workgroup(bracket, node_off, nq, total_nodes, u64(blockIdx.x) * TPB, TPB, g, g < total_nodes);
   if(g >= total_nodes) { return; }
   u64 node, dest;
-  locate_item(img, ranges, nq, node_off, raw_off, total_nodes, g, node, dest);
+  locate_item(img, ranges, q, node_off, raw_off, g, node, dest);
   u64 entry = img.locate_tab[node];
   if(entry & LOCATE_DIRECT) { values[dest] = entry & ~LOCATE_DIRECT; return; }
   u64 s = entry & ((u64(1) << LOCATE_INDEX_BITS) - 1), steps = entry >> LOCATE_INDEX_BITS;
@@ -275,7 +300,8 @@ constexpr u32 BIG_SEGMENT = 8192;
 __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
                                                        unsigned long long* __restrict__ totals,
                                                        u64* __restrict__ seg_begin, u64* __restrict__ seg_end,
-                                                       u64* __restrict__ huge_begin, u64* __restrict__ huge_end, u32 medium_limit)
+                                                       u64* __restrict__ huge_begin, u64* __restrict__ huge_end, u32 medium_limit,
+                                                       u32 big_limit)
 {
   __shared__ WgSlots slots;
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
@@ -283,9 +309,9 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
   if(q == 0) { totals[0] = node_off[nq]; totals[1] = raw_off[nq]; }
   u64 b = 0, e = 0;
   if(q < nq) { b = raw_off[q]; e = raw_off[q + 1]; }
-  const u64 multi = __ballot(e - b >= 2), large = __ballot(e - b > medium_limit && e - b <= BIG_SEGMENT);
+  const u64 multi = __ballot(e - b >= 2), large = __ballot(e - b > medium_limit && e - b <= big_limit);
   const u64 medium = __ballot(e - b > SMALL_SEGMENT && e - b <= medium_limit);
-  const u64 huge = __ballot(e - b > BIG_SEGMENT);
+  const u64 huge = __ballot(e - b > medium_limit && e - b > big_limit);
   wg_reserve(slots, totals + 4, u32(__popcll(multi)));           // (every wave of the workgroup: wg_reserve synchronises it)
   u64 slot = wg_reserve(slots, totals + 2, u32(__popcll(large)));
   if((large >> lane) & 1)
@@ -375,14 +401,18 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict_
 
 // one workgroup per HUGE segment (more than BIG_SEGMENT values before deduplication): on a repeat-rich index such a segment
 // holds a few distinct values many times over (five raw values per distinct one in profiles/r03_locate.md), so the duplicates
-// are removed BEFORE sorting, through a hash set in 128 KB of LDS.  A segment with at most BIG_SEGMENT distinct values leaves
+// are removed BEFORE sorting, through a hash set in LDS.  (With the filter on, k_collect_multi lists every segment beyond the
+// medium class here: a segment without duplicates pays one extra pass, a tenth of its sort.)  A segment with at most BIG_SEGMENT distinct values leaves
 // as: its distinct values (unsorted) at the front, the rest of the segment filled with its largest value (duplicates that
 // k_mark_unique drops), and the front appended to the medium or large list for the LDS sorts that run next.  A segment with
 // more distinct values is left untouched and listed for the segmented radix sort (over_begin / over_end, counted in totals[7]).
+// Two instantiations share the list, like k_sort_big: 8192 slots (64 KB, two workgroups per CU) take the segments of up to
+// 4096 values, which cannot overflow; 16384 slots (128 KB) the longer ones.  A workgroup whose segment belongs to the other
+// instantiation exits at once.
 constexpr int HUGE_THREADS = 512;
-constexpr u32 HUGE_SLOTS = 2 * BIG_SEGMENT;          // 16384 x 8 bytes
 constexpr u64 HUGE_EMPTY = ~u64(0);
 
+template<u32 HUGE_SLOTS, u32 ABOVE, u32 UPTO>
 __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restrict__ huge_begin, const u64* __restrict__ huge_end,
                                                             u64* __restrict__ values, u64 nq, u32 medium_limit,
                                                             unsigned long long* __restrict__ totals,
@@ -394,6 +424,8 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   __shared__ unsigned long long largest;
   const u32 tid = threadIdx.x;
   const u64 b = huge_begin[blockIdx.x], e = huge_end[blockIdx.x], len = e - b;
+  if(len <= ABOVE || len > UPTO) { return; }                // the other instantiation's segment (uniform per workgroup)
+  constexpr u32 MOST = HUGE_SLOTS / 2;                      // distinct values a segment may have here
   for(u32 i = tid; i < HUGE_SLOTS; i += HUGE_THREADS) { table[i] = HUGE_EMPTY; }
   if(tid == 0) { distinct = 0; has_ones = 0; placed = 0; largest = 0; }
   __syncthreads();
@@ -407,7 +439,7 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
       if(v == HUGE_EMPTY) { has_ones = 1; }
       else
       {
-        u32 slot = u32((v * 0x9E3779B97F4A7C15ull) >> 50);          // 14 bits
+        u32 slot = u32((v * 0x9E3779B97F4A7C15ull) >> 32) & (HUGE_SLOTS - 1);
         while(true)
         {
           const unsigned long long prev = atomicCAS(&table[slot], HUGE_EMPTY, (unsigned long long)v);
@@ -418,8 +450,8 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
       }
     }
     __syncthreads();
-    // at most BIG_SEGMENT + HUGE_THREADS of the 2 x BIG_SEGMENT slots are ever taken: the probing always ends
-    if(distinct + has_ones > BIG_SEGMENT) { overflow = true; break; }          // uniform: read after the barrier
+    // at most MOST + HUGE_THREADS of the 2 x MOST slots are ever taken: the probing always ends
+    if(distinct + has_ones > MOST) { overflow = true; break; }          // uniform: read after the barrier
     __syncthreads();
   }
   if(overflow)
@@ -694,36 +726,44 @@ __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __
   while(!bv_get(img.samples, s - 1));                        // lastSample, gcsa.h:208
 }
 
-// flag the first occurrence of every value inside its (sorted) segment
-__global__ __launch_bounds__(TPB) void k_mark_unique(const u64* __restrict__ sorted, const u64* __restrict__ raw_off,
-                                                     u64 nq, u64 total, u32* __restrict__ flags)
+// flag the first occurrence of every value inside its (sorted) segment: a value that differs from its predecessor
+// (k_mark_changes, one streaming pass) or the first value of a non-empty query (k_mark_starts, one lane per query, afterwards).
+// (Round 2 found the owner of every value by binary search over the offsets: 1.9 of the 9 ms of the repeat-rich batch.)
+__global__ __launch_bounds__(TPB) void k_mark_changes(const u64* __restrict__ sorted, u64 total, u32* __restrict__ flags)
+{
+  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(g > total) { return; }
+  flags[g] = (g < total && (g == 0 || sorted[g] != sorted[g - 1])) ? 1u : 0u;          // entry `total` = 0: the scan's total
+}
+
+__global__ __launch_bounds__(TPB) void k_mark_starts(const u64* __restrict__ raw_off, u64 nq, u32* __restrict__ flags)
+{
+  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  const u64 b = raw_off[q];
+  if(raw_off[q + 1] > b) { flags[b] = 1u; }
+}
+
+// flag_scan = exclusive prefix sums of the flags, total + 1 entries (fewer than 2^31 values per pass: locate_core)
+__global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted, const u32* __restrict__ flag_scan, u64 total,
+                                                 u64* __restrict__ out)
 {
   u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
   if(g >= total) { return; }
-  // segments of empty queries share their start with the next one; lo is the last of them,
-  // which is the only one that can contain g.
-  const u64 lo = owner_of(raw_off, nq, total, g);
-  flags[g] = (g == raw_off[lo] || sorted[g] != sorted[g - 1]) ? 1u : 0u;
+  const u32 at = flag_scan[g];
+  if(flag_scan[g + 1] != at) { out[at] = sorted[g]; }
 }
 
-__global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted, const u32* __restrict__ flags,
-                                                 const u64* __restrict__ flag_scan, u64 total, u64* __restrict__ out)
-{
-  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(g >= total) { return; }
-  if(flags[g]) { out[flag_scan[g]] = sorted[g]; }
-}
-
-__global__ void k_publish(const u64* __restrict__ src, unsigned long long* __restrict__ dst) { *dst = *src; }
+__global__ void k_publish(const u32* __restrict__ src, unsigned long long* __restrict__ dst) { *dst = *src; }
 
 // in place: offsets[] holds the raw (with duplicates) offsets on entry, the final ones on return
-__global__ __launch_bounds__(TPB) void k_final_offsets(const u64* __restrict__ flag_scan, u64 nq, u64 total, u64 total_unique,
+__global__ __launch_bounds__(TPB) void k_final_offsets(const u32* __restrict__ flag_scan, u64 nq, u64 total, u64 total_unique,
                                                        u64* offsets)
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q > nq) { return; }
   u64 r = (q < nq ? offsets[q] : total);
-  offsets[q] = (r < total ? flag_scan[r] : total_unique);
+  offsets[q] = (r < total ? u64(flag_scan[r]) : total_unique);
 }
 
 
