@@ -83,8 +83,10 @@ struct gcsa2_index
   u64 order = 0;
   // Host pipeline of the large host-pointer batches (gcsa2_find_batch): PIPE_LANES host threads, each with two pinned + device
   // staging sets and a stream of its own, made at the first large batch and kept (one pipelined call at a time per handle).
-  struct PipeSet { char* h = nullptr; char* d = nullptr; hipEvent_t done = nullptr; bool busy = false; u64 first = 0, count = 0; };
-  struct PipeLane { hipStream_t stream = nullptr; PipeSet set[2]; };
+  struct PipeSet { char* h = nullptr; char* d = nullptr; hipEvent_t computed = nullptr, done = nullptr; bool busy = false; u64 first = 0, count = 0; };
+  // uploads + kernel on `stream`, downloads on `down`: a stream that alternates copy directions gets two thirds of the link
+  // (tests/perf/pcie_rate.hip: 34 + 34 GB/s mixed against 54 + 22 GB/s with one direction per stream)
+  struct PipeLane { hipStream_t stream = nullptr, down = nullptr; PipeSet set[2]; };
   mutable std::mutex pipe_lock;
   mutable std::vector<PipeLane> pipe;
   // tuning knobs, read from the environment ONCE, when the index is created (A/B measurements; results never depend on them)
@@ -95,6 +97,8 @@ struct gcsa2_index
     u64 ms_grid = 0;                   // GCSA2_MS_GRID: ... most workgroups launched (0: what the device holds at once)
     u32 sort_medium_limit = 0;         // GCSA2_SORT_MEDIUM=0 sends the 17..1024-value locate segments to the segmented radix sort
     u64 locate_split = (u64(1) << 31) - 1;   // GCSA2_LOCATE_SPLIT: most values (before deduplication) one pass of the locate pipeline handles
+    u32 pipe_lanes = 12;               // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
+    bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
     bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the segmented radix sort
     bool zero_copy = true;             // GCSA2_ZERO_COPY=0: small host-pointer calls copy through the arenas like large ones
   } tune;
@@ -480,6 +484,8 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.locate_split = u64(knob("GCSA2_LOCATE_SPLIT", (long(1) << 31) - 1, 2, (long(1) << 31) - 1));
     ix->tune.zero_copy = (knob("GCSA2_ZERO_COPY", 1, 0, 1) != 0);
     ix->tune.dedup_huge = (knob("GCSA2_DEDUP_HUGE", 1, 0, 1) != 0);
+    ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 12, 1, 16));
+    ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);
   }
   std::memset(&ix->img, 0, sizeof(DevImage));
   DevImage& img = ix->img;
@@ -848,8 +854,10 @@ void gcsa2_index_destroy(gcsa2_index* ix)
       if(set.h) { (void)hipHostFree(set.h); }
       if(set.d) { (void)hipFree(set.d); }
       if(set.done) { (void)hipEventDestroy(set.done); }
+      if(set.computed) { (void)hipEventDestroy(set.computed); }
     }
     if(lane.stream) { (void)hipStreamDestroy(lane.stream); }
+    if(lane.down) { (void)hipStreamDestroy(lane.down); }
   }
   for(Staging* st : ix->staging_pool)
   {
@@ -1351,26 +1359,29 @@ namespace {
 // H2D + k_find2 + D2H on the lane's own stream, and while that runs prepare the next chunk in the lane's other staging set;
 // a set's results are copied to the caller's array when its event has fired.  Both PCIe directions, the kernel and the host
 // copies overlap; what bounds the batch is the host's memcpy rate (56 bytes per 32-mer query through pinned memory).
-constexpr unsigned PIPE_LANES = 12;
+// (lanes: tune.pipe_lanes, GCSA2_PIPE_LANES, 1..16, default 12)
 constexpr u64 PIPE_CHUNK_QUERIES = u64(1) << 17, PIPE_CHUNK_BYTES = u64(8) << 20;     // per chunk: at most this many patterns and pattern bytes
 constexpr u64 PIPE_MIN_QUERIES = u64(1) << 19;                                       // smaller batches take the single-copy path
 constexpr int PIPE_PATTERN_TOO_LONG = 1;                                             // internal: not a gcsa2_status
 
-inline u64 pipe_set_bytes() { return (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8 + PIPE_CHUNK_QUERIES * 16; }
+inline u64 pipe_set_bytes() { return (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8 + PIPE_CHUNK_QUERIES * 16; }      // patterns (+ 32 bytes of phase, + slack) | offsets | ranges
 
 int pipe_prepare(const gcsa2_index* ix)
 {
   if(!ix->pipe.empty()) { return GCSA2_OK; }
+  const unsigned PIPE_LANES = ix->tune.pipe_lanes;
   std::vector<gcsa2_index::PipeLane> lanes(PIPE_LANES);
   hipError_t e = hipSuccess;
   for(gcsa2_index::PipeLane& lane : lanes)
   {
     if(e == hipSuccess) { e = hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking); }
+    if(e == hipSuccess) { e = hipStreamCreateWithFlags(&lane.down, hipStreamNonBlocking); }
     for(gcsa2_index::PipeSet& set : lane.set)
     {
       if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&set.h), pipe_set_bytes(), hipHostMallocDefault); }
       if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&set.d), pipe_set_bytes()); }
       if(e == hipSuccess) { e = hipEventCreateWithFlags(&set.done, hipEventDisableTiming); }
+      if(e == hipSuccess) { e = hipEventCreateWithFlags(&set.computed, hipEventDisableTiming); }
     }
   }
   if(e != hipSuccess)
@@ -1380,8 +1391,10 @@ int pipe_prepare(const gcsa2_index* ix)
       for(gcsa2_index::PipeSet& set : lane.set)
       {
         if(set.h) { (void)hipHostFree(set.h); } if(set.d) { (void)hipFree(set.d); } if(set.done) { (void)hipEventDestroy(set.done); }
+        if(set.computed) { (void)hipEventDestroy(set.computed); }
       }
       if(lane.stream) { (void)hipStreamDestroy(lane.stream); }
+      if(lane.down) { (void)hipStreamDestroy(lane.down); }
     }
     return fail(e == hipErrorOutOfMemory ? GCSA2_ERR_OUT_OF_MEMORY : GCSA2_ERR_HIP, std::string("host pipeline: ") + hipGetErrorString(e));
   }
@@ -1413,6 +1426,21 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
     cut.push_back(e);
   }
   const u64 chunks = cut.size() - 1;
+  // A caller's buffer that is already page-locked (hipHostMalloc / hipHostRegister: a pinned torch tensor, the facade's own
+  // arena) is handed to the copy engines where it lies; only pageable memory goes through the lanes' pinned staging sets.
+  auto page_locked = [](const void* first, u64 bytes) -> bool
+  {
+    if(bytes == 0) { return false; }
+    hipPointerAttribute_t a, b;
+    const bool yes = hipPointerGetAttributes(&a, first) == hipSuccess && a.type == hipMemoryTypeHost &&
+                     hipPointerGetAttributes(&b, static_cast<const char*>(first) + bytes - 1) == hipSuccess && b.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return yes;
+  };
+  const bool direct_pat = page_locked(patterns, offsets[nq] - offsets[0]), direct_off = page_locked(offsets, (nq + 1) * sizeof(u64)),
+             direct_out = page_locked(ranges, 2 * nq * sizeof(u64));
+  const unsigned PIPE_LANES = ix->tune.pipe_lanes;
+  const bool split = ix->tune.pipe_split;
   std::vector<int> status(PIPE_LANES, GCSA2_OK);
   std::vector<std::string> messages(PIPE_LANES);
   auto work = [&](unsigned t)
@@ -1425,8 +1453,11 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
       if(!set.busy) { return true; }
       hipError_t e = hipEventSynchronize(set.done);
       if(e != hipSuccess) { fail_lane("hipEventSynchronize", e); return false; }
-      const char* h_out = set.h + (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8;
-      std::memcpy(ranges + 2 * set.first, h_out, set.count * 16);
+      if(!direct_out)
+      {
+        const char* h_out = set.h + (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8;
+        std::memcpy(ranges + 2 * set.first, h_out, set.count * 16);
+      }
       set.busy = false;
       return true;
     };
@@ -1438,26 +1469,46 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
       const u64 b = cut[c], e = cut[c + 1], count = e - b, base = offsets[b], bytes = offsets[e] - base;
       char* h_pat = set.h; u64* h_off = reinterpret_cast<u64*>(set.h + (PIPE_CHUNK_BYTES + 64));
       char* h_out = reinterpret_cast<char*>(h_off + PIPE_CHUNK_QUERIES + 8);
+      // the chunk's pattern bytes land at the same phase within 16 bytes as in the caller's array (the kernel reads aligned
+      // words around a pattern's ends); with the caller's absolute offsets the kernel gets the pointer moved back by `base`
+      const u64 phase = 16 + (base & 15);
       u64 bad = 0;
-      for(u64 i = 0; i <= count; i++) { const u64 o = offsets[b + i]; h_off[i] = o - base; bad |= u64(i > 0 && o < offsets[b + i - 1]); }
+      if(direct_off) { for(u64 i = 1; i <= count; i++) { bad |= u64(offsets[b + i] < offsets[b + i - 1]); } }
+      else { for(u64 i = 0; i <= count; i++) { const u64 o = offsets[b + i]; h_off[i] = o - base; bad |= u64(i > 0 && o < offsets[b + i - 1]); } }
       if(bad != 0 || bytes > PIPE_CHUNK_BYTES) { status[t] = GCSA2_ERR_INVALID_ARGUMENT; messages[t] = "pattern offsets are not non-decreasing"; break; }
-      std::memcpy(h_pat, patterns + base, bytes);
       char* d_pat = set.d; u64* d_off = reinterpret_cast<u64*>(set.d + (PIPE_CHUNK_BYTES + 64));
       u64* d_out = d_off + PIPE_CHUNK_QUERIES + 8;
-      hipError_t err = hipMemcpyAsync(d_pat, h_pat, (bytes + 7) / 8 * 8, hipMemcpyHostToDevice, lane.stream);
-      if(err == hipSuccess) { err = hipMemcpyAsync(d_off, h_off, (count + 1) * sizeof(u64), hipMemcpyHostToDevice, lane.stream); }
+      hipError_t err = hipSuccess;
+      if(direct_pat) { err = hipMemcpyAsync(d_pat + phase, patterns + base, bytes, hipMemcpyHostToDevice, lane.stream); }
+      else
+      {
+        std::memcpy(h_pat + phase, patterns + base, bytes);
+        err = hipMemcpyAsync(d_pat, h_pat, (phase + bytes + 7) / 8 * 8, hipMemcpyHostToDevice, lane.stream);
+      }
+      if(err == hipSuccess)
+      {
+        err = hipMemcpyAsync(d_off, direct_off ? offsets + b : h_off, (count + 1) * sizeof(u64), hipMemcpyHostToDevice, lane.stream);
+      }
       if(err != hipSuccess) { fail_lane("hipMemcpyAsync", err); break; }
-      int rc_find = gcsa2_find_device(ix, reinterpret_cast<const uint8_t*>(d_pat), d_off, count, d_out, lane.stream);
+      const uint8_t* d_first = reinterpret_cast<const uint8_t*>(d_pat + phase) - (direct_off ? base : 0);
+      int rc_find = gcsa2_find_device(ix, d_first, d_off, count, d_out, lane.stream);
       if(rc_find != GCSA2_OK) { status[t] = rc_find; messages[t] = g_error; break; }
-      err = hipMemcpyAsync(h_out, d_out, count * 16, hipMemcpyDeviceToHost, lane.stream);
-      if(err == hipSuccess) { err = hipEventRecord(set.done, lane.stream); }
+      hipStream_t back = lane.stream;
+      if(split)
+      {
+        back = lane.down;
+        err = hipEventRecord(set.computed, lane.stream);
+        if(err == hipSuccess) { err = hipStreamWaitEvent(lane.down, set.computed, 0); }
+      }
+      if(err == hipSuccess) { err = hipMemcpyAsync(direct_out ? reinterpret_cast<char*>(ranges + 2 * b) : h_out, d_out, count * 16, hipMemcpyDeviceToHost, back); }
+      if(err == hipSuccess) { err = hipEventRecord(set.done, back); }
       if(err != hipSuccess) { fail_lane("hipMemcpyAsync / hipEventRecord", err); break; }
       set.busy = true; set.first = b; set.count = count;
     }
     for(gcsa2_index::PipeSet& set : lane.set) { if(status[t] == GCSA2_OK) { (void)retire(set); } }
     if(status[t] != GCSA2_OK)           // nothing of this call may still be in flight when it returns
     {
-      (void)hipStreamSynchronize(lane.stream);
+      (void)hipStreamSynchronize(lane.stream); (void)hipStreamSynchronize(lane.down);
       for(gcsa2_index::PipeSet& set : lane.set) { set.busy = false; }
     }
   };

@@ -300,6 +300,57 @@ def test_match_stats_ragged_host_batch(engine):
     assert np.array_equal(gm, cm) and np.array_equal(gr, cr) and np.array_equal(gf, cf)
 
 
+def test_find_host_pipeline_pageable_and_page_locked(engine):
+    """gcsa2_find_batch of 2^19 or more patterns runs chunked over several streams (find_pipelined).  Ragged lengths (chunk
+    bases at every phase of the kernel's aligned word reads, empty patterns included), from pageable memory -- staged through
+    the lanes' pinned sets -- and from page-locked memory, which the copy engines read and write in place: same ranges as the
+    single-launch device path and as the oracle on a sample; each buffer may be page-locked independently."""
+    import torch
+    from oracle.oracle import OracleIndex
+    name, g, K = CASES[-1]
+    ix = build(g, K, sample_period=8, branching=4)
+    gpu, lcp = engine.open_index(ix)
+    cpu = OracleIndex(ix)
+    rng = np.random.default_rng(0x97)
+    nq = (1 << 19) + 4099
+    lengths = rng.integers(0, 37, size=nq)
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    data = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.choice(5, size=int(off[-1]), p=[0.245, 0.245, 0.245, 0.245, 0.02])].copy()
+    dev = torch.device("cuda", 0)
+    d_pat = torch.zeros(int(off[-1]) + 16, dtype=torch.uint8, device=dev)
+    d_pat[: int(off[-1])] = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    want = d_out.cpu().numpy().view(np.uint64)
+    sample = rng.choice(nq, size=3000, replace=False)
+    for q in sample:
+        assert tuple(int(x) for x in want[q]) == tuple(cpu.find(bytes(data[int(off[q]):int(off[q + 1])]))), q
+    assert np.array_equal(gpu.find_batch(data, off), want)                      # pageable
+    p_data = torch.empty(data.shape[0], dtype=torch.uint8).pin_memory()
+    p_off = torch.empty(nq + 1, dtype=torch.int64).pin_memory()
+    p_out = torch.empty((nq, 2), dtype=torch.int64).pin_memory()
+    p_data.numpy()[:] = data
+    p_off.numpy().view(np.uint64)[:] = off
+    pinned = (p_data.numpy(), p_off.numpy().view(np.uint64), p_out.numpy().view(np.uint64))
+    for mask in range(1, 8):                                                    # which of the three buffers are page-locked
+        a = pinned[0] if mask & 1 else data
+        b = pinned[1] if mask & 2 else off
+        c = pinned[2] if mask & 4 else np.zeros((nq, 2), dtype=np.uint64)
+        c[:] = 7
+        got = gpu.find_batch(a, b, out=c)
+        assert np.array_equal(got, want), mask
+    # a batch that does not start at the beginning of the page-locked arrays
+    skip = 1234
+    got = gpu.find_batch(pinned[0], pinned[1][skip:], out=pinned[2][skip:])
+    assert np.array_equal(got, want[skip:])
+    bad = pinned[1].copy()
+    bad[nq // 2] = bad[nq // 2 + 1] + 5
+    with pytest.raises(engine.Gcsa2Error):
+        gpu.find_batch(pinned[0], bad)
+
+
 def widen_alphabet(ix):
     """Same index over a 9-letter alphabet: two never-occurring comps are inserted after T, so
     N becomes comp 7 and # comp 8.  Exercises sigma != 7 (sigma > 8 disables the pred4 nibbles and
