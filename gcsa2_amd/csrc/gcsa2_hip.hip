@@ -126,7 +126,7 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
 inline unsigned grid_for(u64 n) { return unsigned((n + TPB - 1) / TPB); }
 
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
-                        u64 total_nodes, u64* values, hipStream_t stream);
+                        u64 total_nodes, u64* values, u64* owners, hipStream_t stream);
 
 // host-side staging of the device image --------------------------------------------------
 
@@ -371,18 +371,23 @@ struct Scratch
 }  // namespace
 
 namespace {
+// owners: scratch of total_nodes / TPB2 + 3 entries (k_block_owners)
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
-                        u64 total_nodes, u64* values, hipStream_t stream)
+                        u64 total_nodes, u64* values, u64* owners, hipStream_t stream)
 {
   if(ix->img.locate_tab != nullptr)
   {
-    hipLaunchKernelGGL(k_locate_tab, dim3(grid_for(total_nodes)), dim3(TPB), 0, stream,
-                       ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values);
+    const u64 blocks = grid_for(total_nodes);
+    hipLaunchKernelGGL(k_block_owners, dim3(grid_for(blocks + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, u32(TPB), blocks, owners);
+    hipLaunchKernelGGL(k_locate_tab, dim3(unsigned(blocks)), dim3(TPB), 0, stream,
+                       ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values, owners);
   }
   else if(ix->img.pred4 != nullptr)
   {
-    hipLaunchKernelGGL(k_locate_walk2, dim3(unsigned((total_nodes + TPB2 - 1) / TPB2)), dim3(TPB2), 0, stream,
-                       ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values);
+    const u64 blocks = (total_nodes + TPB2 - 1) / TPB2;
+    hipLaunchKernelGGL(k_block_owners, dim3(grid_for(blocks + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, u32(TPB2), blocks, owners);
+    hipLaunchKernelGGL(k_locate_walk2, dim3(unsigned(blocks)), dim3(TPB2), 0, stream,
+                       ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values, owners);
   }
   else
   {
@@ -1095,6 +1100,11 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate: one range alone has 2^31 or more values before deduplication");
   }
 
+  // the per-workgroup owners of the walk kernel (k_block_owners) fit into the count arrays, which the scans have consumed,
+  // unless the ranges are wide
+  u64* owners = node_counts;
+  if(total_nodes / TPB2 + 3 > 2 * (nq + 1)) { HIP_TRY(scratch.get(owners, total_nodes / TPB2 + 3)); }
+
   if(total_raw == 0)
   {
     HIP_TRY(hipMemsetAsync(d_offsets, 0, (nq + 1) * sizeof(u64), stream));
@@ -1107,7 +1117,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     // value per query that output is already sorted and distinct.
     u64* out = values_for(total_raw);
     if(out == nullptr) { *total_out = total_raw; return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
-    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, out, stream);
+    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, out, owners, stream);
     LAUNCH_CHECK("k_locate_walk");
     HIP_TRY(hipStreamSynchronize(stream));
     *total_out = total_raw;
@@ -1117,7 +1127,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     u64 *raw = nullptr, *sorted = nullptr; u32 *flags = nullptr, *flag_scan = nullptr;
     HIP_TRY(scratch.get(sorted, total_raw));
     HIP_TRY(scratch.get(flags, total_raw + 1)); HIP_TRY(scratch.get(flag_scan, total_raw + 1));
-    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, stream);
+    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, owners, stream);
     LAUNCH_CHECK("k_locate_walk");
 
     // removeDuplicates: queries with up to SMALL_SEGMENT values are sorted in registers, up to MEDIUM_SEGMENT by a wavefront
@@ -1127,9 +1137,9 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     if(huge > 0 && !ix->tune.dedup_huge) { over = huge; over_begin = huge_begin; over_end = huge_end; }
     else if(huge > 0)
     {
-      hipLaunchKernelGGL((k_dedup_huge<BIG_SEGMENT, 0, BIG_SEGMENT / 2>), dim3(unsigned(huge)), dim3(HUGE_THREADS), 0, stream, huge_begin, huge_end, sorted, nq,
+      hipLaunchKernelGGL((k_dedup_huge<BIG_SEGMENT, 0, BIG_SEGMENT / 2, 512>), dim3(unsigned(huge)), dim3(512), 0, stream, huge_begin, huge_end, sorted, nq,
                          medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end);
-      hipLaunchKernelGGL((k_dedup_huge<2 * BIG_SEGMENT, BIG_SEGMENT / 2, ~u32(0)>), dim3(unsigned(huge)), dim3(HUGE_THREADS), 0, stream, huge_begin, huge_end, sorted, nq,
+      hipLaunchKernelGGL((k_dedup_huge<2 * BIG_SEGMENT, BIG_SEGMENT / 2, ~u32(0), 1024>), dim3(unsigned(huge)), dim3(1024), 0, stream, huge_begin, huge_end, sorted, nq,
                          medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end);
       LAUNCH_CHECK("k_dedup_huge");
       HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));

@@ -119,19 +119,25 @@ __device__ __forceinline__ u64 owner_of(const u64* __restrict__ node_off, u64 nq
   return owner_between(node_off, 0, nq - 1, 0, total_nodes, g);
 }
 
-// The owners of a workgroup's consecutive flattened nodes lie between the owners of its first and its last one: two full
-// searches per workgroup, then every lane searches that bracket only (a single query when the ranges are wide: no probe at
-// all).  All threads of the workgroup must call it.
-struct OwnerBracket { u64 q[2]; };
+// The owners of a workgroup's consecutive flattened nodes lie between the owner of its first node and the owner of the next
+// workgroup's first node: k_block_owners finds those once, one lane per workgroup of the walk kernel (entry `blocks` = the
+// owner of the last node), and every lane of the walk kernel searches its bracket only -- a single query when the ranges are
+// wide: no probe at all.  (Two full searches by two lanes of every workgroup, the others waiting at a barrier, were most of
+// k_locate_tab on the repeat-rich batch.)
+__global__ __launch_bounds__(TPB) void k_block_owners(const u64* __restrict__ node_off, u64 nq, u64 total_nodes, u32 threads, u64 blocks,
+                                                      u64* __restrict__ owners)
+{
+  const u64 j = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(j > blocks) { return; }
+  const u64 g = (j * threads < total_nodes ? j * threads : total_nodes - 1);
+  owners[j] = owner_of(node_off, nq, total_nodes, g);
+}
 
-__device__ __forceinline__ u64 owner_in_workgroup(OwnerBracket& sh, const u64* __restrict__ node_off, u64 nq, u64 total_nodes,
+__device__ __forceinline__ u64 owner_in_workgroup(const u64* __restrict__ owners, const u64* __restrict__ node_off, u64 total_nodes,
                                                   u64 g_first, u32 threads, u64 g, bool live)
 {
-  const u64 g_last = (g_first + threads <= total_nodes ? g_first + threads : total_nodes) - 1;      // g_first < total_nodes
-  if(threadIdx.x == 0) { sh.q[0] = owner_of(node_off, nq, total_nodes, g_first); }
-  if(threadIdx.x == 64) { sh.q[1] = owner_of(node_off, nq, total_nodes, g_last); }
-  __syncthreads();
-  return live ? owner_between(node_off, sh.q[0], sh.q[1], g_first, g_last + 1, g) : 0;
+  const u64 g_end = (g_first + threads <= total_nodes ? g_first + threads : total_nodes);      // g_first < total_nodes
+  return live ? owner_between(node_off, owners[blockIdx.x], owners[blockIdx.x + 1], g_first, g_end, g) : 0;
 }
 
 __device__ __forceinline__ void locate_item(const DevImage& img, const u64* __restrict__ ranges, u64 q,
@@ -188,16 +194,15 @@ __device__ __forceinline__ u64 first_sample(const DevImage& img, u64 node)      
 // one lane per (query, path node): locateInternal (gcsa.cpp:880-896), wave-cooperative walk.
 __global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* __restrict__ ranges, u64 nq,
                                                       const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
-                                                      u64 total_nodes, u64* __restrict__ values)
+                                                      u64 total_nodes, u64* __restrict__ values, const u64* __restrict__ owners)
 {
   __shared__ ulonglong2 stage[TPB2 * 8];
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  __shared__ OwnerBracket bracket;
   u64 g = u64(blockIdx.x) * TPB2 + threadIdx.x;
   bool live = g < total_nodes;
   u64 node = 0, dest = 0, steps = 0;
-  const u64 q = owner_in_workgroup(bracket, node_off, nq, total_nodes, u64(blockIdx.x) * TPB2, TPB2, g, live);
+  const u64 q = owner_in_workgroup(owners, node_off, total_nodes, u64(blockIdx.x) * TPB2, TPB2, g, live);
   if(live) { locate_item(img, ranges, q, node_off, raw_off, g, node, dest); }
   walk_to_sample(img, node, steps, live, wave_stage, lane);
   if(live)
@@ -240,25 +245,57 @@ __global__ __launch_bounds__(TPB2) void k_build_locate_table(DevImage img, u64 f
   table[g] = entry;
 }
 
+// Where a path node's values go: raw_off[q] + the values of the query's earlier nodes.  Only the FIRST lane of a query's run
+// inside the workgroup asks the counters for that (SadaSparse::count: two ranks and two selects); the other lanes add the
+// workgroup-wide running sum of the value counts their table entries show.  (Every lane asking was half of this kernel.)
 __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __restrict__ ranges, u64 nq,
                                                     const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
-                                                    u64 total_nodes, u64* __restrict__ values)
+                                                    u64 total_nodes, u64* __restrict__ values, const u64* __restrict__ owners)
 {
-  __shared__ OwnerBracket bracket;
-  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
-  const u64 q = owner_in_workgroup(bracket, node_off, nq, total_nodes, u64(blockIdx.x) * TPB, TPB, g, g < total_nodes);
-  if(g >= total_nodes) { return; }
-  u64 node, dest;
-  locate_item(img, ranges, q, node_off, raw_off, g, node, dest);
-  u64 entry = img.locate_tab[node];
-  if(entry & LOCATE_DIRECT) { values[dest] = entry & ~LOCATE_DIRECT; return; }
-  u64 s = entry & ((u64(1) << LOCATE_INDEX_BITS) - 1), steps = entry >> LOCATE_INDEX_BITS;
-  do
+  __shared__ u64 s_query[TPB], s_base[TPB];
+  __shared__ u32 s_before[TPB], s_wave_sum[TPB / 64], s_wave_head[TPB / 64];
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u64 g = u64(blockIdx.x) * TPB + tid;
+  const bool live = g < total_nodes;
+  const u64 q = owner_in_workgroup(owners, node_off, total_nodes, u64(blockIdx.x) * TPB, TPB, g, live);
+  u64 sp = 0, node = 0, entry = LOCATE_DIRECT, s = 0, steps = 0;
+  u32 count = 0;
+  if(live)
   {
-    values[dest++] = packed_get(img.stored, img.sample_width, s) + steps;     // gcsa.cpp:893
-    s++;
+    sp = ranges[2 * q];
+    node = sp + (g - node_off[q]);
+    entry = img.locate_tab[node];
+    count = 1;
+    if(!(entry & LOCATE_DIRECT))
+    {
+      s = entry & ((u64(1) << LOCATE_INDEX_BITS) - 1); steps = entry >> LOCATE_INDEX_BITS;
+      u64 t = s;
+      while(!bv_get(img.samples, t)) { t++; count++; }           // lastSample, gcsa.h:208
+    }
   }
-  while(!bv_get(img.samples, s - 1));
+  s_query[tid] = q;
+  __syncthreads();
+  const bool head = live && (tid == 0 || s_query[tid - 1] != q);
+  // inclusive scans over the wave: values so far, and the latest run head (lane index + 1; 0 = none in this wave so far)
+  u32 sum = count, latest = (head ? tid + 1 : 0);
+#pragma unroll
+  for(u32 d = 1; d < 64; d <<= 1)
+  {
+    const u32 other_sum = __shfl_up(sum, d), other_head = __shfl_up(latest, d);
+    if(lane >= d) { sum += other_sum; latest = (other_head > latest ? other_head : latest); }
+  }
+  if(lane == 63) { s_wave_sum[wave] = sum; s_wave_head[wave] = latest; }
+  __syncthreads();
+  u32 before = sum - count;                                       // values of the workgroup's earlier lanes
+  for(u32 w = 0; w < wave; w++) { before += s_wave_sum[w]; if(latest == 0 && s_wave_head[wave - 1 - w] != 0) { latest = s_wave_head[wave - 1 - w]; } }
+  s_before[tid] = before;
+  if(head) { s_base[tid] = raw_off[q] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0); }
+  __syncthreads();
+  if(!live) { return; }
+  const u32 first = latest - 1;                                   // the head of this lane's run (lane 0 of the workgroup is one)
+  u64 dest = s_base[first] + (before - s_before[first]);
+  if(entry & LOCATE_DIRECT) { values[dest] = entry & ~LOCATE_DIRECT; return; }
+  for(u32 j = 0; j < count; j++) { values[dest + j] = packed_get(img.stored, img.sample_width, s + j) + steps; }     // gcsa.cpp:893
 }
 
 // Output slots for a whole workgroup with ONE atomic: every wave passes the number of slots it wants and
@@ -408,11 +445,13 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict_
 // more distinct values is left untouched and listed for the segmented radix sort (over_begin / over_end, counted in totals[7]).
 // Two instantiations share the list, like k_sort_big: 8192 slots (64 KB, two workgroups per CU) take the segments of up to
 // 4096 values, which cannot overflow; 16384 slots (128 KB) the longer ones.  A workgroup whose segment belongs to the other
-// instantiation exits at once.
-constexpr int HUGE_THREADS = 512;
+// instantiation exits at once.  512 threads with 64 KB (two workgroups per CU), 1024 with 128 KB (one).
 constexpr u64 HUGE_EMPTY = ~u64(0);
 
-template<u32 HUGE_SLOTS, u32 ABOVE, u32 UPTO>
+// (Reading the locate table from this kernel instead of the walk's output -- the raw values of these queries never written --
+// was measured: 8.7 against 5.9 ms for the repeat-rich batch.  One or two workgroups per CU do not hide the latency of the
+// table gathers; the walk kernel with a lane per path node does.)
+template<u32 HUGE_SLOTS, u32 ABOVE, u32 UPTO, int HUGE_THREADS>
 __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restrict__ huge_begin, const u64* __restrict__ huge_end,
                                                             u64* __restrict__ values, u64 nq, u32 medium_limit,
                                                             unsigned long long* __restrict__ totals,
@@ -426,34 +465,45 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   const u64 b = huge_begin[blockIdx.x], e = huge_end[blockIdx.x], len = e - b;
   if(len <= ABOVE || len > UPTO) { return; }                // the other instantiation's segment (uniform per workgroup)
   constexpr u32 MOST = HUGE_SLOTS / 2;                      // distinct values a segment may have here
+  constexpr u32 STOP = HUGE_SLOTS - HUGE_THREADS - 1;       // no insertion beyond this many: a slot stays free, the probing always ends
   for(u32 i = tid; i < HUGE_SLOTS; i += HUGE_THREADS) { table[i] = HUGE_EMPTY; }
   if(tid == 0) { distinct = 0; has_ones = 0; placed = 0; largest = 0; }
   __syncthreads();
-  bool overflow = false;
-  for(u64 base = 0; base < len; base += HUGE_THREADS)
+  auto insert = [&](u64 v)
   {
-    const u64 i = base + tid;
-    if(i < len)
+    if(v == HUGE_EMPTY) { has_ones = 1; return; }
+    if(*reinterpret_cast<volatile u32*>(&distinct) >= STOP) { return; }        // the segment has overflowed (STOP > MOST)
+    u32 slot = u32((v * 0x9E3779B97F4A7C15ull) >> 32) & (HUGE_SLOTS - 1);
+    while(true)
     {
-      const u64 v = values[b + i];
-      if(v == HUGE_EMPTY) { has_ones = 1; }
-      else
-      {
-        u32 slot = u32((v * 0x9E3779B97F4A7C15ull) >> 32) & (HUGE_SLOTS - 1);
-        while(true)
-        {
-          const unsigned long long prev = atomicCAS(&table[slot], HUGE_EMPTY, (unsigned long long)v);
-          if(prev == HUGE_EMPTY) { atomicAdd(&distinct, 1u); break; }
-          if(prev == v) { break; }
-          slot = (slot + 1) & (HUGE_SLOTS - 1);
-        }
-      }
+      const unsigned long long prev = atomicCAS(&table[slot], HUGE_EMPTY, (unsigned long long)v);
+      if(prev == HUGE_EMPTY) { atomicAdd(&distinct, 1u); break; }
+      if(prev == v) { break; }
+      slot = (slot + 1) & (HUGE_SLOTS - 1);
     }
-    __syncthreads();
-    // at most MOST + HUGE_THREADS of the 2 x MOST slots are ever taken: the probing always ends
-    if(distinct + has_ones > MOST) { overflow = true; break; }          // uniform: read after the barrier
-    __syncthreads();
+  };
+  const u64 items = len;
+  // no barrier inside the loop: insert() stops by itself before the table fills, and whether the segment overflowed is
+  // only asked at the end; four independent loads per lane are in flight before the first insertion
+  constexpr u32 AHEAD = 4;
+  for(u64 base = tid; base < items; base += AHEAD * HUGE_THREADS)
+  {
+    u64 got[AHEAD];
+#pragma unroll
+    for(u32 j = 0; j < AHEAD; j++)
+    {
+      const u64 i = base + u64(j) * HUGE_THREADS;
+      got[j] = 0;
+      if(i < items) { got[j] = values[b + i]; }
+    }
+#pragma unroll
+    for(u32 j = 0; j < AHEAD; j++)
+    {
+      if(base + u64(j) * HUGE_THREADS < items) { insert(got[j]); }
+    }
   }
+  __syncthreads();
+  const bool overflow = (distinct + has_ones > MOST);          // uniform: read after the barrier
   if(overflow)
   {
     if(tid == 0)
