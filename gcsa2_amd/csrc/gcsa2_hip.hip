@@ -1124,9 +1124,10 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   }
   else
   {
-    u64 *raw = nullptr, *sorted = nullptr; u32 *flags = nullptr, *flag_scan = nullptr;
+    u64 *raw = nullptr, *sorted = nullptr, *words = nullptr; u32 *word_counts = nullptr, *word_before = nullptr;
+    const u64 nwords = total_raw / 64 + 1;
     HIP_TRY(scratch.get(sorted, total_raw));
-    HIP_TRY(scratch.get(flags, total_raw + 1)); HIP_TRY(scratch.get(flag_scan, total_raw + 1));
+    HIP_TRY(scratch.get(words, nwords)); HIP_TRY(scratch.get(word_counts, nwords + 1)); HIP_TRY(scratch.get(word_before, nwords + 1));
     launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, owners, stream);
     LAUNCH_CHECK("k_locate_walk");
 
@@ -1174,25 +1175,26 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
       HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(over),
                                                          over_begin, over_end, 0, 64, stream));
     }
-    hipLaunchKernelGGL(k_mark_changes, dim3(grid_for(total_raw + 1)), dim3(TPB), 0, stream, sorted, total_raw, flags);
-    hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, flags);
-    LAUNCH_CHECK("k_mark_changes / k_mark_starts");
+    hipLaunchKernelGGL(k_mark_changes, dim3(grid_for(nwords * 64)), dim3(TPB), 0, stream, sorted, total_raw, words);
+    hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, words);
+    hipLaunchKernelGGL(k_word_counts, dim3(grid_for(nwords + 1)), dim3(TPB), 0, stream, words, nwords, word_counts);
+    LAUNCH_CHECK("k_mark_changes / k_mark_starts / k_word_counts");
     size_t scan_bytes = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, flag_scan, int(total_raw + 1), stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, word_counts, word_before, int(nwords + 1), stream));
     char* scan_tmp = nullptr;
     HIP_TRY(scratch.get(scan_tmp, scan_bytes));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flags, flag_scan, int(total_raw + 1), stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, word_counts, word_before, int(nwords + 1), stream));
     u64 total_unique = 0;
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, flag_scan + total_raw, d_totals + 3);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, word_before + nwords, d_totals + 3);
     LAUNCH_CHECK("k_publish");
     HIP_TRY(hipMemcpyAsync(&total_unique, d_totals + 3, sizeof(u64), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     *total_out = total_unique;
     u64* out = values_for(total_unique);
     if(out == nullptr) { return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
-    hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, flag_scan, total_raw, out);
+    hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, words, word_before, total_raw, out);
     LAUNCH_CHECK("k_compact");
-    hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, flag_scan, nq, total_raw, total_unique, d_offsets);
+    hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, words, word_before, nq, total_raw, total_unique, d_offsets);
     LAUNCH_CHECK("k_final_offsets");
     HIP_TRY(hipStreamSynchronize(stream));
   }

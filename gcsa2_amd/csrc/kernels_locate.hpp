@@ -246,16 +246,15 @@ __global__ __launch_bounds__(TPB2) void k_build_locate_table(DevImage img, u64 f
 }
 
 // Where a path node's values go: raw_off[q] + the values of the query's earlier nodes.  Only the FIRST lane of a query's run
-// inside the workgroup asks the counters for that (SadaSparse::count: two ranks and two selects); the other lanes add the
-// workgroup-wide running sum of the value counts their table entries show.  (Every lane asking was half of this kernel.)
+// inside the WAVEFRONT asks the counters for that (SadaSparse::count: two ranks and two selects); the other lanes add the
+// wave's running sum of the value counts their table entries show.  No barrier, no LDS: the waves of a workgroup share
+// nothing but the owner bracket.
 __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __restrict__ ranges, u64 nq,
                                                     const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
                                                     u64 total_nodes, u64* __restrict__ values, const u64* __restrict__ owners)
 {
-  __shared__ u64 s_query[TPB], s_base[TPB];
-  __shared__ u32 s_before[TPB], s_wave_sum[TPB / 64], s_wave_head[TPB / 64];
-  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const u64 g = u64(blockIdx.x) * TPB + tid;
+  const u32 lane = threadIdx.x & 63;
+  const u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
   const bool live = g < total_nodes;
   const u64 q = owner_in_workgroup(owners, node_off, total_nodes, u64(blockIdx.x) * TPB, TPB, g, live);
   u64 sp = 0, node = 0, entry = LOCATE_DIRECT, s = 0, steps = 0;
@@ -273,27 +272,24 @@ __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __r
       while(!bv_get(img.samples, t)) { t++; count++; }           // lastSample, gcsa.h:208
     }
   }
-  s_query[tid] = q;
-  __syncthreads();
-  const bool head = live && (tid == 0 || s_query[tid - 1] != q);
-  // inclusive scans over the wave: values so far, and the latest run head (lane index + 1; 0 = none in this wave so far)
-  u32 sum = count, latest = (head ? tid + 1 : 0);
+  const u64 q_left = __shfl_up(q, 1);
+  const bool head = live && (lane == 0 || q_left != q);           // (live lanes are a prefix of the wave)
+  u64 base = 0;
+  if(head) { base = raw_off[q] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0); }
+  // inclusive scans over the wave: values so far, and the latest run head (lane index + 1)
+  u32 sum = count, latest = (head ? lane + 1 : 0);
 #pragma unroll
   for(u32 d = 1; d < 64; d <<= 1)
   {
     const u32 other_sum = __shfl_up(sum, d), other_head = __shfl_up(latest, d);
     if(lane >= d) { sum += other_sum; latest = (other_head > latest ? other_head : latest); }
   }
-  if(lane == 63) { s_wave_sum[wave] = sum; s_wave_head[wave] = latest; }
-  __syncthreads();
-  u32 before = sum - count;                                       // values of the workgroup's earlier lanes
-  for(u32 w = 0; w < wave; w++) { before += s_wave_sum[w]; if(latest == 0 && s_wave_head[wave - 1 - w] != 0) { latest = s_wave_head[wave - 1 - w]; } }
-  s_before[tid] = before;
-  if(head) { s_base[tid] = raw_off[q] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0); }
-  __syncthreads();
+  const u32 before = sum - count;                                 // values of the wave's earlier lanes
+  const u32 first = (latest > 0 ? latest - 1 : 0);                // the head of this lane's run (lane 0 is one)
+  const u64 run_base = __shfl(base, first);
+  const u32 run_before = __shfl(before, first);
   if(!live) { return; }
-  const u32 first = latest - 1;                                   // the head of this lane's run (lane 0 of the workgroup is one)
-  u64 dest = s_base[first] + (before - s_before[first]);
+  u64 dest = run_base + (before - run_before);
   if(entry & LOCATE_DIRECT) { values[dest] = entry & ~LOCATE_DIRECT; return; }
   for(u32 j = 0; j < count; j++) { values[dest + j] = packed_get(img.stored, img.sample_width, s + j) + steps; }     // gcsa.cpp:893
 }
@@ -776,44 +772,58 @@ __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __
   while(!bv_get(img.samples, s - 1));                        // lastSample, gcsa.h:208
 }
 
-// flag the first occurrence of every value inside its (sorted) segment: a value that differs from its predecessor
-// (k_mark_changes, one streaming pass) or the first value of a non-empty query (k_mark_starts, one lane per query, afterwards).
-// (Round 2 found the owner of every value by binary search over the offsets: 1.9 of the 9 ms of the repeat-rich batch.)
-__global__ __launch_bounds__(TPB) void k_mark_changes(const u64* __restrict__ sorted, u64 total, u32* __restrict__ flags)
+// First occurrences of every value inside its (sorted) segment -- a value that differs from its predecessor (k_mark_changes, one
+// streaming pass) or the first value of a non-empty query (k_mark_starts, one lane per query, afterwards) -- as a BIT MAP, one
+// 64-bit word per 64 values (a wavefront's ballot), and their exclusive prefix sums per WORD (k_word_counts + a scan over
+// total / 64 counts).  The place of a kept value is its word's prefix + the ones below it in the word.  (Round 2 found the
+// owner of every value by binary search over the offsets; the first half of round 3 kept 32-bit flags and their scan per
+// VALUE: 1.3 GB of traffic that is now 30 MB.)  words: total / 64 + 1 (bit `total` exists and is 0); word_before: one more.
+__global__ __launch_bounds__(TPB) void k_mark_changes(const u64* __restrict__ sorted, u64 total, u64* __restrict__ words)
 {
-  u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(g > total) { return; }
-  flags[g] = (g < total && (g == 0 || sorted[g] != sorted[g - 1])) ? 1u : 0u;          // entry `total` = 0: the scan's total
+  const u64 g = u64(blockIdx.x) * TPB + threadIdx.x;            // the grid covers whole words up to bit `total`
+  const bool first = (g < total && (g == 0 || sorted[g] != sorted[g - 1]));
+  const u64 mask = __ballot(first);
+  if((threadIdx.x & 63) == 0 && g <= total) { words[g >> 6] = mask; }
 }
 
-__global__ __launch_bounds__(TPB) void k_mark_starts(const u64* __restrict__ raw_off, u64 nq, u32* __restrict__ flags)
+__global__ __launch_bounds__(TPB) void k_mark_starts(const u64* __restrict__ raw_off, u64 nq, u64* __restrict__ words)
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q >= nq) { return; }
   const u64 b = raw_off[q];
-  if(raw_off[q + 1] > b) { flags[b] = 1u; }
+  if(raw_off[q + 1] > b) { atomicOr(reinterpret_cast<unsigned long long*>(words + (b >> 6)), 1ull << (b & 63)); }
 }
 
-// flag_scan = exclusive prefix sums of the flags, total + 1 entries (fewer than 2^31 values per pass: locate_core)
-__global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted, const u32* __restrict__ flag_scan, u64 total,
-                                                 u64* __restrict__ out)
+__global__ __launch_bounds__(TPB) void k_word_counts(const u64* __restrict__ words, u64 nwords, u32* __restrict__ counts)
+{
+  const u64 w = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(w <= nwords) { counts[w] = (w < nwords ? u32(__popcll(words[w])) : 0u); }          // entry nwords = 0: the scan's total
+}
+
+__device__ __forceinline__ u64 kept_before(const u64* __restrict__ words, const u32* __restrict__ word_before, u64 g)
+{
+  return u64(word_before[g >> 6]) + u64(__popcll(words[g >> 6] & ((u64(1) << (g & 63)) - 1)));
+}
+
+__global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted, const u64* __restrict__ words,
+                                                 const u32* __restrict__ word_before, u64 total, u64* __restrict__ out)
 {
   u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
   if(g >= total) { return; }
-  const u32 at = flag_scan[g];
-  if(flag_scan[g + 1] != at) { out[at] = sorted[g]; }
+  const u64 word = words[g >> 6];
+  if((word >> (g & 63)) & 1) { out[u64(word_before[g >> 6]) + u64(__popcll(word & ((u64(1) << (g & 63)) - 1)))] = sorted[g]; }
 }
 
 __global__ void k_publish(const u32* __restrict__ src, unsigned long long* __restrict__ dst) { *dst = *src; }
 
 // in place: offsets[] holds the raw (with duplicates) offsets on entry, the final ones on return
-__global__ __launch_bounds__(TPB) void k_final_offsets(const u32* __restrict__ flag_scan, u64 nq, u64 total, u64 total_unique,
-                                                       u64* offsets)
+__global__ __launch_bounds__(TPB) void k_final_offsets(const u64* __restrict__ words, const u32* __restrict__ word_before, u64 nq, u64 total,
+                                                       u64 total_unique, u64* offsets)
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q > nq) { return; }
   u64 r = (q < nq ? offsets[q] : total);
-  offsets[q] = (r < total ? u64(flag_scan[r]) : total_unique);
+  offsets[q] = (r < total ? kept_before(words, word_before, r) : total_unique);
 }
 
 
