@@ -126,7 +126,7 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
 inline unsigned grid_for(u64 n) { return unsigned((n + TPB - 1) / TPB); }
 
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
-                        u64 total_nodes, u64* values, u64* owners, hipStream_t stream);
+                        u64 total_nodes, u64* values, u64* owners, hipStream_t stream, u64* extra_slots = nullptr);
 
 // host-side staging of the device image --------------------------------------------------
 
@@ -371,16 +371,25 @@ struct Scratch
 }  // namespace
 
 namespace {
-// owners: scratch of total_nodes / TPB2 + 3 entries (k_block_owners)
+// owners: scratch of total_nodes / TPB2 + 3 entries (k_block_owners).  extra_slots: nq zeroed counters, or nullptr when the
+// values must come out in path order (sort = false); only the table walk uses them.
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
-                        u64 total_nodes, u64* values, u64* owners, hipStream_t stream)
+                        u64 total_nodes, u64* values, u64* owners, hipStream_t stream, u64* extra_slots)
 {
   if(ix->img.locate_tab != nullptr)
   {
     const u64 blocks = grid_for(total_nodes);
     hipLaunchKernelGGL(k_block_owners, dim3(grid_for(blocks + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, u32(TPB), blocks, owners);
-    hipLaunchKernelGGL(k_locate_tab, dim3(unsigned(blocks)), dim3(TPB), 0, stream,
-                       ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values, owners);
+    if(extra_slots != nullptr)
+    {
+      hipLaunchKernelGGL(k_locate_tab<false>, dim3(unsigned(blocks)), dim3(TPB), 0, stream,
+                         ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values, owners, reinterpret_cast<unsigned long long*>(extra_slots));
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_locate_tab<true>, dim3(unsigned(blocks)), dim3(TPB), 0, stream,
+                         ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values, owners, nullptr);
+    }
   }
   else if(ix->img.pred4 != nullptr)
   {
@@ -1100,10 +1109,11 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate: one range alone has 2^31 or more values before deduplication");
   }
 
-  // the per-workgroup owners of the walk kernel (k_block_owners) fit into the count arrays, which the scans have consumed,
-  // unless the ranges are wide
-  u64* owners = node_counts;
-  if(total_nodes / TPB2 + 3 > 2 * (nq + 1)) { HIP_TRY(scratch.get(owners, total_nodes / TPB2 + 3)); }
+  // the per-workgroup owners of the walk kernel (k_block_owners) fit into one of the count arrays, which the scans have
+  // consumed, unless the ranges are wide; the other one serves as the per-query slot counters of the unordered table walk
+  u64* owners = raw_counts;
+  if(total_nodes / TPB2 + 3 > nq + 1) { HIP_TRY(scratch.get(owners, total_nodes / TPB2 + 3)); }
+  u64* extra_slots = node_counts;
 
   if(total_raw == 0)
   {
@@ -1128,7 +1138,8 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     const u64 nwords = total_raw / 64 + 1;
     HIP_TRY(scratch.get(sorted, total_raw));
     HIP_TRY(scratch.get(words, nwords)); HIP_TRY(scratch.get(word_counts, nwords + 1)); HIP_TRY(scratch.get(word_before, nwords + 1));
-    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, owners, stream);
+    HIP_TRY(hipMemsetAsync(extra_slots, 0, nq * sizeof(u64), stream));
+    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, owners, stream, extra_slots);
     LAUNCH_CHECK("k_locate_walk");
 
     // removeDuplicates: queries with up to SMALL_SEGMENT values are sorted in registers, up to MEDIUM_SEGMENT by a wavefront

@@ -249,9 +249,15 @@ __global__ __launch_bounds__(TPB2) void k_build_locate_table(DevImage img, u64 f
 // inside the WAVEFRONT asks the counters for that (SadaSparse::count: two ranks and two selects); the other lanes add the
 // wave's running sum of the value counts their table entries show.  No barrier, no LDS: the waves of a workgroup share
 // nothing but the owner bracket.
+// ORDERED = false (the values are sorted afterwards, so their order inside the query's segment is free): a node's first value
+// goes to raw_off[q] + its rank among the query's nodes, further values of a node to slots drawn from a per-query counter
+// behind those -- no question to the counters at all, whose two ranks and two selects were the longest part of the dependent
+// chain that bounds this kernel (25 memory instructions per wave, most of them theirs; 32 VGPRs, so occupancy is not the limit).
+template<bool ORDERED>
 __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __restrict__ ranges, u64 nq,
                                                     const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
-                                                    u64 total_nodes, u64* __restrict__ values, const u64* __restrict__ owners)
+                                                    u64 total_nodes, u64* __restrict__ values, const u64* __restrict__ owners,
+                                                    unsigned long long* __restrict__ extra_slots)
 {
   const u32 lane = threadIdx.x & 63;
   const u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
@@ -272,10 +278,28 @@ __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __r
       while(!bv_get(img.samples, t)) { t++; count++; }           // lastSample, gcsa.h:208
     }
   }
+  if constexpr(!ORDERED)
+  {
+    if(!live) { return; }
+    const u64 b = raw_off[q], first = node_off[q];
+    values[b + (g - first)] = (entry & LOCATE_DIRECT) ? (entry & ~LOCATE_DIRECT) : packed_get(img.stored, img.sample_width, s) + steps;
+    if(count > 1)
+    {
+      const u64 at = b + (node_off[q + 1] - first) + atomicAdd(extra_slots + q, (unsigned long long)(count - 1));
+      for(u32 j = 1; j < count; j++) { values[at + j - 1] = packed_get(img.stored, img.sample_width, s + j) + steps; }
+    }
+    return;
+  }
   const u64 q_left = __shfl_up(q, 1);
   const bool head = live && (lane == 0 || q_left != q);           // (live lanes are a prefix of the wave)
   u64 base = 0;
-  if(head) { base = raw_off[q] + (node - sp) + (node > sp ? sada_sparse_count(img, sp, node - 1) : 0); }
+  if(head)
+  {
+    // a query whose values are as many as its path nodes has no node with several values: nothing to ask the counters
+    const u64 b = raw_off[q];
+    const bool extras = (raw_off[q + 1] - b) != (node_off[q + 1] - node_off[q]);
+    base = b + (node - sp) + (node > sp && extras ? sada_sparse_count(img, sp, node - 1) : 0);
+  }
   // inclusive scans over the wave: values so far, and the latest run head (lane index + 1)
   u32 sum = count, latest = (head ? lane + 1 : 0);
 #pragma unroll
