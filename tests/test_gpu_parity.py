@@ -1095,3 +1095,29 @@ def test_index_from_device_resident_arrays(case, engine):
     assert np.array_equal(resident.count_batch(ranges), gpu.count_batch(ranges)), name
     assert np.array_equal(rlcp.parent_batch(ranges), lcp.parent_batch(ranges)), name
     resident.close()
+
+
+def test_small_calls_copy_and_zero_copy(case, engine, monkeypatch):
+    """Host-pointer calls that move less than 32 KB run zero-copy (their buffers are page-locked memory the kernel reads and
+    writes); GCSA2_ZERO_COPY=0 sends them through the device arena like larger calls.  Same answers either way, and for a
+    batch just above the limit."""
+    name, g, K, ix, gpu, lcp, cpu = case
+    monkeypatch.setenv("GCSA2_ZERO_COPY", "0")
+    copied, clcp = engine.open_index(ix, device=0)
+    pats = random_patterns(g, K, 0x2C0, 40)
+    cat, off = concat_patterns(pats)
+    want = gpu.find_batch(cat, off)
+    assert np.array_equal(copied.find_batch(cat, off), want), name
+    for p, r in zip(pats, want):
+        assert tuple(int(x) for x in r) == tuple(cpu.find(p)), (name, p)
+    ranges = np.array([r for r in all_ranges(ix, 0x2C1, 30) if r[0] <= r[1]], dtype=np.uint64)[:200]
+    comps = (np.arange(ranges.shape[0]) % int(ix.sigma)).astype(np.uint8)
+    assert np.array_equal(copied.lf_batch(ranges, comps), gpu.lf_batch(ranges, comps)), name
+    assert np.array_equal(copied.count_batch(ranges), gpu.count_batch(ranges)), name
+    assert np.array_equal(clcp.parent_batch(ranges), lcp.parent_batch(ranges)), name
+    for a, b in zip(copied.locate_batch(ranges), gpu.locate_batch(ranges)):
+        assert np.array_equal(a, b), name
+    many = [pats[i % len(pats)] for i in range(3000)]                 # ~ 60 KB with offsets and ranges: beyond the zero-copy limit
+    cat, off = concat_patterns(many)
+    assert np.array_equal(gpu.find_batch(cat, off), np.concatenate([want] * 75)), name
+    copied.close()
