@@ -261,7 +261,9 @@ def setup_human(args, D, dev, local_rank, branching=False, total_queries=None):
     available = sorted(d for d in mseq_torch.TAPS if d <= degree)
     if degree not in available:
         raise SystemExit(f"--degree must be one of {sorted(mseq_torch.TAPS)}")
-    while len(available) > 1 and available[-1] > 24 and not host_memory_ok(local_world * 12 * (1 << available[-1])):
+    # (decided together: ranks that read /proc/meminfo at different moments must not end up with different indexes;
+    # the staging copy of rounds 1-2 is gone, what a rank holds on the host now is the plain arrays: ~5 bytes per path node)
+    while len(available) > 1 and available[-1] > 24 and not D.all_true(host_memory_ok(local_world * 5 * (1 << available[-1]))):
         available.pop()
     degree = available[-1]
     if degree != (args.degree or 32):
@@ -354,13 +356,15 @@ def setup_pangenome(args, D, dev, local_rank, total_queries=None):
     if degree not in dbg_torch.LFSR:
         raise SystemExit(f"--degree must be one of {sorted(dbg_torch.LFSR)}")
     kind = {"pangenome": "junction", "pangenome_plain": "plain", "pangenome_snp": "snp"}[args.workload if args.workload.startswith("pangenome") else "pangenome"]
-    # every rank stages its own replica on the host: ~5 bytes per path node for find() alone, ~9 with samples and LCP
+    # every rank holds the plain arrays of its own replica on the host (the image itself is built on the device): ~5 bytes
+    # per path node for find() alone, ~9 with samples and LCP
     # (config 5 runs sharded at N > 1, so every rank needs them)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", D.world))
+    # (both decisions are taken together: ranks that read /proc/meminfo at different moments must not disagree)
     full = (not args.no_secondary and kind != "snp" and args.secondary in ("all", "config5")
-            and (degree <= 20 or host_memory_ok(local_world * 9 * dbg_torch.text_length(degree))))
+            and (degree <= 20 or D.all_true(host_memory_ok(local_world * 9 * dbg_torch.text_length(degree)))))
     need = local_world * (9 if full else 5) * dbg_torch.text_length(degree) * (1.25 if kind == "snp" else 1.0)
-    if degree > 20 and not host_memory_ok(need):
+    if degree > 20 and not D.all_true(host_memory_ok(need)):
         log(f"warning: host memory too small for {local_world} replicas of the degree-{degree} index ({need / 1e9:.0f} GB); "
             f"falling back to the 2^32 - 1 node index of rounds 1-2")
         args.degree = 0
