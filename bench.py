@@ -526,13 +526,17 @@ def measure(args, D, dev, wl, steps, warmup):
     counts = [e - b for b, e in bounds]
     total = sum(counts)
     # wire format: (sp, len) u32 pairs when every path node / edge number is below 2^32 (sp <= max(n, e), len <= n),
-    # else the u64 pairs
-    pack32 = D.active and max(int(wl.ix.n), int(wl.ix.e)) < (1 << 32)
-    wire_bytes = 8 if pack32 else 16
-    wire = [torch.zeros((nq, 2), dtype=torch.int32, device=dev) for _ in outs] if pack32 else outs
+    # 40 bits each (10 bytes) below 2^40 -- the 5.7 G-node index --, else the u64 pairs
+    top = max(int(wl.ix.n), int(wl.ix.e))
+    wire_env = os.environ.get("GCSA2_BENCH_WIRE", "")          # tests: "40" / "64" force a wider format than the index needs
+    pack32 = D.active and top < (1 << 32) and wire_env == ""
+    pack40 = D.active and not pack32 and top < (1 << 40) and wire_env != "64"
+    packed = pack32 or pack40
+    wire_bytes = 8 if pack32 else (10 if pack40 else 16)
+    wire = [torch.zeros(nq * wire_bytes + 6, dtype=torch.uint8, device=dev) for _ in outs] if packed else outs
     root = D.active and D.rank == 0
-    recv = [torch.zeros(total * wire_bytes, dtype=torch.uint8, device=dev) for _ in outs] if root else [None] * nbuf
-    gathered = torch.zeros((total, 2), dtype=torch.int64, device=dev) if (root and pack32) else None
+    recv = [torch.zeros(total * wire_bytes + 6, dtype=torch.uint8, device=dev) for _ in outs] if root else [None] * nbuf
+    gathered = torch.zeros((total, 2), dtype=torch.int64, device=dev) if (root and packed) else None
     free_ev = [None] * nbuf                  # the gather of the buffer's previous contents has completed
 
     def step(k, record=None):
@@ -548,6 +552,8 @@ def measure(args, D, dev, wl, steps, warmup):
             return
         if pack32:
             binding.pack_ranges32_device(outs[b].data_ptr(), nq, wire[b].data_ptr(), stream.cuda_stream)
+        elif pack40:
+            binding.pack_ranges40_device(outs[b].data_ptr(), nq, wire[b].data_ptr(), stream.cuda_stream)
         ready = torch.cuda.Event()
         ready.record(stream)
         comm_stream.wait_event(ready)
@@ -558,7 +564,7 @@ def measure(args, D, dev, wl, steps, warmup):
             with torch.cuda.stream(comm_stream):
                 width = max(counts) * wire_bytes
                 mine = torch.zeros(width, dtype=torch.uint8, device=dev)
-                mine[: nq * wire_bytes] = wire[b].view(torch.uint8).reshape(-1)
+                mine[: nq * wire_bytes] = wire[b].view(torch.uint8).reshape(-1)[: nq * wire_bytes]
                 parts = [torch.zeros(width, dtype=torch.uint8, device=dev) for _ in counts] if root else None
                 D.dist.gather(mine, parts, dst=0)
                 if root:
@@ -568,12 +574,14 @@ def measure(args, D, dev, wl, steps, warmup):
                         at += c * wire_bytes
         else:                                # gloo control-flow check: through host memory
             comm_stream.synchronize()
-            parts = gather_via_host(D, wire[b].view(torch.uint8).reshape(-1).cpu(), counts, wire_bytes)
+            parts = gather_via_host(D, wire[b].view(torch.uint8).reshape(-1)[: nq * wire_bytes].cpu(), counts, wire_bytes)
             if root:
                 with torch.cuda.stream(comm_stream):
-                    recv[b].copy_(parts)
+                    recv[b][: total * wire_bytes].copy_(parts)
         if root and pack32:
             binding.unpack_ranges32_device(recv[b].data_ptr(), total, gathered.data_ptr(), comm_stream.cuda_stream)
+        elif root and pack40:
+            binding.unpack_ranges40_device(recv[b].data_ptr(), total, gathered.data_ptr(), comm_stream.cuda_stream)
         done = torch.cuda.Event()
         done.record(comm_stream)
         free_ev[b] = done
@@ -598,12 +606,12 @@ def measure(args, D, dev, wl, steps, warmup):
     last = (steps - 1) % nbuf if steps > 0 else 0
     d_out = outs[last]
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if steps > 0 else 0.0
-    result = dict(elapsed=elapsed, kernel_ms=kernel_ms, d_out=d_out, gathered=None, pack32=pack32,
+    result = dict(elapsed=elapsed, kernel_ms=kernel_ms, d_out=d_out, gathered=None, pack32=pack32, pack40=pack40,
                   gather=("gcsa2_comm_gather (library RCCL communicator)" if D.comm is not None else
                           ("torch.distributed.gather (fallback)" if D.active and D.backend == "nccl" else
                            ("host copies (gloo control-flow check)" if D.active else "none (one GPU)"))))
     if root and steps > 0:
-        result["gathered"] = gathered if pack32 else recv[last].view(torch.int64).view(total, 2)
+        result["gathered"] = gathered if packed else recv[last][: total * 16].view(torch.int64).view(total, 2)
         mine = result["gathered"][bounds[0][0]:bounds[0][1]]
         assert torch.equal(mine, d_out), "gathered shard differs from the computed ranges"
 
@@ -751,7 +759,7 @@ def find_config(wl, r, world):
             "second_fetch_fraction_of_steps": r["second_fetches"] / max(r["fetch_steps"], 1), "wide_seed_entries_hit": r["wide_seeds"],
             "blocks_per_query": r["blocks"] / wl.nq, "block_bytes": gpu.find_block_bytes(),
             "parallelism": f"replicated index, contiguous query shards x{world}, one gather of ranges per step: {r['gather']}"
-                           + (" as (sp, len) u32 pairs" if r["pack32"] else "")}
+                           + (" as (sp, len) u32 pairs" if r["pack32"] else (" as (sp, len) 40-bit pairs, 10 bytes" if r.get("pack40") else ""))}
 
 
 # ---- N = 1 secondaries ---------------------------------------------------------------------------------------

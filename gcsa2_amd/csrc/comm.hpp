@@ -89,6 +89,29 @@ __global__ __launch_bounds__(TPB) void k_unpack_ranges32(const uint2* __restrict
   reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(u64(r.x), u64(r.x) + u64(r.y) - 1);
 }
 
+// The same for indexes below 2^40 path nodes and edges (the 5.7 G-node index of BASELINE configs[3]): 10 bytes per range, five
+// u16 -- sp bits 0..31, length bits 0..31, then the two high bytes -- instead of 16.
+__global__ __launch_bounds__(TPB) void k_pack_ranges40(const u64* __restrict__ in, u64 nq, unsigned short* __restrict__ out)
+{
+  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  const ulonglong2 r = reinterpret_cast<const ulonglong2*>(in)[q];
+  const u64 sp = r.x, len = r.y + 1 - r.x;
+  unsigned short* o = out + 5 * q;
+  o[0] = (unsigned short)sp; o[1] = (unsigned short)(sp >> 16); o[2] = (unsigned short)len; o[3] = (unsigned short)(len >> 16);
+  o[4] = (unsigned short)(((sp >> 32) & 0xFF) | (((len >> 32) & 0xFF) << 8));
+}
+
+__global__ __launch_bounds__(TPB) void k_unpack_ranges40(const unsigned short* __restrict__ in, u64 nq, u64* __restrict__ out)
+{
+  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  const unsigned short* o = in + 5 * q;
+  const u64 sp = u64(o[0]) | (u64(o[1]) << 16) | (u64(o[4] & 0xFF) << 32);
+  const u64 len = u64(o[2]) | (u64(o[3]) << 16) | (u64(o[4] >> 8) << 32);
+  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, sp + len - 1);
+}
+
 // grouped send / recv gather: rank r contributes bytes[r] bytes; the root receives them back to back in rank order
 int gather_bytes(ncclComm_t comm, int rank, int world, const void* d_send, const u64* bytes, void* d_recv, int root, hipStream_t st)
 {
@@ -192,6 +215,22 @@ int gcsa2_unpack_ranges32_device(const uint32_t* d_packed, uint64_t nq, uint64_t
   if(nq == 0) { return GCSA2_OK; }
   hipLaunchKernelGGL(k_unpack_ranges32, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const uint2*>(d_packed), nq, d_ranges);
   LAUNCH_CHECK("k_unpack_ranges32");
+  return GCSA2_OK;
+}
+
+int gcsa2_pack_ranges40_device(const uint64_t* d_ranges, uint64_t nq, void* d_packed, void* stream)
+{
+  if(nq == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_pack_ranges40, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream), d_ranges, nq, static_cast<unsigned short*>(d_packed));
+  LAUNCH_CHECK("k_pack_ranges40");
+  return GCSA2_OK;
+}
+
+int gcsa2_unpack_ranges40_device(const void* d_packed, uint64_t nq, uint64_t* d_ranges, void* stream)
+{
+  if(nq == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_unpack_ranges40, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(d_packed), nq, d_ranges);
+  LAUNCH_CHECK("k_unpack_ranges40");
   return GCSA2_OK;
 }
 

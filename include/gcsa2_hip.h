@@ -474,6 +474,10 @@ int gcsa2_comm_locate(gcsa2_comm* comm, const gcsa2_index* index, const uint64_t
  * include/gcsa/utils.h:93-96).  Halves the bytes of the gather.  Launch on the current device. */
 int gcsa2_pack_ranges32_device(const uint64_t* d_ranges, uint64_t n_queries, uint32_t* d_packed, void* stream);
 int gcsa2_unpack_ranges32_device(const uint32_t* d_packed, uint64_t n_queries, uint64_t* d_ranges, void* stream);
+/* The same for indexes whose path node and edge numbers are below 2^40 (BASELINE configs[3]: 5.7 G path nodes): 10 bytes per
+ * range (sp and length, 40 bits each) instead of 16; d_packed holds 10 * n_queries bytes, 2-byte aligned. */
+int gcsa2_pack_ranges40_device(const uint64_t* d_ranges, uint64_t n_queries, void* d_packed, void* stream);
+int gcsa2_unpack_ranges40_device(const void* d_packed, uint64_t n_queries, uint64_t* d_ranges, void* stream);
 
 #ifdef __cplusplus
 }

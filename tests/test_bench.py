@@ -74,11 +74,18 @@ def test_distributed_path_world_size_1(no_comm):
     assert "u32 pairs" in d["config"]["parallelism"]
 
 
-def test_two_ranks_share_the_gpu_through_the_host():
+@pytest.mark.parametrize("wire", ["", "40", "64"], ids=["u32-pairs", "40-bit-pairs", "u64-pairs"])
+def test_two_ranks_share_the_gpu_through_the_host(wire):
+    """(the wire format of the gathered ranges follows the index size: u32 pairs below 2^32, 40-bit pairs below 2^40 -- the
+    headline index --, u64 pairs beyond; GCSA2_BENCH_WIRE forces the wider ones on this small index)"""
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
              "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--degree", "24", "--queries", "1000001", "--steps", "2",
-             "--warmup", "1", "--no-cpu", "--secondary", "config5"], env={"GCSA2_BENCH_BACKEND": "gloo"})
+             "--warmup", "1", "--no-cpu"] + (["--secondary", "config5"] if wire == "" else ["--no-secondary"]),
+            env={"GCSA2_BENCH_BACKEND": "gloo", "GCSA2_BENCH_WIRE": wire})
     check_line(d, 2, 2)
+    assert ("40-bit pairs" in d["config"]["parallelism"]) == (wire == "40") and ("u32 pairs" in d["config"]["parallelism"]) == (wire == "")
+    if wire != "":
+        return
     assert d["scaling"] == "strong" and d["config"]["queries_per_gpu"] == 500001 and d["config"]["queries_total"] == 1000001
     # config 5 sharded over the two ranks: matching statistics and the CSR of located values gathered on the root
     c5 = d["config5"]

@@ -903,6 +903,16 @@ def test_group_find_device_and_comm(engine):
     engine.unpack_ranges32_device(d_packed.data_ptr(), both.shape[0], d_back.data_ptr(), st)
     torch.cuda.synchronize()
     assert torch.equal(d_in, d_back)
+    # the 10-byte form for indexes below 2^40 (sp, length: 40 bits each)
+    wide = np.array([[2**40 - 1, 2**40 - 2], [2**33 + 5, 2**39 + 77], [0, 2**40 - 2], [2**39, 2**39], [1, 0]], dtype=np.uint64)
+    both = np.concatenate([both[: want.shape[0] + 3], wide])
+    d_in = torch.from_numpy(both.view(np.int64).copy()).to(dev)
+    d_packed = torch.zeros(both.shape[0] * 10 + 6, dtype=torch.uint8, device=dev)
+    d_back = torch.zeros_like(d_in)
+    engine.pack_ranges40_device(d_in.data_ptr(), both.shape[0], d_packed.data_ptr(), st)
+    engine.unpack_ranges40_device(d_packed.data_ptr(), both.shape[0], d_back.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(d_in, d_back)
 
 
 def test_sharded_match_stats_and_locate(engine):
