@@ -468,15 +468,21 @@ class GCSA:
                                                    _p64(left), counts[1], _p64(right), counts[2]))
         return tuple(int(x) for x in out), left[: counts[1]], right[: counts[2]]
 
-    def match_stats_batch(self, patterns, offsets):
+    def match_stats_batch(self, patterns, offsets, out=None):
         """Matching statistics by fused LF + parent (needs the LCP array):
-        (ms uint16[total bytes], ranges (nq, 2), parent() calls per pattern)."""
+        (ms uint16[total bytes], ranges (nq, 2), parent() calls per pattern).  `out`: the three arrays of an earlier call
+        of the same shape, to be filled again (fresh arrays cost their page faults: 0.5 GB for 1 M x 256 bp)."""
         patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         nq = offsets.shape[0] - 1
-        ms = np.zeros(max(int(offsets[nq]), 1), dtype=np.uint16)
-        ranges = np.zeros((nq, 2), dtype=np.uint64)
-        fallbacks = np.zeros(nq, dtype=np.uint64)
+        if out is not None:
+            ms, ranges, fallbacks = out
+            ms = ms.base if ms.base is not None and ms.base.shape[0] >= max(int(offsets[nq]), 1) else ms
+            assert ms.dtype == np.uint16 and ms.shape[0] >= int(offsets[nq]) and ranges.shape == (nq, 2) and fallbacks.shape == (nq,)
+        else:
+            ms = np.zeros(max(int(offsets[nq]), 1), dtype=np.uint16)
+            ranges = np.zeros((nq, 2), dtype=np.uint64)
+            fallbacks = np.zeros(nq, dtype=np.uint64)
         _check(self._L.gcsa2_match_stats_batch(self._h, _p8(patterns), _p64(offsets), nq, ms.ctypes.data,
                                                _p64(ranges), _p64(fallbacks)))
         return ms[: int(offsets[nq])], ranges, fallbacks

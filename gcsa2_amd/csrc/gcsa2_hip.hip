@@ -99,6 +99,7 @@ struct gcsa2_index
     u64 locate_split = (u64(1) << 31) - 1;   // GCSA2_LOCATE_SPLIT: most values (before deduplication) one pass of the locate pipeline handles
     u32 pipe_lanes = 12;               // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
+    bool ms_pieces = true;             // GCSA2_MS_PIECES=0: large host batches of matching statistics go through one copy in, one launch, one copy out
     bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the segmented radix sort
     bool zero_copy = true;             // GCSA2_ZERO_COPY=0: small host-pointer calls copy through the arenas like large ones
   } tune;
@@ -500,6 +501,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.dedup_huge = (knob("GCSA2_DEDUP_HUGE", 1, 0, 1) != 0);
     ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 12, 1, 16));
     ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);
+    ix->tune.ms_pieces = (knob("GCSA2_MS_PIECES", 1, 0, 1) != 0);
   }
   std::memset(&ix->img, 0, sizeof(DevImage));
   DevImage& img = ix->img;
@@ -2595,14 +2597,12 @@ extern "C" int gcsa2_match_stats_device_sized(const gcsa2_index* ix, int variant
   return match_stats_launch(ix, variant, d_patterns, d_offsets, nq, total_pattern_bytes, d_ms, d_ranges, d_fallbacks, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq,
-                                       uint16_t* ms, uint64_t* ranges, uint64_t* fallbacks)
+namespace {
+
+// one copy in, one launch, copies out (offsets[0] = 0)
+int match_stats_single(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, u64 longest,
+                       uint16_t* ms, uint64_t* ranges, uint64_t* fallbacks)
 {
-  CHECK_INDEX(ix);
-  if(nq == 0) { return GCSA2_OK; }
-  if(offsets == nullptr || ms == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
-  u64 longest = 0;
-  if(!offsets_ok(offsets, nq, &longest)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets are not non-decreasing"); }
   DeviceGuard guard(ix->device);
   const u64 total = offsets[nq];
   Lease lease(ix);
@@ -2620,6 +2620,72 @@ extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* pat
   if(fallbacks != nullptr) { HIP_TRY(lease.down(fallbacks, d_fb, nq * sizeof(u64))); }
   HIP_TRY(lease.finish());
   return GCSA2_OK;
+}
+
+// A large host batch moves three times the pattern bytes over the link (one byte in, two out per position) and the kernel
+// is faster than that: it is cut into pieces of ~MS_PIECE_BYTES pattern bytes which MS_PIECE_THREADS host threads send through
+// the single-copy path, each on the stream and arenas of its own lease -- one piece's upload, another's kernel and a third's
+// download overlap.  (1 M x 256 bp on the chr22-like index: 22.4 ms = 45 M patterns/s in a row, 17.5 ms = 57 M/s in pieces;
+// eight threads or 8 MB pieces change nothing: what is left is the rate of copies to and from pageable memory,
+// tests/perf/ms_host_batch.py.)
+constexpr u64 MS_PIECE_BYTES = u64(16) << 20, MS_PIECED_MIN_BYTES = u64(64) << 20;
+constexpr unsigned MS_PIECE_THREADS = 4;
+
+int match_stats_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, u64 longest,
+                       uint16_t* ms, uint64_t* ranges, uint64_t* fallbacks)
+{
+  std::vector<u64> cut(1, 0);
+  while(cut.back() < nq)
+  {
+    const u64 b = cut.back();
+    u64 lo = b + 1, hi = nq;                               // largest e with offsets[e] - offsets[b] <= MS_PIECE_BYTES, at least one pattern
+    while(lo < hi) { const u64 mid = (lo + hi + 1) / 2; if(offsets[mid] - offsets[b] <= MS_PIECE_BYTES) { lo = mid; } else { hi = mid - 1; } }
+    cut.push_back(lo);
+  }
+  const u64 pieces = cut.size() - 1;
+  const unsigned threads = unsigned(pieces < MS_PIECE_THREADS ? pieces : MS_PIECE_THREADS);
+  std::vector<int> status(threads, GCSA2_OK);
+  std::vector<std::string> messages(threads);
+  auto work = [&](unsigned t)
+  {
+    std::vector<u64> local;
+    for(u64 c = t; c < pieces && status[t] == GCSA2_OK; c += threads)
+    {
+      const u64 b = cut[c], count = cut[c + 1] - b, base = offsets[b];
+      local.resize(count + 1);
+      for(u64 i = 0; i <= count; i++) { local[i] = offsets[b + i] - base; }
+      status[t] = match_stats_single(ix, patterns + base, local.data(), count, longest, ms + base, ranges + 2 * b,
+                                     fallbacks != nullptr ? fallbacks + b : nullptr);
+      if(status[t] != GCSA2_OK) { messages[t] = g_error; }
+    }
+  };
+  std::vector<std::thread> workers;
+  for(unsigned t = 1; t < threads; t++) { workers.emplace_back(work, t); }
+  work(0);
+  for(std::thread& w : workers) { w.join(); }
+  for(unsigned t = 0; t < threads; t++) { if(status[t] != GCSA2_OK) { return fail(status[t], messages[t]); } }
+  return GCSA2_OK;
+}
+
+}  // namespace
+
+extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq,
+                                       uint16_t* ms, uint64_t* ranges, uint64_t* fallbacks)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  if(offsets == nullptr || ms == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  u64 longest = 0;
+  if(!offsets_ok(offsets, nq, &longest)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets are not non-decreasing"); }
+  try
+  {
+    if(ix->tune.ms_pieces && offsets[0] == 0 && offsets[nq] >= MS_PIECED_MIN_BYTES && longest <= MS_PIECE_BYTES)
+    {
+      return match_stats_pieced(ix, patterns, offsets, nq, longest, ms, ranges, fallbacks);
+    }
+  }
+  catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_match_stats_batch: ") + e.what()); }
+  return match_stats_single(ix, patterns, offsets, nq, longest, ms, ranges, fallbacks);
 }
 
 // ---- host-view container file ("G2HV"): the interchange format between a process that can read
