@@ -2627,7 +2627,8 @@ int match_stats_single(const gcsa2_index* ix, const uint8_t* patterns, const uin
 // the single-copy path, each on the stream and arenas of its own lease -- one piece's upload, another's kernel and a third's
 // download overlap.  (1 M x 256 bp on the chr22-like index: 22.4 ms = 45 M patterns/s in a row, 17.5 ms = 57 M/s in pieces;
 // eight threads or 8 MB pieces change nothing: what is left is the rate of copies to and from pageable memory,
-// tests/perf/ms_host_batch.py.)
+// tests/perf/ms_host_batch.py.  Staging those copies ourselves through a ring of pinned 2 MB pieces was measured and is
+// twice as slow as the runtime's own path for pageable memory: 47 ms in a row, 24-28 ms in pieces.)
 constexpr u64 MS_PIECE_BYTES = u64(16) << 20, MS_PIECED_MIN_BYTES = u64(64) << 20;
 constexpr unsigned MS_PIECE_THREADS = 4;
 
