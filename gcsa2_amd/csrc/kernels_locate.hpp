@@ -285,8 +285,9 @@ __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __r
     values[b + (g - first)] = (entry & LOCATE_DIRECT) ? (entry & ~LOCATE_DIRECT) : packed_get(img.stored, img.sample_width, s) + steps;
     if(count > 1)
     {
-      const u64 at = b + (node_off[q + 1] - first) + atomicAdd(extra_slots + q, (unsigned long long)(count - 1));
-      for(u32 j = 1; j < count; j++) { values[at + j - 1] = packed_get(img.stored, img.sample_width, s + j) + steps; }
+      // (the guard only matters for an index whose counters disagree with its samples: nothing is written outside the query's segment)
+      const u64 at = b + (node_off[q + 1] - first) + atomicAdd(extra_slots + q, (unsigned long long)(count - 1)), end = raw_off[q + 1];
+      for(u32 j = 1; j < count && at + j - 1 < end; j++) { values[at + j - 1] = packed_get(img.stored, img.sample_width, s + j) + steps; }
     }
     return;
   }
@@ -314,8 +315,9 @@ __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __r
   const u32 run_before = __shfl(before, first);
   if(!live) { return; }
   u64 dest = run_base + (before - run_before);
-  if(entry & LOCATE_DIRECT) { values[dest] = entry & ~LOCATE_DIRECT; return; }
-  for(u32 j = 0; j < count; j++) { values[dest + j] = packed_get(img.stored, img.sample_width, s + j) + steps; }     // gcsa.cpp:893
+  const u64 end = raw_off[q + 1];                                 // (see the guard above)
+  if(entry & LOCATE_DIRECT) { if(dest < end) { values[dest] = entry & ~LOCATE_DIRECT; } return; }
+  for(u32 j = 0; j < count && dest + j < end; j++) { values[dest + j] = packed_get(img.stored, img.sample_width, s + j) + steps; }     // gcsa.cpp:893
 }
 
 // Output slots for a whole workgroup with ONE atomic: every wave passes the number of slots it wants and
