@@ -356,14 +356,14 @@ def setup_pangenome(args, D, dev, local_rank, total_queries=None):
     if degree not in dbg_torch.LFSR:
         raise SystemExit(f"--degree must be one of {sorted(dbg_torch.LFSR)}")
     kind = {"pangenome": "junction", "pangenome_plain": "plain", "pangenome_snp": "snp"}[args.workload if args.workload.startswith("pangenome") else "pangenome"]
-    # every rank holds the plain arrays of its own replica on the host (the image itself is built on the device): ~5 bytes
-    # per path node for find() alone, ~9 with samples and LCP
+    # every rank holds the plain arrays of its own replica on the host (the image itself is built on the device): ~1 byte
+    # per path node for find() alone (7 B_c + edges as bits), ~6 with samples (packed and plain), counters and LCP, ~8.5 at the peak of the generator; budgeted at 3 and 9
     # (config 5 runs sharded at N > 1, so every rank needs them)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", D.world))
     # (both decisions are taken together: ranks that read /proc/meminfo at different moments must not disagree)
     full = (not args.no_secondary and kind != "snp" and args.secondary in ("all", "config5")
             and (degree <= 20 or D.all_true(host_memory_ok(local_world * 9 * dbg_torch.text_length(degree)))))
-    need = local_world * (9 if full else 5) * dbg_torch.text_length(degree) * (1.25 if kind == "snp" else 1.0)
+    need = local_world * (9 if full else 3) * dbg_torch.text_length(degree) * (1.25 if kind == "snp" else 1.0)
     if degree > 20 and not D.all_true(host_memory_ok(need)):
         log(f"warning: host memory too small for {local_world} replicas of the degree-{degree} index ({need / 1e9:.0f} GB); "
             f"falling back to the 2^32 - 1 node index of rounds 1-2")
