@@ -372,15 +372,15 @@ struct Scratch
 }  // namespace
 
 namespace {
-// owners: scratch of total_nodes / TPB2 + 3 entries (k_block_owners).  extra_slots: nq zeroed counters, or nullptr when the
+// owners: scratch of total_nodes / OWNER_SPAN + 3 entries (k_block_owners).  extra_slots: nq zeroed counters, or nullptr when the
 // values must come out in path order (sort = false); only the table walk uses them.
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
                         u64 total_nodes, u64* values, u64* owners, hipStream_t stream, u64* extra_slots)
 {
   if(ix->img.locate_tab != nullptr)
   {
-    const u64 blocks = grid_for(total_nodes);
-    hipLaunchKernelGGL(k_block_owners, dim3(grid_for(blocks + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, u32(TPB), blocks, owners);
+    const u64 blocks = grid_for(total_nodes), spans = (total_nodes + OWNER_SPAN - 1) / OWNER_SPAN;
+    hipLaunchKernelGGL(k_block_owners, dim3(grid_for(spans + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, OWNER_SPAN, spans, owners);
     if(extra_slots != nullptr)
     {
       hipLaunchKernelGGL(k_locate_tab<false>, dim3(unsigned(blocks)), dim3(TPB), 0, stream,
@@ -394,8 +394,8 @@ inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, cons
   }
   else if(ix->img.pred4 != nullptr)
   {
-    const u64 blocks = (total_nodes + TPB2 - 1) / TPB2;
-    hipLaunchKernelGGL(k_block_owners, dim3(grid_for(blocks + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, u32(TPB2), blocks, owners);
+    const u64 blocks = (total_nodes + TPB2 - 1) / TPB2, spans = (total_nodes + OWNER_SPAN - 1) / OWNER_SPAN;
+    hipLaunchKernelGGL(k_block_owners, dim3(grid_for(spans + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, OWNER_SPAN, spans, owners);
     hipLaunchKernelGGL(k_locate_walk2, dim3(unsigned(blocks)), dim3(TPB2), 0, stream,
                        ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values, owners);
   }
@@ -1114,7 +1114,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   // the per-workgroup owners of the walk kernel (k_block_owners) fit into one of the count arrays, which the scans have
   // consumed, unless the ranges are wide; the other one serves as the per-query slot counters of the unordered table walk
   u64* owners = raw_counts;
-  if(total_nodes / TPB2 + 3 > nq + 1) { HIP_TRY(scratch.get(owners, total_nodes / TPB2 + 3)); }
+  if(total_nodes / OWNER_SPAN + 3 > nq + 1) { HIP_TRY(scratch.get(owners, total_nodes / OWNER_SPAN + 3)); }
   u64* extra_slots = node_counts;
 
   if(total_raw == 0)

@@ -119,8 +119,8 @@ __device__ __forceinline__ u64 owner_of(const u64* __restrict__ node_off, u64 nq
   return owner_between(node_off, 0, nq - 1, 0, total_nodes, g);
 }
 
-// The owners of a workgroup's consecutive flattened nodes lie between the owner of its first node and the owner of the next
-// workgroup's first node: k_block_owners finds those once, one lane per workgroup of the walk kernel (entry `blocks` = the
+// The owners of a block of consecutive flattened nodes lie between the owner of its first node and the owner of the next
+// block's first node: k_block_owners finds those once, one lane per block (entry `blocks` = the
 // owner of the last node), and every lane of the walk kernel searches its bracket only -- a single query when the ranges are
 // wide: no probe at all.  (Two full searches by two lanes of every workgroup, the others waiting at a barrier, were most of
 // k_locate_tab on the repeat-rich batch.)
@@ -133,11 +133,16 @@ __global__ __launch_bounds__(TPB) void k_block_owners(const u64* __restrict__ no
   owners[j] = owner_of(node_off, nq, total_nodes, g);
 }
 
-__device__ __forceinline__ u64 owner_in_workgroup(const u64* __restrict__ owners, const u64* __restrict__ node_off, u64 total_nodes,
-                                                  u64 g_first, u32 threads, u64 g, bool live)
+// (the brackets are per WAVEFRONT, 64 consecutive nodes: with ranges of a few hundred path nodes most wavefronts lie inside
+// one query and skip the search; per workgroup of 256 most did not)
+constexpr u32 OWNER_SPAN = 64;
+
+__device__ __forceinline__ u64 owner_in_wave(const u64* __restrict__ owners, const u64* __restrict__ node_off, u64 total_nodes,
+                                             u64 g, bool live)
 {
-  const u64 g_end = (g_first + threads <= total_nodes ? g_first + threads : total_nodes);      // g_first < total_nodes
-  return live ? owner_between(node_off, owners[blockIdx.x], owners[blockIdx.x + 1], g_first, g_end, g) : 0;
+  const u64 j = g / OWNER_SPAN, g_first = j * OWNER_SPAN;
+  const u64 g_end = (g_first + OWNER_SPAN <= total_nodes ? g_first + OWNER_SPAN : total_nodes);
+  return live ? owner_between(node_off, owners[j], owners[j + 1], g_first, g_end, g) : 0;
 }
 
 __device__ __forceinline__ void locate_item(const DevImage& img, const u64* __restrict__ ranges, u64 q,
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(TPB2) void k_locate_walk2(DevImage img, const u64* 
   u64 g = u64(blockIdx.x) * TPB2 + threadIdx.x;
   bool live = g < total_nodes;
   u64 node = 0, dest = 0, steps = 0;
-  const u64 q = owner_in_workgroup(owners, node_off, total_nodes, u64(blockIdx.x) * TPB2, TPB2, g, live);
+  const u64 q = owner_in_wave(owners, node_off, total_nodes, g, live);
   if(live) { locate_item(img, ranges, q, node_off, raw_off, g, node, dest); }
   walk_to_sample(img, node, steps, live, wave_stage, lane);
   if(live)
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __r
   const u32 lane = threadIdx.x & 63;
   const u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
   const bool live = g < total_nodes;
-  const u64 q = owner_in_workgroup(owners, node_off, total_nodes, u64(blockIdx.x) * TPB, TPB, g, live);
+  const u64 q = owner_in_wave(owners, node_off, total_nodes, g, live);
   u64 sp = 0, node = 0, entry = LOCATE_DIRECT, s = 0, steps = 0;
   u32 count = 0;
   if(live)
