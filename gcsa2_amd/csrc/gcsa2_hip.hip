@@ -1228,6 +1228,12 @@ __global__ void k_locate_cut(const u64* __restrict__ raw_off, u64 nq, u64 q0, u6
   *out = lo;
 }
 
+__global__ __launch_bounds__(TPB) void k_uniform_offsets(u64* __restrict__ dst, u64 count, u64 stride)
+{
+  const u64 i = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(i < count) { dst[i] = i * stride; }
+}
+
 __global__ __launch_bounds__(TPB) void k_shift_offsets(const u64* __restrict__ src, u64 count, u64 base, u64* __restrict__ dst)
 {
   const u64 i = u64(blockIdx.x) * TPB + threadIdx.x;
@@ -1497,10 +1503,13 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
       // the chunk's pattern bytes land at the same phase within 16 bytes as in the caller's array (the kernel reads aligned
       // words around a pattern's ends); with the caller's absolute offsets the kernel gets the pointer moved back by `base`
       const u64 phase = 16 + (base & 15);
-      u64 bad = 0;
-      if(direct_off) { for(u64 i = 1; i <= count; i++) { bad |= u64(offsets[b + i] < offsets[b + i - 1]); } }
-      else { for(u64 i = 0; i <= count; i++) { const u64 o = offsets[b + i]; h_off[i] = o - base; bad |= u64(i > 0 && o < offsets[b + i - 1]); } }
+      // patterns of one length (k-mer batches): the chunk's offsets are base + i * length, made on the device instead of sent
+      const u64 stride = (offsets[b + 1] - base);
+      u64 bad = 0, ragged = 0;
+      if(direct_off) { for(u64 i = 1; i <= count; i++) { const u64 o = offsets[b + i]; bad |= u64(o < offsets[b + i - 1]); ragged |= (o - base) ^ (i * stride); } }
+      else { for(u64 i = 0; i <= count; i++) { const u64 o = offsets[b + i]; h_off[i] = o - base; bad |= u64(i > 0 && o < offsets[b + i - 1]); ragged |= (o - base) ^ (i * stride); } }
       if(bad != 0 || bytes > PIPE_CHUNK_BYTES) { status[t] = GCSA2_ERR_INVALID_ARGUMENT; messages[t] = "pattern offsets are not non-decreasing"; break; }
+      const bool uniform = (ragged == 0);
       char* d_pat = set.d; u64* d_off = reinterpret_cast<u64*>(set.d + (PIPE_CHUNK_BYTES + 64));
       u64* d_out = d_off + PIPE_CHUNK_QUERIES + 8;
       hipError_t err = hipSuccess;
@@ -1510,12 +1519,17 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
         std::memcpy(h_pat + phase, patterns + base, bytes);
         err = hipMemcpyAsync(d_pat, h_pat, (phase + bytes + 7) / 8 * 8, hipMemcpyHostToDevice, lane.stream);
       }
-      if(err == hipSuccess)
+      if(err == hipSuccess && uniform)
+      {
+        hipLaunchKernelGGL(k_uniform_offsets, dim3(grid_for(count + 1)), dim3(TPB), 0, lane.stream, d_off, count + 1, stride);
+        err = hipGetLastError();
+      }
+      else if(err == hipSuccess)
       {
         err = hipMemcpyAsync(d_off, direct_off ? offsets + b : h_off, (count + 1) * sizeof(u64), hipMemcpyHostToDevice, lane.stream);
       }
       if(err != hipSuccess) { fail_lane("hipMemcpyAsync", err); break; }
-      const uint8_t* d_first = reinterpret_cast<const uint8_t*>(d_pat + phase) - (direct_off ? base : 0);
+      const uint8_t* d_first = reinterpret_cast<const uint8_t*>(d_pat + phase) - (direct_off && !uniform ? base : 0);
       int rc_find = gcsa2_find_device(ix, d_first, d_off, count, d_out, lane.stream);
       if(rc_find != GCSA2_OK) { status[t] = rc_find; messages[t] = g_error; break; }
       hipStream_t back = lane.stream;
