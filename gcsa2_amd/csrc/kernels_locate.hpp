@@ -468,7 +468,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict_
 // are removed BEFORE sorting, through a hash set in LDS.  (With the filter on, k_collect_multi lists every segment beyond the
 // medium class here: a segment without duplicates pays one extra pass, a tenth of its sort.)  A segment with at most BIG_SEGMENT distinct values leaves
 // as: its distinct values (unsorted) at the front, the rest of the segment filled with its largest value (duplicates that
-// k_mark_unique drops), and the front appended to the medium or large list for the LDS sorts that run next.  A segment with
+// the flag pass drops), and the front appended to the medium or large list for the LDS sorts that run next.  A segment with
 // more distinct values is left untouched and listed for the segmented radix sort (over_begin / over_end, counted in totals[7]).
 // Two instantiations share the list, like k_sort_big: 8192 slots (64 KB, two workgroups per CU) take the segments of up to
 // 4096 values, which cannot overflow; 16384 slots (128 KB) the longer ones.  A workgroup whose segment belongs to the other
