@@ -477,7 +477,8 @@ class GCSA:
         nq = offsets.shape[0] - 1
         if out is not None:
             ms, ranges, fallbacks = out
-            ms = ms.base if ms.base is not None and ms.base.shape[0] >= max(int(offsets[nq]), 1) else ms
+            if isinstance(ms.base, np.ndarray) and ms.base.dtype == np.uint16 and ms.base.ndim == 1 and ms.base.shape[0] >= max(int(offsets[nq]), 1):
+                ms = ms.base              # the slice an earlier call returned: its whole array
             assert ms.dtype == np.uint16 and ms.shape[0] >= int(offsets[nq]) and ranges.shape == (nq, 2) and fallbacks.shape == (nq,)
         else:
             ms = np.zeros(max(int(offsets[nq]), 1), dtype=np.uint16)
