@@ -436,3 +436,39 @@ def test_branching_footprint_index_closed_form():
     cm, cr, cf = cpu.match_stats_batch(d_pat[: ns * m].cpu().numpy(), np.arange(ns + 1, dtype=np.uint64) * np.uint64(m), threads=8)
     assert np.array_equal(d_ms[: ns * m].cpu().numpy().view(np.uint16), cm)
     assert np.array_equal(d_rng[:ns].cpu().numpy().view(np.uint64), cr) and np.array_equal(d_fb[:ns].cpu().numpy().view(np.uint64), cf)
+
+
+def test_match_stats_large_host_batch_in_pieces(monkeypatch):
+    """gcsa2_match_stats_batch cuts a batch of 64 MB or more of pattern bytes into pieces that several host threads send through
+    the single-copy path concurrently (GCSA2_MS_PIECES=0: one copy, one launch).  Ragged lengths, so that piece boundaries fall
+    anywhere: both ways give the same statistics, ranges and parent() counts, and the oracle agrees on a sample of patterns."""
+    from workload import graphs, builder, patterns
+    from oracle.oracle import OracleIndex, max_threads
+    from gcsa2_amd import binding
+    g = graphs.snp_graph(1 << 16, 0x6C5A0030, 0x6C5A0031)
+    ix = builder.build(g, 64, keep_table=False)
+    nq, m = 330_000, 256
+    walks = patterns.walk_patterns(g, nq, m, 0x6C5A0032)
+    for col in range(29, m, 47):                               # substitutions in two thirds of the patterns
+        rows = np.arange(nq) % 3 != 0
+        walks[rows, col] = np.frombuffer(b"CGTA", dtype=np.uint8)[np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), walks[rows, col]) % 4]
+    rng = np.random.default_rng(0x33)
+    lengths = rng.integers(200, m + 1, size=nq)
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    flat = np.ascontiguousarray(walks[np.arange(m)[None, :] < lengths[:, None]])          # row-major: pattern after pattern
+    assert flat.shape[0] == int(off[-1]) and flat.shape[0] >= (64 << 20)
+    gpu, _ = binding.open_index(ix)
+    gm, gr, gf = gpu.match_stats_batch(flat, off)
+    monkeypatch.setenv("GCSA2_MS_PIECES", "0")
+    single, _ = binding.open_index(ix)
+    sm, sr, sf = single.match_stats_batch(flat, off)
+    assert np.array_equal(gm, sm) and np.array_equal(gr, sr) and np.array_equal(gf, sf)
+    cpu = OracleIndex(ix)
+    pick = np.sort(rng.choice(nq, size=4000, replace=False))
+    sub_off = np.concatenate([[0], np.cumsum(lengths[pick])]).astype(np.uint64)
+    sub = np.concatenate([flat[int(off[q]): int(off[q + 1])] for q in pick])
+    cm, cr, cf = cpu.match_stats_batch(sub, sub_off, threads=max_threads())
+    got = np.concatenate([gm[int(off[q]): int(off[q + 1])] for q in pick])
+    assert np.array_equal(got, cm) and np.array_equal(gr[pick], cr) and np.array_equal(gf[pick], cf)
+    assert int(gf.max()) > 0
+    gpu.close(); single.close()
