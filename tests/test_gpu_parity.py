@@ -345,6 +345,19 @@ def test_find_host_pipeline_pageable_and_page_locked(engine):
     skip = 1234
     got = gpu.find_batch(pinned[0], pinned[1][skip:], out=pinned[2][skip:])
     assert np.array_equal(got, want[skip:])
+    # patterns of one length: the chunk's offsets are generated on the device instead of sent (chunk bases at odd phases)
+    m = 15
+    assert nq * m <= data.shape[0]
+    uni_off = (np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)) + np.uint64(0)
+    uni = data[: nq * m]
+    d_off2 = torch.from_numpy(uni_off.view(np.int64)).to(dev)
+    gpu.find_device(d_pat.data_ptr(), d_off2.data_ptr(), nq, d_out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    want_uni = d_out.cpu().numpy().view(np.uint64)
+    assert np.array_equal(gpu.find_batch(uni, uni_off), want_uni)
+    p_off.numpy().view(np.uint64)[:] = uni_off
+    assert np.array_equal(gpu.find_batch(pinned[0][: nq * m], pinned[1], out=pinned[2]), want_uni)
+    p_off.numpy().view(np.uint64)[:] = off
     bad = pinned[1].copy()
     bad[nq // 2] = bad[nq // 2 + 1] + 5
     with pytest.raises(engine.Gcsa2Error):
