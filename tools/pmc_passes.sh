@@ -17,11 +17,11 @@ for WL in $WORKLOADS; do
   ONLY="--kernel-include-regex k_find2"      # counters for the find kernels only (collecting them for every torch kernel of the generator is slow, and crashed once)
   for P in $PASSES; do
     case $P in
-      rdreq) rocprofv3 $ONLY --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum \
+      rdreq) timeout ${PASS_TIMEOUT:-420} rocprofv3 $ONLY --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum \
                 --output-format csv -d $ROOT/gpurun_out/${TAG}_${WL}_rdreq -o x -- $CMD > $ROOT/gpurun_out/${TAG}_${WL}_rdreq.log 2>&1 ;;
-      l2)    rocprofv3 $ONLY --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $ROOT/gpurun_out/${TAG}_${WL}_l2 -o x -- $CMD > $ROOT/gpurun_out/${TAG}_${WL}_l2.log 2>&1 ;;
-      fetch) rocprofv3 $ONLY --pmc FETCH_SIZE --output-format csv -d $ROOT/gpurun_out/${TAG}_${WL}_fetch -o x -- $CMD > $ROOT/gpurun_out/${TAG}_${WL}_fetch.log 2>&1 ;;
-      trace) rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_${WL}_trace -o x -- \
+      l2)    timeout ${PASS_TIMEOUT:-420} rocprofv3 $ONLY --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $ROOT/gpurun_out/${TAG}_${WL}_l2 -o x -- $CMD > $ROOT/gpurun_out/${TAG}_${WL}_l2.log 2>&1 ;;
+      fetch) timeout ${PASS_TIMEOUT:-420} rocprofv3 $ONLY --pmc FETCH_SIZE --output-format csv -d $ROOT/gpurun_out/${TAG}_${WL}_fetch -o x -- $CMD > $ROOT/gpurun_out/${TAG}_${WL}_fetch.log 2>&1 ;;
+      trace) timeout ${PASS_TIMEOUT:-420} rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_${WL}_trace -o x -- \
                 python $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --no-cpu --no-secondary --no-extras $EXTRA > $ROOT/gpurun_out/${TAG}_${WL}_trace.log 2>&1 ;;
     esac
   done
