@@ -127,7 +127,7 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
 inline unsigned grid_for(u64 n) { return unsigned((n + TPB - 1) / TPB); }
 
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
-                        u64 total_nodes, u64* values, u64* owners, hipStream_t stream, u64* extra_slots = nullptr);
+                        u64 total_nodes, u64* values, u64* owners, hipStream_t stream);
 
 // host-side staging of the device image --------------------------------------------------
 
@@ -372,25 +372,17 @@ struct Scratch
 }  // namespace
 
 namespace {
-// owners: scratch of total_nodes / OWNER_SPAN + 3 entries (k_block_owners).  extra_slots: nq zeroed counters, or nullptr when the
-// values must come out in path order (sort = false); only the table walk uses them.
+// owners: scratch of total_nodes / OWNER_SPAN + 3 entries (k_block_owners).  Values in path order (the table walk has an
+// unordered two-pass form for the sorted mode: locate_chunk).
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
-                        u64 total_nodes, u64* values, u64* owners, hipStream_t stream, u64* extra_slots)
+                        u64 total_nodes, u64* values, u64* owners, hipStream_t stream)
 {
   if(ix->img.locate_tab != nullptr)
   {
     const u64 blocks = grid_for(total_nodes), spans = (total_nodes + OWNER_SPAN - 1) / OWNER_SPAN;
     hipLaunchKernelGGL(k_block_owners, dim3(grid_for(spans + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, OWNER_SPAN, spans, owners);
-    if(extra_slots != nullptr)
-    {
-      hipLaunchKernelGGL(k_locate_tab<false>, dim3(unsigned(blocks)), dim3(TPB), 0, stream,
-                         ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values, owners, reinterpret_cast<unsigned long long*>(extra_slots));
-    }
-    else
-    {
-      hipLaunchKernelGGL(k_locate_tab<true>, dim3(unsigned(blocks)), dim3(TPB), 0, stream,
-                         ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values, owners, nullptr);
-    }
+    hipLaunchKernelGGL(k_locate_tab, dim3(unsigned(blocks)), dim3(TPB), 0, stream,
+                       ix->img, d_ranges, nq, node_off, raw_off, total_nodes, values, owners);
   }
   else if(ix->img.pred4 != nullptr)
   {
@@ -1140,8 +1132,24 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     const u64 nwords = total_raw / 64 + 1;
     HIP_TRY(scratch.get(sorted, total_raw));
     HIP_TRY(scratch.get(words, nwords)); HIP_TRY(scratch.get(word_counts, nwords + 1)); HIP_TRY(scratch.get(word_before, nwords + 1));
-    HIP_TRY(hipMemsetAsync(extra_slots, 0, nq * sizeof(u64), stream));
-    launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, owners, stream, extra_slots);
+    if(ix->img.locate_tab != nullptr)
+    {
+      // unordered table walk in two passes (kernels_locate.hpp): single values at once, the path nodes with several values
+      // marked (one word per 64 nodes) and worked through afterwards
+      const u64 blocks = grid_for(total_nodes), spans = (total_nodes + OWNER_SPAN - 1) / OWNER_SPAN;
+      u64* later_words = nullptr;
+      HIP_TRY(scratch.get(later_words, spans));
+      HIP_TRY(hipMemsetAsync(extra_slots, 0, nq * sizeof(u64), stream));
+      hipLaunchKernelGGL(k_block_owners, dim3(grid_for(spans + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, OWNER_SPAN, spans, owners);
+      hipLaunchKernelGGL(k_locate_tab_unordered, dim3(unsigned(blocks)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_off, raw_off,
+                         total_nodes, sorted, owners, later_words);
+      if(total_raw > total_nodes)                  // some path node has several values
+      {
+        hipLaunchKernelGGL(k_locate_tab_rest, dim3(grid_for(spans)), dim3(TPB), 0, stream, ix->img, d_ranges, node_off, raw_off, total_nodes, sorted,
+                           owners, later_words, spans, reinterpret_cast<unsigned long long*>(extra_slots));
+      }
+    }
+    else { launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, owners, stream); }
     LAUNCH_CHECK("k_locate_walk");
 
     // removeDuplicates: queries with up to SMALL_SEGMENT values are sorted in registers, up to MEDIUM_SEGMENT by a wavefront

@@ -25,6 +25,21 @@ __device__ __forceinline__ u64 sada_count(const DevImage& img, u64 sp, u64 ep)
   return (bv_select(img.redundant, ep + 1) - ep) - (sp > 0 ? bv_select(img.redundant, sp) + 1 - sp : 0);
 }
 
+// Number of values of a sampled node whose first sample has index s: the samples up to and including the next one marked
+// last (gcsa.h:208), found 64 marks at a time instead of by one dependent load per sample (tandem repeats put hundreds of
+// samples on a node, and the lane that met one held its wavefront).
+__device__ __forceinline__ u32 sample_run(const DevImage& img, u64 s)
+{
+  u64 pos = s;
+  while(pos < img.samples.size)
+  {
+    const u64 w = bv_bits64(img.samples, pos);
+    if(w != 0) { return u32(pos + u64(__ffsll((long long)w) - 1) - s + 1); }
+    pos += 64;
+  }
+  return u32(img.samples.size > s ? img.samples.size - s : 1);          // no last mark: a broken index; stay inside the array
+}
+
 __device__ __forceinline__ u64 count_range(const DevImage& img, u64 sp, u64 ep)
 {
   if(range_empty(sp, ep) || ep >= img.n) { return 0; }                  // gcsa.cpp:805
@@ -254,15 +269,10 @@ __global__ __launch_bounds__(TPB2) void k_build_locate_table(DevImage img, u64 f
 // inside the WAVEFRONT asks the counters for that (SadaSparse::count: two ranks and two selects); the other lanes add the
 // wave's running sum of the value counts their table entries show.  No barrier, no LDS: the waves of a workgroup share
 // nothing but the owner bracket.
-// ORDERED = false (the values are sorted afterwards, so their order inside the query's segment is free): a node's first value
-// goes to raw_off[q] + its rank among the query's nodes, further values of a node to slots drawn from a per-query counter
-// behind those -- no question to the counters at all, whose two ranks and two selects were the longest part of the dependent
-// chain that bounds this kernel (25 memory instructions per wave, most of them theirs; 32 VGPRs, so occupancy is not the limit).
-template<bool ORDERED>
+// (Path order: locate(sort = false).  When the values are sorted afterwards the unordered two-pass walk below is used.)
 __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __restrict__ ranges, u64 nq,
                                                     const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
-                                                    u64 total_nodes, u64* __restrict__ values, const u64* __restrict__ owners,
-                                                    unsigned long long* __restrict__ extra_slots)
+                                                    u64 total_nodes, u64* __restrict__ values, const u64* __restrict__ owners)
 {
   const u32 lane = threadIdx.x & 63;
   const u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
@@ -279,22 +289,8 @@ __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __r
     if(!(entry & LOCATE_DIRECT))
     {
       s = entry & ((u64(1) << LOCATE_INDEX_BITS) - 1); steps = entry >> LOCATE_INDEX_BITS;
-      u64 t = s;
-      while(!bv_get(img.samples, t)) { t++; count++; }           // lastSample, gcsa.h:208
+      count = sample_run(img, s);
     }
-  }
-  if constexpr(!ORDERED)
-  {
-    if(!live) { return; }
-    const u64 b = raw_off[q], first = node_off[q];
-    values[b + (g - first)] = (entry & LOCATE_DIRECT) ? (entry & ~LOCATE_DIRECT) : packed_get(img.stored, img.sample_width, s) + steps;
-    if(count > 1)
-    {
-      // (the guard only matters for an index whose counters disagree with its samples: nothing is written outside the query's segment)
-      const u64 at = b + (node_off[q + 1] - first) + atomicAdd(extra_slots + q, (unsigned long long)(count - 1)), end = raw_off[q + 1];
-      for(u32 j = 1; j < count && at + j - 1 < end; j++) { values[at + j - 1] = packed_get(img.stored, img.sample_width, s + j) + steps; }
-    }
-    return;
   }
   const u64 q_left = __shfl_up(q, 1);
   const bool head = live && (lane == 0 || q_left != q);           // (live lanes are a prefix of the wave)
@@ -323,6 +319,97 @@ __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __r
   const u64 end = raw_off[q + 1];                                 // (see the guard above)
   if(entry & LOCATE_DIRECT) { if(dest < end) { values[dest] = entry & ~LOCATE_DIRECT; } return; }
   for(u32 j = 0; j < count && dest + j < end; j++) { values[dest + j] = packed_get(img.stored, img.sample_width, s + j) + steps; }     // gcsa.cpp:893
+}
+
+// The unordered table walk (the values are sorted afterwards), in two passes.  Elimination runs on the repeat-rich batch
+// (110 M path nodes): reading the entries and storing them as they are takes 0.55 ms, the whole kernel took 1.7 ms whatever its
+// shape (owner search per workgroup or wavefront, scalar loads for what is uniform, two or eight nodes per lane) -- the two
+// path nodes in a hundred whose walk ends in a node with several values (sample-by-sample loop, packed samples, a slot
+// counter) sat in three waves out of four and held the other 63 lanes for a chain of dependent gathers.  So the first pass
+// stores the single values and only MARKS the other nodes, one 64-bit word per wavefront (a list with one atomic per
+// wavefront was tried first: 1.2 M atomics on one counter took 8 ms); the second pass gives every word to one lane, which
+// works through its one or two marked nodes.  Everything that is uniform over a wavefront is read through the scalar cache.
+__global__ __launch_bounds__(TPB) void k_locate_tab_unordered(DevImage img, const u64* __restrict__ ranges, u64 nq,
+                                                              const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
+                                                              u64 total_nodes, u64* __restrict__ values, const u64* __restrict__ owners,
+                                                              u64* __restrict__ later_words)
+{
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  const u64 j = u64(blockIdx.x) * (TPB / OWNER_SPAN) + wave;           // this wave's span of OWNER_SPAN = 64 nodes
+  const u64 g_first = j * OWNER_SPAN;
+  if(g_first >= total_nodes) { return; }                               // uniform
+  const u64 g = g_first + lane;
+  const bool live = g < total_nodes;
+  const u64 qa = owners[j], qb = owners[j + 1];                        // uniform addresses: scalar loads
+  u64 q, sp, first, b;
+  if(qa == qb)                                                         // uniform branch: the whole wave inside one query
+  {
+    q = qa; sp = ranges[2 * qa]; first = node_off[qa]; b = raw_off[qa];
+  }
+  else
+  {
+    const u64 g_end = (g_first + OWNER_SPAN <= total_nodes ? g_first + OWNER_SPAN : total_nodes);
+    q = owner_between(node_off, qa, qb, g_first, g_end, live ? g : g_first);
+    sp = ranges[2 * q]; first = node_off[q]; b = raw_off[q];
+  }
+  const u64 entry = live ? img.locate_tab[sp + (g - first)] : LOCATE_DIRECT;
+  if(live && (entry & LOCATE_DIRECT)) { values[b + (g - first)] = entry & ~LOCATE_DIRECT; }
+  const u64 later = __ballot(live && !(entry & LOCATE_DIRECT));
+  if(lane == 0) { later_words[j] = later; }
+}
+
+// second pass: one lane per word of marks; its path nodes have several values each.  A node with more than COOP_RUN values
+// (tandem repeats put hundreds of samples on one node) is unpacked by the whole wavefront, 64 samples at a time.
+constexpr u32 COOP_RUN = 16;
+
+__global__ __launch_bounds__(TPB) void k_locate_tab_rest(DevImage img, const u64* __restrict__ ranges, const u64* __restrict__ node_off,
+                                                         const u64* __restrict__ raw_off, u64 total_nodes, u64* __restrict__ values,
+                                                         const u64* __restrict__ owners, const u64* __restrict__ later_words, u64 spans,
+                                                         unsigned long long* __restrict__ extra_slots)
+{
+  const u64 j = u64(blockIdx.x) * TPB + threadIdx.x;
+  const u32 lane = threadIdx.x & 63;
+  u64 marks = (j < spans ? later_words[j] : 0);
+  u64 qa = 0, qb = 0;
+  const u64 g_first = j * OWNER_SPAN;
+  const u64 g_end = (g_first + OWNER_SPAN <= total_nodes ? g_first + OWNER_SPAN : total_nodes);
+  if(marks != 0) { qa = owners[j]; qb = owners[j + 1]; }
+  while(__any(marks != 0))                                   // uniform over the wavefront: the lanes with marks take one node each
+  {
+    u64 s = 0, steps = 0, at = 0, end = 0;
+    u32 count = 0;
+    if(marks != 0)
+    {
+      const u64 g = g_first + u64(__ffsll((long long)marks) - 1);
+      marks &= marks - 1;
+      const u64 q = owner_between(node_off, qa, qb, g_first, g_end, g);
+      const u64 b = raw_off[q], first = node_off[q];
+      end = raw_off[q + 1];
+      const u64 entry = img.locate_tab[ranges[2 * q] + (g - first)];
+      s = entry & ((u64(1) << LOCATE_INDEX_BITS) - 1); steps = entry >> LOCATE_INDEX_BITS;
+      count = sample_run(img, s);
+      values[b + (g - first)] = packed_get(img.stored, img.sample_width, s) + steps;
+      // (the guard below only matters for an index whose counters disagree with its samples: nothing is written outside the query's segment)
+      if(count > 1) { at = b + (node_off[q + 1] - first) + atomicAdd(extra_slots + q, (unsigned long long)(count - 1)); }
+      if(count <= COOP_RUN)
+      {
+        for(u32 k = 1; k < count && at + k - 1 < end; k++) { values[at + k - 1] = packed_get(img.stored, img.sample_width, s + k) + steps; }
+      }
+    }
+    u64 big = __ballot(count > COOP_RUN);
+    while(big != 0)                                          // uniform
+    {
+      const u32 src = u32(__ffsll((long long)big)) - 1;
+      big &= big - 1;
+      const u64 run_s = __shfl(s, src), run_steps = __shfl(steps, src), run_at = __shfl(at, src), run_end = __shfl(end, src);
+      const u32 run_count = __shfl(count, src);
+      for(u32 k = 1 + lane; k < run_count; k += 64)
+      {
+        if(run_at + k - 1 < run_end) { values[run_at + k - 1] = packed_get(img.stored, img.sample_width, run_s + k) + run_steps; }
+      }
+    }
+  }
 }
 
 // Output slots for a whole workgroup with ONE atomic: every wave passes the number of slots it wants and
