@@ -75,6 +75,46 @@ def parse():
     return ap.parse_args()
 
 
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` launched plainly (no RANK / WORLD_SIZE in the environment) measures N GPUs by itself:
+    it replaces itself with `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`,
+    one rank per GPU, and rank 0 prints the line.  Under a launcher it checks that the launcher's world is the one asked
+    for.  Anything else -- fewer GPUs than ranks, a world that differs from --gpus -- ends with a non-zero exit code
+    instead of a line that says n_gpus: 1 (VERDICT r03 / ADVICE r03)."""
+    world_env = os.environ.get("WORLD_SIZE")
+    backend = os.environ.get("GCSA2_BENCH_BACKEND", "nccl")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if world_env is not None and "RANK" in os.environ:
+        if int(world_env) != args.gpus:
+            print(f"bench.py: launched with WORLD_SIZE={world_env} but --gpus {args.gpus}; refusing to report a line for "
+                  f"a world that was not asked for", file=sys.stderr, flush=True)
+            raise SystemExit(2)
+        return
+    if args.gpus == 1:
+        return
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend == "nccl" and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this host shows {have} GPU(s); refusing to measure fewer devices than "
+              f"asked for", file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching " + " ".join(cmd))
+    os.environ["GCSA2_BENCH_SELF_LAUNCHED"] = "1"
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 class Dist:
     """torch.distributed for the launch contract (rendezvous, barrier, max over ranks); the data-path gather
     is the library's own RCCL communicator (gcsa2_comm_*), created from an id broadcast through torch."""
@@ -554,9 +594,12 @@ def measure(args, D, dev, wl, steps, warmup):
             binding.pack_ranges32_device(outs[b].data_ptr(), nq, wire[b].data_ptr(), stream.cuda_stream)
         elif pack40:
             binding.pack_ranges40_device(outs[b].data_ptr(), nq, wire[b].data_ptr(), stream.cuda_stream)
-        ready = torch.cuda.Event()
+        ready = torch.cuda.Event(enable_timing=record is not None)
         ready.record(stream)
         comm_stream.wait_event(ready)
+        if record is not None:               # per-rank breakdown: pack = record[1]..record[2], gather (+ unpack) = record[3]..record[4]
+            record[2] = ready
+            record[3].record(comm_stream)
         if D.comm is not None:               # the single collective of the path: one gather of hit ranges over xGMI
             D.comm.gather(wire[b].data_ptr(), [c * wire_bytes for c in counts], recv[b].data_ptr() if root else 0, 0,
                           comm_stream.cuda_stream)
@@ -582,7 +625,7 @@ def measure(args, D, dev, wl, steps, warmup):
             binding.unpack_ranges32_device(recv[b].data_ptr(), total, gathered.data_ptr(), comm_stream.cuda_stream)
         elif root and pack40:
             binding.unpack_ranges40_device(recv[b].data_ptr(), total, gathered.data_ptr(), comm_stream.cuda_stream)
-        done = torch.cuda.Event()
+        done = record[4] if record is not None else torch.cuda.Event()
         done.record(comm_stream)
         free_ev[b] = done
 
@@ -593,7 +636,7 @@ def measure(args, D, dev, wl, steps, warmup):
     for k in range(warmup):
         step(k)
     drain()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -601,15 +644,38 @@ def measure(args, D, dev, wl, steps, warmup):
         step(k, events[k])
     drain()
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
     D.barrier()
     elapsed = D.max(time.perf_counter() - t0)
     last = (steps - 1) % nbuf if steps > 0 else 0
     d_out = outs[last]
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if steps > 0 else 0.0
+    kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events])) if steps > 0 else 0.0
+    per_rank = None
+    if D.active and steps > 0:
+        # What each rank spent per step, on its own clock: the find kernel, the wire packing, the gather as its stream saw it
+        # (on the root: receiving 7 shards + unpacking; on a peer: its send, which waits for the root to post the receive), and
+        # from kernel start of step k to kernel start of step k + 1 (the pace the rank actually kept).  The gather of step k runs
+        # on the second stream under the kernel of step k + 1: `gather_hidden_frac` = the share of gather time that did NOT
+        # lengthen the step, 1 - (pace - kernel - pack) / gather.
+        mine = dict(rank=D.rank, device=torch.cuda.current_device(), queries=nq,
+                    kernel_ms=kernel_ms,
+                    pack_ms=float(np.mean([e[1].elapsed_time(e[2]) for e in events])),
+                    gather_ms=float(np.mean([e[3].elapsed_time(e[4]) for e in events])),
+                    pace_ms=(float(np.mean([events[k][0].elapsed_time(events[k + 1][0]) for k in range(steps - 1)])) if steps > 1 else None),
+                    wall_ms_per_step=local_elapsed / steps * 1e3)
+        exposed = max(0.0, (mine["pace_ms"] if mine["pace_ms"] is not None else mine["wall_ms_per_step"]) - mine["kernel_ms"] - mine["pack_ms"])
+        mine["gather_hidden_frac"] = max(0.0, min(1.0, 1.0 - exposed / mine["gather_ms"])) if mine["gather_ms"] > 0 else None
+        mine["wire_bytes_sent"] = 0 if D.rank == 0 else nq * wire_bytes
+        mine["rccl_ranks"] = D.comm.rccl_ranks() if D.comm is not None else None
+        everyone = [None] * D.world
+        D.dist.all_gather_object(everyone, mine)
+        per_rank = everyone
     result = dict(elapsed=elapsed, kernel_ms=kernel_ms, d_out=d_out, gathered=None, pack32=pack32, pack40=pack40,
                   gather=("gcsa2_comm_gather (library RCCL communicator)" if D.comm is not None else
                           ("torch.distributed.gather (fallback)" if D.active and D.backend == "nccl" else
                            ("host copies (gloo control-flow check)" if D.active else "none (one GPU)"))))
+    result["per_rank"] = per_rank
+    result["wire_bytes_per_query"] = wire_bytes if D.active else None
     if root and steps > 0:
         result["gathered"] = gathered if packed else recv[last][: total * 16].view(torch.int64).view(total, 2)
         mine = result["gathered"][bounds[0][0]:bounds[0][1]]
@@ -1144,6 +1210,7 @@ def cpu_baseline_match_stats(ix, d_pat, d_ms, d_rng, d_fb, m, ns=4000):
 
 def main():
     args = parse()
+    launch_ranks(args)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
@@ -1155,7 +1222,7 @@ def main():
     D = Dist(dev)
     rank, world = D.rank, D.world
     if world != args.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
+        raise SystemExit(f"bench.py: world size {world} but --gpus {args.gpus}")
     from gcsa2_amd import binding
     D.make_comm(binding, local_rank)
     ceiling = measured_request_ceiling() if (rank == 0 and world == 1 and not args.no_extras) else None
@@ -1192,6 +1259,19 @@ def main():
             "roofline": roofline(args, r, wl, f"{args.workload}_{size}_{wl.m}_{args.set}"),
         }
         result["config"]["pattern_set"] = args.set
+        if r["per_rank"] is not None:
+            ranks = r["per_rank"]
+            result["multi_gpu"] = {
+                "launched_by": "bench.py itself (torch.distributed.run re-exec)" if os.environ.get("GCSA2_BENCH_SELF_LAUNCHED") else "external launcher",
+                "backend": D.backend, "gather": r["gather"], "wire_bytes_per_query": r["wire_bytes_per_query"],
+                "bytes_into_root_per_step": sum(x["wire_bytes_sent"] for x in ranks),
+                "rccl_ranks": ranks[0]["rccl_ranks"],
+                "slowest_kernel_ms": max(x["kernel_ms"] for x in ranks), "root_gather_ms": ranks[0]["gather_ms"],
+                "root_gather_hidden_frac": ranks[0]["gather_hidden_frac"],
+                "note": "per rank and step, HIP events on the rank's own streams: kernel = k_find2 over the shard; pack = wire format; "
+                        "gather = the grouped send / recv (+ unpack on the root) on the second stream, overlapping the next kernel; "
+                        "pace = kernel start to kernel start; gather_hidden_frac = 1 - (pace - kernel - pack) / gather",
+                "per_rank": ranks}
         result["config"]["all_ranges_equal_closed_form"] = checked
         if ceiling is not None:
             rr = result["roofline"]["request_rate"]

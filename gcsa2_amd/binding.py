@@ -36,7 +36,7 @@ EXPORTS = [
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
     "gcsa2_group_find_batch", "gcsa2_group_find_device", "gcsa2_group_uses_rccl",
     "gcsa2_group_match_stats_device", "gcsa2_group_locate_device", "gcsa2_comm_match_stats", "gcsa2_comm_locate",
-    "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_gather",
+    "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_rccl_ranks", "gcsa2_comm_gather",
     "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_pack_ranges40_device", "gcsa2_unpack_ranges40_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
@@ -157,6 +157,7 @@ def load_library():
     L.gcsa2_comm_destroy.restype = None
     L.gcsa2_comm_rank.argtypes = [vp]
     L.gcsa2_comm_world.argtypes = [vp]
+    L.gcsa2_comm_rccl_ranks.argtypes = [vp, C.POINTER(C.c_int)]
     L.gcsa2_comm_gather.argtypes = [vp, vp, u64p, vp, i32, vp]
     L.gcsa2_pack_ranges32_device.argtypes = [vp, u64, vp, vp]
     L.gcsa2_unpack_ranges32_device.argtypes = [vp, u64, vp, vp]
@@ -693,6 +694,12 @@ class Comm:
         _check(self._L.gcsa2_comm_create(_p8(buf), rank, world, device, C.byref(h)))
         self._h = h
         self.rank, self.world = rank, world
+
+    def rccl_ranks(self) -> int:
+        """The number of ranks RCCL itself reports for this communicator (ncclCommCount)."""
+        n = C.c_int(0)
+        _check(self._L.gcsa2_comm_rccl_ranks(self._h, C.byref(n)))
+        return n.value
 
     def gather(self, d_send, bytes_per_rank, d_recv, root=0, stream=0):
         """Enqueue the gather: rank r sends bytes_per_rank[r] bytes from device pointer d_send; the root receives

@@ -5,9 +5,21 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "gcsa2_hip.hip")
-DEPS = [SRC, os.path.join(os.path.dirname(HERE), "include", "gcsa2_hip.h")] + \
-       [os.path.join(HERE, "csrc", f) for f in ("layout.hpp", "kernels_common.hpp", "kernels_find.hpp",
-                                                 "kernels_locate.hpp", "kernels_lcp.hpp", "sdsl_reader.hpp", "sdsl_writer.hpp", "comm.hpp")]
+
+
+def _deps():
+    """Everything the library is compiled from: every file under csrc/ that the translation unit can include and
+    the public headers under include/ (globbed, so that a new header cannot be forgotten)."""
+    import glob
+    root = os.path.dirname(HERE)
+    found = [SRC]
+    found += sorted(glob.glob(os.path.join(HERE, "csrc", "*.hpp")))
+    found += sorted(glob.glob(os.path.join(HERE, "csrc", "*.h")))
+    found += sorted(glob.glob(os.path.join(root, "include", "*.h")))
+    return found
+
+
+DEPS = _deps()
 OUT = os.path.join(HERE, "lib", "libgcsa2_hip.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
@@ -16,7 +28,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wal
 
 def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
         return OUT
     cmd = ["hipcc"] + FLAGS + ["-o", OUT, SRC]
     if verbose:

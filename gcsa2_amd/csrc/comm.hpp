@@ -27,6 +27,7 @@ struct RcclApi
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -60,6 +61,7 @@ RcclApi& rccl()
     };
     bind(api.GetUniqueId, "ncclGetUniqueId"); bind(api.CommInitRank, "ncclCommInitRank");
     bind(api.CommInitAll, "ncclCommInitAll"); bind(api.CommDestroy, "ncclCommDestroy");
+    bind(api.CommCount, "ncclCommCount");
     bind(api.GroupStart, "ncclGroupStart"); bind(api.GroupEnd, "ncclGroupEnd");
     bind(api.Send, "ncclSend"); bind(api.Recv, "ncclRecv"); bind(api.GetErrorString, "ncclGetErrorString");
     api.ok = all;
@@ -193,6 +195,15 @@ void gcsa2_comm_destroy(gcsa2_comm* c)
 
 int gcsa2_comm_rank(const gcsa2_comm* c) { return c == nullptr ? -1 : c->rank; }
 int gcsa2_comm_world(const gcsa2_comm* c) { return c == nullptr ? 0 : c->world; }
+
+int gcsa2_comm_rccl_ranks(const gcsa2_comm* c, int* ranks)
+{
+  if(c == nullptr || ranks == nullptr || c->comm == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad communicator"); }
+  RcclApi& api = rccl();
+  if(!api.ok) { return fail(GCSA2_ERR_MISSING_COMPONENT, api.error); }
+  RCCL_TRY(api.CommCount(c->comm, ranks));
+  return GCSA2_OK;
+}
 
 int gcsa2_comm_gather(gcsa2_comm* c, const void* d_send, const uint64_t* bytes, void* d_recv, int root, void* stream)
 {

@@ -102,6 +102,8 @@ struct gcsa2_index
     bool ms_pieces = true;             // GCSA2_MS_PIECES=0: large host batches of matching statistics go through one copy in, one launch, one copy out
     bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the segmented radix sort
     bool zero_copy = true;             // GCSA2_ZERO_COPY=0: small host-pointer calls copy through the arenas like large ones
+    u32 seed_wide = (u32(1) << 24) - 1;   // GCSA2_SEED_WIDE: seed-table entries of this many path nodes or more are marked, not stored (tests)
+    u64 budget_bytes = 0;              // GCSA2_MEMORY_BUDGET_MB: most device memory the image may take (0: what the device has free)
   } tune;
 };
 
@@ -125,6 +127,9 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
               std::string(#expr) + ": " + hipGetErrorString(e_)); } } while(0)
 
 inline unsigned grid_for(u64 n) { return unsigned((n + TPB - 1) / TPB); }
+
+// what a memory budget (GCSA2_MEMORY_BUDGET_MB, read at create time) leaves for the next optional table
+inline u64 budget_left(const gcsa2_index* ix) { return ix->tune.budget_bytes > ix->bytes ? ix->tune.budget_bytes - ix->bytes : 0; }
 
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
                         u64 total_nodes, u64* values, u64* owners, hipStream_t stream);
@@ -494,6 +499,8 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 12, 1, 16));
     ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);
     ix->tune.ms_pieces = (knob("GCSA2_MS_PIECES", 1, 0, 1) != 0);
+    ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
+    ix->tune.budget_bytes = u64(knob("GCSA2_MEMORY_BUDGET_MB", 0, 0, long(1) << 30)) << 20;
   }
   std::memset(&ix->img, 0, sizeof(DevImage));
   DevImage& img = ix->img;
@@ -667,8 +674,19 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       const char* penv = std::getenv("GCSA2_PAIR_BLOCKS");
       const u64 nb = img.n / PAIR_BITS + 1, pair_bytes = 16 * nb * FLB_BYTES;
       size_t free_bytes = 0, total_bytes = 0;
-      if(!(penv != nullptr && std::atoi(penv) == 0) && img.sigma >= 5 && img.n > 0 && 16 * nb < u64(PAIR_FLAG) &&
-         hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && pair_bytes <= free_bytes / 3)
+      bool fits = hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && pair_bytes <= free_bytes / 3;
+      if(fits && ix->tune.budget_bytes > 0)
+      {
+        // Under a memory budget (GCSA2_MEMORY_BUDGET_MB) the tables are taken in the order of what they buy find() per byte:
+        // a seed table of up to an eighth of what the budget leaves (every character it covers removes one LF step per query
+        // for 4x the bytes), then the pair blocks (half the memory requests of the remaining steps for 10.7 bytes per path
+        // node), then the seed table grown into what is left, then the locate table (8 bytes per path node; locate() only).
+        const u64 left = budget_left(ix);
+        u64 reserve = 0;
+        for(u32 k0 = 1; k0 <= 16 && (u64(8) << (2 * k0)) <= left / 8; k0++) { reserve = u64(8) << (2 * k0); }
+        fits = pair_bytes + reserve <= left;
+      }
+      if(!(penv != nullptr && std::atoi(penv) == 0) && img.sigma >= 5 && img.n > 0 && 16 * nb < u64(PAIR_FLAG) && fits)
       {
         e = hipMalloc(&ix->d_pairs, pair_bytes);
         if(e == hipSuccess)
@@ -714,9 +732,10 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
         const u64 image_bytes = 2 * ix->bytes;
         while(k < 16 && (entry_bytes << (2 * (k + 1))) <= image_bytes && (entry_bytes << (2 * (k + 1))) <= free_bytes / 4) { k++; }
       }
+      if(ix->tune.budget_bytes > 0) { while(k > 0 && (entry_bytes << (2 * k)) > budget_left(ix)) { k--; } }
     }
     if(img.sigma < 5 || (img.n > img.e ? img.n : img.e) + 2 >= (u64(1) << SEED_SP_BITS)) { k = 0; }
-    img.kmer_k = 0; img.kmer_table = nullptr;
+    img.kmer_k = 0; img.kmer_table = nullptr; img.seed_wide = ix->tune.seed_wide;
     if(k > 0)
     {
       u64 entries = u64(1) << (2 * k);
@@ -763,6 +782,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     const char* env = std::getenv("GCSA2_LOCATE_TABLE");
     size_t free_bytes = 0, total_bytes = 0;
     bool wanted = ix->img.has_samples && ix->img.pred4 != nullptr && ix->img.n > 0 && !(env != nullptr && std::atoi(env) == 0);
+    if(wanted && ix->tune.budget_bytes > 0 && ix->img.n * sizeof(u64) > budget_left(ix)) { wanted = false; }
     if(wanted && hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && ix->img.n * sizeof(u64) <= free_bytes / 3)
     {
       u32* d_overflow = nullptr; u32 overflow = 1;
@@ -802,6 +822,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     size_t free_bytes = 0, total_bytes = 0;
     const u64 n = ix->img.n, bytes = n * sizeof(ulonglong2);
     if(env != nullptr && std::atoi(env) != 0 && n > 0 && n <= JUMP_NODE_MASK && ix->img.sigma >= 5 &&
+       (ix->tune.budget_bytes == 0 || bytes <= budget_left(ix)) &&
        hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && 2 * bytes <= free_bytes / 2)
     {
       void* other = nullptr;

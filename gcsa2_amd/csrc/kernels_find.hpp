@@ -16,12 +16,14 @@ namespace {
 //
 // One entry = 8 bytes: sp in bits [0, 40), len = ep + 1 - sp in bits [40, 64).  An empty range has
 // len = 0 (LF-produced empties and charRange of an absent character are always (x, x - 1), utils.h:93-96);
-// len = SEED_WIDE marks a range of 2^24 - 1 or more path nodes, which is searched from scratch instead.
+// len = SEED_WIDE marks a range of `wide` or more path nodes, which is searched from scratch instead (what gcsa.h:96-110
+// does for every pattern).  wide = img.seed_wide = 2^24 - 1, the largest length the field holds; tests lower it at create
+// time (GCSA2_SEED_WIDE) so that the marked entries -- on a large index only those of the few shortest k-mers -- are met.
 constexpr u64 SEED_SP_BITS = 40, SEED_SP_MASK = (u64(1) << SEED_SP_BITS) - 1, SEED_WIDE = (u64(1) << 24) - 1;
-__device__ __forceinline__ u64 seed_pack(u64 sp, u64 ep)
+__device__ __forceinline__ u64 seed_pack(u64 sp, u64 ep, u64 wide)
 {
   const u64 len = ep + 1 - sp;
-  return (sp & SEED_SP_MASK) | ((len < SEED_WIDE ? len : SEED_WIDE) << SEED_SP_BITS);
+  return (sp & SEED_SP_MASK) | ((len < wide ? len : SEED_WIDE) << SEED_SP_BITS);
 }
 
 // The table is built in place, level by level: the (j + 1)-mer t extends the j-mer t & (4^j - 1) by the character
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(TPB) void k_seed_level(DevImage img, u32 j, u64 fir
       path_node_range(img, sp, ep);
     }
   }
-  table[tix] = seed_pack(sp, ep);
+  table[tix] = seed_pack(sp, ep, img.seed_wide);
 }
 
 // ---- find, version 2: fused 128-byte LF blocks, wave-cooperative fetch through LDS -----------

@@ -116,6 +116,7 @@ struct DevImage
                                // (gcsa.h:165-183 probe order), bit 3 = sampled(node); nullptr if sigma > 8
   const u64* kmer_table;       // find() of every k-mer over comps 1..4: 4^kmer_k packed entries (kernels_find.hpp, seed_pack)
   u32 kmer_k;                  // 0 = no table
+  u32 seed_wide;               // ranges of this many path nodes or more are marked instead of stored (2^24 - 1; lower in tests)
   u32 lcp_shift;               // log2(lcp_branching) when that is a power of two (the reference's default 64), else 0
   const ulonglong2* jump_tab;  // memoised unary LF chains, one entry per path node, or nullptr: x = node reached | steps << 56
                                // (0..8 steps), y = the comps (minus 1) of those steps, 2 bits each, first step lowest

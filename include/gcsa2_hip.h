@@ -453,6 +453,9 @@ int gcsa2_comm_create(const uint8_t* id, int rank, int world, int device, gcsa2_
 void gcsa2_comm_destroy(gcsa2_comm* comm);
 int gcsa2_comm_rank(const gcsa2_comm* comm);
 int gcsa2_comm_world(const gcsa2_comm* comm);
+/* The number of ranks RCCL itself reports for the communicator (ncclCommCount): what a benchmark prints to show that the
+ * gather really spanned `world` devices. */
+int gcsa2_comm_rccl_ranks(const gcsa2_comm* comm, int* ranks);
 /* Rank r contributes bytes[r] bytes from d_send (bytes[] has `world` entries and is the same on every rank);
  * the root receives them back to back in rank order in d_recv (its own part by a device copy; d_recv may be
  * NULL elsewhere).  Enqueues on `stream` of the communicator's device and does not synchronise. */

@@ -91,3 +91,38 @@ def test_two_ranks_share_the_gpu_through_the_host(wire):
     c5 = d["config5"]
     assert c5["n_gpus"] == 2 and c5["unmodified_half_equals_closed_form"] is True
     assert c5["locate"]["count_equals_located"] is True and c5["locate"]["unmodified_half_equals_closed_form"] is True
+
+
+def test_plain_invocation_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command) starts two ranks by
+    itself and prints n_gpus: 2 with the per-rank kernel / pack / gather breakdown (reference shape of the
+    only data-parallel query path: src/algorithms.cpp:106-114, a static split)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"GCSA2_BENCH_BACKEND": "gloo"})
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--degree", "24", "--queries", "1000001", "--steps", "3", "--warmup", "1",
+                          "--no-cpu", "--no-secondary"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    check_line(d, 2, 3)
+    mg = d["multi_gpu"]
+    assert mg["launched_by"].startswith("bench.py itself") and len(mg["per_rank"]) == 2
+    assert [x["rank"] for x in mg["per_rank"]] == [0, 1] and sum(x["queries"] for x in mg["per_rank"]) == 1000001
+    for x in mg["per_rank"]:
+        assert x["kernel_ms"] > 0 and x["pack_ms"] >= 0 and x["gather_ms"] >= 0 and x["pace_ms"] > 0
+        assert x["gather_hidden_frac"] is None or 0.0 <= x["gather_hidden_frac"] <= 1.0
+
+
+def test_world_mismatch_is_refused():
+    """More GPUs asked for than the launcher's world holds, or than the host has: a non-zero exit code, never a line that
+    quietly says n_gpus: 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "64", "--degree", "20", "--queries", "1000", "--steps", "1", "--warmup", "0",
+                          "--no-cpu", "--no-secondary"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "refusing" in out.stderr
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--degree", "20", "--queries", "1000", "--steps", "1",
+                          "--warmup", "0", "--no-cpu", "--no-secondary"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]

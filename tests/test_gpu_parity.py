@@ -656,6 +656,52 @@ def test_seed_table_sizes(engine, monkeypatch):
     assert len(seen) >= 5
 
 
+@pytest.mark.parametrize("pairs", ["1", "0"], ids=["pair-blocks", "single-blocks"])
+def test_wide_seed_entries(engine, monkeypatch, pairs):
+    """A seed-table entry whose range has 2^24 - 1 or more path nodes is marked, not stored, and the pattern is searched from
+    scratch, as gcsa.h:96-110 searches every pattern.  On a large index only the shortest k-mers have such ranges, so no run
+    met the branch; GCSA2_SEED_WIDE (read at create time) lowers the threshold to 2 / 3 / 30 path nodes here: the table
+    builder's restart from charRange (k_seed_level) and the kernels' from-scratch start (k_find2, k_match_stats2) all run,
+    `wide_seeds` of the instrumented kernel says how often, and every result equals the oracle."""
+    import torch
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    g = graphs.snp_graph(6000, 0xE5, 0xE6, snp_period=9, node_len=16)
+    ix = builder.build(g, 16, sample_period=16, branching=4)
+    cpu = OracleIndex(ix)
+    pats = [truncate_at_sink(p)[: 1 + q % 24] for q, p in enumerate(random_patterns(g, 24, 0xE7, 2000))]
+    rng = SplitMix64(0xE8)
+    pats += [bytes(b"ACGTN"[rng.below(5)] for _ in range(1 + rng.below(14))) for _ in range(600)] + [b"", b"A", b"AC", b"ACG"]
+    data, off = concat_patterns(pats)
+    want = cpu.find_batch(data, off)
+    cm, cr, cf = cpu.match_stats_batch(data, off, threads=2)
+    dev = torch.device("cuda", 0)
+    d_pat = torch.zeros(int(off[-1]) + 16, dtype=torch.uint8, device=dev)
+    d_pat[: int(off[-1])] = torch.from_numpy(data[: int(off[-1])]).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64).copy()).to(dev)
+    monkeypatch.setenv("GCSA2_PAIR_BLOCKS", pairs)
+    hits = []
+    for wide, k in (("2", "3"), ("3", "6"), ("30", "4"), ("2", "8"), (None, "3")):
+        monkeypatch.setenv("GCSA2_KMER_TABLE", k)
+        if wide is None:
+            monkeypatch.delenv("GCSA2_SEED_WIDE", raising=False)
+        else:
+            monkeypatch.setenv("GCSA2_SEED_WIDE", wide)
+        gpu, lcp = engine.open_index(ix, device=0)
+        assert gpu.kmer_table_k() == int(k) and (gpu.pair_block_bytes() > 0) == (pairs == "1")
+        assert np.array_equal(gpu.find_batch(data, off), want), (wide, k)
+        d_out = torch.zeros((len(pats), 2), dtype=torch.int64, device=dev)
+        d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
+        gpu.find_stats_device(d_pat.data_ptr(), d_off.data_ptr(), len(pats), d_out.data_ptr(), d_stats.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), (wide, k)
+        hits.append(int(d_stats[6].item()))
+        gm, gr, gf = gpu.match_stats_batch(data, off)
+        assert np.array_equal(gm, cm) and np.array_equal(gr, cr) and np.array_equal(gf, cf), (wide, k)
+        gpu.close()
+    assert all(h > 0 for h in hits[:4]) and hits[4] == 0, hits       # the branch ran in every lowered setting, never at the default
+
+
 def test_deep_lcp_tree(engine):
     """A binary range-minimum tree (branching 2, the smallest the reference's constructor accepts) over 70 k values has 18
     levels: more than the 16 an earlier build admitted.  Every LCP operation equals the oracle."""
