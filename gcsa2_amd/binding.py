@@ -20,7 +20,7 @@ STATUS = {0: "OK", -1: "INVALID_ARGUMENT", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY",
           -5: "MISSING_COMPONENT", -6: "BUFFER_TOO_SMALL"}
 
 EXPORTS = [
-    "gcsa2_device_count", "gcsa2_index_create", "gcsa2_index_destroy", "gcsa2_last_error",
+    "gcsa2_device_count", "gcsa2_index_create", "gcsa2_index_destroy", "gcsa2_index_set_tables", "gcsa2_last_error",
     "gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count", "gcsa2_sample_bits",
     "gcsa2_device", "gcsa2_device_bytes", "gcsa2_block_bits",
     "gcsa2_find_batch", "gcsa2_find_device", "gcsa2_find_stats_device", "gcsa2_find_device_variant",
@@ -78,6 +78,7 @@ def load_library():
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.gcsa2_last_error.restype = C.c_char_p
     L.gcsa2_index_create.argtypes = [C.POINTER(HostView), i32, C.POINTER(vp)]
+    L.gcsa2_index_set_tables.argtypes = [vp, i32, i32, i32]
     L.gcsa2_index_destroy.argtypes = [vp]
     L.gcsa2_index_destroy.restype = None
     for name in ("gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count",
@@ -364,6 +365,11 @@ class GCSA:
 
     def jump_table_bytes(self):
         return int(self._L.gcsa2_jump_table_bytes(self._h))
+
+    def set_tables(self, pair_blocks=-1, kmer_k=-1, locate_table=-1):
+        """Drop (0) / build (1) / leave (-1) the pair blocks and the locate table, resize the k-mer seed table (0 drops it):
+        gcsa2_index_set_tables.  Results of every query stay the same; no queries may run on the handle meanwhile."""
+        _check(self._L.gcsa2_index_set_tables(self._h, int(pair_blocks), int(kmer_k), int(locate_table)))
 
     def pair_block_bytes(self):
         return int(self._L.gcsa2_pair_block_bytes(self._h))

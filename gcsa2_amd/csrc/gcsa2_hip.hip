@@ -134,6 +134,129 @@ inline u64 budget_left(const gcsa2_index* ix) { return ix->tune.budget_bytes > i
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
                         u64 total_nodes, u64* values, u64* owners, hipStream_t stream);
 
+// ---- the optional tables of an image (pair blocks, k-mer seed table, locate table): built at create time and again by
+// gcsa2_index_set_tables.  Each maker leaves the image without the table when it fails.
+
+inline u64 pair_block_bytes_of(const DevImage& img) { return 16 * (img.n / PAIR_BITS + 1) * FLB_BYTES; }
+inline bool pair_blocks_possible(const DevImage& img) { return img.sigma >= 5 && img.n > 0 && 16 * (img.n / PAIR_BITS + 1) < u64(PAIR_FLAG); }
+inline bool seed_table_possible(const DevImage& img) { return img.sigma >= 5 && (img.n > img.e ? img.n : img.e) + 2 < (u64(1) << SEED_SP_BITS); }
+inline bool locate_table_possible(const DevImage& img) { return img.has_samples && img.pred4 != nullptr && img.n > 0; }
+
+void drop_pair_blocks(gcsa2_index* ix)
+{
+  if(ix->d_pairs != nullptr) { (void)hipFree(ix->d_pairs); ix->d_pairs = nullptr; ix->bytes -= pair_block_bytes_of(ix->img); }
+  ix->img.flp = nullptr; ix->img.flp_nblocks = 0;
+}
+
+hipError_t make_pair_blocks(gcsa2_index* ix)
+{
+  drop_pair_blocks(ix);
+  DevImage& img = ix->img;
+  const u64 nb = img.n / PAIR_BITS + 1, pair_bytes = pair_block_bytes_of(img);
+  hipError_t e = hipMalloc(&ix->d_pairs, pair_bytes);
+  if(e == hipSuccess)
+  {
+    img.flp_nblocks = nb;
+    const u64 slice = u64(1) << 20;          // blocks per launch: 2^20 x 4 workgroups of 192 threads
+    for(u64 first = 0; first < nb && e == hipSuccess; first += slice)
+    {
+      const u64 count = (nb - first < slice ? nb - first : slice);
+      hipLaunchKernelGGL(k_build_pair_blocks, dim3(unsigned(count), 4), dim3(unsigned(PAIR_BITS)), 0, nullptr, img, first, static_cast<u64*>(ix->d_pairs));
+      e = hipGetLastError();
+    }
+    if(e == hipSuccess) { e = hipDeviceSynchronize(); }
+  }
+  if(e != hipSuccess)
+  {
+    if(ix->d_pairs != nullptr) { (void)hipFree(ix->d_pairs); ix->d_pairs = nullptr; }
+    img.flp_nblocks = 0; (void)hipGetLastError();
+    return e;
+  }
+  img.flp = static_cast<const u64*>(ix->d_pairs);
+  ix->bytes += pair_bytes;
+  return hipSuccess;
+}
+
+void drop_seed_table(gcsa2_index* ix)
+{
+  if(ix->d_kmer != nullptr) { (void)hipFree(ix->d_kmer); ix->d_kmer = nullptr; ix->bytes -= u64(8) << (2 * ix->img.kmer_k); }
+  ix->img.kmer_table = nullptr; ix->img.kmer_k = 0;
+}
+
+// find() of every k-mer over comps 1..4, level by level in place (kernels_find.hpp: k_seed_level); 1 <= k <= 16
+hipError_t make_seed_table(gcsa2_index* ix, u32 k)
+{
+  drop_seed_table(ix);
+  DevImage& img = ix->img;
+  img.seed_wide = ix->tune.seed_wide;
+  const u64 entry_bytes = 8, entries = u64(1) << (2 * k);
+  hipError_t e = hipMalloc(&ix->d_kmer, entries * entry_bytes);
+  const u64 slice = u64(1) << 30;            // a HIP grid holds < 2^32 threads
+  for(u32 j = 0; j < k && e == hipSuccess; j++)
+  {
+    // level j + 1 from level j: first the quarters with a non-zero leading code, then level j in place
+    const u64 have = u64(1) << (2 * j), want = have << 2;
+    for(int pass = 0; pass < 2 && e == hipSuccess; pass++)
+    {
+      const u64 lo = (j == 0 ? 0 : (pass == 0 ? have : 0)), hi = (j == 0 ? (pass == 0 ? want : 0) : (pass == 0 ? want : have));
+      for(u64 first = lo; first < hi && e == hipSuccess; first += slice)
+      {
+        u64 count = (hi - first < slice ? hi - first : slice);
+        hipLaunchKernelGGL(k_seed_level, dim3(grid_for(count)), dim3(TPB), 0, nullptr, img, j, first, first + count, static_cast<u64*>(ix->d_kmer));
+        e = hipGetLastError();
+      }
+    }
+  }
+  if(e == hipSuccess) { e = hipDeviceSynchronize(); }
+  if(e != hipSuccess)
+  {
+    if(ix->d_kmer != nullptr) { (void)hipFree(ix->d_kmer); ix->d_kmer = nullptr; }
+    (void)hipGetLastError();
+    return e;
+  }
+  img.kmer_table = static_cast<const u64*>(ix->d_kmer); img.kmer_k = k;
+  ix->bytes += entries * entry_bytes;
+  return hipSuccess;
+}
+
+void drop_locate_table(gcsa2_index* ix)
+{
+  if(ix->d_locate != nullptr) { (void)hipFree(ix->d_locate); ix->d_locate = nullptr; ix->bytes -= ix->img.n * sizeof(u64); }
+  ix->img.locate_tab = nullptr;
+}
+
+// the walk of locateInternal (gcsa.cpp:880-896) memoised for every path node; false when an entry does not fit or on any error
+bool make_locate_table(gcsa2_index* ix)
+{
+  drop_locate_table(ix);
+  u32* d_overflow = nullptr; u32 overflow = 1;
+  hipError_t e = hipMalloc(&ix->d_locate, ix->img.n * sizeof(u64));
+  if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&d_overflow), sizeof(u32)); }
+  if(e == hipSuccess) { e = hipMemset(d_overflow, 0, sizeof(u32)); }
+  if(e == hipSuccess)
+  {
+    const u64 slice = u64(1) << 30;
+    for(u64 first = 0; first < ix->img.n && e == hipSuccess; first += slice)
+    {
+      u64 count = (ix->img.n - first < slice ? ix->img.n - first : slice);
+      hipLaunchKernelGGL(k_build_locate_table, dim3(unsigned((count + TPB2 - 1) / TPB2)), dim3(TPB2), 0, nullptr,
+                         ix->img, first, static_cast<u64*>(ix->d_locate), d_overflow);
+      e = hipGetLastError();
+    }
+    if(e == hipSuccess) { e = hipMemcpy(&overflow, d_overflow, sizeof(u32), hipMemcpyDeviceToHost); }
+  }
+  if(d_overflow) { (void)hipFree(d_overflow); }
+  if(e == hipSuccess && overflow == 0)
+  {
+    ix->img.locate_tab = static_cast<const u64*>(ix->d_locate);
+    ix->bytes += ix->img.n * sizeof(u64);
+    return true;
+  }
+  if(ix->d_locate) { (void)hipFree(ix->d_locate); ix->d_locate = nullptr; }
+  (void)hipGetLastError();
+  return false;
+}
+
 // host-side staging of the device image --------------------------------------------------
 
 // The image is laid out first (offsets only), allocated once, and filled by the kernels of kernels_build.hpp.
@@ -500,7 +623,11 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);
     ix->tune.ms_pieces = (knob("GCSA2_MS_PIECES", 1, 0, 1) != 0);
     ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
-    ix->tune.budget_bytes = u64(knob("GCSA2_MEMORY_BUDGET_MB", 0, 0, long(1) << 30)) << 20;
+    {
+      const char* b = std::getenv("GCSA2_MEMORY_BUDGET_MB");           // megabytes, fractions allowed (small test indexes)
+      const double mb = (b != nullptr && *b != 0 ? std::atof(b) : 0.0);
+      ix->tune.budget_bytes = (mb > 0.0 ? u64(mb * 1048576.0) : 0);
+    }
   }
   std::memset(&ix->img, 0, sizeof(DevImage));
   DevImage& img = ix->img;
@@ -672,7 +799,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     img.flp = nullptr; img.flp_nblocks = 0;
     {
       const char* penv = std::getenv("GCSA2_PAIR_BLOCKS");
-      const u64 nb = img.n / PAIR_BITS + 1, pair_bytes = 16 * nb * FLB_BYTES;
+      const u64 pair_bytes = pair_block_bytes_of(img);
       size_t free_bytes = 0, total_bytes = 0;
       bool fits = hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && pair_bytes <= free_bytes / 3;
       if(fits && ix->tune.budget_bytes > 0)
@@ -686,28 +813,14 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
         for(u32 k0 = 1; k0 <= 16 && (u64(8) << (2 * k0)) <= left / 8; k0++) { reserve = u64(8) << (2 * k0); }
         fits = pair_bytes + reserve <= left;
       }
-      if(!(penv != nullptr && std::atoi(penv) == 0) && img.sigma >= 5 && img.n > 0 && 16 * nb < u64(PAIR_FLAG) && fits)
+      if(!(penv != nullptr && std::atoi(penv) == 0) && pair_blocks_possible(img) && fits)
       {
-        e = hipMalloc(&ix->d_pairs, pair_bytes);
-        if(e == hipSuccess)
-        {
-          img.flp_nblocks = nb;
-          const u64 slice = u64(1) << 20;          // blocks per launch: 2^20 x 4 workgroups of 192 threads
-          for(u64 first = 0; first < nb && e == hipSuccess; first += slice)
-          {
-            const u64 count = (nb - first < slice ? nb - first : slice);
-            hipLaunchKernelGGL(k_build_pair_blocks, dim3(unsigned(count), 4), dim3(unsigned(PAIR_BITS)), 0, nullptr, img, first, static_cast<u64*>(ix->d_pairs));
-            e = hipGetLastError();
-          }
-          if(e == hipSuccess) { e = hipDeviceSynchronize(); }
-        }
+        e = make_pair_blocks(ix);
         if(e != hipSuccess)
         {
           gcsa2_index_destroy(ix);
           return fail(GCSA2_ERR_HIP, std::string("pair blocks: ") + hipGetErrorString(e));
         }
-        img.flp = static_cast<const u64*>(ix->d_pairs);
-        ix->bytes += pair_bytes;
       }
     }
 
@@ -734,36 +847,16 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
       }
       if(ix->tune.budget_bytes > 0) { while(k > 0 && (entry_bytes << (2 * k)) > budget_left(ix)) { k--; } }
     }
-    if(img.sigma < 5 || (img.n > img.e ? img.n : img.e) + 2 >= (u64(1) << SEED_SP_BITS)) { k = 0; }
+    if(!seed_table_possible(img)) { k = 0; }
     img.kmer_k = 0; img.kmer_table = nullptr; img.seed_wide = ix->tune.seed_wide;
     if(k > 0)
     {
-      u64 entries = u64(1) << (2 * k);
-      e = hipMalloc(&ix->d_kmer, entries * entry_bytes);
-      const u64 slice = u64(1) << 30;            // a HIP grid holds < 2^32 threads
-      for(u32 j = 0; j < k && e == hipSuccess; j++)
-      {
-        // level j + 1 from level j: first the quarters with a non-zero leading code, then level j in place
-        const u64 have = u64(1) << (2 * j), want = have << 2;
-        for(int pass = 0; pass < 2 && e == hipSuccess; pass++)
-        {
-          const u64 lo = (j == 0 ? 0 : (pass == 0 ? have : 0)), hi = (j == 0 ? (pass == 0 ? want : 0) : (pass == 0 ? want : have));
-          for(u64 first = lo; first < hi && e == hipSuccess; first += slice)
-          {
-            u64 count = (hi - first < slice ? hi - first : slice);
-            hipLaunchKernelGGL(k_seed_level, dim3(grid_for(count)), dim3(TPB), 0, nullptr, img, j, first, first + count, static_cast<u64*>(ix->d_kmer));
-            e = hipGetLastError();
-          }
-        }
-      }
-      if(e == hipSuccess) { e = hipDeviceSynchronize(); }
+      e = make_seed_table(ix, k);
       if(e != hipSuccess)
       {
         gcsa2_index_destroy(ix);
         return fail(GCSA2_ERR_HIP, std::string("k-mer table: ") + hipGetErrorString(e));
       }
-      img.kmer_table = static_cast<const u64*>(ix->d_kmer); img.kmer_k = k;
-      ix->bytes += entries * entry_bytes;
     }
   }
   catch(const std::bad_alloc&)
@@ -781,37 +874,11 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
   {
     const char* env = std::getenv("GCSA2_LOCATE_TABLE");
     size_t free_bytes = 0, total_bytes = 0;
-    bool wanted = ix->img.has_samples && ix->img.pred4 != nullptr && ix->img.n > 0 && !(env != nullptr && std::atoi(env) == 0);
+    bool wanted = locate_table_possible(ix->img) && !(env != nullptr && std::atoi(env) == 0);
     if(wanted && ix->tune.budget_bytes > 0 && ix->img.n * sizeof(u64) > budget_left(ix)) { wanted = false; }
     if(wanted && hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && ix->img.n * sizeof(u64) <= free_bytes / 3)
     {
-      u32* d_overflow = nullptr; u32 overflow = 1;
-      hipError_t e = hipMalloc(&ix->d_locate, ix->img.n * sizeof(u64));
-      if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&d_overflow), sizeof(u32)); }
-      if(e == hipSuccess) { e = hipMemset(d_overflow, 0, sizeof(u32)); }
-      if(e == hipSuccess)
-      {
-        const u64 slice = u64(1) << 30;
-        for(u64 first = 0; first < ix->img.n && e == hipSuccess; first += slice)
-        {
-          u64 count = (ix->img.n - first < slice ? ix->img.n - first : slice);
-          hipLaunchKernelGGL(k_build_locate_table, dim3(unsigned((count + TPB2 - 1) / TPB2)), dim3(TPB2), 0, nullptr,
-                             ix->img, first, static_cast<u64*>(ix->d_locate), d_overflow);
-          e = hipGetLastError();
-        }
-        if(e == hipSuccess) { e = hipMemcpy(&overflow, d_overflow, sizeof(u32), hipMemcpyDeviceToHost); }
-      }
-      if(d_overflow) { (void)hipFree(d_overflow); }
-      if(e == hipSuccess && overflow == 0)
-      {
-        ix->img.locate_tab = static_cast<const u64*>(ix->d_locate);
-        ix->bytes += ix->img.n * sizeof(u64);
-      }
-      else
-      {
-        if(ix->d_locate) { (void)hipFree(ix->d_locate); ix->d_locate = nullptr; }
-        (void)hipGetLastError();
-      }
+      (void)make_locate_table(ix);
     }
   }
   // memoised unary LF chains for find(): 16 bytes per path node, opt-in (GCSA2_JUMP_TABLE=1).  Built by
@@ -861,6 +928,39 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     }
   }
   *out = ix;
+  return GCSA2_OK;
+}
+
+int gcsa2_index_set_tables(gcsa2_index* ix, int pair_blocks, int kmer_k, int locate_table)
+{
+  if(ix == nullptr || pair_blocks < -1 || pair_blocks > 1 || locate_table < -1 || locate_table > 1 || kmer_k < -1 || kmer_k > 16)
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "set_tables: pair_blocks / locate_table in {-1, 0, 1}, kmer_k in -1 .. 16");
+  }
+  DeviceGuard guard(ix->device);
+  if(!guard.ok) { return fail(GCSA2_ERR_HIP, "hipSetDevice failed"); }
+  HIP_TRY(hipDeviceSynchronize());           // launches in flight hold the old pointers
+  // drops first, so that what is built next finds the memory
+  if(pair_blocks == 0) { drop_pair_blocks(ix); }
+  if(locate_table == 0) { drop_locate_table(ix); }
+  if(kmer_k >= 0 && u32(kmer_k) != ix->img.kmer_k) { drop_seed_table(ix); }
+  if(kmer_k > 0 && ix->img.kmer_k == 0)
+  {
+    if(!seed_table_possible(ix->img)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "this index cannot have a seed table (no comps 1..4, or positions beyond 40 bits)"); }
+    hipError_t e = make_seed_table(ix, u32(kmer_k));
+    if(e != hipSuccess) { return fail(e == hipErrorOutOfMemory ? GCSA2_ERR_OUT_OF_MEMORY : GCSA2_ERR_HIP, std::string("k-mer table: ") + hipGetErrorString(e)); }
+  }
+  if(pair_blocks == 1 && ix->img.flp == nullptr)
+  {
+    if(!pair_blocks_possible(ix->img)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "this index cannot have pair blocks"); }
+    hipError_t e = make_pair_blocks(ix);
+    if(e != hipSuccess) { return fail(e == hipErrorOutOfMemory ? GCSA2_ERR_OUT_OF_MEMORY : GCSA2_ERR_HIP, std::string("pair blocks: ") + hipGetErrorString(e)); }
+  }
+  if(locate_table == 1 && ix->img.locate_tab == nullptr)
+  {
+    if(!locate_table_possible(ix->img)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "this index cannot have a locate table (no samples)"); }
+    if(!make_locate_table(ix)) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "locate table: no memory, or an entry that does not fit"); }
+  }
   return GCSA2_OK;
 }
 

@@ -124,6 +124,18 @@ int gcsa2_device_count(void);
 int gcsa2_index_create(const gcsa2_host_view* view, int device, gcsa2_index** out);
 void gcsa2_index_destroy(gcsa2_index* index);
 
+/* The optional tables of an image -- memoisations of reference functions that change no result: the two-character pair
+ * blocks (10.7 bytes per path node; two LF steps of gcsa.h:155-162 per memory request), the k-mer seed table (8 * 4^k bytes;
+ * find() of every k-mer, gcsa.h:96-110) and the locate table (8 bytes per path node; the walk of locateInternal,
+ * src/gcsa.cpp:880-896).  gcsa2_index_create builds what the free device memory allows, or what the environment says, read
+ * once at create time: GCSA2_PAIR_BLOCKS=0, GCSA2_KMER_TABLE=k, GCSA2_LOCATE_TABLE=0, and GCSA2_MEMORY_BUDGET_MB=m, a cap on
+ * the whole image under which the tables are taken in the order seed table (small) / pair blocks / seed table (grown) /
+ * locate table.  gcsa2_index_set_tables re-shapes an existing image, e.g. to give memory back under pressure:
+ * pair_blocks and locate_table: 0 = drop, 1 = build if absent, -1 = leave; kmer_k: 0 = drop, 1..16 = exactly that size,
+ * -1 = leave.  It waits for the device to idle first; the caller must not run queries on this handle (or on facade copies
+ * sharing it) during the call.  On failure the table in question is absent and every query still works. */
+int gcsa2_index_set_tables(gcsa2_index* index, int pair_blocks, int kmer_k, int locate_table);
+
 /* Thread-local description of the last failing call. */
 const char* gcsa2_last_error(void);
 

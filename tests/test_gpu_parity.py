@@ -545,6 +545,75 @@ def test_locate_table_and_walk_agree(engine, monkeypatch):
                     assert np.array_equal(gv, np.concatenate(want) if len(want) else gv)
 
 
+def test_memory_ladder(engine, monkeypatch):
+    """The optional tables (pair blocks, k-mer seed table, locate table) are memoisations: find(), locate() and the matching
+    statistics equal the oracle on every rung of the memory ladder, whether the rung is reached by re-shaping a live image
+    (gcsa2_index_set_tables: drop, rebuild, resize) or by creating the image under a cap (GCSA2_MEMORY_BUDGET_MB: seed table
+    first, then pair blocks, then a larger seed table, then the locate table)."""
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    g = graphs.snp_graph(40000, 0xB1, 0xB2, snp_period=12, node_len=16)
+    ix = builder.build(g, 16, sample_period=16, branching=8)
+    cpu = OracleIndex(ix)
+    pats = [truncate_at_sink(p) for p in random_patterns(g, 40, 0xB3, 3000)]
+    rng = SplitMix64(0xB4)
+    pats += [bytes(b"ACGTN"[rng.below(5)] for _ in range(1 + rng.below(20))) for _ in range(500)]
+    data, off = concat_patterns(pats)
+    want = cpu.find_batch(data, off)
+    co, cv = cpu.locate_batch(want)
+    cm, cr, cf = cpu.match_stats_batch(data, off, threads=2)
+
+    def check(gpu, tag):
+        got = gpu.find_batch(data, off)
+        assert np.array_equal(got, want), tag
+        go, gv = gpu.locate_batch(got)
+        assert np.array_equal(go, co) and np.array_equal(gv, cv), tag
+        gm, gr, gf = gpu.match_stats_batch(data, off)
+        assert np.array_equal(gm, cm) and np.array_equal(gr, cr) and np.array_equal(gf, cf), tag
+
+    pair_bytes, locate_bytes = 16 * (ix.n // 192 + 1) * 128, 8 * ix.n
+    gpu, lcp = engine.open_index(ix, device=0)
+    full, k_full = gpu.device_bytes(), gpu.kmer_table_k()
+    assert gpu.pair_block_bytes() == pair_bytes and gpu.locate_table_bytes() == locate_bytes and k_full >= 6
+    check(gpu, "everything")
+    gpu.set_tables(locate_table=0)
+    assert gpu.locate_table_bytes() == 0 and gpu.device_bytes() == full - locate_bytes
+    check(gpu, "no locate table")
+    gpu.set_tables(kmer_k=k_full - 1)
+    assert gpu.kmer_table_k() == k_full - 1 and gpu.device_bytes() == full - locate_bytes - 6 * 4 ** k_full
+    check(gpu, "smaller seed table")
+    gpu.set_tables(pair_blocks=0, kmer_k=4)
+    assert gpu.pair_block_bytes() == 0 and gpu.kmer_table_k() == 4
+    bare = gpu.device_bytes() - 8 * 4 ** 4
+    check(gpu, "no pair blocks, k = 4")
+    gpu.set_tables(kmer_k=0)
+    assert gpu.kmer_table_k() == 0 and gpu.device_bytes() == bare
+    check(gpu, "bare image")
+    gpu.set_tables(pair_blocks=1, kmer_k=k_full, locate_table=1)           # and back up
+    assert gpu.device_bytes() == full and gpu.pair_block_bytes() == pair_bytes and gpu.locate_table_bytes() == locate_bytes
+    check(gpu, "rebuilt")
+    with pytest.raises(engine.Gcsa2Error):
+        gpu.set_tables(kmer_k=17)
+    gpu.close()
+
+    # the same ladder by creating under a cap; MB with fractions, since this index is small
+    mb = 1048576.0
+    seen = []
+    for budget in (full + 1, full - locate_bytes // 2, bare + pair_bytes + 8 * 4 ** 5, bare + pair_bytes // 2, bare // 2):
+        monkeypatch.setenv("GCSA2_MEMORY_BUDGET_MB", repr(budget / mb))
+        capped, _ = engine.open_index(ix, device=0)
+        assert capped.device_bytes() <= max(budget, bare), budget          # the image proper is never refused: only tables are dropped
+        seen.append((capped.pair_block_bytes() > 0, capped.kmer_table_k(), capped.locate_table_bytes() > 0))
+        check(capped, f"budget {budget}")
+        capped.close()
+    monkeypatch.delenv("GCSA2_MEMORY_BUDGET_MB")
+    assert seen[0] == (True, k_full, True), seen
+    assert seen[1][0] and not seen[1][2] and seen[1][1] >= k_full - 1, seen        # the locate table goes first
+    assert seen[2][0] and not seen[2][2] and 5 <= seen[2][1] < k_full, seen        # then the seed table shrinks
+    assert not seen[3][0] and not seen[3][2] and seen[3][1] >= 5, seen             # then the pair blocks go, a seed table stays
+    assert seen[4] == (False, 0, False), seen                                      # below the image itself: no tables at all
+
+
 def test_locate_many_small_calls(engine):
     """Thousands of one-range locate() calls in a row (the access pattern of locate(range, max_positions),
     gcsa.cpp:859-871): every call returns exactly count() values.  Guards the host read-backs of the
