@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the config-5 and chr22 measurements")
     ap.add_argument("--no-extras", action="store_true", help="skip the request-rate ceiling, the device telemetry and the host-batch leg "
                                                                "(profiler passes: only the timed kernel and its instrumented twin run)")
-    ap.add_argument("--secondary", choices=["all", "config5", "chr22", "repeats", "human32", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
+    ap.add_argument("--secondary", choices=["all", "config5", "wide", "ladder", "chr22", "repeats", "repeats30", "human32", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
     ap.add_argument("--variant", type=int, default=2, help="find launch shape (2 = one lane per query in batch order, 4 = queries ordered by length first)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
@@ -401,7 +401,7 @@ def setup_pangenome(args, D, dev, local_rank, total_queries=None):
     # (config 5 runs sharded at N > 1, so every rank needs them)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", D.world))
     # (both decisions are taken together: ranks that read /proc/meminfo at different moments must not disagree)
-    full = (not args.no_secondary and kind != "snp" and args.secondary in ("all", "config5")
+    full = (not args.no_secondary and kind != "snp" and args.secondary in ("all", "config5", "ladder")
             and (degree <= 20 or D.all_true(host_memory_ok(local_world * 9 * dbg_torch.text_length(degree)))))
     need = local_world * (9 if full else 3) * dbg_torch.text_length(degree) * (1.25 if kind == "snp" else 1.0)
     if degree > 20 and not D.all_true(host_memory_ok(need)):
@@ -1094,6 +1094,176 @@ def repeats_secondary(args, D, dev, local_rank):
     return out
 
 
+# ---- wide ranges and the memory ladder on the headline index ---------------------------------
+
+class Leg(Workload):
+    """The headline's image with another batch of patterns: what measure() / roofline() / find_config() read."""
+
+    def __init__(self, wl, d_pat, nq, m, label):
+        import torch
+        super().__init__()
+        self.gpu, self.ix, self.scaling = wl.gpu, wl.ix, "strong"
+        self.d_pat, self.nq, self.m, self.total_queries, self.first = d_pat, nq, m, nq, 0
+        self.d_off = torch.arange(nq + 1, dtype=torch.int64, device=d_pat.device) * m
+        self.label = label
+
+
+def find_leg(args, D, dev, leg, steps, expect=None):
+    """One find() measurement as a compact object: rate, requests per query, share of steps that fetch a second block
+    (a range whose ends lie in different blocks), mean range width, roofline, and the closed-form check."""
+    import torch
+    r = measure(args, D, dev, leg, steps, 1)
+    d_out = r["d_out"]
+    width = (d_out[:, 1] - d_out[:, 0] + 1).to(torch.float64)
+    rf = roofline(args, r, leg, "unprofiled")
+    out = {"workload": leg.label, "value": leg.nq / (r["kernel_ms"] * 1e-3), "unit": "queries/s", "kernel_ms": r["kernel_ms"], "queries": leg.nq,
+           "pattern_len": leg.m, "kmer_table_k": leg.gpu.kmer_table_k(), "pair_blocks": bool(leg.gpu.pair_block_bytes()),
+           "mean_range_width_path_nodes": float(width.mean().item()), "ranges_wider_than_one": float((width > 1).to(torch.float64).mean().item()),
+           "lf_steps_per_query": r["lf_steps"] / leg.nq, "blocks_per_query": r["blocks"] / leg.nq,
+           "requests_per_query": rf["request_rate"]["requests_per_query"], "requests_G_per_s": rf["request_rate"]["achieved_G_per_s"],
+           "second_fetch_fraction_of_steps": r["second_fetches"] / max(r["fetch_steps"], 1), "wide_seed_entries_hit": r["wide_seeds"],
+           "algorithmic_bytes_per_launch": r["algo_bytes"], "achieved_GBps": rf["achieved"], "frac": rf["frac"],
+           "working_set_bytes": rf["working_set_bytes"], "image_bytes_hbm": leg.gpu.device_bytes()}
+    if expect is not None:
+        out["all_ranges_equal_closed_form"] = bool(expect(d_out))
+    return out, d_out
+
+
+def wide_ranges_secondary(args, D, dev, wl):
+    """The hot path on WIDE ranges at HBM footprint, on the headline index itself.  (i) 12-, 14- and 16-mers: prefixes of
+    path labels, whose ranges are intervals of the k-mer bitmap's ranks (workload/dbg_torch.py::prefix_patterns_device):
+    ~341 / 21 / 1.3 path nodes per range at 5.73 G nodes; shorter than the seed table's k, the 12- and 14-mers are searched
+    from charRange on, every step on a range of thousands to millions of path nodes (sp and ep + 1 in different blocks: two
+    memory requests per step).  (ii) The headline's 32-mers with the seed table cut to k = 8 (gcsa2_index_set_tables): 24
+    steps per query, the first nine of them on wide ranges (4^9 = 262 144 -> 1 path nodes).  Every range is checked against
+    its closed form.  The headline's own batch (k = 16) meets no wide range after its seed entry."""
+    import torch
+    from workload import dbg_torch
+    out = {}
+    k_full = wl.gpu.kmer_table_k()
+    nq = min(25_000_000, max(100_000, wl.total_queries // 4))
+    k = wl.dbg.k
+    for m in ((12, 14, 16) if k == 17 else sorted({max(1, k - 5), max(1, k - 3), k - 1})):       # (small test indexes: scaled with k)
+        pats, sp, ep = dbg_torch.prefix_patterns_device(wl.dbg, 0, nq, m, HUMAN_PATTERN_SEED + 0x100 + m)
+        leg = Leg(wl, padded_bytes(pats), nq, m, f"{nq} x {m}-mers, prefixes of path labels of the headline index (closed form: rank interval of the k-mer bitmap)")
+        del pats
+        out[f"{m}-mers"], _ = find_leg(args, D, dev, leg, 5, expect=lambda d: torch.equal(d[:, 0], sp) and torch.equal(d[:, 1], ep))
+        del leg, sp, ep
+    k_cut = min(8, max(1, wl.dbg.k // 2))
+    if k_full > k_cut:
+        wl.gpu.set_tables(kmer_k=k_cut)
+        leg = Leg(wl, wl.d_pat, wl.nq, wl.m, f"the headline batch ({wl.nq} x {wl.m}-mers) with the seed table cut to k = {k_cut}")
+        out[f"{wl.m}-mers, seed table k = {k_cut}"], _ = find_leg(args, D, dev, leg, 3, expect=lambda d: wl.verify(d, wl.first, wl.nq))
+        wl.gpu.set_tables(kmer_k=k_full)
+    return out
+
+
+def memory_ladder(args, D, dev, wl, headline):
+    """What each optional table buys, at HBM scale: the headline batch and locate() of its first 10 M ranges on the same image
+    re-shaped rung by rung with gcsa2_index_set_tables (no re-creation; the ladder only goes down).  Every rung is checked
+    bit for bit against the closed form (find) and count() (locate).  Rungs: everything (the headline itself); without the
+    locate table (locate() walks: k_locate_walk2); seed table one size down; no pair blocks and the seed table three sizes
+    down (the image north_star's "~30 GB" had in mind).  GCSA2_MEMORY_BUDGET_MB at create time takes the same decisions from
+    a cap (tests/test_gpu_parity.py::test_memory_ladder)."""
+    import torch
+    gpu = wl.gpu
+    k_full = gpu.kmer_table_k()
+    has_samples = gpu.sampleCount() > 0
+    nloc = min(10_000_000, wl.nq)
+    rungs = []
+
+    def rung(name, first=False):
+        leg = Leg(wl, wl.d_pat, wl.nq, wl.m, name)
+        if first:
+            o = {"workload": name, "value": headline["value"], "kernel_ms": headline["roofline"]["kernel_ms"],
+                 "requests_per_query": headline["roofline"]["request_rate"]["requests_per_query"], "frac": headline["roofline"]["frac"],
+                 "all_ranges_equal_closed_form": headline["config"]["all_ranges_equal_closed_form"], "from": "the headline measurement above"}
+            d_out = torch.zeros((wl.nq, 2), dtype=torch.int64, device=dev)
+            gpu.find_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), wl.nq, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        else:
+            o, d_out = find_leg(args, D, dev, leg, 3, expect=lambda d: wl.verify(d, wl.first, wl.nq))
+            o = {key: o[key] for key in ("workload", "value", "kernel_ms", "requests_per_query", "lf_steps_per_query", "frac", "all_ranges_equal_closed_form")}
+        o.update(image_bytes_hbm=gpu.device_bytes(), pair_block_bytes=gpu.pair_block_bytes(), kmer_table_k=gpu.kmer_table_k(),
+                 locate_table_bytes=gpu.locate_table_bytes())
+        if has_samples:
+            loc, _, _ = measure_locate(gpu, d_out[:nloc].contiguous(), dev, 2)
+            o["locate"] = {key: loc[key] for key in ("value", "unit", "ms_per_step", "values", "count_equals_located")}
+        del d_out
+        torch.cuda.empty_cache()
+        rungs.append(o)
+
+    rung("everything: pair blocks, seed table, locate table", first=True)
+    if gpu.locate_table_bytes() > 0:
+        gpu.set_tables(locate_table=0)
+        rung("without the locate table")
+    if k_full >= 2:
+        gpu.set_tables(kmer_k=k_full - 1)
+        rung(f"... and the seed table at k = {k_full - 1}")
+    if gpu.pair_block_bytes() > 0:
+        gpu.set_tables(pair_blocks=0, kmer_k=max(1, k_full - 3))
+        rung(f"... no pair blocks, seed table at k = {max(1, k_full - 3)}")
+    return {"note": "one image re-shaped with gcsa2_index_set_tables; find() = the headline batch, locate() = its first "
+                    f"{nloc} ranges; results identical on every rung", "rungs": rungs}
+
+
+# ---- a repeat-rich text at HBM footprint: wide ranges as real genomes have them (VERDICT r03 #2 ii) ----------------
+
+REPEATS30_SEED = 0x6C5A0060
+
+
+def repeats_hbm_secondary(args, D, dev, local_rank, log2_bases=30):
+    """2^30 bases with planted repeat families (workload/repeats_torch.py: interspersed copies at 7 % divergence in families
+    of 115 k, a young family, tandem arrays) as a linear graph (workload/linear_torch.py: prefix doubling on the GPU, one
+    path node per position): found 32-mers match hundreds of path nodes on average and 16-mers thousands, like the paper's
+    human indexes (paper.tex:403,408), on an image of tens of gigabytes.  find() of 20 M 32-mers and 16-mers, locate() of
+    400 k / 100 k ranges; checks: range width == number of occurrences in the text for a sample (the definition, by comparing
+    windows of the text), the oracle on a sample, count() == located values for every range."""
+    import torch
+    from workload import linear_torch, repeats_torch
+    from gcsa2_amd.binding import GCSA
+    n = 1 << log2_bases
+    t = time.time()
+    seq = repeats_torch.repeat_bases_torch(n, REPEATS30_SEED, dev)
+    ix = linear_torch.build_linear(n, REPEATS30_SEED, order=256, device=dev, with_lcp=False, verbose=log, sequence=seq)
+    torch.cuda.empty_cache()
+    log(f"repeat-rich text: 2^{log2_bases} bases, n = {ix.n} path nodes ({time.time() - t:.1f} s)")
+    t = time.time()
+    wl = Workload()
+    wl.gpu = GCSA(ix, device=local_rank, with_lcp=False)
+    wl.ix, wl.scaling = ix, "strong"
+    log(f"device image: {wl.gpu.device_bytes() / 1e9:.2f} GB, seed table k = {wl.gpu.kmer_table_k()} ({time.time() - t:.1f} s)")
+    out = {"workload": f"repeat-rich text of 2^{log2_bases} bases (families of interspersed repeats at 7 % divergence, a young family at 6 %, "
+                       f"tandem arrays) as a linear graph: {ix.n} path nodes, order 256", "image_bytes_hbm": wl.gpu.device_bytes()}
+    nq = args.queries or (20_000_000 if log2_bases >= 28 else 2_000_000)
+    cpu = None if args.no_cpu else cpu_open(ix)
+    for m in (32, 16):
+        pats, _ = repeats_torch.substring_patterns_device(seq, nq, m, REPEATS30_SEED + m)
+        leg = Leg(wl, padded_bytes(pats), nq, m, f"{nq} x {m}-mers, substrings of the text at SplitMix64 positions")
+        o, d_out = find_leg(args, D, dev, leg, 5)
+        ns = 64
+        occ = repeats_torch.count_occurrences_device(seq, pats[:ns])
+        o["range_width_equals_occurrences_in_text_on_sample"] = bool(torch.equal(d_out[:ns, 1] - d_out[:ns, 0] + 1, occ))
+        if cpu is not None:
+            o["cpu_baseline"] = cpu_baseline_sample(cpu, leg, d_out, min(nq, 200_000))
+        nloc = min(nq, 400_000 if m == 32 else 100_000)
+        loc, d_loff, d_val = measure_locate(wl.gpu, d_out[:nloc].contiguous(), dev, 3)
+        sizes = d_loff[1:] - d_loff[:-1]
+        loc["segments"] = {"one value": int((sizes == 1).sum().item()), "2..16": int(((sizes >= 2) & (sizes <= 16)).sum().item()),
+                           "17..1024": int(((sizes >= 17) & (sizes <= 1024)).sum().item()), "more than 1024": int((sizes > 1024).sum().item()),
+                           "largest": int(sizes.max().item())}
+        # a linear graph: every path node has one value, the start position of its suffix; locate() of a pattern = its occurrences
+        first_vals = d_val[: int(d_loff[1].item())]
+        loc["sorted_distinct_first_range"] = bool((first_vals[1:] > first_vals[:-1]).all().item()) if first_vals.numel() > 1 else True
+        o["locate"] = loc
+        out[f"{m}-mers"] = o
+        del pats, leg, d_out, d_loff, d_val, sizes
+    if cpu is not None:
+        cpu.close()
+    release(wl)
+    return out
+
+
 def chr22_secondary(args, D, dev, local_rank):
     """BASELINE configs[1] and [2] on one GPU."""
     wl = setup_chr22(args, D, dev, local_rank, nq=10_000_000)
@@ -1184,6 +1354,23 @@ def cpu_baseline(args, wl, d_out, seconds):
                       f"({tall:.1f} s); single thread: first {n1} patterns ({t1:.1f} s); oracle index built in {build_s:.1f} s",
             "single_thread_value": n1 / t1, "single_thread_us_per_query": t1 / n1 * 1e6,
             "gpu_matches_cpu_on_sample": parity}
+
+
+def cpu_open(ix):
+    """The oracle over the find() part of an index (for legs that time it on several batches)."""
+    from oracle.oracle import OracleIndex
+    return OracleIndex(ix, with_samples=False, with_counters=False, with_lcp=False)
+
+
+def cpu_baseline_sample(cpu, leg, d_out, nc):
+    """The oracle on the first `nc` patterns of a leg, all cores; checks the GPU ranges of the sample."""
+    from oracle.oracle import max_threads
+    cores = max_threads()
+    flat = leg.d_pat[: nc * leg.m].cpu().numpy()
+    want = cpu.find_batch(flat, np.arange(nc + 1, dtype=np.uint64) * np.uint64(leg.m), threads=cores)
+    return {"value": nc / cpu.last_seconds, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"first {nc} of the {leg.nq} patterns, {leg.m}-mers, OpenMP static split over {cores} threads ({cpu.last_seconds:.1f} s)",
+            "gpu_matches_cpu_on_sample": bool(np.array_equal(d_out[:nc].cpu().numpy().view(np.uint64), want))}
 
 
 def cpu_baseline_match_stats(ix, d_pat, d_ms, d_rng, d_fb, m, ns=4000):
@@ -1295,6 +1482,10 @@ def main():
     secondary = args.workload in ("pangenome", "pangenome_plain", "human") and world == 1 and not args.no_secondary
     if secondary and args.secondary in ("all", "config5") and wl.ix.lcp_size > 0:
         result["config5"] = config5(args, wl, dev)
+    if secondary and args.secondary in ("all", "wide") and args.workload.startswith("pangenome") and args.set == "S":
+        result["wide_ranges"] = wide_ranges_secondary(args, D, dev, wl)
+    if secondary and args.secondary in ("all", "ladder") and args.workload.startswith("pangenome") and args.set == "S":
+        result["memory_ladder"] = memory_ladder(args, D, dev, wl, result)        # re-shapes the image: the last user of the headline index
     if world > 1 and not args.no_secondary and args.secondary in ("all", "config5") and D.all_true(wl.ix.lcp_size > 0 and wl.gpu.sampleCount() > 0):
         c5 = config5_sharded(args, D, wl, dev)
         if rank == 0:
@@ -1308,7 +1499,10 @@ def main():
         result["chr22"] = chr22_secondary(args, D, dev, local_rank)
     if secondary and args.secondary in ("all", "repeats"):
         result["repeats"] = repeats_secondary(args, D, dev, local_rank)
-    if secondary and args.workload != "human" and args.secondary in ("all", "human32") and full_size:
+    if secondary and args.secondary in ("all", "repeats30"):
+        # the repeat-rich text at HBM footprint; scaled down with the headline index in small runs (tests)
+        result["repeats_hbm"] = repeats_hbm_secondary(args, D, dev, local_rank, log2_bases=(30 if full_size else 22))
+    if secondary and args.workload != "human" and args.secondary == "human32" and full_size:       # rounds 1-2's headline, on request only
         result["human32"] = human32_secondary(args, D, dev, local_rank)
     if secondary and args.secondary == "human_snp":
         result["human_branching"] = human_snp_secondary(args, D, dev, local_rank)

@@ -126,3 +126,31 @@ def test_world_mismatch_is_refused():
                           "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--degree", "20", "--queries", "1000", "--steps", "1",
                           "--warmup", "0", "--no-cpu", "--no-secondary"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_wide_range_and_ladder_secondaries():
+    """The wide-range legs (prefixes of path labels in closed form; the batch with a short seed table), the memory ladder
+    (one image re-shaped rung by rung, bit-exact on each) and the repeat-rich text through the prefix-doubling generator, at
+    small footprints."""
+    d = run([sys.executable, "bench.py", "--degree", "20", "--queries", "300000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1",
+             "--secondary", "wide"])
+    w = d["wide_ranges"]
+    assert len(w) == 4 and all(leg["all_ranges_equal_closed_form"] is True for leg in w.values())
+    widths = [w[f"{m}-mers"]["mean_range_width_path_nodes"] for m in (5, 7, 9)]
+    assert widths[0] > 250 and widths[0] > widths[1] > widths[2] >= 1.0
+    assert w["5-mers"]["second_fetch_fraction_of_steps"] > 0.3
+    cut = [leg for name, leg in w.items() if "seed table" in name][0]
+    assert cut["kmer_table_k"] == 5 and cut["lf_steps_per_query"] == 27.0
+    d = run([sys.executable, "bench.py", "--degree", "20", "--queries", "300000", "--steps", "2", "--warmup", "1", "--no-cpu", "--secondary", "ladder"])
+    rungs = d["memory_ladder"]["rungs"]
+    assert len(rungs) == 4 and all(r["all_ranges_equal_closed_form"] is True and r["locate"]["count_equals_located"] is True for r in rungs)
+    assert rungs[0]["locate_table_bytes"] > 0 and rungs[1]["locate_table_bytes"] == 0 and rungs[3]["pair_block_bytes"] == 0
+    assert [r["image_bytes_hbm"] for r in rungs] == sorted((r["image_bytes_hbm"] for r in rungs), reverse=True)
+    assert rungs[3]["requests_per_query"] > 1.5 * rungs[0]["requests_per_query"]
+    d = run([sys.executable, "bench.py", "--degree", "20", "--queries", "300000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1",
+             "--secondary", "repeats30"])
+    r = d["repeats_hbm"]
+    for m in ("32-mers", "16-mers"):
+        leg = r[m]
+        assert leg["range_width_equals_occurrences_in_text_on_sample"] is True and leg["cpu_baseline"]["gpu_matches_cpu_on_sample"] is True
+        assert leg["locate"]["count_equals_located"] is True and leg["mean_range_width_path_nodes"] > 1.5

@@ -599,7 +599,7 @@ def test_memory_ladder(engine, monkeypatch):
     # the same ladder by creating under a cap; MB with fractions, since this index is small
     mb = 1048576.0
     seen = []
-    for budget in (full + 1, full - locate_bytes // 2, bare + pair_bytes + 8 * 4 ** 5, bare + pair_bytes // 2, bare // 2):
+    for budget in (full + 1, full - locate_bytes // 2, bare + pair_bytes + 8 * 4 ** 6 + 64, bare + pair_bytes // 2, bare // 2):
         monkeypatch.setenv("GCSA2_MEMORY_BUDGET_MB", repr(budget / mb))
         capped, _ = engine.open_index(ix, device=0)
         assert capped.device_bytes() <= max(budget, bare), budget          # the image proper is never refused: only tables are dropped

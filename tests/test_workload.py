@@ -49,6 +49,43 @@ def test_linear_torch_matches_general_builder(n, seed):
     assert not a.extra_filter[:w].any() and not b.extra_filter[:w].any()
 
 
+@pytest.mark.parametrize("n,seed,family_blocks", [(9000, 0x6C5A0060, 5), (20011, 11, 8)])
+def test_repeat_rich_text_matches_general_builder(n, seed, family_blocks):
+    """The repeat-rich text of workload/repeats_torch.py (families of interspersed and young repeats, tandem arrays) through
+    the prefix-doubling generator equals the general builder on the linear graph of the same text, field by field, and its
+    found 32-mers are answered with wide ranges: range width == number of occurrences in the text (the definition)."""
+    import torch
+    from workload import linear_torch, repeats_torch
+    from oracle.oracle import OracleIndex
+    from gcsa2_amd.hostview import concat_patterns
+    dev = torch.device("cpu")
+    seq = repeats_torch.repeat_bases_torch(n, seed, dev, family_blocks=family_blocks)
+    assert seq.shape[0] == n and int(seq.min()) >= 1 and int(seq.max()) <= 4
+    assert not torch.equal(seq, linear_torch.random_bases_torch(n, seed, dev))
+    a = builder.build(graphs.linear_graph(n, seed, sequence=seq.numpy()), 256)
+    b = linear_torch.build_linear(n, seed, order=256, device=dev, sequence=seq)
+    assert (a.n, a.e, a.sample_count, a.sample_width) == (b.n, b.e, b.sample_count, b.sample_width)
+    assert np.array_equal(a.C, b.C)
+    w = (a.n + 63) // 64
+    for c in range(a.sigma):
+        assert np.array_equal(a.bwt[c][:w], b.bwt[c][:w]), c
+    assert np.array_equal(a.edges[:w], b.edges[:w]) and np.array_equal(a.sampled_paths[:w], b.sampled_paths[:w])
+    assert np.array_equal(a.stored_samples_plain, b.stored_samples_plain)
+    assert np.array_equal(a.lcp_data, b.lcp_data) and np.array_equal(a.lcp_offsets, b.lcp_offsets)
+    c = linear_torch.build_linear(n, seed, order=256, device=dev, sequence=seq, with_lcp=False)     # what the bench builds
+    for comp in range(a.sigma):
+        assert np.array_equal(c.bwt[comp][:w], b.bwt[comp][:w])
+    assert np.array_equal(c.stored_samples_plain, b.stored_samples_plain) and c.lcp_size == 0
+    pats, start = repeats_torch.substring_patterns_device(seq, 400, 32, seed + 1)
+    occ = repeats_torch.count_occurrences_device(seq, pats).numpy()
+    data, off = concat_patterns([bytes(p) for p in pats.numpy()])
+    got = OracleIndex(b).find_batch(data, off)
+    assert np.array_equal(got[:, 1] - got[:, 0] + 1, occ.astype(np.uint64))
+    assert occ.min() >= 1 and occ.mean() > 1.05 and occ.max() >= 3          # a handful of copies per family at this size
+    a2, s2 = repeats_torch.substring_patterns_device(seq, 100, 32, seed + 1, first=300)
+    assert torch.equal(a2, pats[300:]) and torch.equal(s2, start[300:])          # any shard of the batch is the same
+
+
 @pytest.mark.parametrize("degree", [8, 12, 16])
 def test_mseq_index_has_analytic_answers(degree):
     """The sort-free m-sequence index: find() of any substring of length >= degree / 2 is the
@@ -499,3 +536,21 @@ def test_repeat_rich_backbone():
         uniq, inv, counts = np.unique(v, return_inverse=True, return_counts=True)
         return float(counts[inv[:: 97]].mean())
     assert mean_occurrences(a) > 20 and mean_occurrences(graphs.random_bases(n, 0x6C5A0020)) < 1.01
+
+
+@pytest.mark.parametrize("degree,junctions", [(12, 80), (16, 0)])
+def test_dbg_prefix_patterns_closed_form(degree, junctions):
+    """find() of the first m < k characters of a path label = the interval of the bitmap ranks of the k-mers with that prefix
+    (workload/dbg_torch.py::prefix_patterns_device, the wide-range legs of bench.py): equals the oracle's backward search."""
+    import torch
+    from workload import dbg_torch
+    from oracle.oracle import OracleIndex
+    from gcsa2_amd.hostview import concat_patterns
+    ix, dbg = dbg_torch.build_dbg(degree, junctions=junctions, device=torch.device("cpu"), full=True)
+    cpu = OracleIndex(ix)
+    for m in range(1, degree // 2):
+        pats, sp, ep = dbg_torch.prefix_patterns_device(dbg, 5, 700, m, 0x77 + m)
+        data, off = concat_patterns([bytes(p) for p in pats.numpy()])
+        got = cpu.find_batch(data, off)
+        assert np.array_equal(got[:, 0], sp.numpy().astype(np.uint64)) and np.array_equal(got[:, 1], ep.numpy().astype(np.uint64)), m
+        assert int((ep - sp).min()) >= 0

@@ -481,3 +481,37 @@ def walk_patterns_device(wl: DbgWorkload, first: int, count: int, m: int, seed: 
         expected[b:e] = wl.nodes.rank(v)
         del idx, chosen, v
     return out, start, expected
+
+
+def prefix_patterns_device(wl: DbgWorkload, first: int, count: int, m: int, seed: int):
+    """Queries first .. first + count - 1 of the global batch `seed`: the first m < k characters of the k-mer at a
+    SplitMix64 text position.  Every path label is a distinct k-mer and the path nodes are the k-mers in lexicographic
+    order, so find() of such a prefix is the interval of the nodes whose k-mer starts with it: with lo = prefix << 2 (k - m)
+    and hi = lo + 4^(k - m), (sp, ep) = (rank(lo), rank(hi) - 1) through the bitmap of the k-mer universe -- about
+    n / 4^m path nodes (341 / 21 / 1.3 for m = 12 / 14 / 16 at 5.73 G nodes): the wide ranges a pattern meets in the first
+    steps of its search.  Returns (patterns (count, m) uint8 bytes, sp int64, ep int64)."""
+    device = wl.sym_t.device
+    P, k = wl.P, wl.k
+    assert 1 <= m < k
+    r = splitmix64_range_torch(seed, first, count, device)
+    start = _lsr(r, 11) % P
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    out = torch.empty((count, m), dtype=torch.uint8, device=device)
+    sp = torch.empty(count, dtype=torch.int64, device=device)
+    ep = torch.empty(count, dtype=torch.int64, device=device)
+    shift = 2 * (k - m)
+    chunk = 1 << 22
+    last_word = wl.nodes.words.shape[0] - 1
+    for b in range(0, count, chunk):
+        e = min(count, b + chunk)
+        v = wl.values_at(start[b:e])
+        for j in range(m):
+            out[b:e, j] = lut[(v >> (2 * (k - 1 - j))) & 3]
+        lo = (v >> shift) << shift
+        hi = lo + (1 << shift)
+        sp[b:e] = wl.nodes.rank(lo)
+        # rank(4^k) = n: the position one past the bitmap
+        inside = hi < wl.nodes.universe
+        ep[b:e] = torch.where(inside, wl.nodes.rank(torch.where(inside, hi, torch.zeros_like(hi))), torch.full_like(hi, wl.nodes.n)) - 1
+        del v, lo, hi, inside
+    return out, sp, ep

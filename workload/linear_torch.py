@@ -74,7 +74,9 @@ def pack_bits_torch(bits: torch.Tensor, pad_words: int = 1) -> np.ndarray:
 
 def build_linear(n: int, seed: int, order: int = 256, node_len: int = 32, sample_period: int = 64,
                  branching: int = 64, device=None, with_lcp: bool = True, with_samples: bool = True,
-                 verbose=None) -> IndexArrays:
+                 verbose=None, sequence=None) -> IndexArrays:
+    """`sequence`: the n backbone comps (1..4) as a tensor instead of random_bases_torch(n, seed) -- e.g. the repeat-rich
+    text of workload/repeats_torch.py; every order-`order` path must still be distinct."""
     if device is None:
         device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
     N = n + 2
@@ -87,7 +89,7 @@ def build_linear(n: int, seed: int, order: int = 256, node_len: int = 32, sample
 
     text = torch.empty(N, dtype=torch.uint8, device=device)
     text[0] = 6
-    text[1:n + 1] = random_bases_torch(n, seed, device)
+    text[1:n + 1] = random_bases_torch(n, seed, device) if sequence is None else sequence.to(device)
     text[n + 1] = 0
 
     # ---- prefix doubling over the cyclic text -------------------------------------------------
@@ -96,7 +98,8 @@ def build_linear(n: int, seed: int, order: int = 256, node_len: int = 32, sample
     levels = []           # rank arrays: level l orders rotations by their first 2^l characters
     h = 1
     rank = torch.unique(rank, return_inverse=True)[1]
-    levels.append(rank.to(torch.int32))
+    if with_lcp:
+        levels.append(rank.to(torch.int32))
     distinct = int(rank.max().item()) + 1
     while distinct < N:
         if h >= order:
@@ -108,7 +111,8 @@ def build_linear(n: int, seed: int, order: int = 256, node_len: int = 32, sample
         rank = torch.unique(key, return_inverse=True)[1]
         del key
         h *= 2
-        levels.append(rank.to(torch.int32))
+        if with_lcp:
+            levels.append(rank.to(torch.int32))
         distinct = int(rank.max().item()) + 1
         log(f"doubling: {h} characters -> {distinct} / {N} distinct")
     sa = torch.empty(N, dtype=torch.int64, device=device)
