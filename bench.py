@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["pangenome", "pangenome_plain", "pangenome_snp", "human", "human_snp", "chr22", "repeats", "linear"], default="pangenome",
+    ap.add_argument("--workload", choices=["pangenome", "pangenome_plain", "pangenome_snp", "human", "human_snp", "chr22", "repeats", "repeats30", "linear"], default="pangenome",
                     help="pangenome: whole-human-pangenome-sized branching index (5.73 G path nodes, e = 1.08 n), one batch sharded over "
                          "the GPUs (config 4); pangenome_plain / pangenome_snp: the same text without junction edges / with SNP bubbles "
                          "(6.9 G path nodes); human: rounds 1-2's 2^32 - 1 node index; human_snp: that text with SNP bubbles; "
@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the request-rate ceiling, the device telemetry and the host-batch leg "
                                                                "(profiler passes: only the timed kernel and its instrumented twin run)")
     ap.add_argument("--secondary", choices=["all", "config5", "wide", "ladder", "chr22", "repeats", "repeats30", "human32", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
+    ap.add_argument("--locate", action="store_true", help="chr22 / repeats / repeats30: run the locate() leg even with --no-extras (profiler passes)")
     ap.add_argument("--variant", type=int, default=2, help="find launch shape (2 = one lane per query in batch order, 4 = queries ordered by length first)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
@@ -426,7 +427,10 @@ def setup_pangenome(args, D, dev, local_rank, total_queries=None):
     wl.first, wl.nq = b, e - b
     t = time.time()
     expected = None
-    if args.set == "S":
+    short = args.set == "S" and wl.m < dbg.k          # prefixes of path labels: wide ranges, closed form = a rank interval
+    if short:
+        pats, exp_sp, exp_ep = dbg_torch.prefix_patterns_device(dbg, b, e - b, wl.m, HUMAN_PATTERN_SEED + 0x100 + wl.m)
+    elif args.set == "S":
         pats, _, expected = dbg_torch.walk_patterns_device(dbg, b, e - b, wl.m, HUMAN_PATTERN_SEED)
     else:
         pats = uniform_patterns_device(b, e - b, wl.m, HUMAN_PATTERN_SEED, dev)
@@ -444,7 +448,13 @@ def setup_pangenome(args, D, dev, local_rank, total_queries=None):
     def verify(d_ranges, first, count):
         # find() of a walk of >= k characters = the single node of its first k characters, in closed form (the bitmap
         # rank of that k-mer); a shard other than this rank's own is regenerated
-        if args.set != "S" or wl.m < degree // 2:
+        if short:
+            if (first, count) == (b, e - b):
+                sp_, ep_ = exp_sp, exp_ep
+            else:
+                _, sp_, ep_ = dbg_torch.prefix_patterns_device(dbg, first, count, wl.m, HUMAN_PATTERN_SEED + 0x100 + wl.m)
+            return bool(torch.equal(d_ranges[:, 0], sp_)) and bool(torch.equal(d_ranges[:, 1], ep_))
+        if args.set != "S":
             return None
         ok = True
         step = 1 << 23
@@ -1212,13 +1222,8 @@ def memory_ladder(args, D, dev, wl, headline):
 REPEATS30_SEED = 0x6C5A0060
 
 
-def repeats_hbm_secondary(args, D, dev, local_rank, log2_bases=30):
-    """2^30 bases with planted repeat families (workload/repeats_torch.py: interspersed copies at 7 % divergence in families
-    of 115 k, a young family, tandem arrays) as a linear graph (workload/linear_torch.py: prefix doubling on the GPU, one
-    path node per position): found 32-mers match hundreds of path nodes on average and 16-mers thousands, like the paper's
-    human indexes (paper.tex:403,408), on an image of tens of gigabytes.  find() of 20 M 32-mers and 16-mers, locate() of
-    400 k / 100 k ranges; checks: range width == number of occurrences in the text for a sample (the definition, by comparing
-    windows of the text), the oracle on a sample, count() == located values for every range."""
+def setup_repeats30(args, D, dev, local_rank, log2_bases=30):
+    """The repeat-rich text as a primary workload (`--workload repeats30`; profiler passes): 20 M patterns per GPU."""
     import torch
     from workload import linear_torch, repeats_torch
     from gcsa2_amd.binding import GCSA
@@ -1231,8 +1236,40 @@ def repeats_hbm_secondary(args, D, dev, local_rank, log2_bases=30):
     t = time.time()
     wl = Workload()
     wl.gpu = GCSA(ix, device=local_rank, with_lcp=False)
-    wl.ix, wl.scaling = ix, "strong"
+    wl.ix, wl.scaling, wl.seq, wl.log2_bases = ix, "weak", seq, log2_bases
     log(f"device image: {wl.gpu.device_bytes() / 1e9:.2f} GB, seed table k = {wl.gpu.kmer_table_k()} ({time.time() - t:.1f} s)")
+    wl.nq = args.queries or (20_000_000 if log2_bases >= 28 else 2_000_000)
+    wl.m = args.pattern_len
+    wl.total_queries, wl.first = wl.nq * D.world, wl.nq * D.rank
+    pats, _ = repeats_torch.substring_patterns_device(seq, wl.nq, wl.m, REPEATS30_SEED + wl.m, first=wl.first)
+    wl.d_pat = padded_bytes(pats)
+    wl.d_off = torch.arange(wl.nq + 1, dtype=torch.int64, device=dev) * wl.m
+    wl.label = (f"repeat-rich text of 2^{log2_bases} bases (families of interspersed repeats at 7 % divergence, a young family at 6 %, tandem "
+                f"arrays; workload/repeats_torch.py) as a linear graph: {ix.n} path nodes, order 256; {wl.nq} x {wl.m}-mer find() per GPU, "
+                f"substrings of the text")
+
+    def verify(d_ranges, first, count):
+        # the definition on a sample: range width == number of occurrences of the pattern in the text
+        if first != wl.first:
+            return None
+        ns = 48
+        occ = repeats_torch.count_occurrences_device(seq, pats[:ns])
+        return bool(torch.equal(d_ranges[:ns, 1] - d_ranges[:ns, 0] + 1, occ))
+    wl.verify = verify
+    return wl
+
+
+def repeats_hbm_secondary(args, D, dev, local_rank, log2_bases=30):
+    """2^30 bases with planted repeat families (workload/repeats_torch.py: interspersed copies at 7 % divergence in families
+    of 115 k, a young family, tandem arrays) as a linear graph (workload/linear_torch.py: prefix doubling on the GPU, one
+    path node per position): found 32-mers match hundreds of path nodes on average and 16-mers thousands, like the paper's
+    human indexes (paper.tex:403,408), on an image of tens of gigabytes.  find() of 20 M 32-mers and 16-mers, locate() of
+    400 k / 100 k ranges; checks: range width == number of occurrences in the text for a sample (the definition, by comparing
+    windows of the text), the oracle on a sample, count() == located values for every range."""
+    import torch
+    from workload import repeats_torch
+    wl = setup_repeats30(args, D, dev, local_rank, log2_bases=log2_bases)
+    ix, seq = wl.ix, wl.seq
     out = {"workload": f"repeat-rich text of 2^{log2_bases} bases (families of interspersed repeats at 7 % divergence, a young family at 6 %, "
                        f"tandem arrays) as a linear graph: {ix.n} path nodes, order 256", "image_bytes_hbm": wl.gpu.device_bytes()}
     nq = args.queries or (20_000_000 if log2_bases >= 28 else 2_000_000)
@@ -1424,6 +1461,8 @@ def main():
         wl = setup_chr22(args, D, dev, local_rank)
     elif args.workload == "repeats":
         wl = setup_repeats(args, D, dev, local_rank)
+    elif args.workload == "repeats30":
+        wl = setup_repeats30(args, D, dev, local_rank, log2_bases=args.log2_bases or 30)
     else:
         wl = setup_linear(args, D, dev, local_rank)
 
@@ -1436,7 +1475,7 @@ def main():
 
     result = None
     if rank == 0:
-        size = {"chr22": args.log2_bases or 25, "repeats": args.log2_bases or 23, "linear": args.log2_bases or 30}.get(args.workload, getattr(wl, "degree", args.degree))
+        size = {"chr22": args.log2_bases or 25, "repeats": args.log2_bases or 23, "repeats30": args.log2_bases or 30, "linear": args.log2_bases or 30}.get(args.workload, getattr(wl, "degree", args.degree))
         result = {
             "metric": "kmer_find_queries_per_sec", "value": wl.total_queries * args.steps / r["elapsed"], "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1476,8 +1515,8 @@ def main():
             result["host_batch"] = host_batch_rate(wl, r["d_out"])
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds)
-    if rank == 0 and world == 1 and args.workload in ("repeats", "chr22") and wl.gpu.sampleCount() > 0:
-        nloc = min(wl.nq, 400_000 if args.workload == "repeats" else wl.nq)
+    if rank == 0 and world == 1 and args.workload in ("repeats", "repeats30", "chr22") and wl.gpu.sampleCount() > 0 and (args.locate or not args.no_extras):
+        nloc = min(wl.nq, 400_000 if args.workload.startswith("repeats") else wl.nq)
         result["locate"], _, _ = measure_locate(wl.gpu, r["d_out"][:nloc].contiguous(), dev, 3)
     secondary = args.workload in ("pangenome", "pangenome_plain", "human") and world == 1 and not args.no_secondary
     if secondary and args.secondary in ("all", "config5") and wl.ix.lcp_size > 0:

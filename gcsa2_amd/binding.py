@@ -20,7 +20,7 @@ STATUS = {0: "OK", -1: "INVALID_ARGUMENT", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY",
           -5: "MISSING_COMPONENT", -6: "BUFFER_TOO_SMALL"}
 
 EXPORTS = [
-    "gcsa2_device_count", "gcsa2_index_create", "gcsa2_index_destroy", "gcsa2_index_set_tables", "gcsa2_last_error",
+    "gcsa2_device_count", "gcsa2_index_create", "gcsa2_index_destroy", "gcsa2_index_set_tables", "gcsa2_index_trim", "gcsa2_last_error",
     "gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count", "gcsa2_sample_bits",
     "gcsa2_device", "gcsa2_device_bytes", "gcsa2_block_bits",
     "gcsa2_find_batch", "gcsa2_find_device", "gcsa2_find_stats_device", "gcsa2_find_device_variant",
@@ -79,6 +79,7 @@ def load_library():
     L.gcsa2_last_error.restype = C.c_char_p
     L.gcsa2_index_create.argtypes = [C.POINTER(HostView), i32, C.POINTER(vp)]
     L.gcsa2_index_set_tables.argtypes = [vp, i32, i32, i32]
+    L.gcsa2_index_trim.argtypes = [vp]
     L.gcsa2_index_destroy.argtypes = [vp]
     L.gcsa2_index_destroy.restype = None
     for name in ("gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count",
@@ -370,6 +371,10 @@ class GCSA:
         """Drop (0) / build (1) / leave (-1) the pair blocks and the locate table, resize the k-mer seed table (0 drops it):
         gcsa2_index_set_tables.  Results of every query stay the same; no queries may run on the handle meanwhile."""
         _check(self._L.gcsa2_index_set_tables(self._h, int(pair_blocks), int(kmer_k), int(locate_table)))
+
+    def trim(self):
+        """Give back the host pipeline, the staging objects and the scratch pool of this handle (gcsa2_index_trim)."""
+        _check(self._L.gcsa2_index_trim(self._h))
 
     def pair_block_bytes(self):
         return int(self._L.gcsa2_pair_block_bytes(self._h))

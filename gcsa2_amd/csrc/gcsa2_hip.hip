@@ -75,7 +75,9 @@ struct gcsa2_index
   // call in 5000; tools/hip/pool_readback_repro.hip shows the ROCm pool itself delivers 1.1 M such read-backs
   // correctly in every stream / host-memory combination, so that symptom was this engine's then-code, not ROCm.)
   unsigned long long* d_slots = nullptr;
+  unsigned long long* h_slots = nullptr;     // the same slots in page-locked host memory the device writes and the host polls (read_totals)
   mutable std::atomic<unsigned> next_slot{0};
+  mutable std::atomic<unsigned long long> next_ticket{1};
   mutable std::mutex staging_lock;
   mutable std::vector<Staging*> staging_pool;
   int compute_units = 256;
@@ -100,7 +102,7 @@ struct gcsa2_index
     u32 pipe_lanes = 12;               // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
     bool ms_pieces = true;             // GCSA2_MS_PIECES=0: large host batches of matching statistics go through one copy in, one launch, one copy out
-    bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the segmented radix sort
+    bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the device-wide radix sort, duplicates and all
     bool zero_copy = true;             // GCSA2_ZERO_COPY=0: small host-pointer calls copy through the arenas like large ones
     u32 seed_wide = (u32(1) << 24) - 1;   // GCSA2_SEED_WIDE: seed-table entries of this many path nodes or more are marked, not stored (tests)
     u64 budget_bytes = 0;              // GCSA2_MEMORY_BUDGET_MB: most device memory the image may take (0: what the device has free)
@@ -127,6 +129,16 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
               std::string(#expr) + ": " + hipGetErrorString(e_)); } } while(0)
 
 inline unsigned grid_for(u64 n) { return unsigned((n + TPB - 1) / TPB); }
+
+// Host worker threads of one call.  If starting one of them throws (std::system_error: thread limit), the ones already
+// running are joined before the exception travels on -- destroying a joinable std::thread ends the process.
+struct Workers
+{
+  std::vector<std::thread> threads;
+  template<class... Args> void emplace_back(Args&&... args) { threads.emplace_back(std::forward<Args>(args)...); }
+  void join() { for(std::thread& t : threads) { if(t.joinable()) { t.join(); } } }
+  ~Workers() { join(); }
+};
 
 // what a memory budget (GCSA2_MEMORY_BUDGET_MB, read at create time) leaves for the next optional table
 inline u64 budget_left(const gcsa2_index* ix) { return ix->tune.budget_bytes > ix->bytes ? ix->tune.budget_bytes - ix->bytes : 0; }
@@ -709,7 +721,9 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     hipError_t e = hipMalloc(&ix->d_base, ix->bytes > 0 ? ix->bytes : 8);
     if(e != hipSuccess) { delete ix; return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(image): ") + hipGetErrorString(e)); }
     e = hipMemset(ix->d_base, 0, ix->bytes > 0 ? ix->bytes : 8);       // alignment gaps, the words behind the samples and the LCP values
-    if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&ix->d_slots), RESULT_SLOTS * 8 * sizeof(unsigned long long)); }
+    if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&ix->d_slots), RESULT_SLOTS * TOTAL_WORDS * sizeof(unsigned long long)); }
+    if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&ix->h_slots), RESULT_SLOTS * TOTAL_WORDS * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent); }
+    if(e == hipSuccess) { std::memset(ix->h_slots, 0, RESULT_SLOTS * TOTAL_WORDS * sizeof(unsigned long long)); }
     if(e != hipSuccess) { gcsa2_index_destroy(ix); return fail(GCSA2_ERR_HIP, std::string("image allocation: ") + hipGetErrorString(e)); }
 
     // The image is built on the device from the plain arrays of the view, each of them copied once (they may already be in
@@ -964,18 +978,11 @@ int gcsa2_index_set_tables(gcsa2_index* ix, int pair_blocks, int kmer_k, int loc
   return GCSA2_OK;
 }
 
-void gcsa2_index_destroy(gcsa2_index* ix)
+namespace {
+// the host pipeline of the large host-pointer batches and the staging objects of the small ones (pinned + device memory)
+void release_host_staging(gcsa2_index* ix)
 {
-  if(ix == nullptr) { return; }
-  DeviceGuard guard(ix->device);
-  if(ix->d_base) { (void)hipFree(ix->d_base); }
-  if(ix->d_kmer) { (void)hipFree(ix->d_kmer); }
-  if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
-  if(ix->d_locate) { (void)hipFree(ix->d_locate); }
-  if(ix->d_jump) { (void)hipFree(ix->d_jump); }
-  if(ix->d_pairs) { (void)hipFree(ix->d_pairs); }
-  if(ix->d_slots) { (void)hipFree(ix->d_slots); }
-  if(ix->pool) { (void)hipDeviceSynchronize(); (void)hipMemPoolDestroy(ix->pool); }
+  std::lock_guard<std::mutex> pipe_guard(ix->pipe_lock);
   for(gcsa2_index::PipeLane& lane : ix->pipe)
   {
     for(gcsa2_index::PipeSet& set : lane.set)
@@ -988,6 +995,8 @@ void gcsa2_index_destroy(gcsa2_index* ix)
     if(lane.stream) { (void)hipStreamDestroy(lane.stream); }
     if(lane.down) { (void)hipStreamDestroy(lane.down); }
   }
+  ix->pipe.clear();
+  std::lock_guard<std::mutex> staging_guard(ix->staging_lock);
   for(Staging* st : ix->staging_pool)
   {
     if(st->stream) { (void)hipStreamDestroy(st->stream); }
@@ -996,6 +1005,35 @@ void gcsa2_index_destroy(gcsa2_index* ix)
     if(st->z) { (void)hipHostFree(st->z); }
     delete st;
   }
+  ix->staging_pool.clear();
+}
+}  // namespace
+
+int gcsa2_index_trim(gcsa2_index* ix)
+{
+  if(ix == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null index"); }
+  DeviceGuard guard(ix->device);
+  if(!guard.ok) { return fail(GCSA2_ERR_HIP, "hipSetDevice failed"); }
+  HIP_TRY(hipDeviceSynchronize());
+  release_host_staging(ix);
+  if(ix->pool != nullptr) { HIP_TRY(hipMemPoolTrimTo(ix->pool, 0)); }
+  return GCSA2_OK;
+}
+
+void gcsa2_index_destroy(gcsa2_index* ix)
+{
+  if(ix == nullptr) { return; }
+  DeviceGuard guard(ix->device);
+  if(ix->d_base) { (void)hipFree(ix->d_base); }
+  if(ix->d_kmer) { (void)hipFree(ix->d_kmer); }
+  if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
+  if(ix->d_locate) { (void)hipFree(ix->d_locate); }
+  if(ix->d_jump) { (void)hipFree(ix->d_jump); }
+  if(ix->d_pairs) { (void)hipFree(ix->d_pairs); }
+  if(ix->d_slots) { (void)hipFree(ix->d_slots); }
+  if(ix->h_slots) { (void)hipHostFree(ix->h_slots); }
+  if(ix->pool) { (void)hipDeviceSynchronize(); (void)hipMemPoolDestroy(ix->pool); }
+  release_host_staging(ix);
   delete ix;
 }
 
@@ -1173,11 +1211,40 @@ namespace {
 
 constexpr int LOCATE_NEEDS_SPLIT = 1;      // internal: not a gcsa2_status
 
-// One pass of the locate pipeline.  The library calls inside (hipCUB scans and the segmented sort) count in `int`, so a pass
-// takes fewer than 2^31 values before deduplication; a larger batch returns LOCATE_NEEDS_SPLIT (allow_split) with the
-// exclusive scan of the per-query raw counts left in d_offsets, and locate_core below cuts it.
+// The totals of a pass on the host: k_publish_totals copies the slot to page-locked host memory and writes a ticket behind
+// it; the host polls the ticket (tests/perf/launch_latency.hip: 8 us against 13 us for launch + hipStreamSynchronize, and
+// against the 100-400 us a hipMemcpyAsync into pageable memory + synchronise took on this path: three of them were 1.2 ms of
+// a 5 ms locate() batch, profiles/r03_locate.md).  The stream is asked now and then, so that a failed launch ends the wait.
+int read_totals(const gcsa2_index* ix, unsigned slot, unsigned long long (&totals)[TOTAL_WORDS], hipStream_t stream)
+{
+  const unsigned long long ticket = ix->next_ticket.fetch_add(1);
+  volatile unsigned long long* h = ix->h_slots + u64(TOTAL_WORDS) * slot;
+  hipLaunchKernelGGL(k_publish_totals, dim3(1), dim3(64), 0, stream, ix->d_slots + u64(TOTAL_WORDS) * slot, h, ticket);
+  LAUNCH_CHECK("k_publish_totals");
+  for(u64 spins = 1; h[TOTAL_WORDS - 1] != ticket; spins++)
+  {
+    if((spins & 0xFFF) == 0)
+    {
+      const hipError_t q = hipStreamQuery(stream);
+      if(q == hipSuccess) { if(h[TOTAL_WORDS - 1] == ticket) { break; } return fail(GCSA2_ERR_HIP, "locate: the stream went idle without publishing its totals"); }
+      if(q != hipErrorNotReady) { return fail(GCSA2_ERR_HIP, std::string("locate: ") + hipGetErrorString(q)); }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for(u32 i = 0; i < TOTAL_WORDS; i++) { totals[i] = h[i]; }
+  return GCSA2_OK;
+}
+
+// One pass of the locate pipeline.  The library scans inside count in `int`, so a pass takes fewer than 2^31 values before
+// deduplication; a larger batch returns LOCATE_NEEDS_SPLIT (allow_split) with the exclusive scan of the per-query raw counts
+// left in d_offsets, and locate_core below cuts it.
+// known_out / known_capacity: the caller's own value buffer (gcsa2_locate_into).  The pass then never waits for the number of
+// distinct values: the compaction writes into the buffer under a capacity guard and the total is read with the final
+// synchronisation (too small a buffer is reported then, as before).  Host round trips of a pass in sorted mode: the totals
+// after the size scans (needed for the scratch), one more only if some segment has more than 4096 values, the end.
 int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u64* d_offsets,
-                 const ValuesProvider& values_for, u64* total_out, hipStream_t stream, bool allow_split)
+                 const ValuesProvider& values_for, u64* total_out, hipStream_t stream, bool allow_split,
+                 u64* known_out = nullptr, u64 known_capacity = 0)
 {
   *total_out = 0;
   if(nq == 0)
@@ -1188,11 +1255,12 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   }
   Scratch scratch(ix, stream);
 
-  // [node_counts | raw_counts | node_off] (nq + 1 each), [seg_begin | seg_end] (nq each), 3 totals; the
+  // [node_counts | raw_counts | node_off] (nq + 1 each), [seg_begin | seg_end] (nq each), the totals; the
   // scan of the raw counts goes straight into the job's offsets (final as they are unless duplicates
   // have to be removed, rewritten in place otherwise)
   u64* sizes = nullptr; u64* segs = nullptr;
-  unsigned long long* d_totals = ix->d_slots + 8 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);   // {nodes, raw, large, unique, multi, medium}
+  const unsigned slot = ix->next_slot.fetch_add(1) % RESULT_SLOTS;
+  unsigned long long* d_totals = ix->d_slots + u64(TOTAL_WORDS) * slot;
   HIP_TRY(scratch.get(sizes, 3 * (nq + 1))); HIP_TRY(scratch.get(segs, 6 * nq));
   u64 *node_counts = sizes, *raw_counts = sizes + (nq + 1), *node_off = sizes + 2 * (nq + 1), *raw_off = d_offsets;
   u64 *seg_begin = segs, *seg_end = segs + nq, *huge_begin = segs + 2 * nq, *huge_end = segs + 3 * nq, *over_begin = segs + 4 * nq, *over_end = segs + 5 * nq;
@@ -1213,11 +1281,11 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   const u32 big_limit = (ix->tune.dedup_huge && sort ? (medium_limit > SMALL_SEGMENT ? medium_limit : SMALL_SEGMENT) : BIG_SEGMENT);
   hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, huge_begin, huge_end, medium_limit, big_limit);
   LAUNCH_CHECK("k_collect_multi");
-  unsigned long long totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  const u64 total_nodes = totals[0], total_raw = totals[1], multi = totals[4], huge = totals[6];
-  u64 large = totals[2], medium = totals[5], over = 0;
+  unsigned long long totals[TOTAL_WORDS];
+  int rc = read_totals(ix, slot, totals, stream);
+  if(rc != GCSA2_OK) { return rc; }
+  const u64 total_nodes = totals[T_NODES], total_raw = totals[T_RAW], multi = totals[T_MULTI], huge_a = totals[T_HUGE_A], huge_b = totals[T_HUGE_B];
+  const u64 large = totals[T_LARGE], medium = totals[T_MEDIUM];
   if(total_raw > ix->tune.locate_split)
   {
     if(allow_split) { return LOCATE_NEEDS_SPLIT; }
@@ -1234,113 +1302,169 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   {
     HIP_TRY(hipMemsetAsync(d_offsets, 0, (nq + 1) * sizeof(u64), stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    return GCSA2_OK;
   }
-  else if(!sort || multi == 0)
+  if(!sort || multi == 0)
   {
     // sort == false (gcsa.cpp:827-842 without removeDuplicates): values in path order, the values of
     // one path node in sample order, duplicates kept -- exactly the walk's output.  With at most one
     // value per query that output is already sorted and distinct.
-    u64* out = values_for(total_raw);
+    u64* out = (known_out != nullptr ? (total_raw <= known_capacity ? known_out : nullptr) : values_for(total_raw));
     if(out == nullptr) { *total_out = total_raw; return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
     launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, out, owners, stream);
     LAUNCH_CHECK("k_locate_walk");
     HIP_TRY(hipStreamSynchronize(stream));
     *total_out = total_raw;
+    return GCSA2_OK;
   }
-  else
-  {
-    u64 *raw = nullptr, *sorted = nullptr, *words = nullptr; u32 *word_counts = nullptr, *word_before = nullptr;
-    const u64 nwords = total_raw / 64 + 1;
-    HIP_TRY(scratch.get(sorted, total_raw));
-    HIP_TRY(scratch.get(words, nwords)); HIP_TRY(scratch.get(word_counts, nwords + 1)); HIP_TRY(scratch.get(word_before, nwords + 1));
-    if(ix->img.locate_tab != nullptr)
-    {
-      // unordered table walk in two passes (kernels_locate.hpp): single values at once, the path nodes with several values
-      // marked (one word per 64 nodes) and worked through afterwards
-      const u64 blocks = grid_for(total_nodes), spans = (total_nodes + OWNER_SPAN - 1) / OWNER_SPAN;
-      u64* later_words = nullptr;
-      HIP_TRY(scratch.get(later_words, spans));
-      HIP_TRY(hipMemsetAsync(extra_slots, 0, nq * sizeof(u64), stream));
-      hipLaunchKernelGGL(k_block_owners, dim3(grid_for(spans + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, OWNER_SPAN, spans, owners);
-      hipLaunchKernelGGL(k_locate_tab_unordered, dim3(unsigned(blocks)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_off, raw_off,
-                         total_nodes, sorted, owners, later_words);
-      if(total_raw > total_nodes)                  // some path node has several values
-      {
-        hipLaunchKernelGGL(k_locate_tab_rest, dim3(grid_for(spans)), dim3(TPB), 0, stream, ix->img, d_ranges, node_off, raw_off, total_nodes, sorted,
-                           owners, later_words, spans, reinterpret_cast<unsigned long long*>(extra_slots));
-      }
-    }
-    else { launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, owners, stream); }
-    LAUNCH_CHECK("k_locate_walk");
 
-    // removeDuplicates: queries with up to SMALL_SEGMENT values are sorted in registers, up to MEDIUM_SEGMENT by a wavefront
-    // and up to BIG_SEGMENT by a workgroup in LDS, all in place.  Longer ones first lose their duplicates (k_dedup_huge) and
-    // join those lists with their distinct values; only a segment with more than BIG_SEGMENT distinct values goes to hipCUB's
-    // segmented radix sort (from a copy).  Then flag + scan + compact.
-    if(huge > 0 && !ix->tune.dedup_huge) { over = huge; over_begin = huge_begin; over_end = huge_end; }
-    else if(huge > 0)
+  u64 *sorted = nullptr, *words = nullptr; u32 *word_counts = nullptr, *word_before = nullptr;
+  const u64 nwords = total_raw / 64 + 1;
+  HIP_TRY(scratch.get(sorted, total_raw));
+  HIP_TRY(scratch.get(words, nwords)); HIP_TRY(scratch.get(word_counts, nwords + 1)); HIP_TRY(scratch.get(word_before, nwords + 1));
+  if(ix->img.locate_tab != nullptr)
+  {
+    // unordered table walk in two passes (kernels_locate.hpp): single values at once, the path nodes with several values
+    // marked (one word per 64 nodes) and worked through afterwards.  (The second pass runs whenever the first one may have
+    // marked a node: also a node with ONE value is marked when that value does not fit a direct entry.)
+    const u64 blocks = grid_for(total_nodes), spans = (total_nodes + OWNER_SPAN - 1) / OWNER_SPAN;
+    u64* later_words = nullptr;
+    HIP_TRY(scratch.get(later_words, spans));
+    HIP_TRY(hipMemsetAsync(extra_slots, 0, nq * sizeof(u64), stream));
+    hipLaunchKernelGGL(k_block_owners, dim3(grid_for(spans + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, OWNER_SPAN, spans, owners);
+    hipLaunchKernelGGL(k_locate_tab_unordered, dim3(unsigned(blocks)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_off, raw_off,
+                       total_nodes, sorted, owners, later_words);
+    if(total_raw > total_nodes || ix->img.sample_width >= 63)
     {
-      hipLaunchKernelGGL((k_dedup_huge<BIG_SEGMENT, 0, BIG_SEGMENT / 2, 512>), dim3(unsigned(huge)), dim3(512), 0, stream, huge_begin, huge_end, sorted, nq,
-                         medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end);
-      hipLaunchKernelGGL((k_dedup_huge<2 * BIG_SEGMENT, BIG_SEGMENT / 2, ~u32(0), 1024>), dim3(unsigned(huge)), dim3(1024), 0, stream, huge_begin, huge_end, sorted, nq,
-                         medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end);
-      LAUNCH_CHECK("k_dedup_huge");
-      HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      large = totals[2]; medium = totals[5]; over = totals[7];
+      hipLaunchKernelGGL(k_locate_tab_rest, dim3(grid_for(spans)), dim3(TPB), 0, stream, ix->img, d_ranges, node_off, raw_off, total_nodes, sorted,
+                         owners, later_words, spans, reinterpret_cast<unsigned long long*>(extra_slots));
     }
-    if(over > 0)
-    {
-      HIP_TRY(scratch.get(raw, total_raw));
-      HIP_TRY(hipMemcpyAsync(raw, sorted, total_raw * sizeof(u64), hipMemcpyDeviceToDevice, stream));
-    }
-    hipLaunchKernelGGL(k_sort_small, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, sorted);
-    LAUNCH_CHECK("k_sort_small");
-    if(medium > 0)
-    {
-      hipLaunchKernelGGL(k_sort_medium, dim3(unsigned(medium)), dim3(64), 0, stream, seg_begin, seg_end, nq - 1, sorted);
-      LAUNCH_CHECK("k_sort_medium");
-    }
-    if(large > 0)
-    {
-      hipLaunchKernelGGL((k_sort_big<4096, 0>), dim3(unsigned(large)), dim3(BIG_THREADS), 0, stream, seg_begin, seg_end, sorted);
-      hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(large)), dim3(BIG_THREADS), 0, stream, seg_begin, seg_end, sorted);
-      LAUNCH_CHECK("k_sort_big");
-    }
-    if(over > 0)
-    {
-      size_t sort_bytes = 0;
-      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw, sorted, int(total_raw), int(over),
-                                                         over_begin, over_end, 0, 64, stream));
-      char* sort_tmp = nullptr;
-      HIP_TRY(scratch.get(sort_tmp, sort_bytes));
-      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(over),
-                                                         over_begin, over_end, 0, 64, stream));
-    }
-    hipLaunchKernelGGL(k_mark_changes, dim3(grid_for(nwords * 64)), dim3(TPB), 0, stream, sorted, total_raw, words);
-    hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, words);
-    hipLaunchKernelGGL(k_word_counts, dim3(grid_for(nwords + 1)), dim3(TPB), 0, stream, words, nwords, word_counts);
-    LAUNCH_CHECK("k_mark_changes / k_mark_starts / k_word_counts");
+  }
+  else { launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, sorted, owners, stream); }
+  LAUNCH_CHECK("k_locate_walk");
+
+  // removeDuplicates: queries with up to SMALL_SEGMENT values are sorted in registers, up to MEDIUM_SEGMENT by a wavefront
+  // and up to BIG_SEGMENT by a workgroup in LDS, all in place.  Longer ones first lose their duplicates (k_dedup_huge) and
+  // join those lists with their distinct values (the sorts are launched over upper bounds of the list lengths and read the
+  // lengths on the device); a segment with more than BIG_SEGMENT distinct values is listed for the device-wide radix sort
+  // over (segment, value) keys.  Then flag + scan + compact.
+  u64 over = 0, over_values = 0;
+  const u64 huge = huge_a + huge_b;
+  if(huge > 0 && !ix->tune.dedup_huge)
+  {
+    // (A/B knob: no duplicate filter; every segment of more than BIG_SEGMENT values -- all on the second list -- goes to the radix sort)
+    hipLaunchKernelGGL(k_huge_to_over, dim3(grid_for(huge_b)), dim3(TPB), 0, stream, huge_begin, huge_end, nq - 1, huge_b, over_begin, over_end, d_totals);
+    LAUNCH_CHECK("k_huge_to_over");
+    rc = read_totals(ix, slot, totals, stream);
+    if(rc != GCSA2_OK) { return rc; }
+    over = totals[T_OVER]; over_values = totals[T_OVER_VALUES];
+  }
+  else if(huge_a > 0)
+  {
+    hipLaunchKernelGGL((k_dedup_huge<BIG_SEGMENT, false, 512>), dim3(unsigned(huge_a)), dim3(512), 0, stream, huge_begin, huge_end, nq - 1, sorted, nq,
+                       medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end);
+    LAUNCH_CHECK("k_dedup_huge");
+  }
+  if(huge_b > 0 && ix->tune.dedup_huge)
+  {
+    hipLaunchKernelGGL((k_dedup_huge<2 * BIG_SEGMENT, true, 1024>), dim3(unsigned(huge_b)), dim3(1024), 0, stream, huge_begin, huge_end, nq - 1, sorted, nq,
+                       medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end);
+    LAUNCH_CHECK("k_dedup_huge");
+    rc = read_totals(ix, slot, totals, stream);          // only these segments can overflow
+    if(rc != GCSA2_OK) { return rc; }
+    over = totals[T_OVER]; over_values = totals[T_OVER_VALUES];
+  }
+  hipLaunchKernelGGL(k_sort_small, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, sorted);
+  LAUNCH_CHECK("k_sort_small");
+  if(medium + huge > 0)
+  {
+    hipLaunchKernelGGL(k_sort_medium, dim3(unsigned(medium + huge)), dim3(64), 0, stream, seg_begin, seg_end, nq - 1, sorted, d_totals + T_MEDIUM);
+    LAUNCH_CHECK("k_sort_medium");
+  }
+  if(large + huge > 0)
+  {
+    hipLaunchKernelGGL((k_sort_big<4096, 0>), dim3(unsigned(large + huge)), dim3(BIG_THREADS), 0, stream, seg_begin, seg_end, sorted, d_totals + T_LARGE);
+    hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(large + huge)), dim3(BIG_THREADS), 0, stream, seg_begin, seg_end, sorted, d_totals + T_LARGE);
+    LAUNCH_CHECK("k_sort_big");
+  }
+  if(over > 0)
+  {
+    // keys = (rank of the segment) << value_bits | value; a value is a sample + fewer than 2^23 steps
+    u32 value_bits = u32(ix->img.sample_width > 24 ? ix->img.sample_width : 24) + 1, rank_bits = 1;
+    while((u64(1) << rank_bits) < over) { rank_bits++; }
+    u64 *over_off = nullptr, *over_len = nullptr;
+    HIP_TRY(scratch.get(over_off, over + 1)); HIP_TRY(scratch.get(over_len, over + 1));
+    hipLaunchKernelGGL(k_over_lengths, dim3(grid_for(over + 1)), dim3(TPB), 0, stream, over_begin, over_end, over, over_len);
     size_t scan_bytes = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, word_counts, word_before, int(nwords + 1), stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, over_len, over_off, int(over + 1), stream));
     char* scan_tmp = nullptr;
     HIP_TRY(scratch.get(scan_tmp, scan_bytes));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, word_counts, word_before, int(nwords + 1), stream));
-    u64 total_unique = 0;
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, word_before + nwords, d_totals + 3);
-    LAUNCH_CHECK("k_publish");
-    HIP_TRY(hipMemcpyAsync(&total_unique, d_totals + 3, sizeof(u64), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    *total_out = total_unique;
-    u64* out = values_for(total_unique);
-    if(out == nullptr) { return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
-    hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, words, word_before, total_raw, out);
-    LAUNCH_CHECK("k_compact");
-    hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, words, word_before, nq, total_raw, total_unique, d_offsets);
-    LAUNCH_CHECK("k_final_offsets");
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, over_len, over_off, int(over + 1), stream));
+    if(value_bits + rank_bits <= 64)
+    {
+      u64 *keys_a = nullptr, *keys_b = nullptr;
+      HIP_TRY(scratch.get(keys_a, over_values)); HIP_TRY(scratch.get(keys_b, over_values));
+      hipLaunchKernelGGL(k_over_pack, dim3(grid_for(over_values)), dim3(TPB), 0, stream, over_begin, over_off, over, over_values, sorted, value_bits, keys_a);
+      LAUNCH_CHECK("k_over_pack");
+      hipcub::DoubleBuffer<u64> keys(keys_a, keys_b);
+      size_t sort_bytes = 0;
+      HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys, size_t(over_values), 0, int(value_bits + rank_bits), stream));
+      char* sort_tmp = nullptr;
+      HIP_TRY(scratch.get(sort_tmp, sort_bytes));
+      HIP_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, keys, size_t(over_values), 0, int(value_bits + rank_bits), stream));
+      hipLaunchKernelGGL(k_over_unpack, dim3(grid_for(over_values)), dim3(TPB), 0, stream, over_begin, over_off, over_values, keys.Current(), value_bits, sorted);
+      LAUNCH_CHECK("k_over_unpack");
+    }
+    else
+    {
+      // (values too wide to share a key with the segment rank: the library's segmented sort, from a copy)
+      u64* raw = nullptr;
+      HIP_TRY(scratch.get(raw, total_raw));
+      HIP_TRY(hipMemcpyAsync(raw, sorted, total_raw * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+      size_t sort_bytes = 0;
+      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_bytes, raw, sorted, int(total_raw), int(over), over_begin, over_end, 0, 64, stream));
+      char* sort_tmp = nullptr;
+      HIP_TRY(scratch.get(sort_tmp, sort_bytes));
+      HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(over), over_begin, over_end, 0, 64, stream));
+    }
   }
-
+  hipLaunchKernelGGL(k_mark_changes, dim3(grid_for(nwords * 64)), dim3(TPB), 0, stream, sorted, total_raw, words);
+  hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, words);
+  hipLaunchKernelGGL(k_word_counts, dim3(grid_for(nwords + 1)), dim3(TPB), 0, stream, words, nwords, word_counts);
+  LAUNCH_CHECK("k_mark_changes / k_mark_starts / k_word_counts");
+  size_t scan_bytes = 0;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, word_counts, word_before, int(nwords + 1), stream));
+  char* scan_tmp = nullptr;
+  HIP_TRY(scratch.get(scan_tmp, scan_bytes));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, word_counts, word_before, int(nwords + 1), stream));
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, word_before + nwords, d_totals + T_UNIQUE);
+  LAUNCH_CHECK("k_publish");
+  u64 total_unique = 0;
+  u64* out = known_out;
+  u64 capacity = known_capacity;
+  if(out == nullptr)                 // the values buffer is made for the number of distinct values: wait for it
+  {
+    rc = read_totals(ix, slot, totals, stream);
+    if(rc != GCSA2_OK) { return rc; }
+    total_unique = totals[T_UNIQUE];
+    *total_out = total_unique;
+    out = values_for(total_unique);
+    if(out == nullptr) { return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
+    capacity = total_unique;
+  }
+  hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, words, word_before, total_raw, out, capacity);
+  LAUNCH_CHECK("k_compact");
+  hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, words, word_before, nq, total_raw, nwords, d_offsets);
+  LAUNCH_CHECK("k_final_offsets");
+  if(known_out != nullptr)
+  {
+    rc = read_totals(ix, slot, totals, stream);          // in stream order behind everything above: the pass is complete
+    if(rc != GCSA2_OK) { return rc; }
+    total_unique = totals[T_UNIQUE];
+    *total_out = total_unique;
+    if(total_unique > known_capacity) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small"); }
+  }
+  HIP_TRY(hipStreamSynchronize(stream));
   return GCSA2_OK;
 }
 
@@ -1373,14 +1497,14 @@ __global__ __launch_bounds__(TPB) void k_shift_offsets(const u64* __restrict__ s
 // paper's 16-mer batch has 2.5 G, paper.tex:403), otherwise consecutive sub-batches of queries, each below that, whose value
 // arrays are concatenated and whose offsets are shifted -- the same CSR a single pass would give.
 int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u64* d_offsets,
-                const ValuesProvider& values_for, u64* total_out, hipStream_t stream)
+                const ValuesProvider& values_for, u64* total_out, hipStream_t stream, u64* known_out = nullptr, u64 known_capacity = 0)
 {
-  int rc = locate_chunk(ix, d_ranges, nq, sort, d_offsets, values_for, total_out, stream, true);
+  int rc = locate_chunk(ix, d_ranges, nq, sort, d_offsets, values_for, total_out, stream, true, known_out, known_capacity);
   if(rc != LOCATE_NEEDS_SPLIT) { return rc; }
   struct Part { u64 q0 = 0, q1 = 0, total = 0; u64* d_off = nullptr; u64* d_val = nullptr; };
   std::vector<Part> parts;
   struct Release { std::vector<Part>& p; ~Release() { for(Part& x : p) { if(x.d_off) { (void)hipFree(x.d_off); } if(x.d_val) { (void)hipFree(x.d_val); } } } } release{parts};
-  unsigned long long* d_cut = ix->d_slots + 8 * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);
+  unsigned long long* d_cut = ix->d_slots + TOTAL_WORDS * (ix->next_slot.fetch_add(1) % RESULT_SLOTS);
   u64 q0 = 0;
   while(q0 < nq)                                   // d_offsets still holds the scan of the raw counts
   {
@@ -1487,7 +1611,7 @@ int gcsa2_locate_into(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t 
   DeviceGuard guard(ix->device);
   ValuesProvider provide = [d_values, capacity](u64 count) -> u64* { return count <= capacity ? d_values : nullptr; };
   g_error.clear();
-  return locate_core(ix, d_ranges, nq, sort, d_offsets, provide, total_values, static_cast<hipStream_t>(stream_));
+  return locate_core(ix, d_ranges, nq, sort, d_offsets, provide, total_values, static_cast<hipStream_t>(stream_), d_values, capacity);
 }
 
 // ---- host-pointer entry points: copy in, run, copy out, synchronise ----------------------
@@ -1680,11 +1804,11 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
       for(gcsa2_index::PipeSet& set : lane.set) { set.busy = false; }
     }
   };
-  std::vector<std::thread> workers;
+  Workers workers;
   const unsigned lanes = unsigned(chunks < PIPE_LANES ? chunks : PIPE_LANES);
   for(unsigned t = 1; t < lanes; t++) { workers.emplace_back(work, t); }
   work(0);
-  for(std::thread& w : workers) { w.join(); }
+  workers.join();
   for(unsigned t = 0; t < lanes; t++) { if(status[t] != GCSA2_OK) { return fail(status[t], "pipeline lane " + std::to_string(t) + ": " + messages[t]); } }
   return GCSA2_OK;
 }
@@ -2313,7 +2437,7 @@ int gcsa2_group_locate_device(gcsa2_group* g, const uint64_t* const* d_ranges, c
   std::vector<std::string> messages(G);
   struct Discard { std::vector<gcsa2_locate_job*>& j; ~Discard() { for(gcsa2_locate_job* x : j) { gcsa2_locate_discard(x); } } } discard{jobs};
   {
-    std::vector<std::thread> workers;
+    Workers workers;
     for(size_t r = 0; r < G; r++)
     {
       workers.emplace_back([&, r]()
@@ -2322,7 +2446,7 @@ int gcsa2_group_locate_device(gcsa2_group* g, const uint64_t* const* d_ranges, c
         if(status[r] != GCSA2_OK) { messages[r] = g_error; }
       });
     }
-    for(std::thread& t : workers) { t.join(); }
+    workers.join();
   }
   for(size_t r = 0; r < G; r++) { if(status[r] != GCSA2_OK) { return fail(status[r], "shard " + std::to_string(r) + ": " + messages[r]); } }
   u64 total = 0, q_before = 0;
@@ -2391,24 +2515,23 @@ int gcsa2_comm_match_stats(gcsa2_comm* c, const gcsa2_index* ix, const uint8_t* 
   char* buf = nullptr;
   HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&buf), ms_room + 24 * nq + 16, st));
   uint16_t* my_ms = reinterpret_cast<uint16_t*>(buf); u64* my_rng = reinterpret_cast<u64*>(buf + ms_room); u64* my_fb = my_rng + 2 * nq;
-  int rc = (nq > 0 ? match_stats_launch(ix, 0, d_patterns, d_offsets, nq, bytes, my_ms, my_rng, my_fb, st) : GCSA2_OK);
+  // A rank whose kernel launch fails still takes part in the three gathers (its buffers exist; the root receives whatever they
+  // hold) and reports the error afterwards: leaving now would keep the other ranks waiting in ncclSend / ncclRecv for ever.
+  // (The allocation above is the one failure that cannot be carried through: without a buffer there is nothing to send.)
+  const int launch_rc = (nq > 0 ? match_stats_launch(ix, 0, d_patterns, d_offsets, nq, bytes, my_ms, my_rng, my_fb, st) : GCSA2_OK);
+  const std::string launch_error = (launch_rc != GCSA2_OK ? g_error : std::string());
   std::vector<u64> sizes(size_t(c->world));
-  if(rc == GCSA2_OK)
+  int rc = GCSA2_OK;
+  for(int part = 0; part < 3; part++)
   {
-    for(int r = 0; r < c->world; r++) { sizes[size_t(r)] = 2 * pattern_bytes[r]; }
-    rc = gather_bytes(c->comm, c->rank, c->world, my_ms, sizes.data(), d_ms_root, root, st);
-  }
-  if(rc == GCSA2_OK)
-  {
-    for(int r = 0; r < c->world; r++) { sizes[size_t(r)] = 16 * counts[r]; }
-    rc = gather_bytes(c->comm, c->rank, c->world, my_rng, sizes.data(), d_ranges_root, root, st);
-  }
-  if(rc == GCSA2_OK)
-  {
-    for(int r = 0; r < c->world; r++) { sizes[size_t(r)] = 8 * counts[r]; }
-    rc = gather_bytes(c->comm, c->rank, c->world, my_fb, sizes.data(), d_fallbacks_root, root, st);
+    for(int r = 0; r < c->world; r++) { sizes[size_t(r)] = (part == 0 ? 2 * pattern_bytes[r] : (part == 1 ? 16 * counts[r] : 8 * counts[r])); }
+    const void* src = (part == 0 ? static_cast<const void*>(my_ms) : (part == 1 ? static_cast<const void*>(my_rng) : static_cast<const void*>(my_fb)));
+    void* dst = (part == 0 ? static_cast<void*>(d_ms_root) : (part == 1 ? static_cast<void*>(d_ranges_root) : static_cast<void*>(d_fallbacks_root)));
+    const int g_rc = gather_bytes(c->comm, c->rank, c->world, src, sizes.data(), dst, root, st);
+    if(rc == GCSA2_OK) { rc = g_rc; }
   }
   (void)hipFreeAsync(buf, st);
+  if(launch_rc != GCSA2_OK) { return fail(launch_rc, launch_error); }
   return rc;
 }
 
@@ -2428,35 +2551,85 @@ int gcsa2_comm_locate(gcsa2_comm* c, const gcsa2_index* ix, const uint64_t* d_ra
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t W = size_t(c->world);
   const bool is_root = (c->rank == root);
+  // A rank whose own part fails must not leave the others waiting in ncclSend / ncclRecv: it still joins the first gather, with
+  // FAILED as its total, and the later gathers with nothing to send; the root, which sees the mark, expects nothing from that
+  // rank, lets the healthy ranks finish and reports the failure.  Every rank returns its own status.
+  constexpr u64 FAILED = ~u64(0);
   gcsa2_locate_job* mine = nullptr;
-  int rc = gcsa2_locate_device(ix, d_ranges, counts[c->rank], sort, &mine, nullptr, nullptr, nullptr, st);
-  if(rc != GCSA2_OK) { return rc; }
+  const int local_rc = gcsa2_locate_device(ix, d_ranges, counts[c->rank], sort, &mine, nullptr, nullptr, nullptr, st);
+  const std::string local_error = (local_rc != GCSA2_OK ? g_error : std::string());
   struct Discard { gcsa2_locate_job*& j; ~Discard() { gcsa2_locate_discard(j); } } discard{mine};
-  // 1. per-rank totals: the last entry of every rank's offsets
+  // 1. per-rank totals: the last entry of every rank's offsets (a slot of the handle: no allocation that could fail in between)
   std::vector<u64> eight(W, sizeof(u64)), totals(W, 0);
+  const unsigned slot = ix->next_slot.fetch_add(1) % RESULT_SLOTS;
+  u64* d_mark = reinterpret_cast<u64*>(ix->d_slots + u64(TOTAL_WORDS) * slot);
   u64* d_totals = nullptr;
-  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&d_totals), W * sizeof(u64), st));
-  rc = gather_bytes(c->comm, c->rank, c->world, mine->d_offsets + counts[c->rank], eight.data(), d_totals, root, st);
-  if(rc == GCSA2_OK && is_root) { HIP_TRY(hipMemcpyAsync(totals.data(), d_totals, W * sizeof(u64), hipMemcpyDeviceToHost, st)); }
-  if(rc == GCSA2_OK) { HIP_TRY(hipStreamSynchronize(st)); }
-  (void)hipFreeAsync(d_totals, st);
+  struct FreeAsync { u64*& p; hipStream_t st; ~FreeAsync() { if(p != nullptr) { (void)hipFreeAsync(p, st); } } } free_totals{d_totals, st};
+  int rc = GCSA2_OK;
+  if(is_root)
+  {
+    hipError_t e = pool_alloc(ix, reinterpret_cast<void**>(&d_totals), W * sizeof(u64), st);
+    if(e != hipSuccess) { rc = fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("pool_alloc(totals): ") + hipGetErrorString(e)); }
+  }
+  if(rc != GCSA2_OK) { return rc; }               // (the root without 8 bytes per rank: nothing can be received at all)
+  const u64* my_total = (mine != nullptr ? mine->d_offsets + counts[c->rank] : d_mark);
+  if(mine == nullptr)
+  {
+    const u64 mark = FAILED;
+    hipError_t e = hipMemcpyAsync(d_mark, &mark, sizeof(u64), hipMemcpyHostToDevice, st);
+    if(e == hipSuccess) { e = hipStreamSynchronize(st); }
+    if(e != hipSuccess) { return fail(local_rc, local_error); }    // the device itself is gone
+  }
+  rc = gather_bytes(c->comm, c->rank, c->world, my_total, eight.data(), d_totals, root, st);
+  if(rc == GCSA2_OK && is_root)
+  {
+    hipError_t e = hipMemcpyAsync(totals.data(), d_totals, W * sizeof(u64), hipMemcpyDeviceToHost, st);
+    if(e != hipSuccess) { rc = fail(GCSA2_ERR_HIP, std::string("totals of the shards: ") + hipGetErrorString(e)); }
+  }
+  if(rc == GCSA2_OK)
+  {
+    hipError_t e = hipStreamSynchronize(st);
+    if(e != hipSuccess) { rc = fail(GCSA2_ERR_HIP, std::string("totals of the shards: ") + hipGetErrorString(e)); }
+  }
   if(rc != GCSA2_OK) { return rc; }
-  if(!is_root) { totals[size_t(c->rank)] = mine->total; }
+  if(!is_root) { totals[size_t(c->rank)] = (mine != nullptr ? mine->total : FAILED); }
   // 2. offsets (counts[r] entries each) and values (totals[r] each); a peer only needs its own sizes
   std::vector<u64> off_bytes(W), val_bytes(W);
   u64 total = 0, queries = 0;
-  for(size_t r = 0; r < W; r++) { off_bytes[r] = 8 * counts[r]; val_bytes[r] = 8 * totals[r]; total += totals[r]; queries += counts[r]; }
+  int failed_rank = -1;
+  for(size_t r = 0; r < W; r++)
+  {
+    const bool bad = (totals[r] == FAILED);
+    if(bad) { totals[r] = 0; if(failed_rank < 0) { failed_rank = int(r); } }
+    off_bytes[r] = (bad ? 0 : 8 * counts[r]); val_bytes[r] = 8 * totals[r]; total += totals[r]; queries += counts[r];
+  }
   gcsa2_locate_job* result = nullptr;
+  static u64 nothing_to_send = 0;
+  const u64* my_offsets = (mine != nullptr ? mine->d_offsets : &nothing_to_send);
+  const u64* my_values = (mine != nullptr ? mine->d_values : &nothing_to_send);
   if(is_root)
   {
     result = new(std::nothrow) gcsa2_locate_job();
-    if(result == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
-    result->device = c->device; result->nq = queries; result->total = total;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&result->d_values), (total > 0 ? total : 1) * sizeof(u64));
-    if(e != hipSuccess) { delete result; return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("hipMalloc(values): ") + hipGetErrorString(e)); }
+    hipError_t e = hipSuccess;
+    if(result != nullptr)
+    {
+      result->device = c->device; result->nq = queries; result->total = total;
+      e = hipMalloc(reinterpret_cast<void**>(&result->d_values), (total > 0 ? total : 1) * sizeof(u64));
+    }
+    if(result == nullptr || e != hipSuccess)
+    {
+      // the peers are about to send: without a buffer the communicator cannot complete this call on any rank
+      delete result;
+      return fail(GCSA2_ERR_OUT_OF_MEMORY, "no memory for the values of the batch on the root (the other ranks of this call will not return: destroy the communicator)");
+    }
   }
-  rc = gather_bytes(c->comm, c->rank, c->world, mine->d_offsets, off_bytes.data(), d_offsets_root, root, st);
-  if(rc == GCSA2_OK) { rc = gather_bytes(c->comm, c->rank, c->world, mine->d_values, val_bytes.data(), is_root ? result->d_values : nullptr, root, st); }
+  rc = gather_bytes(c->comm, c->rank, c->world, my_offsets, off_bytes.data(), d_offsets_root, root, st);
+  {
+    const int g_rc = gather_bytes(c->comm, c->rank, c->world, my_values, val_bytes.data(), is_root ? result->d_values : nullptr, root, st);
+    if(rc == GCSA2_OK) { rc = g_rc; }
+  }
+  if(rc == GCSA2_OK && local_rc != GCSA2_OK) { rc = fail(local_rc, local_error); }
+  if(rc == GCSA2_OK && failed_rank >= 0) { rc = fail(GCSA2_ERR_HIP, "locate failed on rank " + std::to_string(failed_rank) + " of the communicator; the batch is incomplete"); }
   if(rc == GCSA2_OK && is_root)
   {
     u64 at = 0, base = 0;
@@ -2498,7 +2671,7 @@ int gcsa2_group_find_batch(const gcsa2_group* g, const uint8_t* patterns, const 
   const u64 G = g->replicas.size(), base = nq / G, rem = nq % G;
   std::vector<int> status(G, GCSA2_OK);
   std::vector<std::string> messages(G);
-  std::vector<std::thread> workers;
+  Workers workers;
   u64 begin = 0;
   for(u64 r = 0; r < G; r++)
   {
@@ -2517,7 +2690,7 @@ int gcsa2_group_find_batch(const gcsa2_group* g, const uint8_t* patterns, const 
       catch(const std::exception& e) { status[r] = GCSA2_ERR_OUT_OF_MEMORY; messages[r] = e.what(); }
     });
   }
-  for(std::thread& t : workers) { t.join(); }
+  workers.join();
   for(u64 r = 0; r < G; r++) { if(status[r] != GCSA2_OK) { return fail(status[r], "shard " + std::to_string(r) + ": " + messages[r]); } }
   return GCSA2_OK;
   } catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_group_find_batch: ") + e.what()); }
@@ -2803,10 +2976,10 @@ int match_stats_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uin
       if(status[t] != GCSA2_OK) { messages[t] = g_error; }
     }
   };
-  std::vector<std::thread> workers;
+  Workers workers;
   for(unsigned t = 1; t < threads; t++) { workers.emplace_back(work, t); }
   work(0);
-  for(std::thread& w : workers) { w.join(); }
+  workers.join();
   for(unsigned t = 0; t < threads; t++) { if(status[t] != GCSA2_OK) { return fail(status[t], messages[t]); } }
   return GCSA2_OK;
 }

@@ -439,14 +439,18 @@ __device__ __forceinline__ u64 wg_reserve(WgSlots& sh, unsigned long long* count
 // queries with 2..SMALL_SEGMENT values are sorted in registers by one lane each (k_sort_small), queries with up to
 // MEDIUM_SEGMENT values by one wavefront each in LDS (k_sort_medium), queries with up to BIG_SEGMENT values by one workgroup
 // each in 64 KB of LDS (k_sort_big: the paper's 16-mers average 7129 values, paper.tex:403); longer ones lose their duplicates
-// first (k_dedup_huge) and join those lists, and only what still has more than BIG_SEGMENT DISTINCT values goes to hipCUB's
-// segmented radix sort.  k_collect_multi lists the medium segments (from the end of the segment arrays, downwards), the
-// large ones (from the start; MEDIUM_SEGMENT + 1 .. BIG_SEGMENT values) and the huge ones (arrays of their own) and publishes
-// totals = {nodes, raw values, large segments, (unique values, written later), segments with >= 2 values, medium segments,
-// huge segments}.
+// first (k_dedup_huge) and join those lists, and what still has more than BIG_SEGMENT DISTINCT values is sorted by ONE
+// device-wide radix sort over (segment, value) keys (k_over_pack / k_over_unpack).  k_collect_multi lists the medium
+// segments (from the end of the segment arrays, downwards), the large ones (from the start; MEDIUM_SEGMENT + 1 ..
+// BIG_SEGMENT values) and the huge ones (arrays of their own: up to HUGE_SPLIT values from the start, longer ones from the
+// end downwards -- the two instantiations of k_dedup_huge) and publishes the totals below.
 constexpr u32 SMALL_SEGMENT = 16;
 constexpr u32 MEDIUM_SEGMENT = 1024;
 constexpr u32 BIG_SEGMENT = 8192;
+constexpr u32 HUGE_SPLIT = BIG_SEGMENT / 2;
+// totals of one pass of the locate pipeline (a slot of TOTAL_WORDS u64 in device memory, mirrored to page-locked host memory)
+enum { T_NODES = 0, T_RAW = 1, T_LARGE = 2, T_UNIQUE = 3, T_MULTI = 4, T_MEDIUM = 5, T_HUGE_A = 6, T_OVER = 7, T_HUGE_B = 8, T_OVER_VALUES = 9,
+       TOTAL_WORDS = 16 };
 
 __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
                                                        unsigned long long* __restrict__ totals,
@@ -457,40 +461,50 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
   __shared__ WgSlots slots;
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   const u32 lane = threadIdx.x & 63;
-  if(q == 0) { totals[0] = node_off[nq]; totals[1] = raw_off[nq]; }
+  if(q == 0) { totals[T_NODES] = node_off[nq]; totals[T_RAW] = raw_off[nq]; }
   u64 b = 0, e = 0;
   if(q < nq) { b = raw_off[q]; e = raw_off[q + 1]; }
   const u64 multi = __ballot(e - b >= 2), large = __ballot(e - b > medium_limit && e - b <= big_limit);
   const u64 medium = __ballot(e - b > SMALL_SEGMENT && e - b <= medium_limit);
-  const u64 huge = __ballot(e - b > medium_limit && e - b > big_limit);
-  wg_reserve(slots, totals + 4, u32(__popcll(multi)));           // (every wave of the workgroup: wg_reserve synchronises it)
-  u64 slot = wg_reserve(slots, totals + 2, u32(__popcll(large)));
+  const bool is_huge = e - b > medium_limit && e - b > big_limit;
+  const u64 huge_a = __ballot(is_huge && e - b <= HUGE_SPLIT), huge_b = __ballot(is_huge && e - b > HUGE_SPLIT);
+  wg_reserve(slots, totals + T_MULTI, u32(__popcll(multi)));           // (every wave of the workgroup: wg_reserve synchronises it)
+  u64 slot = wg_reserve(slots, totals + T_LARGE, u32(__popcll(large)));
   if((large >> lane) & 1)
   {
     slot += __popcll(large & ((u64(1) << lane) - 1));
     seg_begin[slot] = b; seg_end[slot] = e;
   }
-  slot = wg_reserve(slots, totals + 5, u32(__popcll(medium)));
+  slot = wg_reserve(slots, totals + T_MEDIUM, u32(__popcll(medium)));
   if((medium >> lane) & 1)
   {
     slot += __popcll(medium & ((u64(1) << lane) - 1));
     seg_begin[nq - 1 - slot] = b; seg_end[nq - 1 - slot] = e;        // a query is in at most one of the two lists
   }
-  slot = wg_reserve(slots, totals + 6, u32(__popcll(huge)));
-  if((huge >> lane) & 1)
+  slot = wg_reserve(slots, totals + T_HUGE_A, u32(__popcll(huge_a)));
+  if((huge_a >> lane) & 1)
   {
-    slot += __popcll(huge & ((u64(1) << lane) - 1));
+    slot += __popcll(huge_a & ((u64(1) << lane) - 1));
     huge_begin[slot] = b; huge_end[slot] = e;
+  }
+  slot = wg_reserve(slots, totals + T_HUGE_B, u32(__popcll(huge_b)));
+  if((huge_b >> lane) & 1)
+  {
+    slot += __popcll(huge_b & ((u64(1) << lane) - 1));
+    huge_begin[nq - 1 - slot] = b; huge_end[nq - 1 - slot] = e;
   }
 }
 
 // one wavefront (= one workgroup) per query with SMALL_SEGMENT + 1 .. MEDIUM_SEGMENT values: bitonic sort in LDS,
 // in place.  Segment s of the list is the one at seg_begin / seg_end [last - s].
+// (The grid is an upper bound -- the duplicate filter appends to the list while the host is not looking --; `count` on the
+// device says how many segments there are.)
 __global__ __launch_bounds__(64) void k_sort_medium(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end, u64 last,
-                                                    u64* __restrict__ values)
+                                                    u64* __restrict__ values, const unsigned long long* __restrict__ count)
 {
   __shared__ u64 buf[MEDIUM_SEGMENT];
   const u32 lane = threadIdx.x;
+  if(blockIdx.x >= *count) { return; }
   const u64 b = seg_begin[last - blockIdx.x];
   const u32 len = u32(seg_end[last - blockIdx.x] - b);
   u32 n2 = 64;
@@ -522,10 +536,11 @@ __global__ __launch_bounds__(64) void k_sort_medium(const u64* __restrict__ seg_
 constexpr int BIG_THREADS = 256;
 template<u32 CAPACITY, u32 ABOVE>
 __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end,
-                                                        u64* __restrict__ values)
+                                                        u64* __restrict__ values, const unsigned long long* __restrict__ count)
 {
   __shared__ u64 buf[CAPACITY];
   const u32 tid = threadIdx.x;
+  if(blockIdx.x >= *count) { return; }                      // the grid is an upper bound (see k_sort_medium)
   const u64 b = seg_begin[blockIdx.x];
   const u32 len = u32(seg_end[blockIdx.x] - b);            // <= BIG_SEGMENT: k_collect_multi
   if(len > CAPACITY || len <= ABOVE) { return; }            // the other instantiation's segment (uniform per workgroup)
@@ -556,17 +571,18 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict_
 // medium class here: a segment without duplicates pays one extra pass, a tenth of its sort.)  A segment with at most BIG_SEGMENT distinct values leaves
 // as: its distinct values (unsorted) at the front, the rest of the segment filled with its largest value (duplicates that
 // the flag pass drops), and the front appended to the medium or large list for the LDS sorts that run next.  A segment with
-// more distinct values is left untouched and listed for the segmented radix sort (over_begin / over_end, counted in totals[7]).
-// Two instantiations share the list, like k_sort_big: 8192 slots (64 KB, two workgroups per CU) take the segments of up to
-// 4096 values, which cannot overflow; 16384 slots (128 KB) the longer ones.  A workgroup whose segment belongs to the other
-// instantiation exits at once.  512 threads with 64 KB (two workgroups per CU), 1024 with 128 KB (one).
+// more distinct values is left untouched and listed for the device-wide radix sort (over_begin / over_end, counted in totals[T_OVER]).
+// Two instantiations, each with its own list (k_collect_multi): 8192 slots (64 KB, two workgroups per CU) take the segments
+// of up to HUGE_SPLIT = 4096 values, which cannot overflow (list from the start of huge_begin / huge_end); 16384 slots (128 KB)
+// the longer ones (FROM_END: segment s of the list is at [last - s]).  512 threads with 64 KB, 1024 with 128 KB (one per CU).
+// A segment that overflows stops reading at once: a range of 200 000 distinct values costs the 16 000 it took to find out.
 constexpr u64 HUGE_EMPTY = ~u64(0);
 
 // (Reading the locate table from this kernel instead of the walk's output -- the raw values of these queries never written --
 // was measured: 8.7 against 5.9 ms for the repeat-rich batch.  One or two workgroups per CU do not hide the latency of the
 // table gathers; the walk kernel with a lane per path node does.)
-template<u32 HUGE_SLOTS, u32 ABOVE, u32 UPTO, int HUGE_THREADS>
-__global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restrict__ huge_begin, const u64* __restrict__ huge_end,
+template<u32 HUGE_SLOTS, bool FROM_END, int HUGE_THREADS>
+__global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restrict__ huge_begin, const u64* __restrict__ huge_end, u64 last,
                                                             u64* __restrict__ values, u64 nq, u32 medium_limit,
                                                             unsigned long long* __restrict__ totals,
                                                             u64* __restrict__ seg_begin, u64* __restrict__ seg_end,
@@ -576,8 +592,8 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   __shared__ u32 distinct, has_ones, placed;
   __shared__ unsigned long long largest;
   const u32 tid = threadIdx.x;
-  const u64 b = huge_begin[blockIdx.x], e = huge_end[blockIdx.x], len = e - b;
-  if(len <= ABOVE || len > UPTO) { return; }                // the other instantiation's segment (uniform per workgroup)
+  const u64 at = (FROM_END ? last - blockIdx.x : u64(blockIdx.x));
+  const u64 b = huge_begin[at], e = huge_end[at], len = e - b;
   constexpr u32 MOST = HUGE_SLOTS / 2;                      // distinct values a segment may have here
   constexpr u32 STOP = HUGE_SLOTS - HUGE_THREADS - 1;       // no insertion beyond this many: a slot stays free, the probing always ends
   for(u32 i = tid; i < HUGE_SLOTS; i += HUGE_THREADS) { table[i] = HUGE_EMPTY; }
@@ -602,6 +618,7 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   constexpr u32 AHEAD = 4;
   for(u64 base = tid; base < items; base += AHEAD * HUGE_THREADS)
   {
+    if(*reinterpret_cast<volatile u32*>(&distinct) >= STOP) { break; }           // overflowed: nothing more to learn
     u64 got[AHEAD];
 #pragma unroll
     for(u32 j = 0; j < AHEAD; j++)
@@ -622,8 +639,9 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   {
     if(tid == 0)
     {
-      const u64 slot = atomicAdd(totals + 7, 1ull);
+      const u64 slot = atomicAdd(totals + T_OVER, 1ull);
       over_begin[slot] = b; over_end[slot] = e;
+      atomicAdd(totals + T_OVER_VALUES, (unsigned long long)len);
     }
     return;
   }
@@ -647,12 +665,12 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   {
     if(count <= medium_limit && medium_limit > SMALL_SEGMENT)
     {
-      const u64 slot = atomicAdd(totals + 5, 1ull);
+      const u64 slot = atomicAdd(totals + T_MEDIUM, 1ull);
       seg_begin[nq - 1 - slot] = b; seg_end[nq - 1 - slot] = b + count;
     }
     else
     {
-      const u64 slot = atomicAdd(totals + 2, 1ull);
+      const u64 slot = atomicAdd(totals + T_LARGE, 1ull);
       seg_begin[slot] = b; seg_end[slot] = b + count;
     }
   }
@@ -845,7 +863,7 @@ __global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* _
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q >= nq) { return; }
-  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; totals[0] = totals[1] = totals[2] = totals[3] = totals[4] = totals[5] = totals[6] = totals[7] = 0; }
+  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; for(u32 i = 0; i < TOTAL_WORDS; i++) { totals[i] = 0; } }
   ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
   u64 nodes = 0, raw = 0;
   if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831
@@ -890,6 +908,62 @@ __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __
   while(!bv_get(img.samples, s - 1));                        // lastSample, gcsa.h:208
 }
 
+// Segments with more than BIG_SEGMENT distinct values (a 16-mer of an interspersed repeat matches 200 000 path nodes on the
+// repeat-rich 2^30-base text): ONE device-wide radix sort over keys (rank of the segment among those segments) << value_bits
+// | value sorts them all at once, whatever their sizes -- round 3 gave them to the library's SEGMENTED sort, whose work per
+// segment made a batch of 16 000 such segments 100 ms.  over_off = exclusive scan of the segment lengths (over + 1 entries).
+__global__ __launch_bounds__(TPB) void k_over_lengths(const u64* __restrict__ over_begin, const u64* __restrict__ over_end, u64 over,
+                                                      u64* __restrict__ lengths)
+{
+  const u64 s = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(s <= over) { lengths[s] = (s < over ? over_end[s] - over_begin[s] : 0); }
+}
+
+__global__ __launch_bounds__(TPB) void k_over_pack(const u64* __restrict__ over_begin, const u64* __restrict__ over_off, u64 over, u64 total,
+                                                   const u64* __restrict__ values, u32 value_bits, u64* __restrict__ keys)
+{
+  const u64 i = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(i >= total) { return; }
+  u64 lo = 0, hi = over - 1;                                  // last segment with over_off[s] <= i
+  while(lo < hi)
+  {
+    const u64 mid = (lo + hi + 1) >> 1;
+    if(over_off[mid] <= i) { lo = mid; } else { hi = mid - 1; }
+  }
+  keys[i] = (lo << value_bits) | values[over_begin[lo] + (i - over_off[lo])];
+}
+
+__global__ __launch_bounds__(TPB) void k_over_unpack(const u64* __restrict__ over_begin, const u64* __restrict__ over_off, u64 total,
+                                                     const u64* __restrict__ keys, u32 value_bits, u64* __restrict__ values)
+{
+  const u64 i = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(i >= total) { return; }
+  const u64 key = keys[i], s = key >> value_bits;
+  values[over_begin[s] + (i - over_off[s])] = key & ((u64(1) << value_bits) - 1);
+}
+
+// (GCSA2_DEDUP_HUGE=0, an A/B knob: the second huge list becomes the list of the radix sort as it is)
+__global__ __launch_bounds__(TPB) void k_huge_to_over(const u64* __restrict__ huge_begin, const u64* __restrict__ huge_end, u64 last, u64 count,
+                                                      u64* __restrict__ over_begin, u64* __restrict__ over_end, unsigned long long* __restrict__ totals)
+{
+  const u64 i = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(i >= count) { return; }
+  const u64 b = huge_begin[last - i], e = huge_end[last - i];
+  over_begin[i] = b; over_end[i] = e;
+  atomicAdd(totals + T_OVER_VALUES, (unsigned long long)(e - b));
+  if(i == 0) { totals[T_OVER] = count; }
+}
+
+// The totals of a pass, copied to page-locked host memory the host polls (h[TOTAL_WORDS - 1] = ticket, written last): a
+// read-back for 10 us instead of the 100-400 us of hipMemcpyAsync into pageable memory + hipStreamSynchronize.
+__global__ __launch_bounds__(64) void k_publish_totals(const unsigned long long* __restrict__ totals, volatile unsigned long long* h, unsigned long long ticket)
+{
+  if(threadIdx.x < TOTAL_WORDS - 1) { h[threadIdx.x] = totals[threadIdx.x]; }
+  __threadfence_system();
+  __syncthreads();
+  if(threadIdx.x == 0) { h[TOTAL_WORDS - 1] = ticket; }
+}
+
 // First occurrences of every value inside its (sorted) segment -- a value that differs from its predecessor (k_mark_changes, one
 // streaming pass) or the first value of a non-empty query (k_mark_starts, one lane per query, afterwards) -- as a BIT MAP, one
 // 64-bit word per 64 values (a wavefront's ballot), and their exclusive prefix sums per WORD (k_word_counts + a scan over
@@ -923,25 +997,30 @@ __device__ __forceinline__ u64 kept_before(const u64* __restrict__ words, const 
   return u64(word_before[g >> 6]) + u64(__popcll(words[g >> 6] & ((u64(1) << (g & 63)) - 1)));
 }
 
+// (capacity: a caller-owned buffer is written while its size is still unchecked on the host -- nothing lands outside it)
 __global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted, const u64* __restrict__ words,
-                                                 const u32* __restrict__ word_before, u64 total, u64* __restrict__ out)
+                                                 const u32* __restrict__ word_before, u64 total, u64* __restrict__ out, u64 capacity)
 {
   u64 g = u64(blockIdx.x) * TPB + threadIdx.x;
   if(g >= total) { return; }
   const u64 word = words[g >> 6];
-  if((word >> (g & 63)) & 1) { out[u64(word_before[g >> 6]) + u64(__popcll(word & ((u64(1) << (g & 63)) - 1)))] = sorted[g]; }
+  if((word >> (g & 63)) & 1)
+  {
+    const u64 dest = u64(word_before[g >> 6]) + u64(__popcll(word & ((u64(1) << (g & 63)) - 1)));
+    if(dest < capacity) { out[dest] = sorted[g]; }
+  }
 }
 
 __global__ void k_publish(const u32* __restrict__ src, unsigned long long* __restrict__ dst) { *dst = *src; }
 
-// in place: offsets[] holds the raw (with duplicates) offsets on entry, the final ones on return
+// in place: offsets[] holds the raw (with duplicates) offsets on entry, the final ones on return; total_unique = word_before[nwords]
 __global__ __launch_bounds__(TPB) void k_final_offsets(const u64* __restrict__ words, const u32* __restrict__ word_before, u64 nq, u64 total,
-                                                       u64 total_unique, u64* offsets)
+                                                       u64 nwords, u64* offsets)
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   if(q > nq) { return; }
   u64 r = (q < nq ? offsets[q] : total);
-  offsets[q] = (r < total ? kept_before(words, word_before, r) : total_unique);
+  offsets[q] = (r < total ? kept_before(words, word_before, r) : u64(word_before[nwords]));
 }
 
 

@@ -1163,8 +1163,8 @@ def test_locate_splits_large_batches(case, engine, monkeypatch):
 def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
     """removeDuplicates at every segment size class: 1 value, 2..16 (registers, one lane), 17..1024 (one wavefront in
     LDS), 1025..8192 (one workgroup in LDS), more (duplicates removed through an LDS hash set, then the LDS sorts; the
-    segmented radix sort when more than 8192 values are distinct -- the whole-index range here -- or, with GCSA2_DEDUP_HUGE=0,
-    always), mixed in one batch and in both sort modes; ranges of consecutive path nodes of a repetitive SNP graph (many
+    device-wide radix sort over (segment, value) keys when more than 8192 values are distinct -- the whole-index range here --
+    or, with GCSA2_DEDUP_HUGE=0, always), mixed in one batch and in both sort modes; ranges of consecutive path nodes of a repetitive SNP graph (many
     duplicates per segment).  A second batch has no segment beyond 8192 values: the library sort is then not called at all."""
     from oracle.oracle import OracleIndex
     from workload import builder
@@ -1200,6 +1200,53 @@ def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
     go, gv = gpu.locate_batch(modest)
     co, cv = cpu.locate_batch(modest, threads=8)
     assert np.array_equal(go, co) and np.array_equal(gv, cv) and int(np.diff(co).max()) > 1024
+
+
+def test_locate_many_large_distinct_segments(engine):
+    """Ranges of thousands of path nodes whose values are all DISTINCT (a linear text: one value per path node), as found
+    16-mers of interspersed repeats have on the 2^30-base text of bench.py: dozens of segments beyond the 8192 distinct values
+    the LDS hash set and sorts hold, sorted by ONE device-wide radix sort over (segment, value) keys; through the job interface
+    (the value buffer is made once the total is known) and into caller-owned buffers (no wait for the total; a buffer that is
+    too small is refused with the size needed and nothing is written behind its end)."""
+    import torch
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    g = graphs.linear_graph(70000, 0x4E1, node_len=32)
+    ix = builder.build(g, 16, sample_period=32)
+    gpu, lcp = engine.open_index(ix)
+    cpu = OracleIndex(ix)
+    rng = SplitMix64(0x4E2)
+    ranges = []
+    for width in (8193, 8500, 9000, 12000, 16384, 20000, 33000, 50000, 3, 1, 700, 4097, 5000):
+        for _ in range(5):
+            a = rng.below(ix.n - width)
+            ranges.append((a, a + width - 1))
+    ranges += [(0, ix.n - 1), (9, 8)]
+    order = list(range(len(ranges)))
+    for k in range(len(order) - 1, 0, -1):
+        j = rng.below(k + 1)
+        order[k], order[j] = order[j], order[k]
+    arr = np.array([ranges[k] for k in order], dtype=np.uint64)
+    co, cv = cpu.locate_batch(arr, threads=8)
+    assert int(np.diff(co).max()) == ix.n and int((np.diff(co) > 8192).sum()) >= 40
+    go, gv = gpu.locate_batch(arr)
+    assert np.array_equal(go, co) and np.array_equal(gv, cv)
+    dev = torch.device("cuda", 0)
+    d_r = torch.from_numpy(arr.view(np.int64)).to(dev)
+    d_o = torch.full((len(arr) + 1,), -1, dtype=torch.int64, device=dev)
+    d_v = torch.full((len(cv) + 7,), -1, dtype=torch.int64, device=dev)
+    for _ in range(3):                                         # the scratch pool and the result slots are reused
+        total = gpu.locate_into(d_r.data_ptr(), len(arr), d_o.data_ptr(), d_v.data_ptr(), d_v.shape[0])
+        assert total == len(cv) and np.array_equal(d_o.cpu().numpy().view(np.uint64), co)
+        assert np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], cv) and (d_v[total:] == -1).all()
+    d_v.fill_(-1)
+    with pytest.raises(engine.Gcsa2Error) as e:
+        gpu.locate_into(d_r.data_ptr(), len(arr), d_o.data_ptr(), d_v.data_ptr(), len(cv) // 2)
+    assert e.value.code == -6 and e.value.needed == len(cv) and (d_v[len(cv) // 2:] == -1).all()
+    gpu.trim()                                                 # gives the pools back; the next call builds them again
+    go, gv = gpu.locate_batch(arr[:20])
+    c2o, c2v = cpu.locate_batch(arr[:20], threads=8)
+    assert np.array_equal(go, c2o) and np.array_equal(gv, c2v)
 
 
 def test_index_from_device_resident_arrays(case, engine):
