@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the request-rate ceiling, the device telemetry and the host-batch leg "
                                                                "(profiler passes: only the timed kernel and its instrumented twin run)")
     ap.add_argument("--secondary", choices=["all", "config5", "wide", "ladder", "chr22", "repeats", "repeats30", "human32", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
+    ap.add_argument("--locate-ranges", type=int, default=0, help="ranges of the locate() leg (default: 400 k on the repeat-rich indexes, every range on chr22)")
     ap.add_argument("--locate", action="store_true", help="chr22 / repeats / repeats30: run the locate() leg even with --no-extras (profiler passes)")
     ap.add_argument("--variant", type=int, default=2, help="find launch shape (2 = one lane per query in batch order, 4 = queries ordered by length first)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
@@ -1516,7 +1517,7 @@ def main():
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds)
     if rank == 0 and world == 1 and args.workload in ("repeats", "repeats30", "chr22") and wl.gpu.sampleCount() > 0 and (args.locate or not args.no_extras):
-        nloc = min(wl.nq, 400_000 if args.workload.startswith("repeats") else wl.nq)
+        nloc = min(wl.nq, args.locate_ranges or (400_000 if args.workload.startswith("repeats") else wl.nq))
         result["locate"], _, _ = measure_locate(wl.gpu, r["d_out"][:nloc].contiguous(), dev, 3)
     secondary = args.workload in ("pangenome", "pangenome_plain", "human") and world == 1 and not args.no_secondary
     if secondary and args.secondary in ("all", "config5") and wl.ix.lcp_size > 0:

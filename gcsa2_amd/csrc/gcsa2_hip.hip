@@ -20,6 +20,8 @@
 #include "../../include/gcsa2_hip.h"
 
 #include <hipcub/hipcub.hpp>
+#include <chrono>
+#include <cstdio>
 
 #include <cstdio>
 #include <cstdlib>
@@ -91,6 +93,10 @@ struct gcsa2_index
   struct PipeLane { hipStream_t stream = nullptr, down = nullptr; PipeSet set[2]; };
   mutable std::mutex pipe_lock;
   mutable std::vector<PipeLane> pipe;
+  // scratch arenas of the locate pipeline that are not in use (struct Scratch)
+  struct Arena { char* base = nullptr; size_t bytes = 0; };
+  mutable std::mutex arena_lock;
+  mutable std::vector<Arena> arenas;
   // tuning knobs, read from the environment ONCE, when the index is created (A/B measurements; results never depend on them)
   struct Tuning
   {
@@ -105,6 +111,7 @@ struct gcsa2_index
     bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the device-wide radix sort, duplicates and all
     bool zero_copy = true;             // GCSA2_ZERO_COPY=0: small host-pointer calls copy through the arenas like large ones
     u32 seed_wide = (u32(1) << 24) - 1;   // GCSA2_SEED_WIDE: seed-table entries of this many path nodes or more are marked, not stored (tests)
+    bool locate_trace = false;         // GCSA2_LOCATE_TRACE=1: host-clock stamps of a locate pass on stderr (profiles/r04_locate.md)
     u64 budget_bytes = 0;              // GCSA2_MEMORY_BUDGET_MB: most device memory the image may take (0: what the device has free)
   } tune;
 };
@@ -495,16 +502,52 @@ inline hipError_t pool_alloc(const gcsa2_index* ix, void** p, size_t bytes, hipS
 }
 
 // stream-ordered scratch: no device-wide synchronisation from allocation or release
+// Scratch of one locate pass: carved out of an ARENA the handle keeps (one per concurrent call; grown to the largest pass seen,
+// released by gcsa2_index_trim).  Round 3 took every buffer from the stream-ordered pool: fifteen hipFreeAsync calls at the end
+// of a pass cost 1.0-1.4 ms of host time -- a quarter of a 4.4 ms batch (GCSA2_LOCATE_TRACE, profiles/r04_locate.md).
+// A buffer that does not fit the arena is a plain allocation for this pass; the arena is re-made at the new size when the pass
+// ends.  The arena goes back to the handle only when the stream is known to be idle (`settled`, or a synchronisation here).
 struct Scratch
 {
-  const gcsa2_index* ix; hipStream_t stream; std::vector<void*> held;
-  Scratch(const gcsa2_index* ix, hipStream_t s) : ix(ix), stream(s) {}
-  ~Scratch() { for(void* p : held) { (void)hipFreeAsync(p, stream); } }
+  const gcsa2_index* ix; hipStream_t stream;
+  gcsa2_index::Arena arena;
+  size_t used = 0, wanted = 0;
+  std::vector<void*> extra;
+  bool settled = false;
+  Scratch(const gcsa2_index* ix, hipStream_t s) : ix(ix), stream(s)
+  {
+    std::lock_guard<std::mutex> guard(ix->arena_lock);
+    size_t best = 0;
+    for(size_t i = 1; i < ix->arenas.size(); i++) { if(ix->arenas[i].bytes > ix->arenas[best].bytes) { best = i; } }
+    if(!ix->arenas.empty()) { arena = ix->arenas[best]; ix->arenas.erase(ix->arenas.begin() + long(best)); }
+  }
+  ~Scratch()
+  {
+    if(!settled) { (void)hipStreamSynchronize(stream); }
+    for(void* p : extra) { (void)hipFree(p); }
+    if(wanted > arena.bytes)
+    {
+      if(arena.base != nullptr) { (void)hipFree(arena.base); }
+      arena.base = nullptr; arena.bytes = 0;
+      void* fresh = nullptr;
+      const size_t want = wanted + wanted / 8;
+      if(hipMalloc(&fresh, want) == hipSuccess) { arena.base = static_cast<char*>(fresh); arena.bytes = want; }
+      else { (void)hipGetLastError(); }
+    }
+    if(arena.base != nullptr)
+    {
+      std::lock_guard<std::mutex> guard(ix->arena_lock);
+      ix->arenas.push_back(arena);
+    }
+  }
   template<class T> hipError_t get(T*& p, u64 count)
   {
+    const size_t bytes = (size_t(count > 0 ? count : 1) * sizeof(T) + 255) & ~size_t(255);
+    wanted += bytes;
+    if(arena.base != nullptr && used + bytes <= arena.bytes) { p = reinterpret_cast<T*>(arena.base + used); used += bytes; return hipSuccess; }
     void* raw = nullptr;
-    hipError_t e = pool_alloc(ix, &raw, (count > 0 ? count : 1) * sizeof(T), stream);
-    if(e == hipSuccess) { held.push_back(raw); p = static_cast<T*>(raw); }
+    hipError_t e = hipMalloc(&raw, bytes);
+    if(e == hipSuccess) { extra.push_back(raw); p = static_cast<T*>(raw); }
     return e;
   }
 };
@@ -634,6 +677,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 12, 1, 16));
     ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);
     ix->tune.ms_pieces = (knob("GCSA2_MS_PIECES", 1, 0, 1) != 0);
+    ix->tune.locate_trace = (knob("GCSA2_LOCATE_TRACE", 0, 0, 1) != 0);
     ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
     {
       const char* b = std::getenv("GCSA2_MEMORY_BUDGET_MB");           // megabytes, fractions allowed (small test indexes)
@@ -1006,6 +1050,9 @@ void release_host_staging(gcsa2_index* ix)
     delete st;
   }
   ix->staging_pool.clear();
+  std::lock_guard<std::mutex> arena_guard(ix->arena_lock);
+  for(gcsa2_index::Arena& a : ix->arenas) { if(a.base) { (void)hipFree(a.base); } }
+  ix->arenas.clear();
 }
 }  // namespace
 
@@ -1254,6 +1301,9 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     return GCSA2_OK;
   }
   Scratch scratch(ix, stream);
+  const auto t_start = std::chrono::steady_clock::now();
+  double stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int k) { if(ix->tune.locate_trace) { stamps[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(); } };
 
   // [node_counts | raw_counts | node_off] (nq + 1 each), [seg_begin | seg_end] (nq each), the totals; the
   // scan of the raw counts goes straight into the job's offsets (final as they are unless duplicates
@@ -1282,8 +1332,11 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, huge_begin, huge_end, medium_limit, big_limit);
   LAUNCH_CHECK("k_collect_multi");
   unsigned long long totals[TOTAL_WORDS];
+  stamp(0);
   int rc = read_totals(ix, slot, totals, stream);
   if(rc != GCSA2_OK) { return rc; }
+  stamp(1);
+  scratch.settled = true;            // the totals have arrived: nothing of this pass is in flight (until the next launch)
   const u64 total_nodes = totals[T_NODES], total_raw = totals[T_RAW], multi = totals[T_MULTI], huge_a = totals[T_HUGE_A], huge_b = totals[T_HUGE_B];
   const u64 large = totals[T_LARGE], medium = totals[T_MEDIUM];
   if(total_raw > ix->tune.locate_split)
@@ -1311,9 +1364,11 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     // value per query that output is already sorted and distinct.
     u64* out = (known_out != nullptr ? (total_raw <= known_capacity ? known_out : nullptr) : values_for(total_raw));
     if(out == nullptr) { *total_out = total_raw; return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
+    scratch.settled = false;
     launch_walk(ix, d_ranges, nq, node_off, raw_off, total_nodes, out, owners, stream);
     LAUNCH_CHECK("k_locate_walk");
     HIP_TRY(hipStreamSynchronize(stream));
+    scratch.settled = true;
     *total_out = total_raw;
     return GCSA2_OK;
   }
@@ -1322,6 +1377,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   const u64 nwords = total_raw / 64 + 1;
   HIP_TRY(scratch.get(sorted, total_raw));
   HIP_TRY(scratch.get(words, nwords)); HIP_TRY(scratch.get(word_counts, nwords + 1)); HIP_TRY(scratch.get(word_before, nwords + 1));
+  scratch.settled = false;
   if(ix->img.locate_tab != nullptr)
   {
     // unordered table walk in two passes (kernels_locate.hpp): single values at once, the path nodes with several values
@@ -1370,9 +1426,11 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     hipLaunchKernelGGL((k_dedup_huge<2 * BIG_SEGMENT, true, 1024>), dim3(unsigned(huge_b)), dim3(1024), 0, stream, huge_begin, huge_end, nq - 1, sorted, nq,
                        medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end);
     LAUNCH_CHECK("k_dedup_huge");
+    stamp(2);
     rc = read_totals(ix, slot, totals, stream);          // only these segments can overflow
     if(rc != GCSA2_OK) { return rc; }
     over = totals[T_OVER]; over_values = totals[T_OVER_VALUES];
+    stamp(3);
   }
   hipLaunchKernelGGL(k_sort_small, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, sorted);
   LAUNCH_CHECK("k_sort_small");
@@ -1448,23 +1506,35 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     if(rc != GCSA2_OK) { return rc; }
     total_unique = totals[T_UNIQUE];
     *total_out = total_unique;
+    scratch.settled = true;
     out = values_for(total_unique);
     if(out == nullptr) { return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
     capacity = total_unique;
+    scratch.settled = false;
   }
   hipLaunchKernelGGL(k_compact, dim3(grid_for(total_raw)), dim3(TPB), 0, stream, sorted, words, word_before, total_raw, out, capacity);
   LAUNCH_CHECK("k_compact");
   hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, words, word_before, nq, total_raw, nwords, d_offsets);
   LAUNCH_CHECK("k_final_offsets");
+  stamp(4);
   if(known_out != nullptr)
   {
     rc = read_totals(ix, slot, totals, stream);          // in stream order behind everything above: the pass is complete
     if(rc != GCSA2_OK) { return rc; }
+    stamp(5);
+    scratch.settled = true;
     total_unique = totals[T_UNIQUE];
     *total_out = total_unique;
     if(total_unique > known_capacity) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small"); }
   }
   HIP_TRY(hipStreamSynchronize(stream));
+  scratch.settled = true;
+  stamp(6);
+  if(ix->tune.locate_trace)
+  {
+    std::fprintf(stderr, "[locate] enqueued sizes %.0f us | totals %.0f | walk + filter enqueued %.0f | totals %.0f | sorts + flags + compact enqueued %.0f | totals %.0f | done %.0f\n",
+                 stamps[0], stamps[1], stamps[2], stamps[3], stamps[4], stamps[5], stamps[6]);
+  }
   return GCSA2_OK;
 }
 
@@ -1611,7 +1681,13 @@ int gcsa2_locate_into(const gcsa2_index* ix, const uint64_t* d_ranges, uint64_t 
   DeviceGuard guard(ix->device);
   ValuesProvider provide = [d_values, capacity](u64 count) -> u64* { return count <= capacity ? d_values : nullptr; };
   g_error.clear();
-  return locate_core(ix, d_ranges, nq, sort, d_offsets, provide, total_values, static_cast<hipStream_t>(stream_), d_values, capacity);
+  const auto t0 = std::chrono::steady_clock::now();
+  rc = locate_core(ix, d_ranges, nq, sort, d_offsets, provide, total_values, static_cast<hipStream_t>(stream_), d_values, capacity);
+  if(ix->tune.locate_trace)
+  {
+    std::fprintf(stderr, "[locate] gcsa2_locate_into: %.0f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
+  return rc;
 }
 
 // ---- host-pointer entry points: copy in, run, copy out, synchronise ----------------------

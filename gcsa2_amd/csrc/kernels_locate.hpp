@@ -595,14 +595,19 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   const u64 at = (FROM_END ? last - blockIdx.x : u64(blockIdx.x));
   const u64 b = huge_begin[at], e = huge_end[at], len = e - b;
   constexpr u32 MOST = HUGE_SLOTS / 2;                      // distinct values a segment may have here
-  constexpr u32 STOP = HUGE_SLOTS - HUGE_THREADS - 1;       // no insertion beyond this many: a slot stays free, the probing always ends
+  // No insertion once more than MOST distinct values have been seen: the segment has overflowed, nothing more to learn.  (Lanes
+  // that passed the test together still insert: at most MOST + HUGE_THREADS values, well below HUGE_SLOTS, so the probing always
+  // ends.  Round 3 filled the table to HUGE_SLOTS - HUGE_THREADS first: linear probing at a load of 0.94 under 1024 lanes of
+  // LDS atomics made every all-distinct segment cost a millisecond, 93 ms of a 134 ms batch; profiles/r04_locate.md.)
+  constexpr u32 STOP = MOST + 1;
+  static_assert(MOST + 1 + HUGE_THREADS < HUGE_SLOTS, "the table must keep free slots");
   for(u32 i = tid; i < HUGE_SLOTS; i += HUGE_THREADS) { table[i] = HUGE_EMPTY; }
   if(tid == 0) { distinct = 0; has_ones = 0; placed = 0; largest = 0; }
   __syncthreads();
   auto insert = [&](u64 v)
   {
     if(v == HUGE_EMPTY) { has_ones = 1; return; }
-    if(*reinterpret_cast<volatile u32*>(&distinct) >= STOP) { return; }        // the segment has overflowed (STOP > MOST)
+    if(*reinterpret_cast<volatile u32*>(&distinct) >= STOP) { return; }        // the segment has overflowed
     u32 slot = u32((v * 0x9E3779B97F4A7C15ull) >> 32) & (HUGE_SLOTS - 1);
     while(true)
     {
@@ -919,18 +924,24 @@ __global__ __launch_bounds__(TPB) void k_over_lengths(const u64* __restrict__ ov
   if(s <= over) { lengths[s] = (s < over ? over_end[s] - over_begin[s] : 0); }
 }
 
+// (the segment of a wavefront's first value is searched once, through the scalar cache; its other lanes step on from there --
+// a segment has thousands of values, so almost always not at all.  A search per value was 14 dependent loads for each.)
 __global__ __launch_bounds__(TPB) void k_over_pack(const u64* __restrict__ over_begin, const u64* __restrict__ over_off, u64 over, u64 total,
                                                    const u64* __restrict__ values, u32 value_bits, u64* __restrict__ keys)
 {
   const u64 i = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(i >= total) { return; }
-  u64 lo = 0, hi = over - 1;                                  // last segment with over_off[s] <= i
+  const u64 first = __builtin_amdgcn_readfirstlane(u32(i >> 32)) * (u64(1) << 32) + __builtin_amdgcn_readfirstlane(u32(i));
+  if(first >= total) { return; }                              // uniform
+  u64 lo = 0, hi = over - 1;                                  // last segment with over_off[s] <= first
   while(lo < hi)
   {
     const u64 mid = (lo + hi + 1) >> 1;
-    if(over_off[mid] <= i) { lo = mid; } else { hi = mid - 1; }
+    if(over_off[mid] <= first) { lo = mid; } else { hi = mid - 1; }
   }
-  keys[i] = (lo << value_bits) | values[over_begin[lo] + (i - over_off[lo])];
+  if(i >= total) { return; }
+  u64 s = lo;
+  while(s + 1 < over && over_off[s + 1] <= i) { s++; }
+  keys[i] = (s << value_bits) | values[over_begin[s] + (i - over_off[s])];
 }
 
 __global__ __launch_bounds__(TPB) void k_over_unpack(const u64* __restrict__ over_begin, const u64* __restrict__ over_off, u64 total,
