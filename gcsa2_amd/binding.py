@@ -37,7 +37,7 @@ EXPORTS = [
     "gcsa2_group_find_batch", "gcsa2_group_find_device", "gcsa2_group_uses_rccl",
     "gcsa2_group_match_stats_device", "gcsa2_group_locate_device", "gcsa2_comm_match_stats", "gcsa2_comm_locate",
     "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_rccl_ranks", "gcsa2_comm_gather",
-    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_pack_ranges40_device", "gcsa2_unpack_ranges40_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device",
+    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_pack_ranges40_device", "gcsa2_unpack_ranges40_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device", "gcsa2_match_breaks_device",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
     "gcsa2_host_view_parse_gcsa", "gcsa2_host_view_parse_lcp", "gcsa2_host_view_serialize_gcsa", "gcsa2_host_view_serialize_lcp",
@@ -140,6 +140,7 @@ def load_library():
     L.gcsa2_match_stats_device_variant.argtypes = [vp, C.c_int, vp, vp, u64, vp, vp, vp, vp]
     L.gcsa2_match_stats_device_sized.argtypes = [vp, C.c_int, vp, vp, u64, u64, vp, vp, vp, vp]
     L.gcsa2_match_stats_profile_device.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp, vp, vp]
+    L.gcsa2_match_breaks_device.argtypes = [vp, vp, vp, u64, u64, i32, vp, vp, u64, u64p, vp, vp, vp]
     L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
     L.gcsa2_group_destroy.argtypes = [vp]
     L.gcsa2_group_destroy.restype = None
@@ -508,6 +509,21 @@ class GCSA:
         else:
             _check(self._L.gcsa2_match_stats_device_sized(self._h, variant, d_patterns, d_offsets, nq, int(total_bytes), d_ms, d_ranges,
                                                           d_fallbacks, stream))
+
+    def match_breaks_device(self, d_patterns, d_offsets, nq, total_bytes, d_break_offsets, d_breaks, capacity, d_ranges=0, d_fallbacks=0,
+                            stream=0, variant=0):
+        """Matching statistics as break points (gcsa2_match_breaks_device): the CSR of the left-maximal matches, records of four
+        u64 {position, length, sp, ep}; returns the number of records.  Raises Gcsa2Error (BUFFER_TOO_SMALL, `.needed`) when
+        `capacity` records are not enough."""
+        total = C.c_uint64()
+        tb = 0xFFFFFFFFFFFFFFFF if total_bytes is None else int(total_bytes)
+        rc = self._L.gcsa2_match_breaks_device(self._h, d_patterns, d_offsets, nq, tb, variant, d_break_offsets, d_breaks, capacity, C.byref(total),
+                                               d_ranges, d_fallbacks, stream)
+        if rc != 0:
+            err = Gcsa2Error(rc, self._L.gcsa2_last_error().decode(errors="replace"))
+            err.needed = total.value
+            raise err
+        return total.value
 
     def match_stats_profile_device(self, d_patterns, d_offsets, nq, total_bytes, d_ms, d_ranges, d_fallbacks, d_prof, stream=0):
         """Diagnostic: the instrumented matching-statistics kernel (cycles per phase and event counts into d_prof[16])."""

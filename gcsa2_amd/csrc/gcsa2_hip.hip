@@ -2213,7 +2213,7 @@ int gcsa2_locate_max(const gcsa2_index* ix, uint64_t sp, uint64_t ep, uint64_t m
 
 namespace {
 int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, u64 total_bytes,
-                       uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st);
+                       uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st, const BreakSink* sink = nullptr);
 int group_comm_init(gcsa2_group* g);
 }  // namespace
 
@@ -2880,7 +2880,7 @@ extern "C" int gcsa2_count_kmers(const gcsa2_index* ix, uint64_t k, int include_
 // device, which waits for the stream once).
 namespace {
 int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, u64 total_bytes,
-                       uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st)
+                       uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st, const BreakSink* sink)
 {
   CHECK_INDEX(ix);
   DeviceGuard guard(ix->device);
@@ -2915,7 +2915,18 @@ int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patt
     if(qe == hipSuccess) { qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st); }
     if(qe != hipSuccess) { (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st); return fail(GCSA2_ERR_HIP, std::string("matching statistics queue: ") + hipGetErrorString(qe)); }
     const unsigned grid = unsigned(lanes_grid < resident ? lanes_grid : resident);
-    if(pair)
+    unsigned long long* none = nullptr;
+    if(sink != nullptr && pair)
+    {
+      hipLaunchKernelGGL((k_match_stats2<true, true, false, true>), dim3(grid), dim3(TPB2), 0, st,
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad, none, *sink);
+    }
+    else if(sink != nullptr)
+    {
+      hipLaunchKernelGGL((k_match_stats2<false, true, false, true>), dim3(grid), dim3(TPB2), 0, st,
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad, none, *sink);
+    }
+    else if(pair)
     {
       hipLaunchKernelGGL((k_match_stats2<true, true>), dim3(grid), dim3(TPB2), 0, st,
                          ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad);
@@ -2924,6 +2935,20 @@ int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patt
     {
       hipLaunchKernelGGL((k_match_stats2<false, true>), dim3(grid), dim3(TPB2), 0, st,
                          ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad);
+    }
+  }
+  else if(sink != nullptr)
+  {
+    unsigned long long* none = nullptr;
+    if(pair)
+    {
+      hipLaunchKernelGGL((k_match_stats2<true, false, false, true>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, none, 64u, codes, bad, none, *sink);
+    }
+    else
+    {
+      hipLaunchKernelGGL((k_match_stats2<false, false, false, true>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, none, 64u, codes, bad, none, *sink);
     }
   }
   else if(pair)
@@ -2954,6 +2979,62 @@ extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_
                                         uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
 {
   return match_stats_launch(ix, 0, d_patterns, d_offsets, nq, GCSA2_UNKNOWN, d_ms, d_ranges, d_fallbacks, static_cast<hipStream_t>(stream));
+}
+
+// Matching statistics as BREAK POINTS (k_match_stats2<.., BREAKS>): the CSR of the left-maximal matches of every pattern.
+// Complete on return: the number of records is read back, and a buffer that is too small is refused with the number needed.
+int gcsa2_match_breaks_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, uint64_t total_bytes,
+                              int variant, uint64_t* d_break_offsets, gcsa2_break* d_breaks, uint64_t capacity, uint64_t* total_breaks,
+                              uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
+{
+  CHECK_INDEX(ix);
+  if(d_break_offsets == nullptr || total_breaks == nullptr || (d_breaks == nullptr && capacity > 0)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  if(nq >= (u64(1) << 31) - 1) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "batch of >= 2^31 patterns; split the batch"); }
+  DeviceGuard guard(ix->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  *total_breaks = 0;
+  if(nq == 0 || ix->img.n == 0)
+  {
+    HIP_TRY(hipMemsetAsync(d_break_offsets, 0, (nq + 1) * sizeof(u64), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GCSA2_OK;
+  }
+  Scratch scratch(ix, st);
+  BreakSink sink{nullptr, capacity, nullptr, nullptr};
+  u64 *wide = nullptr, *own_ranges = nullptr;
+  const unsigned slot = ix->next_slot.fetch_add(1) % RESULT_SLOTS;
+  unsigned long long* d_totals = ix->d_slots + u64(TOTAL_WORDS) * slot;
+  sink.counter = d_totals;
+  HIP_TRY(scratch.get(sink.tmp, (capacity > 0 ? capacity : 1) * BREAK_WORDS));
+  HIP_TRY(scratch.get(sink.counts, nq));
+  HIP_TRY(scratch.get(wide, nq + 1));
+  if(d_ranges == nullptr) { HIP_TRY(scratch.get(own_ranges, 2 * nq)); d_ranges = own_ranges; }
+  HIP_TRY(hipMemsetAsync(d_totals, 0, TOTAL_WORDS * sizeof(unsigned long long), st));
+  HIP_TRY(hipMemsetAsync(sink.counts, 0, nq * sizeof(u32), st));
+  int rc = match_stats_launch(ix, variant, d_patterns, d_offsets, nq, total_bytes, nullptr, d_ranges, d_fallbacks, st, &sink);
+  if(rc != GCSA2_OK) { return rc; }
+  hipLaunchKernelGGL(k_widen_counts, dim3(grid_for(nq + 1)), dim3(TPB), 0, st, sink.counts, nq, wide);
+  size_t scan_bytes = 0;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, wide, d_break_offsets, int(nq + 1), st));
+  char* scan_tmp = nullptr;
+  HIP_TRY(scratch.get(scan_tmp, scan_bytes));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, wide, d_break_offsets, int(nq + 1), st));
+  unsigned long long totals[TOTAL_WORDS];
+  rc = read_totals(ix, slot, totals, st);
+  if(rc != GCSA2_OK) { return rc; }
+  scratch.settled = true;
+  const u64 appended = totals[0];
+  *total_breaks = appended;
+  if(appended > capacity) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "break buffer too small"); }
+  if(appended > 0)
+  {
+    scratch.settled = false;
+    hipLaunchKernelGGL(k_breaks_scatter, dim3(grid_for(appended)), dim3(TPB), 0, st, sink.tmp, appended, d_break_offsets, reinterpret_cast<u64*>(d_breaks), capacity);
+    LAUNCH_CHECK("k_breaks_scatter");
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  scratch.settled = true;
+  return GCSA2_OK;
 }
 
 // Diagnostic: the default kernel instrumented with shader-clock counters per phase of its round (k_match_stats2<.., PROF>),

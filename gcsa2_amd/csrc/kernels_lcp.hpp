@@ -467,14 +467,30 @@ constexpr u64 MS_REFILL_MIN = u64(1) << 19;             // host-pointer API: sma
 // 4 second fetch + evaluation, 5 outcome + statistics, 6 parent() from the LCP window, 7 parent() tree walk; 8 rounds (per wave),
 // 9 rounds with a second fetch, 10 lane steps, 11 lane pair attempts, 12 failed pair attempts, 13 parent() calls, 14 tree walks,
 // 15 lane second fetches.
-template<bool PAIR, bool REFILL, bool PROF = false>
+// BREAKS = true (gcsa2_match_breaks_device): instead of one statistic per pattern position the kernel reports the BREAK POINTS
+// -- the left-maximal matches, what a MEM finder collects: every position p whose match P[p, p + len) cannot be extended
+// by P[p - 1] (LF empties and parent() is taken, lcp.cpp:276-301; the reference's caller shape: src/algorithms.cpp:146-167),
+// with its length and its range, and position 0.  Between two break points the statistics rise by one per position to the
+// left, so the dense array follows from them (ms[i] = len - (i - p) for p <= i < the break point to the right); the result
+// stores, a third of the dense kernel's memory requests, shrink to one 48-byte record per break.  Records are appended to
+// `sink.tmp` through one atomic per wavefront and round -- {pattern, ordinal | position << 32, length, sp, ep, 0} -- and put
+// into CSR order by k_breaks_scatter once the per-pattern counts have been scanned; records beyond `sink.cap` are counted, not
+// stored.  The record of a round is taken at the loop head, where (i, depth, sp, ep) describe the match that starts at
+// position i.  Exactly the positions p with p == 0 or ms[p - 1] != ms[p] + 1 get a record.
+struct BreakSink
+{
+  u64* tmp; u64 cap; unsigned long long* counter; u32* counts;
+};
+constexpr u32 BREAK_WORDS = 6;
+
+template<bool PAIR, bool REFILL, bool PROF = false, bool BREAKS = false>
 __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8* __restrict__ patterns,
                                                        const u64* __restrict__ offsets, u64 nq,
                                                        unsigned short* __restrict__ ms, u64* __restrict__ ranges,
                                                        u64* __restrict__ fallbacks, u32 cool_down,
                                                        unsigned long long* __restrict__ queue, u32 refill_at,
                                                        const u64* __restrict__ codes, const u32* __restrict__ bad,
-                                                       unsigned long long* __restrict__ prof = nullptr)
+                                                       unsigned long long* __restrict__ prof = nullptr, BreakSink sink = BreakSink{nullptr, 0, nullptr, nullptr})
 {
   [[maybe_unused]] u64 prof_t = 0, prof_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] u32 prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -501,9 +517,12 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   // results: eight u16 per 16-byte store (`ms` is 8-byte aligned, the hardware takes the 16-byte store at any dword).  The
   // statistics are a third of the kernel's memory requests -- every lane writes into its own pattern's 512 bytes, nothing
   // coalesces across lanes -- so the only lever is fewer, wider stores per lane (8-byte stores: 64 per 256-bp pattern).
-  u64 packed_lo = 0, packed_hi = 0; u32 have = 0;
+  [[maybe_unused]] u64 packed_lo = 0, packed_hi = 0; [[maybe_unused]] u32 have = 0;
+  [[maybe_unused]] u32 last_break = ~u32(0), n_breaks = 0;     // BREAKS: position of the latest record, records of this pattern
+  [[maybe_unused]] bool pending = false;                       // BREAKS: a character that does not occur: position i is a break of length 0
   auto emit = [&](u32 pos, u32 value)        // ms[begin + pos] = value; positions arrive in descending order
   {
+    if constexpr(BREAKS) { return; }
     const u64 idx = begin + pos;
     const u32 slot = u32(idx & 7);
     const u64 field = u64(value > 65535 ? 65535 : value) << (16 * (slot & 3));
@@ -532,6 +551,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     q = query; has = true;
     begin = offsets[q]; i = total = u32(offsets[q + 1] - begin);
     sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0);
+    if constexpr(BREAKS) { last_break = ~u32(0); n_breaks = 0; pending = false; }
     // The k-mer seed table (find() of every k-mer over the fast characters, kernels_find.hpp): when the pattern's last k
     // characters are fast characters and occur, the search starts behind them -- all k suffixes match, so their statistics
     // are 1 .. k -- and skips the steps on the widest ranges, whose endpoints lie in different blocks.  An empty or wide
@@ -559,10 +579,43 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   }
   while(true)
   {
-    if(has && i == 0)                                          // pattern finished (or empty): final range, parent() count
+    [[maybe_unused]] bool was_pending = false;
+    if constexpr(BREAKS)
+    {
+      // The match that starts at position `pos` cannot be extended to the left: after a failed step (need_parent: pos = i, the
+      // state is still the one of that match), at the pattern's start (i == 0), or -- pending -- when the character before a
+      // match of length 0 does not occur either (the step failed AT THE ROOT and moved on: the break is the position behind,
+      // i + 1; the final record and the end of the pattern then wait one round, a lane writes one record per round).
+      was_pending = pending;
+      const u32 pos = (was_pending ? i + 1 : i);
+      const bool record = has && total > 0 && last_break != pos && (was_pending ? pos < total : (i == 0 || need_parent));
+      const u64 writers = __ballot(record);
+      if(writers != 0)                                         // uniform
+      {
+        const u32 leader = u32(__ffsll((long long)writers)) - 1;
+        unsigned long long base = 0;
+        if(lane == leader) { base = atomicAdd(sink.counter, (unsigned long long)__popcll(writers)); }
+        base = __shfl(base, leader, 64);
+        if(record)
+        {
+          const u64 at = base + __popcll(writers & ((u64(1) << lane) - 1));
+          if(at < sink.cap)
+          {
+            ulonglong2* dst = reinterpret_cast<ulonglong2*>(sink.tmp + at * BREAK_WORDS);
+            dst[0] = make_ulonglong2(q, u64(n_breaks) | (u64(pos) << 32));
+            dst[1] = make_ulonglong2(u64(depth), sp);
+            dst[2] = make_ulonglong2(ep, 0);
+          }
+          n_breaks++; last_break = pos;
+        }
+      }
+      pending = false;
+    }
+    if(has && i == 0 && !was_pending)                          // pattern finished (or empty): final range, parent() count
     {
       reinterpret_cast<ulonglong2*>(ranges)[q] = make_ulonglong2(sp, ep);
       if(fallbacks != nullptr) { fallbacks[q] = calls; }
+      if constexpr(BREAKS) { sink.counts[q] = n_breaks; }
       has = false;
     }
     if constexpr(REFILL)
@@ -697,6 +750,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         else if(sp == 0 && ep == img.n - 1)                    // at the root: no such character
         {
           depth = 0;
+          if constexpr(BREAKS) { pending = true; }
           emit(i - 1, 0); i--; win_used++;
           force_single -= (force_single > 0 ? 1 : 0);
         }
@@ -725,6 +779,27 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   }
 #undef G2_TICK
 #undef G2_COUNT
+}
+
+// the appended break records into CSR order: record j of pattern q at offsets[q] + j as {position, length, sp, ep}
+__global__ __launch_bounds__(TPB) void k_breaks_scatter(const u64* __restrict__ tmp, u64 stored, const u64* __restrict__ offsets,
+                                                        u64* __restrict__ out, u64 capacity)
+{
+  const u64 r = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(r >= stored) { return; }
+  const ulonglong2* src = reinterpret_cast<const ulonglong2*>(tmp + r * BREAK_WORDS);
+  const ulonglong2 a = src[0], b = src[1], c = src[2];
+  const u64 dest = offsets[a.x] + (a.y & 0xFFFFFFFFull);
+  if(dest >= capacity) { return; }
+  ulonglong2* dst = reinterpret_cast<ulonglong2*>(out + 4 * dest);
+  dst[0] = make_ulonglong2(a.y >> 32, b.x);
+  dst[1] = make_ulonglong2(b.y, c.x);
+}
+
+__global__ __launch_bounds__(TPB) void k_widen_counts(const u32* __restrict__ counts, u64 nq, u64* __restrict__ wide)
+{
+  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q <= nq) { wide[q] = (q < nq ? u64(counts[q]) : 0); }
 }
 
 }  // namespace

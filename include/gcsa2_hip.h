@@ -365,6 +365,20 @@ int gcsa2_match_stats_device_variant(const gcsa2_index* index, int variant, cons
 int gcsa2_match_stats_device_sized(const gcsa2_index* index, int variant, const uint8_t* d_patterns,
                                    const uint64_t* d_offsets, uint64_t n_queries, uint64_t total_pattern_bytes,
                                    uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream);
+/* The same backward search with parent() on failure, reported as BREAK POINTS instead of one statistic per position: the
+ * left-maximal matches a MEM finder collects (vg's caller shape; the reference exercises the LF + parent interplay in
+ * verifyIndex, src/algorithms.cpp:146-167).  A record {position p, length, sp, ep} says that P[p, p + length) occurs with
+ * path-node range (sp, ep) = find() of that substring (include/gcsa/gcsa.h:96-110) and cannot be extended by P[p - 1];
+ * exactly the positions p with p == 0 or ms[p - 1] != ms[p] + 1 have a record (an empty pattern has none; a record of length 0
+ * -- no character of the index at p, nor at p - 1 -- carries the whole index as its range).  Records of pattern q: d_breaks[d_break_offsets[q] .. d_break_offsets[q + 1]), in the order
+ * of discovery (descending position).  The dense statistics follow from them: ms[i] = length - (i - p) for the record with the
+ * largest p <= i.  d_break_offsets: n_queries + 1 entries; capacity: records d_breaks holds; *total_breaks: records found --
+ * GCSA2_ERR_BUFFER_TOO_SMALL with that number when it exceeds capacity (nothing is written then).  d_ranges (final ranges) and
+ * d_fallbacks (parent() calls per pattern) may be NULL.  variant as in gcsa2_match_stats_device_variant.  Complete on return. */
+typedef struct gcsa2_break { uint64_t position, length, sp, ep; } gcsa2_break;
+int gcsa2_match_breaks_device(const gcsa2_index* index, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t n_queries,
+                              uint64_t total_pattern_bytes, int variant, uint64_t* d_break_offsets, gcsa2_break* d_breaks,
+                              uint64_t capacity, uint64_t* total_breaks, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream);
 /* Diagnostic (not the timed path): the default kernel instrumented with shader-clock counters, same results.  d_prof[16],
  * zeroed by the caller: [0..7] cycles summed over the wavefronts for the phases of a round (loop head / pattern window, step
  * setup, first block fetch, first evaluation, second fetch + evaluation, outcome + statistics, parent() from the LCP chunks,

@@ -282,6 +282,66 @@ def test_match_stats_kernel_variants(case, engine, variant, knobs, monkeypatch):
     tuned.close()
 
 
+def breaks_from_dense(cpu, pats, cm, off):
+    """The break-point CSR the dense statistics imply (the definition in include/gcsa2_hip.h): position p is a break iff p == 0 or
+    ms[p - 1] != ms[p] + 1; its length is ms[p], its range find() of that substring; per pattern in descending position."""
+    offsets, records, subs = [0], [], []
+    for q, p in enumerate(pats):
+        ms = cm[int(off[q]):int(off[q + 1])].astype(np.int64)
+        here = [i for i in range(len(p) - 1, -1, -1) if i == 0 or ms[i - 1] != ms[i] + 1]
+        for i in here:
+            records.append((i, int(ms[i])))
+            subs.append(p[i:i + int(ms[i])])
+        offsets.append(len(records))
+    data, soff = concat_patterns(subs) if subs else (np.zeros(1, dtype=np.uint8), np.zeros(1, dtype=np.uint64))
+    rng = cpu.find_batch(data, soff) if subs else np.zeros((0, 2), dtype=np.uint64)
+    out = np.zeros((len(records), 4), dtype=np.uint64)
+    for j, (i, length) in enumerate(records):
+        out[j] = (i, length, rng[j, 0], rng[j, 1])
+    return np.asarray(offsets, dtype=np.uint64), out
+
+
+@pytest.mark.parametrize("variant", [0, 5])
+def test_match_breaks(case, engine, variant):
+    """Matching statistics as break points (gcsa2_match_breaks_device): the CSR of left-maximal matches {position, length, sp,
+    ep} equals what the oracle's dense statistics and find() imply -- every position where LF emptied and parent() was taken
+    (the LF + parent interplay of src/algorithms.cpp:146-167), characters that do not occur (length 0 at the root), position 0,
+    nothing for an empty pattern -- with the same final ranges and parent() counts as the dense kernel; a buffer that is too
+    small is refused with the number of records needed."""
+    import torch
+    name, g, K, ix, gpu, lcp, cpu = case
+    pats = [p for p in random_patterns(g, 3 * K, 0x9B, 1200)] + [b"", b"N", b"", b"ACGTNACGT", b"$", b"#A", b"", b"NNNN", b"A", b"TTTTTTTTTTTTTTTTTTTTTTTT"]
+    data, off = concat_patterns(pats)
+    cm, cr, cf = cpu.match_stats_batch(data, off, threads=2)
+    want_off, want = breaks_from_dense(cpu, pats, cm, off)
+    dev = torch.device("cuda", 0)
+    nq, total = len(pats), int(off[-1])
+    d_pat = torch.zeros(total + 16, dtype=torch.uint8, device=dev)
+    d_pat[:total] = torch.from_numpy(data[:total].copy()).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64).copy()).to(dev)
+    d_boff = torch.full((nq + 1,), -1, dtype=torch.int64, device=dev)
+    d_brk = torch.full((len(want) + 3, 4), -1, dtype=torch.int64, device=dev)
+    d_rng = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    d_fb = torch.zeros(nq, dtype=torch.int64, device=dev)
+    for sized in (total, None):
+        d_brk.fill_(-1)
+        n = gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, sized, d_boff.data_ptr(), d_brk.data_ptr(), d_brk.shape[0],
+                                    d_rng.data_ptr(), d_fb.data_ptr(), 0, variant=variant)
+        assert n == len(want), (name, n, len(want))
+        assert np.array_equal(d_boff.cpu().numpy().view(np.uint64), want_off), name
+        got = d_brk.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got[:n], want), name
+        assert (d_brk[n:] == -1).all()
+        assert np.array_equal(d_rng.cpu().numpy().view(np.uint64), cr) and np.array_equal(d_fb.cpu().numpy().view(np.uint64), cf), name
+    # without the optional outputs; then a buffer that is too small
+    n = gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, total, d_boff.data_ptr(), d_brk.data_ptr(), d_brk.shape[0], variant=variant)
+    assert n == len(want) and np.array_equal(d_brk.cpu().numpy().view(np.uint64)[:n], want)
+    with pytest.raises(engine.Gcsa2Error) as e:
+        gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, total, d_boff.data_ptr(), d_brk.data_ptr(), len(want) // 2, variant=variant)
+    assert e.value.code == -6 and e.value.needed == len(want)
+    assert gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), 0, 0, d_boff.data_ptr(), d_brk.data_ptr(), 4, variant=variant) == 0
+
+
 def test_match_stats_ragged_host_batch(engine):
     """A large batch of ragged lengths through the host-pointer entry point, which sends it to the persistent lanes
     (gcsa2_match_stats_batch: longest pattern > 1.25 x the mean, at least 2^19 patterns)."""
