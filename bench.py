@@ -745,6 +745,44 @@ def host_batch_rate(wl, d_out, nq=10_000_000):
                               "GB_per_s_end_to_end": nq * (m + 24) / best / 1e9, "equals_device_resident_run": same}
     except Exception as e:           # the secondary never takes the line down
         out["page_locked"] = {"error": str(e)[:200]}
+    # the same patterns handed over as 2-bit codes (gcsa2_find_batch_packed): 8 + 16 bytes per 32-mer over the link.  The
+    # packing is the caller's (done here outside the timed calls, on the device, with the layout of include/gcsa2_hip.h).
+    try:
+        if m <= 32 and bool((wl.d_pat[: nq * m] != ord("N")).all()):
+            lut = torch.full((256,), 0, dtype=torch.int64, device=wl.d_pat.device)
+            for ch, c in zip(b"ACGT", range(4)):
+                lut[ch] = c
+            comps = lut[wl.d_pat[: nq * m].view(nq, m).to(torch.int64)]
+            code = torch.zeros(nq, dtype=torch.int64, device=wl.d_pat.device)
+            for t in range(m):                                       # distance t from the end -> bits [2t, 2t + 2)
+                code |= comps[:, m - 1 - t] << (2 * t)
+            codes = code.cpu().numpy().view(np.uint64).reshape(nq, 1).copy()
+            del comps, code
+            got = np.ones((nq, 2), dtype=np.uint64)
+            wl.gpu.find_batch_packed(codes[:1_000_000], m)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                wl.gpu.find_batch_packed(codes, m, out=got)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out["packed"] = {"workload": f"the same {nq} x {m}-mers as 2-bit codes (8 bytes each) in pageable host memory -> gcsa2_find_batch_packed "
+                                         "-> ranges in host memory (best of 3; packing not timed: the caller's)",
+                             "value": nq / best, "unit": "queries/s", "ms": best * 1e3, "bytes_per_query_over_pcie": 8 + 16,
+                             "GB_per_s_end_to_end": nq * 24 / best / 1e9, "equals_device_resident_run": bool(np.array_equal(got, want))}
+            p_codes = torch.empty((nq, 1), dtype=torch.int64).pin_memory()
+            p_got = torch.empty((nq, 2), dtype=torch.int64).pin_memory()
+            p_codes.numpy().view(np.uint64)[:] = codes
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                wl.gpu.find_batch_packed(p_codes.numpy().view(np.uint64), m, out=p_got.numpy().view(np.uint64))
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out["packed"]["page_locked"] = {"value": nq / best, "unit": "queries/s", "ms": best * 1e3,
+                                            "equals_device_resident_run": bool(np.array_equal(p_got.numpy().view(np.uint64), want))}
+    except Exception as e:
+        out["packed"] = {"error": str(e)[:200]}
     return out
 
 
@@ -891,6 +929,7 @@ def config5(args, wl, dev):
            "match_stats_ms": ms_time, "patterns_per_s": nq / (ms_time * 1e-3), "bases_per_s": nq * m / (ms_time * 1e-3),
            "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item()),
            "unmodified_half_equals_closed_form": exact_ok}
+    out["match_breaks"] = match_breaks_leg(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, exp, timed, dev)
     # plain find() of the same batch (a substituted pattern usually empties at its first substitution)
     d_find = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
     out["find_ms"] = timed(lambda: gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_find.data_ptr(), stream.cuda_stream))
@@ -907,6 +946,90 @@ def config5(args, wl, dev):
     out["parent_queries_per_s"] = nq / (t_parent * 1e-3)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_match_stats(ix, d_pat, d_ms, d_rng, d_fb, m)
+    return out
+
+
+def match_breaks_leg(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, exp, timed, dev):
+    """The same batch through gcsa2_match_breaks_device: the break points (left-maximal matches {position, length, sp, ep}) as a
+    CSR instead of 2 bytes per pattern position -- what a MEM finder consumes (src/algorithms.cpp:146-167 is the reference's
+    caller of this interplay).  Checks: the unmodified half has exactly one record each, (0, 256, r, r) with r the closed form;
+    the records of the first 200 k patterns expand to exactly the dense statistics of the timed dense run; final ranges and
+    parent() counts equal the dense kernel's.  Also the unmodified patterns alone (a clean batch), dense and as break points."""
+    import torch
+    stream = torch.cuda.current_stream()
+    d_boff = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
+    d_rng2 = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    d_fb2 = torch.zeros(nq, dtype=torch.int64, device=dev)
+    from gcsa2_amd.binding import Gcsa2Error
+    cap = 16 * nq
+    d_brk = torch.zeros((cap, 4), dtype=torch.int64, device=dev)
+    total = [0]
+
+    def run():
+        total[0] = gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, nq * m, d_boff.data_ptr(), d_brk.data_ptr(), cap,
+                                           d_rng2.data_ptr(), d_fb2.data_ptr(), stream.cuda_stream)
+    try:
+        run()
+    except Gcsa2Error as e:              # the refusal carries the number of records needed (a small index breaks far more often)
+        if e.code != -6:
+            raise
+        cap = int(e.needed)
+        d_brk = torch.zeros((cap, 4), dtype=torch.int64, device=dev)
+    t = timed(run)
+    n = total[0]
+    counts = d_boff[1:] - d_boff[:-1]
+    first = d_brk[d_boff[:-1][0::2]]
+    one_each = bool((counts[0::2] == 1).all()) and bool((first[:, 0] == 0).all()) and bool((first[:, 1] == m).all()) and \
+        bool(torch.equal(first[:, 2], exp)) and bool(torch.equal(first[:, 3], exp))
+    same_tail = bool(torch.equal(d_rng2, d_rng)) and bool(torch.equal(d_fb2, d_fb))
+    # expansion of the first patterns' records: record j of a pattern covers [p_j, p_(j-1)) (m for its first record)
+    ns = min(nq, 200_000)
+    r0, r1 = 0, int(d_boff[ns].item())
+    rec = d_brk[r0:r1]
+    owner = torch.repeat_interleave(torch.arange(ns, device=dev), counts[:ns])
+    is_first = torch.ones(r1 - r0, dtype=torch.bool, device=dev)
+    is_first[1:] = owner[1:] != owner[:-1]
+    right = torch.where(is_first, torch.full_like(rec[:, 0], m), torch.cat([rec[:1, 0], rec[:-1, 0]]))
+    span = right - rec[:, 0]
+    covers = bool((span > 0).all()) and int(span.sum().item()) == ns * m
+    dense_ok = False
+    if covers:
+        ridx = torch.repeat_interleave(torch.arange(r1 - r0, device=dev), span)
+        begin = torch.cumsum(span, 0) - span
+        within = torch.arange(ns * m, device=dev) - begin[ridx]                  # i - p, in the order records arrive (descending p per pattern)
+        pos = rec[ridx, 0] + within
+        val = torch.clamp(rec[ridx, 1] - within, max=65535)
+        rebuilt = torch.zeros(ns * m, dtype=torch.int64, device=dev)
+        rebuilt[owner[ridx] * m + pos] = val
+        dense_ok = bool(torch.equal(rebuilt, d_ms[: ns * m].to(torch.int64) & 0xFFFF))
+        del ridx, within, pos, val, rebuilt
+    # a MEM finder's view: only matches of at least 20 bp (right after a mismatch a match is as short as any string of
+    # log4(n) = 16 characters and every position breaks: those records outnumber the bytes of the dense statistics)
+    min_mem = 20
+    t_mem = timed(lambda: total.__setitem__(0, gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, nq * m, d_boff.data_ptr(), d_brk.data_ptr(),
+                                                                         cap, d_rng2.data_ptr(), d_fb2.data_ptr(), stream.cuda_stream, min_length=min_mem)))
+    n_mem = total[0]
+    long_enough = bool((d_brk[:n_mem, 1] >= min_mem).all()) if n_mem else True
+    # diagnostic: a minimum length no match reaches -- the kernel finds every break and writes none (what the record stores cost)
+    t_none = timed(lambda: gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, nq * m, d_boff.data_ptr(), d_brk.data_ptr(), cap,
+                                                   d_rng2.data_ptr(), d_fb2.data_ptr(), stream.cuda_stream, min_length=1 << 30))
+    out = {"ms": t, "patterns_per_s": nq / (t * 1e-3), "records": n, "records_per_pattern": n / nq, "bytes_out_per_pattern": 32 * n / nq + 8,
+           "no_records_ms": t_none,
+           "min_length_20": {"ms": t_mem, "patterns_per_s": nq / (t_mem * 1e-3), "records": n_mem, "records_per_pattern": n_mem / nq,
+                             "bytes_out_per_pattern": 32 * n_mem / nq + 8, "every_record_long_enough": long_enough,
+                             "unmodified_half_still_one_record_each": bool((d_boff[1:][0::2] - d_boff[:-1][0::2] == 1).all())},
+           "unmodified_half_has_one_record_in_closed_form": one_each, "expands_to_the_dense_statistics_on_the_first_patterns": dense_ok,
+           "final_ranges_and_parent_counts_equal_dense": same_tail}
+    # a clean batch: the unmodified patterns alone
+    nc = nq // 2
+    d_clean = padded_bytes(d_pat[: nq * m].view(nq, m)[0::2].contiguous())
+    d_coff = torch.arange(nc + 1, dtype=torch.int64, device=dev) * m
+    d_ms2 = torch.zeros(nc * m + 8, dtype=torch.int16, device=dev)
+    t_dense = timed(lambda: gpu.match_stats_device(d_clean.data_ptr(), d_coff.data_ptr(), nc, d_ms2.data_ptr(), d_rng2.data_ptr(), d_fb2.data_ptr(),
+                                                   stream.cuda_stream, total_bytes=nc * m))
+    t_brk = timed(lambda: gpu.match_breaks_device(d_clean.data_ptr(), d_coff.data_ptr(), nc, nc * m, d_boff.data_ptr(), d_brk.data_ptr(), cap,
+                                                  d_rng2.data_ptr(), d_fb2.data_ptr(), stream.cuda_stream))
+    out["clean_batch"] = {"patterns": nc, "dense_patterns_per_s": nc / (t_dense * 1e-3), "breaks_patterns_per_s": nc / (t_brk * 1e-3)}
     return out
 
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "gcsa2_device_count", "gcsa2_index_create", "gcsa2_index_destroy", "gcsa2_index_set_tables", "gcsa2_index_trim", "gcsa2_last_error",
     "gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count", "gcsa2_sample_bits",
     "gcsa2_device", "gcsa2_device_bytes", "gcsa2_block_bits",
-    "gcsa2_find_batch", "gcsa2_find_device", "gcsa2_find_stats_device", "gcsa2_find_device_variant",
+    "gcsa2_find_batch", "gcsa2_find_batch_packed", "gcsa2_find_packed_device", "gcsa2_find_device", "gcsa2_find_stats_device", "gcsa2_find_device_variant",
     "gcsa2_find_block_bytes", "gcsa2_kmer_table_k", "gcsa2_locate_table_bytes", "gcsa2_jump_table_bytes", "gcsa2_pair_block_bytes", "gcsa2_lf_batch", "gcsa2_lf_device",
     "gcsa2_lf_node_batch", "gcsa2_char_range", "gcsa2_lf_all_batch",
     "gcsa2_count_batch", "gcsa2_count_device",
@@ -91,6 +91,8 @@ def load_library():
     L.gcsa2_device.argtypes = [vp]
     L.gcsa2_find_batch.argtypes = [vp, u8p, u64p, u64, u64p]
     L.gcsa2_find_device.argtypes = [vp, vp, vp, u64, vp, vp]
+    L.gcsa2_find_batch_packed.argtypes = [vp, u64p, u64, u64, u64p]
+    L.gcsa2_find_packed_device.argtypes = [vp, vp, u64, u64, vp, vp]
     L.gcsa2_find_stats_device.argtypes = [vp, vp, vp, u64, vp, vp, vp]
     L.gcsa2_find_device_variant.argtypes = [vp, i32, vp, vp, u64, vp, vp]
     L.gcsa2_lf_batch.argtypes = [vp, u64p, u8p, u64, u64p]
@@ -140,7 +142,7 @@ def load_library():
     L.gcsa2_match_stats_device_variant.argtypes = [vp, C.c_int, vp, vp, u64, vp, vp, vp, vp]
     L.gcsa2_match_stats_device_sized.argtypes = [vp, C.c_int, vp, vp, u64, u64, vp, vp, vp, vp]
     L.gcsa2_match_stats_profile_device.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp, vp, vp]
-    L.gcsa2_match_breaks_device.argtypes = [vp, vp, vp, u64, u64, i32, vp, vp, u64, u64p, vp, vp, vp]
+    L.gcsa2_match_breaks_device.argtypes = [vp, vp, vp, u64, u64, i32, u64, vp, vp, u64, u64p, vp, vp, vp]
     L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
     L.gcsa2_group_destroy.argtypes = [vp]
     L.gcsa2_group_destroy.restype = None
@@ -359,6 +361,20 @@ class GCSA:
         r = self.find_batch(data, off)[0]
         return (int(r[0]), int(r[1]))
 
+    def find_batch_packed(self, codes, pattern_length, out=None):
+        """find() of patterns of one length given as 2-bit codes (pack_kmers): (nq, W) uint64, W = ceil(pattern_length / 32)."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        words = (int(pattern_length) + 31) // 32
+        nq = codes.size // words
+        if out is None:
+            out = np.zeros((nq, 2), dtype=np.uint64)
+        assert out.dtype == np.uint64 and out.shape == (nq, 2) and out.flags["C_CONTIGUOUS"]
+        _check(self._L.gcsa2_find_batch_packed(self._h, _p64(codes), int(pattern_length), nq, _p64(out)))
+        return out
+
+    def find_packed_device(self, d_codes, pattern_length, nq, d_ranges, stream=0):
+        _check(self._L.gcsa2_find_packed_device(self._h, d_codes, int(pattern_length), nq, d_ranges, stream))
+
     def find_device(self, d_patterns, d_offsets, nq, d_ranges, stream=0):
         _check(self._L.gcsa2_find_device(self._h, d_patterns, d_offsets, nq, d_ranges, stream))
 
@@ -511,13 +527,13 @@ class GCSA:
                                                           d_fallbacks, stream))
 
     def match_breaks_device(self, d_patterns, d_offsets, nq, total_bytes, d_break_offsets, d_breaks, capacity, d_ranges=0, d_fallbacks=0,
-                            stream=0, variant=0):
+                            stream=0, variant=0, min_length=0):
         """Matching statistics as break points (gcsa2_match_breaks_device): the CSR of the left-maximal matches, records of four
         u64 {position, length, sp, ep}; returns the number of records.  Raises Gcsa2Error (BUFFER_TOO_SMALL, `.needed`) when
         `capacity` records are not enough."""
         total = C.c_uint64()
         tb = 0xFFFFFFFFFFFFFFFF if total_bytes is None else int(total_bytes)
-        rc = self._L.gcsa2_match_breaks_device(self._h, d_patterns, d_offsets, nq, tb, variant, d_break_offsets, d_breaks, capacity, C.byref(total),
+        rc = self._L.gcsa2_match_breaks_device(self._h, d_patterns, d_offsets, nq, tb, variant, int(min_length), d_break_offsets, d_breaks, capacity, C.byref(total),
                                                d_ranges, d_fallbacks, stream)
         if rc != 0:
             err = Gcsa2Error(rc, self._L.gcsa2_last_error().decode(errors="replace"))

@@ -1150,6 +1150,30 @@ int gcsa2_find_device(const gcsa2_index* ix, const uint8_t* d_patterns, const ui
   return GCSA2_OK;
 }
 
+// find() of patterns handed over as 2-bit codes, all of one length (kernels_find.hpp: k_find2<.., PACKED>)
+int gcsa2_find_packed_device(const gcsa2_index* ix, const uint64_t* d_codes, uint64_t pattern_length, uint64_t nq, uint64_t* d_ranges, void* stream)
+{
+  CHECK_INDEX(ix);
+  DeviceGuard guard(ix->device);
+  if(nq == 0) { return GCSA2_OK; }
+  if(pattern_length == 0 || pattern_length >= (u64(1) << 32)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "packed patterns: the common length must be 1 .. 2^32 - 1"); }
+  if(ix->img.sigma < 5) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "packed patterns need the comps 1..4"); }
+  const unsigned grid = unsigned((nq + TPB2 - 1) / TPB2);
+  const u8* codes = reinterpret_cast<const u8*>(d_codes);
+  const u64* length = reinterpret_cast<const u64*>(pattern_length);       // PACKED: the offsets argument carries the length
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if(ix->img.flp != nullptr)
+  {
+    hipLaunchKernelGGL((k_find2<false, false, true, true>), dim3(grid), dim3(TPB2), 0, st, ix->img, codes, length, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr);
+  }
+  else
+  {
+    hipLaunchKernelGGL((k_find2<false, false, false, true>), dim3(grid), dim3(TPB2), 0, st, ix->img, codes, length, nq, d_ranges, (unsigned long long*)nullptr, (const u32*)nullptr);
+  }
+  LAUNCH_CHECK("k_find2<packed>");
+  return GCSA2_OK;
+}
+
 int gcsa2_find_device_variant(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets,
                               uint64_t nq, uint64_t* d_ranges, void* stream)
 {
@@ -1889,9 +1913,112 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
   return GCSA2_OK;
 }
 
+// The same pipeline for patterns that arrive as 2-bit codes of one length (gcsa2_find_batch_packed): a chunk is its code words
+// up the link (8 bytes per 32 characters), one launch, its ranges down; no offsets at all.
+int find_packed_pipelined(const gcsa2_index* ix, const uint64_t* codes, u64 length, uint64_t nq, uint64_t* ranges)
+{
+  std::lock_guard<std::mutex> hold(ix->pipe_lock);
+  int rc = pipe_prepare(ix);
+  if(rc != GCSA2_OK) { return rc; }
+  const u64 words = (length + 31) >> 5;
+  u64 per_chunk = PIPE_CHUNK_BYTES / (8 * words);
+  if(per_chunk > PIPE_CHUNK_QUERIES) { per_chunk = PIPE_CHUNK_QUERIES; }
+  if(per_chunk == 0) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "packed patterns: one pattern exceeds a pipeline chunk"); }
+  const u64 chunks = (nq + per_chunk - 1) / per_chunk;
+  auto page_locked = [](const void* first, u64 bytes) -> bool
+  {
+    if(bytes == 0) { return false; }
+    hipPointerAttribute_t a, b;
+    const bool yes = hipPointerGetAttributes(&a, first) == hipSuccess && a.type == hipMemoryTypeHost &&
+                     hipPointerGetAttributes(&b, static_cast<const char*>(first) + bytes - 1) == hipSuccess && b.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return yes;
+  };
+  const bool direct_in = page_locked(codes, nq * words * 8), direct_out = page_locked(ranges, 2 * nq * sizeof(u64));
+  const unsigned PIPE_LANES = ix->tune.pipe_lanes;
+  std::vector<int> status(PIPE_LANES, GCSA2_OK);
+  std::vector<std::string> messages(PIPE_LANES);
+  const u64 out_at = (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8;      // where a set keeps its ranges (pipe_set_bytes)
+  auto work = [&](unsigned t)
+  {
+    DeviceGuard guard(ix->device);
+    gcsa2_index::PipeLane& lane = ix->pipe[t];
+    auto fail_lane = [&](const char* what, hipError_t e) { status[t] = GCSA2_ERR_HIP; messages[t] = std::string(what) + ": " + hipGetErrorString(e); };
+    auto retire = [&](gcsa2_index::PipeSet& set) -> bool
+    {
+      if(!set.busy) { return true; }
+      hipError_t e = hipEventSynchronize(set.done);
+      if(e != hipSuccess) { fail_lane("hipEventSynchronize", e); return false; }
+      if(!direct_out) { std::memcpy(ranges + 2 * set.first, set.h + out_at, set.count * 16); }
+      set.busy = false;
+      return true;
+    };
+    unsigned turn = 0;
+    for(u64 c = t; c < chunks && status[t] == GCSA2_OK; c += PIPE_LANES, turn ^= 1)
+    {
+      gcsa2_index::PipeSet& set = lane.set[turn];
+      if(!retire(set)) { break; }
+      const u64 b = c * per_chunk, count = (nq - b < per_chunk ? nq - b : per_chunk), bytes = count * words * 8;
+      hipError_t err = hipSuccess;
+      if(direct_in) { err = hipMemcpyAsync(set.d, codes + b * words, bytes, hipMemcpyHostToDevice, lane.stream); }
+      else
+      {
+        std::memcpy(set.h, codes + b * words, bytes);
+        err = hipMemcpyAsync(set.d, set.h, bytes, hipMemcpyHostToDevice, lane.stream);
+      }
+      if(err != hipSuccess) { fail_lane("hipMemcpyAsync", err); break; }
+      u64* d_out = reinterpret_cast<u64*>(set.d + out_at);
+      int rc_find = gcsa2_find_packed_device(ix, reinterpret_cast<const u64*>(set.d), length, count, d_out, lane.stream);
+      if(rc_find != GCSA2_OK) { status[t] = rc_find; messages[t] = g_error; break; }
+      err = hipMemcpyAsync(direct_out ? reinterpret_cast<char*>(ranges + 2 * b) : set.h + out_at, d_out, count * 16, hipMemcpyDeviceToHost, lane.stream);
+      if(err == hipSuccess) { err = hipEventRecord(set.done, lane.stream); }
+      if(err != hipSuccess) { fail_lane("hipMemcpyAsync / hipEventRecord", err); break; }
+      set.busy = true; set.first = b; set.count = count;
+    }
+    for(gcsa2_index::PipeSet& set : lane.set) { if(status[t] == GCSA2_OK) { (void)retire(set); } }
+    if(status[t] != GCSA2_OK)
+    {
+      (void)hipStreamSynchronize(lane.stream);
+      for(gcsa2_index::PipeSet& set : lane.set) { set.busy = false; }
+    }
+  };
+  Workers workers;
+  const unsigned lanes = unsigned(chunks < PIPE_LANES ? chunks : PIPE_LANES);
+  for(unsigned t = 1; t < lanes; t++) { workers.emplace_back(work, t); }
+  work(0);
+  workers.join();
+  for(unsigned t = 0; t < lanes; t++) { if(status[t] != GCSA2_OK) { return fail(status[t], "pipeline lane " + std::to_string(t) + ": " + messages[t]); } }
+  return GCSA2_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// find() of `nq` patterns of `pattern_length` characters each, given as 2-bit codes in host memory (layout: gcsa2_hip.h)
+int gcsa2_find_batch_packed(const gcsa2_index* ix, const uint64_t* codes, uint64_t pattern_length, uint64_t nq, uint64_t* ranges)
+{
+  CHECK_INDEX(ix);
+  if(nq == 0) { return GCSA2_OK; }
+  if(codes == nullptr || ranges == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  if(pattern_length == 0 || pattern_length >= (u64(1) << 32)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "packed patterns: the common length must be 1 .. 2^32 - 1"); }
+  try
+  {
+    if(nq >= PIPE_MIN_QUERIES / 4) { return find_packed_pipelined(ix, codes, pattern_length, nq, ranges); }
+    // small batches: one copy in, one launch, one copy out
+    DeviceGuard guard(ix->device);
+    const u64 words = (pattern_length + 31) >> 5;
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, nq * words * 8 + nq * 16));
+    u64* d_codes = static_cast<u64*>(d); u64* d_out = d_codes + nq * words;
+    hipError_t e = hipMemcpy(d_codes, codes, nq * words * 8, hipMemcpyHostToDevice);
+    int rc = (e == hipSuccess ? gcsa2_find_packed_device(ix, d_codes, pattern_length, nq, d_out, nullptr) : fail(GCSA2_ERR_HIP, hipGetErrorString(e)));
+    if(rc == GCSA2_OK) { e = hipMemcpy(ranges, d_out, nq * 16, hipMemcpyDeviceToHost); if(e != hipSuccess) { rc = fail(GCSA2_ERR_HIP, hipGetErrorString(e)); } }
+    (void)hipFree(d);
+    return rc;
+  }
+  catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_find_batch_packed: ") + e.what()); }
+}
 
 int gcsa2_find_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t* ranges)
 {
@@ -2984,7 +3111,7 @@ extern "C" int gcsa2_match_stats_device(const gcsa2_index* ix, const uint8_t* d_
 // Matching statistics as BREAK POINTS (k_match_stats2<.., BREAKS>): the CSR of the left-maximal matches of every pattern.
 // Complete on return: the number of records is read back, and a buffer that is too small is refused with the number needed.
 int gcsa2_match_breaks_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, uint64_t total_bytes,
-                              int variant, uint64_t* d_break_offsets, gcsa2_break* d_breaks, uint64_t capacity, uint64_t* total_breaks,
+                              int variant, uint64_t min_length, uint64_t* d_break_offsets, gcsa2_break* d_breaks, uint64_t capacity, uint64_t* total_breaks,
                               uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream)
 {
   CHECK_INDEX(ix);
@@ -2999,41 +3126,56 @@ int gcsa2_match_breaks_device(const gcsa2_index* ix, const uint8_t* d_patterns, 
     HIP_TRY(hipStreamSynchronize(st));
     return GCSA2_OK;
   }
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(); };
   Scratch scratch(ix, st);
-  BreakSink sink{nullptr, capacity, nullptr, nullptr};
+  // slots of the temporary records: what the caller's buffer holds + one block per wavefront that may leave a hole
+  const u64 waves = (nq + 63) / 64;
+  const u64 tmp_slots = capacity + (waves + 1) * BREAK_BLOCK;
+  BreakSink sink{nullptr, tmp_slots, nullptr, nullptr, u32(min_length > 0xFFFFFFFFull ? 0xFFFFFFFFull : min_length)};
   u64 *wide = nullptr, *own_ranges = nullptr;
   const unsigned slot = ix->next_slot.fetch_add(1) % RESULT_SLOTS;
   unsigned long long* d_totals = ix->d_slots + u64(TOTAL_WORDS) * slot;
   sink.counter = d_totals;
-  HIP_TRY(scratch.get(sink.tmp, (capacity > 0 ? capacity : 1) * BREAK_WORDS));
+  HIP_TRY(scratch.get(sink.tmp, tmp_slots * BREAK_WORDS));
   HIP_TRY(scratch.get(sink.counts, nq));
   HIP_TRY(scratch.get(wide, nq + 1));
   if(d_ranges == nullptr) { HIP_TRY(scratch.get(own_ranges, 2 * nq)); d_ranges = own_ranges; }
   HIP_TRY(hipMemsetAsync(d_totals, 0, TOTAL_WORDS * sizeof(unsigned long long), st));
   HIP_TRY(hipMemsetAsync(sink.counts, 0, nq * sizeof(u32), st));
+  const double t_alloc = since();
   int rc = match_stats_launch(ix, variant, d_patterns, d_offsets, nq, total_bytes, nullptr, d_ranges, d_fallbacks, st, &sink);
   if(rc != GCSA2_OK) { return rc; }
+  const double t_launched = since();
   hipLaunchKernelGGL(k_widen_counts, dim3(grid_for(nq + 1)), dim3(TPB), 0, st, sink.counts, nq, wide);
   size_t scan_bytes = 0;
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, wide, d_break_offsets, int(nq + 1), st));
   char* scan_tmp = nullptr;
   HIP_TRY(scratch.get(scan_tmp, scan_bytes));
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, wide, d_break_offsets, int(nq + 1), st));
+  hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, st, d_break_offsets + nq, reinterpret_cast<u64*>(d_totals + 1));
   unsigned long long totals[TOTAL_WORDS];
   rc = read_totals(ix, slot, totals, st);
   if(rc != GCSA2_OK) { return rc; }
   scratch.settled = true;
-  const u64 appended = totals[0];
-  *total_breaks = appended;
-  if(appended > capacity) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "break buffer too small"); }
-  if(appended > 0)
+  const double t_totals = since();
+  const u64 reserved = totals[0], found = totals[1];          // slots the wavefronts reserved (with holes), records in all
+  *total_breaks = found;
+  if(found > capacity) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "break buffer too small"); }
+  if(found > 0)
   {
     scratch.settled = false;
-    hipLaunchKernelGGL(k_breaks_scatter, dim3(grid_for(appended)), dim3(TPB), 0, st, sink.tmp, appended, d_break_offsets, reinterpret_cast<u64*>(d_breaks), capacity);
+    const u64 stored = (reserved < tmp_slots ? reserved : tmp_slots);
+    hipLaunchKernelGGL(k_breaks_scatter, dim3(grid_for(stored)), dim3(TPB), 0, st, sink.tmp, stored, d_break_offsets, reinterpret_cast<u64*>(d_breaks), capacity);
     LAUNCH_CHECK("k_breaks_scatter");
   }
   HIP_TRY(hipStreamSynchronize(st));
   scratch.settled = true;
+  if(ix->tune.locate_trace)
+  {
+    std::fprintf(stderr, "[breaks] scratch %.0f us | launched %.0f | totals %.0f | done %.0f (arena %zu of %zu bytes, %zu extra allocations)\n",
+                 t_alloc, t_launched, t_totals, since(), scratch.used, scratch.arena.bytes, scratch.extra.size());
+  }
   return GCSA2_OK;
 }
 

@@ -316,7 +316,13 @@ __device__ __forceinline__ ulonglong2 jt_make(u64 end, u64 after4, u64 after2, u
 #ifndef GCSA2_FIND_WAVES
 #define GCSA2_FIND_WAVES 4
 #endif
-template<bool STATS, bool JUMP = false, bool PAIR = false>
+// PACKED = true (gcsa2_find_packed_device): the patterns arrive as 2-bit codes, all of one length `offsets` (the argument is
+// then the LENGTH, not an array), last character first -- word j of pattern q, at patterns + 8 (q W + j) with W = ceil(length /
+// 32), holds the characters at distance 32 j .. 32 j + 31 from the pattern's end, comp - 1 of the character at distance t in
+// bits [2 (t & 31), 2 (t & 31) + 2) (the layout k_pack_patterns makes for the matching statistics).  A caller that can pack
+// sends 8 bytes per 32-mer over the link instead of 32 + 8; the kernel's seed index and pattern window are the words
+// themselves.  Only fast characters can be written this way (comps 1..4: a pattern with an N takes the byte interface).
+template<bool STATS, bool JUMP = false, bool PAIR = false, bool PACKED = false>
 __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void k_find2(DevImage img, const u8* __restrict__ patterns,
                                                const u64* __restrict__ offsets, u64 nq,
                                                u64* __restrict__ out, unsigned long long* __restrict__ stats,
@@ -354,7 +360,13 @@ __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void 
   {
     q = query; sp = 0; ep = img.n - 1; i = 0; done = true; word_addr = ~u64(0); tried = false; no_jump = false; win_used = ~u32(0);
     force_single = 0;
-    u64 begin = offsets[q], len = offsets[q + 1] - begin;
+    u64 begin = 0, len = 0;
+    if constexpr(PACKED)
+    {
+      len = reinterpret_cast<u64>(offsets);                    // one length for the whole batch
+      begin = q * ((len + 31) >> 5) * 8;                       // byte offset of the pattern's first code word
+    }
+    else { begin = offsets[q]; len = offsets[q + 1] - begin; }
     if(len > 0 && img.n > 0)                                   // gcsa.h:99
     {
       p = patterns + begin;
@@ -364,11 +376,15 @@ __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void 
       {
         u64 tix = 0;
         bool fast = true;
-        for(u32 j = 0; j < k; j++)                             // j-th character from the end
+        if constexpr(PACKED) { tix = *reinterpret_cast<const u64*>(p) & ((u64(1) << (2 * k)) - 1); }
+        else
         {
-          u32 comp = t.c2c[byte_at(len - 1 - j)];
-          fast = fast && (comp - 1 < 4);
-          tix |= u64((comp - 1) & 3) << (2 * j);
+          for(u32 j = 0; j < k; j++)                           // j-th character from the end
+          {
+            u32 comp = t.c2c[byte_at(len - 1 - j)];
+            fast = fast && (comp - 1 < 4);
+            tix |= u64((comp - 1) & 3) << (2 * j);
+          }
         }
         if(fast)
         {
@@ -385,7 +401,9 @@ __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void 
       if(!seeded)
       {
         i = len - 1;
-        u32 comp = t.c2c[byte_at(i)];
+        u32 comp = 0;
+        if constexpr(PACKED) { comp = 1 + u32(*reinterpret_cast<const u64*>(p) & 3); }
+        else { comp = t.c2c[byte_at(i)]; }
         sp = t.crange[2 * comp]; ep = t.crange[2 * comp + 1];  // charRange, gcsa.h:101-102, 150-153
       }
       done = range_empty(sp, ep) || i == 0;                    // gcsa.h:103
@@ -418,7 +436,20 @@ __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void 
       // position win_top - 1 - r at bits [2r, 2r + 2) of win_code, bit r of win_bad = "not a fast character".
       // Refilled once per 24 consumed characters (five independent word loads), so that neither the
       // jump test nor a step waits for pattern bytes.
-      if(!done && win_used > 24)
+      if constexpr(PACKED)
+      {
+        if(!done && win_used > 24)                             // two code words and a funnel shift
+        {
+          const u64 total = reinterpret_cast<u64>(offsets), words = (total + 31) >> 5;
+          const u64 t0 = total - i, w = t0 >> 5;
+          const u32 s = u32(t0 & 31);
+          const u64* code = reinterpret_cast<const u64*>(p);
+          const u64 c0 = code[w], c1 = (w + 1 < words ? code[w + 1] : 0);
+          win_code = (s == 0 ? c0 : (c0 >> (2 * s)) | (c1 << (64 - 2 * s)));
+          win_bad = 0; win_used = 0;
+        }
+      }
+      else if(!done && win_used > 24)
       {
         win_used = 0; win_code = 0; win_bad = 0;
         const u64 count = (i < 32 ? i : 32), low = reinterpret_cast<u64>(p) + i - count, base = low & ~u64(7);

@@ -472,16 +472,18 @@ constexpr u64 MS_REFILL_MIN = u64(1) << 19;             // host-pointer API: sma
 // by P[p - 1] (LF empties and parent() is taken, lcp.cpp:276-301; the reference's caller shape: src/algorithms.cpp:146-167),
 // with its length and its range, and position 0.  Between two break points the statistics rise by one per position to the
 // left, so the dense array follows from them (ms[i] = len - (i - p) for p <= i < the break point to the right); the result
-// stores, a third of the dense kernel's memory requests, shrink to one 48-byte record per break.  Records are appended to
-// `sink.tmp` through one atomic per wavefront and round -- {pattern, ordinal | position << 32, length, sp, ep, 0} -- and put
-// into CSR order by k_breaks_scatter once the per-pattern counts have been scanned; records beyond `sink.cap` are counted, not
-// stored.  The record of a round is taken at the loop head, where (i, depth, sp, ep) describe the match that starts at
+// stores, a third of the dense kernel's memory requests, shrink to one 32-byte record per break.  Records are appended to
+// `sink.tmp` -- {pattern | ordinal << 32, position | length << 32, sp, ep}; a wavefront reserves blocks of BREAK_BLOCK slots --
+// and put into CSR order by k_breaks_scatter once the per-pattern counts have been scanned; slots beyond `sink.cap` are not
+// written (the exact number of records is the sum of the per-pattern counts).  The record of a round is taken at the loop head, where (i, depth, sp, ep) describe the match that starts at
 // position i.  Exactly the positions p with p == 0 or ms[p - 1] != ms[p] + 1 get a record.
 struct BreakSink
 {
-  u64* tmp; u64 cap; unsigned long long* counter; u32* counts;
+  u64* tmp; u64 cap; unsigned long long* counter; u32* counts; u32 min_length;
 };
-constexpr u32 BREAK_WORDS = 6;
+constexpr u32 BREAK_WORDS = 4;               // {pattern | ordinal << 32, position | length << 32, sp, ep}
+constexpr u32 BREAK_BLOCK = 256;             // record slots a wavefront reserves at a time
+constexpr u64 BREAK_HOLE = ~u64(0);          // pattern field of an unused slot (the tail of a wave's last block)
 
 template<bool PAIR, bool REFILL, bool PROF = false, bool BREAKS = false>
 __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8* __restrict__ patterns,
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
                                                        u64* __restrict__ fallbacks, u32 cool_down,
                                                        unsigned long long* __restrict__ queue, u32 refill_at,
                                                        const u64* __restrict__ codes, const u32* __restrict__ bad,
-                                                       unsigned long long* __restrict__ prof = nullptr, BreakSink sink = BreakSink{nullptr, 0, nullptr, nullptr})
+                                                       unsigned long long* __restrict__ prof = nullptr, BreakSink sink = BreakSink{nullptr, 0, nullptr, nullptr, 0})
 {
   [[maybe_unused]] u64 prof_t = 0, prof_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] u32 prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -519,6 +521,13 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   // coalesces across lanes -- so the only lever is fewer, wider stores per lane (8-byte stores: 64 per 256-bp pattern).
   [[maybe_unused]] u64 packed_lo = 0, packed_hi = 0; [[maybe_unused]] u32 have = 0;
   [[maybe_unused]] u32 last_break = ~u32(0), n_breaks = 0;     // BREAKS: position of the latest record, records of this pattern
+  [[maybe_unused]] u64 blk_base = 0; [[maybe_unused]] u32 blk_used = BREAK_BLOCK;    // BREAKS: the wave's block of record slots (uniform)
+  // (kept in a vector register on purpose: the kernel has no scalar registers to spare, and as a kernel argument the value was
+  // re-read from the argument segment -- an s_load and a full s_waitcnt -- in every round of every wave: +10 % on the batch)
+  [[maybe_unused]] u32 min_length = sink.min_length;
+  if constexpr(BREAKS) { asm volatile("" : "+v"(min_length)); }
+  // (The record buffer's address and capacity stay kernel arguments: they are read only where a record is written.  Holding
+  // them in vector registers as well -- 127 VGPRs -- cost the persistent form 2.9 ms on config 5's batch; profiles/r04_match_stats.md.)
   [[maybe_unused]] bool pending = false;                       // BREAKS: a character that does not occur: position i is a break of length 0
   auto emit = [&](u32 pos, u32 value)        // ms[begin + pos] = value; positions arrive in descending order
   {
@@ -588,26 +597,37 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       // i + 1; the final record and the end of the pattern then wait one round, a lane writes one record per round).
       was_pending = pending;
       const u32 pos = (was_pending ? i + 1 : i);
-      const bool record = has && total > 0 && last_break != pos && (was_pending ? pos < total : (i == 0 || need_parent));
+      const bool is_break = has && total > 0 && last_break != pos && (was_pending ? pos < total : (i == 0 || need_parent));
+      if(is_break) { last_break = pos; }
+      const bool record = is_break && depth >= min_length;          // (a MEM finder's minimum length: shorter matches are not reported)
       const u64 writers = __ballot(record);
       if(writers != 0)                                         // uniform
       {
-        const u32 leader = u32(__ffsll((long long)writers)) - 1;
-        unsigned long long base = 0;
-        if(lane == leader) { base = atomicAdd(sink.counter, (unsigned long long)__popcll(writers)); }
-        base = __shfl(base, leader, 64);
+        // slots: the wavefront owns a block of BREAK_BLOCK records of `sink.tmp` at a time (one atomic on the global counter
+        // per block; one per round was 9 M same-address atomics for config 5's batch: 45 of the kernel's 53 ms).  The writers
+        // of a round that do not fit the current block go to the front of the next one: only a wave's last block has a hole.
+        const u32 count = u32(__popcll(writers)), room = BREAK_BLOCK - blk_used;
+        u64 next_base = 0;
+        if(count > room)
+        {
+          const u32 leader = u32(__ffsll((long long)writers)) - 1;
+          unsigned long long got = 0;
+          if(lane == leader) { got = atomicAdd(sink.counter, (unsigned long long)BREAK_BLOCK); }
+          next_base = __shfl(got, leader, 64);
+        }
         if(record)
         {
-          const u64 at = base + __popcll(writers & ((u64(1) << lane) - 1));
+          const u32 rank = u32(__popcll(writers & ((u64(1) << lane) - 1)));
+          const u64 at = (rank < room ? blk_base + blk_used + rank : next_base + (rank - room));
           if(at < sink.cap)
           {
             ulonglong2* dst = reinterpret_cast<ulonglong2*>(sink.tmp + at * BREAK_WORDS);
-            dst[0] = make_ulonglong2(q, u64(n_breaks) | (u64(pos) << 32));
-            dst[1] = make_ulonglong2(u64(depth), sp);
-            dst[2] = make_ulonglong2(ep, 0);
+            dst[0] = make_ulonglong2(q | (u64(n_breaks) << 32), u64(pos) | (u64(depth) << 32));
+            dst[1] = make_ulonglong2(sp, ep);
           }
-          n_breaks++; last_break = pos;
+          n_breaks++;
         }
+        if(count > room) { blk_base = next_base; blk_used = count - room; } else { blk_used += count; }
       }
       pending = false;
     }
@@ -767,6 +787,14 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     }
     G2_TICK(7);
   }
+  if constexpr(BREAKS)
+  {
+    for(u32 j = blk_used + lane; j < BREAK_BLOCK; j += 64)     // the unused tail of the wave's last block (none if it never wrote)
+    {
+      const u64 at = blk_base + j;
+      if(at < sink.cap) { sink.tmp[at * BREAK_WORDS] = BREAK_HOLE; }
+    }
+  }
   if constexpr(PROF)
   {
 #pragma unroll
@@ -788,13 +816,16 @@ __global__ __launch_bounds__(TPB) void k_breaks_scatter(const u64* __restrict__ 
   const u64 r = u64(blockIdx.x) * TPB + threadIdx.x;
   if(r >= stored) { return; }
   const ulonglong2* src = reinterpret_cast<const ulonglong2*>(tmp + r * BREAK_WORDS);
-  const ulonglong2 a = src[0], b = src[1], c = src[2];
-  const u64 dest = offsets[a.x] + (a.y & 0xFFFFFFFFull);
+  const ulonglong2 a = src[0], b = src[1];
+  if(a.x == BREAK_HOLE) { return; }
+  const u64 dest = offsets[a.x & 0xFFFFFFFFull] + (a.x >> 32);
   if(dest >= capacity) { return; }
   ulonglong2* dst = reinterpret_cast<ulonglong2*>(out + 4 * dest);
-  dst[0] = make_ulonglong2(a.y >> 32, b.x);
-  dst[1] = make_ulonglong2(b.y, c.x);
+  dst[0] = make_ulonglong2(a.y & 0xFFFFFFFFull, a.y >> 32);
+  dst[1] = b;
 }
+
+__global__ void k_copy_word(const u64* __restrict__ src, u64* __restrict__ dst) { *dst = *src; }
 
 __global__ __launch_bounds__(TPB) void k_widen_counts(const u32* __restrict__ counts, u64 nq, u64* __restrict__ wide)
 {

@@ -126,3 +126,24 @@ def concat_patterns(patterns):
     if data.shape[0] == 0:
         data = np.zeros(1, dtype=np.uint8)
     return np.ascontiguousarray(data), offsets
+
+
+def pack_kmers(patterns: np.ndarray, char2comp=None) -> np.ndarray:
+    """(nq, m) pattern bytes over the fast characters -> (nq, ceil(m / 32)) uint64 code words in the layout of
+    gcsa2_find_batch_packed (include/gcsa2_hip.h): last character first, comp - 1 in two bits.  Raises ValueError when a
+    pattern holds a character outside comps 1..4 (such patterns go through the byte interface)."""
+    patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
+    nq, m = patterns.shape
+    if char2comp is None:
+        char2comp = np.full(256, 5, dtype=np.uint8)
+        for ch, c in ((b"$", 0), (b"\0", 0), (b"A", 1), (b"a", 1), (b"C", 2), (b"c", 2), (b"G", 3), (b"g", 3), (b"T", 4), (b"t", 4), (b"#", 6)):
+            char2comp[ch[0]] = c
+    comps = np.asarray(char2comp, dtype=np.uint8)[patterns].astype(np.int64) - 1
+    if ((comps < 0) | (comps > 3)).any():
+        raise ValueError("pack_kmers: a pattern holds a character outside comps 1..4")
+    words = (m + 31) // 32
+    out = np.zeros((nq, words), dtype=np.uint64)
+    rev = comps[:, ::-1].astype(np.uint64)                    # distance t from the end at column t
+    for t in range(m):
+        out[:, t >> 5] |= rev[:, t] << np.uint64(2 * (t & 31))
+    return out

@@ -168,6 +168,16 @@ int gcsa2_find_device(const gcsa2_index* index, const uint8_t* d_patterns,
                       const uint64_t* d_offsets, uint64_t n_queries, uint64_t* d_ranges,
                       void* stream);
 
+/* find() of n_queries patterns of ONE length (k-mer batches) handed over as 2-bit codes: 8 bytes per 32 characters over the link
+ * instead of 32 pattern bytes + an 8-byte offset.  Pattern q occupies W = ceil(pattern_length / 32) u64 words at codes[q W ..];
+ * word j holds the characters at distance 32 j .. 32 j + 31 from the pattern's END, the character at distance t in bits
+ * [2 (t & 31), 2 (t & 31) + 2) as comp - 1 (A C G T = 0 1 2 3 with the default alphabet; unused high bits zero) -- the order
+ * the backward search of gcsa.h:96-110 consumes them.  Only comps 1..4 can be written: a pattern with any other character
+ * goes through gcsa2_find_batch.  Same ranges as the byte interface (the parity suite compares the two). */
+int gcsa2_find_batch_packed(const gcsa2_index* index, const uint64_t* codes, uint64_t pattern_length, uint64_t n_queries, uint64_t* ranges);
+int gcsa2_find_packed_device(const gcsa2_index* index, const uint64_t* d_codes, uint64_t pattern_length, uint64_t n_queries,
+                             uint64_t* d_ranges, void* stream);
+
 /* Launch shape.  variant 2 = the default (k_find2, fused 128-byte blocks, what
  * gcsa2_find_device runs); variant 4 = the same kernel behind a device-side sort of the queries by
  * pattern length, for batches of very uneven lengths (the 64 chains of a wavefront then finish
@@ -374,10 +384,13 @@ int gcsa2_match_stats_device_sized(const gcsa2_index* index, int variant, const 
  * of discovery (descending position).  The dense statistics follow from them: ms[i] = length - (i - p) for the record with the
  * largest p <= i.  d_break_offsets: n_queries + 1 entries; capacity: records d_breaks holds; *total_breaks: records found --
  * GCSA2_ERR_BUFFER_TOO_SMALL with that number when it exceeds capacity (nothing is written then).  d_ranges (final ranges) and
- * d_fallbacks (parent() calls per pattern) may be NULL.  variant as in gcsa2_match_stats_device_variant.  Complete on return. */
+ * d_fallbacks (parent() calls per pattern) may be NULL.  variant as in gcsa2_match_stats_device_variant.  min_length > 0 keeps
+ * only the records of at least that length -- a MEM finder's minimum match length: right after a mismatch the matches are as
+ * short as any string of log4(n) characters and every position is a break point, which on a whole-genome index makes more
+ * bytes of records than the dense statistics have; the dense form no longer follows from the records then.  Complete on return. */
 typedef struct gcsa2_break { uint64_t position, length, sp, ep; } gcsa2_break;
 int gcsa2_match_breaks_device(const gcsa2_index* index, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t n_queries,
-                              uint64_t total_pattern_bytes, int variant, uint64_t* d_break_offsets, gcsa2_break* d_breaks,
+                              uint64_t total_pattern_bytes, int variant, uint64_t min_length, uint64_t* d_break_offsets, gcsa2_break* d_breaks,
                               uint64_t capacity, uint64_t* total_breaks, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream);
 /* Diagnostic (not the timed path): the default kernel instrumented with shader-clock counters, same results.  d_prof[16],
  * zeroed by the caller: [0..7] cycles summed over the wavefronts for the phases of a round (loop head / pattern window, step

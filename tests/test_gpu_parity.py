@@ -333,6 +333,16 @@ def test_match_breaks(case, engine, variant):
         assert np.array_equal(got[:n], want), name
         assert (d_brk[n:] == -1).all()
         assert np.array_equal(d_rng.cpu().numpy().view(np.uint64), cr) and np.array_equal(d_fb.cpu().numpy().view(np.uint64), cf), name
+    # a minimum length: the same records without the shorter ones
+    for min_length in (1, 2, K, 2 * K):
+        keep = want[:, 1] >= min_length
+        n = gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, total, d_boff.data_ptr(), d_brk.data_ptr(), d_brk.shape[0],
+                                    d_rng.data_ptr(), d_fb.data_ptr(), 0, variant=variant, min_length=min_length)
+        assert n == int(keep.sum()) and np.array_equal(d_brk.cpu().numpy().view(np.uint64)[:n], want[keep]), (name, min_length)
+        kept_per_pattern = np.add.reduceat(np.concatenate([keep, [False]]).astype(np.uint64), np.minimum(want_off[:-1], len(keep)).astype(np.int64))
+        kept_per_pattern[want_off[1:] == want_off[:-1]] = 0
+        assert np.array_equal(np.diff(d_boff.cpu().numpy().view(np.uint64)), kept_per_pattern), (name, min_length)
+        assert np.array_equal(d_rng.cpu().numpy().view(np.uint64), cr) and np.array_equal(d_fb.cpu().numpy().view(np.uint64), cf)
     # without the optional outputs; then a buffer that is too small
     n = gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, total, d_boff.data_ptr(), d_brk.data_ptr(), d_brk.shape[0], variant=variant)
     assert n == len(want) and np.array_equal(d_brk.cpu().numpy().view(np.uint64)[:n], want)
@@ -829,6 +839,69 @@ def test_wide_seed_entries(engine, monkeypatch, pairs):
         assert np.array_equal(gm, cm) and np.array_equal(gr, cr) and np.array_equal(gf, cf), (wide, k)
         gpu.close()
     assert all(h > 0 for h in hits[:4]) and hits[4] == 0, hits       # the branch ran in every lowered setting, never at the default
+
+
+@pytest.mark.parametrize("pairs", ["1", "0"], ids=["pair-blocks", "single-blocks"])
+def test_find_packed_patterns(engine, monkeypatch, pairs):
+    """gcsa2_find_batch_packed / gcsa2_find_packed_device: k-mer batches handed over as 2-bit codes (one length per batch, last
+    character first) return exactly the ranges of the byte interface and of the oracle -- hits, misses at every depth (edge-space
+    empty ranges, gcsa.h:160), lengths below, at and above the seed table's k, lengths that are not multiples of 32 and span
+    several code words; small batches (one copy) and large ones (the chunked host pipeline, pageable and page-locked)."""
+    import torch
+    from oracle.oracle import OracleIndex
+    from workload import builder
+    from gcsa2_amd.hostview import pack_kmers
+    g = graphs.snp_graph(20000, 0xF1, 0xF2, snp_period=9, node_len=16)
+    ix = builder.build(g, 16)
+    cpu = OracleIndex(ix)
+    monkeypatch.setenv("GCSA2_PAIR_BLOCKS", pairs)
+    rng = SplitMix64(0xF3)
+    for kmer, m in (("0", 5), ("6", 5), ("6", 6), ("6", 19), (None, 32), ("8", 33), ("3", 64), ("7", 77)):
+        if kmer is None:
+            monkeypatch.delenv("GCSA2_KMER_TABLE", raising=False)
+        else:
+            monkeypatch.setenv("GCSA2_KMER_TABLE", kmer)
+        gpu = engine.GCSA(ix, with_samples=False, with_counters=False, with_lcp=False)
+        walks = [p for p in random_patterns(g, m, 0xF4 + m, 3000) if len(p) == m and all(c in b"ACGT" for c in p)]
+        for p in list(walks[:1500]):                              # substitutions: misses at every depth
+            k = rng.below(m)
+            walks.append(p[:k] + bytes([b"ACGT"[rng.below(4)]]) + p[k + 1:])
+        walks += [bytes(b"ACGT"[rng.below(4)] for _ in range(m)) for _ in range(500)]
+        arr = np.frombuffer(b"".join(walks), dtype=np.uint8).reshape(len(walks), m)
+        data, off = concat_patterns(walks)
+        want = cpu.find_batch(data, off)
+        codes = pack_kmers(arr, ix.char2comp)
+        assert codes.shape == (len(walks), (m + 31) // 32)
+        assert np.array_equal(gpu.find_batch(data, off), want), (kmer, m)
+        assert np.array_equal(gpu.find_batch_packed(codes, m), want), (kmer, m)
+        dev = torch.device("cuda", 0)
+        d_codes = torch.from_numpy(codes.view(np.int64).copy()).to(dev)
+        d_out = torch.zeros((len(walks), 2), dtype=torch.int64, device=dev)
+        gpu.find_packed_device(d_codes.data_ptr(), m, len(walks), d_out.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), (kmer, m)
+        gpu.close()
+    with pytest.raises(ValueError):
+        pack_kmers(np.frombuffer(b"ACGN", dtype=np.uint8).reshape(1, 4), ix.char2comp)
+    # the chunked pipeline: 2^18 patterns, pageable and page-locked
+    monkeypatch.delenv("GCSA2_KMER_TABLE", raising=False)
+    gpu = engine.GCSA(ix, with_samples=False, with_counters=False, with_lcp=False)
+    m, nq = 32, (1 << 18) + 4321
+    base = np.frombuffer(b"".join(p for p in random_patterns(g, m, 0xF9, 6000) if len(p) == m and all(c in b"ACGT" for c in p)), dtype=np.uint8).reshape(-1, m)
+    arr = base[np.random.default_rng(0xFA).integers(0, base.shape[0], size=nq)].copy()
+    flip = np.random.default_rng(0xFB).integers(0, 4, size=nq) == 0
+    arr[flip, 7] = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(0xFC).integers(0, 4, size=int(flip.sum()))]
+    off = np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)
+    want = gpu.find_batch(arr.reshape(-1), off)
+    sample = np.random.default_rng(0xFD).integers(0, nq, size=3000)
+    assert np.array_equal(want[sample], cpu.find_batch(arr[sample].reshape(-1).copy(), np.arange(3001, dtype=np.uint64) * np.uint64(m)))
+    codes = pack_kmers(arr, ix.char2comp)
+    assert np.array_equal(gpu.find_batch_packed(codes, m), want)
+    p_codes = torch.empty((nq, 1), dtype=torch.int64).pin_memory()
+    p_out = torch.zeros((nq, 2), dtype=torch.int64).pin_memory()
+    p_codes.numpy().view(np.uint64)[:] = codes
+    gpu.find_batch_packed(p_codes.numpy().view(np.uint64), m, out=p_out.numpy().view(np.uint64))
+    assert np.array_equal(p_out.numpy().view(np.uint64), want)
 
 
 def test_deep_lcp_tree(engine):
