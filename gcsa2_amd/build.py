@@ -81,6 +81,17 @@ def build_cli(name, force=False):
     return out
 
 
+def build_gcsa_inspect(force=False):
+    """tools/cpp/gcsa_inspect.cpp: the member-by-member listing of a .gcsa / .lcp file (host code only, nothing linked)."""
+    src, out = os.path.join(ROOT, "tools", "cpp", "gcsa_inspect.cpp"), os.path.join(HERE, "lib", "gcsa_inspect")
+    deps = [src, os.path.join(HERE, "csrc", "sdsl_reader.hpp")]
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", src, "-o", out])
+    return out
+
+
 def build_query_gcsa(force=False):
     return build_cli("query_gcsa", force)
 

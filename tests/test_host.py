@@ -447,3 +447,44 @@ def test_create_validates_the_view(built):
     def wrong_branching(b):
         b.lcp_branching = 8
     refuses(wrong_branching, "offsets|root")
+
+
+def test_gcsa_inspect_lists_every_member(built, tmp_path):
+    """tools/cpp/gcsa_inspect: the walk over a .gcsa / .lcp pair (here written by the independent Python restatement of the
+    container encodings, workload/sdsl_format.py) accounts for every byte and names each member of GCSA::serialize /
+    LCPArray::serialize in order (reference src/gcsa.cpp:140-179, src/lcp.cpp:116-128); a damaged file stops the walk at the
+    member and byte offset in question.  This is the tool to run first on a file written by the real library (SURVEY 8(f)-1:
+    the encodings are unpinned here)."""
+    import subprocess
+    from gcsa2_amd import build as engine_build
+    from workload import graphs, builder, sdsl_format
+    tool = engine_build.build_gcsa_inspect()
+    ix = builder.build(graphs.snp_graph(3000, 0x21, 0x22, snp_period=7, node_len=16), 16, sample_period=16, branching=4)
+    base = str(tmp_path / "g")
+    sdsl_format.write(ix, base)
+    out = subprocess.run([tool, base + ".gcsa", base + ".lcp"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr
+    lines = out.stdout.splitlines()
+    assert sum("every byte accounted for" in l for l in lines) == 2
+    members = [l.split()[0] for l in lines if l and not l.startswith(("#", "member"))]
+    want = (["header", "alpha.char2comp", "alpha.comp2char", "alpha.C", "alpha.sigma,"] + [f"fast_bwt[{c}]" for c in range(ix.sigma)] + ["fast_rank[0..sigma)"]
+            + [f"sparse_bwt[{c}]" for c in range(ix.sigma)] + ["sparse_rank[0..sigma)", "edges", "sampled_paths", "stored_samples", "samples",
+            "sample_select", "extra_pointers.filter", "extra_pointers.values", "redundant_pointers.data", "redundant_pointers.select", "header", "data", "offsets"])
+    assert members == want
+    head = [l for l in lines if l.startswith("header")][0]
+    assert f"path_nodes {ix.n}," in head and f"edges {ix.e}," in head and "tag 0x6C5A6C5A" in head
+    # offsets are contiguous: every member starts where the one before ended
+    rows = [l.split() for l in lines if l and not l.startswith(("#", "member"))]
+    gcsa_rows = rows[: len(rows) - 3]
+    at = 0
+    for r in gcsa_rows:
+        nums = [int(x) for x in r if x.isdigit()][:2]
+        assert nums[0] == at, r
+        at += nums[1]
+    assert at == os.path.getsize(base + ".gcsa")
+    # a damaged file: the walk stops and says where
+    blob = bytearray(open(base + ".gcsa", "rb").read())
+    blob[len(blob) // 2] ^= 0xFF
+    open(base + "_bad.gcsa", "wb").write(bytes(blob[: len(blob) - 9]))
+    out = subprocess.run([tool, base + "_bad.gcsa"], capture_output=True, text=True)
+    assert out.returncode != 0 and ("STOPPED" in out.stdout or "NOT ACCOUNTED" in out.stdout)
