@@ -15,7 +15,8 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # k_find2<STATS = false, JUMP = false, PAIR = *>: the timed default kernel (rounds 1-2: <false, false, false, true, PAIR>)
-TIMED = re.compile(r"k_find2<false, false, (true|false)>|k_find2<false, false, false, true, (true|false)>")
+# (round 4 added a fourth parameter, PACKED; the timed byte-pattern kernel is <false, false, PAIR, false>)
+TIMED = re.compile(r"k_find2<false, false, (true|false)(, false)?>|k_find2<false, false, false, true, (true|false)>")
 
 
 def counters(directory):
