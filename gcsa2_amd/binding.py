@@ -37,7 +37,7 @@ EXPORTS = [
     "gcsa2_group_find_batch", "gcsa2_group_find_device", "gcsa2_group_uses_rccl",
     "gcsa2_group_match_stats_device", "gcsa2_group_locate_device", "gcsa2_comm_match_stats", "gcsa2_comm_locate",
     "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_rccl_ranks", "gcsa2_comm_gather",
-    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_pack_ranges40_device", "gcsa2_unpack_ranges40_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device", "gcsa2_match_breaks_device",
+    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_pack_ranges40_device", "gcsa2_unpack_ranges40_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device", "gcsa2_match_breaks_device", "gcsa2_match_breaks_batch",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
     "gcsa2_host_view_parse_gcsa", "gcsa2_host_view_parse_lcp", "gcsa2_host_view_serialize_gcsa", "gcsa2_host_view_serialize_lcp",
@@ -142,6 +142,7 @@ def load_library():
     L.gcsa2_match_stats_device_variant.argtypes = [vp, C.c_int, vp, vp, u64, vp, vp, vp, vp]
     L.gcsa2_match_stats_device_sized.argtypes = [vp, C.c_int, vp, vp, u64, u64, vp, vp, vp, vp]
     L.gcsa2_match_stats_profile_device.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp, vp, vp]
+    L.gcsa2_match_breaks_batch.argtypes = [vp, u8p, u64p, u64, u64, u64p, vp, u64, u64p, vp, vp]
     L.gcsa2_match_breaks_device.argtypes = [vp, vp, vp, u64, u64, i32, u64, vp, vp, u64, u64p, vp, vp, vp]
     L.gcsa2_group_create.argtypes = [C.POINTER(HostView), C.POINTER(i32), i32, C.POINTER(vp)]
     L.gcsa2_group_destroy.argtypes = [vp]
@@ -525,6 +526,28 @@ class GCSA:
         else:
             _check(self._L.gcsa2_match_stats_device_sized(self._h, variant, d_patterns, d_offsets, nq, int(total_bytes), d_ms, d_ranges,
                                                           d_fallbacks, stream))
+
+    def match_breaks_batch(self, patterns, offsets, min_length=0, capacity=None):
+        """Break points of a batch in host memory: (break_offsets (nq + 1), breaks (total, 4) = {position, length, sp, ep}, ranges,
+        parent() counts).  The record buffer is sized from the refusal when `capacity` is too small (default: 4 per pattern)."""
+        patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nq = offsets.shape[0] - 1
+        cap = int(capacity if capacity is not None else 4 * nq + 16)
+        boff = np.zeros(nq + 1, dtype=np.uint64)
+        rng = np.zeros((max(nq, 1), 2), dtype=np.uint64)
+        fb = np.zeros(max(nq, 1), dtype=np.uint64)
+        total = C.c_uint64()
+        for _ in range(2):
+            brk = np.zeros((max(cap, 1), 4), dtype=np.uint64)
+            rc = self._L.gcsa2_match_breaks_batch(self._h, _p8(patterns), _p64(offsets), nq, int(min_length), _p64(boff), brk.ctypes.data, cap,
+                                                  C.byref(total), rng.ctypes.data, fb.ctypes.data)
+            if rc == -6 and total.value > cap:
+                cap = total.value
+                continue
+            _check(rc)
+            return boff, brk[: total.value], rng[:nq], fb[:nq]
+        _check(rc)
 
     def match_breaks_device(self, d_patterns, d_offsets, nq, total_bytes, d_break_offsets, d_breaks, capacity, d_ranges=0, d_fallbacks=0,
                             stream=0, variant=0, min_length=0):

@@ -3179,6 +3179,43 @@ int gcsa2_match_breaks_device(const gcsa2_index* ix, const uint8_t* d_patterns, 
   return GCSA2_OK;
 }
 
+// The break points of a batch in host memory: one copy in, gcsa2_match_breaks_device, the CSR out.
+int gcsa2_match_breaks_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t min_length,
+                             uint64_t* break_offsets, gcsa2_break* breaks, uint64_t capacity, uint64_t* total_breaks,
+                             uint64_t* ranges, uint64_t* fallbacks)
+{
+  CHECK_INDEX(ix);
+  if(offsets == nullptr || break_offsets == nullptr || total_breaks == nullptr || (breaks == nullptr && capacity > 0) || (patterns == nullptr && nq > 0 && offsets[nq] > offsets[0]))
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer");
+  }
+  *total_breaks = 0;
+  if(nq == 0) { break_offsets[0] = 0; return GCSA2_OK; }
+  if(offsets[0] != 0 || !offsets_ok(offsets, nq)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets must start at 0 and be non-decreasing"); }
+  try
+  {
+    DeviceGuard guard(ix->device);
+    const u64 total = offsets[nq];
+    Lease lease(ix);
+    HIP_TRY(lease.begin(Lease::need(total + 16) + Lease::need((nq + 1) * 8) + Lease::need((nq + 1) * 8) + Lease::need((capacity > 0 ? capacity : 1) * 32)
+                        + Lease::need(2 * nq * 8) + Lease::need(nq * 8)));
+    u8* d_pat = lease.dev<u8>(total + 16); u64* d_off = lease.dev<u64>(nq + 1); u64* d_boff = lease.dev<u64>(nq + 1);
+    gcsa2_break* d_brk = reinterpret_cast<gcsa2_break*>(lease.dev<u64>(4 * (capacity > 0 ? capacity : 1)));
+    u64* d_rng = lease.dev<u64>(2 * nq); u64* d_fb = lease.dev<u64>(nq);
+    HIP_TRY(lease.up(d_pat, patterns, total));
+    HIP_TRY(lease.up(d_off, offsets, (nq + 1) * sizeof(u64)));
+    int rc = gcsa2_match_breaks_device(ix, d_pat, d_off, nq, total, 0, min_length, d_boff, d_brk, capacity, total_breaks, d_rng, d_fb, lease.stream());
+    if(rc != GCSA2_OK) { return rc; }
+    HIP_TRY(lease.down(break_offsets, d_boff, (nq + 1) * sizeof(u64)));
+    if(*total_breaks > 0) { HIP_TRY(lease.down(breaks, d_brk, *total_breaks * sizeof(gcsa2_break))); }
+    if(ranges != nullptr) { HIP_TRY(lease.down(ranges, d_rng, 2 * nq * sizeof(u64))); }
+    if(fallbacks != nullptr) { HIP_TRY(lease.down(fallbacks, d_fb, nq * sizeof(u64))); }
+    HIP_TRY(lease.finish());
+    return GCSA2_OK;
+  }
+  catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("gcsa2_match_breaks_batch: ") + e.what()); }
+}
+
 // Diagnostic: the default kernel instrumented with shader-clock counters per phase of its round (k_match_stats2<.., PROF>),
 // same results; d_prof[0..15] (zeroed by the caller) receives the cycle sums and event counts listed at the kernel.
 extern "C" int gcsa2_match_stats_profile_device(const gcsa2_index* ix, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq,

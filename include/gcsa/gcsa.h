@@ -120,6 +120,67 @@ public:
     return result;
   }
 
+  // Batched find of k-mers handed over as 2-bit codes (gcsa2_find_batch_packed: `length` characters each, last character
+  // first, comp - 1 in two bits, ceil(length / 32) words per pattern): 8 instead of 40 bytes per 32-mer over the link.
+  std::vector<range_type> find_packed_batch(const std::vector<std::uint64_t>& codes, size_type length) const
+  {
+    const size_type words = (length + 31) / 32, nq = (words == 0 ? 0 : codes.size() / words);
+    std::vector<range_type> result(nq);
+    if(nq > 0) { check(gcsa2_find_batch_packed(handle, codes.data(), length, nq, reinterpret_cast<size_type*>(result.data())), "GCSA::find_packed_batch()"); }
+    return result;
+  }
+  // codes of `count` patterns of `length` bytes each (A C G T in either case; anything else throws): the packing a caller does
+  static std::vector<std::uint64_t> pack_kmers(const std::uint8_t* patterns, size_type count, size_type length)
+  {
+    const size_type words = (length + 31) / 32;
+    std::vector<std::uint64_t> codes(count * words, 0);
+    for(size_type q = 0; q < count; q++)
+    {
+      for(size_type t = 0; t < length; t++)                  // distance t from the pattern's end
+      {
+        std::uint64_t code = 0;
+        switch(patterns[q * length + (length - 1 - t)])
+        {
+          case 'A': case 'a': code = 0; break; case 'C': case 'c': code = 1; break;
+          case 'G': case 'g': code = 2; break; case 'T': case 't': code = 3; break;
+          default: throw std::invalid_argument("GCSA::pack_kmers(): a pattern holds a character outside ACGT");
+        }
+        codes[q * words + (t >> 5)] |= code << (2 * (t & 31));
+      }
+    }
+    return codes;
+  }
+
+  // The LF + parent() loop of a MEM finder for a whole batch (gcsa2_match_breaks_batch; the reference's caller shape:
+  // src/algorithms.cpp:146-167): the left-maximal matches of every pattern, of at least min_length characters, as
+  // {position, length, sp, ep} with (sp, ep) = find() of the match.  Needs an index created together with its LCP array
+  // (the two-file constructor / load of base.gcsa + base.lcp).  breaks of pattern q: [offsets_out[q], offsets_out[q + 1]).
+  void match_breaks_batch(const std::vector<std::uint8_t>& patterns, const std::vector<size_type>& offsets, size_type min_length,
+                          std::vector<size_type>& offsets_out, std::vector<gcsa2_break>& breaks) const
+  {
+    const size_type nq = offsets.empty() ? 0 : offsets.size() - 1;
+    offsets_out.assign(nq + 1, 0);
+    breaks.assign(4 * nq + 16, gcsa2_break());
+    std::uint8_t dummy = 0;
+    size_type total = 0;
+    for(int attempt = 0; attempt < 2; attempt++)
+    {
+      const int rc = gcsa2_match_breaks_batch(handle, patterns.empty() ? &dummy : patterns.data(), offsets.data(), nq, min_length, offsets_out.data(),
+                                              breaks.data(), breaks.size(), &total, nullptr, nullptr);
+      if(rc == GCSA2_ERR_BUFFER_TOO_SMALL && total > breaks.size()) { breaks.assign(total, gcsa2_break()); continue; }
+      check(rc, "GCSA::match_breaks_batch()");
+      break;
+    }
+    breaks.resize(total);
+  }
+
+  // Memory pressure (gcsa2_index_set_tables / gcsa2_index_trim): drop (0), build (1) or leave (-1) the pair blocks and the
+  // locate table, resize the seed table (kmer_k: -1 leaves it, 0 drops it); give back staging and scratch memory.  Results
+  // never change.  Not to be called while queries run on this index or on copies of it (copies share the device image).
+  void setTables(int pair_blocks, int kmer_k, int locate_table) { check(gcsa2_index_set_tables(owner.get(), pair_blocks, kmer_k, locate_table), "GCSA::setTables()"); }
+  void trim() { check(gcsa2_index_trim(owner.get()), "GCSA::trim()"); }
+  size_type deviceBytes() const { return gcsa2_device_bytes(handle); }
+
   size_type count(range_type range) const                                   // src/gcsa.cpp:802-809
   {
     size_type in[2] = { range.first, range.second }, out = 0;

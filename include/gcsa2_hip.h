@@ -392,6 +392,10 @@ typedef struct gcsa2_break { uint64_t position, length, sp, ep; } gcsa2_break;
 int gcsa2_match_breaks_device(const gcsa2_index* index, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t n_queries,
                               uint64_t total_pattern_bytes, int variant, uint64_t min_length, uint64_t* d_break_offsets, gcsa2_break* d_breaks,
                               uint64_t capacity, uint64_t* total_breaks, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream);
+/* The same for a batch in host memory (offsets[0] == 0): copies in, runs, copies the CSR out.  ranges / fallbacks may be NULL. */
+int gcsa2_match_breaks_batch(const gcsa2_index* index, const uint8_t* patterns, const uint64_t* offsets, uint64_t n_queries,
+                             uint64_t min_length, uint64_t* break_offsets, gcsa2_break* breaks, uint64_t capacity,
+                             uint64_t* total_breaks, uint64_t* ranges, uint64_t* fallbacks);
 /* Diagnostic (not the timed path): the default kernel instrumented with shader-clock counters, same results.  d_prof[16],
  * zeroed by the caller: [0..7] cycles summed over the wavefronts for the phases of a round (loop head / pattern window, step
  * setup, first block fetch, first evaluation, second fetch + evaluation, outcome + statistics, parent() from the LCP chunks,

@@ -110,5 +110,55 @@ int main(int argc, char** argv)
               << index.sample(0) << " " << index.lastSample(0) << "\n";
     std::cout << "sv " << lcp.psv(r.first).first << " " << lcp.nsv(r.first).first << " " << lcp.rmq(r).first << " " << lcp[r.first] << "\n";
   }
+
+  // ---- engine additions of round 4: packed k-mers, break points, re-shaping the image ----------------------------------
+  // packed find(): the patterns of one length over ACGT, as 2-bit codes, must give what find() gives
+  const std::size_t klen = 6;
+  std::vector<std::uint8_t> flat;
+  std::vector<gcsa::range_type> want;
+  for(const std::string& p : patterns)
+  {
+    if(p.length() < klen || p.find_first_not_of("ACGT") != std::string::npos) { continue; }
+    flat.insert(flat.end(), p.begin(), p.begin() + klen);
+    want.push_back(index.find(p.substr(0, klen)));
+  }
+  std::vector<gcsa::range_type> packed = index.find_packed_batch(gcsa::GCSA::pack_kmers(flat.data(), want.size(), klen), klen);
+  std::cout << "packed " << want.size() << " " << (packed == want ? "same" : "DIFFERENT") << "\n";
+
+  // break points (left-maximal matches) of every pattern, all of them and those of at least 3 characters
+  std::vector<std::uint8_t> all;
+  std::vector<gcsa::size_type> offsets(1, 0);
+  for(const std::string& p : patterns) { all.insert(all.end(), p.begin(), p.end()); offsets.push_back(all.size()); }
+  for(gcsa::size_type min_length : {gcsa::size_type(0), gcsa::size_type(3)})
+  {
+    std::vector<gcsa::size_type> boff;
+    std::vector<gcsa2_break> breaks;
+    index.match_breaks_batch(all, offsets, min_length, boff, breaks);
+    std::cout << "breaks " << min_length << " " << breaks.size();
+    for(gcsa::size_type q = 0; q + 1 < boff.size(); q++)
+    {
+      std::cout << " |";
+      for(gcsa::size_type j = boff[q]; j < boff[q + 1]; j++) { std::cout << " " << breaks[j].position << ":" << breaks[j].length << ":" << breaks[j].sp << ":" << breaks[j].ep; }
+    }
+    std::cout << "\n";
+  }
+
+  // the memory ladder on a live image: every answer stays what it was
+  const gcsa::size_type full = index.deviceBytes();
+  bool same = true;
+  const int shapes[4][3] = { {-1, -1, 0}, {-1, 2, -1}, {0, 0, -1}, {1, 5, 1} };
+  for(const int* shape : shapes)
+  {
+    index.setTables(shape[0], shape[1], shape[2]);
+    for(std::size_t q = 0; q < patterns.size() && q < 30; q++)
+    {
+      gcsa::range_type r = index.find(patterns[q]);
+      std::vector<gcsa::node_type> occ;
+      if(!gcsa::Range::empty(r) && r.second < index.size()) { index.locate(r, occ); same = same && occ.size() == index.count(r); }
+      same = same && (packed.empty() || index.find_packed_batch(gcsa::GCSA::pack_kmers(flat.data(), 1, klen), klen)[0] == want[0]);
+    }
+  }
+  index.trim();
+  std::cout << "ladder " << (same ? "same" : "DIFFERENT") << " " << (index.deviceBytes() <= full ? "ok" : "grew") << " " << index.find(patterns[0]).first << "\n";
   return 0;
 }

@@ -91,6 +91,27 @@ def test_facade_matches_oracle(tmp_path):
         assert next(it) == f"LF {lf[0]} {lf[1]} {cpu.LF(r[0])}"
         assert next(it) == f"sample {int(cpu.sampled(r[0]))} {cpu.firstSample(r[0])} {cpu.sample(0)} {int(cpu.lastSample(0))}"
         assert next(it) == f"sv {cpu.psv(r[0])[0]} {cpu.nsv(r[0])[0]} {cpu.rmq(*r)[0]} {int(ix.lcp_data[r[0]])}"
+    # round 4's additions through the facade: packed k-mers, break points (against the oracle's dense statistics + find()), the ladder
+    from gcsa2_amd.hostview import concat_patterns
+    from test_gpu_parity import breaks_from_dense
+    packed = next(it).split()
+    assert packed[0] == "packed" and int(packed[1]) > 10 and packed[2] == "same"
+    data, off = concat_patterns(pats)
+    cm, cr, cf = cpu.match_stats_batch(data, off, threads=2)
+    want_off, want = breaks_from_dense(cpu, pats, cm, off)
+    for min_length in (0, 3):
+        keep = want[:, 1] >= min_length
+        line = next(it)
+        head, _, rest = line.partition(" |")
+        assert head.split() == ["breaks", str(min_length), str(int(keep.sum()))]
+        groups = [g.split() for g in (" |" + rest).split(" |")[1:]]
+        assert len(groups) == len(pats)
+        for q, g in enumerate(groups):
+            rows = want[int(want_off[q]):int(want_off[q + 1])]
+            rows = rows[rows[:, 1] >= min_length]
+            assert g == [":".join(str(int(x)) for x in r) for r in rows], (q, pats[q])
+    ladder = next(it).split()
+    assert ladder[:3] == ["ladder", "same", "ok"] and int(ladder[3]) == cpu.find(pats[0])[0]
 
 
 def _run_env():

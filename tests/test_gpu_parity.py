@@ -1253,6 +1253,17 @@ def test_sharded_match_stats_and_locate(engine):
     job, d_val, nval = comm.locate(gpu, d_r.data_ptr(), [ranges.shape[0]], d_loff.data_ptr(), 0, st)
     assert nval == int(lo[-1]) and np.array_equal(d_loff.cpu().numpy().view(np.uint64), lo)
     assert np.array_equal(engine.fetch_job(job, nval), lv)
+    assert comm.rccl_ranks() == 1
+    # a rank whose own part fails (here: an index without samples cannot locate) still goes through the collectives of the call --
+    # its total travels as a failure mark, it sends nothing afterwards -- and returns ITS error instead of leaving a peer waiting;
+    # the communicator stays usable
+    bare = engine.GCSA(ix, device=0, with_samples=False, with_counters=False)
+    with pytest.raises(engine.Gcsa2Error) as e:
+        comm.locate(bare, d_r.data_ptr(), [ranges.shape[0]], d_loff.data_ptr(), 0, st)
+    assert e.value.code == -5                        # GCSA2_ERR_MISSING_COMPONENT, from gcsa2_locate_device
+    job, d_val, nval = comm.locate(gpu, d_r.data_ptr(), [ranges.shape[0]], d_loff.data_ptr(), 0, st)
+    assert nval == int(lo[-1]) and np.array_equal(engine.fetch_job(job, nval), lv)
+    bare.close()
     comm.close()
 
 
