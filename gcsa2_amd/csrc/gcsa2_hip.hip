@@ -107,6 +107,7 @@ struct gcsa2_index
     u64 locate_split = (u64(1) << 31) - 1;   // GCSA2_LOCATE_SPLIT: most values (before deduplication) one pass of the locate pipeline handles
     u32 pipe_lanes = 12;               // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
+    bool pipe_wide = false;            // GCSA2_PIPE_WIRE=16: the packed-pattern pipeline brings the ranges home as u64 pairs (A/B)
     bool ms_pieces = true;             // GCSA2_MS_PIECES=0: large host batches of matching statistics go through one copy in, one launch, one copy out
     bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the device-wide radix sort, duplicates and all
     bool zero_copy = true;             // GCSA2_ZERO_COPY=0: small host-pointer calls copy through the arenas like large ones
@@ -676,6 +677,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.dedup_huge = (knob("GCSA2_DEDUP_HUGE", 1, 0, 1) != 0);
     ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 12, 1, 16));
     ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);
+    ix->tune.pipe_wide = (knob("GCSA2_PIPE_WIRE", 0, 0, 16) == 16);
     ix->tune.ms_pieces = (knob("GCSA2_MS_PIECES", 1, 0, 1) != 0);
     ix->tune.locate_trace = (knob("GCSA2_LOCATE_TRACE", 0, 0, 1) != 0);
     ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
@@ -1939,6 +1941,10 @@ int find_packed_pipelined(const gcsa2_index* ix, const uint64_t* codes, u64 leng
   std::vector<int> status(PIPE_LANES, GCSA2_OK);
   std::vector<std::string> messages(PIPE_LANES);
   const u64 out_at = (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8;      // where a set keeps its ranges (pipe_set_bytes)
+  // the ranges travel home as (sp, length) pairs in the narrowest exact form (comm.hpp): 8 bytes below 2^32 path nodes and
+  // edges, 10 below 2^40, else the 16 bytes of the u64 pairs; GCSA2_PIPE_WIRE=16 keeps the wide form (A/B)
+  const u64 top = (ix->img.n > ix->img.e ? ix->img.n : ix->img.e);
+  const u64 wire = (ix->tune.pipe_wide ? 16 : (top < (u64(1) << 32) ? 8 : (top < (u64(1) << 40) ? 10 : 16)));
   auto work = [&](unsigned t)
   {
     DeviceGuard guard(ix->device);
@@ -1949,7 +1955,22 @@ int find_packed_pipelined(const gcsa2_index* ix, const uint64_t* codes, u64 leng
       if(!set.busy) { return true; }
       hipError_t e = hipEventSynchronize(set.done);
       if(e != hipSuccess) { fail_lane("hipEventSynchronize", e); return false; }
-      if(!direct_out) { std::memcpy(ranges + 2 * set.first, set.h + out_at, set.count * 16); }
+      u64* dst = ranges + 2 * set.first;
+      if(wire == 10)                     // (sp, length) as five u16 (k_pack_ranges40): the ranges come home in 10 bytes instead of 16
+      {
+        const unsigned short* w = reinterpret_cast<const unsigned short*>(set.h);
+        for(u64 i = 0; i < set.count; i++, w += 5)
+        {
+          const u64 sp = u64(w[0]) | (u64(w[1]) << 16) | (u64(w[4] & 0xFF) << 32), len = u64(w[2]) | (u64(w[3]) << 16) | (u64(w[4] >> 8) << 32);
+          dst[2 * i] = sp; dst[2 * i + 1] = sp + len - 1;
+        }
+      }
+      else if(wire == 8)                 // (sp, length) as u32 pairs (k_pack_ranges32)
+      {
+        const u32* w = reinterpret_cast<const u32*>(set.h);
+        for(u64 i = 0; i < set.count; i++) { dst[2 * i] = w[2 * i]; dst[2 * i + 1] = u64(w[2 * i]) + u64(w[2 * i + 1]) - 1; }
+      }
+      else if(!direct_out) { std::memcpy(dst, set.h + out_at, set.count * 16); }
       set.busy = false;
       return true;
     };
@@ -1970,7 +1991,14 @@ int find_packed_pipelined(const gcsa2_index* ix, const uint64_t* codes, u64 leng
       u64* d_out = reinterpret_cast<u64*>(set.d + out_at);
       int rc_find = gcsa2_find_packed_device(ix, reinterpret_cast<const u64*>(set.d), length, count, d_out, lane.stream);
       if(rc_find != GCSA2_OK) { status[t] = rc_find; messages[t] = g_error; break; }
-      err = hipMemcpyAsync(direct_out ? reinterpret_cast<char*>(ranges + 2 * b) : set.h + out_at, d_out, count * 16, hipMemcpyDeviceToHost, lane.stream);
+      if(wire == 16) { err = hipMemcpyAsync(direct_out ? reinterpret_cast<char*>(ranges + 2 * b) : set.h + out_at, d_out, count * 16, hipMemcpyDeviceToHost, lane.stream); }
+      else
+      {
+        // the code words have been consumed: their place takes the narrow form of the ranges, which is what travels
+        int rc_pack = (wire == 10 ? gcsa2_pack_ranges40_device(d_out, count, set.d, lane.stream) : gcsa2_pack_ranges32_device(d_out, count, reinterpret_cast<uint32_t*>(set.d), lane.stream));
+        if(rc_pack != GCSA2_OK) { status[t] = rc_pack; messages[t] = g_error; break; }
+        err = hipMemcpyAsync(set.h, set.d, count * wire, hipMemcpyDeviceToHost, lane.stream);
+      }
       if(err == hipSuccess) { err = hipEventRecord(set.done, lane.stream); }
       if(err != hipSuccess) { fail_lane("hipMemcpyAsync / hipEventRecord", err); break; }
       set.busy = true; set.first = b; set.count = count;
