@@ -80,13 +80,34 @@ def main():
         gm, gr, gf = gpu.match_stats_batch(data, off)
         cm, cr, cf = cpu.match_stats_batch(data, off, threads=threads)
         assert np.array_equal(gm, cm) and np.array_equal(gr, cr) and np.array_equal(gf, cf), (seed, "match_stats")
-        for variant_env in ({"GCSA2_MATCH_STATS": "5", "GCSA2_MS_GRID": "3"}, {"GCSA2_MATCH_STATS": "1"}):
-            os.environ.update(variant_env)
-            vm, vr, vf = gpu.match_stats_batch(data, off)
-            for key in variant_env:
-                del os.environ[key]
-            assert np.array_equal(vm, cm) and np.array_equal(vr, cr) and np.array_equal(vf, cf), (seed, "match_stats", variant_env)
-        print(line + "  ok", flush=True)
+        # round 4: break points (all, and with a minimum length) against what the dense statistics + find() imply; k-mers as 2-bit
+        # codes; locate() into caller-owned buffers; all of it again on a re-shaped image (tables dropped / resized at random)
+        import torch
+        from test_gpu_parity import breaks_from_dense
+        from gcsa2_amd.hostview import pack_kmers
+        want_off, want_brk = breaks_from_dense(cpu, rows, cm, off)
+        fixed = [r for r in rows if len(r) == m and all(c in b"ACGT" for c in r)]
+        fixed_arr = np.frombuffer(b"".join(fixed), dtype=np.uint8).reshape(len(fixed), m) if fixed else None
+        dev = torch.device("cuda", 0)
+        for shape in (None, (int(mutate.integers(0, 2)), int(mutate.integers(0, 9)), int(mutate.integers(0, 2)))):
+            if shape is not None:
+                gpu.set_tables(pair_blocks=shape[0], kmer_k=shape[1], locate_table=shape[2])
+                assert np.array_equal(gpu.find_batch(data, off), c_find), (seed, "find", shape)
+            for min_length in (0, 1 + int(mutate.integers(0, 2 * K))):
+                boff, brk, brng, bfb = gpu.match_breaks_batch(data, off, min_length=min_length)
+                keep = want_brk[:, 1] >= min_length
+                assert np.array_equal(brk, want_brk[keep]), (seed, "match_breaks", shape, min_length)
+                assert int(boff[-1]) == int(keep.sum()) and np.array_equal(brng, cr) and np.array_equal(bfb, cf), (seed, "match_breaks tail", shape)
+            if fixed_arr is not None:
+                fd, fo = concat_patterns(fixed)
+                assert np.array_equal(gpu.find_batch_packed(pack_kmers(fixed_arr, ix.char2comp), m), cpu.find_batch(fd, fo, threads=threads)), (seed, "packed", shape)
+            co, cv = cpu.locate_batch(wide)
+            d_r = torch.from_numpy(wide.view(np.int64).copy()).to(dev)
+            d_o = torch.zeros(len(wide) + 1, dtype=torch.int64, device=dev)
+            d_v = torch.zeros(len(cv) + 1, dtype=torch.int64, device=dev)
+            total = gpu.locate_into(d_r.data_ptr(), len(wide), d_o.data_ptr(), d_v.data_ptr(), d_v.shape[0])
+            assert total == len(cv) and np.array_equal(d_o.cpu().numpy().view(np.uint64), co) and np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], cv), (seed, "locate_into", shape)
+        print(line + f"  breaks={len(want_brk)} packed={len(fixed)}  ok", flush=True)
         gpu.close()
     print(f"campaign of {args.seeds} graphs: no difference ({time.time() - t_start:.0f} s)")
 
