@@ -111,6 +111,7 @@ struct gcsa2_index
     bool ms_pieces = true;             // GCSA2_MS_PIECES=0: large host batches of matching statistics go through one copy in, one launch, one copy out
     bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the device-wide radix sort, duplicates and all
     bool zero_copy = true;             // GCSA2_ZERO_COPY=0: small host-pointer calls copy through the arenas like large ones
+    bool poll_small = true;            // GCSA2_POLL_SMALL=0: zero-copy calls end with hipStreamSynchronize instead of a polled ticket
     u32 seed_wide = (u32(1) << 24) - 1;   // GCSA2_SEED_WIDE: seed-table entries of this many path nodes or more are marked, not stored (tests)
     bool locate_trace = false;         // GCSA2_LOCATE_TRACE=1: host-clock stamps of a locate pass on stderr (profiles/r04_locate.md)
     u64 budget_bytes = 0;              // GCSA2_MEMORY_BUDGET_MB: most device memory the image may take (0: what the device has free)
@@ -422,7 +423,7 @@ public:
       if(s == nullptr) { return hipErrorOutOfMemory; }
       hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
       if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&s->h), PINNED_ARENA, hipHostMallocDefault); }
-      if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&s->z), ZERO_COPY_ARENA, hipHostMallocMapped | hipHostMallocCoherent); }
+      if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&s->z), ZERO_COPY_ARENA + 64, hipHostMallocMapped | hipHostMallocCoherent); }
       if(e != hipSuccess)
       {
         if(s->stream) { (void)hipStreamDestroy(s->stream); } if(s->h) { (void)hipHostFree(s->h); }
@@ -470,10 +471,31 @@ public:
     pending.push_back(Pending{h, slot, bytes});
     return hipMemcpyAsync(slot, d, bytes, hipMemcpyDeviceToHost, s->stream);
   }
-  // wait for everything enqueued on the call's stream and hand the staged results to the caller
+  // wait for everything enqueued on the call's stream and hand the staged results to the caller.  A zero-copy call (the
+  // facade's scalar find() / LF() / count() / parent()) waits for a ticket that a one-thread kernel behind its work writes
+  // into the page-locked arena, instead of for hipStreamSynchronize: 8 against 13 us on this path (tests/perf/launch_latency.hip)
   hipError_t finish()
   {
-    hipError_t e = hipStreamSynchronize(s->stream);
+    hipError_t e = hipSuccess;
+    if(zero && ix->tune.poll_small)
+    {
+      volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(s->z + ZERO_COPY_ARENA);
+      const unsigned long long ticket = ix->next_ticket.fetch_add(1);
+      hipLaunchKernelGGL(k_ticket, dim3(1), dim3(1), 0, s->stream, flag, ticket);
+      e = hipGetLastError();
+      for(u64 spins = 1; e == hipSuccess && *flag != ticket; spins++)
+      {
+        if((spins & 0x3FFF) == 0)
+        {
+          const hipError_t q = hipStreamQuery(s->stream);
+          if(q == hipSuccess) { break; }                        // idle: the ticket is there (or the launch was lost: checked below)
+          if(q != hipErrorNotReady) { e = q; }
+        }
+      }
+      if(e == hipSuccess && *flag != ticket) { e = hipStreamSynchronize(s->stream); }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    else { e = hipStreamSynchronize(s->stream); }
     if(e == hipSuccess) { for(const Pending& p : pending) { std::memcpy(p.user, p.slot, p.bytes); } }
     pending.clear(); busy = false;
     return e;
@@ -674,6 +696,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.sort_medium_limit = (knob("GCSA2_SORT_MEDIUM", 1, 0, 1) == 0 ? SMALL_SEGMENT : MEDIUM_SEGMENT);
     ix->tune.locate_split = u64(knob("GCSA2_LOCATE_SPLIT", (long(1) << 31) - 1, 2, (long(1) << 31) - 1));
     ix->tune.zero_copy = (knob("GCSA2_ZERO_COPY", 1, 0, 1) != 0);
+    ix->tune.poll_small = (knob("GCSA2_POLL_SMALL", 1, 0, 1) != 0);
     ix->tune.dedup_huge = (knob("GCSA2_DEDUP_HUGE", 1, 0, 1) != 0);
     ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 12, 1, 16));
     ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);

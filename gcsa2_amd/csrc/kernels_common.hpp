@@ -63,4 +63,11 @@ __device__ __forceinline__ DevBV bwt_of(const DevImage& img, u32 comp)
 }
 
 
+// completion ticket of a small host-pointer call: written behind the call's kernels into page-locked memory the host polls
+__global__ void k_ticket(volatile unsigned long long* flag, unsigned long long ticket)
+{
+  __threadfence_system();
+  *flag = ticket;
+}
+
 }  // namespace
