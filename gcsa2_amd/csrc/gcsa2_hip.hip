@@ -485,6 +485,7 @@ public:
       e = hipGetLastError();
       for(u64 spins = 1; e == hipSuccess && *flag != ticket; spins++)
       {
+        if(spins > 100000) { std::this_thread::yield(); }
         if((spins & 0x3FFF) == 0)
         {
           const hipError_t q = hipStreamQuery(s->stream);
@@ -1319,6 +1320,7 @@ int read_totals(const gcsa2_index* ix, unsigned slot, unsigned long long (&total
   LAUNCH_CHECK("k_publish_totals");
   for(u64 spins = 1; h[TOTAL_WORDS - 1] != ticket; spins++)
   {
+    if(spins > 20000) { std::this_thread::yield(); }          // a long pass (tens of milliseconds of sorting): leave the core to others
     if((spins & 0xFFF) == 0)
     {
       const hipError_t q = hipStreamQuery(stream);
