@@ -374,6 +374,69 @@ def test_pangenome_index_beyond_32_bits():
     got = d_nodes.cpu().numpy().view(np.uint64)
     for col, name in enumerate(("sp", "ep", "left_lcp", "right_lcp", "node_lcp")):
         assert np.array_equal(got[:, col], want[name]), name
+    # round 4 at this size.  (i) Break points: one record (0, 256, r, r) per unmodified pattern, in closed form; on the sample,
+    # exactly what the oracle's dense statistics and find() imply (positions p with p == 0 or ms[p - 1] != ms[p] + 1, ranges
+    # beyond 2^32); with a minimum length the same records without the shorter ones.
+    from test_gpu_parity import breaks_from_dense
+    d_boff = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
+    cap = 40 * nq
+    d_brk = torch.zeros((cap, 4), dtype=torch.int64, device=dev)
+    d_rng2 = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    d_fb2 = torch.zeros(nq, dtype=torch.int64, device=dev)
+    n_brk = gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, nq * m, d_boff.data_ptr(), d_brk.data_ptr(), cap, d_rng2.data_ptr(), d_fb2.data_ptr(), st)
+    assert torch.equal(d_rng2, d_rng) and torch.equal(d_fb2, d_fb) and int(d_boff[-1].item()) == n_brk
+    counts = d_boff[1:] - d_boff[:-1]
+    first = d_brk[d_boff[:-1][0::2]]
+    assert bool((counts[0::2] == 1).all()) and bool((first[:, 0] == 0).all()) and bool((first[:, 1] == m).all())
+    assert torch.equal(first[:, 2], exp[0::2]) and torch.equal(first[:, 3], exp[0::2])
+    sample_pats = [bytes(flat[q * m:(q + 1) * m]) for q in range(ns)]
+    want_off, want_brk = breaks_from_dense(cpu, sample_pats, cm, off)
+    assert np.array_equal(d_boff[: ns + 1].cpu().numpy().view(np.uint64), want_off)
+    assert np.array_equal(d_brk[: int(want_off[-1])].cpu().numpy().view(np.uint64), want_brk)
+    assert int(want_brk[:, 2].max()) > (1 << 32) and want_brk.shape[0] > 10 * ns
+    n_mem = gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, nq * m, d_boff.data_ptr(), d_brk.data_ptr(), cap, 0, 0, st, min_length=20)
+    assert n_mem < n_brk // 3
+    keep = want_brk[:, 1] >= 20
+    n_keep = int(d_boff[ns].item())
+    assert n_keep == int(keep.sum()) and np.array_equal(d_brk[:n_keep].cpu().numpy().view(np.uint64), want_brk[keep])
+    del d_brk, d_boff, d_rng2, d_fb2, d_ms
+    torch.cuda.empty_cache()
+    # (ii) k-mer batches as 2-bit codes: the 20 M 32-mers of config 4 again, every range in closed form
+    nq4 = 20_000_000
+    pats4, _, _, _, exp4 = batch(nq4, 32, 0x6C5A0041)
+    lut = torch.zeros(256, dtype=torch.int64, device=dev)
+    for ch, c in zip(b"ACGT", range(4)):
+        lut[ch] = c
+    comps = lut[pats4.to(torch.int64)]
+    code = torch.zeros(nq4, dtype=torch.int64, device=dev)
+    for t in range(32):
+        code |= comps[:, 31 - t] << (2 * t)
+    del comps
+    d_out4 = torch.zeros((nq4, 2), dtype=torch.int64, device=dev)
+    gpu.find_packed_device(code.data_ptr(), 32, nq4, d_out4.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out4[:, 0], exp4) and torch.equal(d_out4[:, 1], exp4)
+    host_ranges = gpu.find_batch_packed(code[:3_000_000].cpu().numpy().view(np.uint64).reshape(-1, 1), 32)        # the chunked host pipeline, 40-bit wire
+    assert np.array_equal(host_ranges, d_out4[:3_000_000].cpu().numpy().view(np.uint64))
+    # (iii) the marked (wide) seed entries, reference semantics include/gcsa/gcsa.h:96-110: with the seed table cut to k = 4 every
+    # entry covers n / 256 = 22 M path nodes, more than the 2^24 - 1 the length field holds, so every pattern is searched from
+    # scratch -- and still lands on its closed form; then back to the full table
+    k_full = gpu.kmer_table_k()
+    gpu.set_tables(kmer_k=4)
+    d_flat4 = torch.zeros(nq4 * 32 + 8, dtype=torch.uint8, device=dev)
+    d_flat4[: nq4 * 32] = pats4.reshape(-1)
+    d_off4 = torch.arange(nq4 + 1, dtype=torch.int64, device=dev) * 32
+    d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
+    d_out4.zero_()
+    nw = 2_000_000
+    gpu.find_stats_device(d_flat4.data_ptr(), d_off4.data_ptr(), nw, d_out4.data_ptr(), d_stats.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert int(d_stats[6].item()) == nw and int(d_stats[1].item()) == 31 * nw            # every seed entry wide: 31 LF steps per query
+    assert torch.equal(d_out4[:nw, 0], exp4[:nw]) and torch.equal(d_out4[:nw, 1], exp4[:nw])
+    gpu.set_tables(kmer_k=k_full)
+    gpu.find_device(d_flat4.data_ptr(), d_off4.data_ptr(), nw, d_out4.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert gpu.kmer_table_k() == k_full and torch.equal(d_out4[:nw, 0], exp4[:nw])
 
 
 def test_branching_footprint_index_closed_form():
