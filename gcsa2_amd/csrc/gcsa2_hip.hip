@@ -1333,7 +1333,7 @@ int read_totals(const gcsa2_index* ix, unsigned slot, unsigned long long (&total
   return GCSA2_OK;
 }
 
-// One pass of the locate pipeline.  The library scans inside count in `int`, so a pass takes fewer than 2^31 values before
+// One pass of the locate pipeline.  The flag words' prefix sums are 32-bit, so a pass takes fewer than 2^31 values before
 // deduplication; a larger batch returns LOCATE_NEEDS_SPLIT (allow_split) with the exclusive scan of the per-query raw counts
 // left in d_offsets, and locate_core below cuts it.
 // known_out / known_capacity: the caller's own value buffer (gcsa2_locate_into).  The pass then never waits for the number of
@@ -1370,11 +1370,11 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
 
   // exclusive scans over nq + 1 entries: entry nq becomes the total
   size_t tmp_bytes = 0;
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, node_counts, node_off, int(nq + 1), stream));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, node_counts, node_off, size_t(nq + 1), stream));
   char* tmp = nullptr;
   HIP_TRY(scratch.get(tmp, tmp_bytes));
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, node_counts, node_off, int(nq + 1), stream));
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, raw_counts, raw_off, int(nq + 1), stream));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, node_counts, node_off, size_t(nq + 1), stream));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, raw_counts, raw_off, size_t(nq + 1), stream));
   // segments with more than one raw value: the only ones removeDuplicates has to touch
   const u32 medium_limit = ix->tune.sort_medium_limit;
   // with the duplicate filter every segment beyond the medium class goes through it first (listed as huge), without it only
@@ -1505,10 +1505,10 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     HIP_TRY(scratch.get(over_off, over + 1)); HIP_TRY(scratch.get(over_len, over + 1));
     hipLaunchKernelGGL(k_over_lengths, dim3(grid_for(over + 1)), dim3(TPB), 0, stream, over_begin, over_end, over, over_len);
     size_t scan_bytes = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, over_len, over_off, int(over + 1), stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, over_len, over_off, size_t(over + 1), stream));
     char* scan_tmp = nullptr;
     HIP_TRY(scratch.get(scan_tmp, scan_bytes));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, over_len, over_off, int(over + 1), stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, over_len, over_off, size_t(over + 1), stream));
     if(value_bits + rank_bits <= 64)
     {
       u64 *keys_a = nullptr, *keys_b = nullptr;
@@ -1542,10 +1542,10 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   hipLaunchKernelGGL(k_word_counts, dim3(grid_for(nwords + 1)), dim3(TPB), 0, stream, words, nwords, word_counts);
   LAUNCH_CHECK("k_mark_changes / k_mark_starts / k_word_counts");
   size_t scan_bytes = 0;
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, word_counts, word_before, int(nwords + 1), stream));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, word_counts, word_before, size_t(nwords + 1), stream));
   char* scan_tmp = nullptr;
   HIP_TRY(scratch.get(scan_tmp, scan_bytes));
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, word_counts, word_before, int(nwords + 1), stream));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, word_counts, word_before, size_t(nwords + 1), stream));
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, word_before + nwords, d_totals + T_UNIQUE);
   LAUNCH_CHECK("k_publish");
   u64 total_unique = 0;
@@ -3202,10 +3202,10 @@ int gcsa2_match_breaks_device(const gcsa2_index* ix, const uint8_t* d_patterns, 
   const double t_launched = since();
   hipLaunchKernelGGL(k_widen_counts, dim3(grid_for(nq + 1)), dim3(TPB), 0, st, sink.counts, nq, wide);
   size_t scan_bytes = 0;
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, wide, d_break_offsets, int(nq + 1), st));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, wide, d_break_offsets, size_t(nq + 1), st));
   char* scan_tmp = nullptr;
   HIP_TRY(scratch.get(scan_tmp, scan_bytes));
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, wide, d_break_offsets, int(nq + 1), st));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, wide, d_break_offsets, size_t(nq + 1), st));
   hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, st, d_break_offsets + nq, reinterpret_cast<u64*>(d_totals + 1));
   unsigned long long totals[TOTAL_WORDS];
   rc = read_totals(ix, slot, totals, st);
