@@ -105,6 +105,7 @@ struct gcsa2_index
     u64 ms_grid = 0;                   // GCSA2_MS_GRID: ... most workgroups launched (0: what the device holds at once)
     u32 sort_medium_limit = 0;         // GCSA2_SORT_MEDIUM=0 sends the 17..1024-value locate segments to the segmented radix sort
     u64 locate_split = (u64(1) << 31) - 1;   // GCSA2_LOCATE_SPLIT: most values (before deduplication) one pass of the locate pipeline handles
+    u64 locate_split_queries = u64(1) << 30; // GCSA2_LOCATE_SPLIT_QUERIES: most ranges one pass handles (its lists and grids are 32-bit)
     u32 pipe_lanes = 12;               // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
     bool pipe_wide = false;            // GCSA2_PIPE_WIRE=16: the packed-pattern pipeline brings the ranges home as u64 pairs (A/B)
@@ -696,6 +697,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.ms_grid = u64(knob("GCSA2_MS_GRID", 0, 0, long(1) << 30));
     ix->tune.sort_medium_limit = (knob("GCSA2_SORT_MEDIUM", 1, 0, 1) == 0 ? SMALL_SEGMENT : MEDIUM_SEGMENT);
     ix->tune.locate_split = u64(knob("GCSA2_LOCATE_SPLIT", (long(1) << 31) - 1, 2, (long(1) << 31) - 1));
+    ix->tune.locate_split_queries = u64(knob("GCSA2_LOCATE_SPLIT_QUERIES", long(1) << 30, 1, long(1) << 30));
     ix->tune.zero_copy = (knob("GCSA2_ZERO_COPY", 1, 0, 1) != 0);
     ix->tune.poll_small = (knob("GCSA2_POLL_SMALL", 1, 0, 1) != 0);
     ix->tune.dedup_huge = (knob("GCSA2_DEDUP_HUGE", 1, 0, 1) != 0);
@@ -1390,7 +1392,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   scratch.settled = true;            // the totals have arrived: nothing of this pass is in flight (until the next launch)
   const u64 total_nodes = totals[T_NODES], total_raw = totals[T_RAW], multi = totals[T_MULTI], huge_a = totals[T_HUGE_A], huge_b = totals[T_HUGE_B];
   const u64 large = totals[T_LARGE], medium = totals[T_MEDIUM];
-  if(total_raw > ix->tune.locate_split)
+  if(total_raw > ix->tune.locate_split || nq > ix->tune.locate_split_queries)
   {
     if(allow_split) { return LOCATE_NEEDS_SPLIT; }
     return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate: one range alone has 2^31 or more values before deduplication");
@@ -1589,10 +1591,10 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   return GCSA2_OK;
 }
 
-// largest q1 in (q0, nq] with raw_off[q1] - raw_off[q0] <= limit (q0 if even the first query exceeds it); one thread
-__global__ void k_locate_cut(const u64* __restrict__ raw_off, u64 nq, u64 q0, u64 limit, unsigned long long* __restrict__ out)
+// largest q1 in (q0, min(nq, q0 + most)] with raw_off[q1] - raw_off[q0] <= limit (q0 if even the first query exceeds it); one thread
+__global__ void k_locate_cut(const u64* __restrict__ raw_off, u64 nq, u64 q0, u64 limit, u64 most, unsigned long long* __restrict__ out)
 {
-  u64 lo = q0, hi = nq;
+  u64 lo = q0, hi = (nq - q0 > most ? q0 + most : nq);
   const u64 base = raw_off[q0];
   while(lo < hi)
   {
@@ -1614,7 +1616,7 @@ __global__ __launch_bounds__(TPB) void k_shift_offsets(const u64* __restrict__ s
   if(i < count) { dst[i] = src[i] + base; }
 }
 
-// The locate pipeline for batches of any size: one pass when the batch has fewer than 2^31 values before deduplication (the
+// The locate pipeline for batches of any size: one pass when the batch has at most 2^30 ranges and fewer than 2^31 values before deduplication (the
 // paper's 16-mer batch has 2.5 G, paper.tex:403), otherwise consecutive sub-batches of queries, each below that, whose value
 // arrays are concatenated and whose offsets are shifted -- the same CSR a single pass would give.
 int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u64* d_offsets,
@@ -1630,7 +1632,7 @@ int locate_core(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u6
   while(q0 < nq)                                   // d_offsets still holds the scan of the raw counts
   {
     unsigned long long q1 = 0;
-    hipLaunchKernelGGL(k_locate_cut, dim3(1), dim3(1), 0, stream, d_offsets, nq, q0, ix->tune.locate_split, d_cut);
+    hipLaunchKernelGGL(k_locate_cut, dim3(1), dim3(1), 0, stream, d_offsets, nq, q0, ix->tune.locate_split, ix->tune.locate_split_queries, d_cut);
     HIP_TRY(hipMemcpyAsync(&q1, d_cut, sizeof(q1), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if(q1 <= q0) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate: one range alone has 2^31 or more values before deduplication"); }
@@ -1677,7 +1679,7 @@ int locate_checks(const gcsa2_index* ix, u64 nq)
   {
     return fail(GCSA2_ERR_MISSING_COMPONENT, "locate needs samples and counters (extra_pointers sizes the output)");
   }
-  if(nq >= (u64(1) << 31) - 1) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate batch of >= 2^31 queries; split the batch"); }
+  if(nq >= (u64(1) << 38)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "locate batch of >= 2^38 ranges; split the batch"); }      // (batches beyond 2^30 ranges run in sub-batches: locate_core)
   return GCSA2_OK;
 }
 

@@ -1294,6 +1294,21 @@ def test_locate_splits_large_batches(case, engine, monkeypatch):
     torch.cuda.synchronize()
     assert np.array_equal(d_off.cpu().numpy().view(np.uint64), want_o) and np.array_equal(d_val[: int(want_o[-1])].cpu().numpy().view(np.uint64), want_v)
     small.close()
+    # the same cutting by the NUMBER of ranges (a pass handles at most 2^30; GCSA2_LOCATE_SPLIT_QUERIES lowers that here): empty
+    # ranges included, so that a sub-batch can be all empty
+    monkeypatch.delenv("GCSA2_LOCATE_SPLIT")
+    monkeypatch.setenv("GCSA2_LOCATE_SPLIT_QUERIES", "37")
+    padded = np.concatenate([ranges[:50], np.array([(5, 4)] * 90, dtype=np.uint64), ranges[50:]])
+    want_po, want_pv = cpu.locate_batch(padded)
+    few, _ = engine.open_index(ix, device=0)
+    go, gv = few.locate_batch(padded)
+    assert np.array_equal(go, want_po) and np.array_equal(gv, want_pv), name
+    d_r = torch.from_numpy(padded.view(np.int64).copy()).to(dev)
+    d_off = torch.zeros(padded.shape[0] + 1, dtype=torch.int64, device=dev)
+    assert few.locate_into(d_r.data_ptr(), padded.shape[0], d_off.data_ptr(), d_val.data_ptr(), d_val.shape[0], 0) == int(want_po[-1])
+    assert np.array_equal(d_off.cpu().numpy().view(np.uint64), want_po) and np.array_equal(d_val[: int(want_po[-1])].cpu().numpy().view(np.uint64), want_pv)
+    few.close()
+    monkeypatch.delenv("GCSA2_LOCATE_SPLIT_QUERIES")
     if widest > 3:
         monkeypatch.setenv("GCSA2_LOCATE_SPLIT", "2")
         tiny, _ = engine.open_index(ix, device=0)
