@@ -106,6 +106,7 @@ struct gcsa2_index
     u32 sort_medium_limit = 0;         // GCSA2_SORT_MEDIUM=0 sends the 17..1024-value locate segments to the segmented radix sort
     u64 locate_split = (u64(1) << 31) - 1;   // GCSA2_LOCATE_SPLIT: most values (before deduplication) one pass of the locate pipeline handles
     u64 locate_split_queries = u64(1) << 30; // GCSA2_LOCATE_SPLIT_QUERIES: most ranges one pass handles (its lists and grids are 32-bit)
+    u64 pipe_chunk = u64(1) << 17;     // GCSA2_PIPE_CHUNK (log2): patterns per chunk of the host pipeline
     u32 pipe_lanes = 12;               // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
     bool pipe_wide = false;            // GCSA2_PIPE_WIRE=16: the packed-pattern pipeline brings the ranges home as u64 pairs (A/B)
@@ -702,6 +703,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.poll_small = (knob("GCSA2_POLL_SMALL", 1, 0, 1) != 0);
     ix->tune.dedup_huge = (knob("GCSA2_DEDUP_HUGE", 1, 0, 1) != 0);
     ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 12, 1, 16));
+    ix->tune.pipe_chunk = u64(1) << knob("GCSA2_PIPE_CHUNK", 17, 15, 20);
     ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);
     ix->tune.pipe_wide = (knob("GCSA2_PIPE_WIRE", 0, 0, 16) == 16);
     ix->tune.ms_pieces = (knob("GCSA2_MS_PIECES", 1, 0, 1) != 0);
@@ -1773,11 +1775,11 @@ namespace {
 // a set's results are copied to the caller's array when its event has fired.  Both PCIe directions, the kernel and the host
 // copies overlap; what bounds the batch is the host's memcpy rate (56 bytes per 32-mer query through pinned memory).
 // (lanes: tune.pipe_lanes, GCSA2_PIPE_LANES, 1..16, default 12)
-constexpr u64 PIPE_CHUNK_QUERIES = u64(1) << 17, PIPE_CHUNK_BYTES = u64(8) << 20;     // per chunk: at most this many patterns and pattern bytes
+constexpr u64 PIPE_CHUNK_BYTES = u64(8) << 20;     // per chunk: at most this many pattern bytes, and tune.pipe_chunk patterns (GCSA2_PIPE_CHUNK = log2, 15..20, default 17)
 constexpr u64 PIPE_MIN_QUERIES = u64(1) << 19;                                       // smaller batches take the single-copy path
 constexpr int PIPE_PATTERN_TOO_LONG = 1;                                             // internal: not a gcsa2_status
 
-inline u64 pipe_set_bytes() { return (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8 + PIPE_CHUNK_QUERIES * 16; }      // patterns (+ 32 bytes of phase, + slack) | offsets | ranges
+inline u64 pipe_set_bytes(u64 PIPE_CHUNK_QUERIES) { return (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8 + PIPE_CHUNK_QUERIES * 16; }      // patterns (+ 32 bytes of phase, + slack) | offsets | ranges
 
 int pipe_prepare(const gcsa2_index* ix)
 {
@@ -1791,8 +1793,8 @@ int pipe_prepare(const gcsa2_index* ix)
     if(e == hipSuccess) { e = hipStreamCreateWithFlags(&lane.down, hipStreamNonBlocking); }
     for(gcsa2_index::PipeSet& set : lane.set)
     {
-      if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&set.h), pipe_set_bytes(), hipHostMallocDefault); }
-      if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&set.d), pipe_set_bytes()); }
+      if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&set.h), pipe_set_bytes(ix->tune.pipe_chunk), hipHostMallocDefault); }
+      if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&set.d), pipe_set_bytes(ix->tune.pipe_chunk)); }
       if(e == hipSuccess) { e = hipEventCreateWithFlags(&set.done, hipEventDisableTiming); }
       if(e == hipSuccess) { e = hipEventCreateWithFlags(&set.computed, hipEventDisableTiming); }
     }
@@ -1818,6 +1820,7 @@ int pipe_prepare(const gcsa2_index* ix)
 int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t* ranges)
 {
   std::lock_guard<std::mutex> hold(ix->pipe_lock);
+  const u64 PIPE_CHUNK_QUERIES = ix->tune.pipe_chunk;
   int rc = pipe_prepare(ix);
   if(rc != GCSA2_OK) { return rc; }
   // chunk boundaries: at most PIPE_CHUNK_QUERIES patterns and PIPE_CHUNK_BYTES pattern bytes each.  The offsets are validated
@@ -1947,6 +1950,7 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
 int find_packed_pipelined(const gcsa2_index* ix, const uint64_t* codes, u64 length, uint64_t nq, uint64_t* ranges)
 {
   std::lock_guard<std::mutex> hold(ix->pipe_lock);
+  const u64 PIPE_CHUNK_QUERIES = ix->tune.pipe_chunk;
   int rc = pipe_prepare(ix);
   if(rc != GCSA2_OK) { return rc; }
   const u64 words = (length + 31) >> 5;
