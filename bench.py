@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the request-rate ceiling, the device telemetry and the host-batch leg "
                                                                "(profiler passes: only the timed kernel and its instrumented twin run)")
     ap.add_argument("--secondary", choices=["all", "config5", "wide", "ladder", "chr22", "repeats", "repeats30", "human32", "human_snp"], default="all", help="N = 1: which secondary measurements to run")
+    ap.add_argument("--pipeline-sweep", default="", help="diagnostic: lanes:chunk_log2[,...] -- the host-batch leg repeated per shape of the host pipeline (gcsa2_index_set_pipeline)")
     ap.add_argument("--locate-ranges", type=int, default=0, help="ranges of the locate() leg (default: 400 k on the repeat-rich indexes, every range on chr22)")
     ap.add_argument("--locate", action="store_true", help="chr22 / repeats / repeats30: run the locate() leg even with --no-extras (profiler passes)")
     ap.add_argument("--variant", type=int, default=2, help="find launch shape (2 = one lane per query in batch order, 4 = queries ordered by length first)")
@@ -706,7 +707,26 @@ def measure(args, D, dev, wl, steps, warmup):
     return result
 
 
-def host_batch_rate(wl, d_out, nq=10_000_000):
+def timed_calls(call, warm=3, warm_seconds=0.5, timed=6):
+    """Best wall-clock time of `timed` calls after at least `warm` untimed ones and `warm_seconds` of them.  The host legs need
+    the warm-up: after a pause the first calls of a 10 M-pattern batch run 30-40 % below the steady state on these boxes (same
+    shape of the pipeline, same arrays, same process: profiles/r04_host.md), and a caller that streams batches sees the steady
+    state."""
+    t_end = time.perf_counter() + warm_seconds
+    done = 0
+    while done < warm or time.perf_counter() < t_end:
+        call()
+        done += 1
+    best = None
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        call()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def host_batch_rate(wl, d_out, nq=10_000_000, sweep=None, default_shape=(6, 18)):
     """The PCIe-inclusive rate (never `value`): the first `nq` patterns of the batch in host memory through gcsa2_find_batch
     -- chunked and double-buffered on several streams (csrc: find_pipelined) -- results back in host memory; checked against
     the device-resident run.  Twice: from pageable memory (the lanes copy through their pinned staging sets) and from
@@ -718,19 +738,14 @@ def host_batch_rate(wl, d_out, nq=10_000_000):
 
     def run(flat, offsets, got):
         wl.gpu.find_batch(flat[: 1_000_000 * m], offsets[:1_000_001])         # first call: the pipeline's pinned and device buffers
-        best = None
         got[:] = 1                                                             # touched: no page faults inside the timed calls
-        for _ in range(3):
-            t0 = time.perf_counter()
-            wl.gpu.find_batch(flat, offsets, out=got)
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
+        best = timed_calls(lambda: wl.gpu.find_batch(flat, offsets, out=got))
         return best, bool(np.array_equal(got, want))
 
     flat = wl.d_pat[: nq * m].cpu().numpy().copy()
     offsets = np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)
     best, same = run(flat, offsets, np.zeros((nq, 2), dtype=np.uint64))
-    out = {"workload": f"{nq} x {m}-mers in pageable host memory -> gcsa2_find_batch -> ranges in host memory (best of 3)",
+    out = {"workload": f"{nq} x {m}-mers in pageable host memory -> gcsa2_find_batch -> ranges in host memory (best of 6 after half a second of untimed calls)",
            "value": nq / best, "unit": "queries/s", "ms": best * 1e3, "bytes_per_query_over_pcie": m + 8 + 16,
            "GB_per_s_end_to_end": nq * (m + 24) / best / 1e9, "equals_device_resident_run": same}
     try:
@@ -760,27 +775,40 @@ def host_batch_rate(wl, d_out, nq=10_000_000):
             del comps, code
             got = np.ones((nq, 2), dtype=np.uint64)
             wl.gpu.find_batch_packed(codes[:1_000_000], m)
-            best = None
-            for _ in range(3):
-                t0 = time.perf_counter()
-                wl.gpu.find_batch_packed(codes, m, out=got)
-                dt = time.perf_counter() - t0
-                best = dt if best is None else min(best, dt)
+            best = timed_calls(lambda: wl.gpu.find_batch_packed(codes, m, out=got))
             out["packed"] = {"workload": f"the same {nq} x {m}-mers as 2-bit codes (8 bytes each) in pageable host memory -> gcsa2_find_batch_packed "
-                                         "-> ranges in host memory (best of 3; packing not timed: the caller's)",
+                                         "-> ranges in host memory (best of 6 after half a second of untimed calls; packing not timed: the caller's)",
                              "value": nq / best, "unit": "queries/s", "ms": best * 1e3, "bytes_per_query_over_pcie": 8 + 16,
                              "GB_per_s_end_to_end": nq * 24 / best / 1e9, "equals_device_resident_run": bool(np.array_equal(got, want))}
             p_codes = torch.empty((nq, 1), dtype=torch.int64).pin_memory()
             p_got = torch.empty((nq, 2), dtype=torch.int64).pin_memory()
             p_codes.numpy().view(np.uint64)[:] = codes
-            best = None
-            for _ in range(3):
-                t0 = time.perf_counter()
-                wl.gpu.find_batch_packed(p_codes.numpy().view(np.uint64), m, out=p_got.numpy().view(np.uint64))
-                dt = time.perf_counter() - t0
-                best = dt if best is None else min(best, dt)
+            best = timed_calls(lambda: wl.gpu.find_batch_packed(p_codes.numpy().view(np.uint64), m, out=p_got.numpy().view(np.uint64)))
             out["packed"]["page_locked"] = {"value": nq / best, "unit": "queries/s", "ms": best * 1e3,
                                             "equals_device_resident_run": bool(np.array_equal(p_got.numpy().view(np.uint64), want))}
+            if sweep:                    # diagnostic (--pipeline-sweep): the pipeline's shape on this host, one live image
+                rows = []
+                for lanes, chunk, *rest in sweep:
+                    blocking = rest[0] if rest else 0
+                    if lanes >= 0:                  # -1: the shape and the buffers stay as they are
+                        wl.gpu.set_pipeline(lanes, chunk, blocking)
+                    row = {"lanes": lanes, "chunk_log2": chunk, "blocking": blocking}
+                    for name, call in (("packed", lambda: wl.gpu.find_batch_packed(codes, m, out=got)),
+                                       ("packed_page_locked", lambda: wl.gpu.find_batch_packed(p_codes.numpy().view(np.uint64), m, out=p_got.numpy().view(np.uint64))),
+                                       ("bytes", lambda: wl.gpu.find_batch(flat, offsets, out=got))):
+                        call()
+                        times = []
+                        for _ in range(4):
+                            t0 = time.perf_counter()
+                            call()
+                            times.append(time.perf_counter() - t0)
+                        row[name + "_Gqps"] = round(nq / min(times) / 1e9, 3)
+                        row[name + "_median_Gqps"] = round(nq / sorted(times)[len(times) // 2] / 1e9, 3)
+                    row["same"] = bool(np.array_equal(got, want))
+                    rows.append(row)
+                    log(f"pipeline sweep: {row}")
+                out["sweep"] = rows
+                wl.gpu.set_pipeline(*default_shape, 0)
     except Exception as e:
         out["packed"] = {"error": str(e)[:200]}
     return out
@@ -1636,7 +1664,8 @@ def main():
                 for _ in range(max(1, int(1000 / max(r["kernel_ms"], 0.1)))):
                     wl.gpu.find_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), wl.nq, d_tmp.data_ptr(), st.cuda_stream)
             result["device"] = device_telemetry(under_load)
-            result["host_batch"] = host_batch_rate(wl, r["d_out"])
+            sweep = [tuple(int(x) for x in c.split(":")) for c in args.pipeline_sweep.split(",")] if args.pipeline_sweep else None
+            result["host_batch"] = host_batch_rate(wl, r["d_out"], sweep=sweep)
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds)
     if rank == 0 and world == 1 and args.workload in ("repeats", "repeats30", "chr22") and wl.gpu.sampleCount() > 0 and (args.locate or not args.no_extras):

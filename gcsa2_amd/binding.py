@@ -20,7 +20,7 @@ STATUS = {0: "OK", -1: "INVALID_ARGUMENT", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY",
           -5: "MISSING_COMPONENT", -6: "BUFFER_TOO_SMALL"}
 
 EXPORTS = [
-    "gcsa2_device_count", "gcsa2_index_create", "gcsa2_index_destroy", "gcsa2_index_set_tables", "gcsa2_index_trim", "gcsa2_last_error",
+    "gcsa2_device_count", "gcsa2_index_create", "gcsa2_index_destroy", "gcsa2_index_set_tables", "gcsa2_index_trim", "gcsa2_index_set_pipeline", "gcsa2_last_error",
     "gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count", "gcsa2_sample_bits",
     "gcsa2_device", "gcsa2_device_bytes", "gcsa2_block_bits",
     "gcsa2_find_batch", "gcsa2_find_batch_packed", "gcsa2_find_packed_device", "gcsa2_find_device", "gcsa2_find_stats_device", "gcsa2_find_device_variant",
@@ -80,6 +80,7 @@ def load_library():
     L.gcsa2_index_create.argtypes = [C.POINTER(HostView), i32, C.POINTER(vp)]
     L.gcsa2_index_set_tables.argtypes = [vp, i32, i32, i32]
     L.gcsa2_index_trim.argtypes = [vp]
+    L.gcsa2_index_set_pipeline.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.gcsa2_index_destroy.argtypes = [vp]
     L.gcsa2_index_destroy.restype = None
     for name in ("gcsa2_size", "gcsa2_edge_count", "gcsa2_order", "gcsa2_sample_count",
@@ -393,6 +394,10 @@ class GCSA:
     def trim(self):
         """Give back the host pipeline, the staging objects and the scratch pool of this handle (gcsa2_index_trim)."""
         _check(self._L.gcsa2_index_trim(self._h))
+
+    def set_pipeline(self, lanes=0, chunk_log2=0, blocking=-1):
+        """Shape of the host pipeline of find_batch / find_batch_packed (gcsa2_index_set_pipeline; 0 leaves a value)."""
+        _check(self._L.gcsa2_index_set_pipeline(self._h, int(lanes), int(chunk_log2), int(blocking)))
 
     def pair_block_bytes(self):
         return int(self._L.gcsa2_pair_block_bytes(self._h))

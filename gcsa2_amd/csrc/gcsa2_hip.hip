@@ -106,8 +106,9 @@ struct gcsa2_index
     u32 sort_medium_limit = 0;         // GCSA2_SORT_MEDIUM=0 sends the 17..1024-value locate segments to the segmented radix sort
     u64 locate_split = (u64(1) << 31) - 1;   // GCSA2_LOCATE_SPLIT: most values (before deduplication) one pass of the locate pipeline handles
     u64 locate_split_queries = u64(1) << 30; // GCSA2_LOCATE_SPLIT_QUERIES: most ranges one pass handles (its lists and grids are 32-bit)
-    u64 pipe_chunk = u64(1) << 17;     // GCSA2_PIPE_CHUNK (log2): patterns per chunk of the host pipeline
-    u32 pipe_lanes = 12;               // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
+    u64 pipe_chunk = u64(1) << 18;     // GCSA2_PIPE_CHUNK (log2): patterns per chunk of the host pipeline
+    u32 pipe_lanes = 6;                // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
+    bool pipe_blocking = false;        // GCSA2_PIPE_BLOCKING=1: the lanes' events are made with hipEventBlockingSync
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
     bool pipe_wide = false;            // GCSA2_PIPE_WIRE=16: the packed-pattern pipeline brings the ranges home as u64 pairs (A/B)
     bool ms_pieces = true;             // GCSA2_MS_PIECES=0: large host batches of matching statistics go through one copy in, one launch, one copy out
@@ -702,9 +703,10 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.zero_copy = (knob("GCSA2_ZERO_COPY", 1, 0, 1) != 0);
     ix->tune.poll_small = (knob("GCSA2_POLL_SMALL", 1, 0, 1) != 0);
     ix->tune.dedup_huge = (knob("GCSA2_DEDUP_HUGE", 1, 0, 1) != 0);
-    ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 12, 1, 16));
-    ix->tune.pipe_chunk = u64(1) << knob("GCSA2_PIPE_CHUNK", 17, 15, 20);
+    ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 6, 1, 16));
+    ix->tune.pipe_chunk = u64(1) << knob("GCSA2_PIPE_CHUNK", 18, 15, 20);
     ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);
+    ix->tune.pipe_blocking = (knob("GCSA2_PIPE_BLOCKING", 0, 0, 1) != 0);
     ix->tune.pipe_wide = (knob("GCSA2_PIPE_WIRE", 0, 0, 16) == 16);
     ix->tune.ms_pieces = (knob("GCSA2_MS_PIECES", 1, 0, 1) != 0);
     ix->tune.locate_trace = (knob("GCSA2_LOCATE_TRACE", 0, 0, 1) != 0);
@@ -1094,6 +1096,22 @@ int gcsa2_index_trim(gcsa2_index* ix)
   HIP_TRY(hipDeviceSynchronize());
   release_host_staging(ix);
   if(ix->pool != nullptr) { HIP_TRY(hipMemPoolTrimTo(ix->pool, 0)); }
+  return GCSA2_OK;
+}
+
+// Shape of the host pipeline (gcsa2_find_batch / _packed): lanes = host threads with their streams and staging sets (1..16),
+// chunk_log2 = log2 of the patterns per chunk (15..20); 0 / negative leaves a value as it is; blocking: 1 = the lanes sleep in
+// hipEventSynchronize (hipEventBlockingSync), 0 = they spin, -1 = as it is.  Gives the current pipeline back.
+int gcsa2_index_set_pipeline(gcsa2_index* ix, int lanes, int chunk_log2, int blocking)
+{
+  if(ix == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null index"); }
+  if(lanes > 16 || chunk_log2 > 20 || (chunk_log2 > 0 && chunk_log2 < 15)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "host pipeline: lanes 1..16, chunk_log2 15..20"); }
+  const int rc = gcsa2_index_trim(ix);
+  if(rc != GCSA2_OK) { return rc; }
+  std::lock_guard<std::mutex> hold(ix->pipe_lock);
+  if(lanes > 0) { ix->tune.pipe_lanes = u32(lanes); }
+  if(chunk_log2 > 0) { ix->tune.pipe_chunk = u64(1) << chunk_log2; }
+  if(blocking >= 0) { ix->tune.pipe_blocking = (blocking != 0); }
   return GCSA2_OK;
 }
 
@@ -1774,8 +1792,12 @@ namespace {
 // H2D + k_find2 + D2H on the lane's own stream, and while that runs prepare the next chunk in the lane's other staging set;
 // a set's results are copied to the caller's array when its event has fired.  Both PCIe directions, the kernel and the host
 // copies overlap; what bounds the batch is the host's memcpy rate (56 bytes per 32-mer query through pinned memory).
-// (lanes: tune.pipe_lanes, GCSA2_PIPE_LANES, 1..16, default 12)
-constexpr u64 PIPE_CHUNK_BYTES = u64(8) << 20;     // per chunk: at most this many pattern bytes, and tune.pipe_chunk patterns (GCSA2_PIPE_CHUNK = log2, 15..20, default 17)
+// (lanes: tune.pipe_lanes, GCSA2_PIPE_LANES, 1..16, default 6; patterns per chunk: tune.pipe_chunk, GCSA2_PIPE_CHUNK = log2, default 18.
+// Round 4 re-measured the shape on the headline index, one live image re-shaped with gcsa2_index_set_pipeline: 12 lanes x 2^17
+// -- round 3's choice -- 1.4-1.8 G packed 32-mers/s, 6 lanes x 2^18 2.1-2.5 G; 0.9-1.0 -> 1.15-1.3 G for the bytes interface.  The
+// boxes give a container 16 CPUs' worth of time: twelve spinning lanes plus the runtime's own threads run into that quota --
+// with hipEventBlockingSync twelve lanes gain 20 %, six gain nothing; profiles/r04_host.md.)
+constexpr u64 PIPE_CHUNK_BYTES = u64(8) << 20;     // per chunk: at most this many pattern bytes, and tune.pipe_chunk patterns (GCSA2_PIPE_CHUNK = log2, 15..20, default 18)
 constexpr u64 PIPE_MIN_QUERIES = u64(1) << 19;                                       // smaller batches take the single-copy path
 constexpr int PIPE_PATTERN_TOO_LONG = 1;                                             // internal: not a gcsa2_status
 
@@ -1795,7 +1817,7 @@ int pipe_prepare(const gcsa2_index* ix)
     {
       if(e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void**>(&set.h), pipe_set_bytes(ix->tune.pipe_chunk), hipHostMallocDefault); }
       if(e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&set.d), pipe_set_bytes(ix->tune.pipe_chunk)); }
-      if(e == hipSuccess) { e = hipEventCreateWithFlags(&set.done, hipEventDisableTiming); }
+      if(e == hipSuccess) { e = hipEventCreateWithFlags(&set.done, hipEventDisableTiming | (ix->tune.pipe_blocking ? hipEventBlockingSync : 0)); }
       if(e == hipSuccess) { e = hipEventCreateWithFlags(&set.computed, hipEventDisableTiming); }
     }
   }
@@ -1817,10 +1839,40 @@ int pipe_prepare(const gcsa2_index* ix)
   return GCSA2_OK;
 }
 
+// The ranges of a chunk travel home as (sp, length) pairs in the narrowest exact form (comm.hpp: k_pack_ranges32 / 40): 8 bytes
+// per query below 2^32 path nodes and edges, 10 below 2^40, else the 16 bytes of the u64 pairs.  GCSA2_PIPE_WIRE=16 keeps the wide
+// form (A/B).  A lane widens them into the caller's array when it retires the chunk.
+inline u64 pipe_wire_bytes(const gcsa2_index* ix)
+{
+  const u64 top = (ix->img.n > ix->img.e ? ix->img.n : ix->img.e);
+  return (ix->tune.pipe_wide ? 16 : (top < (u64(1) << 32) ? 8 : (top < (u64(1) << 40) ? 10 : 16)));
+}
+
+inline void pipe_widen(const char* h, u64 count, u64 wire, u64* dst)
+{
+  if(wire == 10)                     // (sp, length) as five u16
+  {
+    const unsigned short* w = reinterpret_cast<const unsigned short*>(h);
+    for(u64 i = 0; i < count; i++, w += 5)
+    {
+      const u64 sp = u64(w[0]) | (u64(w[1]) << 16) | (u64(w[4] & 0xFF) << 32), len = u64(w[2]) | (u64(w[3]) << 16) | (u64(w[4] >> 8) << 32);
+      dst[2 * i] = sp; dst[2 * i + 1] = sp + len - 1;
+    }
+  }
+  else                               // (sp, length) as u32 pairs
+  {
+    const u32* w = reinterpret_cast<const u32*>(h);
+    for(u64 i = 0; i < count; i++) { dst[2 * i] = w[2 * i]; dst[2 * i + 1] = u64(w[2 * i]) + u64(w[2 * i + 1]) - 1; }
+  }
+}
+
 int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t* ranges)
 {
   std::lock_guard<std::mutex> hold(ix->pipe_lock);
-  const u64 PIPE_CHUNK_QUERIES = ix->tune.pipe_chunk;
+  // patterns per chunk: the handle's setting, less for a batch too small to give every lane two chunks of that size
+  u64 PIPE_CHUNK_QUERIES = ix->tune.pipe_chunk;
+  { const u64 even = ((nq / (2 * u64(ix->tune.pipe_lanes)) + 63) & ~u64(63)), least = u64(1) << 15;
+    if(even < PIPE_CHUNK_QUERIES) { PIPE_CHUNK_QUERIES = (even > least ? even : least); } }
   int rc = pipe_prepare(ix);
   if(rc != GCSA2_OK) { return rc; }
   // chunk boundaries: at most PIPE_CHUNK_QUERIES patterns and PIPE_CHUNK_BYTES pattern bytes each.  The offsets are validated
@@ -1857,6 +1909,9 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
              direct_out = page_locked(ranges, 2 * nq * sizeof(u64));
   const unsigned PIPE_LANES = ix->tune.pipe_lanes;
   const bool split = ix->tune.pipe_split;
+  // pageable result arrays are filled by the lanes anyway: their ranges come home in the narrow form (the pattern bytes of the
+  // chunk have been consumed by then: their place in both staging buffers takes it); a page-locked array is written in place
+  const u64 wire = (direct_out ? 16 : pipe_wire_bytes(ix));
   std::vector<int> status(PIPE_LANES, GCSA2_OK);
   std::vector<std::string> messages(PIPE_LANES);
   auto work = [&](unsigned t)
@@ -1869,7 +1924,8 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
       if(!set.busy) { return true; }
       hipError_t e = hipEventSynchronize(set.done);
       if(e != hipSuccess) { fail_lane("hipEventSynchronize", e); return false; }
-      if(!direct_out)
+      if(wire != 16) { pipe_widen(set.h, set.count, wire, ranges + 2 * set.first); }
+      else if(!direct_out)
       {
         const char* h_out = set.h + (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8;
         std::memcpy(ranges + 2 * set.first, h_out, set.count * 16);
@@ -1924,7 +1980,13 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
         err = hipEventRecord(set.computed, lane.stream);
         if(err == hipSuccess) { err = hipStreamWaitEvent(lane.down, set.computed, 0); }
       }
-      if(err == hipSuccess) { err = hipMemcpyAsync(direct_out ? reinterpret_cast<char*>(ranges + 2 * b) : h_out, d_out, count * 16, hipMemcpyDeviceToHost, back); }
+      if(err == hipSuccess && wire != 16)
+      {
+        const int rc_pack = (wire == 10 ? gcsa2_pack_ranges40_device(d_out, count, set.d, back) : gcsa2_pack_ranges32_device(d_out, count, reinterpret_cast<uint32_t*>(set.d), back));
+        if(rc_pack != GCSA2_OK) { status[t] = rc_pack; messages[t] = g_error; break; }
+        err = hipMemcpyAsync(set.h, set.d, count * wire, hipMemcpyDeviceToHost, back);
+      }
+      else if(err == hipSuccess) { err = hipMemcpyAsync(direct_out ? reinterpret_cast<char*>(ranges + 2 * b) : h_out, d_out, count * 16, hipMemcpyDeviceToHost, back); }
       if(err == hipSuccess) { err = hipEventRecord(set.done, back); }
       if(err != hipSuccess) { fail_lane("hipMemcpyAsync / hipEventRecord", err); break; }
       set.busy = true; set.first = b; set.count = count;
@@ -1950,7 +2012,10 @@ int find_pipelined(const gcsa2_index* ix, const uint8_t* patterns, const uint64_
 int find_packed_pipelined(const gcsa2_index* ix, const uint64_t* codes, u64 length, uint64_t nq, uint64_t* ranges)
 {
   std::lock_guard<std::mutex> hold(ix->pipe_lock);
-  const u64 PIPE_CHUNK_QUERIES = ix->tune.pipe_chunk;
+  // patterns per chunk: the handle's setting, less for a batch too small to give every lane two chunks of that size
+  u64 PIPE_CHUNK_QUERIES = ix->tune.pipe_chunk;
+  { const u64 even = ((nq / (2 * u64(ix->tune.pipe_lanes)) + 63) & ~u64(63)), least = u64(1) << 15;
+    if(even < PIPE_CHUNK_QUERIES) { PIPE_CHUNK_QUERIES = (even > least ? even : least); } }
   int rc = pipe_prepare(ix);
   if(rc != GCSA2_OK) { return rc; }
   const u64 words = (length + 31) >> 5;
@@ -1974,8 +2039,7 @@ int find_packed_pipelined(const gcsa2_index* ix, const uint64_t* codes, u64 leng
   const u64 out_at = (PIPE_CHUNK_BYTES + 64) + (PIPE_CHUNK_QUERIES + 8) * 8;      // where a set keeps its ranges (pipe_set_bytes)
   // the ranges travel home as (sp, length) pairs in the narrowest exact form (comm.hpp): 8 bytes below 2^32 path nodes and
   // edges, 10 below 2^40, else the 16 bytes of the u64 pairs; GCSA2_PIPE_WIRE=16 keeps the wide form (A/B)
-  const u64 top = (ix->img.n > ix->img.e ? ix->img.n : ix->img.e);
-  const u64 wire = (ix->tune.pipe_wide ? 16 : (top < (u64(1) << 32) ? 8 : (top < (u64(1) << 40) ? 10 : 16)));
+  const u64 wire = pipe_wire_bytes(ix);
   auto work = [&](unsigned t)
   {
     DeviceGuard guard(ix->device);
@@ -1987,20 +2051,7 @@ int find_packed_pipelined(const gcsa2_index* ix, const uint64_t* codes, u64 leng
       hipError_t e = hipEventSynchronize(set.done);
       if(e != hipSuccess) { fail_lane("hipEventSynchronize", e); return false; }
       u64* dst = ranges + 2 * set.first;
-      if(wire == 10)                     // (sp, length) as five u16 (k_pack_ranges40): the ranges come home in 10 bytes instead of 16
-      {
-        const unsigned short* w = reinterpret_cast<const unsigned short*>(set.h);
-        for(u64 i = 0; i < set.count; i++, w += 5)
-        {
-          const u64 sp = u64(w[0]) | (u64(w[1]) << 16) | (u64(w[4] & 0xFF) << 32), len = u64(w[2]) | (u64(w[3]) << 16) | (u64(w[4] >> 8) << 32);
-          dst[2 * i] = sp; dst[2 * i + 1] = sp + len - 1;
-        }
-      }
-      else if(wire == 8)                 // (sp, length) as u32 pairs (k_pack_ranges32)
-      {
-        const u32* w = reinterpret_cast<const u32*>(set.h);
-        for(u64 i = 0; i < set.count; i++) { dst[2 * i] = w[2 * i]; dst[2 * i + 1] = u64(w[2 * i]) + u64(w[2 * i + 1]) - 1; }
-      }
+      if(wire != 16) { pipe_widen(set.h, set.count, wire, dst); }
       else if(!direct_out) { std::memcpy(dst, set.h + out_at, set.count * 16); }
       set.busy = false;
       return true;

@@ -135,12 +135,18 @@ void gcsa2_index_destroy(gcsa2_index* index);
  * -1 = leave.  It waits for the device to idle first; the caller must not run queries on this handle (or on facade copies
  * sharing it) during the call.  On failure the table in question is absent and every query still works. */
 int gcsa2_index_set_tables(gcsa2_index* index, int pair_blocks, int kmer_k, int locate_table);
-/* A handle keeps what its host-pointer entry points have grown to: the pipeline of gcsa2_find_batch (12 lanes x 2 sets of
- * ~11 MB: about 270 MB of page-locked host memory and as much device memory, made at the first batch of 2^19 or more
+/* A handle keeps what its host-pointer entry points have grown to: the pipeline of gcsa2_find_batch (6 lanes x 2 sets of
+ * ~14 MB: about 170 MB of page-locked host memory and as much device memory, made at the first batch of 2^19 or more
  * patterns), the staging objects of the small calls (8 MB pinned + a grow-only device arena each) and the stream-ordered
  * scratch pool of the queries.  gcsa2_index_trim gives all of it back (the next call builds what it needs again); like
  * set_tables it waits for the device and must not run beside queries on the same handle. */
 int gcsa2_index_trim(gcsa2_index* index);
+/* Shape of that pipeline: `lanes` host threads, each with its stream and two staging sets (1..16; default 6, or
+ * GCSA2_PIPE_LANES at create time), 2^chunk_log2 patterns per chunk (15..20; default 18, GCSA2_PIPE_CHUNK); 0 leaves a value
+ * as it is; blocking: 1 = the lanes sleep while they wait for a chunk (hipEventBlockingSync), 0 = they spin, -1 = as it is.
+ * Trims the handle first (same rules as gcsa2_index_trim).  What is best depends on the host: tests/perf/
+ * packed_pipeline.py sweeps both on a live image. */
+int gcsa2_index_set_pipeline(gcsa2_index* index, int lanes, int chunk_log2, int blocking);
 
 /* Thread-local description of the last failing call. */
 const char* gcsa2_last_error(void);

@@ -434,6 +434,45 @@ def test_find_host_pipeline_pageable_and_page_locked(engine):
         gpu.find_batch(pinned[0], bad)
 
 
+@pytest.mark.gpu
+def test_host_pipeline_shapes(engine):
+    """gcsa2_index_set_pipeline: whatever the shape of the host pipeline -- one lane or sixteen, chunks of 2^15 or 2^20
+    patterns, lanes that spin or sleep -- gcsa2_find_batch and gcsa2_find_batch_packed return the ranges of the single-launch
+    device path (a batch that gives the lanes fewer than two full chunks each is cut finer); arguments out of range are refused
+    and leave the shape as it was."""
+    import torch
+    from gcsa2_amd.hostview import pack_kmers
+    name, g, K = CASES[-1]
+    ix = build(g, K, sample_period=8, branching=4)
+    gpu, lcp = engine.open_index(ix)
+    rng = np.random.default_rng(0x98)
+    m, nq = 21, (1 << 19) + 777
+    arr = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(nq, m))].copy()
+    walks = [p for p in random_patterns(g, m, 0x99, 4000) if len(p) == m and all(c in b"ACGT" for c in p)]
+    if walks:
+        hits = np.frombuffer(b"".join(walks), dtype=np.uint8).reshape(-1, m)
+        arr[::3] = hits[rng.integers(0, hits.shape[0], size=arr[::3].shape[0])]
+    off = np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)
+    dev = torch.device("cuda", 0)
+    d_pat = torch.zeros(nq * m + 16, dtype=torch.uint8, device=dev)
+    d_pat[: nq * m] = torch.from_numpy(arr.reshape(-1)).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_out = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    want = d_out.cpu().numpy().view(np.uint64)
+    codes = pack_kmers(arr, ix.char2comp)
+    for lanes, chunk, blocking in ((1, 15, 0), (16, 20, 1), (3, 16, 1), (6, 18, 0), (0, 0, -1)):
+        gpu.set_pipeline(lanes, chunk, blocking)
+        assert np.array_equal(gpu.find_batch(arr.reshape(-1), off), want), (lanes, chunk, blocking)
+        assert np.array_equal(gpu.find_batch_packed(codes, m), want), (lanes, chunk, blocking)
+    for bad in ((17, 18, 0), (6, 21, 0), (6, 14, 0)):
+        with pytest.raises(engine.Gcsa2Error) as e:
+            gpu.set_pipeline(*bad)
+        assert e.value.code == -1
+    assert np.array_equal(gpu.find_batch_packed(codes, m), want)
+
+
 def widen_alphabet(ix):
     """Same index over a 9-letter alphabet: two never-occurring comps are inserted after T, so
     N becomes comp 7 and # comp 8.  Exercises sigma != 7 (sigma > 8 disables the pred4 nibbles and
