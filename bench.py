@@ -142,7 +142,20 @@ class Dist:
 
     def make_comm(self, binding, device_index):
         import torch
-        if not self.active or self.backend != "nccl" or os.environ.get("GCSA2_BENCH_NO_COMM"):    # the env knob tests the fallback
+        if not self.active or os.environ.get("GCSA2_BENCH_NO_COMM"):    # the env knob tests the fallback
+            return
+        if self.backend != "nccl":
+            # control-flow runs with ranks sharing a GPU (RCCL refuses that): the library's communicator over a gather through
+            # host memory (gcsa2_comm_create_custom), so that everything above the transport is the C++ that runs under RCCL
+            from gcsa2_amd.host_transport import HostGather
+            try:
+                self.comm = binding.Comm.custom(self.rank, self.world, device_index, HostGather(self.dist, self.rank, self.world))
+            except Exception as e:
+                print(f"[bench] rank {self.rank}: gcsa2_comm_create_custom failed ({e})", file=sys.stderr, flush=True)
+            if not self.all_true(self.comm is not None):
+                if self.comm is not None:
+                    self.comm.close()
+                self.comm = None
             return
         # Safety net: if the library's communicator cannot be created on some rank (RCCL not loadable there, ...), every
         # rank falls back to torch.distributed.gather for the data path and the line says so (config.parallelism).
@@ -683,7 +696,8 @@ def measure(args, D, dev, wl, steps, warmup):
         D.dist.all_gather_object(everyone, mine)
         per_rank = everyone
     result = dict(elapsed=elapsed, kernel_ms=kernel_ms, d_out=d_out, gathered=None, pack32=pack32, pack40=pack40,
-                  gather=("gcsa2_comm_gather (library RCCL communicator)" if D.comm is not None else
+                  gather=(("gcsa2_comm_gather (library RCCL communicator)" if D.backend == "nccl" else
+                           "gcsa2_comm_gather over a host-memory transport (gcsa2_comm_create_custom; control-flow check)") if D.comm is not None else
                           ("torch.distributed.gather (fallback)" if D.active and D.backend == "nccl" else
                            ("host copies (gloo control-flow check)" if D.active else "none (one GPU)"))))
     result["per_rank"] = per_rank
@@ -1181,7 +1195,9 @@ def config5_sharded(args, D, wl, dev):
         located_ok = bool(np.array_equal(first_vals, mseq_torch.node_values(start_all[0::2].cpu().numpy()))) if start_all is not None else None
         out = {"workload": f"{nq_total} x {m}-bp walks, every second one with a substitution every 41 bp, sharded contiguously over {D.world} GPU(s): "
                            "backward search with parent() on failure + locate() of the final ranges on every shard, results gathered on the root "
-                           + ("(gcsa2_comm_match_stats / gcsa2_comm_locate: grouped RCCL send / recv)" if use_comm else "(through host memory: control-flow check)"),
+                           + (("(gcsa2_comm_match_stats / gcsa2_comm_locate: grouped RCCL send / recv)" if D.backend == "nccl" else
+                              "(gcsa2_comm_match_stats / gcsa2_comm_locate over a host-memory transport: control-flow check)") if use_comm
+                              else "(through host memory, Python mirror of the sharding: control-flow check)"),
                "n_gpus": D.world, "match_stats_ms": ms_time, "patterns_per_s": nq_total / (ms_time * 1e-3), "bases_per_s": nq_total * m / (ms_time * 1e-3),
                "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item()), "unmodified_half_equals_closed_form": exact_ok,
                "locate": {"ms_per_step": loc_ms, "value": nq_total / (loc_ms * 1e-3), "unit": "queries/s", "values": loc_total,

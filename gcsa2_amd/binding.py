@@ -8,6 +8,7 @@ fallback: if the library or a device is missing, construction raises.
 """
 import ctypes as C
 import os
+import sys
 import numpy as np
 
 from .hostview import (HostView, STNode, STNODE_DTYPE, UNKNOWN, make_host_view, concat_patterns,
@@ -36,7 +37,7 @@ EXPORTS = [
     "gcsa2_group_create", "gcsa2_group_destroy", "gcsa2_group_size", "gcsa2_group_index",
     "gcsa2_group_find_batch", "gcsa2_group_find_device", "gcsa2_group_uses_rccl",
     "gcsa2_group_match_stats_device", "gcsa2_group_locate_device", "gcsa2_comm_match_stats", "gcsa2_comm_locate",
-    "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_rccl_ranks", "gcsa2_comm_gather",
+    "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_create_custom", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_rccl_ranks", "gcsa2_comm_gather",
     "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_pack_ranges40_device", "gcsa2_unpack_ranges40_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device", "gcsa2_match_breaks_device", "gcsa2_match_breaks_batch",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
@@ -160,6 +161,7 @@ def load_library():
     L.gcsa2_comm_locate.argtypes = [vp, vp, vp, u64p, i32, i32, vp, C.POINTER(vp), C.POINTER(vp), u64p, vp]
     L.gcsa2_comm_unique_id.argtypes = [u8p]
     L.gcsa2_comm_create.argtypes = [u8p, i32, i32, i32, C.POINTER(vp)]
+    L.gcsa2_comm_create_custom.argtypes = [i32, i32, i32, vp, vp, C.POINTER(vp)]
     L.gcsa2_comm_destroy.argtypes = [vp]
     L.gcsa2_comm_destroy.restype = None
     L.gcsa2_comm_rank.argtypes = [vp]
@@ -765,6 +767,30 @@ class Comm:
         _check(self._L.gcsa2_comm_create(_p8(buf), rank, world, device, C.byref(h)))
         self._h = h
         self.rank, self.world = rank, world
+
+    GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_int, C.c_void_p)
+
+    @classmethod
+    def custom(cls, rank: int, world: int, device: int, gather):
+        """A communicator over the application's own transport (gcsa2_comm_create_custom): `gather(d_send, sizes, d_recv, root,
+        stream) -> int` with device pointers as integers and `sizes` the list of bytes per rank; 0 = success.  Everything above
+        the transport -- sharded matching statistics, sharded locate() with its CSR rebasing -- is the library's C++ as with
+        RCCL (gcsa2_amd/host_transport.py holds a gather through host memory over torch.distributed)."""
+        self = cls.__new__(cls)
+        self._L = load_library()
+        self.rank, self.world = rank, world
+
+        def trampoline(user, d_send, sizes, d_recv, root, stream):
+            try:
+                return int(gather(d_send or 0, [int(sizes[r]) for r in range(world)], d_recv or 0, int(root), stream or 0))
+            except Exception as e:                   # an exception must not cross the C frames
+                print(f"gcsa2 custom gather failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
+                return 1
+        self._callback = Comm.GATHER_FN(trampoline)             # kept alive with the communicator
+        h = C.c_void_p()
+        _check(self._L.gcsa2_comm_create_custom(rank, world, device, C.cast(self._callback, C.c_void_p), None, C.byref(h)))
+        self._h = h
+        return self
 
     def rccl_ranks(self) -> int:
         """The number of ranks RCCL itself reports for this communicator (ncclCommCount)."""

@@ -114,9 +114,32 @@ __global__ __launch_bounds__(TPB) void k_unpack_ranges40(const unsigned short* _
   reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, sp + len - 1);
 }
 
-// grouped send / recv gather: rank r contributes bytes[r] bytes; the root receives them back to back in rank order
-int gather_bytes(ncclComm_t comm, int rank, int world, const void* d_send, const u64* bytes, void* d_recv, int root, hipStream_t st)
+}  // namespace
+
+// One rank of the query path's communicator: an RCCL communicator (gcsa2_comm_create), or the application's own transport
+// (gcsa2_comm_create_custom: MPI, a host-memory gather, ...) behind the same gather contract.
+struct gcsa2_comm
 {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  gcsa2_gather_fn custom = nullptr;
+  void* user = nullptr;
+};
+
+namespace {
+
+// the gather of the query path: rank r contributes bytes[r] bytes; the root receives them back to back in rank order.
+// RCCL: grouped send / recv, enqueued on `st`.  Custom transport: the application's function, same contract.
+int gather_bytes(const gcsa2_comm* c, const void* d_send, const u64* bytes, void* d_recv, int root, hipStream_t st)
+{
+  const int rank = c->rank, world = c->world;
+  if(c->custom != nullptr)
+  {
+    const int rc = c->custom(c->user, d_send, bytes, d_recv, root, static_cast<void*>(st));
+    if(rc != 0) { return fail(GCSA2_ERR_HIP, "the communicator's gather function failed with " + std::to_string(rc)); }
+    return GCSA2_OK;
+  }
+  ncclComm_t comm = c->comm;
   RcclApi& api = rccl();
   RCCL_TRY(api.GroupStart());
   ncclResult_t r = ncclSuccess;
@@ -146,12 +169,6 @@ int gather_bytes(ncclComm_t comm, int rank, int world, const void* d_send, const
 }
 
 }  // namespace
-
-struct gcsa2_comm
-{
-  ncclComm_t comm = nullptr;
-  int rank = 0, world = 1, device = 0;
-};
 
 extern "C" {
 
@@ -186,6 +203,19 @@ int gcsa2_comm_create(const uint8_t* id, int rank, int world, int device, gcsa2_
   return GCSA2_OK;
 }
 
+int gcsa2_comm_create_custom(int rank, int world, int device, gcsa2_gather_fn gather, void* user, gcsa2_comm** out)
+{
+  if(gather == nullptr || out == nullptr || world <= 0 || rank < 0 || rank >= world) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad communicator arguments"); }
+  *out = nullptr;
+  DeviceGuard guard(device);
+  if(!guard.ok) { return fail(GCSA2_ERR_HIP, "hipSetDevice failed"); }
+  gcsa2_comm* c = new(std::nothrow) gcsa2_comm();
+  if(c == nullptr) { return fail(GCSA2_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+  c->rank = rank; c->world = world; c->device = device; c->custom = gather; c->user = user;
+  *out = c;
+  return GCSA2_OK;
+}
+
 void gcsa2_comm_destroy(gcsa2_comm* c)
 {
   if(c == nullptr) { return; }
@@ -198,7 +228,9 @@ int gcsa2_comm_world(const gcsa2_comm* c) { return c == nullptr ? 0 : c->world; 
 
 int gcsa2_comm_rccl_ranks(const gcsa2_comm* c, int* ranks)
 {
-  if(c == nullptr || ranks == nullptr || c->comm == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad communicator"); }
+  if(c == nullptr || ranks == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad communicator"); }
+  if(c->custom != nullptr) { *ranks = 0; return GCSA2_OK; }            // not an RCCL communicator
+  if(c->comm == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad communicator"); }
   RcclApi& api = rccl();
   if(!api.ok) { return fail(GCSA2_ERR_MISSING_COMPONENT, api.error); }
   RCCL_TRY(api.CommCount(c->comm, ranks));
@@ -210,7 +242,7 @@ int gcsa2_comm_gather(gcsa2_comm* c, const void* d_send, const uint64_t* bytes, 
   if(c == nullptr || bytes == nullptr || root < 0 || root >= c->world) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "bad gather arguments"); }
   if(c->rank == root && d_recv == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "the root needs a receive buffer"); }
   DeviceGuard guard(c->device);
-  return gather_bytes(c->comm, c->rank, c->world, d_send, bytes, d_recv, root, static_cast<hipStream_t>(stream));
+  return gather_bytes(c, d_send, bytes, d_recv, root, static_cast<hipStream_t>(stream));
 }
 
 int gcsa2_pack_ranges32_device(const uint64_t* d_ranges, uint64_t nq, uint32_t* d_packed, void* stream)

@@ -2840,7 +2840,7 @@ int gcsa2_comm_match_stats(gcsa2_comm* c, const gcsa2_index* ix, const uint8_t* 
     for(int r = 0; r < c->world; r++) { sizes[size_t(r)] = (part == 0 ? 2 * pattern_bytes[r] : (part == 1 ? 16 * counts[r] : 8 * counts[r])); }
     const void* src = (part == 0 ? static_cast<const void*>(my_ms) : (part == 1 ? static_cast<const void*>(my_rng) : static_cast<const void*>(my_fb)));
     void* dst = (part == 0 ? static_cast<void*>(d_ms_root) : (part == 1 ? static_cast<void*>(d_ranges_root) : static_cast<void*>(d_fallbacks_root)));
-    const int g_rc = gather_bytes(c->comm, c->rank, c->world, src, sizes.data(), dst, root, st);
+    const int g_rc = gather_bytes(c, src, sizes.data(), dst, root, st);
     if(rc == GCSA2_OK) { rc = g_rc; }
   }
   (void)hipFreeAsync(buf, st);
@@ -2893,7 +2893,7 @@ int gcsa2_comm_locate(gcsa2_comm* c, const gcsa2_index* ix, const uint64_t* d_ra
     if(e == hipSuccess) { e = hipStreamSynchronize(st); }
     if(e != hipSuccess) { return fail(local_rc, local_error); }    // the device itself is gone
   }
-  rc = gather_bytes(c->comm, c->rank, c->world, my_total, eight.data(), d_totals, root, st);
+  rc = gather_bytes(c, my_total, eight.data(), d_totals, root, st);
   if(rc == GCSA2_OK && is_root)
   {
     hipError_t e = hipMemcpyAsync(totals.data(), d_totals, W * sizeof(u64), hipMemcpyDeviceToHost, st);
@@ -2936,9 +2936,9 @@ int gcsa2_comm_locate(gcsa2_comm* c, const gcsa2_index* ix, const uint64_t* d_ra
       return fail(GCSA2_ERR_OUT_OF_MEMORY, "no memory for the values of the batch on the root (the other ranks of this call will not return: destroy the communicator)");
     }
   }
-  rc = gather_bytes(c->comm, c->rank, c->world, my_offsets, off_bytes.data(), d_offsets_root, root, st);
+  rc = gather_bytes(c, my_offsets, off_bytes.data(), d_offsets_root, root, st);
   {
-    const int g_rc = gather_bytes(c->comm, c->rank, c->world, my_values, val_bytes.data(), is_root ? result->d_values : nullptr, root, st);
+    const int g_rc = gather_bytes(c, my_values, val_bytes.data(), is_root ? result->d_values : nullptr, root, st);
     if(rc == GCSA2_OK) { rc = g_rc; }
   }
   if(rc == GCSA2_OK && local_rc != GCSA2_OK) { rc = fail(local_rc, local_error); }

@@ -505,6 +505,15 @@ int gcsa2_group_locate_device(gcsa2_group* group, const uint64_t* const* d_range
 typedef struct gcsa2_comm gcsa2_comm;
 int gcsa2_comm_unique_id(uint8_t* id /* GCSA2_COMM_ID_BYTES */);
 int gcsa2_comm_create(const uint8_t* id, int rank, int world, int device, gcsa2_comm** out);
+/* A communicator over the APPLICATION's transport instead of RCCL (MPI, a gather through host memory on hosts without RCCL,
+ * the world-size-2 tests of this repository on one GPU): `gather` has the contract of gcsa2_comm_gather below -- rank r
+ * contributes bytes[r] bytes of device memory at d_send, the root receives all parts back to back, in rank order, in device
+ * memory at d_recv (its own part included) -- and is called by gcsa2_comm_gather / _match_stats / _locate wherever they would
+ * use RCCL.  It may work asynchronously on `stream` or complete before it returns (after waiting for `stream`, on which the
+ * data it sends was produced); 0 = success.  `user` is passed through.  gcsa2_comm_rccl_ranks reports 0 for such a
+ * communicator. */
+typedef int (*gcsa2_gather_fn)(void* user, const void* d_send, const uint64_t* bytes, void* d_recv, int root, void* stream);
+int gcsa2_comm_create_custom(int rank, int world, int device, gcsa2_gather_fn gather, void* user, gcsa2_comm** out);
 void gcsa2_comm_destroy(gcsa2_comm* comm);
 int gcsa2_comm_rank(const gcsa2_comm* comm);
 int gcsa2_comm_world(const gcsa2_comm* comm);
