@@ -603,6 +603,10 @@ def measure(args, D, dev, wl, steps, warmup):
     recv = [torch.zeros(total * wire_bytes + 6, dtype=torch.uint8, device=dev) for _ in outs] if root else [None] * nbuf
     gathered = torch.zeros((total, 2), dtype=torch.int64, device=dev) if (root and packed) else None
     free_ev = [None] * nbuf                  # the gather of the buffer's previous contents has completed
+    # the root widens the gathered pairs on a THIRD stream: at N = 8 the unpack of 100 M pairs (0.45 ms) would otherwise sit
+    # between two gathers on the gather stream, which is the slowest stage of the step (7 x 125 MB into the root)
+    unpack_stream = torch.cuda.Stream(device=dev) if (root and packed) else None
+    unpacked_ev = [None] * nbuf              # the unpack that read recv[b] has completed
 
     def step(k, record=None):
         b = k % nbuf
@@ -625,6 +629,8 @@ def measure(args, D, dev, wl, steps, warmup):
         if record is not None:               # per-rank breakdown: pack = record[1]..record[2], gather (+ unpack) = record[3]..record[4]
             record[2] = ready
             record[3].record(comm_stream)
+        if unpack_stream is not None and unpacked_ev[b] is not None:
+            comm_stream.wait_event(unpacked_ev[b])                 # recv[b] is free again
         if D.comm is not None:               # the single collective of the path: one gather of hit ranges over xGMI
             D.comm.gather(wire[b].data_ptr(), [c * wire_bytes for c in counts], recv[b].data_ptr() if root else 0, 0,
                           comm_stream.cuda_stream)
@@ -646,17 +652,27 @@ def measure(args, D, dev, wl, steps, warmup):
             if root:
                 with torch.cuda.stream(comm_stream):
                     recv[b][: total * wire_bytes].copy_(parts)
-        if root and pack32:
-            binding.unpack_ranges32_device(recv[b].data_ptr(), total, gathered.data_ptr(), comm_stream.cuda_stream)
-        elif root and pack40:
-            binding.unpack_ranges40_device(recv[b].data_ptr(), total, gathered.data_ptr(), comm_stream.cuda_stream)
+        last_stream = comm_stream
+        if unpack_stream is not None:
+            arrived = torch.cuda.Event()
+            arrived.record(comm_stream)
+            unpack_stream.wait_event(arrived)
+            if pack32:
+                binding.unpack_ranges32_device(recv[b].data_ptr(), total, gathered.data_ptr(), unpack_stream.cuda_stream)
+            else:
+                binding.unpack_ranges40_device(recv[b].data_ptr(), total, gathered.data_ptr(), unpack_stream.cuda_stream)
+            last_stream = unpack_stream
         done = record[4] if record is not None else torch.cuda.Event()
-        done.record(comm_stream)
+        done.record(last_stream)
         free_ev[b] = done
+        if unpack_stream is not None:
+            unpacked_ev[b] = done
 
     def drain():
         if comm_stream is not None:
             comm_stream.synchronize()
+        if unpack_stream is not None:
+            unpack_stream.synchronize()
 
     for k in range(warmup):
         step(k)

@@ -179,6 +179,9 @@ public:
   // never change.  Not to be called while queries run on this index or on copies of it (copies share the device image).
   void setTables(int pair_blocks, int kmer_k, int locate_table) { check(gcsa2_index_set_tables(owner.get(), pair_blocks, kmer_k, locate_table), "GCSA::setTables()"); }
   void trim() { check(gcsa2_index_trim(owner.get()), "GCSA::trim()"); }
+  // Shape of the host pipeline behind find_batch / find_packed_batch (gcsa2_index_set_pipeline): host threads, log2 of the
+  // patterns per chunk, spinning (0) or sleeping (1) waits; 0 / 0 / -1 leave a value as it is.
+  void setPipeline(int lanes, int chunk_log2, int blocking = -1) { check(gcsa2_index_set_pipeline(owner.get(), lanes, chunk_log2, blocking), "GCSA::setPipeline()"); }
   size_type deviceBytes() const { return gcsa2_device_bytes(handle); }
 
   size_type count(range_type range) const                                   // src/gcsa.cpp:802-809

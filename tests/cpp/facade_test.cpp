@@ -159,6 +159,11 @@ int main(int argc, char** argv)
     }
   }
   index.trim();
+  index.setPipeline(2, 15, 1);               // a small pipeline with sleeping waits: same answers (the shape is the caller's to choose)
+  {
+    const std::vector<std::uint8_t> one(patterns[0].begin(), patterns[0].end());
+    same = same && index.find(patterns[0]) == index.find_batch(one, std::vector<gcsa::size_type>{0, one.size()})[0];
+  }
   std::cout << "ladder " << (same ? "same" : "DIFFERENT") << " " << (index.deviceBytes() <= full ? "ok" : "grew") << " " << index.find(patterns[0]).first << "\n";
   return 0;
 }
