@@ -1088,6 +1088,34 @@ def match_breaks_leg(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, exp, timed, de
     t_brk = timed(lambda: gpu.match_breaks_device(d_clean.data_ptr(), d_coff.data_ptr(), nc, nc * m, d_boff.data_ptr(), d_brk.data_ptr(), cap,
                                                   d_rng2.data_ptr(), d_fb2.data_ptr(), stream.cuda_stream))
     out["clean_batch"] = {"patterns": nc, "dense_patterns_per_s": nc / (t_dense * 1e-3), "breaks_patterns_per_s": nc / (t_brk * 1e-3)}
+    # where a MEM finder's reads actually live: the batch in pageable HOST memory -> gcsa2_match_breaks_batch (pieces of 16 MB of
+    # pattern bytes on four streams, records committed in piece order) -> CSR, final ranges and parent() counts in host memory
+    try:
+        h_pat = d_pat[: nq * m].cpu().numpy().copy()
+        h_off = np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)
+        bufs = (np.ones(nq + 1, dtype=np.uint64), np.ones((max(n_mem, 1) + 16, 4), dtype=np.uint64), np.ones((nq, 2), dtype=np.uint64), np.ones(nq, dtype=np.uint64))
+        best = timed_calls(lambda: gpu.match_breaks_batch(h_pat, h_off, min_length=min_mem, out=bufs), warm=2, warm_seconds=0.3, timed=4)
+        hb, hr, hrng, hfb = gpu.match_breaks_batch(h_pat, h_off, min_length=min_mem, out=bufs)
+        assert gpu.match_breaks_device(d_pat.data_ptr(), d_off.data_ptr(), nq, nq * m, d_boff.data_ptr(), d_brk.data_ptr(), cap, d_rng2.data_ptr(),
+                                       d_fb2.data_ptr(), stream.cuda_stream, min_length=min_mem) == n_mem       # the device-resident run to compare with
+        torch.cuda.synchronize()
+        same = bool(np.array_equal(hb, d_boff.cpu().numpy().view(np.uint64))) and hr.shape[0] == n_mem and \
+            bool(np.array_equal(hr, d_brk[:n_mem].cpu().numpy().view(np.uint64))) and bool(np.array_equal(hrng, d_rng2.cpu().numpy().view(np.uint64))) and \
+            bool(np.array_equal(hfb, d_fb2.cpu().numpy().view(np.uint64)))
+        out["host_batch_min_length_20"] = {"workload": f"the same {nq} x {m}-bp patterns in pageable host memory -> gcsa2_match_breaks_batch (min_length {min_mem}) -> "
+                                                       "break points, final ranges and parent() counts in host memory (best of 4 after warm-up)",
+                                           "ms": best * 1e3, "patterns_per_s": nq / best, "bytes_per_pattern_over_pcie": m + 8 + 32 * n_mem / nq + 8 + 24,
+                                           "GB_per_s_end_to_end": nq * (m + 40 + 32 * n_mem / nq) / best / 1e9, "equals_device_resident_run": same}
+        # the same with every array of the caller page-locked (the copy engines read and write them in place)
+        pin = lambda a: torch.from_numpy(a).pin_memory().numpy()
+        p_pat, p_off = pin(h_pat), pin(h_off.view(np.int64)).view(np.uint64)
+        p_bufs = tuple(pin(b.view(np.int64)).view(np.uint64) for b in bufs)
+        best = timed_calls(lambda: gpu.match_breaks_batch(p_pat, p_off, min_length=min_mem, out=p_bufs), warm=2, warm_seconds=0.3, timed=4)
+        pb_, pr_, _, _ = gpu.match_breaks_batch(p_pat, p_off, min_length=min_mem, out=p_bufs)
+        out["host_batch_min_length_20"]["page_locked"] = {"ms": best * 1e3, "patterns_per_s": nq / best,
+                                                          "equals_pageable_run": bool(np.array_equal(pb_, hb) and np.array_equal(pr_, hr))}
+    except Exception as e:
+        out["host_batch_min_length_20"] = dict(out.get("host_batch_min_length_20", {}), error=str(e)[:200])
     return out
 
 

@@ -534,12 +534,27 @@ class GCSA:
             _check(self._L.gcsa2_match_stats_device_sized(self._h, variant, d_patterns, d_offsets, nq, int(total_bytes), d_ms, d_ranges,
                                                           d_fallbacks, stream))
 
-    def match_breaks_batch(self, patterns, offsets, min_length=0, capacity=None):
+    def match_breaks_batch(self, patterns, offsets, min_length=0, capacity=None, out=None):
         """Break points of a batch in host memory: (break_offsets (nq + 1), breaks (total, 4) = {position, length, sp, ep}, ranges,
-        parent() counts).  The record buffer is sized from the refusal when `capacity` is too small (default: 4 per pattern)."""
+        parent() counts).  The record buffer is sized from the refusal when `capacity` is too small (default: 4 per pattern).
+        `out` = (break_offsets, breaks, ranges, fallbacks) arrays of the caller (a caller that reuses them avoids the page faults
+        of fresh ones); too few rows in `breaks` raise BUFFER_TOO_SMALL with `needed`."""
         patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         nq = offsets.shape[0] - 1
+        if out is not None:
+            boff, brk, rng, fb = out
+            assert boff.dtype == np.uint64 and boff.shape[0] >= nq + 1 and brk.dtype == np.uint64 and brk.flags.c_contiguous and brk.shape[1] == 4
+            assert rng.dtype == np.uint64 and rng.shape[0] >= nq and fb.dtype == np.uint64 and fb.shape[0] >= nq
+            total = C.c_uint64()
+            rc = self._L.gcsa2_match_breaks_batch(self._h, _p8(patterns), _p64(offsets), nq, int(min_length), _p64(boff), brk.ctypes.data, brk.shape[0],
+                                                  C.byref(total), rng.ctypes.data, fb.ctypes.data)
+            if rc == -6:
+                err = Gcsa2Error(rc, self._L.gcsa2_last_error().decode(errors="replace"))
+                err.needed = total.value
+                raise err
+            _check(rc)
+            return boff[: nq + 1], brk[: total.value], rng[:nq], fb[:nq]
         cap = int(capacity if capacity is not None else 4 * nq + 16)
         boff = np.zeros(nq + 1, dtype=np.uint64)
         rng = np.zeros((max(nq, 1), 2), dtype=np.uint64)

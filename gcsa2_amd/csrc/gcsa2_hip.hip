@@ -21,6 +21,7 @@
 
 #include <hipcub/hipcub.hpp>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 
 #include <cstdio>
@@ -108,6 +109,7 @@ struct gcsa2_index
     u64 locate_split_queries = u64(1) << 30; // GCSA2_LOCATE_SPLIT_QUERIES: most ranges one pass handles (its lists and grids are 32-bit)
     u64 pipe_chunk = u64(1) << 18;     // GCSA2_PIPE_CHUNK (log2): patterns per chunk of the host pipeline
     u32 pipe_lanes = 6;                // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
+    u64 ms_piece_bytes = u64(32) << 20;   // GCSA2_MS_PIECE_MB: pattern bytes per piece of the large host batches of matching statistics / break points
     bool pipe_blocking = false;        // GCSA2_PIPE_BLOCKING=1: the lanes' events are made with hipEventBlockingSync
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
     bool pipe_wide = false;            // GCSA2_PIPE_WIRE=16: the packed-pattern pipeline brings the ranges home as u64 pairs (A/B)
@@ -709,6 +711,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.pipe_blocking = (knob("GCSA2_PIPE_BLOCKING", 0, 0, 1) != 0);
     ix->tune.pipe_wide = (knob("GCSA2_PIPE_WIRE", 0, 0, 16) == 16);
     ix->tune.ms_pieces = (knob("GCSA2_MS_PIECES", 1, 0, 1) != 0);
+    ix->tune.ms_piece_bytes = u64(knob("GCSA2_MS_PIECE_MB", 32, 1, 1024)) << 20;
     ix->tune.locate_trace = (knob("GCSA2_LOCATE_TRACE", 0, 0, 1) != 0);
     ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
     {
@@ -2452,6 +2455,10 @@ namespace {
 int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, u64 total_bytes,
                        uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st, const BreakSink* sink = nullptr);
 int group_comm_init(gcsa2_group* g);
+int match_breaks_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t min_length,
+                        uint64_t* break_offsets, gcsa2_break* breaks, uint64_t capacity, uint64_t* total_breaks, uint64_t* ranges, uint64_t* fallbacks);
+constexpr u64 MS_PIECED_MIN_BYTES = u64(64) << 20;      // (the piece size: tune.ms_piece_bytes, GCSA2_MS_PIECE_MB, 32 MB)
+constexpr unsigned MS_PIECE_THREADS = 4;
 }  // namespace
 
 #include "comm.hpp"
@@ -3301,9 +3308,14 @@ int gcsa2_match_breaks_batch(const gcsa2_index* ix, const uint8_t* patterns, con
   }
   *total_breaks = 0;
   if(nq == 0) { break_offsets[0] = 0; return GCSA2_OK; }
-  if(offsets[0] != 0 || !offsets_ok(offsets, nq)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets must start at 0 and be non-decreasing"); }
+  u64 longest = 0;
+  if(offsets[0] != 0 || !offsets_ok(offsets, nq, &longest)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets must start at 0 and be non-decreasing"); }
   try
   {
+    if(ix->tune.ms_pieces && offsets[nq] >= MS_PIECED_MIN_BYTES && longest <= ix->tune.ms_piece_bytes)
+    {
+      return match_breaks_pieced(ix, patterns, offsets, nq, min_length, break_offsets, breaks, capacity, total_breaks, ranges, fallbacks);
+    }
     DeviceGuard guard(ix->device);
     const u64 total = offsets[nq];
     Lease lease(ix);
@@ -3385,14 +3397,17 @@ int match_stats_single(const gcsa2_index* ix, const uint8_t* patterns, const uin
 }
 
 // A large host batch moves three times the pattern bytes over the link (one byte in, two out per position) and the kernel
-// is faster than that: it is cut into pieces of ~MS_PIECE_BYTES pattern bytes which MS_PIECE_THREADS host threads send through
+// is faster than that: it is cut into pieces of tune.ms_piece_bytes pattern bytes which MS_PIECE_THREADS host threads send through
 // the single-copy path, each on the stream and arenas of its own lease -- one piece's upload, another's kernel and a third's
 // download overlap.  (1 M x 256 bp on the chr22-like index: 22.4 ms = 45 M patterns/s in a row, 17.5 ms = 57 M/s in pieces;
 // eight threads or 8 MB pieces change nothing: what is left is the rate of copies to and from pageable memory,
 // tests/perf/ms_host_batch.py.  Staging those copies ourselves through a ring of pinned 2 MB pieces was measured and is
 // twice as slow as the runtime's own path for pageable memory: 47 ms in a row, 24-28 ms in pieces.)
-constexpr u64 MS_PIECE_BYTES = u64(16) << 20, MS_PIECED_MIN_BYTES = u64(64) << 20;
-constexpr unsigned MS_PIECE_THREADS = 4;
+// (pieces of tune.ms_piece_bytes = 32 MB (GCSA2_MS_PIECE_MB) for batches of MS_PIECED_MIN_BYTES = 64 MB and more, MS_PIECE_THREADS = 4: declared with
+// the forward declarations above.  Round 4 re-measured the piece size, 1 M x 256 bp: dense statistics on the chr22-like index 15.9-17.4 ms
+// with 16 MB, 15.0 with 32, 16.1 with 64, 18.9 with 128, 22.3 in one copy; break points of at least 20 bp on the 5.73 G-node index 24.5 /
+// 16.7 / 16.9 / 19.5 ms and 17.9 in one copy -- a piece must still fill the device: the kernel's time per pattern is latency, not work;
+// profiles/r04_host.md)
 
 int match_stats_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, u64 longest,
                        uint16_t* ms, uint64_t* ranges, uint64_t* fallbacks)
@@ -3402,7 +3417,7 @@ int match_stats_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uin
   {
     const u64 b = cut.back();
     u64 lo = b + 1, hi = nq;                               // largest e with offsets[e] - offsets[b] <= MS_PIECE_BYTES, at least one pattern
-    while(lo < hi) { const u64 mid = (lo + hi + 1) / 2; if(offsets[mid] - offsets[b] <= MS_PIECE_BYTES) { lo = mid; } else { hi = mid - 1; } }
+    while(lo < hi) { const u64 mid = (lo + hi + 1) / 2; if(offsets[mid] - offsets[b] <= ix->tune.ms_piece_bytes) { lo = mid; } else { hi = mid - 1; } }
     cut.push_back(lo);
   }
   const u64 pieces = cut.size() - 1;
@@ -3430,6 +3445,96 @@ int match_stats_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uin
   return GCSA2_OK;
 }
 
+// The break points of a large host batch, in pieces like the dense statistics above (a MEM finder's reads live in host memory:
+// one copy in, one kernel, copies out leaves the device idle two thirds of the time).  A piece's records land in the caller's
+// array behind those of the pieces before it, so the pieces COMMIT in order: when its kernel has finished a piece knows its
+// number of records, waits for the running total of the pieces before it (they started earlier; the wait is the tail of one
+// kernel at most), takes its place and downloads there.  The device-side record buffer of a piece is sized by an estimate
+// (one record per 8 pattern bytes; a piece that needs more runs again with the exact size).  Once the caller's capacity is
+// exceeded the remaining pieces only count: GCSA2_ERR_BUFFER_TOO_SMALL with the number of records of the whole batch.
+int match_breaks_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t min_length,
+                        uint64_t* break_offsets, gcsa2_break* breaks, uint64_t capacity, uint64_t* total_breaks, uint64_t* ranges, uint64_t* fallbacks)
+{
+  std::vector<u64> cut(1, 0);
+  while(cut.back() < nq)
+  {
+    const u64 b = cut.back();
+    u64 lo = b + 1, hi = nq;                               // largest e with offsets[e] - offsets[b] <= MS_PIECE_BYTES, at least one pattern
+    while(lo < hi) { const u64 mid = (lo + hi + 1) / 2; if(offsets[mid] - offsets[b] <= ix->tune.ms_piece_bytes) { lo = mid; } else { hi = mid - 1; } }
+    cut.push_back(lo);
+  }
+  const u64 pieces = cut.size() - 1;
+  const unsigned threads = unsigned(pieces < MS_PIECE_THREADS ? pieces : MS_PIECE_THREADS);
+  std::vector<int> status(threads, GCSA2_OK);
+  std::vector<std::string> messages(threads);
+  struct Order { std::mutex m; std::condition_variable cv; u64 next = 0, base = 0; bool failed = false; } order;
+  auto work = [&](unsigned t)
+  {
+    DeviceGuard guard(ix->device);
+    std::vector<u64> local;
+    auto give_up = [&](int rc, const std::string& what)
+    {
+      status[t] = rc; messages[t] = what;
+      std::lock_guard<std::mutex> hold(order.m);
+      order.failed = true;
+      order.cv.notify_all();
+    };
+    for(u64 c = t; c < pieces && status[t] == GCSA2_OK; c += threads)
+    {
+      const u64 b = cut[c], count = cut[c + 1] - b, first = offsets[b], bytes = offsets[b + count] - first;
+      local.resize(count + 1);
+      for(u64 i = 0; i <= count; i++) { local[i] = offsets[b + i] - first; }
+      u64 room = bytes / 8 + count + 1, found = 0;
+      bool placed = false;
+      for(int attempt = 0; attempt < 2 && !placed && status[t] == GCSA2_OK; attempt++)
+      {
+        Lease lease(ix);
+        hipError_t e = lease.begin(Lease::need(bytes + 16) + 2 * Lease::need((count + 1) * 8) + Lease::need(room * 32) + Lease::need(2 * count * 8) + Lease::need(count * 8));
+        if(e != hipSuccess) { give_up(GCSA2_ERR_OUT_OF_MEMORY, std::string("staging of a piece: ") + hipGetErrorString(e)); break; }
+        u8* d_pat = lease.dev<u8>(bytes + 16); u64* d_off = lease.dev<u64>(count + 1); u64* d_boff = lease.dev<u64>(count + 1);
+        gcsa2_break* d_brk = reinterpret_cast<gcsa2_break*>(lease.dev<u64>(4 * room));
+        u64* d_rng = lease.dev<u64>(2 * count); u64* d_fb = lease.dev<u64>(count);
+        e = lease.up(d_pat, patterns + first, bytes);
+        if(e == hipSuccess) { e = lease.up(d_off, local.data(), (count + 1) * sizeof(u64)); }
+        if(e != hipSuccess) { give_up(GCSA2_ERR_HIP, std::string("upload of a piece: ") + hipGetErrorString(e)); break; }
+        const int rc = gcsa2_match_breaks_device(ix, d_pat, d_off, count, bytes, 0, min_length, d_boff, d_brk, room, &found, d_rng, d_fb, lease.stream());
+        if(rc == GCSA2_ERR_BUFFER_TOO_SMALL && attempt == 0 && found > room) { room = found; (void)lease.finish(); continue; }    // the estimate was short: once more, exactly
+        if(rc != GCSA2_OK) { give_up(rc, g_error); break; }
+        // commit in piece order: the position of this piece's first record
+        u64 at = 0;
+        {
+          std::unique_lock<std::mutex> hold(order.m);
+          order.cv.wait(hold, [&]() { return order.next == c || order.failed; });
+          if(order.failed) { status[t] = GCSA2_ERR_HIP; messages[t] = "another piece of the batch failed"; break; }
+          at = order.base; order.base += found; order.next = c + 1;
+          order.cv.notify_all();
+        }
+        placed = true;
+        if(at + found <= capacity)
+        {
+          e = lease.down(local.data(), d_boff, (count + 1) * sizeof(u64));
+          if(e == hipSuccess && found > 0) { e = lease.down(breaks + at, d_brk, found * sizeof(gcsa2_break)); }
+          if(e == hipSuccess && ranges != nullptr) { e = lease.down(ranges + 2 * b, d_rng, 2 * count * sizeof(u64)); }
+          if(e == hipSuccess && fallbacks != nullptr) { e = lease.down(fallbacks + b, d_fb, count * sizeof(u64)); }
+          if(e == hipSuccess) { e = lease.finish(); }
+          if(e != hipSuccess) { give_up(GCSA2_ERR_HIP, std::string("download of a piece: ") + hipGetErrorString(e)); break; }
+          for(u64 i = 0; i <= count; i++) { break_offsets[b + i] = local[i] + at; }     // (the last entry is the next piece's first: same value)
+        }
+        else { (void)lease.finish(); }
+      }
+    }
+  };
+  Workers workers;
+  for(unsigned t = 1; t < threads; t++) { workers.emplace_back(work, t); }
+  work(0);
+  workers.join();
+  for(unsigned t = 0; t < threads; t++) { if(status[t] != GCSA2_OK && messages[t] != "another piece of the batch failed") { return fail(status[t], messages[t]); } }
+  for(unsigned t = 0; t < threads; t++) { if(status[t] != GCSA2_OK) { return fail(status[t], messages[t]); } }
+  *total_breaks = order.base;
+  if(order.base > capacity) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "break buffer too small"); }
+  return GCSA2_OK;
+}
+
 }  // namespace
 
 extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq,
@@ -3442,7 +3547,7 @@ extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* pat
   if(!offsets_ok(offsets, nq, &longest)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets are not non-decreasing"); }
   try
   {
-    if(ix->tune.ms_pieces && offsets[0] == 0 && offsets[nq] >= MS_PIECED_MIN_BYTES && longest <= MS_PIECE_BYTES)
+    if(ix->tune.ms_pieces && offsets[0] == 0 && offsets[nq] >= MS_PIECED_MIN_BYTES && longest <= ix->tune.ms_piece_bytes)
     {
       return match_stats_pieced(ix, patterns, offsets, nq, longest, ms, ranges, fallbacks);
     }

@@ -31,8 +31,9 @@ def main():
     p_out = (torch.empty(nq * m + 8, dtype=torch.int16).pin_memory().numpy().view(np.uint16), torch.empty((nq, 2), dtype=torch.int64).pin_memory().numpy().view(np.uint64),
              torch.empty(nq, dtype=torch.int64).pin_memory().numpy().view(np.uint64))
     want = None
-    for pieces in (1, 0, 1, 0):
+    for pieces, piece_mb in ((1, 16), (0, 16), (1, 32), (1, 64), (1, 16), (1, 128)):
         os.environ["GCSA2_MS_PIECES"] = str(pieces)
+        os.environ["GCSA2_MS_PIECE_MB"] = str(piece_mb)
         gpu, lcp = open_index(ix)
         got = gpu.match_stats_batch(flat, off)
         best = None
@@ -44,7 +45,7 @@ def main():
         if want is None:
             want = tuple(a.copy() for a in got)
         same = all(np.array_equal(a, b) for a, b in zip(got, want))
-        row = {"pieces": pieces, "ms": round(best * 1e3, 2), "patterns_per_s": round(nq / best / 1e6, 1), "same": same}
+        row = {"pieces": pieces, "piece_mb": piece_mb, "ms": round(best * 1e3, 2), "patterns_per_s": round(nq / best / 1e6, 1), "same": same}
         got = gpu.match_stats_batch(p_flat.numpy(), p_off.numpy().view(np.uint64), out=p_out)
         best = None
         for _ in range(3):

@@ -534,4 +534,27 @@ def test_match_stats_large_host_batch_in_pieces(monkeypatch):
     got = np.concatenate([gm[int(off[q]): int(off[q + 1])] for q in pick])
     assert np.array_equal(got, cm) and np.array_equal(gr[pick], cr) and np.array_equal(gf[pick], cf)
     assert int(gf.max()) > 0
+    # the break points of the same batch (gcsa2_match_breaks_batch): in pieces that commit their records in order == one copy,
+    # one launch; final ranges and parent() counts equal the dense run's; the records expand to the dense statistics; a
+    # capacity that is too small is refused with the number of records of the whole batch, which then fits
+    for min_length in (0, 12):
+        pb, pr, prng, pfb = gpu.match_breaks_batch(flat, off, min_length=min_length, capacity=(5 if min_length == 0 else None))
+        sb, sr_, srng, sfb = single.match_breaks_batch(flat, off, min_length=min_length)
+        assert np.array_equal(pb, sb) and np.array_equal(pr, sr_) and np.array_equal(prng, srng) and np.array_equal(pfb, sfb), min_length
+        assert np.array_equal(prng, gr) and np.array_equal(pfb, gf)
+        assert int(pb[-1]) == pr.shape[0] and bool((np.diff(pb.astype(np.int64)) >= 0).all())
+        if min_length > 0:
+            assert bool((pr[:, 1] >= min_length).all())
+    pb, pr, _, _ = gpu.match_breaks_batch(flat, off)
+    for q in pick[:1500]:
+        rec = pr[int(pb[q]): int(pb[q + 1])]                   # descending positions; ms[i] = length - (i - p) for the record with the largest p <= i
+        want = gm[int(off[q]): int(off[q + 1])]
+        L = int(lengths[q])
+        dense = np.zeros(L, dtype=np.int64)
+        end = L
+        for pos, length, _sp, _ep in rec:
+            pos, length = int(pos), int(length)
+            dense[pos:end] = length - (np.arange(pos, end) - pos)
+            end = pos
+        assert end == 0 and np.array_equal(dense, want.astype(np.int64)), q
     gpu.close(); single.close()
