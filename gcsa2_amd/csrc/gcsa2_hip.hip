@@ -3416,7 +3416,7 @@ int match_stats_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uin
   while(cut.back() < nq)
   {
     const u64 b = cut.back();
-    u64 lo = b + 1, hi = nq;                               // largest e with offsets[e] - offsets[b] <= MS_PIECE_BYTES, at least one pattern
+    u64 lo = b + 1, hi = nq;                               // largest e with offsets[e] - offsets[b] <= the piece size, at least one pattern
     while(lo < hi) { const u64 mid = (lo + hi + 1) / 2; if(offsets[mid] - offsets[b] <= ix->tune.ms_piece_bytes) { lo = mid; } else { hi = mid - 1; } }
     cut.push_back(lo);
   }
@@ -3459,7 +3459,7 @@ int match_breaks_pieced(const gcsa2_index* ix, const uint8_t* patterns, const ui
   while(cut.back() < nq)
   {
     const u64 b = cut.back();
-    u64 lo = b + 1, hi = nq;                               // largest e with offsets[e] - offsets[b] <= MS_PIECE_BYTES, at least one pattern
+    u64 lo = b + 1, hi = nq;                               // largest e with offsets[e] - offsets[b] <= the piece size, at least one pattern
     while(lo < hi) { const u64 mid = (lo + hi + 1) / 2; if(offsets[mid] - offsets[b] <= ix->tune.ms_piece_bytes) { lo = mid; } else { hi = mid - 1; } }
     cut.push_back(lo);
   }

@@ -398,7 +398,10 @@ typedef struct gcsa2_break { uint64_t position, length, sp, ep; } gcsa2_break;
 int gcsa2_match_breaks_device(const gcsa2_index* index, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t n_queries,
                               uint64_t total_pattern_bytes, int variant, uint64_t min_length, uint64_t* d_break_offsets, gcsa2_break* d_breaks,
                               uint64_t capacity, uint64_t* total_breaks, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream);
-/* The same for a batch in host memory (offsets[0] == 0): copies in, runs, copies the CSR out.  ranges / fallbacks may be NULL. */
+/* The same for a batch in host memory (offsets[0] == 0): copies in, runs, copies the CSR out.  ranges / fallbacks may be NULL.
+ * A batch of 64 MB or more of pattern bytes goes in pieces (32 MB each, GCSA2_MS_PIECE_MB; four host threads with a stream each)
+ * whose records are committed in pattern order; with GCSA2_ERR_BUFFER_TOO_SMALL (*total_breaks = the records of the whole batch)
+ * the contents of the result arrays are unspecified. */
 int gcsa2_match_breaks_batch(const gcsa2_index* index, const uint8_t* patterns, const uint64_t* offsets, uint64_t n_queries,
                              uint64_t min_length, uint64_t* break_offsets, gcsa2_break* breaks, uint64_t capacity,
                              uint64_t* total_breaks, uint64_t* ranges, uint64_t* fallbacks);
