@@ -109,6 +109,7 @@ struct gcsa2_index
     u64 locate_split_queries = u64(1) << 30; // GCSA2_LOCATE_SPLIT_QUERIES: most ranges one pass handles (its lists and grids are 32-bit)
     u64 pipe_chunk = u64(1) << 18;     // GCSA2_PIPE_CHUNK (log2): patterns per chunk of the host pipeline
     u32 pipe_lanes = 6;                // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
+    u32 ms_threads = 4;                   // GCSA2_MS_THREADS: host threads (one stream each) that send the pieces
     u64 ms_piece_bytes = u64(32) << 20;   // GCSA2_MS_PIECE_MB: pattern bytes per piece of the large host batches of matching statistics / break points
     bool pipe_blocking = false;        // GCSA2_PIPE_BLOCKING=1: the lanes' events are made with hipEventBlockingSync
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
@@ -712,6 +713,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.pipe_wide = (knob("GCSA2_PIPE_WIRE", 0, 0, 16) == 16);
     ix->tune.ms_pieces = (knob("GCSA2_MS_PIECES", 1, 0, 1) != 0);
     ix->tune.ms_piece_bytes = u64(knob("GCSA2_MS_PIECE_MB", 32, 1, 1024)) << 20;
+    ix->tune.ms_threads = u32(knob("GCSA2_MS_THREADS", 4, 1, 16));
     ix->tune.locate_trace = (knob("GCSA2_LOCATE_TRACE", 0, 0, 1) != 0);
     ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
     {
@@ -3421,7 +3423,7 @@ int match_stats_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uin
     cut.push_back(lo);
   }
   const u64 pieces = cut.size() - 1;
-  const unsigned threads = unsigned(pieces < MS_PIECE_THREADS ? pieces : MS_PIECE_THREADS);
+  const unsigned threads = unsigned(pieces < ix->tune.ms_threads ? pieces : ix->tune.ms_threads);
   std::vector<int> status(threads, GCSA2_OK);
   std::vector<std::string> messages(threads);
   auto work = [&](unsigned t)
@@ -3464,7 +3466,7 @@ int match_breaks_pieced(const gcsa2_index* ix, const uint8_t* patterns, const ui
     cut.push_back(lo);
   }
   const u64 pieces = cut.size() - 1;
-  const unsigned threads = unsigned(pieces < MS_PIECE_THREADS ? pieces : MS_PIECE_THREADS);
+  const unsigned threads = unsigned(pieces < ix->tune.ms_threads ? pieces : ix->tune.ms_threads);
   std::vector<int> status(threads, GCSA2_OK);
   std::vector<std::string> messages(threads);
   struct Order { std::mutex m; std::condition_variable cv; u64 next = 0, base = 0; bool failed = false; } order;
