@@ -2460,7 +2460,7 @@ int group_comm_init(gcsa2_group* g);
 int match_breaks_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t min_length,
                         uint64_t* break_offsets, gcsa2_break* breaks, uint64_t capacity, uint64_t* total_breaks, uint64_t* ranges, uint64_t* fallbacks);
 constexpr u64 MS_PIECED_MIN_BYTES = u64(64) << 20;      // (the piece size: tune.ms_piece_bytes, GCSA2_MS_PIECE_MB, 32 MB)
-constexpr unsigned MS_PIECE_THREADS = 4;
+
 }  // namespace
 
 #include "comm.hpp"

@@ -240,6 +240,48 @@ __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 id
   __builtin_amdgcn_wave_barrier();
 }
 
+// The same fetch with gfx950's direct global -> LDS loads (global_load_lds_dwordx4; the matching statistics use it, round 4): no
+// destination registers -- the eight requests of a wave are in flight without the 32 VGPRs the register form keeps for them
+// (k_match_stats2: 123 -> 109 VGPRs), and the request can be ISSUED long before its data is needed (fetch_blocks_issue ...
+// fetch_blocks_wait).  find() keeps the register form: same speed there (20.2-20.4 ms either way), it is bound by the request rate.  The instruction writes lane L's
+// 16 bytes at M0 + 16 L, i.e. linearly; the XOR swizzle of the slots therefore moves to the SOURCE side: the lane at
+// position `sub` of an owner's slot loads chunk sub ^ (owner & 7) of the block, which is the same layout as above.
+template<bool PAIR = false, bool LCPW = false>
+__device__ __forceinline__ void fetch_blocks_issue(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane,
+                                                   const u64* __restrict__ flp = nullptr, const u8* __restrict__ lcp = nullptr)
+{
+  const u32 sub = lane & 7;
+  __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): every read of the slots' previous contents has returned
+  __builtin_amdgcn_wave_barrier();
+  const u32 lds_base = __builtin_amdgcn_readfirstlane(u32(reinterpret_cast<size_t>(wave_stage)));     // LDS address of the wave's slots (uniform)
+#pragma unroll
+  for(u32 j = 0; j < 8; j++)
+  {
+    const u32 owner = 8 * j + (lane >> 3);
+    u32 oidx = __shfl(need ? idx : 0u, owner, 64);
+    const u64* base = flb;
+    u32 unit = FLB_WORDS;
+    if constexpr(PAIR) { base = (oidx & PAIR_FLAG) ? flp : flb; }
+    if constexpr(LCPW) { if(oidx & LCP_FLAG) { base = reinterpret_cast<const u64*>(lcp); unit = 2; } }
+    oidx &= ~(PAIR_FLAG | LCP_FLAG);
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(base + u64(oidx) * unit) + (sub ^ (owner & 7));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(size_t(lds_base + j * 1024u)), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ void fetch_blocks_wait()
+{
+  __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) on gfx9 encodings: vmcnt = 0, expcnt / lgkmcnt untouched
+  __builtin_amdgcn_wave_barrier();
+}
+template<bool PAIR = false, bool LCPW = false>
+__device__ __forceinline__ void fetch_blocks_direct(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane,
+                                                    const u64* __restrict__ flp = nullptr, const u8* __restrict__ lcp = nullptr)
+{
+  fetch_blocks_issue<PAIR, LCPW>(flb, idx, need, wave_stage, lane, flp, lcp);
+  fetch_blocks_wait();
+}
+
 __device__ __forceinline__ void read_block(const ulonglong2* wave_stage, u32 lane, ulonglong2 (&blk)[8])
 {
 #pragma unroll

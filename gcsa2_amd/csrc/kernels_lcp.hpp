@@ -516,10 +516,12 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   u32 force_single = 0;
   u64 win_code = 0;                         // packed pattern window, as in k_find2
   u32 win_used = ~u32(0), win_bad = 0;
-  // results: eight u16 per 16-byte store (`ms` is 8-byte aligned, the hardware takes the 16-byte store at any dword).  The
-  // statistics are a third of the kernel's memory requests -- every lane writes into its own pattern's 512 bytes, nothing
-  // coalesces across lanes -- so the only lever is fewer, wider stores per lane (8-byte stores: 64 per 256-bp pattern).
-  [[maybe_unused]] u64 packed_lo = 0, packed_hi = 0; [[maybe_unused]] u32 have = 0;
+  // results: sixteen u16 per flush, as two 16-byte stores back to back (`ms` is 8-byte aligned, the hardware takes the 16-byte
+  // store at any dword).  The statistics are a third of the kernel's memory requests -- every lane writes into its own
+  // pattern's 512 bytes, nothing coalesces across lanes -- so the only lever is fewer, wider writes per lane (8-byte stores: 64
+  // per 256-bp pattern; one 16-byte store per eight positions until round 4; a whole 32-byte sector at once: +3 % on a batch
+  // without mismatches, profiles/r04_match_stats.md).
+  [[maybe_unused]] u64 packed_lo = 0, packed_hi = 0, packed_2 = 0, packed_3 = 0; [[maybe_unused]] u32 have = 0;
   [[maybe_unused]] u32 last_break = ~u32(0), n_breaks = 0;     // BREAKS: position of the latest record, records of this pattern
   [[maybe_unused]] u64 blk_base = 0; [[maybe_unused]] u32 blk_used = BREAK_BLOCK;    // BREAKS: the wave's block of record slots (uniform)
   // (kept in a vector register on purpose: the kernel has no scalar registers to spare, and as a kernel argument the value was
@@ -532,27 +534,34 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   auto emit = [&](u32 pos, u32 value)        // ms[begin + pos] = value; positions arrive in descending order
   {
     if constexpr(BREAKS) { return; }
+    // sixteen statistics = one 32-byte sector per flush (two 16-byte stores back to back): a 16-byte store is half a
+    // sector, and its other half follows ~40 us later -- the memory side then pays for two partial writes
     const u64 idx = begin + pos;
-    const u32 slot = u32(idx & 7);
+    const u32 slot = u32(idx & 15), w = slot >> 2;
     const u64 field = u64(value > 65535 ? 65535 : value) << (16 * (slot & 3));
-    if(slot < 4) { packed_lo |= field; } else { packed_hi |= field; }
+    packed_lo |= (w == 0 ? field : 0); packed_hi |= (w == 1 ? field : 0); packed_2 |= (w == 2 ? field : 0); packed_3 |= (w == 3 ? field : 0);
     have |= 1u << slot;
     if(slot == 0 || pos == 0)
     {
-      unsigned short* group = ms + (idx & ~u64(7));
-      if(have == 0xFFu)
+      unsigned short* group = ms + (idx & ~u64(15));
+      typedef unsigned long long ull2 __attribute__((ext_vector_type(2), aligned(8)));
+      if(have == 0xFFFFu)
       {
-        typedef unsigned long long ull2 __attribute__((ext_vector_type(2), aligned(8)));
         *reinterpret_cast<ull2*>(group) = ull2{packed_lo, packed_hi};
+        *reinterpret_cast<ull2*>(group + 8) = ull2{packed_2, packed_3};
       }
       else
       {
-        if((have & 0x0Fu) == 0x0Fu) { *reinterpret_cast<u64*>(group) = packed_lo; }
-        else { for(u32 s = 0; s < 4; s++) { if((have >> s) & 1) { group[s] = (unsigned short)(packed_lo >> (16 * s)); } } }
-        if((have & 0xF0u) == 0xF0u) { *reinterpret_cast<u64*>(group + 4) = packed_hi; }
-        else { for(u32 s = 0; s < 4; s++) { if((have >> (4 + s)) & 1) { group[4 + s] = (unsigned short)(packed_hi >> (16 * s)); } } }
+        const u64 words[4] = {packed_lo, packed_hi, packed_2, packed_3};
+#pragma unroll
+        for(u32 k = 0; k < 4; k++)
+        {
+          const u32 h = (have >> (4 * k)) & 0xF;
+          if(h == 0xF) { *reinterpret_cast<u64*>(group + 4 * k) = words[k]; }
+          else { for(u32 t = 0; t < 4; t++) { if((h >> t) & 1) { group[4 * k + t] = (unsigned short)(words[k] >> (16 * t)); } } }
+        }
       }
-      packed_lo = 0; packed_hi = 0; have = 0;
+      packed_lo = 0; packed_hi = 0; packed_2 = 0; packed_3 = 0; have = 0;
     }
   };
   auto start = [&](u64 query)
@@ -586,8 +595,161 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     const u64 gid = u64(blockIdx.x) * TPB2 + threadIdx.x;
     if(gid < nq) { start(gid); }
   }
+  // Software-pipelined rounds (round 4; on the direct global -> LDS fetch, fetch_blocks_issue / _wait): as soon as a round's outcome is known the
+  // NEXT round's blocks are requested, and everything that does not feed that request -- the result stores, the break records,
+  // finished patterns, new patterns for idle lanes, the window refill -- runs while the requests are in flight.  A lane that
+  // starts a pattern joins with the following request (one round late).  The plan of a request (what was asked for, and where
+  // in the block the answer lies) lives across the loop edge in the registers the direct fetch no longer needs.
+  bool planned = false, pair = false;       // planned: this lane has a block (or LCP window) in flight
+  u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0, emit_code = 0;
+  u64 wstart = 0;
+  auto refill_window = [&]()
+  {
+    const bool active = has && i > 0;
+    // packed pattern window, as in k_find2: the 32 positions below i as 2-bit codes + "not a fast character" bits, slot r =
+    // position i - 1 - r; refilled from the pre-packed codes (k_pack_patterns): two words and a funnel shift, no loop
+    if(active && win_used > 24)
+    {
+      const u32 t0 = total - i, s = t0 & 31;
+      const u64 word = (begin >> 5) + q + (t0 >> 5);
+      const u64 c0 = codes[word], c1 = codes[word + 1];
+      const u32 b0 = bad[word], b1 = bad[word + 1];
+      win_code = (s == 0 ? c0 : (c0 >> (2 * s)) | (c1 << (64 - 2 * s)));
+      win_bad = (s == 0 ? b0 : (b0 >> s) | (b1 << (32 - s)));
+      win_used = 0;
+    }
+  };
+  auto plan_and_issue = [&]()
+  {
+    const bool active = has && i > 0;
+    planned = active;
+    const bool stepping = active && !need_parent, parenting = active && need_parent;
+    comp = 0; r_sp = 0; r_ep = 0; idx_sp = 0; idx_ep = 0; pair = false; wstart = 0;
+    if(parenting)
+    {
+      // parent(): the 128 bytes of the LCP array around the range, through the same cooperative fetch as the blocks
+      const u64 unit = sp >> 4;
+      wstart = (unit >= 3 ? unit - 3 : 0) << 4;
+      idx_sp = idx_ep = u32(wstart >> 4) | LCP_FLAG;
+    }
+    if(stepping)
+    {
+      const u32 r = win_used;                                  // window slot of position i - 1
+      if constexpr(PAIR)
+      {
+        if(force_single == 0 && i >= 2)
+        {
+          pair = ((win_bad >> r) & 3) == 0;
+          if(pair)
+          {
+            const u32 c2 = u32(win_code >> (2 * r)) & 3, c1 = u32(win_code >> (2 * r + 2)) & 3;
+            u32 b_sp, b_ep;
+            pair_block_of(sp, b_sp, r_sp); pair_block_of(ep + 1, b_ep, r_ep);
+            const u32 first = (c1 * 4 + c2) * u32(img.flp_nblocks);
+            idx_sp = (first + b_sp) | PAIR_FLAG; idx_ep = (first + b_ep) | PAIR_FLAG;
+          }
+        }
+      }
+      if(!pair)
+      {
+        if((win_bad >> r) & 1)
+        {
+          const u64 addr = reinterpret_cast<u64>(patterns) + begin + i - 1;
+          comp = c2c[u32(*reinterpret_cast<const u64*>(addr & ~u64(7)) >> ((addr & 7) * 8)) & 0xFF];
+        }
+        else { comp = 1 + (u32(win_code >> (2 * r)) & 3); }
+        u32 b_sp, b_ep;
+        flb_block_of(sp, b_sp, r_sp); flb_block_of(ep + 1, b_ep, r_ep);
+        idx_sp = comp * u32(img.flb_nblocks) + b_sp; idx_ep = comp * u32(img.flb_nblocks) + b_ep;
+      }
+    }
+
+    if(__any(active)) { fetch_blocks_issue<PAIR, true>(img.flb, idx_sp, active, wave_stage, lane, img.flp, img.lcp); }
+  };
+  refill_window();
+  plan_and_issue();
   while(true)
   {
+    const bool active = planned;
+    const bool stepping = active && !need_parent, parenting = active && need_parent;
+    PairEnd p_sp = {0, 0, 0}, p_ep = {0, 0, 0};                // a single step keeps (edge, node) in .raw / .node
+    const bool need2 = stepping && idx_ep != idx_sp;
+    gcsa2_stnode node;
+    bool decided = false;
+    emit_code = 0;
+    G2_TICK(1);
+    G2_COUNT(0, lane == 0); G2_COUNT(2, stepping); G2_COUNT(3, pair); G2_COUNT(7, need2);
+    if(__any(active))
+    {
+      fetch_blocks_wait();
+      if constexpr(PROF) { if(active) { asm volatile("" :: "v"(wave_stage[lane * 8 + (lane & 7)].x)); } }     // the fetch has landed
+      G2_TICK(2);
+      if(stepping)                               // one evaluation for single and pair steps alike (eval_staged)
+      {
+        p_sp = eval_staged(wave_stage, lane, PAIR && pair, r_sp, false);
+        if(idx_ep == idx_sp) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
+      }
+      G2_TICK(3);
+      if(parenting) { decided = parent_from_window(wave_stage, lane, wstart, img.lcp_size, sp, ep, node); G2_COUNT(5, 1); }
+      if constexpr(PROF) { if(parenting && decided) { asm volatile("" :: "v"(node.sp)); } }
+      G2_TICK(6);
+      if(__any(need2))
+      {
+        G2_COUNT(1, lane == 0);
+        __builtin_amdgcn_wave_barrier();
+        fetch_blocks_direct<PAIR>(img.flb, idx_ep, need2, wave_stage, lane, img.flp);
+        if(need2) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
+      }
+      __builtin_amdgcn_wave_barrier();
+      G2_TICK(4);
+    }
+    if(stepping)
+    {
+      if(PAIR && pair)
+      {
+        u64 a = 0, b = 0;
+        if(pair_outcome(p_sp, p_ep, idx_ep == idx_sp, a, b) == 2)          // neither step empties (layout.hpp)
+        {
+          sp = p_sp.node; ep = p_ep.node;
+          emit_code = 2;
+          depth += 2; i -= 2; win_used += 2;
+        }
+        else { force_single = 2; G2_COUNT(4, 1); }             // an emptying step needs parent(): one character at a time
+      }
+      else
+      {
+        const u64 a = p_sp.raw, b = p_ep.raw - 1;              // gcsa.h:155-162
+        if(!range_empty(a, b))
+        {
+          sp = p_sp.node; ep = p_ep.node; depth++;
+          emit_code = 1; i--; win_used++;
+          force_single -= (force_single > 0 ? 1 : 0);
+        }
+        else if(sp == 0 && ep == img.n - 1)                    // at the root: no such character
+        {
+          depth = 0;
+          if constexpr(BREAKS) { pending = true; }
+          emit_code = 1; i--; win_used++;
+          force_single -= (force_single > 0 ? 1 : 0);
+        }
+        else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }   // parent() in the next round
+      }
+    }
+    G2_TICK(5);
+    if(parenting)
+    {
+      if(!decided) { lcp_parent(img, sp, ep, node); G2_COUNT(6, 1); }      // the interval reaches beyond the window: tree walk (lcp.cpp:276-301)
+      calls++;
+      sp = node.sp; ep = node.ep; depth = u32(node.node_lcp);
+      need_parent = false;
+    }
+    G2_TICK(7);
+    plan_and_issue();                                            // the next round's requests leave here
+    if constexpr(!BREAKS)                                        // the statistics of the step just taken (positions i + 1 / i after the update)
+    {
+      if(emit_code == 2) { emit(i + 1, depth - 1); }
+      if(emit_code != 0) { emit(i, depth); }
+    }
     [[maybe_unused]] bool was_pending = false;
     if constexpr(BREAKS)
     {
@@ -660,132 +822,8 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     {
       if(!__any(has)) { break; }
     }
-    const bool active = has && i > 0;
-    // packed pattern window, as in k_find2: the 32 positions below i as 2-bit codes + "not a fast character" bits, slot r =
-    // position i - 1 - r; refilled from the pre-packed codes (k_pack_patterns): two words and a funnel shift, no loop
-    if(active && win_used > 24)
-    {
-      const u32 t0 = total - i, s = t0 & 31;
-      const u64 word = (begin >> 5) + q + (t0 >> 5);
-      const u64 c0 = codes[word], c1 = codes[word + 1];
-      const u32 b0 = bad[word], b1 = bad[word + 1];
-      win_code = (s == 0 ? c0 : (c0 >> (2 * s)) | (c1 << (64 - 2 * s)));
-      win_bad = (s == 0 ? b0 : (b0 >> s) | (b1 << (32 - s)));
-      win_used = 0;
-    }
+    refill_window();
     G2_TICK(0);
-    const bool stepping = active && !need_parent, parenting = active && need_parent;
-    u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0;
-    bool pair = false;
-    u64 wstart = 0;
-    if(parenting)
-    {
-      // parent(): the 128 bytes of the LCP array around the range, through the same cooperative fetch as the blocks
-      const u64 unit = sp >> 4;
-      wstart = (unit >= 3 ? unit - 3 : 0) << 4;
-      idx_sp = idx_ep = u32(wstart >> 4) | LCP_FLAG;
-    }
-    if(stepping)
-    {
-      const u32 r = win_used;                                  // window slot of position i - 1
-      if constexpr(PAIR)
-      {
-        if(force_single == 0 && i >= 2)
-        {
-          pair = ((win_bad >> r) & 3) == 0;
-          if(pair)
-          {
-            const u32 c2 = u32(win_code >> (2 * r)) & 3, c1 = u32(win_code >> (2 * r + 2)) & 3;
-            u32 b_sp, b_ep;
-            pair_block_of(sp, b_sp, r_sp); pair_block_of(ep + 1, b_ep, r_ep);
-            const u32 first = (c1 * 4 + c2) * u32(img.flp_nblocks);
-            idx_sp = (first + b_sp) | PAIR_FLAG; idx_ep = (first + b_ep) | PAIR_FLAG;
-          }
-        }
-      }
-      if(!pair)
-      {
-        if((win_bad >> r) & 1)
-        {
-          const u64 addr = reinterpret_cast<u64>(patterns) + begin + i - 1;
-          comp = c2c[u32(*reinterpret_cast<const u64*>(addr & ~u64(7)) >> ((addr & 7) * 8)) & 0xFF];
-        }
-        else { comp = 1 + (u32(win_code >> (2 * r)) & 3); }
-        u32 b_sp, b_ep;
-        flb_block_of(sp, b_sp, r_sp); flb_block_of(ep + 1, b_ep, r_ep);
-        idx_sp = comp * u32(img.flb_nblocks) + b_sp; idx_ep = comp * u32(img.flb_nblocks) + b_ep;
-      }
-    }
-    PairEnd p_sp = {0, 0, 0}, p_ep = {0, 0, 0};                // a single step keeps (edge, node) in .raw / .node
-    const bool need2 = stepping && idx_ep != idx_sp;
-    gcsa2_stnode node;
-    bool decided = false;
-    G2_TICK(1);
-    G2_COUNT(0, lane == 0); G2_COUNT(2, stepping); G2_COUNT(3, pair); G2_COUNT(7, need2);
-    {
-      fetch_blocks<PAIR, true>(img.flb, idx_sp, active, wave_stage, lane, img.flp, img.lcp);
-      if constexpr(PROF) { if(active) { asm volatile("" :: "v"(wave_stage[lane * 8 + (lane & 7)].x)); } }     // the fetch has landed
-      G2_TICK(2);
-      if(stepping)                               // one evaluation for single and pair steps alike (eval_staged)
-      {
-        p_sp = eval_staged(wave_stage, lane, PAIR && pair, r_sp, false);
-        if(idx_ep == idx_sp) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
-      }
-      G2_TICK(3);
-      if(parenting) { decided = parent_from_window(wave_stage, lane, wstart, img.lcp_size, sp, ep, node); G2_COUNT(5, 1); }
-      if constexpr(PROF) { if(parenting && decided) { asm volatile("" :: "v"(node.sp)); } }
-      G2_TICK(6);
-      if(__any(need2))
-      {
-        G2_COUNT(1, lane == 0);
-        __builtin_amdgcn_wave_barrier();
-        fetch_blocks<PAIR>(img.flb, idx_ep, need2, wave_stage, lane, img.flp);
-        if(need2) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
-      }
-      __builtin_amdgcn_wave_barrier();
-      G2_TICK(4);
-    }
-    if(stepping)
-    {
-      if(PAIR && pair)
-      {
-        u64 a = 0, b = 0;
-        if(pair_outcome(p_sp, p_ep, idx_ep == idx_sp, a, b) == 2)          // neither step empties (layout.hpp)
-        {
-          sp = p_sp.node; ep = p_ep.node;
-          emit(i - 1, depth + 1); emit(i - 2, depth + 2);
-          depth += 2; i -= 2; win_used += 2;
-        }
-        else { force_single = 2; G2_COUNT(4, 1); }             // an emptying step needs parent(): one character at a time
-      }
-      else
-      {
-        const u64 a = p_sp.raw, b = p_ep.raw - 1;              // gcsa.h:155-162
-        if(!range_empty(a, b))
-        {
-          sp = p_sp.node; ep = p_ep.node; depth++;
-          emit(i - 1, depth); i--; win_used++;
-          force_single -= (force_single > 0 ? 1 : 0);
-        }
-        else if(sp == 0 && ep == img.n - 1)                    // at the root: no such character
-        {
-          depth = 0;
-          if constexpr(BREAKS) { pending = true; }
-          emit(i - 1, 0); i--; win_used++;
-          force_single -= (force_single > 0 ? 1 : 0);
-        }
-        else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }   // parent() in the next round
-      }
-    }
-    G2_TICK(5);
-    if(parenting)
-    {
-      if(!decided) { lcp_parent(img, sp, ep, node); G2_COUNT(6, 1); }      // the interval reaches beyond the window: tree walk (lcp.cpp:276-301)
-      calls++;
-      sp = node.sp; ep = node.ep; depth = u32(node.node_lcp);
-      need_parent = false;
-    }
-    G2_TICK(7);
   }
   if constexpr(BREAKS)
   {
