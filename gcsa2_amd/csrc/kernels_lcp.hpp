@@ -448,6 +448,9 @@ __device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage,
 // (lcp.cpp:276-301) -- the 128 bytes of the LCP array around its range travel through the same cooperative fetch as the other
 // lanes' blocks and decide the call in all but a few per cent of the cases (parent_from_window) -- and retries the character
 // in the round after that.
+// Round 4: the blocks and LCP windows arrive through gfx950's direct global -> LDS loads (fetch_blocks_issue / _wait,
+// kernels_find.hpp), and the rounds are software-pipelined: the requests of round k + 1 leave as soon as the outcome of round k
+// is known; the result stores, the break records, finished and new patterns and the window refill run under them.
 // After a step that needed parent() the next COOL_DOWN characters are stepped singly: right after a mismatch the match is
 // short and the following characters fail often, so a pair attempt mostly wastes its round (deep suffix tree, 37 parent()
 // calls per pattern: 60 -> 68 M patterns/s with 6; 3 / 12 / 24 give 67 / 67 / 66; profiles/r02_config5.md).
