@@ -3428,16 +3428,20 @@ int match_stats_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uin
   std::vector<std::string> messages(threads);
   auto work = [&](unsigned t)
   {
-    std::vector<u64> local;
-    for(u64 c = t; c < pieces && status[t] == GCSA2_OK; c += threads)
+    try                                   // (an exception must not leave a worker thread: std::terminate)
     {
-      const u64 b = cut[c], count = cut[c + 1] - b, base = offsets[b];
-      local.resize(count + 1);
-      for(u64 i = 0; i <= count; i++) { local[i] = offsets[b + i] - base; }
-      status[t] = match_stats_single(ix, patterns + base, local.data(), count, longest, ms + base, ranges + 2 * b,
-                                     fallbacks != nullptr ? fallbacks + b : nullptr);
-      if(status[t] != GCSA2_OK) { messages[t] = g_error; }
+      std::vector<u64> local;
+      for(u64 c = t; c < pieces && status[t] == GCSA2_OK; c += threads)
+      {
+        const u64 b = cut[c], count = cut[c + 1] - b, base = offsets[b];
+        local.resize(count + 1);
+        for(u64 i = 0; i <= count; i++) { local[i] = offsets[b + i] - base; }
+        status[t] = match_stats_single(ix, patterns + base, local.data(), count, longest, ms + base, ranges + 2 * b,
+                                       fallbacks != nullptr ? fallbacks + b : nullptr);
+        if(status[t] != GCSA2_OK) { messages[t] = g_error; }
+      }
     }
+    catch(const std::exception& e) { status[t] = GCSA2_ERR_OUT_OF_MEMORY; messages[t] = std::string("a piece of the batch: ") + e.what(); }
   };
   Workers workers;
   for(unsigned t = 1; t < threads; t++) { workers.emplace_back(work, t); }
@@ -3481,6 +3485,7 @@ int match_breaks_pieced(const gcsa2_index* ix, const uint8_t* patterns, const ui
       order.failed = true;
       order.cv.notify_all();
     };
+    try {
     for(u64 c = t; c < pieces && status[t] == GCSA2_OK; c += threads)
     {
       const u64 b = cut[c], count = cut[c + 1] - b, first = offsets[b], bytes = offsets[b + count] - first;
@@ -3525,6 +3530,7 @@ int match_breaks_pieced(const gcsa2_index* ix, const uint8_t* patterns, const ui
         else { (void)lease.finish(); }
       }
     }
+    } catch(const std::exception& e) { give_up(GCSA2_ERR_OUT_OF_MEMORY, std::string("a piece of the batch: ") + e.what()); }     // (not out of a worker thread)
   };
   Workers workers;
   for(unsigned t = 1; t < threads; t++) { workers.emplace_back(work, t); }
