@@ -437,6 +437,14 @@ def test_pangenome_index_beyond_32_bits():
     gpu.find_device(d_flat4.data_ptr(), d_off4.data_ptr(), nw, d_out4.data_ptr(), st)
     torch.cuda.synchronize()
     assert gpu.kmer_table_k() == k_full and torch.equal(d_out4[:nw, 0], exp4[:nw])
+    # (iv) countKMers (src/algorithms.cpp:387-421) in closed form: the distinct k-prefixes of the node labels, from the bitmap of the
+    # 17-mer universe (workload/dbg_torch.py::distinct_prefixes, pinned on the oracle at small degrees in tests/test_workload.py).
+    # k = 16: 3.4 G k-mers; k = 17 = the order: one per path node, through a frontier of 3.4 G states cut into 64 M-state pieces
+    order = degree // 2
+    counted = {k: gpu.count_kmers(k) for k in (11, order - 1, order)}
+    for k, got in counted.items():
+        assert got == dbg_torch.distinct_prefixes(dbg.nodes, order, k), k
+    assert counted[order] == ix.n and gpu.count_kmers(order + 1) == 0                 # beyond the order: 0 unless forced (algorithms.cpp:391-395)
 
 
 def test_branching_footprint_index_closed_form():

@@ -538,6 +538,22 @@ def test_repeat_rich_backbone():
     assert mean_occurrences(a) > 20 and mean_occurrences(graphs.random_bases(n, 0x6C5A0020)) < 1.01
 
 
+@pytest.mark.parametrize("degree,junctions", [(10, 80), (12, 0), (16, 80)])
+def test_dbg_kmer_counts_closed_form(degree, junctions):
+    """countKMers(k) on the de Bruijn indexes in closed form (workload/dbg_torch.py::distinct_prefixes: the distinct k-prefixes of
+    the node labels, read off the bitmap of the k-mer universe) equals what the oracle counts by walking the LF search tree
+    (src/algorithms.cpp:387-421), for every k up to the order; junction edges between existing nodes add no k-mer."""
+    import torch
+    from workload import dbg_torch
+    from oracle.oracle import OracleIndex
+    order = degree // 2
+    ix, wl = dbg_torch.build_dbg(degree, junctions=junctions, device=torch.device("cpu"))
+    cpu = OracleIndex(ix)
+    for k in range(1, order + 1):
+        assert dbg_torch.distinct_prefixes(wl.nodes, order, k) == cpu.count_kmers(k), k
+    assert dbg_torch.distinct_prefixes(wl.nodes, order, order) == ix.n
+
+
 @pytest.mark.parametrize("degree,junctions", [(12, 80), (16, 0)])
 def test_dbg_prefix_patterns_closed_form(degree, junctions):
     """find() of the first m < k characters of a path label = the interval of the bitmap ranks of the k-mers with that prefix

@@ -420,6 +420,40 @@ def build_dbg(degree: int, period: int = 0, junctions: int = 0, device=None, ver
     return ix, wl
 
 
+def distinct_prefixes(nodes, order, k):
+    """Number of distinct k-prefixes of the node set (k <= order), from its packed bitmap (value = first character highest): the
+    closed form of countKMers(k) on these indexes -- every k-mer of a de Bruijn graph of that order is a prefix of a node label,
+    and junction edges between existing nodes add none (reference: src/algorithms.cpp:387-421 counts the non-empty states at
+    depth k of the LF search tree)."""
+    drop = 2 * (order - k)                      # low bits of the value that a prefix ignores
+    w = nodes.words
+    if drop >= 6:
+        group = 1 << (drop - 6)                 # whole words per prefix
+        total = 0
+        chunk = (1 << 24) // max(1, group) * group or group
+        for b in range(0, w.shape[0], chunk):
+            part = w[b:b + chunk]
+            pad = (-part.shape[0]) % group
+            if pad:
+                part = torch.cat([part, torch.zeros(pad, dtype=part.dtype, device=part.device)])
+            total += int((part.view(-1, group) != 0).any(dim=1).sum().item())
+        return total
+    width = 1 << drop                           # bits per prefix inside a word: 1, 4 or 16
+    total = 0
+    mask = {1: -1, 4: 0x1111111111111111, 16: 0x0001000100010001}[width]
+    for b in range(0, w.shape[0], 1 << 24):
+        x = w[b:b + (1 << 24)].clone()
+        s = 1
+        while s < width:
+            x |= (x >> s) & ((1 << (64 - s)) - 1 if s else -1)       # logical shift on int64
+            s <<= 1
+        if mask != -1:
+            x &= mask - (1 << 64) if mask >= (1 << 63) else mask
+        total += int(popcount64(x).sum().item())
+    return total
+
+
+
 def cycle_graph(degree: int):
     """The input graph of the plain text: one cycle of P positions (no source / sink)."""
     from .graphs import Graph
