@@ -93,6 +93,10 @@ def test_two_ranks_share_the_gpu_through_the_host(wire):
     # config 5 sharded over the two ranks: matching statistics and the CSR of located values gathered on the root
     c5 = d["config5"]
     assert c5["n_gpus"] == 2 and c5["unmodified_half_equals_closed_form"] is True
+    # both went through the library's C++ (gcsa2_comm_gather / _match_stats / _locate over the host-memory transport of
+    # gcsa2_comm_create_custom), not through the Python mirror of the sharding
+    assert d["multi_gpu"]["gather"].startswith("gcsa2_comm_gather over a host-memory transport") and d["multi_gpu"]["rccl_ranks"] == 0
+    assert "gcsa2_comm_match_stats / gcsa2_comm_locate over a host-memory transport" in c5["workload"]
     assert c5["locate"]["count_equals_located"] is True and c5["locate"]["unmodified_half_equals_closed_form"] is True
 
 
