@@ -248,24 +248,31 @@ __device__ __forceinline__ void fetch_blocks(const u64* __restrict__ flb, u32 id
 // position `sub` of an owner's slot loads chunk sub ^ (owner & 7) of the block, which is the same layout as above.
 template<bool PAIR = false, bool LCPW = false>
 __device__ __forceinline__ void fetch_blocks_issue(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane,
-                                                   const u64* __restrict__ flp = nullptr, const u8* __restrict__ lcp = nullptr)
+                                                   const u64* __restrict__ flp, const u8* __restrict__ lcp, u64* wave_addr)
 {
-  const u32 sub = lane & 7;
+  // Every lane works out the address of ITS block once and publishes it in a 64-entry table of the wave in LDS (`wave_addr`);
+  // the eight lanes that fetch a block read it from there -- one LDS round trip for the whole fetch.  (Round 4's first form
+  // sent the 32-bit index through ds_bpermute and rebuilt the address -- array, unit, 64-bit multiply -- in each of the eight
+  // iterations, every one waiting for its own permute: 150 instructions and eight LDS latencies per fetch.)
+  const u64* base = flb;
+  u32 unit = FLB_WORDS;                                     // u64 words per index step
+  if constexpr(PAIR) { base = (idx & PAIR_FLAG) ? flp : flb; }
+  if constexpr(LCPW) { if(idx & LCP_FLAG) { base = reinterpret_cast<const u64*>(lcp); unit = 2; } }
+  const u64 mine = reinterpret_cast<u64>(need ? base + u64(idx & ~(PAIR_FLAG | LCP_FLAG)) * unit : flb);
   __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): every read of the slots' previous contents has returned
   __builtin_amdgcn_wave_barrier();
+  wave_addr[lane] = mine;
+  __builtin_amdgcn_wave_barrier();
   const u32 lds_base = __builtin_amdgcn_readfirstlane(u32(reinterpret_cast<size_t>(wave_stage)));     // LDS address of the wave's slots (uniform)
+  const u32 group = lane >> 3;
+  const u64 chunk = u64(((lane & 7) ^ (group & 7)) * 16);       // the swizzle on the source side: (8 j + group) & 7 = group & 7
+  u64 src[8];
+#pragma unroll
+  for(u32 j = 0; j < 8; j++) { src[j] = wave_addr[8 * j + group]; }
 #pragma unroll
   for(u32 j = 0; j < 8; j++)
   {
-    const u32 owner = 8 * j + (lane >> 3);
-    u32 oidx = __shfl(need ? idx : 0u, owner, 64);
-    const u64* base = flb;
-    u32 unit = FLB_WORDS;
-    if constexpr(PAIR) { base = (oidx & PAIR_FLAG) ? flp : flb; }
-    if constexpr(LCPW) { if(oidx & LCP_FLAG) { base = reinterpret_cast<const u64*>(lcp); unit = 2; } }
-    oidx &= ~(PAIR_FLAG | LCP_FLAG);
-    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(base + u64(oidx) * unit) + (sub ^ (owner & 7));
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + chunk),
                                      (__attribute__((address_space(3))) void*)(size_t(lds_base + j * 1024u)), 16, 0, 0);
   }
 }
@@ -276,9 +283,9 @@ __device__ __forceinline__ void fetch_blocks_wait()
 }
 template<bool PAIR = false, bool LCPW = false>
 __device__ __forceinline__ void fetch_blocks_direct(const u64* __restrict__ flb, u32 idx, bool need, ulonglong2* wave_stage, u32 lane,
-                                                    const u64* __restrict__ flp = nullptr, const u8* __restrict__ lcp = nullptr)
+                                                    const u64* __restrict__ flp, const u8* __restrict__ lcp, u64* wave_addr)
 {
-  fetch_blocks_issue<PAIR, LCPW>(flb, idx, need, wave_stage, lane, flp, lcp);
+  fetch_blocks_issue<PAIR, LCPW>(flb, idx, need, wave_stage, lane, flp, lcp, wave_addr);
   fetch_blocks_wait();
 }
 

@@ -466,8 +466,10 @@ constexpr u64 MS_REFILL_MIN = u64(1) << 19;             // host-pointer API: sma
 // and mismatching patterns of one length gains nothing either, a round costs a wave the same whether 32 or 64 lanes take it
 // (profiles/r02_config5.md).
 // PROF = true (gcsa2_match_stats_profile_device, a diagnostic): shader-clock cycles per phase of the round, summed over the
-// waves, and event counts, added to prof[0..15]: 0 loop head / window, 1 step setup, 2 first fetch, 3 first evaluation,
-// 4 second fetch + evaluation, 5 outcome + statistics, 6 parent() from the LCP window, 7 parent() tree walk; 8 rounds (per wave),
+// waves, and event counts, added to prof[0..15]: 0 statistics stores + loop head (records, finished / new patterns) + window
+// refill -- all under the requests in flight since round 4 --, 1 step setup + issue of the next round's requests, 2 the wait
+// for the requests, 3 first evaluation, 4 second fetch + evaluation, 5 outcome, 6 parent() from the LCP window, 7 parent() tree
+// walk; 8 rounds (per wave),
 // 9 rounds with a second fetch, 10 lane steps, 11 lane pair attempts, 12 failed pair attempts, 13 parent() calls, 14 tree walks,
 // 15 lane second fetches.
 // BREAKS = true (gcsa2_match_breaks_device): instead of one statistic per pattern position the kernel reports the BREAK POINTS
@@ -503,12 +505,14 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
 #define G2_TICK(phase) do { if constexpr(PROF) { const u64 now_ = clock64(); prof_c[phase] += now_ - prof_t; prof_t = now_; } } while(0)
 #define G2_COUNT(slot, value) do { if constexpr(PROF) { prof_n[slot] += u32(value); } } while(0)
   __shared__ ulonglong2 stage[TPB2 * 8];
+  __shared__ u64 addr_table[TPB2];          // the block address of every lane, for the eight lanes that fetch it (fetch_blocks_issue)
   __shared__ u8 c2c[256];
   c2c[threadIdx.x] = img.char2comp[threadIdx.x];
   c2c[threadIdx.x + TPB2] = img.char2comp[threadIdx.x + TPB2];
   __syncthreads();
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  u64* wave_addr = addr_table + (threadIdx.x & ~63u);
   u64 q = 0, begin = 0;
   u32 i = 0, total = 0;                     // characters left / in all (a pattern is shorter than 2^32 characters)
   bool has = false;
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       }
     }
 
-    if(__any(active)) { fetch_blocks_issue<PAIR, true>(img.flb, idx_sp, active, wave_stage, lane, img.flp, img.lcp); }
+    if(__any(active)) { fetch_blocks_issue<PAIR, true>(img.flb, idx_sp, active, wave_stage, lane, img.flp, img.lcp, wave_addr); }
   };
   refill_window();
   plan_and_issue();
@@ -680,7 +684,6 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     gcsa2_stnode node;
     bool decided = false;
     emit_code = 0;
-    G2_TICK(1);
     G2_COUNT(0, lane == 0); G2_COUNT(2, stepping); G2_COUNT(3, pair); G2_COUNT(7, need2);
     if(__any(active))
     {
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       {
         G2_COUNT(1, lane == 0);
         __builtin_amdgcn_wave_barrier();
-        fetch_blocks_direct<PAIR>(img.flb, idx_ep, need2, wave_stage, lane, img.flp);
+        fetch_blocks_direct<PAIR>(img.flb, idx_ep, need2, wave_stage, lane, img.flp, nullptr, wave_addr);
         if(need2) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
       }
       __builtin_amdgcn_wave_barrier();
@@ -748,6 +751,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     }
     G2_TICK(7);
     plan_and_issue();                                            // the next round's requests leave here
+    G2_TICK(1);
     if constexpr(!BREAKS)                                        // the statistics of the step just taken (positions i + 1 / i after the update)
     {
       if(emit_code == 2) { emit(i + 1, depth - 1); }

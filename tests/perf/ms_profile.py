@@ -13,8 +13,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-PHASES = ["loop head / window", "step setup", "first fetch", "first evaluation", "second fetch + evaluation", "outcome + statistics",
-          "parent() from chunks", "parent() tree walk"]
+PHASES = ["stores + loop head + window refill (under the requests in flight)", "step setup + issue of the next requests", "wait for the requests", "first evaluation",
+          "second fetch + evaluation", "outcome", "parent() from the LCP window", "parent() tree walk"]
 EVENTS = ["rounds (per wave)", "rounds with a second fetch", "lane steps", "pair attempts", "failed pair attempts", "parent() calls",
           "tree walks", "lane second fetches"]
 
