@@ -405,24 +405,37 @@ __global__ __launch_bounds__(TPB) void k_pack_patterns(DevImage img, const u8* _
 // After a failed LF step the climb rarely passes intervals of a few dozen path nodes (a range of w nodes extends with
 // probability 1 - 0.73^w on a whole-genome index), so the window decides nearly every call; round 2's two 16-byte chunks left
 // 39 % of the calls to the tree walk, which then was 44 % of the kernel's time (profiles/r03_match_stats.md).
+// bit 8 k + 7 set iff byte k of w < bound (bound <= 255): the bytes of each 32-bit half in 16-bit lanes, borrow-free subtract;
+// the flags stay where the bytes are, so that the nearest one is a count of leading / trailing zeros away (bytes_below above
+// compacts them to eight bits: half of its instructions)
+__device__ __forceinline__ u64 below_flags(u64 w, u32 bound)
+{
+  const u32 lo = u32(w), hi = u32(w >> 32), v = bound * 0x00010001u, H = 0x80008000u, M = 0x00FF00FFu;
+  const u32 e_lo = ((lo & M) | H) - v, o_lo = (((lo >> 8) & M) | H) - v;          // lane bit 15 CLEAR iff the byte < bound
+  const u32 e_hi = ((hi & M) | H) - v, o_hi = (((hi >> 8) & M) | H) - v;
+  const u32 f_lo = ((~e_lo & H) >> 8) | (~o_lo & H);                               // even bytes: bit 16 j + 15 -> 16 j + 7
+  const u32 f_hi = ((~e_hi & H) >> 8) | (~o_hi & H);
+  return u64(f_lo) | (u64(f_hi) << 32);
+}
+
 __device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage, u32 lane, u64 wstart, u64 lcp_size, u64 sp, u64 ep,
                                                    gcsa2_stnode& out)
 {
   if(sp == 0 || ep + 2 >= lcp_size || ep + 1 >= wstart + 128) { return false; }
   const u32 lo = u32(sp - wstart), ro = u32(ep + 1 - wstart);              // byte offsets of LCP[sp], LCP[ep + 1] in the window
   const u64 lw = staged_word(wave_stage, lane, lo >> 3), rw = staged_word(wave_stage, lane, ro >> 3);
-  const u64 left_lcp = (lw >> (8 * (lo & 7))) & 0xFF, right_lcp = (rw >> (8 * (ro & 7))) & 0xFF;
-  const u64 node_lcp = (left_lcp > right_lcp ? left_lcp : right_lcp);
+  const u32 left_lcp = u32(lw >> (8 * (lo & 7))) & 0xFF, right_lcp = u32(rw >> (8 * (ro & 7))) & 0xFF;
+  const u32 node_lcp = (left_lcp > right_lcp ? left_lcp : right_lcp);
   u64 lpos = sp, lval = left_lcp, rpos = ep + 1, rval = right_lcp;
   bool decided = true;
   if(left_lcp == node_lcp)
   {
     u32 w = lo >> 3;
     u64 word = lw;
-    u32 mask = bytes_below(word, left_lcp) & ((1u << (lo & 7)) - 1);
-    while(mask == 0 && w > 0) { w--; word = staged_word(wave_stage, lane, w); mask = bytes_below(word, left_lcp); }
-    if(mask == 0) { decided = false; }
-    else { const u32 byte = 31 - __clz(int(mask)); lpos = wstart + 8 * w + byte; lval = (word >> (8 * byte)) & 0xFF; }
+    u64 flags = below_flags(word, left_lcp) & ((u64(1) << (8 * (lo & 7))) - 1);          // the bytes before LCP[sp] in its word
+    while(flags == 0 && w > 0) { w--; word = staged_word(wave_stage, lane, w); flags = below_flags(word, left_lcp); }
+    if(flags == 0) { decided = false; }
+    else { const u32 byte = (63u - u32(__clzll((long long)flags))) >> 3; lpos = wstart + 8 * w + byte; lval = (word >> (8 * byte)) & 0xFF; }
   }
   if(right_lcp == node_lcp)
   {
@@ -430,11 +443,11 @@ __device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage,
     const u32 last = (wstart + 128 <= lcp_size ? 15u : u32((lcp_size - 1 - wstart) >> 3));
     u32 w = ro >> 3;
     u64 word = rw;
-    u32 mask = bytes_below(word, right_lcp) & ~((2u << (ro & 7)) - 1) & 0xFF;
-    while(mask == 0 && w < last) { w++; word = staged_word(wave_stage, lane, w); mask = bytes_below(word, right_lcp); }
-    if(w == last && wstart + 8 * w + 8 > lcp_size) { mask &= (1u << (lcp_size - wstart - 8 * w)) - 1; }
-    if(mask == 0) { decided = false; }
-    else { const u32 byte = u32(__ffs(int(mask))) - 1; rpos = wstart + 8 * w + byte; rval = (word >> (8 * byte)) & 0xFF; }
+    u64 flags = below_flags(word, right_lcp) & ((ro & 7) == 7 ? u64(0) : ~u64(0) << (8 * ((ro & 7) + 1)));   // the bytes behind LCP[ep + 1]
+    while(flags == 0 && w < last) { w++; word = staged_word(wave_stage, lane, w); flags = below_flags(word, right_lcp); }
+    if(w == last && wstart + 8 * w + 8 > lcp_size) { flags &= (u64(1) << (8 * (lcp_size - wstart - 8 * w))) - 1; }
+    if(flags == 0) { decided = false; }
+    else { const u32 byte = (u32(__ffsll((long long)flags)) - 1) >> 3; rpos = wstart + 8 * w + byte; rval = (word >> (8 * byte)) & 0xFF; }
   }
   out = gcsa2_stnode{lpos, rpos - 1, lval, rval, node_lcp};
   return decided;
