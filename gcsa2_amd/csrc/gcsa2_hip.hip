@@ -3035,60 +3035,58 @@ int kmer_level(const gcsa2_index* ix, const u64* d_in, u64 n_in, u32 limit, u64*
   return GCSA2_OK;
 }
 
-// takes ownership of d_frontier
-int kmer_run(const gcsa2_index* ix, u64* d_frontier, u64 n, u64 depth, u64 k, u32 limit, unsigned long long* d_counter, u64& total)
+// One frontier buffer per depth of the search, reused by every piece of that depth (a depth-first walk over pieces: when a
+// piece of depth d is taken up, everything below the piece before it is finished) and grown to the largest piece seen.
+struct KmerBufs
 {
-  const u64 MAX_FRONTIER = u64(1) << 26;   // 64 M states = 1 GB
-  struct Free { u64*& p; ~Free() { if(p) { (void)hipFree(p); p = nullptr; } } } guard{d_frontier};
+  std::vector<u64*> p; std::vector<size_t> cap;
+  ~KmerBufs() { for(u64* q : p) { if(q != nullptr) { (void)hipFree(q); } } }
+  hipError_t get(size_t depth, size_t bytes, u64*& out)
+  {
+    if(p.size() <= depth) { p.resize(depth + 1, nullptr); cap.resize(depth + 1, 0); }
+    if(cap[depth] < bytes)
+    {
+      if(p[depth] != nullptr) { (void)hipFree(p[depth]); p[depth] = nullptr; cap[depth] = 0; }
+      hipError_t e = hipMalloc(reinterpret_cast<void**>(&p[depth]), bytes);
+      if(e != hipSuccess) { p[depth] = nullptr; return e; }
+      cap[depth] = bytes;
+    }
+    out = p[depth];
+    return hipSuccess;
+  }
+};
+
+// The level-synchronous search tree of countKMers below a frontier of `n` states (pairs sp, ep) at depth `depth`.  A frontier
+// whose children might not fit one 2 GB buffer (n x limit > 2^27) is cut in halves that are searched one after the other IN
+// PLACE; the children of a piece go into the buffer of their depth.  (Until late round 4 the halves were copied, larger levels
+// were expanded twice -- a counting pass, then a filling pass -- and every piece allocated and freed its buffer: k = 17 on the
+// 5.73 G-node index, a last frontier of 3.4 G states, took 4.5 s, most of it in hipMalloc / hipFree of gigabyte blocks.)
+int kmer_run(const gcsa2_index* ix, const u64* d_frontier, u64 n, u64 depth, u64 k, u32 limit, unsigned long long* d_counter, u64& total, KmerBufs& bufs)
+{
+  const u64 MAX_CHILDREN = u64(1) << 27;   // 128 M states = 2 GB
   while(depth < k && n > 0)
   {
-    if(n > MAX_FRONTIER)    // split: each half continues on its own copy
-    {
-      u64 half = n / 2, parts[2][2] = {{0, half}, {half, n - half}};
-      for(auto& part : parts)
-      {
-        u64* copy = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&copy), part[1] * 2 * sizeof(u64)));
-        hipError_t e = hipMemcpy(copy, d_frontier + 2 * part[0], part[1] * 2 * sizeof(u64), hipMemcpyDeviceToDevice);
-        if(e != hipSuccess) { (void)hipFree(copy); return fail(GCSA2_ERR_HIP, hipGetErrorString(e)); }
-        int rc = kmer_run(ix, copy, part[1], depth, k, limit, d_counter, total);
-        if(rc != GCSA2_OK) { return rc; }
-      }
-      return GCSA2_OK;
-    }
     u64 produced = 0;
     int rc = GCSA2_OK;
-    if(depth + 1 == k)      // last level: the children only have to be counted
+    if(depth + 1 == k)      // last level: the children only have to be counted (no buffer: any size)
     {
       rc = kmer_level(ix, d_frontier, n, limit, nullptr, d_counter, produced);
       if(rc != GCSA2_OK) { return rc; }
       total += produced;
       return GCSA2_OK;
     }
-    // one pass into a buffer sized for the worst case (every state has `limit` children) while that
-    // stays below 2 GB; otherwise count first, then fill an exactly sized buffer
-    u64* next = nullptr;
-    const u64 worst = n * limit;
-    if(worst <= (u64(1) << 27))
+    if(n * limit > MAX_CHILDREN && n > 1)
     {
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&next), worst * 2 * sizeof(u64)));
-      rc = kmer_level(ix, d_frontier, n, limit, next, d_counter, produced);
-      if(rc != GCSA2_OK) { (void)hipFree(next); return rc; }
+      const u64 half = n / 2;
+      rc = kmer_run(ix, d_frontier, half, depth, k, limit, d_counter, total, bufs);
+      if(rc == GCSA2_OK) { rc = kmer_run(ix, d_frontier + 2 * half, n - half, depth, k, limit, d_counter, total, bufs); }
+      return rc;
     }
-    else
-    {
-      rc = kmer_level(ix, d_frontier, n, limit, nullptr, d_counter, produced);     // count pass
-      if(rc != GCSA2_OK) { return rc; }
-      if(produced > 0)
-      {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&next), produced * 2 * sizeof(u64)));
-        u64 again = 0;
-        rc = kmer_level(ix, d_frontier, n, limit, next, d_counter, again);         // fill pass
-        if(rc != GCSA2_OK || again != produced) { (void)hipFree(next); return rc != GCSA2_OK ? rc : fail(GCSA2_ERR_HIP, "k-mer frontier changed between passes"); }
-      }
-    }
-    if(produced == 0) { if(next) { (void)hipFree(next); } return GCSA2_OK; }
-    (void)hipFree(d_frontier);
+    u64* next = nullptr;           // one pass into the buffer of the next depth, sized for the worst case (`limit` children per state)
+    HIP_TRY(bufs.get(size_t(depth + 1), size_t(n * limit * 2 * sizeof(u64)), next));
+    rc = kmer_level(ix, d_frontier, n, limit, next, d_counter, produced);
+    if(rc != GCSA2_OK) { return rc; }
+    if(produced == 0) { return GCSA2_OK; }
     d_frontier = next; n = produced; depth++;
   }
   if(depth == k) { total += n; }
@@ -3109,13 +3107,13 @@ extern "C" int gcsa2_count_kmers(const gcsa2_index* ix, uint64_t k, int include_
   DeviceGuard guard(ix->device);
   DBuf<unsigned long long> counter;
   HIP_TRY(counter.alloc(1));
+  KmerBufs bufs;
   u64* frontier = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&frontier), 2 * sizeof(u64)));
+  HIP_TRY(bufs.get(0, 2 * sizeof(u64), frontier));
   u64 root[2] = {0, ix->img.n - 1};
-  hipError_t e = hipMemcpy(frontier, root, sizeof(root), hipMemcpyHostToDevice);
-  if(e != hipSuccess) { (void)hipFree(frontier); return fail(GCSA2_ERR_HIP, hipGetErrorString(e)); }
+  HIP_TRY(hipMemcpy(frontier, root, sizeof(root), hipMemcpyHostToDevice));
   u64 total = 0;
-  int rc = kmer_run(ix, frontier, 1, 0, k, limit, counter.p, total);
+  int rc = kmer_run(ix, frontier, 1, 0, k, limit, counter.p, total, bufs);
   if(rc != GCSA2_OK) { return rc; }
   *result = total;
   return GCSA2_OK;
