@@ -110,6 +110,7 @@ struct gcsa2_index
     u64 pipe_chunk = u64(1) << 18;     // GCSA2_PIPE_CHUNK (log2): patterns per chunk of the host pipeline
     u32 pipe_lanes = 6;                // GCSA2_PIPE_LANES: host threads (each with its streams and staging sets) of the large host batches
     u32 ms_threads = 4;                   // GCSA2_MS_THREADS: host threads (one stream each) that send the pieces
+    u64 kmer_piece = u64(1) << 27;        // GCSA2_KMER_PIECE (tests): children of one piece of a countKMers / compareKMers frontier
     u64 ms_piece_bytes = u64(32) << 20;   // GCSA2_MS_PIECE_MB: pattern bytes per piece of the large host batches of matching statistics / break points
     bool pipe_blocking = false;        // GCSA2_PIPE_BLOCKING=1: the lanes' events are made with hipEventBlockingSync
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
@@ -714,6 +715,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.ms_pieces = (knob("GCSA2_MS_PIECES", 1, 0, 1) != 0);
     ix->tune.ms_piece_bytes = u64(knob("GCSA2_MS_PIECE_MB", 32, 1, 1024)) << 20;
     ix->tune.ms_threads = u32(knob("GCSA2_MS_THREADS", 4, 1, 16));
+    ix->tune.kmer_piece = u64(knob("GCSA2_KMER_PIECE", long(1) << 27, 4, long(1) << 27));
     ix->tune.locate_trace = (knob("GCSA2_LOCATE_TRACE", 0, 0, 1) != 0);
     ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
     {
@@ -3063,7 +3065,7 @@ struct KmerBufs
 // 5.73 G-node index, a last frontier of 3.4 G states, took 4.5 s, most of it in hipMalloc / hipFree of gigabyte blocks.)
 int kmer_run(const gcsa2_index* ix, const u64* d_frontier, u64 n, u64 depth, u64 k, u32 limit, unsigned long long* d_counter, u64& total, KmerBufs& bufs)
 {
-  const u64 MAX_CHILDREN = u64(1) << 27;   // 128 M states = 2 GB
+  const u64 MAX_CHILDREN = ix->tune.kmer_piece;   // 2^27 states = 2 GB (GCSA2_KMER_PIECE: tests cut finer)
   while(depth < k && n > 0)
   {
     u64 produced = 0;
@@ -3733,6 +3735,62 @@ extern "C" int gcsa2_index_create_from_file(const char* path, int device, gcsa2_
 // the unique k-mers are returned as the reference dumps them to output.left / output.right (:606-610).
 namespace {
 
+// The search below one piece of the frontier (pairs of ranges, 4 u64 per state; with records also the 3-u64 keys), depth-first
+// over pieces like countKMers (kmer_run): a frontier of any size, where round 3 refused more than 2^27 / limit states.
+struct CompareRun
+{
+  const DevImage* images; unsigned long long* counters; u32 limit; u64 k; bool records; u64 piece;
+  uint64_t* left_records; uint64_t left_capacity; uint64_t* right_records; uint64_t right_capacity;
+  u64 shared = 0, left_only = 0, right_only = 0;       // totals (the unique ones count on even when their records no longer fit)
+  KmerBufs states, keys;
+};
+
+int compare_run(CompareRun& c, const u64* frontier, const u64* keys, u64 n, u64 depth)
+{
+  unsigned long long host_counters[4] = {0, 0, 0, 0};
+  while(depth < c.k && n > 0)
+  {
+    HIP_TRY(hipMemset(c.counters, 0, 4 * sizeof(unsigned long long)));
+    if(depth + 1 == c.k)        // last level: classify the children; any size
+    {
+      hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, c.images, c.images + 1, frontier, keys, n, c.limit,
+                         u32(depth), 1, (u64*)nullptr, (u64*)nullptr, c.counters, (u64*)nullptr, (u64*)nullptr);
+      LAUNCH_CHECK("k_kmer_compare");
+      HIP_TRY(hipMemcpy(host_counters, c.counters, sizeof(host_counters), hipMemcpyDeviceToHost));
+      const u64 l = host_counters[2], r = host_counters[3];
+      if(c.records && (l > 0 || r > 0) && c.left_only + l <= c.left_capacity && c.right_only + r <= c.right_capacity)
+      {
+        DBuf<u64> d_left, d_right;
+        HIP_TRY(d_left.alloc(8 * l)); HIP_TRY(d_right.alloc(8 * r));
+        HIP_TRY(hipMemset(c.counters, 0, 4 * sizeof(unsigned long long)));
+        hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, c.images, c.images + 1, frontier, keys, n, c.limit,
+                           u32(depth), 2, (u64*)nullptr, (u64*)nullptr, c.counters, d_left.p, d_right.p);
+        LAUNCH_CHECK("k_kmer_compare");
+        if(l > 0) { HIP_TRY(hipMemcpy(c.left_records + 8 * c.left_only, d_left.p, 8 * l * sizeof(u64), hipMemcpyDeviceToHost)); }
+        if(r > 0) { HIP_TRY(hipMemcpy(c.right_records + 8 * c.right_only, d_right.p, 8 * r * sizeof(u64), hipMemcpyDeviceToHost)); }
+      }
+      c.shared += host_counters[1]; c.left_only += l; c.right_only += r;
+      return GCSA2_OK;
+    }
+    if(n * c.limit > c.piece && n > 1)        // the children might not fit one buffer: halves, one after the other, in place
+    {
+      const u64 half = n / 2;
+      int rc = compare_run(c, frontier, keys, half, depth);
+      if(rc == GCSA2_OK) { rc = compare_run(c, frontier + 4 * half, (keys != nullptr ? keys + 3 * half : nullptr), n - half, depth); }
+      return rc;
+    }
+    u64 *next = nullptr, *next_keys = nullptr;
+    HIP_TRY(c.states.get(size_t(depth + 1), size_t(n * c.limit * 4 * sizeof(u64)), next));
+    if(c.records) { HIP_TRY(c.keys.get(size_t(depth + 1), size_t(n * c.limit * 3 * sizeof(u64)), next_keys)); }
+    hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, c.images, c.images + 1, frontier, keys, n, c.limit,
+                       u32(depth), 0, next, next_keys, c.counters, (u64*)nullptr, (u64*)nullptr);
+    LAUNCH_CHECK("k_kmer_compare");
+    HIP_TRY(hipMemcpy(host_counters, c.counters, sizeof(host_counters), hipMemcpyDeviceToHost));
+    frontier = next; keys = next_keys; n = host_counters[0]; depth++;
+  }
+  return GCSA2_OK;
+}
+
 int compare_kmers_impl(const gcsa2_index* left, const gcsa2_index* right, uint64_t k, int include_ns, int force, uint64_t* result,
                        uint64_t* left_records, uint64_t left_capacity, uint64_t* right_records, uint64_t right_capacity, bool records)
 {
@@ -3745,57 +3803,25 @@ int compare_kmers_impl(const gcsa2_index* left, const gcsa2_index* right, uint64
   if(left->img.sigma != right->img.sigma || left->img.fast_chars != right->img.fast_chars) { return GCSA2_OK; }   // :556-560
   if(left->device != right->device) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "both indexes must live on the same device"); }
   if(left->img.n == 0 || right->img.n == 0 || left->img.sigma < 3) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "empty index or alphabet too small"); }
-  const u32 limit = u32(include_ns ? left->img.sigma - 2 : left->img.fast_chars);
+  try {
   DeviceGuard guard(left->device);
   DBuf<DevImage> images; DBuf<unsigned long long> counters;
   HIP_TRY(images.alloc(2)); HIP_TRY(counters.alloc(4));
   HIP_TRY(hipMemcpy(images.p, &left->img, sizeof(DevImage), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(images.p + 1, &right->img, sizeof(DevImage), hipMemcpyHostToDevice));
-  DBuf<u64> frontier, keys;
-  HIP_TRY(frontier.alloc(4));
-  u64 root[4] = {0, left->img.n - 1, 0, right->img.n - 1};
-  HIP_TRY(hipMemcpy(frontier.p, root, sizeof(root), hipMemcpyHostToDevice));
-  if(records) { HIP_TRY(keys.alloc(3)); HIP_TRY(hipMemset(keys.p, 0, 3 * sizeof(u64))); }
-  u64 n = 1;
-  unsigned long long host_counters[4] = {0, 0, 0, 0};
-  for(u64 depth = 0; depth < k && n > 0; depth++)
-  {
-    const bool last = (depth + 1 == k);
-    if(n * limit > (u64(1) << 27)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "compareKMers frontier exceeds 2^27 states; use a smaller k"); }
-    HIP_TRY(hipMemset(counters.p, 0, 4 * sizeof(unsigned long long)));
-    if(last)
-    {
-      hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, images.p, images.p + 1, frontier.p, keys.p, n, limit,
-                         u32(depth), 1, (u64*)nullptr, (u64*)nullptr, counters.p, (u64*)nullptr, (u64*)nullptr);
-      LAUNCH_CHECK("k_kmer_compare");
-      HIP_TRY(hipMemcpy(host_counters, counters.p, sizeof(host_counters), hipMemcpyDeviceToHost));
-      result[0] = host_counters[1]; result[1] = host_counters[2]; result[2] = host_counters[3];
-      if(records)
-      {
-        if(result[1] > left_capacity || result[2] > right_capacity) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "record buffers smaller than result[1] / result[2]"); }
-        DBuf<u64> d_left, d_right;
-        HIP_TRY(d_left.alloc(8 * result[1])); HIP_TRY(d_right.alloc(8 * result[2]));
-        HIP_TRY(hipMemset(counters.p, 0, 4 * sizeof(unsigned long long)));
-        hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, images.p, images.p + 1, frontier.p, keys.p, n, limit,
-                           u32(depth), 2, (u64*)nullptr, (u64*)nullptr, counters.p, d_left.p, d_right.p);
-        LAUNCH_CHECK("k_kmer_compare");
-        if(result[1] > 0) { HIP_TRY(hipMemcpy(left_records, d_left.p, 8 * result[1] * sizeof(u64), hipMemcpyDeviceToHost)); }
-        if(result[2] > 0) { HIP_TRY(hipMemcpy(right_records, d_right.p, 8 * result[2] * sizeof(u64), hipMemcpyDeviceToHost)); }
-      }
-      break;
-    }
-    DBuf<u64> next, next_keys;
-    HIP_TRY(next.alloc(n * limit * 4));
-    if(records) { HIP_TRY(next_keys.alloc(n * limit * 3)); }
-    hipLaunchKernelGGL(k_kmer_compare, dim3(grid_for(n)), dim3(TPB), 0, nullptr, images.p, images.p + 1, frontier.p, keys.p, n, limit,
-                       u32(depth), 0, next.p, next_keys.p, counters.p, (u64*)nullptr, (u64*)nullptr);
-    LAUNCH_CHECK("k_kmer_compare");
-    HIP_TRY(hipMemcpy(host_counters, counters.p, sizeof(host_counters), hipMemcpyDeviceToHost));
-    n = host_counters[0];
-    std::swap(frontier.p, next.p);      // `next` / `next_keys` now own the old buffers and free them
-    std::swap(keys.p, next_keys.p);
-  }
+  CompareRun run{images.p, counters.p, u32(include_ns ? left->img.sigma - 2 : left->img.fast_chars), k, records, left->tune.kmer_piece,
+                 left_records, left_capacity, right_records, right_capacity};
+  u64 *frontier = nullptr, *keys = nullptr;
+  HIP_TRY(run.states.get(0, 4 * sizeof(u64), frontier));
+  const u64 root[4] = {0, left->img.n - 1, 0, right->img.n - 1};
+  HIP_TRY(hipMemcpy(frontier, root, sizeof(root), hipMemcpyHostToDevice));
+  if(records) { HIP_TRY(run.keys.get(0, 3 * sizeof(u64), keys)); HIP_TRY(hipMemset(keys, 0, 3 * sizeof(u64))); }
+  const int rc = compare_run(run, frontier, keys, 1, 0);
+  if(rc != GCSA2_OK) { return rc; }
+  result[0] = run.shared; result[1] = run.left_only; result[2] = run.right_only;
+  if(records && (result[1] > left_capacity || result[2] > right_capacity)) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "record buffers smaller than result[1] / result[2]"); }
   return GCSA2_OK;
+  } catch(const std::exception& e) { return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("compareKMers: ") + e.what()); }
 }
 
 } // namespace

@@ -26,6 +26,8 @@ def main():
     dev = torch.device("cuda", 0)
     ix, dbg = dbg_torch.build_dbg(args.degree, junctions=80, device=dev)
     order = args.degree // 2
+    cmp_want = {k: dbg_torch.distinct_prefixes(dbg.nodes, order, k) for k in (10, 14)}
+    dbg_torch_count = cmp_want.get
     want = {k: dbg_torch.distinct_prefixes(dbg.nodes, order, k) for k in (int(x) for x in args.ks.split(","))}
     del dbg
     torch.cuda.empty_cache()
@@ -37,6 +39,15 @@ def main():
         dt = time.perf_counter() - t0
         out[f"k={k}"] = {"kmers": got, "closed_form": expect, "equal": got == expect, "seconds": round(dt, 3), "G_states_per_s": round(got / dt / 1e9, 3)}
         print(json.dumps({f"k={k}": out[f"k={k}"]}), flush=True)
+    # compareKMers of the index with itself: every k-mer shared; at k = 14 the frontier (268 M states x 4 children) needs pieces
+    for k in (10, 14):
+        if k in want or True:
+            t0 = time.perf_counter()
+            got = gpu.compare_kmers(gpu, k)
+            dt = time.perf_counter() - t0
+            expect = dbg_torch_count(k)
+            out[f"compare k={k}"] = {"result": got, "equal": got == (expect, 0, 0), "seconds": round(dt, 3)}
+            print(json.dumps({f"compare k={k}": out[f"compare k={k}"]}), flush=True)
     print(json.dumps(out))
 
 

@@ -593,13 +593,22 @@ def test_create_from_gcsa_files(engine, tmp_path):
     assert (gpu.size(), gpu.edgeCount(), gpu.order(), gpu.sigma, lcp.size()) == (ix.n, ix.e, ix.order, ix.sigma, ix.lcp_size)
 
 
-def test_compare_kmers(engine):
-    """compareKMers (reference src/algorithms.cpp:534-616) on two graphs sharing a backbone."""
+@pytest.mark.parametrize("piece", ["", "4", "50"])
+def test_compare_kmers(engine, monkeypatch, piece):
+    """compareKMers (reference src/algorithms.cpp:534-616) on two graphs sharing a backbone.  The search tree is walked
+    depth-first over pieces of the frontier whose children fit one buffer (2^27 states; GCSA2_KMER_PIECE cuts it to 4 / 50
+    states here, so that every level is searched in many pieces): counts and record sets are the same however it is cut,
+    and a record buffer that is too small is refused with the counts."""
     from oracle.oracle import OracleIndex
+    if piece:
+        monkeypatch.setenv("GCSA2_KMER_PIECE", piece)
     g1 = graphs.snp_graph(400, 0x52, 0x53, snp_period=8, node_len=8)
     g2 = graphs.snp_graph(400, 0x52, 0x99, snp_period=6, node_len=8)
     i1, i2 = build(g1, 8, sample_period=8, branching=4), build(g2, 8, sample_period=8, branching=4)
     ga, gb = engine.GCSA(i1), engine.GCSA(i2)
+    if piece:
+        for k in (3, 6, 9):                              # countKMers in pieces too
+            assert ga.count_kmers(k) == OracleIndex(i1).count_kmers(k), k
     ca, cb = OracleIndex(i1), OracleIndex(i2)
     for k in range(0, 10):
         for ns in (False, True):
@@ -614,6 +623,14 @@ def test_compare_kmers(engine):
         cc, cl, cr = ca.compare_kmers_records(cb, k, include_Ns=ns, force=True)
         assert gc == cc and canon(gl) == canon(cl) and canon(gr) == canon(cr), (k, ns)
         assert len(gl) == gc[1] and len(gr) == gc[2]
+    # record buffers that are too small: refused, with the counts
+    import ctypes as C
+    counts = ga.compare_kmers(gb, 7)
+    assert counts[1] > 1 and counts[2] > 1
+    out, small = np.zeros(3, dtype=np.uint64), np.zeros((1, 8), dtype=np.uint64)
+    rc = ga._L.gcsa2_compare_kmers_records(ga._h, gb._h, 7, 0, 0, out.ctypes.data_as(C.POINTER(C.c_uint64)), small.ctypes.data_as(C.POINTER(C.c_uint64)), 1,
+                                           small.ctypes.data_as(C.POINTER(C.c_uint64)), 1)
+    assert rc == -6 and tuple(int(x) for x in out) == counts
 
 
 def test_locate_table_and_walk_agree(engine, monkeypatch):
