@@ -2121,7 +2121,8 @@ int gcsa2_find_batch_packed(const gcsa2_index* ix, const uint64_t* codes, uint64
   if(pattern_length == 0 || pattern_length >= (u64(1) << 32)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "packed patterns: the common length must be 1 .. 2^32 - 1"); }
   try
   {
-    if(nq >= PIPE_MIN_QUERIES / 4) { return find_packed_pipelined(ix, codes, pattern_length, nq, ranges); }
+    // (patterns whose codes alone exceed a pipeline chunk -- 32 M characters -- take the single copy below)
+    if(nq >= PIPE_MIN_QUERIES / 4 && ((pattern_length + 31) >> 5) * 8 <= PIPE_CHUNK_BYTES) { return find_packed_pipelined(ix, codes, pattern_length, nq, ranges); }
     // small batches: one copy in, one launch, one copy out
     DeviceGuard guard(ix->device);
     const u64 words = (pattern_length + 31) >> 5;
