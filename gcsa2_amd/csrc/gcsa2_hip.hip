@@ -2462,7 +2462,7 @@ int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patt
 int group_comm_init(gcsa2_group* g);
 int match_breaks_pieced(const gcsa2_index* ix, const uint8_t* patterns, const uint64_t* offsets, uint64_t nq, uint64_t min_length,
                         uint64_t* break_offsets, gcsa2_break* breaks, uint64_t capacity, uint64_t* total_breaks, uint64_t* ranges, uint64_t* fallbacks);
-constexpr u64 MS_PIECED_MIN_BYTES = u64(64) << 20;      // (the piece size: tune.ms_piece_bytes, GCSA2_MS_PIECE_MB, 32 MB)
+// (large host batches of matching statistics / break points go in pieces of tune.ms_piece_bytes -- GCSA2_MS_PIECE_MB, 32 MB -- from two pieces' worth on)
 
 }  // namespace
 
@@ -3315,7 +3315,7 @@ int gcsa2_match_breaks_batch(const gcsa2_index* ix, const uint8_t* patterns, con
   if(offsets[0] != 0 || !offsets_ok(offsets, nq, &longest)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets must start at 0 and be non-decreasing"); }
   try
   {
-    if(ix->tune.ms_pieces && offsets[nq] >= MS_PIECED_MIN_BYTES && longest <= ix->tune.ms_piece_bytes)
+    if(ix->tune.ms_pieces && offsets[nq] >= 2 * ix->tune.ms_piece_bytes && longest <= ix->tune.ms_piece_bytes)
     {
       return match_breaks_pieced(ix, patterns, offsets, nq, min_length, break_offsets, breaks, capacity, total_breaks, ranges, fallbacks);
     }
@@ -3406,7 +3406,7 @@ int match_stats_single(const gcsa2_index* ix, const uint8_t* patterns, const uin
 // eight threads or 8 MB pieces change nothing: what is left is the rate of copies to and from pageable memory,
 // tests/perf/ms_host_batch.py.  Staging those copies ourselves through a ring of pinned 2 MB pieces was measured and is
 // twice as slow as the runtime's own path for pageable memory: 47 ms in a row, 24-28 ms in pieces.)
-// (pieces of tune.ms_piece_bytes = 32 MB (GCSA2_MS_PIECE_MB) for batches of MS_PIECED_MIN_BYTES = 64 MB and more, MS_PIECE_THREADS = 4: declared with
+// (pieces of tune.ms_piece_bytes = 32 MB (GCSA2_MS_PIECE_MB) for batches of two pieces' worth (64 MB) and more, on tune.ms_threads = 4 host threads: declared with
 // the forward declarations above.  Round 4 re-measured the piece size, 1 M x 256 bp: dense statistics on the chr22-like index 15.9-17.4 ms
 // with 16 MB, 15.0 with 32, 16.1 with 64, 18.9 with 128, 22.3 in one copy; break points of at least 20 bp on the 5.73 G-node index 24.5 /
 // 16.7 / 16.9 / 19.5 ms and 17.9 in one copy -- a piece must still fill the device: the kernel's time per pattern is latency, not work;
@@ -3556,7 +3556,7 @@ extern "C" int gcsa2_match_stats_batch(const gcsa2_index* ix, const uint8_t* pat
   if(!offsets_ok(offsets, nq, &longest)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets are not non-decreasing"); }
   try
   {
-    if(ix->tune.ms_pieces && offsets[0] == 0 && offsets[nq] >= MS_PIECED_MIN_BYTES && longest <= ix->tune.ms_piece_bytes)
+    if(ix->tune.ms_pieces && offsets[0] == 0 && offsets[nq] >= 2 * ix->tune.ms_piece_bytes && longest <= ix->tune.ms_piece_bytes)
     {
       return match_stats_pieced(ix, patterns, offsets, nq, longest, ms, ranges, fallbacks);
     }

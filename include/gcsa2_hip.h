@@ -399,7 +399,7 @@ int gcsa2_match_breaks_device(const gcsa2_index* index, const uint8_t* d_pattern
                               uint64_t total_pattern_bytes, int variant, uint64_t min_length, uint64_t* d_break_offsets, gcsa2_break* d_breaks,
                               uint64_t capacity, uint64_t* total_breaks, uint64_t* d_ranges, uint64_t* d_fallbacks, void* stream);
 /* The same for a batch in host memory (offsets[0] == 0): copies in, runs, copies the CSR out.  ranges / fallbacks may be NULL.
- * A batch of 64 MB or more of pattern bytes goes in pieces (32 MB each, GCSA2_MS_PIECE_MB; four host threads with a stream each)
+ * A batch of two pieces' worth of pattern bytes or more goes in pieces (32 MB each, GCSA2_MS_PIECE_MB; four host threads with a stream each)
  * whose records are committed in pattern order; with GCSA2_ERR_BUFFER_TOO_SMALL (*total_breaks = the records of the whole batch)
  * the contents of the result arrays are unspecified. */
 int gcsa2_match_breaks_batch(const gcsa2_index* index, const uint8_t* patterns, const uint64_t* offsets, uint64_t n_queries,

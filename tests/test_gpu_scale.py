@@ -566,3 +566,17 @@ def test_match_stats_large_host_batch_in_pieces(monkeypatch):
             end = pos
         assert end == 0 and np.array_equal(dense, want.astype(np.int64)), q
     gpu.close(); single.close()
+    # pieces whose device-side record buffer was sized too small by the estimate (one record per 8 pattern bytes) run once more
+    # with the exact size: random strings break at nearly every position.  (1 MB pieces, so that 3 MB make a pieced batch.)
+    monkeypatch.setenv("GCSA2_MS_PIECES", "1")
+    monkeypatch.setenv("GCSA2_MS_PIECE_MB", "1")
+    small, _ = binding.open_index(ix)
+    monkeypatch.setenv("GCSA2_MS_PIECES", "0")
+    whole, _ = binding.open_index(ix)
+    nr = 30_000
+    rflat = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=nr * 100)].copy()
+    roff = np.arange(nr + 1, dtype=np.uint64) * np.uint64(100)
+    a = small.match_breaks_batch(rflat, roff)
+    b = whole.match_breaks_batch(rflat, roff)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[1].shape[0] > nr * 100 // 4        # more than one record per 8 bytes
+    small.close(); whole.close()
