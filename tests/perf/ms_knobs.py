@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Sweep of the matching-statistics tuning knobs (read at create) on config 5 batch, pangenome-sized index: the defaults
-(cool-down 3, refill at the library default) are at the optimum: 129.6 M patterns/s; cool-down 0: 121.9, 8: 123.9, 24: 117.1."""
+(cool-down 3, refill at 8 idle lanes, a grid of what the device holds) are at the optimum; final kernel of round 4 (profiles/r04_ms_knobs_final.jsonl):
+141 M patterns/s; cool-down 0: 134, 8: 140, 24: 129; refill at 1: 106, 48: 120; twice the grid: 130."""
 import json, os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from workload import dbg_torch
 from gcsa2_amd.binding import GCSA
@@ -19,9 +20,9 @@ d_off = torch.arange(nq + 1, dtype=torch.int64, device=dev) * m
 d_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev); d_rng = torch.zeros((nq, 2), dtype=torch.int64, device=dev); d_fb = torch.zeros(nq, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream()
 ref = None
-for knob, values in (("GCSA2_COOL_DOWN", (None, 0, 2, 4, 8, 12, 16, 24)), ("GCSA2_MS_REFILL_AT", (4, 8, 16, 24, 32, 48))):
+for knob, values in (("GCSA2_COOL_DOWN", (None, 0, 2, 4, 8, 12, 16, 24)), ("GCSA2_MS_REFILL_AT", (1, 2, 4, 8, 16, 24, 32, 48)), ("GCSA2_MS_GRID", (2048, 3072, 4096))):
     for v in values:
-        for k in ("GCSA2_COOL_DOWN", "GCSA2_MS_REFILL_AT"): os.environ.pop(k, None)
+        for k in ("GCSA2_COOL_DOWN", "GCSA2_MS_REFILL_AT", "GCSA2_MS_GRID"): os.environ.pop(k, None)
         if v is not None: os.environ[knob] = str(v)
         gpu = GCSA(ix, device=0, with_samples=False, with_counters=False, with_lcp=True)
         run = lambda: gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), st.cuda_stream, variant=0, total_bytes=nq * m)
