@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--locate-ranges", type=int, default=0, help="ranges of the locate() leg (default: 400 k on the repeat-rich indexes, every range on chr22)")
     ap.add_argument("--locate", action="store_true", help="chr22 / repeats / repeats30: run the locate() leg even with --no-extras (profiler passes)")
     ap.add_argument("--variant", type=int, default=2, help="find launch shape (2 = one lane per query in batch order, 4 = queries ordered by length first)")
+    ap.add_argument("--full-json", default="bench_full.json", help="where the full result object goes (every leg in full; the stdout line is the compact form)")
+    ap.add_argument("--full-line", action="store_true", help="print the full object as the stdout line (profiles/; the driver needs the compact line)")
     ap.add_argument("--cache-dir", default=os.environ.get("GCSA2_CACHE", "/tmp/gcsa2_bench_cache"))
     return ap.parse_args()
 
@@ -1644,6 +1646,213 @@ def cpu_baseline_match_stats(ix, d_pat, d_ms, d_rng, d_fb, m, ns=4000):
             "gpu_matches_cpu_on_sample": parity}
 
 
+# ---- the line -------------------------------------------------------------------------------------------------
+
+LINE_LIMIT = 4096        # the driver keeps the tail of stdout; round 4's 23 KB line could not be parsed from it
+
+
+def pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def short(text, n=240):
+    return text if not isinstance(text, str) or len(text) <= n else text[: n - 3] + "..."
+
+
+def one_number(key, leg):
+    """A secondary leg in the compact line: its rate (and request-rate fraction where it has one), or its error."""
+    if not isinstance(leg, dict):
+        return leg
+    if "error" in leg:
+        return {"error": short(leg["error"], 120)}
+    if key == "config5":
+        out = pick(leg, "patterns_per_s", "find_patterns_per_s", "n_gpus")
+        out["match_stats_frac_of_request_ceiling"] = leg.get("roofline", {}).get("frac_of_request_ceiling")
+        out["match_breaks_patterns_per_s"] = leg.get("match_breaks", {}).get("patterns_per_s")
+        out["locate_values_per_s"] = leg.get("locate", {}).get("values_per_s")
+        return out
+    if key == "host_batch":
+        return {"queries_per_s": leg.get("value"), "packed_queries_per_s": leg.get("packed", {}).get("value")}
+    if key == "memory_ladder":
+        return {short(x["workload"], 60): {"queries_per_s": x["value"], "GB": round(x["image_bytes_hbm"] / 1e9, 1)} for x in leg.get("rungs", [])}
+    if key == "locate":
+        return pick(leg, "values_per_s", "ms_per_step")
+    if "value" in leg:                      # chr22, human32, human_branching
+        out = {"queries_per_s": leg["value"], "frac": leg.get("roofline", {}).get("frac")}
+        if "locate" in leg:
+            out["locate_values_per_s"] = leg["locate"].get("values_per_s")
+        return out
+    # wide_ranges, repeats, repeats_hbm: one object per pattern length
+    return {short(k, 40): {"queries_per_s": v["value"], "served": v.get("served", v.get("roofline", {}).get("served"))}
+            for k, v in leg.items() if isinstance(v, dict) and "value" in v}
+
+
+def compact_line(full):
+    """The stdout line: the contract's keys, `roofline`, `cpu_baseline` and one number per secondary; everything else lives in
+    bench_full.json (and on stderr).  Kept under LINE_LIMIT bytes by construction, and by dropping secondaries if it is not."""
+    out = pick(full, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    cfg = dict(full["config"])
+    cfg["workload"] = short(cfg["workload"], 360)
+    cfg["parallelism"] = short(cfg.get("parallelism", ""), 200)
+    out["config"] = cfg
+    rf = dict(full["roofline"])
+    for k in ("working_set_note", "traffic_source"):
+        rf.pop(k, None)
+    if "request_rate" in rf:
+        rf["request_rate"] = {k: v for k, v in rf["request_rate"].items() if k != "ceiling_source"}
+    out["roofline"] = rf
+    if "value_at_reference_footprint" in full:
+        out["value_at_reference_footprint"] = full["value_at_reference_footprint"]
+    if "cpu_baseline" in full:
+        cb = dict(full["cpu_baseline"])
+        if "sample" in cb:
+            cb["sample"] = short(cb["sample"], 200)
+        if "error" in cb:
+            cb["error"] = short(cb["error"], 200)
+        out["cpu_baseline"] = cb
+    if "multi_gpu" in full:
+        mg = full["multi_gpu"]
+        out["multi_gpu"] = pick(mg, "backend", "wire_bytes_per_query", "bytes_into_root_per_step", "rccl_ranks", "slowest_kernel_ms",
+                                "root_gather_ms", "root_gather_hidden_frac")
+        out["multi_gpu"]["gather"] = short(mg.get("gather", ""), 100)
+        out["multi_gpu"]["kernel_ms_per_rank"] = [round(x["kernel_ms"], 3) for x in mg.get("per_rank", [])]
+    out["full"] = full.get("full_json")
+    sec = {}
+    for key, leg in full.items():
+        if key in out or key in ("device", "full_json", "errors"):
+            continue
+        sec[key] = one_number(key, leg)
+    if full.get("errors"):
+        sec["errors"] = [short(e, 100) for e in full["errors"]][:4]
+    out["secondary"] = sec
+    out = rounded(out, keep=("value", "ms_per_step"))
+    line = json.dumps(out, allow_nan=False)
+    while len(line) >= LINE_LIMIT and out["secondary"]:
+        out["secondary"].pop(max(out["secondary"], key=lambda k: len(json.dumps(out["secondary"][k]))))
+        out["secondary_dropped_for_size"] = True
+        line = json.dumps(out, allow_nan=False)
+    return line
+
+
+def rounded(o, keep=()):
+    """Six significant digits for everything but the keys named (the line is for reading; bench_full.json keeps full precision)."""
+    if isinstance(o, float):
+        return float(f"{o:.6g}")
+    if isinstance(o, dict):
+        return {k: (v if k in keep else rounded(v)) for k, v in o.items()}
+    if isinstance(o, list):
+        return [rounded(v) for v in o]
+    return o
+
+
+def finite(o):
+    """NaN / inf never reach the line (strict JSON): replaced by None."""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {str(k): finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [finite(v) for v in o]
+    if isinstance(o, np.generic):
+        return finite(o.item())
+    return o
+
+
+class Emitter:
+    """Owns the result object from the moment the headline exists.  Every later leg runs under leg(): an exception becomes
+    {"error": ...} under the leg's key; after each leg the full object is checkpointed to --full-json.  emit() prints the
+    compact line exactly once -- at the normal end, from main()'s `finally` on any exception after the headline, or from the
+    SIGTERM watcher thread (a launcher tearing the job down while the main thread sits in a collective)."""
+
+    def __init__(self, args, rank):
+        import threading
+        self.args, self.rank, self.result, self.done = args, rank, None, False
+        self.lock = threading.Lock()
+        if rank == 0:
+            self._watch_sigterm()
+
+    def _watch_sigterm(self):
+        import signal
+        import socket
+        import threading
+        try:
+            rd, wr = socket.socketpair()
+            wr.setblocking(False)
+            signal.signal(signal.SIGTERM, lambda *_: None)            # (the wake-up fd is written at C level, whatever the main thread is blocked in)
+            signal.set_wakeup_fd(wr.fileno(), warn_on_full_buffer=False)
+        except (ValueError, OSError):
+            return
+        self._sockets = (rd, wr)
+
+        def watch():
+            while True:
+                data = rd.recv(16)
+                if not data:
+                    return
+                if signal.SIGTERM in data:
+                    if self.result is not None:
+                        self.result.setdefault("errors", []).append("SIGTERM before the last leg finished")
+                    self.emit()
+                    os._exit(143)
+        threading.Thread(target=watch, daemon=True).start()
+
+    def headline(self, result):
+        self.result = result
+        if result is not None:
+            result["full_json"] = self.args.full_json
+            self.checkpoint()
+
+    def checkpoint(self):
+        if self.result is None or not self.args.full_json:
+            return
+        try:
+            tmp = self.args.full_json + ".tmp"
+            with open(tmp, "w") as f:
+                json.dump(finite(self.result), f, allow_nan=False)
+            os.replace(tmp, self.args.full_json)
+        except OSError as e:
+            log(f"could not write {self.args.full_json}: {e}")
+
+    def leg(self, key, fn, keep=True):
+        t = time.time()
+        fail = os.environ.get("GCSA2_BENCH_FAIL_LEG", "")           # tests: a leg that raises must not cost the line
+        try:
+            if fail and fail == key:
+                raise RuntimeError(f"GCSA2_BENCH_FAIL_LEG={key}")
+            value = fn()
+        except Exception as e:
+            import traceback
+            log(f"leg {key} failed: {traceback.format_exc()}")
+            value = {"error": f"{type(e).__name__}: {e}"[:400]}
+            if self.result is None:
+                raise                                   # not the root: the launcher ends the job, the root's watcher prints the line
+            if self.args.gpus > 1:
+                self.result[key] = value                # the other ranks are inside this leg's collectives: print what exists, then fail
+                self.emit()
+                raise
+            try:
+                import torch
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+            except Exception:
+                pass
+        if self.result is not None and (keep or (isinstance(value, dict) and "error" in value)):
+            self.result[key] = value
+            log(f"leg {key}: {time.time() - t:.1f} s")
+            self.checkpoint()
+
+    def emit(self):
+        with self.lock:
+            if self.done or self.result is None:
+                return
+            self.done = True
+            full = finite(self.result)
+            self.checkpoint()
+            print(json.dumps(full), file=sys.stderr, flush=True)
+            line = json.dumps(full, allow_nan=False) if self.args.full_line else compact_line(full)
+            print(line, flush=True)
+
+
 def main():
     args = parse()
     launch_ranks(args)
@@ -1678,6 +1887,20 @@ def main():
     else:
         wl = setup_linear(args, D, dev, local_rank)
 
+    emitter = Emitter(args, rank)
+    try:
+        run_legs(args, D, dev, local_rank, wl, ceiling, emitter)
+    finally:
+        emitter.emit()
+    D.barrier()
+    D.close()
+
+
+def run_legs(args, D, dev, local_rank, wl, ceiling, emitter):
+    """The headline first -- from then on the line exists and only grows: every other leg runs under emitter.leg(), which
+    turns an exception into {"error": ...} under that leg's key and checkpoints bench_full.json."""
+    import torch
+    rank, world = D.rank, D.world
     r = measure(args, D, dev, wl, args.steps, args.warmup)
     # every rank checks its own shard; the root also checks everything it gathered
     ok = wl.verify(r["d_out"], wl.first, wl.nq)
@@ -1716,52 +1939,50 @@ def main():
             rr["ceiling_G_per_s"] = ceiling
             rr["ceiling_source"] = "gather_bench --mode lds128 35 on this box, before the index was loaded"
             rr["frac_of_ceiling"] = rr["achieved_G_per_s"] / ceiling
-        if world == 1 and not args.no_extras:
-            st = torch.cuda.current_stream()
+    emitter.headline(result)
+    leg = emitter.leg
+    if rank == 0 and not args.no_cpu and world == 1:
+        leg("cpu_baseline", lambda: cpu_baseline(args, wl, r["d_out"], args.cpu_seconds))
+    if rank == 0 and world == 1 and not args.no_extras:
+        st = torch.cuda.current_stream()
 
-            def under_load():
-                d_tmp = torch.zeros((wl.nq, 2), dtype=torch.int64, device=dev)
-                for _ in range(max(1, int(1000 / max(r["kernel_ms"], 0.1)))):
-                    wl.gpu.find_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), wl.nq, d_tmp.data_ptr(), st.cuda_stream)
-            result["device"] = device_telemetry(under_load)
-            sweep = [tuple(int(x) for x in c.split(":")) for c in args.pipeline_sweep.split(",")] if args.pipeline_sweep else None
-            result["host_batch"] = host_batch_rate(wl, r["d_out"], sweep=sweep)
-        if not args.no_cpu and world == 1:
-            result["cpu_baseline"] = cpu_baseline(args, wl, r["d_out"], args.cpu_seconds)
+        def under_load():
+            d_tmp = torch.zeros((wl.nq, 2), dtype=torch.int64, device=dev)
+            for _ in range(max(1, int(1000 / max(r["kernel_ms"], 0.1)))):
+                wl.gpu.find_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), wl.nq, d_tmp.data_ptr(), st.cuda_stream)
+        leg("device", lambda: device_telemetry(under_load))
+        sweep = [tuple(int(x) for x in c.split(":")) for c in args.pipeline_sweep.split(",")] if args.pipeline_sweep else None
+        leg("host_batch", lambda: host_batch_rate(wl, r["d_out"], sweep=sweep))
     if rank == 0 and world == 1 and args.workload in ("repeats", "repeats30", "chr22") and wl.gpu.sampleCount() > 0 and (args.locate or not args.no_extras):
         nloc = min(wl.nq, args.locate_ranges or (400_000 if args.workload.startswith("repeats") else wl.nq))
-        result["locate"], _, _ = measure_locate(wl.gpu, r["d_out"][:nloc].contiguous(), dev, 3)
+        leg("locate", lambda: measure_locate(wl.gpu, r["d_out"][:nloc].contiguous(), dev, 3)[0])
     secondary = args.workload in ("pangenome", "pangenome_plain", "human") and world == 1 and not args.no_secondary
     if secondary and args.secondary in ("all", "config5") and wl.ix.lcp_size > 0:
-        result["config5"] = config5(args, wl, dev)
+        leg("config5", lambda: config5(args, wl, dev))
     if secondary and args.secondary in ("all", "wide") and args.workload.startswith("pangenome") and args.set == "S":
-        result["wide_ranges"] = wide_ranges_secondary(args, D, dev, wl)
+        leg("wide_ranges", lambda: wide_ranges_secondary(args, D, dev, wl))
     if secondary and args.secondary in ("all", "ladder") and args.workload.startswith("pangenome") and args.set == "S":
-        result["memory_ladder"] = memory_ladder(args, D, dev, wl, result)        # re-shapes the image: the last user of the headline index
+        leg("memory_ladder", lambda: memory_ladder(args, D, dev, wl, result))        # re-shapes the image: the last user of the headline index
     if world > 1 and not args.no_secondary and args.secondary in ("all", "config5") and D.all_true(wl.ix.lcp_size > 0 and wl.gpu.sampleCount() > 0):
-        c5 = config5_sharded(args, D, wl, dev)
-        if rank == 0:
-            result["config5"] = c5
+        # (every rank enters the leg; an exception on one rank alone ends the job through the launcher -- the root's line is
+        # already safe with the emitter's SIGTERM watcher)
+        leg("config5", lambda: config5_sharded(args, D, wl, dev))
     del r
     full_size = getattr(wl, "degree", 0) >= 32
     if secondary:
-        release(wl)
+        leg("release", lambda: release(wl), keep=False)
         del wl
     if secondary and args.secondary in ("all", "chr22"):
-        result["chr22"] = chr22_secondary(args, D, dev, local_rank)
+        leg("chr22", lambda: chr22_secondary(args, D, dev, local_rank))
     if secondary and args.secondary in ("all", "repeats"):
-        result["repeats"] = repeats_secondary(args, D, dev, local_rank)
+        leg("repeats", lambda: repeats_secondary(args, D, dev, local_rank))
     if secondary and args.secondary in ("all", "repeats30"):
         # the repeat-rich text at HBM footprint; scaled down with the headline index in small runs (tests)
-        result["repeats_hbm"] = repeats_hbm_secondary(args, D, dev, local_rank, log2_bases=(30 if full_size else 22))
+        leg("repeats_hbm", lambda: repeats_hbm_secondary(args, D, dev, local_rank, log2_bases=(30 if full_size else 22)))
     if secondary and args.workload != "human" and args.secondary == "human32" and full_size:       # rounds 1-2's headline, on request only
-        result["human32"] = human32_secondary(args, D, dev, local_rank)
+        leg("human32", lambda: human32_secondary(args, D, dev, local_rank))
     if secondary and args.secondary == "human_snp":
-        result["human_branching"] = human_snp_secondary(args, D, dev, local_rank)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    D.barrier()
-    D.close()
+        leg("human_branching", lambda: human_snp_secondary(args, D, dev, local_rank))
 
 
 if __name__ == "__main__":

@@ -67,11 +67,19 @@ CLI_SRC = os.path.join(ROOT, "tools", "cpp", "query_gcsa.cpp")
 CLI_OUT = os.path.join(HERE, "lib", "query_gcsa")
 
 
+def cli_deps(src):
+    """Everything a facade client is compiled from: its source, the C header and every header of the facade
+    (include/gcsa2_hip/gcsa.hpp is six #includes of include/gcsa/*.h -- VERDICT r04 #7)."""
+    import glob
+    inc = os.path.join(ROOT, "include")
+    return [src, os.path.join(inc, "gcsa2_hip.h")] + sorted(glob.glob(os.path.join(inc, "gcsa2_hip", "*.hpp")) + glob.glob(os.path.join(inc, "gcsa", "*.h")))
+
+
 def build_cli(name, force=False):
     """A reference command line tool (tools/cpp/<name>.cpp) as a client of the C++ facade (host compiler only)."""
     build()
     src, out = os.path.join(ROOT, "tools", "cpp", name + ".cpp"), os.path.join(HERE, "lib", name)
-    deps = [src, os.path.join(ROOT, "include", "gcsa2_hip", "gcsa.hpp"), os.path.join(ROOT, "include", "gcsa2_hip.h")]
+    deps = cli_deps(src)
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     libdir = os.path.dirname(OUT)

@@ -121,6 +121,7 @@ struct gcsa2_index
     bool poll_small = true;            // GCSA2_POLL_SMALL=0: zero-copy calls end with hipStreamSynchronize instead of a polled ticket
     u32 seed_wide = (u32(1) << 24) - 1;   // GCSA2_SEED_WIDE: seed-table entries of this many path nodes or more are marked, not stored (tests)
     bool locate_trace = false;         // GCSA2_LOCATE_TRACE=1: host-clock stamps of a locate pass on stderr (profiles/r04_locate.md)
+    size_t arena_cap = size_t(24) << 30;  // GCSA2_ARENA_CAP_MB: most scratch a handle keeps between calls per arena (struct Scratch)
     u64 budget_bytes = 0;              // GCSA2_MEMORY_BUDGET_MB: most device memory the image may take (0: what the device has free)
   } tune;
 };
@@ -556,12 +557,16 @@ struct Scratch
   {
     if(!settled) { (void)hipStreamSynchronize(stream); }
     for(void* p : extra) { (void)hipFree(p); }
-    if(wanted > arena.bytes)
+    // the arena grows to 1.125 x the largest request, up to tune.arena_cap (GCSA2_ARENA_CAP_MB, default 24 GB): what a pass
+    // needs beyond it is allocated and freed by that pass, so that one huge locate() does not pin tens of GB on the handle
+    // until gcsa2_index_trim
+    size_t want = wanted + wanted / 8;
+    if(want > ix->tune.arena_cap) { want = ix->tune.arena_cap; }
+    if(want > arena.bytes)
     {
       if(arena.base != nullptr) { (void)hipFree(arena.base); }
       arena.base = nullptr; arena.bytes = 0;
       void* fresh = nullptr;
-      const size_t want = wanted + wanted / 8;
       if(hipMalloc(&fresh, want) == hipSuccess) { arena.base = static_cast<char*>(fresh); arena.bytes = want; }
       else { (void)hipGetLastError(); }
     }
@@ -717,6 +722,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.ms_threads = u32(knob("GCSA2_MS_THREADS", 4, 1, 16));
     ix->tune.kmer_piece = u64(knob("GCSA2_KMER_PIECE", long(1) << 27, 4, long(1) << 27));
     ix->tune.locate_trace = (knob("GCSA2_LOCATE_TRACE", 0, 0, 1) != 0);
+    ix->tune.arena_cap = size_t(knob("GCSA2_ARENA_CAP_MB", 24576, 0, long(1) << 20)) << 20;    // 24 GB: 1/12 of an MI355X's HBM per arena
     ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
     {
       const char* b = std::getenv("GCSA2_MEMORY_BUDGET_MB");           // megabytes, fractions allowed (small test indexes)
@@ -2929,9 +2935,9 @@ int gcsa2_comm_locate(gcsa2_comm* c, const gcsa2_index* ix, const uint64_t* d_ra
     off_bytes[r] = (bad ? 0 : 8 * counts[r]); val_bytes[r] = 8 * totals[r]; total += totals[r]; queries += counts[r];
   }
   gcsa2_locate_job* result = nullptr;
-  static u64 nothing_to_send = 0;
-  const u64* my_offsets = (mine != nullptr ? mine->d_offsets : &nothing_to_send);
-  const u64* my_values = (mine != nullptr ? mine->d_values : &nothing_to_send);
+  // a rank whose pass failed sends zero bytes -- from a device address that always exists (a custom transport may look at it)
+  const u64* my_offsets = (mine != nullptr ? mine->d_offsets : d_mark);
+  const u64* my_values = (mine != nullptr ? mine->d_values : d_mark);
   if(is_root)
   {
     result = new(std::nothrow) gcsa2_locate_job();
@@ -3250,8 +3256,15 @@ int gcsa2_match_breaks_device(const gcsa2_index* ix, const uint8_t* d_patterns, 
   auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(); };
   Scratch scratch(ix, st);
   // slots of the temporary records: what the caller's buffer holds + one block per wavefront that may leave a hole
-  const u64 waves = (nq + 63) / 64;
-  const u64 tmp_slots = capacity + (waves + 1) * BREAK_BLOCK;
+  // (the wavefronts that can leave one: with a lane per pattern every wave of the grid, on the persistent lanes -- what
+  // match_stats_launch picks for a batch of more than two generations of workgroups -- only the resident ones; and never more
+  // records than one per pattern position and one per pattern, whatever the caller's capacity is: ADVICE r04)
+  const u64 lane_waves = (nq + 63) / 64, lanes_grid = (nq + TPB2 - 1) / TPB2;
+  const u64 resident = ix->tune.ms_grid != 0 ? ix->tune.ms_grid : u64(ix->compute_units) * 8;
+  const bool persistent = (variant == 5 || (variant == 0 && lanes_grid > 2 * resident));
+  const u64 waves = (persistent && resident * (TPB2 / 64) < lane_waves ? resident * (TPB2 / 64) : lane_waves);
+  const u64 most = (total_bytes != GCSA2_UNKNOWN && total_bytes + nq < capacity ? total_bytes + nq : capacity);
+  const u64 tmp_slots = most + (waves + 1) * BREAK_BLOCK;
   BreakSink sink{nullptr, tmp_slots, nullptr, nullptr, u32(min_length > 0xFFFFFFFFull ? 0xFFFFFFFFull : min_length)};
   u64 *wide = nullptr, *own_ranges = nullptr;
   const unsigned slot = ix->next_slot.fetch_add(1) % RESULT_SLOTS;
@@ -3305,12 +3318,17 @@ int gcsa2_match_breaks_batch(const gcsa2_index* ix, const uint8_t* patterns, con
                              uint64_t* ranges, uint64_t* fallbacks)
 {
   CHECK_INDEX(ix);
-  if(offsets == nullptr || break_offsets == nullptr || total_breaks == nullptr || (breaks == nullptr && capacity > 0) || (patterns == nullptr && nq > 0 && offsets[nq] > offsets[0]))
+  if(nq == 0)             // an empty batch: no records, whatever the (possibly null) input arrays are
+  {
+    if(total_breaks != nullptr) { *total_breaks = 0; }
+    if(break_offsets != nullptr) { break_offsets[0] = 0; }
+    return GCSA2_OK;
+  }
+  if(offsets == nullptr || break_offsets == nullptr || total_breaks == nullptr || (breaks == nullptr && capacity > 0) || (patterns == nullptr && offsets[nq] > offsets[0]))
   {
     return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer");
   }
   *total_breaks = 0;
-  if(nq == 0) { break_offsets[0] = 0; return GCSA2_OK; }
   u64 longest = 0;
   if(offsets[0] != 0 || !offsets_ok(offsets, nq, &longest)) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "pattern offsets must start at 0 and be non-decreasing"); }
   try

@@ -493,8 +493,14 @@ constexpr u64 MS_REFILL_MIN = u64(1) << 19;             // host-pointer API: sma
 // stores, a third of the dense kernel's memory requests, shrink to one 32-byte record per break.  Records are appended to
 // `sink.tmp` -- {pattern | ordinal << 32, position | length << 32, sp, ep}; a wavefront reserves blocks of BREAK_BLOCK slots --
 // and put into CSR order by k_breaks_scatter once the per-pattern counts have been scanned; slots beyond `sink.cap` are not
-// written (the exact number of records is the sum of the per-pattern counts).  The record of a round is taken at the loop head, where (i, depth, sp, ep) describe the match that starts at
-// position i.  Exactly the positions p with p == 0 or ms[p - 1] != ms[p] + 1 get a record.
+// written (the exact number of records is the sum of the per-pattern counts).  
+// The record of a round is taken AFTER the step and after plan_and_issue() (the next round's requests are in flight): a failed
+// step leaves (i, depth, sp, ep) untouched and sets need_parent, so at that point they still describe the match that starts
+// at position i -- the break.  At i == 0 the pattern's first position is the last record.  A character that does not occur
+// fails AT THE ROOT and moves on (i--, `pending`): the break is position i + 1, and when that step also reached i == 0 the
+// final record and the end of the pattern are deferred by one round (a lane writes one record per round).  The order matters:
+// need_parent, pending and last_break are read after the step; moving the record back to the loop head reports the state of
+// the NEXT match.  Exactly the positions p with p == 0 or ms[p - 1] != ms[p] + 1 get a record.
 struct BreakSink
 {
   u64* tmp; u64 cap; unsigned long long* counter; u32* counts; u32 min_length;

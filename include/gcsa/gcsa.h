@@ -129,8 +129,23 @@ public:
     if(nq > 0) { check(gcsa2_find_batch_packed(handle, codes.data(), length, nq, reinterpret_cast<size_type*>(result.data())), "GCSA::find_packed_batch()"); }
     return result;
   }
-  // codes of `count` patterns of `length` bytes each (A C G T in either case; anything else throws): the packing a caller does
+  // codes of `count` patterns of `length` bytes each, through THIS index's alphabet: comp - 1 of the fast characters
+  // (char2comp values 1..4); any other byte throws.  The packing a caller does.
+  std::vector<std::uint64_t> packKMers(const std::uint8_t* patterns, size_type count, size_type length) const
+  {
+    std::uint8_t code_of[256];
+    for(size_type c = 0; c < 256; c++) { const size_type comp = alpha.char2comp[c]; code_of[c] = (comp >= 1 && comp <= 4 ? std::uint8_t(comp - 1) : 0xFF); }
+    return pack_with(code_of, patterns, count, length);
+  }
+  // the same for the default alphabet "$ACGTN#" (A C G T in either case): no index needed
   static std::vector<std::uint64_t> pack_kmers(const std::uint8_t* patterns, size_type count, size_type length)
+  {
+    std::uint8_t code_of[256];
+    for(size_type c = 0; c < 256; c++) { code_of[c] = 0xFF; }
+    code_of['A'] = code_of['a'] = 0; code_of['C'] = code_of['c'] = 1; code_of['G'] = code_of['g'] = 2; code_of['T'] = code_of['t'] = 3;
+    return pack_with(code_of, patterns, count, length);
+  }
+  static std::vector<std::uint64_t> pack_with(const std::uint8_t* code_of, const std::uint8_t* patterns, size_type count, size_type length)
   {
     const size_type words = (length + 31) / 32;
     std::vector<std::uint64_t> codes(count * words, 0);
@@ -138,13 +153,8 @@ public:
     {
       for(size_type t = 0; t < length; t++)                  // distance t from the pattern's end
       {
-        std::uint64_t code = 0;
-        switch(patterns[q * length + (length - 1 - t)])
-        {
-          case 'A': case 'a': code = 0; break; case 'C': case 'c': code = 1; break;
-          case 'G': case 'g': code = 2; break; case 'T': case 't': code = 3; break;
-          default: throw std::invalid_argument("GCSA::pack_kmers(): a pattern holds a character outside ACGT");
-        }
+        const std::uint64_t code = code_of[patterns[q * length + (length - 1 - t)]];
+        if(code > 3) { throw std::invalid_argument("GCSA::pack_kmers(): a pattern holds a character that is not one of the index's four fast characters"); }
         codes[q * words + (t >> 5)] |= code << (2 * (t & 31));
       }
     }
@@ -160,6 +170,7 @@ public:
   {
     const size_type nq = offsets.empty() ? 0 : offsets.size() - 1;
     offsets_out.assign(nq + 1, 0);
+    if(nq == 0) { breaks.clear(); return; }                    // an empty batch: no records
     breaks.assign(4 * nq + 16, gcsa2_break());
     std::uint8_t dummy = 0;
     size_type total = 0;

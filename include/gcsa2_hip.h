@@ -514,7 +514,7 @@ int gcsa2_comm_create(const uint8_t* id, int rank, int world, int device, gcsa2_
  * memory at d_recv (its own part included) -- and is called by gcsa2_comm_gather / _match_stats / _locate wherever they would
  * use RCCL.  It may work asynchronously on `stream` or complete before it returns (after waiting for `stream`, on which the
  * data it sends was produced); 0 = success.  `user` is passed through.  gcsa2_comm_rccl_ranks reports 0 for such a
- * communicator. */
+ * communicator.  d_send is always a valid device address, also when bytes[rank] == 0 (nothing is to be read from it then). */
 typedef int (*gcsa2_gather_fn)(void* user, const void* d_send, const uint64_t* bytes, void* d_recv, int root, void* stream);
 int gcsa2_comm_create_custom(int rank, int world, int device, gcsa2_gather_fn gather, void* user, gcsa2_comm** out);
 void gcsa2_comm_destroy(gcsa2_comm* comm);

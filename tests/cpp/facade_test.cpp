@@ -123,7 +123,14 @@ int main(int argc, char** argv)
     want.push_back(index.find(p.substr(0, klen)));
   }
   std::vector<gcsa::range_type> packed = index.find_packed_batch(gcsa::GCSA::pack_kmers(flat.data(), want.size(), klen), klen);
-  std::cout << "packed " << want.size() << " " << (packed == want ? "same" : "DIFFERENT") << "\n";
+  // (packKMers goes through the index's own alphabet; on the default alphabet it equals the static form.  An empty batch of
+  // break points is no records, not an error: ADVICE r04)
+  const bool member_same = index.packKMers(flat.data(), want.size(), klen) == gcsa::GCSA::pack_kmers(flat.data(), want.size(), klen);
+  std::vector<gcsa::size_type> no_offsets, empty_boff;
+  std::vector<gcsa2_break> empty_breaks(3);
+  index.match_breaks_batch(std::vector<std::uint8_t>(), no_offsets, 0, empty_boff, empty_breaks);
+  const bool empty_ok = empty_breaks.empty() && empty_boff.size() == 1 && empty_boff[0] == 0;
+  std::cout << "packed " << want.size() << " " << (packed == want && member_same && empty_ok ? "same" : "DIFFERENT") << "\n";
 
   // break points (left-maximal matches) of every pattern, all of them and those of at least 3 characters
   std::vector<std::uint8_t> all;

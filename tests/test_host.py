@@ -488,3 +488,28 @@ def test_gcsa_inspect_lists_every_member(built, tmp_path):
     open(base + "_bad.gcsa", "wb").write(bytes(blob[: len(blob) - 9]))
     out = subprocess.run([tool, base + "_bad.gcsa"], capture_output=True, text=True)
     assert out.returncode != 0 and ("STOPPED" in out.stdout or "NOT ACCOUNTED" in out.stdout)
+
+
+def test_editing_a_facade_header_rebuilds_the_cli(built):
+    """build_cli's dependency list is every header a facade client is compiled from (include/gcsa/*.h through
+    include/gcsa2_hip/gcsa.hpp): a newer include/gcsa/gcsa.h makes query_gcsa stale and it is recompiled (VERDICT r04 #7)."""
+    import glob
+    from gcsa2_amd import build as engine_build
+    src = os.path.join(ROOT, "tools", "cpp", "query_gcsa.cpp")
+    deps = engine_build.cli_deps(src)
+    for h in glob.glob(os.path.join(ROOT, "include", "gcsa", "*.h")) + glob.glob(os.path.join(ROOT, "include", "gcsa2_hip", "*.hpp")):
+        assert h in deps, h
+    out = engine_build.build_query_gcsa()
+    first = os.stat(out).st_mtime_ns
+    assert engine_build.build_query_gcsa() == out and os.stat(out).st_mtime_ns == first          # up to date: left alone
+    header = os.path.join(ROOT, "include", "gcsa", "gcsa.h")
+    st = os.stat(header)
+    try:
+        os.utime(header, ns=(st.st_atime_ns, max(first, st.st_mtime_ns) + 2_000_000_000))
+        engine_build.build_query_gcsa()
+        assert os.stat(out).st_mtime_ns > first
+    finally:
+        os.utime(header, ns=(st.st_atime_ns, st.st_mtime_ns))
+    # (the rebuilt binary is now newer than the restored header: nothing is stale afterwards)
+    second = os.stat(out).st_mtime_ns
+    assert engine_build.build_query_gcsa() == out and os.stat(out).st_mtime_ns == second
