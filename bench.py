@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 HBM_MEASURED_GBS = 6290.0
-REQUEST_CEILING_GPS = 50.0       # dependent random 128-byte fetches/s at HBM footprints (gather_bench, profiles/r01_gather_bench.md)
+REQUEST_CEILING_GPS = 48.5       # dependent random 128-byte fetches/s at HBM footprints (gather_bench lds128, profiles/r01_gather_bench.md; r04: 48.47)
+MEASURED_CEILING = None          # ... as measured on this box at the start of the run (N = 1, unless --no-extras)
 LINEAR_SEED = 0x6C5A0040
 HUMAN_PATTERN_SEED = 0x6C5A0041
 CONFIG5_SEED = 0x6C5A0050
@@ -149,9 +150,14 @@ class Dist:
         if self.backend != "nccl":
             # control-flow runs with ranks sharing a GPU (RCCL refuses that): the library's communicator over a gather through
             # host memory (gcsa2_comm_create_custom), so that everything above the transport is the C++ that runs under RCCL
-            from gcsa2_amd.host_transport import HostGather
+            # (GCSA2_BENCH_TRANSPORT=blocking: the gather completes inside the call, as rounds 3-4 had it; the default only enqueues,
+            # so that gather k really runs under kernel k + 1 and `gather_hidden_frac` means something on one GPU)
+            from gcsa2_amd.host_transport import HostGather, AsyncHostGather
+            kind = HostGather if os.environ.get("GCSA2_BENCH_TRANSPORT", "async") == "blocking" else AsyncHostGather
+            self.transport = None
             try:
-                self.comm = binding.Comm.custom(self.rank, self.world, device_index, HostGather(self.dist, self.rank, self.world))
+                self.transport = kind(self.dist, self.rank, self.world)
+                self.comm = binding.Comm.custom(self.rank, self.world, device_index, self.transport)
             except Exception as e:
                 print(f"[bench] rank {self.rank}: gcsa2_comm_create_custom failed ({e})", file=sys.stderr, flush=True)
             if not self.all_true(self.comm is not None):
@@ -202,6 +208,8 @@ class Dist:
     def close(self):
         if self.comm is not None:
             self.comm.close()
+        if getattr(self, "transport", None) is not None and hasattr(self.transport, "close"):
+            self.transport.close()
         if self.active:
             self.dist.destroy_process_group()
 
@@ -715,7 +723,8 @@ def measure(args, D, dev, wl, steps, warmup):
         per_rank = everyone
     result = dict(elapsed=elapsed, kernel_ms=kernel_ms, d_out=d_out, gathered=None, pack32=pack32, pack40=pack40,
                   gather=(("gcsa2_comm_gather (library RCCL communicator)" if D.backend == "nccl" else
-                           "gcsa2_comm_gather over a host-memory transport (gcsa2_comm_create_custom; control-flow check)") if D.comm is not None else
+                           "gcsa2_comm_gather over a host-memory transport (gcsa2_comm_create_custom; control-flow check; "
+                           + ("blocking" if os.environ.get("GCSA2_BENCH_TRANSPORT", "async") == "blocking" else "asynchronous: enqueued on the gather stream") + ")") if D.comm is not None else
                           ("torch.distributed.gather (fallback)" if D.active and D.backend == "nccl" else
                            ("host copies (gloo control-flow check)" if D.active else "none (one GPU)"))))
     result["per_rank"] = per_rank
@@ -728,12 +737,23 @@ def measure(args, D, dev, wl, steps, warmup):
     # algorithmic traffic of one launch (instrumented kernel, outside the timed region)
     d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
     d_out2 = torch.zeros_like(d_out)
+    # the twin also marks every block it fetches in a bitmap over the image's blocks (d_stats[7]): the distinct blocks are
+    # the batch's working set -- what decides whether a leg is served by HBM or partly by L2 / the Infinity Cache
+    n_blocks = int(wl.ix.sigma) * (int(wl.ix.n) // 384 + 1) + 16 * (int(wl.ix.n) // 192 + 1)
+    d_touched = torch.zeros(n_blocks // 32 + 2, dtype=torch.int32, device=dev)
+    d_stats[7] = d_touched.data_ptr()
     gpu.find_stats_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), nq, d_out2.data_ptr(), d_stats.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(d_out, d_out2), "instrumented and timed kernels disagree"
     blocks, lf_steps, lookups, jumps, fetch_steps, second_fetches, wide_seeds, _ = (int(x) for x in d_stats.cpu())
+    bits = torch.tensor([bin(b).count("1") for b in range(256)], dtype=torch.int64, device=dev)
+    distinct_blocks = 0
+    as_bytes = d_touched.view(torch.uint8)
+    for a in range(0, as_bytes.shape[0], 1 << 26):
+        distinct_blocks += int(bits[as_bytes[a: a + (1 << 26)].to(torch.int64)].sum().item())
+    del d_touched, as_bytes
     result.update(blocks=blocks, lf_steps=lf_steps, lookups=lookups, jumps=jumps, fetch_steps=fetch_steps, second_fetches=second_fetches,
-                  wide_seeds=wide_seeds,
+                  wide_seeds=wide_seeds, distinct_blocks=distinct_blocks,
                   algo_bytes=blocks * gpu.find_block_bytes() + lookups * 8 + jumps * 16 + nq * (m + 16),
                   found=int((d_out[:, 0] <= d_out[:, 1]).sum().item()))
     return result
@@ -872,10 +892,35 @@ def measure_locate(gpu, d_ranges, dev, steps):
     gpu.count_device(d_ranges.data_ptr(), nq, d_cnt.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     consistent = bool(torch.equal(d_off[1:] - d_off[:-1], d_cnt)) and int(d_off[-1]) == int(total)
-    return {"count_equals_located": consistent,
-            "workload": f"locate() of the {nq} ranges found above, sorted distinct values per range, results into caller-owned HBM buffers",
-            "value": nq / (ms * 1e-3), "unit": "queries/s", "ms_per_step": ms, "values": int(total),
-            "values_per_s": int(total) / (ms * 1e-3), "locate_table_bytes": gpu.locate_table_bytes()}, d_off, d_val
+    out = {"count_equals_located": consistent,
+           "workload": f"locate() of the {nq} ranges found above, sorted distinct values per range, results into caller-owned HBM buffers",
+           "value": nq / (ms * 1e-3), "unit": "queries/s", "ms_per_step": ms, "values": int(total),
+           "values_per_s": int(total) / (ms * 1e-3), "locate_table_bytes": gpu.locate_table_bytes()}
+    out["roofline"] = locate_roofline(gpu, d_ranges, nq, int(total), ms)
+    return out, d_off, d_val
+
+
+def locate_roofline(gpu, d_ranges, nq, total, ms):
+    """What locate() must move at least, against the call's whole duration on the stream (several kernels and, in the general
+    pipeline, two host polls: `call_ms` is the caller's time, not a kernel time).  Path nodes = sum of the range widths; with the
+    locate table every path node costs one 8-byte table entry -- a RANDOM 128-byte line when the range is one node, consecutive
+    entries of a line when it is wide -- and every value 8 bytes out; ranges and offsets are streamed.  A batch of one-node
+    ranges is a pure gather: its request rate against the box's ceiling is the figure of merit.  Wide ranges pay for
+    removeDuplicates (sort + compaction), which no byte count of the INPUT bounds: their `frac` is reported, not argued."""
+    import torch
+    width = (d_ranges[:, 1] - d_ranges[:, 0] + 1).clamp(min=0)
+    nodes = int(width.sum().item())
+    singles = int((width == 1).sum().item())
+    lines = singles + int(torch.div(width[width > 1] + 15, 16, rounding_mode="floor").sum().item())      # 16 entries per 128-byte line
+    algo = 16 * nq + 8 * nodes + 8 * total + 8 * (nq + 1)
+    limit = MEASURED_CEILING or REQUEST_CEILING_GPS
+    rate = lines / (ms * 1e-3) / 1e9
+    achieved = algo / (ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "kernel": "k_locate_single" if (singles == nq and total == nq and gpu.locate_table_bytes()) else "locate pipeline (walk / table, sorts, compaction)",
+           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+           "algorithmic_bytes_per_call": algo, "call_ms": ms, "path_nodes": nodes, "one_node_ranges": singles,
+           "request_rate": {"table_lines_per_call": lines, "achieved_G_per_s": rate, "ceiling_G_per_s": limit, "frac_of_ceiling": rate / limit}}
+    return out
 
 
 def pmc_traffic(args, key, gpu, nq, m):
@@ -894,30 +939,50 @@ def pmc_traffic(args, key, gpu, nq, m):
     return entry["read_bytes_per_launch"]
 
 
-def working_set(gpu, ix):
+def working_set(gpu, r, nq):
+    """Bytes a launch gathers from: the DISTINCT blocks it fetched (the instrumented twin's bitmap) and the lines of the seed
+    table its lookups fall into (expected number for uniformly spread indices: L (1 - exp(-lookups / L)) of L lines of 16 entries)."""
     k = gpu.kmer_table_k()
-    blocks = gpu.pair_block_bytes() or int(ix.sigma) * (int(ix.n) // 384 + 1) * 128
-    return int(blocks + ((8 << (2 * k)) if k else 0))
+    lines = float(1 << (2 * k)) / 16.0 if k else 0.0
+    seed_lines = lines * (1.0 - float(np.exp(-r["lookups"] / lines))) if lines >= 1.0 and r["lookups"] else 0.0
+    return int(r["distinct_blocks"] * gpu.find_block_bytes() + seed_lines * 128)
 
 
-def roofline(args, r, wl, key):
+CACHE_BYTES = 256 << 20          # Infinity Cache (MALL) of an MI355X; the eight L2s add 32 MB
+
+
+def roofline(args, r, wl, key, ceiling=None):
     gpu, nq, m = wl.gpu, wl.nq, wl.m
     achieved = r["algo_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9
     traffic = pmc_traffic(args, key, gpu, nq, m)
-    ws = working_set(gpu, wl.ix)
+    ws = working_set(gpu, r, nq)
+    requests = r["blocks"] + r["lookups"] + r["jumps"]
+    req_rate = requests / (r["kernel_ms"] * 1e-3) / 1e9
+    limit = ceiling or MEASURED_CEILING or REQUEST_CEILING_GPS
+    # Who serves the launch.  A batch whose working set is many times the on-die caches AND whose request rate stays below what
+    # HBM delivers for dependent random 128-byte fetches (gather_bench) is served by HBM: `frac` is then an HBM fraction.
+    # Anything else -- a working set within a few multiples of the Infinity Cache, repeated blocks (ranges that share their
+    # upper levels: requests per distinct block well above one), a request rate above the HBM ceiling -- is served partly
+    # on-die, and `achieved` / `frac` are ALGORITHMIC rates, not memory-side ones (VERDICT r04 weak #3).
+    reuse = requests / max(1.0, ws / 128.0)
+    on_die = ws < 8 * CACHE_BYTES or req_rate > limit or achieved > HBM_PEAK_GBS or reuse > 1.5
     out = {"bound": "hbm", "kernel": "k_find2<pair>" if gpu.pair_block_bytes() else "k_find2",
            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
            "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"], "working_set_bytes": ws,
-           "working_set_note": ("blocks + seed table the launch gathers from: far beyond the 256 MiB Infinity Cache, served by HBM" if ws > (2 << 30)
-                                else "within a few multiples of the 256 MiB Infinity Cache: partly served on-die, `frac` is not an HBM fraction here")}
+           "requests_per_distinct_line": reuse,
+           "served": "L2 / Infinity Cache (partly)" if on_die else "HBM",
+           "working_set_note": ("distinct blocks fetched (bitmap of the instrumented twin) + seed-table lines: "
+                                + ("partly served on-die, `achieved` and `frac` are algorithmic rates, not HBM fractions" if on_die
+                                   else "far beyond the 256 MiB Infinity Cache, one request per line: served by HBM"))}
     # what bounds a random-gather kernel beyond L2 is requests per second (profiles/r01_gather_bench.md:
     # ~50 G dependent random 128-byte fetches/s at HBM footprints); reported beside the byte roofline
-    requests = r["blocks"] + r["lookups"] + r["jumps"]
-    out["request_rate"] = {"achieved_G_per_s": requests / (r["kernel_ms"] * 1e-3) / 1e9, "ceiling_G_per_s": REQUEST_CEILING_GPS,
-                           "requests_per_query": requests / nq}
+    out["request_rate"] = {"achieved_G_per_s": req_rate, "ceiling_G_per_s": limit, "requests_per_query": requests / nq}
+    if not on_die:
+        out["request_rate"]["frac_of_ceiling"] = req_rate / limit
     if traffic is not None:
         out["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_*_sum pass of this workload; "
                                  "128 B x RDREQ_128B + 64 B x RDREQ_64B + 32 B x RDREQ_32B)")
+        out["traffic_over_algorithmic"] = traffic / r["algo_bytes"]
         out["traffic_GBps"] = traffic / (r["kernel_ms"] * 1e-3) / 1e9
         # the guide's measured streaming rate (MI355X_MICROARCH.md: 6.29 TB/s float4 copy = 79 % of the 8 TB/s spec): how close the
         # launch's memory-side traffic is to what HBM delivers at all
@@ -989,7 +1054,14 @@ def config5(args, wl, dev):
            "match_stats_ms": ms_time, "patterns_per_s": nq / (ms_time * 1e-3), "bases_per_s": nq * m / (ms_time * 1e-3),
            "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item()),
            "unmodified_half_equals_closed_form": exact_ok}
+    try:
+        out["roofline"] = match_stats_roofline(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, ms_time, dev, records=None)
+    except Exception as e:               # (the twin needs the pair blocks: absent on an image made under a tight memory budget)
+        out["roofline"] = {"error": str(e)[:200]}
     out["match_breaks"] = match_breaks_leg(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, exp, timed, dev)
+    if "error" not in out["roofline"]:
+        mb = out["match_breaks"]
+        mb["roofline"] = match_stats_roofline(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, mb["ms"], dev, records=mb["records"], events=out["roofline"]["events"])
     # plain find() of the same batch (a substituted pattern usually empties at its first substitution)
     d_find = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
     out["find_ms"] = timed(lambda: gpu.find_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_find.data_ptr(), stream.cuda_stream))
@@ -1007,6 +1079,45 @@ def config5(args, wl, dev):
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_match_stats(ix, d_pat, d_ms, d_rng, d_fb, m)
     return out
+
+
+def match_stats_roofline(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, kernel_ms, dev, records=None, events=None):
+    """Memory requests of one launch of the matching-statistics kernel from its instrumented twin (gcsa2_match_stats_profile_device:
+    same results, event counts), against the box's request ceiling -- the kernel is a gather like find(): blocks requested first
+    (one per lane step or pair attempt), second blocks (endpoints in different blocks), LCP windows (parent()), all 128-byte
+    lines; one 16-byte pattern record per 32 characters, the seed entry, the pattern's offsets; the statistics go out as 32-byte
+    sectors (16 positions), break points as 32-byte records.  `kernel_ms` is the timed launch (pre-pass included)."""
+    import torch
+    if events is None:
+        d_prof = torch.zeros(16, dtype=torch.int64, device=dev)
+        keep = (d_ms.clone(), d_rng.clone(), d_fb.clone())
+        gpu.match_stats_profile_device(d_pat.data_ptr(), d_off.data_ptr(), nq, nq * m, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), d_prof.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(keep[0], d_ms) and torch.equal(keep[1], d_rng) and torch.equal(keep[2], d_fb), "instrumented and timed kernels disagree"
+        prof = [int(x) for x in d_prof.cpu()]
+        if os.environ.get("GCSA2_MS_KERNEL", "2") == "3":
+            names = ["rounds", "second_fetches", "lane_steps", "pair_attempts", "failed_pair_attempts", "parent_calls", "lcp_windows", "retries_from_staged_block"]
+            events = dict(zip(names, prof[8:16]))
+        else:                             # k_match_stats2's twin: one window per parent() call, every retry a block request (a lane step)
+            names = ["rounds", "rounds_with_second_fetch", "lane_steps", "pair_attempts", "failed_pair_attempts", "parent_calls", "tree_walks", "second_fetches"]
+            events = dict(zip(names, prof[8:16]))
+            events["lcp_windows"] = events["parent_calls"]
+        del keep
+    lines = events["lane_steps"] + events["second_fetches"] + events["lcp_windows"]
+    records_in = nq * ((m + 31) // 32 + 2)
+    small = records_in + 2 * nq                                   # pattern records, seed entry, offsets
+    writes = nq * ((m + 15) // 16) if records is None else records + nq
+    algo = 128 * lines + 16 * records_in + 24 * nq + 32 * writes + 24 * nq
+    requests = lines + small + writes
+    limit = MEASURED_CEILING or REQUEST_CEILING_GPS
+    rate = requests / (kernel_ms * 1e-3) / 1e9
+    achieved = algo / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": ("k_match_stats3" if os.environ.get("GCSA2_MS_KERNEL", "2") == "3" else "k_match_stats2") + ("<breaks>" if records is not None else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo, "kernel_ms": kernel_ms,
+            "events": events, "requests_per_pattern": requests / nq, "line_requests_per_pattern": lines / nq,
+            "request_rate": {"achieved_G_per_s": rate, "ceiling_G_per_s": limit, "frac_of_ceiling": rate / limit},
+            "frac_of_request_ceiling": rate / limit}
 
 
 def match_breaks_leg(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, exp, timed, dev):
@@ -1332,14 +1443,14 @@ class Leg(Workload):
         self.label = label
 
 
-def find_leg(args, D, dev, leg, steps, expect=None):
+def find_leg(args, D, dev, leg, steps, expect=None, key="unprofiled"):
     """One find() measurement as a compact object: rate, requests per query, share of steps that fetch a second block
     (a range whose ends lie in different blocks), mean range width, roofline, and the closed-form check."""
     import torch
     r = measure(args, D, dev, leg, steps, 1)
     d_out = r["d_out"]
     width = (d_out[:, 1] - d_out[:, 0] + 1).to(torch.float64)
-    rf = roofline(args, r, leg, "unprofiled")
+    rf = roofline(args, r, leg, key)
     out = {"workload": leg.label, "value": leg.nq / (r["kernel_ms"] * 1e-3), "unit": "queries/s", "kernel_ms": r["kernel_ms"], "queries": leg.nq,
            "pattern_len": leg.m, "kmer_table_k": leg.gpu.kmer_table_k(), "pair_blocks": bool(leg.gpu.pair_block_bytes()),
            "mean_range_width_path_nodes": float(width.mean().item()), "ranges_wider_than_one": float((width > 1).to(torch.float64).mean().item()),
@@ -1347,7 +1458,15 @@ def find_leg(args, D, dev, leg, steps, expect=None):
            "requests_per_query": rf["request_rate"]["requests_per_query"], "requests_G_per_s": rf["request_rate"]["achieved_G_per_s"],
            "second_fetch_fraction_of_steps": r["second_fetches"] / max(r["fetch_steps"], 1), "wide_seed_entries_hit": r["wide_seeds"],
            "algorithmic_bytes_per_launch": r["algo_bytes"], "achieved_GBps": rf["achieved"], "frac": rf["frac"],
-           "working_set_bytes": rf["working_set_bytes"], "image_bytes_hbm": leg.gpu.device_bytes()}
+           "served": rf["served"], "working_set_bytes": rf["working_set_bytes"], "requests_per_distinct_line": rf["requests_per_distinct_line"],
+           "image_bytes_hbm": leg.gpu.device_bytes()}
+    if rf["served"] != "HBM":
+        out["frac_is"] = "algorithmic bytes / kernel time / 8 TB/s: the launch is partly served on-die, this is NOT an HBM fraction"
+    else:
+        out["frac_of_request_ceiling"] = rf["request_rate"].get("frac_of_ceiling")
+    for name in ("traffic", "traffic_over_algorithmic", "traffic_GBps", "traffic_frac_of_measured_hbm_rate"):
+        if rf.get(name) is not None:
+            out[name] = rf[name]
     if expect is not None:
         out["all_ranges_equal_closed_form"] = bool(expect(d_out))
     return out, d_out
@@ -1371,28 +1490,34 @@ def wide_ranges_secondary(args, D, dev, wl):
         pats, sp, ep = dbg_torch.prefix_patterns_device(wl.dbg, 0, nq, m, HUMAN_PATTERN_SEED + 0x100 + m)
         leg = Leg(wl, padded_bytes(pats), nq, m, f"{nq} x {m}-mers, prefixes of path labels of the headline index (closed form: rank interval of the k-mer bitmap)")
         del pats
-        out[f"{m}-mers"], _ = find_leg(args, D, dev, leg, 5, expect=lambda d: torch.equal(d[:, 0], sp) and torch.equal(d[:, 1], ep))
+        out[f"{m}-mers"], _ = find_leg(args, D, dev, leg, 5, expect=lambda d: torch.equal(d[:, 0], sp) and torch.equal(d[:, 1], ep),
+                                       key=f"pangenome_{wl.degree}_{m}_prefix")
         del leg, sp, ep
     k_cut = min(8, max(1, wl.dbg.k // 2))
     if k_full > k_cut:
         wl.gpu.set_tables(kmer_k=k_cut)
         leg = Leg(wl, wl.d_pat, wl.nq, wl.m, f"the headline batch ({wl.nq} x {wl.m}-mers) with the seed table cut to k = {k_cut}")
-        out[f"{wl.m}-mers, seed table k = {k_cut}"], _ = find_leg(args, D, dev, leg, 3, expect=lambda d: wl.verify(d, wl.first, wl.nq))
+        out[f"{wl.m}-mers, seed table k = {k_cut}"], _ = find_leg(args, D, dev, leg, 3, expect=lambda d: wl.verify(d, wl.first, wl.nq),
+                                                               key=f"pangenome_{wl.degree}_{wl.m}_S_k{k_cut}")
         wl.gpu.set_tables(kmer_k=k_full)
     return out
 
 
 def memory_ladder(args, D, dev, wl, headline):
-    """What each optional table buys, at HBM scale: the headline batch and locate() of its first 10 M ranges on the same image
-    re-shaped rung by rung with gcsa2_index_set_tables (no re-creation; the ladder only goes down).  Every rung is checked
-    bit for bit against the closed form (find) and count() (locate).  Rungs: everything (the headline itself); without the
-    locate table (locate() walks: k_locate_walk2); seed table one size down; no pair blocks and the seed table three sizes
-    down (the image north_star's "~30 GB" had in mind).  GCSA2_MEMORY_BUDGET_MB at create time takes the same decisions from
-    a cap (tests/test_gpu_parity.py::test_memory_ladder)."""
+    """What each optional table buys per gigabyte, at HBM scale: the headline batch and locate() of its first 10 M ranges on the
+    same image re-shaped rung by rung with gcsa2_index_set_tables (no re-creation).  Every rung is checked bit for bit against
+    the closed form (find) and count() (locate).  The rungs go down in the order that loses least find() throughput per
+    gigabyte freed (round 4's ladder gave up the 61 GB pair blocks before a 26 GB seed level worth a ninth of them, VERDICT r04
+    #4): locate table, then seed-table levels (each quarters the table and costs one LF step per query), and only then the pair
+    blocks; the second half shows the seed table's value without pair blocks.  The last rung is the image north_star's "~30 GB"
+    had in mind (paper.tex:380: 14.6 GB for the reference's encoding) -- its rate goes into the line as
+    `value_at_reference_footprint`.  GCSA2_MEMORY_BUDGET_MB at create time takes the same decisions from a cap
+    (tests/test_gpu_parity.py::test_memory_ladder)."""
     import torch
     gpu = wl.gpu
     k_full = gpu.kmer_table_k()
     has_samples = gpu.sampleCount() > 0
+    has_pairs = gpu.pair_block_bytes() > 0
     nloc = min(10_000_000, wl.nq)
     rungs = []
 
@@ -1401,15 +1526,21 @@ def memory_ladder(args, D, dev, wl, headline):
         if first:
             o = {"workload": name, "value": headline["value"], "kernel_ms": headline["roofline"]["kernel_ms"],
                  "requests_per_query": headline["roofline"]["request_rate"]["requests_per_query"], "frac": headline["roofline"]["frac"],
+                 "frac_of_request_ceiling": headline["roofline"]["request_rate"].get("frac_of_ceiling"), "served": headline["roofline"]["served"],
                  "all_ranges_equal_closed_form": headline["config"]["all_ranges_equal_closed_form"], "from": "the headline measurement above"}
             d_out = torch.zeros((wl.nq, 2), dtype=torch.int64, device=dev)
             gpu.find_device(wl.d_pat.data_ptr(), wl.d_off.data_ptr(), wl.nq, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
         else:
             o, d_out = find_leg(args, D, dev, leg, 3, expect=lambda d: wl.verify(d, wl.first, wl.nq))
-            o = {key: o[key] for key in ("workload", "value", "kernel_ms", "requests_per_query", "lf_steps_per_query", "frac", "all_ranges_equal_closed_form")}
+            o = {key: o.get(key) for key in ("workload", "value", "kernel_ms", "requests_per_query", "lf_steps_per_query", "frac", "frac_of_request_ceiling",
+                                             "served", "all_ranges_equal_closed_form")}
         o.update(image_bytes_hbm=gpu.device_bytes(), pair_block_bytes=gpu.pair_block_bytes(), kmer_table_k=gpu.kmer_table_k(),
                  locate_table_bytes=gpu.locate_table_bytes())
+        if rungs:
+            freed = (rungs[-1]["image_bytes_hbm"] - o["image_bytes_hbm"]) / 1e9
+            if freed > 0:
+                o["queries_per_s_lost_per_GB_freed"] = (rungs[-1]["value"] - o["value"]) / freed
         if has_samples:
             loc, _, _ = measure_locate(gpu, d_out[:nloc].contiguous(), dev, 2)
             o["locate"] = {key: loc[key] for key in ("value", "unit", "ms_per_step", "values", "count_equals_located")}
@@ -1421,14 +1552,27 @@ def memory_ladder(args, D, dev, wl, headline):
     if gpu.locate_table_bytes() > 0:
         gpu.set_tables(locate_table=0)
         rung("without the locate table")
-    if k_full >= 2:
-        gpu.set_tables(kmer_k=k_full - 1)
-        rung(f"... and the seed table at k = {k_full - 1}")
-    if gpu.pair_block_bytes() > 0:
-        gpu.set_tables(pair_blocks=0, kmer_k=max(1, k_full - 3))
-        rung(f"... no pair blocks, seed table at k = {max(1, k_full - 3)}")
-    return {"note": "one image re-shaped with gcsa2_index_set_tables; find() = the headline batch, locate() = its first "
-                    f"{nloc} ranges; results identical on every rung", "rungs": rungs}
+    seen = {k_full}
+    for k in (k_full - 1, k_full - 2, k_full - 3):
+        if k >= 1 and k not in seen:
+            seen.add(k)
+            gpu.set_tables(kmer_k=k)
+            rung(f"... seed table at k = {k}" + (" (pair blocks kept)" if has_pairs else ""))
+    if has_pairs:
+        seen = set()
+        for k in (k_full, k_full - 1, k_full - 3):
+            if k >= 1 and k not in seen:
+                seen.add(k)
+                gpu.set_tables(pair_blocks=0, kmer_k=k)
+                rung(f"no pair blocks, seed table at k = {k}")
+    out = {"note": "one image re-shaped with gcsa2_index_set_tables; find() = the headline batch, locate() = its first "
+                   f"{nloc} ranges; results identical on every rung", "rungs": rungs}
+    last = rungs[-1]
+    headline["value_at_reference_footprint"] = {
+        "value": last["value"], "unit": "queries/s", "image_GB": round(last["image_bytes_hbm"] / 1e9, 1), "frac": last["frac"],
+        "frac_of_request_ceiling": last.get("frac_of_request_ceiling"), "requests_per_query": last["requests_per_query"],
+        "tables": last["workload"], "note": "the headline batch on the smallest image of the memory ladder (north_star: ~30 GB)"}
+    return out
 
 
 # ---- a repeat-rich text at HBM footprint: wide ranges as real genomes have them (VERDICT r03 #2 ii) ----------------
@@ -1491,7 +1635,7 @@ def repeats_hbm_secondary(args, D, dev, local_rank, log2_bases=30):
     for m in (32, 16):
         pats, _ = repeats_torch.substring_patterns_device(seq, nq, m, REPEATS30_SEED + m)
         leg = Leg(wl, padded_bytes(pats), nq, m, f"{nq} x {m}-mers, substrings of the text at SplitMix64 positions")
-        o, d_out = find_leg(args, D, dev, leg, 5)
+        o, d_out = find_leg(args, D, dev, leg, 5, key=f"repeats30_{log2_bases}_{m}_S")
         ns = 64
         occ = repeats_torch.count_occurrences_device(seq, pats[:ns])
         o["range_width_equals_occurrences_in_text_on_sample"] = bool(torch.equal(d_out[:ns, 1] - d_out[:ns, 0] + 1, occ))
@@ -1670,17 +1814,20 @@ def one_number(key, leg):
         out["match_stats_frac_of_request_ceiling"] = leg.get("roofline", {}).get("frac_of_request_ceiling")
         out["match_breaks_patterns_per_s"] = leg.get("match_breaks", {}).get("patterns_per_s")
         out["locate_values_per_s"] = leg.get("locate", {}).get("values_per_s")
+        out["locate_frac_of_request_ceiling"] = leg.get("locate", {}).get("roofline", {}).get("request_rate", {}).get("frac_of_ceiling")
         return out
     if key == "host_batch":
         return {"queries_per_s": leg.get("value"), "packed_queries_per_s": leg.get("packed", {}).get("value")}
     if key == "memory_ladder":
-        return {short(x["workload"], 60): {"queries_per_s": x["value"], "GB": round(x["image_bytes_hbm"] / 1e9, 1)} for x in leg.get("rungs", [])}
+        rungs = leg.get("rungs", [])       # (image GB, G queries/s) rung by rung; the tables of each rung are in bench_full.json
+        return {"image_GB": [round(x["image_bytes_hbm"] / 1e9, 1) for x in rungs], "G_queries_per_s": [round(x["value"] / 1e9, 3) for x in rungs]}
     if key == "locate":
         return pick(leg, "values_per_s", "ms_per_step")
     if "value" in leg:                      # chr22, human32, human_branching
         out = {"queries_per_s": leg["value"], "frac": leg.get("roofline", {}).get("frac")}
         if "locate" in leg:
             out["locate_values_per_s"] = leg["locate"].get("values_per_s")
+            out["locate_frac_of_request_ceiling"] = leg["locate"].get("roofline", {}).get("request_rate", {}).get("frac_of_ceiling")
         return out
     # wide_ranges, repeats, repeats_hbm: one object per pattern length
     return {short(k, 40): {"queries_per_s": v["value"], "served": v.get("served", v.get("roofline", {}).get("served"))}
@@ -1870,7 +2017,9 @@ def main():
         raise SystemExit(f"bench.py: world size {world} but --gpus {args.gpus}")
     from gcsa2_amd import binding
     D.make_comm(binding, local_rank)
+    global MEASURED_CEILING
     ceiling = measured_request_ceiling() if (rank == 0 and world == 1 and not args.no_extras) else None
+    MEASURED_CEILING = ceiling
     if ceiling is not None:
         log(f"request-rate ceiling of this box: {ceiling:.1f} G dependent random 128-byte fetches/s (gather_bench lds128, 32 GB)")
 
@@ -1935,10 +2084,7 @@ def run_legs(args, D, dev, local_rank, wl, ceiling, emitter):
                 "per_rank": ranks}
         result["config"]["all_ranges_equal_closed_form"] = checked
         if ceiling is not None:
-            rr = result["roofline"]["request_rate"]
-            rr["ceiling_G_per_s"] = ceiling
-            rr["ceiling_source"] = "gather_bench --mode lds128 35 on this box, before the index was loaded"
-            rr["frac_of_ceiling"] = rr["achieved_G_per_s"] / ceiling
+            result["roofline"]["request_rate"]["ceiling_source"] = "gather_bench --mode lds128 35 on this box, before the index was loaded"
     emitter.headline(result)
     leg = emitter.leg
     if rank == 0 and not args.no_cpu and world == 1:

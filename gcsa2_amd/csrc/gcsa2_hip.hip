@@ -44,6 +44,7 @@ using namespace g2;
 #include "kernels_find.hpp"
 #include "kernels_locate.hpp"
 #include "kernels_lcp.hpp"
+#include "kernels_ms3.hpp"
 #include "kernels_build.hpp"
 
 // ==========================================================================================
@@ -121,6 +122,13 @@ struct gcsa2_index
     bool poll_small = true;            // GCSA2_POLL_SMALL=0: zero-copy calls end with hipStreamSynchronize instead of a polled ticket
     u32 seed_wide = (u32(1) << 24) - 1;   // GCSA2_SEED_WIDE: seed-table entries of this many path nodes or more are marked, not stored (tests)
     bool locate_trace = false;         // GCSA2_LOCATE_TRACE=1: host-clock stamps of a locate pass on stderr (profiles/r04_locate.md)
+    u32 split_target = SPLIT_TARGET;   // GCSA2_SPLIT_TARGET (tests): values per bucket k_over_split aims at
+    u32 split_skew = BIG_SEGMENT;      // GCSA2_SPLIT_SKEW (tests): buckets of more values than this count as skewed and go to the radix sort
+    bool locate_split_sort = true;     // GCSA2_LOCATE_SPLIT_SORT=0: segments beyond 8192 distinct values go to the library's device-wide radix sort (round 4; A/B)
+    bool locate_single = true;         // GCSA2_LOCATE_SINGLE=0: batches of one-value ranges go through the general locate pipeline too (A/B)
+    u32 ms_kernel = 2;                 // GCSA2_MS_KERNEL=3: variant 0 of the matching statistics runs k_match_stats3 (kernels_ms3.hpp; A/B: it loses, profiles/r05_match_stats.md)
+    bool ms_short_parent = false;      // GCSA2_MS_SHORT_PARENT=1: k_match_stats2 tries parent() from the eight bytes on either side first (A/B: 7.18 against 6.81 ms, it loses there -- with ~6 parenting lanes per round some lane needs the whole window anyway)
+    u32 ms_speculate = 1;              // GCSA2_MS_SPECULATE: bit 0 clear: k_match_stats3 requests an LCP window only after a step has failed; bit 1: one parent() per round; bit 2: no short parent() (A/B)
     size_t arena_cap = size_t(24) << 30;  // GCSA2_ARENA_CAP_MB: most scratch a handle keeps between calls per arena (struct Scratch)
     u64 budget_bytes = 0;              // GCSA2_MEMORY_BUDGET_MB: most device memory the image may take (0: what the device has free)
   } tune;
@@ -722,6 +730,13 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.ms_threads = u32(knob("GCSA2_MS_THREADS", 4, 1, 16));
     ix->tune.kmer_piece = u64(knob("GCSA2_KMER_PIECE", long(1) << 27, 4, long(1) << 27));
     ix->tune.locate_trace = (knob("GCSA2_LOCATE_TRACE", 0, 0, 1) != 0);
+    ix->tune.locate_single = (knob("GCSA2_LOCATE_SINGLE", 1, 0, 1) != 0);
+    ix->tune.locate_split_sort = (knob("GCSA2_LOCATE_SPLIT_SORT", 1, 0, 1) != 0);
+    ix->tune.split_skew = u32(knob("GCSA2_SPLIT_SKEW", BIG_SEGMENT, 16, BIG_SEGMENT));
+    ix->tune.split_target = u32(knob("GCSA2_SPLIT_TARGET", SPLIT_TARGET, 1, 4096));
+    ix->tune.ms_kernel = u32(knob("GCSA2_MS_KERNEL", 2, 2, 3));
+    ix->tune.ms_speculate = u32(knob("GCSA2_MS_SPECULATE", 3, 0, 7));
+    ix->tune.ms_short_parent = (knob("GCSA2_MS_SHORT_PARENT", 0, 0, 1) != 0);
     ix->tune.arena_cap = size_t(knob("GCSA2_ARENA_CAP_MB", 24576, 0, long(1) << 20)) << 20;    // 24 GB: 1/12 of an MI355X's HBM per arena
     ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
     {
@@ -1397,6 +1412,39 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   u64* sizes = nullptr; u64* segs = nullptr;
   const unsigned slot = ix->next_slot.fetch_add(1) % RESULT_SLOTS;
   unsigned long long* d_totals = ix->d_slots + u64(TOTAL_WORDS) * slot;
+  if(ix->img.locate_tab != nullptr && ix->tune.locate_single)
+  {
+    // every range one path node with one directly stored value?  Then this kernel is the whole answer (k_locate_single); the
+    // first misfit sends the batch through the pipeline below.  (The answer does not depend on `sort`: one value per range.)
+    // (into scratch, copied out on success: a batch with a misfit must not leave values of this attempt in the caller's buffer
+    // beyond what the pipeline then writes)
+    u64* out = nullptr;
+    HIP_TRY(scratch.get(out, nq));
+    HIP_TRY(hipMemsetAsync(d_totals, 0, TOTAL_WORDS * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(k_locate_single, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, d_offsets, out, nq, d_totals);
+    LAUNCH_CHECK("k_locate_single");
+    unsigned long long first[TOTAL_WORDS];
+    int rc1 = read_totals(ix, slot, first, stream);              // in stream order behind the kernel
+    if(rc1 != GCSA2_OK) { return rc1; }
+    scratch.settled = true;
+    if(first[0] == 0)
+    {
+      *total_out = nq;
+      u64* dest = known_out;
+      if(known_out != nullptr) { if(known_capacity < nq) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small"); } }
+      else
+      {
+        dest = values_for(nq);
+        if(dest == nullptr) { return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
+      }
+      scratch.settled = false;
+      HIP_TRY(hipMemcpyAsync(dest, out, nq * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      scratch.settled = true;
+      return GCSA2_OK;
+    }
+    scratch.settled = false;
+  }
   HIP_TRY(scratch.get(sizes, 3 * (nq + 1))); HIP_TRY(scratch.get(segs, 6 * nq));
   u64 *node_counts = sizes, *raw_counts = sizes + (nq + 1), *node_off = sizes + 2 * (nq + 1), *raw_off = d_offsets;
   u64 *seg_begin = segs, *seg_end = segs + nq, *huge_begin = segs + 2 * nq, *huge_end = segs + 3 * nq, *over_begin = segs + 4 * nq, *over_end = segs + 5 * nq;
@@ -1531,7 +1579,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(large + huge)), dim3(BIG_THREADS), 0, stream, seg_begin, seg_end, sorted, d_totals + T_LARGE);
     LAUNCH_CHECK("k_sort_big");
   }
-  if(over > 0)
+  auto radix_over = [&](u64* over_begin, u64* over_end, u64 over, u64 over_values) -> int
   {
     // keys = (rank of the segment) << value_bits | value; a value is a sample + fewer than 2^23 steps
     u32 value_bits = u32(ix->img.sample_width > 24 ? ix->img.sample_width : 24) + 1, rank_bits = 1;
@@ -1571,7 +1619,36 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
       HIP_TRY(scratch.get(sort_tmp, sort_bytes));
       HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, sort_bytes, raw, sorted, int(total_raw), int(over), over_begin, over_end, 0, 64, stream));
     }
+    return GCSA2_OK;
+  };
+  if(over > 0 && ix->tune.locate_split_sort)
+  {
+    // segments of more than BIG_SEGMENT distinct values: one workgroup each splits its segment into buckets that the
+    // workgroup sort holds (k_over_split); what a skewed segment leaves over goes to the device-wide radix sort as before
+    const u64 bucket_cap = over_values / 64 + over + 16;                  // listed buckets have more than 64 values
+    u64 *split_tmp = nullptr, *bkt_begin = nullptr, *bkt_end = nullptr, *skew_begin = nullptr, *skew_end = nullptr;
+    HIP_TRY(scratch.get(split_tmp, total_raw));
+    HIP_TRY(scratch.get(bkt_begin, bucket_cap)); HIP_TRY(scratch.get(bkt_end, bucket_cap));
+    const u32 skew_above = ix->tune.split_skew;                            // BIG_SEGMENT (lower in tests): what the workgroup sort takes
+    const u64 skew_cap = over_values / skew_above + over + 16;
+    HIP_TRY(scratch.get(skew_begin, skew_cap)); HIP_TRY(scratch.get(skew_end, skew_cap));
+    hipLaunchKernelGGL(k_over_split, dim3(unsigned(over)), dim3(SPLIT_THREADS), 0, stream, over_begin, over_end, sorted, split_tmp,
+                       bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target);
+    LAUNCH_CHECK("k_over_split");
+    rc = read_totals(ix, slot, totals, stream);
+    if(rc != GCSA2_OK) { return rc; }
+    const u64 buckets = totals[T_BUCKETS], skew = totals[T_SKEW], skew_values = totals[T_SKEW_VALUES];
+    if(buckets > bucket_cap) { return fail(GCSA2_ERR_HIP, "locate: more buckets than the split reserved"); }
+    if(buckets > 0)
+    {
+      hipLaunchKernelGGL(k_sort_bucket, dim3(unsigned(buckets)), dim3(64), 0, stream, bkt_begin, bkt_end, sorted, split_tmp, d_totals + T_BUCKETS);
+      hipLaunchKernelGGL((k_sort_big<4096, MEDIUM_SEGMENT>), dim3(unsigned(buckets)), dim3(BIG_THREADS), 0, stream, bkt_begin, bkt_end, sorted, d_totals + T_BUCKETS, split_tmp);
+      hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(buckets)), dim3(BIG_THREADS), 0, stream, bkt_begin, bkt_end, sorted, d_totals + T_BUCKETS, split_tmp);
+      LAUNCH_CHECK("k_sort_big (buckets)");
+    }
+    if(skew > 0) { rc = radix_over(skew_begin, skew_end, skew, skew_values); if(rc != GCSA2_OK) { return rc; } }
   }
+  else if(over > 0) { rc = radix_over(over_begin, over_end, over, over_values); if(rc != GCSA2_OK) { return rc; } }
   hipLaunchKernelGGL(k_mark_changes, dim3(grid_for(nwords * 64)), dim3(TPB), 0, stream, sorted, total_raw, words);
   hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, words);
   hipLaunchKernelGGL(k_word_counts, dim3(grid_for(nwords + 1)), dim3(TPB), 0, stream, words, nwords, word_counts);
@@ -3132,27 +3209,78 @@ extern "C" int gcsa2_count_kmers(const gcsa2_index* ix, uint64_t k, int include_
 // patterns from a counter, 0 = the library chooses by batch size.  total_bytes = offsets[nq] when the caller knows it (GCSA2_UNKNOWN: read back from the
 // device, which waits for the stream once).
 namespace {
+// k_match_stats3 (kernels_ms3.hpp): the pre-pass writes 16-byte pattern records; persistent lanes or a lane per pattern
+template<bool PAIR, bool REFILL, bool BREAKS>
+void launch_ms3(const gcsa2_index* ix, unsigned grid, hipStream_t st, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq,
+                unsigned short* out, uint64_t* d_ranges, uint64_t* d_fallbacks, unsigned long long* queue, const ulonglong2* recs, const BreakSink* sink)
+{
+  unsigned long long* none = nullptr;
+  hipLaunchKernelGGL((k_match_stats3<PAIR, REFILL, false, BREAKS>), dim3(grid), dim3(TPB2), 0, st,
+                     ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, ix->tune.cool_down, queue, REFILL ? ix->tune.ms_refill_at : 64u,
+                     recs, ix->tune.ms_speculate, none, BREAKS ? *sink : BreakSink{nullptr, 0, nullptr, nullptr, 0});
+}
+
+int match_stats_launch3(const gcsa2_index* ix, bool persistent, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, u64 total_bytes,
+                        uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st, const BreakSink* sink)
+{
+  const u64 records = (total_bytes >> 5) + nq + 6;
+  ulonglong2* recs = nullptr;
+  unsigned long long* queue = nullptr;
+  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&recs), records * sizeof(ulonglong2), st));
+  hipLaunchKernelGGL(k_pack_records, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, recs);
+  const u64 lanes_grid = (nq + TPB2 - 1) / TPB2;
+  const u64 resident = ix->tune.ms_grid != 0 ? ix->tune.ms_grid : u64(ix->compute_units) * 8;
+  unsigned grid = unsigned(lanes_grid);
+  if(persistent)
+  {
+    hipError_t qe = pool_alloc(ix, reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st);
+    if(qe == hipSuccess) { qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st); }
+    if(qe != hipSuccess) { (void)hipFreeAsync(recs, st); return fail(GCSA2_ERR_HIP, std::string("matching statistics queue: ") + hipGetErrorString(qe)); }
+    grid = unsigned(lanes_grid < resident ? lanes_grid : resident);
+  }
+  unsigned short* out = reinterpret_cast<unsigned short*>(d_ms);
+  const bool pair = ix->img.flp != nullptr, breaks = sink != nullptr;
+#define GCSA2_MS3(P, R, B) launch_ms3<P, R, B>(ix, grid, st, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, queue, recs, sink)
+  if(pair) { if(persistent) { if(breaks) { GCSA2_MS3(true, true, true); } else { GCSA2_MS3(true, true, false); } }
+             else { if(breaks) { GCSA2_MS3(true, false, true); } else { GCSA2_MS3(true, false, false); } } }
+  else { if(persistent) { if(breaks) { GCSA2_MS3(false, true, true); } else { GCSA2_MS3(false, true, false); } }
+         else { if(breaks) { GCSA2_MS3(false, false, true); } else { GCSA2_MS3(false, false, false); } } }
+#undef GCSA2_MS3
+  hipError_t le = hipGetLastError();
+  if(queue != nullptr) { (void)hipFreeAsync(queue, st); }
+  (void)hipFreeAsync(recs, st);                                        // stream-ordered: released after the kernel
+  if(le != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats3: ") + hipGetErrorString(le)); }
+  return GCSA2_OK;
+}
+
 int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, u64 total_bytes,
                        uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st, const BreakSink* sink)
 {
   CHECK_INDEX(ix);
   DeviceGuard guard(ix->device);
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
-  if(variant != 0 && variant != 2 && variant != 5) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown matching statistics variant (0 / 2: one lane per pattern, 5: persistent lanes)"); }
+  if(variant != 0 && variant != 2 && variant != 5 && variant != 6 && variant != 7)
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown matching statistics variant (0: the library chooses; 2 / 5: k_match_stats2 with a lane per pattern / persistent lanes; 6 / 7: k_match_stats3)");
+  }
   if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
   if(total_bytes == GCSA2_UNKNOWN)
   {
     HIP_TRY(hipMemcpyAsync(&total_bytes, d_offsets + nq, sizeof(u64), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
   }
-  // pre-pass: the patterns as 2-bit codes, last character first (k_pack_patterns); stream-ordered scratch
-  const u64 words = (total_bytes >> 5) + nq + 2;
-  u64* codes = nullptr; u32* bad = nullptr;
-  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&codes), words * sizeof(u64), st));
-  hipError_t pe = pool_alloc(ix, reinterpret_cast<void**>(&bad), words * sizeof(u32), st);
-  if(pe != hipSuccess) { (void)hipFreeAsync(codes, st); return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("matching statistics scratch: ") + hipGetErrorString(pe)); }
-  hipLaunchKernelGGL(k_pack_patterns, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, codes, bad);
-  const u32 cool = ix->tune.cool_down;
+  {
+    // variant 0 chooses the launch shape (below) and the kernel (tune.ms_kernel)
+    const u64 lanes_grid0 = (nq + TPB2 - 1) / TPB2;
+    const u64 resident0 = ix->tune.ms_grid != 0 ? ix->tune.ms_grid : u64(ix->compute_units) * 8;
+    if(variant == 0 && ix->tune.ms_kernel == 3) { variant = (lanes_grid0 > 2 * resident0 ? 7 : 6); }
+    if(variant == 6 || variant == 7) { return match_stats_launch3(ix, variant == 7, d_patterns, d_offsets, nq, total_bytes, d_ms, d_ranges, d_fallbacks, st, sink); }
+  }
+  // pre-pass: the patterns as 16-byte records, last character first (k_pack_records); stream-ordered scratch
+  ulonglong2* recs = nullptr;
+  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&recs), ((total_bytes >> 5) + nq + 6) * sizeof(ulonglong2), st));
+  hipLaunchKernelGGL(k_pack_records, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, recs);
+  const u32 cool = ix->tune.cool_down | (ix->tune.ms_short_parent ? 0u : 0x80000000u);
   unsigned short* out = reinterpret_cast<unsigned short*>(d_ms);
   const u64 lanes_grid = (nq + TPB2 - 1) / TPB2;
   const bool pair = ix->img.flp != nullptr;
@@ -3166,28 +3294,28 @@ int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patt
   {
     hipError_t qe = pool_alloc(ix, reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st);
     if(qe == hipSuccess) { qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st); }
-    if(qe != hipSuccess) { (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st); return fail(GCSA2_ERR_HIP, std::string("matching statistics queue: ") + hipGetErrorString(qe)); }
+    if(qe != hipSuccess) { (void)hipFreeAsync(recs, st); return fail(GCSA2_ERR_HIP, std::string("matching statistics queue: ") + hipGetErrorString(qe)); }
     const unsigned grid = unsigned(lanes_grid < resident ? lanes_grid : resident);
     unsigned long long* none = nullptr;
     if(sink != nullptr && pair)
     {
       hipLaunchKernelGGL((k_match_stats2<true, true, false, true>), dim3(grid), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad, none, *sink);
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, recs, none, *sink);
     }
     else if(sink != nullptr)
     {
       hipLaunchKernelGGL((k_match_stats2<false, true, false, true>), dim3(grid), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad, none, *sink);
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, recs, none, *sink);
     }
     else if(pair)
     {
       hipLaunchKernelGGL((k_match_stats2<true, true>), dim3(grid), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad);
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, recs);
     }
     else
     {
       hipLaunchKernelGGL((k_match_stats2<false, true>), dim3(grid), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, codes, bad);
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, queue, ix->tune.ms_refill_at, recs);
     }
   }
   else if(sink != nullptr)
@@ -3196,27 +3324,27 @@ int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patt
     if(pair)
     {
       hipLaunchKernelGGL((k_match_stats2<true, false, false, true>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, none, 64u, codes, bad, none, *sink);
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, none, 64u, recs, none, *sink);
     }
     else
     {
       hipLaunchKernelGGL((k_match_stats2<false, false, false, true>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
-                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, none, 64u, codes, bad, none, *sink);
+                         ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, none, 64u, recs, none, *sink);
     }
   }
   else if(pair)
   {
     hipLaunchKernelGGL((k_match_stats2<true, false>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, codes, bad);
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, recs);
   }
   else
   {
     hipLaunchKernelGGL((k_match_stats2<false, false>), dim3(unsigned(lanes_grid)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, codes, bad);
+                       ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, cool, (unsigned long long*)nullptr, 64u, recs);
   }
   hipError_t le = hipGetLastError();
   if(queue != nullptr) { (void)hipFreeAsync(queue, st); }
-  (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st);         // stream-ordered: released after the kernel
+  (void)hipFreeAsync(recs, st);                                        // stream-ordered: released after the kernel
   if(le != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats2: ") + hipGetErrorString(le)); }
   return GCSA2_OK;
 }
@@ -3261,7 +3389,7 @@ int gcsa2_match_breaks_device(const gcsa2_index* ix, const uint8_t* d_patterns, 
   // records than one per pattern position and one per pattern, whatever the caller's capacity is: ADVICE r04)
   const u64 lane_waves = (nq + 63) / 64, lanes_grid = (nq + TPB2 - 1) / TPB2;
   const u64 resident = ix->tune.ms_grid != 0 ? ix->tune.ms_grid : u64(ix->compute_units) * 8;
-  const bool persistent = (variant == 5 || (variant == 0 && lanes_grid > 2 * resident));
+  const bool persistent = (variant == 5 || variant == 7 || (variant == 0 && lanes_grid > 2 * resident));
   const u64 waves = (persistent && resident * (TPB2 / 64) < lane_waves ? resident * (TPB2 / 64) : lane_waves);
   const u64 most = (total_bytes != GCSA2_UNKNOWN && total_bytes + nq < capacity ? total_bytes + nq : capacity);
   const u64 tmp_slots = most + (waves + 1) * BREAK_BLOCK;
@@ -3371,17 +3499,27 @@ extern "C" int gcsa2_match_stats_profile_device(const gcsa2_index* ix, const uin
   if(d_prof == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null profile buffer"); }
   if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const u64 words = (total_bytes >> 5) + nq + 2;
-  u64* codes = nullptr; u32* bad = nullptr;
-  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&codes), words * sizeof(u64), st));
-  hipError_t pe = pool_alloc(ix, reinterpret_cast<void**>(&bad), words * sizeof(u32), st);
-  if(pe != hipSuccess) { (void)hipFreeAsync(codes, st); return fail(GCSA2_ERR_OUT_OF_MEMORY, std::string("matching statistics scratch: ") + hipGetErrorString(pe)); }
-  hipLaunchKernelGGL(k_pack_patterns, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, codes, bad);
+  if(ix->tune.ms_kernel == 3)
+  {
+    ulonglong2* recs = nullptr;
+    HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&recs), ((total_bytes >> 5) + nq + 6) * sizeof(ulonglong2), st));
+    hipLaunchKernelGGL(k_pack_records, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, recs);
+    hipLaunchKernelGGL((k_match_stats3<true, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
+                       ix->img, d_patterns, d_offsets, nq, reinterpret_cast<unsigned short*>(d_ms), d_ranges, d_fallbacks, ix->tune.cool_down,
+                       (unsigned long long*)nullptr, 64u, recs, ix->tune.ms_speculate, reinterpret_cast<unsigned long long*>(d_prof));
+    hipError_t le3 = hipGetLastError();
+    (void)hipFreeAsync(recs, st);
+    if(le3 != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats3<prof>: ") + hipGetErrorString(le3)); }
+    return GCSA2_OK;
+  }
+  ulonglong2* recs = nullptr;
+  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&recs), ((total_bytes >> 5) + nq + 6) * sizeof(ulonglong2), st));
+  hipLaunchKernelGGL(k_pack_records, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, recs);
   hipLaunchKernelGGL((k_match_stats2<true, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
                      ix->img, d_patterns, d_offsets, nq, reinterpret_cast<unsigned short*>(d_ms), d_ranges, d_fallbacks, ix->tune.cool_down,
-                     (unsigned long long*)nullptr, 64u, codes, bad, reinterpret_cast<unsigned long long*>(d_prof));
+                     (unsigned long long*)nullptr, 64u, recs, reinterpret_cast<unsigned long long*>(d_prof));
   hipError_t le = hipGetLastError();
-  (void)hipFreeAsync(codes, st); (void)hipFreeAsync(bad, st);
+  (void)hipFreeAsync(recs, st);
   if(le != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats2<prof>: ") + hipGetErrorString(le)); }
   return GCSA2_OK;
 }

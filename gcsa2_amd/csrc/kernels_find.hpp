@@ -389,6 +389,8 @@ __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void 
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
   u64 blocks = 0, steps = 0, lookups = 0, jumps = 0;
   [[maybe_unused]] u64 fetch_steps = 0, second_fetches = 0, wide_seeds = 0;     // STATS only
+  [[maybe_unused]] unsigned int* touched = nullptr;
+  if constexpr(STATS) { touched = reinterpret_cast<unsigned int*>(stats[7]); }
 
   u64 q = ~u64(0), sp = 0, ep = img.n - 1, i = 0;
   const u8* p = patterns;
@@ -561,7 +563,19 @@ __global__ __launch_bounds__(TPB2, (STATS || JUMP) ? 4 : GCSA2_FIND_WAVES) void 
     }
     PairEnd p_sp = {0, 0, 0}, p_ep = {0, 0, 0};   // a single step keeps (edge, node) in .raw / .node: one set of registers
     const bool need2 = stepping && idx_ep != idx_sp;
-    if(STATS && stepping) { blocks += 1 + (need2 ? 1 : 0); fetch_steps++; second_fetches += (need2 ? 1 : 0); }
+    if(STATS && stepping)
+    {
+      blocks += 1 + (need2 ? 1 : 0); fetch_steps++; second_fetches += (need2 ? 1 : 0);
+      // stats[7], when the caller put a device address there: a bitmap over the blocks of the image (the FLB128 blocks of all
+      // comps, then the FLP128 blocks of all pairs) -- the DISTINCT blocks a batch touches are its working set (bench.py)
+      if(touched != nullptr)
+      {
+        const u32 singles = u32(img.sigma) * u32(img.flb_nblocks);
+        const u32 a = (idx_sp & PAIR_FLAG) ? singles + (idx_sp & ~PAIR_FLAG) : idx_sp;
+        atomicOr(touched + (a >> 5), 1u << (a & 31));
+        if(need2) { const u32 b = (idx_ep & PAIR_FLAG) ? singles + (idx_ep & ~PAIR_FLAG) : idx_ep; atomicOr(touched + (b >> 5), 1u << (b & 31)); }
+      }
+    }
     ulonglong2 blk[8];
     fetch_blocks<PAIR>(img.flb, idx_sp, stepping, wave_stage, lane, img.flp);
     if(stepping)

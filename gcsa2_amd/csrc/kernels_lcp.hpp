@@ -356,46 +356,8 @@ __global__ __launch_bounds__(TPB) void k_lcp_access(DevImage img, const u64* __r
 // skipped.  ms[offset + i] = length of the longest match starting at i (capped at 65535), the final
 // range is the one of position 0.  Paper: paper.tex:344 (after Ohlebusch et al. 2010).
 
-// Pre-pass of k_match_stats2: every pattern as 2-bit codes, LAST character first.  Code word j of pattern q lives at
-// index (offsets[q] >> 5) + q + j (consecutive patterns never overlap: floor((o + len) / 32) + 1 - floor(o / 32) >=
-// ceil(len / 32)) and holds the characters at distance t = 32 j .. 32 j + 31 from the pattern's end, t at bits
-// [2 (t & 31), 2 (t & 31) + 2) = comp - 1 of a fast character; bit (t & 31) of `bad` word j marks any other character
-// and the positions past the pattern's first character.  The step loop then refills its 32-character window with two
-// word loads and a funnel shift.  Round 2's kernel translated the bytes itself, a 32-iteration loop per refill; once
-// the lanes of a wave diverge some lane refills in nearly every round and the whole wave pays for the loop -- it was
-// about a third of the VALU instructions on a branching index (profiles/r03_match_stats.md).
-__global__ __launch_bounds__(TPB) void k_pack_patterns(DevImage img, const u8* __restrict__ patterns, const u64* __restrict__ offsets,
-                                                      u64 nq, u64* __restrict__ codes, u32* __restrict__ bad)
-{
-  __shared__ u8 c2c[256];
-  c2c[threadIdx.x] = img.char2comp[threadIdx.x];
-  __syncthreads();
-  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  const u64 begin = offsets[q], len = offsets[q + 1] - begin;
-  const u64 first_word = (begin >> 5) + q, words = (len + 31) >> 5;
-  for(u64 j = 0; j < words; j++)
-  {
-    const u64 high = len - 32 * j;                              // one past the pattern position of t = 32 j
-    const u64 count = (high < 32 ? high : 32), low = reinterpret_cast<u64>(patterns) + begin + high - count;
-    const u64 base = low & ~u64(7), last = (low + count - 1) & ~u64(7);
-    u64 w[5];
-#pragma unroll
-    for(u32 k = 0; k < 5; k++) { const u64 a = base + 8 * k; w[k] = *reinterpret_cast<const u64*>(a < last ? a : last); }
-    u64 code = 0; u32 flags = (count < 32 ? ~u32(0) << count : 0u);
-    for(u32 r = 0; r < count; r++)
-    {
-      const u64 at = (low - base) + (count - 1 - r);           // byte offset of the character at distance 32 j + r from the end
-      u64 word = w[0];
-#pragma unroll
-      for(u32 k = 1; k < 5; k++) { if((at >> 3) == k) { word = w[k]; } }
-      const u32 c = u32(c2c[u32(word >> ((at & 7) * 8)) & 0xFF]) - 1;
-      code |= u64(c & 3) << (2 * r);
-      flags |= u32(c < 4 ? 0 : 1) << r;
-    }
-    codes[first_word + j] = code; bad[first_word + j] = flags;
-  }
-}
+// (the pre-pass that packs the patterns -- 2-bit codes and flags, last character first, 16-byte records -- is k_pack_records,
+// kernels_ms3.hpp; round 4's k_pack_patterns wrote the codes and the flags as two arrays)
 
 // parent() of (sp, ep) from a 128-byte window of the LCP array staged in the lane's LDS slot (fetch_blocks with LCP_FLAG): the
 // window starts at byte `wstart` (a multiple of 16), 48..63 positions before sp.  node_lcp = max(LCP[sp], LCP[ep + 1]); the
@@ -448,6 +410,40 @@ __device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage,
     if(w == last && wstart + 8 * w + 8 > lcp_size) { flags &= (u64(1) << (8 * (lcp_size - wstart - 8 * w))) - 1; }
     if(flags == 0) { decided = false; }
     else { const u32 byte = (u32(__ffsll((long long)flags)) - 1) >> 3; rpos = wstart + 8 * w + byte; rval = (word >> (8 * byte)) & 0xFF; }
+  }
+  out = gcsa2_stnode{lpos, rpos - 1, lval, rval, node_lcp};
+  return decided;
+}
+
+// parent() of (sp, ep) from the eight LCP bytes on either side of the interval -- the bytes ending at LCP[sp] and the bytes
+// starting at LCP[ep + 1], four independent LDS reads and no loop: after a failed step the interval is a few path nodes wide
+// and the nearest smaller values lie one to three positions away (the general scan of the whole window, parent_from_window,
+// kernels_lcp.hpp, runs its two word-by-word loops as long as the slowest lane needs: half of this kernel's time when a dozen
+// lanes of a wave take it in every round).  false: not decidable from those bytes -- the caller tries the whole window.
+__device__ __forceinline__ bool parent_near(const ulonglong2* wave_wstage, u32 slot, u64 wstart, u64 lcp_size, u64 sp, u64 ep, gcsa2_stnode& out)
+{
+  if(sp < wstart + 8 || ep + 10 >= wstart + 128 || ep + 10 >= lcp_size) { return false; }
+  const u32 lo = u32(sp - wstart), ro = u32(ep + 1 - wstart);
+  const u32 lw = lo >> 3, ls = lo & 7, rw = ro >> 3, rs = ro & 7;
+  const u64 l1 = staged_word(wave_wstage, slot, lw), l0 = staged_word(wave_wstage, slot, lw - 1);
+  const u64 r0 = staged_word(wave_wstage, slot, rw), r1 = staged_word(wave_wstage, slot, rw + 1);
+  const u64 L = (l1 << (8 * (7 - ls))) | (ls == 7 ? u64(0) : l0 >> (8 * (ls + 1)));      // byte 7 = LCP[sp], byte 6 = LCP[sp - 1], ...
+  const u64 R = (r0 >> (8 * rs)) | (rs == 0 ? u64(0) : r1 << (8 * (8 - rs)));            // byte 0 = LCP[ep + 1], byte 1 = LCP[ep + 2], ...
+  const u32 left_lcp = u32(L >> 56), right_lcp = u32(R) & 0xFF;
+  const u32 node_lcp = (left_lcp > right_lcp ? left_lcp : right_lcp);
+  u64 lpos = sp, lval = left_lcp, rpos = ep + 1, rval = right_lcp;
+  bool decided = true;
+  if(left_lcp == node_lcp)
+  {
+    const u64 flags = below_flags(L, left_lcp) & 0x0080808080808080ull;
+    if(flags == 0) { decided = false; }
+    else { const u32 byte = (63u - u32(__clzll((long long)flags))) >> 3; lpos = sp - (7 - byte); lval = (L >> (8 * byte)) & 0xFF; }
+  }
+  if(right_lcp == node_lcp)
+  {
+    const u64 flags = below_flags(R, right_lcp) & 0x8080808080808000ull;
+    if(flags == 0) { decided = false; }
+    else { const u32 byte = (u32(__ffsll((long long)flags)) - 1) >> 3; rpos = ep + 1 + byte; rval = (R >> (8 * byte)) & 0xFF; }
   }
   out = gcsa2_stnode{lpos, rpos - 1, lval, rval, node_lcp};
   return decided;
@@ -515,7 +511,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
                                                        unsigned short* __restrict__ ms, u64* __restrict__ ranges,
                                                        u64* __restrict__ fallbacks, u32 cool_down,
                                                        unsigned long long* __restrict__ queue, u32 refill_at,
-                                                       const u64* __restrict__ codes, const u32* __restrict__ bad,
+                                                       const ulonglong2* __restrict__ recs,
                                                        unsigned long long* __restrict__ prof = nullptr, BreakSink sink = BreakSink{nullptr, 0, nullptr, nullptr, 0})
 {
   [[maybe_unused]] u64 prof_t = 0, prof_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -529,6 +525,8 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   c2c[threadIdx.x] = img.char2comp[threadIdx.x];
   c2c[threadIdx.x + TPB2] = img.char2comp[threadIdx.x + TPB2];
   __syncthreads();
+  const bool short_parent = (cool_down >> 31) == 0;          // (bit 31 of the argument: GCSA2_MS_SHORT_PARENT=0, an A/B knob)
+  cool_down &= 0x7FFFFFFFu;
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
   u64* wave_addr = addr_table + (threadIdx.x & ~63u);
@@ -540,8 +538,14 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   u32 depth = 0, calls = 0;
   bool need_parent = false;
   u32 force_single = 0;
-  u64 win_code = 0;                         // packed pattern window, as in k_find2
-  u32 win_used = ~u32(0), win_bad = 0;
+  // Round 5: the pattern as 16-byte RECORDS (k_pack_records, kernels_ms3.hpp: 2-bit codes + "not a fast character" flags of 32
+  // characters).  The lane holds the record of position i - 1 (slot (total - i) & 31), the one behind it (a pair step at
+  // slot 31 reads its first character there) and the one behind that, REQUESTED when a record is entered and not looked at
+  // before the next entry.  Round 4 re-read two code words and two flag words from two arrays every 24 characters and used
+  // them at once: ~44 memory requests per 256-bp pattern (a sixth of the kernel's reads) and, with 64 lanes out of step, a
+  // memory latency that the whole wave waited for in nearly every round.
+  u64 win_code = 0, next_code = 0, pend_code = 0;
+  u32 win_bad = 0, next_bad = ~u32(0), pend_bad = ~u32(0);
   // results: sixteen u16 per flush, as two 16-byte stores back to back (`ms` is 8-byte aligned, the hardware takes the 16-byte
   // store at any dword).  The statistics are a third of the kernel's memory requests -- every lane writes into its own
   // pattern's 512 bytes, nothing coalesces across lanes -- so the only lever is fewer, wider writes per lane (8-byte stores: 64
@@ -594,8 +598,13 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   {
     q = query; has = true;
     begin = offsets[q]; i = total = u32(offsets[q + 1] - begin);
-    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0; win_used = ~u32(0);
+    sp = 0; ep = img.n - 1; depth = 0; calls = 0; need_parent = false; force_single = 0;
     if constexpr(BREAKS) { last_break = ~u32(0); n_breaks = 0; pending = false; }
+    {
+      const u64 word = (begin >> 5) + q;
+      const ulonglong2 r0 = recs[word], r1 = recs[word + 1], r2 = recs[word + 2];
+      win_code = r0.x; win_bad = u32(r0.y); next_code = r1.x; next_bad = u32(r1.y); pend_code = r2.x; pend_bad = u32(r2.y);
+    }
     // The k-mer seed table (find() of every k-mer over the fast characters, kernels_find.hpp): when the pattern's last k
     // characters are fast characters and occur, the search starts behind them -- all k suffixes match, so their statistics
     // are 1 .. k -- and skips the steps on the widest ranges, whose endpoints lie in different blocks.  An empty or wide
@@ -603,17 +612,28 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     const u32 k = img.kmer_k;
     if(k > 0 && total >= k && img.n > 0)
     {
-      const u64 word = (begin >> 5) + q;
-      const u64 tix = codes[word] & ((u64(1) << (2 * k)) - 1);
-      const bool fast = (bad[word] & ((1u << k) - 1)) == 0;
+      const u64 tix = win_code & ((u64(1) << (2 * k)) - 1);
+      const bool fast = (win_bad & ((1u << k) - 1)) == 0;
       const u64 entry = img.kmer_table[fast ? tix : 0];
       const u64 width = entry >> SEED_SP_BITS;
       if(fast && width != 0 && width != SEED_WIDE)
       {
         sp = entry & SEED_SP_MASK; ep = sp + width - 1;
         for(u32 j = 0; j < k; j++) { emit(total - 1 - j, j + 1); }
-        depth = k; i = total - k;
+        depth = k; i = total - k;            // (k <= 16: still inside record 0)
       }
+    }
+  };
+  // `adv` characters were consumed (i is already lowered): entering the next record makes it the current one and requests
+  // the one behind the next -- needed 32 characters from now
+  auto consumed = [&](u32 adv)
+  {
+    const u32 t = total - i;
+    if((t & 31) < adv)
+    {
+      win_code = next_code; win_bad = next_bad; next_code = pend_code; next_bad = pend_bad;
+      const ulonglong2 r = recs[(begin >> 5) + q + (t >> 5) + 2];
+      pend_code = r.x; pend_bad = u32(r.y);
     }
   };
   if constexpr(!REFILL)
@@ -629,22 +649,6 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   bool planned = false, pair = false;       // planned: this lane has a block (or LCP window) in flight
   u32 comp = 0, r_sp = 0, r_ep = 0, idx_sp = 0, idx_ep = 0, emit_code = 0;
   u64 wstart = 0;
-  auto refill_window = [&]()
-  {
-    const bool active = has && i > 0;
-    // packed pattern window, as in k_find2: the 32 positions below i as 2-bit codes + "not a fast character" bits, slot r =
-    // position i - 1 - r; refilled from the pre-packed codes (k_pack_patterns): two words and a funnel shift, no loop
-    if(active && win_used > 24)
-    {
-      const u32 t0 = total - i, s = t0 & 31;
-      const u64 word = (begin >> 5) + q + (t0 >> 5);
-      const u64 c0 = codes[word], c1 = codes[word + 1];
-      const u32 b0 = bad[word], b1 = bad[word + 1];
-      win_code = (s == 0 ? c0 : (c0 >> (2 * s)) | (c1 << (64 - 2 * s)));
-      win_bad = (s == 0 ? b0 : (b0 >> s) | (b1 << (32 - s)));
-      win_used = 0;
-    }
-  };
   auto plan_and_issue = [&]()
   {
     const bool active = has && i > 0;
@@ -660,15 +664,16 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     }
     if(stepping)
     {
-      const u32 r = win_used;                                  // window slot of position i - 1
+      const u32 r = (total - i) & 31;                          // slot of position i - 1 in the current record
+      const u32 flags = ((win_bad >> r) & 3) | (r == 31 ? (next_bad & 1) << 1 : 0u);
       if constexpr(PAIR)
       {
         if(force_single == 0 && i >= 2)
         {
-          pair = ((win_bad >> r) & 3) == 0;
+          pair = (flags == 0);
           if(pair)
           {
-            const u32 c2 = u32(win_code >> (2 * r)) & 3, c1 = u32(win_code >> (2 * r + 2)) & 3;
+            const u32 c2 = u32(win_code >> (2 * r)) & 3, c1 = (r == 31 ? u32(next_code) : u32(win_code >> (2 * r + 2))) & 3;
             u32 b_sp, b_ep;
             pair_block_of(sp, b_sp, r_sp); pair_block_of(ep + 1, b_ep, r_ep);
             const u32 first = (c1 * 4 + c2) * u32(img.flp_nblocks);
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       }
       if(!pair)
       {
-        if((win_bad >> r) & 1)
+        if(flags & 1)
         {
           const u64 addr = reinterpret_cast<u64>(patterns) + begin + i - 1;
           comp = c2c[u32(*reinterpret_cast<const u64*>(addr & ~u64(7)) >> ((addr & 7) * 8)) & 0xFF];
@@ -692,7 +697,6 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
 
     if(__any(active)) { fetch_blocks_issue<PAIR, true>(img.flb, idx_sp, active, wave_stage, lane, img.flp, img.lcp, wave_addr); }
   };
-  refill_window();
   plan_and_issue();
   while(true)
   {
@@ -715,7 +719,12 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         if(idx_ep == idx_sp) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
       }
       G2_TICK(3);
-      if(parenting) { decided = parent_from_window(wave_stage, lane, wstart, img.lcp_size, sp, ep, node); G2_COUNT(5, 1); }
+      if(parenting)              // (round 5: the eight bytes on either side first -- no loop; the whole window only when they do not decide)
+      {
+        decided = short_parent && parent_near(wave_stage, lane, wstart, img.lcp_size, sp, ep, node);
+        if(!decided) { decided = parent_from_window(wave_stage, lane, wstart, img.lcp_size, sp, ep, node); }
+        G2_COUNT(5, 1);
+      }
       if constexpr(PROF) { if(parenting && decided) { asm volatile("" :: "v"(node.sp)); } }
       G2_TICK(6);
       if(__any(need2))
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         {
           sp = p_sp.node; ep = p_ep.node;
           emit_code = 2;
-          depth += 2; i -= 2; win_used += 2;
+          depth += 2; i -= 2;
         }
         else { force_single = 2; G2_COUNT(4, 1); }             // an emptying step needs parent(): one character at a time
       }
@@ -747,14 +756,14 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         if(!range_empty(a, b))
         {
           sp = p_sp.node; ep = p_ep.node; depth++;
-          emit_code = 1; i--; win_used++;
+          emit_code = 1; i--;
           force_single -= (force_single > 0 ? 1 : 0);
         }
         else if(sp == 0 && ep == img.n - 1)                    // at the root: no such character
         {
           depth = 0;
           if constexpr(BREAKS) { pending = true; }
-          emit_code = 1; i--; win_used++;
+          emit_code = 1; i--;
           force_single -= (force_single > 0 ? 1 : 0);
         }
         else { need_parent = true; force_single = (force_single > cool_down ? force_single : cool_down); }   // parent() in the next round
@@ -769,6 +778,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
       need_parent = false;
     }
     G2_TICK(7);
+    if(emit_code != 0) { consumed(emit_code); }                 // (one site: the characters this round consumed, 0..2)
     plan_and_issue();                                            // the next round's requests leave here
     G2_TICK(1);
     if constexpr(!BREAKS)                                        // the statistics of the step just taken (positions i + 1 / i after the update)
@@ -848,7 +858,6 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     {
       if(!__any(has)) { break; }
     }
-    refill_window();
     G2_TICK(0);
   }
   if constexpr(BREAKS)

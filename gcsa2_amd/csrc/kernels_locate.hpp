@@ -450,6 +450,7 @@ constexpr u32 BIG_SEGMENT = 8192;
 constexpr u32 HUGE_SPLIT = BIG_SEGMENT / 2;
 // totals of one pass of the locate pipeline (a slot of TOTAL_WORDS u64 in device memory, mirrored to page-locked host memory)
 enum { T_NODES = 0, T_RAW = 1, T_LARGE = 2, T_UNIQUE = 3, T_MULTI = 4, T_MEDIUM = 5, T_HUGE_A = 6, T_OVER = 7, T_HUGE_B = 8, T_OVER_VALUES = 9,
+       T_BUCKETS = 10, T_SKEW = 11, T_SKEW_VALUES = 12,
        TOTAL_WORDS = 16 };
 
 __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
@@ -534,9 +535,11 @@ __global__ __launch_bounds__(64) void k_sort_medium(const u64* __restrict__ seg_
 // Two instantiations share the list: CAPACITY 4096 takes the segments of up to 4096 values in 32 KB of LDS (five workgroups
 // per CU), CAPACITY 8192 the rest in 64 KB (two per CU); a workgroup whose segment belongs to the other one exits at once.
 constexpr int BIG_THREADS = 256;
+// `source`: where the unsorted values are (the same offsets); nullptr = in place.  (The buckets of k_over_split are read from
+// its scratch array and land, sorted, in the values array.)
 template<u32 CAPACITY, u32 ABOVE>
 __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end,
-                                                        u64* __restrict__ values, const unsigned long long* __restrict__ count)
+                                                        u64* values, const unsigned long long* __restrict__ count, const u64* source = nullptr)
 {
   __shared__ u64 buf[CAPACITY];
   const u32 tid = threadIdx.x;
@@ -546,7 +549,8 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict_
   if(len > CAPACITY || len <= ABOVE) { return; }            // the other instantiation's segment (uniform per workgroup)
   u32 n2 = 2048;
   while(n2 < len) { n2 <<= 1; }
-  for(u32 i = tid; i < n2; i += BIG_THREADS) { buf[i] = (i < len ? values[b + i] : ~u64(0)); }    // padding sorts to the end
+  const u64* from = (source != nullptr ? source : values);
+  for(u32 i = tid; i < n2; i += BIG_THREADS) { buf[i] = (i < len ? from[b + i] : ~u64(0)); }    // padding sorts to the end
   __syncthreads();
   for(u32 k = 2; k <= n2; k <<= 1)
   {
@@ -879,6 +883,30 @@ __global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* _
   node_counts[q] = nodes; raw_counts[q] = raw;
 }
 
+// The whole of locate() for a batch in which EVERY range is one path node with one value that the locate table holds directly
+// (config 3's 32-mers on a chr22-like index, the final ranges of config 5's long patterns): value q = the table entry of node
+// sp_q, offsets[q] = q -- one kernel, one random 8-byte read per range, instead of the sizes pass, two prefix sums, the list
+// builder, the owner search and the walk.  Any other range (empty, wider, a node with several samples) sets `misfit` and the
+// caller runs the general pipeline, which rewrites everything written here.
+__global__ __launch_bounds__(TPB) void k_locate_single(DevImage img, const u64* __restrict__ ranges, u64 nq, u64* __restrict__ offsets,
+                                                       u64* __restrict__ values, u64 capacity, unsigned long long* __restrict__ misfit)
+{
+  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q > nq) { return; }
+  offsets[q] = q;
+  bool ok = true;
+  if(q < nq)
+  {
+    const ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
+    ok = (r.x == r.y && r.x < img.n);
+    const u64 entry = (ok ? img.locate_tab[r.x] : 0);
+    ok = ok && (entry & LOCATE_DIRECT) != 0;
+    if(ok && q < capacity) { values[q] = entry & ~LOCATE_DIRECT; }
+  }
+  const u64 bad = __ballot(!ok);
+  if(bad != 0 && (threadIdx.x & 63) == u32(__ffsll((long long)bad)) - 1) { atomicOr(misfit, 1ull); }
+}
+
 // one lane per (query, path node): locateInternal (gcsa.cpp:880-896)
 __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __restrict__ ranges, u64 nq,
                                                      const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
@@ -913,7 +941,178 @@ __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __
   while(!bv_get(img.samples, s - 1));                        // lastSample, gcsa.h:208
 }
 
-// Segments with more than BIG_SEGMENT distinct values (a 16-mer of an interspersed repeat matches 200 000 path nodes on the
+// Segments with more than BIG_SEGMENT distinct values, round 5: ONE WORKGROUP PER SEGMENT sorts it.  It splits the segment on
+// the top bits of (value - the segment's smallest value) into up to 4096 buckets of a few dozen values -- minimum and
+// maximum, a histogram in LDS, its prefix sums, the scatter into `scratch` at the same offsets -- and then its sixteen
+// wavefronts sort the buckets, one bucket of up to 64 values per wavefront at a time, in REGISTERS (a bitonic network over the
+// lanes: 21 exchange steps, no LDS, no barrier) straight into `values`.  A segment is read three times and written twice by
+// the workgroup that owns it (it sits in L2), the values are contiguous per segment already, and nothing is sorted across
+// segments: round 4 packed (segment rank << 37 | value) keys and gave them to the library's device-wide radix sort, seven
+// passes over 51-bit keys of which 14 bits said what the layout already knew (19 of the 35 ms of the 16-mer batch on the
+// 2^30-base text, profiles/r04_locate.md; a first form of this kernel that left buckets of ~1500 values to the workgroup
+// bitonic sort took 22 ms for them: 66 barriers per bucket, profiles/r05_locate.md).  A bucket of more than 64 values is
+// listed for the workgroup sort (k_sort_big reads `scratch`, writes `values`), one of more than `skew_above` values -- values
+// crowded into a small part of the segment's span -- goes on the `skew` list, which the host hands to that radix sort as before.
+constexpr int SPLIT_THREADS = 1024;
+constexpr u32 SPLIT_BUCKETS = 4096;
+constexpr u32 SPLIT_TARGET = 24;               // values per bucket aimed at (segments beyond 4096 x 24 values get larger ones)
+
+// ascending bitonic sort of one value per lane across the wavefront (64 lanes; padding = ~0 sorts to the end)
+__device__ __forceinline__ u64 wave_sort(u64 v, u32 lane)
+{
+#pragma unroll
+  for(u32 k = 2; k <= 64; k <<= 1)
+  {
+#pragma unroll
+    for(u32 j = k >> 1; j > 0; j >>= 1)
+    {
+      const u64 other = __shfl_xor(v, int(j), 64);
+      const bool up = ((lane & k) == 0), lower = ((lane & j) == 0);
+      const bool take_min = (up == lower);
+      v = (take_min ? (other < v ? other : v) : (other > v ? other : v));
+    }
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restrict__ over_begin, const u64* __restrict__ over_end,
+                                                             u64* values, u64* scratch, u64* __restrict__ bkt_begin, u64* __restrict__ bkt_end,
+                                                             u64* __restrict__ skew_begin, u64* __restrict__ skew_end,
+                                                             unsigned long long* __restrict__ totals, u32 skew_above, u32 target)
+{
+  __shared__ u32 cursor[SPLIT_BUCKETS];        // histogram, then the buckets' write cursors (= their ends after the scatter)
+  __shared__ u32 starts[SPLIT_BUCKETS];
+  __shared__ u32 wave_sums[SPLIT_THREADS / 64];
+  __shared__ unsigned long long s_lo, s_hi;
+  constexpr u32 PER_THREAD = SPLIT_BUCKETS / SPLIT_THREADS;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u64 b = over_begin[blockIdx.x], len = over_end[blockIdx.x] - b;
+  if(tid == 0) { s_lo = ~0ull; s_hi = 0; }
+  for(u32 k = tid; k < SPLIT_BUCKETS; k += SPLIT_THREADS) { cursor[k] = 0; }
+  __syncthreads();
+  unsigned long long lo = ~0ull, hi = 0;
+  for(u64 i = tid; i < len; i += SPLIT_THREADS) { const u64 v = values[b + i]; lo = (v < lo ? v : lo); hi = (v > hi ? v : hi); }
+  for(int o = 32; o > 0; o >>= 1)
+  {
+    const unsigned long long a = __shfl_down(lo, o, 64), c = __shfl_down(hi, o, 64);
+    lo = (a < lo ? a : lo); hi = (c > hi ? c : hi);
+  }
+  if(lane == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+  __syncthreads();
+  lo = s_lo; hi = s_hi;
+  // buckets: the smallest power of two with len / buckets <= SPLIT_TARGET, at most SPLIT_BUCKETS; bucket = (v - lo) >> shift
+  u32 nb = 2;
+  while(nb < SPLIT_BUCKETS && u64(nb) * target < len) { nb <<= 1; }          // (target: SPLIT_TARGET; GCSA2_SPLIT_TARGET in tests)
+  const u64 span = hi - lo;                                   // largest (v - lo)
+  u32 shift = 0;
+  while(shift < 63 && (span >> shift) >= nb) { shift++; }
+  for(u64 i = tid; i < len; i += SPLIT_THREADS) { atomicAdd(&cursor[u32((values[b + i] - lo) >> shift)], 1u); }
+  __syncthreads();
+  // exclusive prefix sums of the counts: PER_THREAD consecutive buckets per thread, then across the wavefront and the workgroup
+  u32 mine[PER_THREAD], sum = 0;
+#pragma unroll
+  for(u32 k = 0; k < PER_THREAD; k++) { mine[k] = cursor[tid * PER_THREAD + k]; sum += mine[k]; }
+  u32 incl = sum;
+  for(int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(incl, o, 64); if(lane >= u32(o)) { incl += up; } }
+  if(lane == 63) { wave_sums[wave] = incl; }
+  __syncthreads();
+  u32 before = incl - sum;
+  for(u32 w = 0; w < wave; w++) { before += wave_sums[w]; }
+#pragma unroll
+  for(u32 k = 0; k < PER_THREAD; k++) { starts[tid * PER_THREAD + k] = before; cursor[tid * PER_THREAD + k] = before; before += mine[k]; }
+  __syncthreads();
+  for(u64 i = tid; i < len; i += SPLIT_THREADS)
+  {
+    const u64 v = values[b + i];
+    scratch[b + atomicAdd(&cursor[u32((v - lo) >> shift)], 1u)] = v;
+  }
+  __syncthreads();                                             // (the workgroup's stores have completed: s_waitcnt vmcnt(0) + barrier)
+  // Each wavefront takes a contiguous share of the buckets and sorts it in runs of WHOLE buckets that hold at most 64 values
+  // together (the buckets are value-ordered, so a run sorted by value is final): one value per lane, 21 exchange steps.
+  const u32 share = (nb + SPLIT_THREADS / 64 - 1) / (SPLIT_THREADS / 64);
+  const u32 k_end = ((wave + 1) * share < nb ? (wave + 1) * share : nb);
+  const u32 small = (skew_above < 64 ? skew_above : 64u);
+  u32 k = wave * share;
+  while(k < k_end)
+  {
+    const u32 first = starts[k];
+    // ends of the next 64 buckets (lane j: bucket k + j); the run ends behind the last one that keeps it within `small` values
+    const u32 kk = k + lane;
+    const u32 end = (kk < k_end ? cursor[kk] : ~u32(0));
+    const u64 fits = __ballot(kk < k_end && end - first <= small);
+    // (the fitting buckets are a prefix: ends grow)
+    const u32 take = u32(__popcll(fits));
+    if(take == 0)
+    {
+      // bucket k alone has more than `small` values: the workgroup sorts of the next launches take it, or the radix sort
+      const u32 count = cursor[k] - first;
+      if(count <= skew_above)
+      {
+        if(lane == 0)
+        {
+          const u64 slot = atomicAdd(totals + T_BUCKETS, 1ull);
+          bkt_begin[slot] = b + first; bkt_end[slot] = b + first + count;
+        }
+      }
+      else                                                     // (BIG_SEGMENT; lower in tests, GCSA2_SPLIT_SKEW)
+      {
+        if(lane == 0)
+        {
+          const u64 slot = atomicAdd(totals + T_SKEW, 1ull);
+          skew_begin[slot] = b + first; skew_end[slot] = b + first + count;
+          atomicAdd(totals + T_SKEW_VALUES, (unsigned long long)count);
+        }
+        for(u32 i = first + lane; i < first + count; i += 64) { values[b + i] = scratch[b + i]; }     // back to where the radix sort expects them
+      }
+      k++;
+      continue;
+    }
+    const u32 count = cursor[k + take - 1] - first;            // (uniform)
+    if(count > 0)
+    {
+      u64 v = (lane < count ? scratch[b + first + lane] : ~u64(0));
+      if(count > 1) { v = wave_sort(v, lane); }
+      if(lane < count) { values[b + first + lane] = v; }
+    }
+    k += take;
+  }
+}
+
+// one wavefront (= one workgroup) per listed bucket of up to MEDIUM_SEGMENT values: bitonic sort in 8 KB of LDS, read from
+// `source`, written to `values` (k_sort_medium's network; the list is k_over_split's: buckets of 65 .. skew_above values, the
+// longer ones are left to k_sort_big)
+__global__ __launch_bounds__(64) void k_sort_bucket(const u64* __restrict__ bkt_begin, const u64* __restrict__ bkt_end, u64* values,
+                                                    const u64* __restrict__ source, const unsigned long long* __restrict__ count)
+{
+  __shared__ u64 buf[MEDIUM_SEGMENT];
+  if(blockIdx.x >= *count) { return; }
+  const u32 lane = threadIdx.x;
+  const u64 b = bkt_begin[blockIdx.x];
+  const u32 len = u32(bkt_end[blockIdx.x] - b);
+  if(len > MEDIUM_SEGMENT) { return; }                        // k_sort_big's
+  u32 n2 = 128;
+  while(n2 < len) { n2 <<= 1; }
+  for(u32 i = lane; i < n2; i += 64) { buf[i] = (i < len ? source[b + i] : ~u64(0)); }
+  __syncthreads();
+  for(u32 k = 2; k <= n2; k <<= 1)
+  {
+    for(u32 j = k >> 1; j > 0; j >>= 1)
+    {
+      for(u32 t = lane; t < (n2 >> 1); t += 64)
+      {
+        const u32 l = ((t & ~(j - 1)) << 1) | (t & (j - 1)), r = l | j;
+        const u64 x = buf[l], y = buf[r];
+        const bool up = ((l & k) == 0);
+        if((x > y) == up) { buf[l] = y; buf[r] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for(u32 i = lane; i < len; i += 64) { values[b + i] = buf[i]; }
+}
+
+// Segments with more than BIG_SEGMENT distinct values whose split left a bucket too large (k_over_split's skew list), and every
+// such segment with GCSA2_LOCATE_SPLIT_SORT=0 (A/B) (a 16-mer of an interspersed repeat matches 200 000 path nodes on the
 // repeat-rich 2^30-base text): ONE device-wide radix sort over keys (rank of the segment among those segments) << value_bits
 // | value sorts them all at once, whatever their sizes -- round 3 gave them to the library's SEGMENTED sort, whose work per
 // segment made a batch of 16 000 such segments 100 ms.  over_off = exclusive scan of the segment lengths (over + 1 entries).

@@ -202,7 +202,10 @@ int gcsa2_find_device_variant(const gcsa2_index* index, int variant, const uint8
  * counts every block it fetched.  d_stats[4] += fetch rounds taken by lanes (one per single or pair step attempted),
  * d_stats[5] += those whose two endpoints lay in different blocks (a second fetch round for the whole wavefront),
  * d_stats[6] += seed-table entries that were marked "wide" (the range is then searched from scratch).
- * d_stats holds EIGHT counters (rounds 1-2: four; an ABI change of round 3), zeroed by the caller. */
+ * d_stats holds EIGHT words (rounds 1-2: four; an ABI change of round 3), zeroed by the caller.  d_stats[7] is an INPUT: 0, or
+ * the device address of a bitmap of uint32 words, zeroed by the caller, with one bit per block of the image -- sigma x
+ * (path_nodes / 384 + 1) FLB128 blocks, then 16 x (path_nodes / 192 + 1) FLP128 blocks; the kernel sets the bit of every
+ * block it fetches, so that the set bits are the batch's working set in blocks (bench.py reports it). */
 uint64_t gcsa2_find_block_bytes(const gcsa2_index* index);
 /* Length k of the k-mer seed table built at create time (find() of every k-mer over comps 1..4,
  * memoised: a pattern whose last k characters are fast characters starts at step k).  0 = none.

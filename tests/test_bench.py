@@ -134,6 +134,25 @@ def test_two_ranks_share_the_gpu_through_the_host(wire):
     assert c5["locate"]["count_equals_located"] is True and c5["locate"]["unmodified_half_equals_closed_form"] is True
 
 
+def test_eight_ranks_share_the_gpu_with_an_asynchronous_transport():
+    """The target world size as far as one GPU allows: eight ranks, the 40-bit wire format of the headline
+    index (10 bytes per range), ragged shards (8 k + 3 queries), the library's gcsa2_comm_gather over a transport that only
+    ENQUEUES on the gather stream -- so the gather of step k really runs under the kernel of step k + 1 and the root's
+    `gather_hidden_frac` is positive (with a transport that completes inside the call it is ~0: nothing could overlap).
+    Reference shape of the only data-parallel query path: src/algorithms.cpp:106-114 (a static split)."""
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+             "--master-port", str(free_port()), "bench.py", "--gpus", "8", "--degree", "24", "--queries", str(8 * 250_000 + 3), "--steps", "6",
+             "--warmup", "2", "--no-cpu", "--no-secondary"], env={"GCSA2_BENCH_BACKEND": "gloo", "GCSA2_BENCH_WIRE": "40"}, timeout=1500)
+    check_line(d, 8, 6)
+    assert "40-bit pairs" in d["config"]["parallelism"] and d["config"]["queries_total"] == 8 * 250_000 + 3
+    mg = d["multi_gpu"]
+    assert len(mg["per_rank"]) == 8 and sorted(x["queries"] for x in mg["per_rank"]) == [250_000] * 5 + [250_001] * 3
+    assert "asynchronous" in mg["gather"] and mg["rccl_ranks"] == 0 and mg["wire_bytes_per_query"] == 10
+    assert mg["bytes_into_root_per_step"] == 10 * (8 * 250_000 + 3 - mg["per_rank"][0]["queries"])
+    assert mg["root_gather_hidden_frac"] is not None and mg["root_gather_hidden_frac"] > 0.0, mg
+    assert len(d["_line"]["multi_gpu"]["kernel_ms_per_rank"]) == 8
+
+
 def test_plain_invocation_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command) starts two ranks by
     itself and prints n_gpus: 2 with the per-rank kernel / pack / gather breakdown (reference shape of the
@@ -180,11 +199,21 @@ def test_wide_range_and_ladder_secondaries():
     cut = [leg for name, leg in w.items() if "seed table" in name][0]
     assert cut["kmer_table_k"] == 5 and cut["lf_steps_per_query"] == 27.0
     d = run([sys.executable, "bench.py", "--degree", "20", "--queries", "300000", "--steps", "2", "--warmup", "1", "--no-cpu", "--secondary", "ladder"])
+    # the ladder goes down in the order of least find() throughput lost per gigabyte freed: locate table, three seed-table
+    # levels with the pair blocks kept, then without pair blocks at three seed-table sizes; the smallest image's
+    # rate is carried into the line
     rungs = d["memory_ladder"]["rungs"]
-    assert len(rungs) == 4 and all(r["all_ranges_equal_closed_form"] is True and r["locate"]["count_equals_located"] is True for r in rungs)
-    assert rungs[0]["locate_table_bytes"] > 0 and rungs[1]["locate_table_bytes"] == 0 and rungs[3]["pair_block_bytes"] == 0
-    assert [r["image_bytes_hbm"] for r in rungs] == sorted((r["image_bytes_hbm"] for r in rungs), reverse=True)
-    assert rungs[3]["requests_per_query"] > 1.5 * rungs[0]["requests_per_query"]
+    assert len(rungs) == 8 and all(r["all_ranges_equal_closed_form"] is True and r["locate"]["count_equals_located"] is True for r in rungs)
+    assert rungs[0]["locate_table_bytes"] > 0 and all(r["locate_table_bytes"] == 0 for r in rungs[1:])
+    assert all(r["pair_block_bytes"] > 0 for r in rungs[:5]) and all(r["pair_block_bytes"] == 0 for r in rungs[5:])
+    k = rungs[0]["kmer_table_k"]
+    assert [r["kmer_table_k"] for r in rungs] == [k, k, k - 1, k - 2, k - 3, k, k - 1, k - 3]
+    for part in (rungs[:5], rungs[5:]):
+        assert [r["image_bytes_hbm"] for r in part] == sorted((r["image_bytes_hbm"] for r in part), reverse=True)
+    assert rungs[7]["image_bytes_hbm"] == min(r["image_bytes_hbm"] for r in rungs)
+    assert rungs[7]["requests_per_query"] > 1.5 * rungs[0]["requests_per_query"]
+    ref = d["value_at_reference_footprint"]
+    assert ref["value"] == rungs[7]["value"] and abs(d["_line"]["value_at_reference_footprint"]["value"] / ref["value"] - 1) < 1e-4
     d = run([sys.executable, "bench.py", "--degree", "20", "--queries", "300000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1",
              "--secondary", "repeats30"])
     r = d["repeats_hbm"]

@@ -34,7 +34,7 @@ def _bounds(n, world):
     return out
 
 
-def _worker(rank, world, port, nq, fail_rank, out_path):
+def _worker(rank, world, port, nq, fail_rank, out_path, transport_kind="blocking"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -44,14 +44,14 @@ def _worker(rank, world, port, nq, fail_rank, out_path):
     from workload.rng import SplitMix64
     from gcsa2_amd import binding
     from gcsa2_amd.hostview import concat_patterns
-    from gcsa2_amd.host_transport import HostGather
+    from gcsa2_amd.host_transport import HostGather, AsyncHostGather
     from oracle.oracle import OracleIndex
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     ix = build(graphs.snp_graph(300, 0x52, 0x53, snp_period=8, node_len=8), 8, sample_period=8, branching=4)
     gpu, lcp = binding.open_index(ix)
-    transport = HostGather(dist, rank, world)
+    transport = (AsyncHostGather if transport_kind == "async" else HostGather)(dist, rank, world)
     comm = binding.Comm.custom(rank, world, 0, transport)
     assert comm.rccl_ranks() == 0                     # not an RCCL communicator
     rng = SplitMix64(11 + nq)
@@ -162,6 +162,8 @@ def _worker(rank, world, port, nq, fail_rank, out_path):
         if is_root:
             assert d_got.cpu().tolist() == [x for r in range(world) for x in (r + 1, r + 1)]
     comm.close()
+    if hasattr(transport, "close"):
+        transport.close()
     if loc_gpu is not gpu:
         loc_gpu.close()
     gpu.close()
@@ -169,12 +171,16 @@ def _worker(rank, world, port, nq, fail_rank, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nq,fail_rank", [(2, 301, -1), (3, 50, -1), (3, 2, -1), (2, 1, -1), (3, 120, 1), (2, 90, 0)])
-def test_comm_entry_points_beyond_one_rank(tmp_path, world, nq, fail_rank):
+@pytest.mark.parametrize("world,nq,fail_rank,transport", [(2, 301, -1, "blocking"), (3, 50, -1, "blocking"), (3, 2, -1, "blocking"), (2, 1, -1, "blocking"),
+                                                          (3, 120, 1, "blocking"), (2, 90, 0, "blocking"),
+                                                          # the target world size, ragged shards (8 k + 3) and fewer queries than ranks, over the
+                                                          # transport that only enqueues (gcsa2_amd/host_transport.py::AsyncHostGather); a failing rank
+                                                          (8, 8 * 37 + 3, -1, "async"), (8, 5, -1, "async"), (3, 50, -1, "async"), (8, 8 * 11 + 3, 5, "async")])
+def test_comm_entry_points_beyond_one_rank(tmp_path, world, nq, fail_rank, transport):
     import torch
     import torch.multiprocessing as mp
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     out = tmp_path / "ok.txt"
-    mp.spawn(_worker, args=(world, _free_port(), nq, fail_rank, str(out)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), nq, fail_rank, str(out), transport), nprocs=world, join=True)
     assert out.read_text() == "ok"

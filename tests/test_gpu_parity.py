@@ -252,9 +252,22 @@ def test_match_stats(case):
     (5, {}),
     (0, {"GCSA2_COOL_DOWN": "0"}),
     (5, {"GCSA2_MS_GRID": "2", "GCSA2_COOL_DOWN": "12"}),
+    (2, {}),                                                            # round 4's kernel with a lane per pattern (0 now chooses k_match_stats3)
+    (0, {"GCSA2_MS_KERNEL": "2"}),
+    # k_match_stats3 (round 5: pattern records, a second LDS slot for the LCP window, parent() + retry in one round): a lane per
+    # pattern (6) and persistent lanes (7), with and without the speculative window request, with cool-downs that make every
+    # single step ask for a window (the 16 window slots of a wave run out: the others wait a round)
+    (6, {}),
+    (7, {}),
+    (6, {"GCSA2_MS_SPECULATE": "0"}),
+    (7, {"GCSA2_MS_SPECULATE": "0", "GCSA2_MS_GRID": "2", "GCSA2_MS_REFILL_AT": "1"}),
+    (7, {"GCSA2_MS_GRID": "2", "GCSA2_MS_REFILL_AT": "1"}),
+    (7, {"GCSA2_MS_GRID": "1", "GCSA2_MS_REFILL_AT": "64", "GCSA2_COOL_DOWN": "1000"}),
+    (6, {"GCSA2_COOL_DOWN": "1000"}),
+    (6, {"GCSA2_COOL_DOWN": "0"}),
 ])
 def test_match_stats_kernel_variants(case, engine, variant, knobs, monkeypatch):
-    """Every launch shape of the matching-statistics kernel returns the oracle's statistics, ranges and parent() counts --
+    """Every launch shape of the matching-statistics kernels returns the oracle's statistics, ranges and parent() counts --
     in particular the persistent lanes that draw patterns from a counter, which small batches do not use by default.  The
     tuning knobs are read once, when an index is created; the variant is an argument."""
     import torch
@@ -301,7 +314,7 @@ def breaks_from_dense(cpu, pats, cm, off):
     return np.asarray(offsets, dtype=np.uint64), out
 
 
-@pytest.mark.parametrize("variant", [0, 5])
+@pytest.mark.parametrize("variant", [0, 2, 5, 6, 7])
 def test_match_breaks(case, engine, variant):
     """Matching statistics as break points (gcsa2_match_breaks_device): the CSR of left-maximal matches {position, length, sp,
     ep} equals what the oracle's dense statistics and find() imply -- every position where LF emptied and parent() was taken
@@ -708,6 +721,14 @@ def test_memory_ladder(engine, monkeypatch):
     gpu.set_tables(kmer_k=k_full - 1)
     assert gpu.kmer_table_k() == k_full - 1 and gpu.device_bytes() == full - locate_bytes - 6 * 4 ** k_full
     check(gpu, "smaller seed table")
+    # (bench.py's ladder: seed-table levels go before the pair blocks -- a level frees 3/4 of the table for one LF step per query,
+    # the pair blocks halve the requests of every remaining step; then the seed table's value without pair blocks)
+    gpu.set_tables(kmer_k=k_full - 3)
+    assert gpu.kmer_table_k() == k_full - 3 and gpu.pair_block_bytes() == pair_bytes
+    check(gpu, "pair blocks, seed table three levels down")
+    gpu.set_tables(pair_blocks=0, kmer_k=k_full)
+    assert gpu.pair_block_bytes() == 0 and gpu.kmer_table_k() == k_full and gpu.device_bytes() == full - locate_bytes - pair_bytes
+    check(gpu, "no pair blocks, full seed table")
     gpu.set_tables(pair_blocks=0, kmer_k=4)
     assert gpu.pair_block_bytes() == 0 and gpu.kmer_table_k() == 4
     bare = gpu.device_bytes() - 8 * 4 ** 4
@@ -785,6 +806,55 @@ def test_locate_into_caller_buffers(engine):
             gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), len(cv) - 1, sort=sort)
         assert e.value.code == -6 and e.value.needed == len(cv)
     assert gpu.locate_into(d_r.data_ptr(), 0, d_o.data_ptr(), 0, 0) == 0 and int(d_o[0]) == 0
+
+
+@pytest.mark.parametrize("single", ["1", "0"], ids=["one-kernel-path", "general-pipeline"])
+def test_locate_batches_of_one_value_ranges(engine, single, monkeypatch):
+    """A batch in which every range is one path node with one value (config 3's 32-mers, the final ranges of long patterns)
+    is answered by ONE kernel from the locate table (k_locate_single, GCSA2_LOCATE_SINGLE=0 switches it off): same CSR as the
+    general pipeline and the oracle (gcsa.cpp:827-842, 880-896), through every entry point, sorted or not; a single misfit in
+    the batch -- an empty range, a wider one, a node with several values -- sends it through the pipeline; too small a buffer
+    is refused with the size needed."""
+    import torch
+    from oracle.oracle import OracleIndex
+    monkeypatch.setenv("GCSA2_LOCATE_SINGLE", single)
+    name, g, K = CASES[-1]
+    ix = build(g, K, sample_period=8, branching=4)
+    gpu, cpu = engine.GCSA(ix), OracleIndex(ix)
+    nodes = np.arange(ix.n, dtype=np.uint64)
+    every = np.stack([nodes, nodes], axis=1)
+    eo, ev = cpu.locate_batch(every)
+    one = nodes[np.diff(eo) == 1]                                  # the path nodes with exactly one value
+    several = nodes[np.diff(eo) > 1]
+    assert len(one) > 100 and len(several) > 0
+    rng = SplitMix64(0x5151)
+    pick = np.array([one[rng.below(len(one))] for _ in range(3000)], dtype=np.uint64)
+    dev = torch.device("cuda", 0)
+    batches = {"all one value": np.stack([pick, pick], axis=1),
+               "one node with several values": np.concatenate([np.stack([pick, pick], axis=1), [[several[0], several[0]]]]).astype(np.uint64),
+               "an empty range in front": np.concatenate([[[1, 0]], np.stack([pick, pick], axis=1)]).astype(np.uint64),
+               "a wider range": np.concatenate([np.stack([pick[:50], pick[:50]], axis=1), [[0, 3]]]).astype(np.uint64)}
+    for tag, ranges in batches.items():
+        co, cv = cpu.locate_batch(ranges)
+        go, gv = gpu.locate_batch(ranges)
+        assert np.array_equal(go, co) and np.array_equal(gv, cv), tag
+        d_r = torch.from_numpy(ranges.view(np.int64).copy()).to(dev)
+        for sort in (True, False):
+            if not sort:
+                parts = [cpu.locate((int(a), int(b)), sort=False) for a, b in ranges]
+                wo = np.concatenate([[0], np.cumsum([len(x) for x in parts])]).astype(np.uint64)
+                wv = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64)
+            else:
+                wo, wv = co, cv
+            d_o = torch.full((len(ranges) + 1,), -1, dtype=torch.int64, device=dev)
+            d_v = torch.full((len(wv) + 5,), -1, dtype=torch.int64, device=dev)
+            total = gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), d_v.shape[0], sort=sort)
+            assert total == len(wv) and np.array_equal(d_o.cpu().numpy().view(np.uint64), wo), (tag, sort)
+            assert np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], wv) and (d_v[total:] == -1).all(), (tag, sort)
+            with pytest.raises(engine.Gcsa2Error) as e:
+                gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), len(wv) - 1, sort=sort)
+            assert e.value.code == -6 and e.value.needed == len(wv), (tag, sort)
+    gpu.close()
 
 
 def test_concurrent_host_threads(engine):
@@ -1417,15 +1487,24 @@ def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
     assert np.array_equal(go, co) and np.array_equal(gv, cv) and int(np.diff(co).max()) > 1024
 
 
-def test_locate_many_large_distinct_segments(engine):
+@pytest.mark.parametrize("knobs", [{}, {"GCSA2_SPLIT_TARGET": "300"}, {"GCSA2_SPLIT_TARGET": "1500", "GCSA2_SPLIT_SKEW": "700"}, {"GCSA2_SPLIT_SKEW": "16"},
+                                   {"GCSA2_LOCATE_SPLIT_SORT": "0"}],
+                         ids=["split", "split-with-listed-buckets", "split-with-listed-and-skewed-buckets", "split-with-skewed-buckets", "radix-sort"])
+def test_locate_many_large_distinct_segments(engine, knobs, monkeypatch):
     """Ranges of thousands of path nodes whose values are all DISTINCT (a linear text: one value per path node), as found
     16-mers of interspersed repeats have on the 2^30-base text of bench.py: dozens of segments beyond the 8192 distinct values
-    the LDS hash set and sorts hold, sorted by ONE device-wide radix sort over (segment, value) keys; through the job interface
+    the LDS hash set and sorts hold.  Round 5: one workgroup per such segment splits it into buckets of a few dozen values and
+    sorts them in registers, a wavefront per bucket (k_over_split); a bucket of more than 64 values is listed for the
+    workgroup sort, one that is still too large for that goes to the device-wide radix sort over (segment, value) keys, which
+    sorted all of them in round 4 (GCSA2_LOCATE_SPLIT_SORT=0) -- the test knobs make buckets of ~300 / ~1500 values and call
+    more than 700 / 16 values too large, so that every branch runs; through the job interface
     (the value buffer is made once the total is known) and into caller-owned buffers (no wait for the total; a buffer that is
     too small is refused with the size needed and nothing is written behind its end)."""
     import torch
     from oracle.oracle import OracleIndex
     from workload import builder
+    for key, value in knobs.items():
+        monkeypatch.setenv(key, value)
     g = graphs.linear_graph(70000, 0x4E1, node_len=32)
     ix = builder.build(g, 16, sample_period=32)
     gpu, lcp = engine.open_index(ix)
