@@ -961,11 +961,12 @@ def roofline(args, r, wl, key, ceiling=None):
     limit = ceiling or MEASURED_CEILING or REQUEST_CEILING_GPS
     # Who serves the launch.  A batch whose working set is many times the on-die caches AND whose request rate stays below what
     # HBM delivers for dependent random 128-byte fetches (gather_bench) is served by HBM: `frac` is then an HBM fraction.
-    # Anything else -- a working set within a few multiples of the Infinity Cache, repeated blocks (ranges that share their
-    # upper levels: requests per distinct block well above one), a request rate above the HBM ceiling -- is served partly
-    # on-die, and `achieved` / `frac` are ALGORITHMIC rates, not memory-side ones.
-    reuse = requests / max(1.0, ws / 128.0)
-    on_die = ws < 8 * CACHE_BYTES or req_rate > limit or achieved > HBM_PEAK_GBS or reuse > 1.5
+    # Anything else -- a working set within a few multiples of the Infinity Cache, a request rate above the HBM ceiling (ranges
+    # that share their upper levels: the same blocks again and again), memory-side traffic (PMC pass) below the algorithmic
+    # bytes -- is served partly on-die, and `achieved` / `frac` are ALGORITHMIC rates, not memory-side ones.
+    reuse = requests / max(1.0, ws / 128.0)          # (information: requests per distinct line; a 60 GB working set touched twice by
+    #                                                    # different queries at random times is still served by HBM)
+    on_die = ws < 8 * CACHE_BYTES or req_rate > limit or achieved > HBM_PEAK_GBS or (traffic is not None and traffic < 0.9 * r["algo_bytes"])
     out = {"bound": "hbm", "kernel": "k_find2<pair>" if gpu.pair_block_bytes() else "k_find2",
            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
            "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"], "working_set_bytes": ws,
@@ -1839,21 +1840,23 @@ def compact_line(full):
     bench_full.json (and on stderr).  Kept under LINE_LIMIT bytes by construction, and by dropping secondaries if it is not."""
     out = pick(full, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     cfg = dict(full["config"])
-    cfg["workload"] = short(cfg["workload"], 360)
-    cfg["parallelism"] = short(cfg.get("parallelism", ""), 200)
+    for k in ("single_block_bytes", "block_bytes", "wide_seed_entries_hit", "found"):        # (in bench_full.json)
+        cfg.pop(k, None)
+    cfg["workload"] = short(cfg["workload"], 250)
+    cfg["parallelism"] = short(cfg.get("parallelism", ""), 160)
     out["config"] = cfg
     rf = dict(full["roofline"])
-    for k in ("working_set_note", "traffic_source"):
+    for k in ("working_set_note", "traffic_source", "traffic_GBps", "traffic_frac_of_measured_hbm_rate"):
         rf.pop(k, None)
     if "request_rate" in rf:
         rf["request_rate"] = {k: v for k, v in rf["request_rate"].items() if k != "ceiling_source"}
     out["roofline"] = rf
     if "value_at_reference_footprint" in full:
-        out["value_at_reference_footprint"] = full["value_at_reference_footprint"]
+        out["value_at_reference_footprint"] = {k: v for k, v in full["value_at_reference_footprint"].items() if k != "note"}
     if "cpu_baseline" in full:
         cb = dict(full["cpu_baseline"])
         if "sample" in cb:
-            cb["sample"] = short(cb["sample"], 200)
+            cb["sample"] = short(cb["sample"], 110)
         if "error" in cb:
             cb["error"] = short(cb["error"], 200)
         out["cpu_baseline"] = cb
@@ -1863,7 +1866,7 @@ def compact_line(full):
                                 "root_gather_ms", "root_gather_hidden_frac")
         out["multi_gpu"]["gather"] = short(mg.get("gather", ""), 100)
         out["multi_gpu"]["kernel_ms_per_rank"] = [round(x["kernel_ms"], 3) for x in mg.get("per_rank", [])]
-    out["full"] = full.get("full_json")
+    out["full"] = os.path.basename(full.get("full_json") or "")
     sec = {}
     for key, leg in full.items():
         if key in out or key in ("device", "full_json", "errors"):
