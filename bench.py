@@ -717,6 +717,10 @@ def measure(args, D, dev, wl, steps, warmup):
         exposed = max(0.0, (mine["pace_ms"] if mine["pace_ms"] is not None else mine["wall_ms_per_step"]) - mine["kernel_ms"] - mine["pack_ms"])
         mine["gather_hidden_frac"] = max(0.0, min(1.0, 1.0 - exposed / mine["gather_ms"])) if mine["gather_ms"] > 0 else None
         mine["wire_bytes_sent"] = 0 if D.rank == 0 else nq * wire_bytes
+        transport = getattr(D, "transport", None)
+        if transport is not None:            # (host-memory transports of the one-GPU rehearsals: how many gather calls returned before their bytes had moved)
+            mine["transport_calls"] = transport.calls
+            mine["transport_early_returns"] = getattr(transport, "early_returns", 0)
         mine["rccl_ranks"] = D.comm.rccl_ranks() if D.comm is not None else None
         everyone = [None] * D.world
         D.dist.all_gather_object(everyone, mine)

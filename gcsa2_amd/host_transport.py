@@ -87,6 +87,7 @@ class AsyncHostGather(HostGather):
         self.pending = {}                       # call id -> what the call owns until the stream has passed it
         self.jobs = queue.Queue()
         self.failed = None
+        self.early_returns = 0                  # calls that returned before their bytes had moved (the evidence that nothing blocks)
         self._wait_cb = self.HOSTFN(self._wait_for_arrival)        # (kept alive: the runtime calls it from its own thread)
         self.worker = threading.Thread(target=self._work, daemon=True)
         self.worker.start()
@@ -172,6 +173,8 @@ class AsyncHostGather(HostGather):
                     self._check(h.hipMemcpyAsync(dst, src, n, self.H2D, st), "hipMemcpyAsync")
                 self._check(h.hipEventRecord(call["event"], st), "hipEventRecord")
                 call["done"] = True
+                if not call["arrived"].is_set():
+                    self.early_returns += 1
             else:
                 self._release(call)
         elif sizes[self.rank] > 0:
@@ -182,6 +185,8 @@ class AsyncHostGather(HostGather):
             self._check(h.hipEventRecord(call["event"], st), "hipEventRecord")
             self.jobs.put(("send", call, buf, n, root))
             self.bytes_moved += n
+            if h.hipEventQuery(call["event"]) != 0:             # hipErrorNotReady: the copy has not run yet, the call returns all the same
+                self.early_returns += 1
         return 0
 
     def close(self):
