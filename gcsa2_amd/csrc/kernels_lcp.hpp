@@ -380,6 +380,22 @@ __device__ __forceinline__ u64 below_flags(u64 w, u32 bound)
   return u64(f_lo) | (u64(f_hi) << 32);
 }
 
+// Where the 128-byte window of the LCP array around (sp, ep) starts (a multiple of 16).  Round 5: when the interval and
+// MS_WINDOW_MARGIN bytes on either side lie inside ONE 128-byte line of the array, the window IS that line -- one memory
+// request; otherwise it starts 48..63 bytes before sp as in rounds 3-4, which straddles two lines seven times out of eight
+// (the PMC pass of round 5 found 1.9 requests per window: 32 M of the kernel's 263 M reads; profiles/r05_match_stats.md).
+#ifndef MS_WINDOW_MARGIN
+#define MS_WINDOW_MARGIN 24
+#endif
+__device__ __forceinline__ u64 lcp_window_start(u64 sp, u64 ep)
+{
+  const u32 off = u32(sp) & 127;
+  const u64 width = ep - sp;                                  // (a range wider than the window is not decided from it anyway)
+  if(off >= MS_WINDOW_MARGIN && off + width + 1 + MS_WINDOW_MARGIN <= 128) { return sp & ~u64(127); }
+  const u64 unit = sp >> 4;
+  return (unit >= 3 ? unit - 3 : 0) << 4;
+}
+
 __device__ __forceinline__ bool parent_from_window(const ulonglong2* wave_stage, u32 lane, u64 wstart, u64 lcp_size, u64 sp, u64 ep,
                                                    gcsa2_stnode& out)
 {
@@ -658,8 +674,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
     if(parenting)
     {
       // parent(): the 128 bytes of the LCP array around the range, through the same cooperative fetch as the blocks
-      const u64 unit = sp >> 4;
-      wstart = (unit >= 3 ? unit - 3 : 0) << 4;
+      wstart = lcp_window_start(sp, ep);
       idx_sp = idx_ep = u32(wstart >> 4) | LCP_FLAG;
     }
     if(stepping)

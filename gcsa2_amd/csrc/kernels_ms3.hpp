@@ -262,7 +262,7 @@ __global__ __launch_bounds__(TPB2, MS3_WAVES) void k_match_stats3(DevImage img, 
   u32 wslot = MS3_NONE;                     // the lane's LCP-window slot of this round
   // (a window starts 48..63 bytes before sp: the same expression where it is requested and where it is read -- sp does not
   // change between the two for a lane that fails)
-  auto window_start = [&](u64 at) -> u64 { const u64 unit = at >> 4; return (unit >= 3 ? unit - 3 : 0) << 4; };
+  auto window_start = [&](u64 at) -> u64 { return lcp_window_start(at, ep); };             // (kernels_lcp.hpp: one line of the array when the interval sits well inside it)
   // (the block address without a select between two pointers: LLVM turns `flag ? img.flp : img.flb` into a per-lane LOAD of the
   // pointer -- from the kernel-argument segment, or from a two-entry array it spills to scratch for the purpose -- with a full
   // s_waitcnt vmcnt(0) in front of every fetch; an opaque register holding the distance between the arrays compiles to one v_cndmask)
