@@ -127,7 +127,6 @@ struct gcsa2_index
     bool locate_split_sort = true;     // GCSA2_LOCATE_SPLIT_SORT=0: segments beyond 8192 distinct values go to the library's device-wide radix sort (round 4; A/B)
     bool locate_single = true;         // GCSA2_LOCATE_SINGLE=0: batches of one-value ranges go through the general locate pipeline too (A/B)
     u32 ms_kernel = 2;                 // GCSA2_MS_KERNEL=3: variant 0 of the matching statistics runs k_match_stats3 (kernels_ms3.hpp; A/B: it loses, profiles/r05_match_stats.md)
-    bool ms_short_parent = false;      // GCSA2_MS_SHORT_PARENT=1: k_match_stats2 tries parent() from the eight bytes on either side first (A/B: 7.18 against 6.81 ms, it loses there -- with ~6 parenting lanes per round some lane needs the whole window anyway)
     u32 ms_speculate = 1;              // GCSA2_MS_SPECULATE: bit 0 clear: k_match_stats3 requests an LCP window only after a step has failed; bit 1: one parent() per round; bit 2: no short parent() (A/B)
     size_t arena_cap = size_t(24) << 30;  // GCSA2_ARENA_CAP_MB: most scratch a handle keeps between calls per arena (struct Scratch)
     u64 budget_bytes = 0;              // GCSA2_MEMORY_BUDGET_MB: most device memory the image may take (0: what the device has free)
@@ -736,7 +735,6 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.split_target = u32(knob("GCSA2_SPLIT_TARGET", SPLIT_TARGET, 1, 4096));
     ix->tune.ms_kernel = u32(knob("GCSA2_MS_KERNEL", 2, 2, 3));
     ix->tune.ms_speculate = u32(knob("GCSA2_MS_SPECULATE", 3, 0, 7));
-    ix->tune.ms_short_parent = (knob("GCSA2_MS_SHORT_PARENT", 0, 0, 1) != 0);
     ix->tune.arena_cap = size_t(knob("GCSA2_ARENA_CAP_MB", 24576, 0, long(1) << 20)) << 20;    // 24 GB: 1/12 of an MI355X's HBM per arena
     ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
     {
@@ -3280,7 +3278,7 @@ int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patt
   ulonglong2* recs = nullptr;
   HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&recs), ((total_bytes >> 5) + nq + 6) * sizeof(ulonglong2), st));
   hipLaunchKernelGGL(k_pack_records, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, recs);
-  const u32 cool = ix->tune.cool_down | (ix->tune.ms_short_parent ? 0u : 0x80000000u);
+  const u32 cool = ix->tune.cool_down;
   unsigned short* out = reinterpret_cast<unsigned short*>(d_ms);
   const u64 lanes_grid = (nq + TPB2 - 1) / TPB2;
   const bool pair = ix->img.flp != nullptr;

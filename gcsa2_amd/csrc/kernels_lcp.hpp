@@ -541,8 +541,6 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   c2c[threadIdx.x] = img.char2comp[threadIdx.x];
   c2c[threadIdx.x + TPB2] = img.char2comp[threadIdx.x + TPB2];
   __syncthreads();
-  const bool short_parent = (cool_down >> 31) == 0;          // (bit 31 of the argument: GCSA2_MS_SHORT_PARENT=0, an A/B knob)
-  cool_down &= 0x7FFFFFFFu;
   const u32 lane = threadIdx.x & 63;
   ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
   u64* wave_addr = addr_table + (threadIdx.x & ~63u);
@@ -734,12 +732,9 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
         if(idx_ep == idx_sp) { p_ep = eval_staged(wave_stage, lane, PAIR && pair, r_ep, true); }
       }
       G2_TICK(3);
-      if(parenting)              // (round 5: the eight bytes on either side first -- no loop; the whole window only when they do not decide)
-      {
-        decided = short_parent && parent_near(wave_stage, lane, wstart, img.lcp_size, sp, ep, node);
-        if(!decided) { decided = parent_from_window(wave_stage, lane, wstart, img.lcp_size, sp, ep, node); }
-        G2_COUNT(5, 1);
-      }
+      // (round 5 tried parent_near -- the eight bytes on either side, no loop -- in front of this: 7.18 against 6.81 ms; with ~6
+      // parenting lanes per round one of them needs the whole window anyway, and then both forms run.  k_match_stats3 uses it.)
+      if(parenting) { decided = parent_from_window(wave_stage, lane, wstart, img.lcp_size, sp, ep, node); G2_COUNT(5, 1); }
       if constexpr(PROF) { if(parenting && decided) { asm volatile("" :: "v"(node.sp)); } }
       G2_TICK(6);
       if(__any(need2))
