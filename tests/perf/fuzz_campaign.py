@@ -107,7 +107,32 @@ def main():
             d_v = torch.zeros(len(cv) + 1, dtype=torch.int64, device=dev)
             total = gpu.locate_into(d_r.data_ptr(), len(wide), d_o.data_ptr(), d_v.data_ptr(), d_v.shape[0])
             assert total == len(cv) and np.array_equal(d_o.cpu().numpy().view(np.uint64), co) and np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], cv), (seed, "locate_into", shape)
-        print(line + f"  breaks={len(want_brk)} packed={len(fixed)}  ok", flush=True)
+        # round 5: every launch shape of both matching-statistics kernels (2 / 5: k_match_stats2, 6 / 7: k_match_stats3) on the device
+        # buffers, and locate() of batches of one-node ranges (the one-kernel path when every node has one value, the pipeline otherwise)
+        total_bytes = int(off[-1])
+        d_pat = torch.zeros(total_bytes + 16, dtype=torch.uint8, device=dev)
+        d_pat[:total_bytes] = torch.from_numpy(np.ascontiguousarray(data[:total_bytes]).copy()).to(dev)
+        d_off = torch.from_numpy(off.view(np.int64).copy()).to(dev)
+        for variant in (2, 5, 6, 7):
+            d_ms = torch.full((total_bytes + 8,), -3, dtype=torch.int16, device=dev)
+            d_rng = torch.zeros((len(rows), 2), dtype=torch.int64, device=dev)
+            d_fb = torch.zeros(len(rows), dtype=torch.int64, device=dev)
+            gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), len(rows), d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), 0, variant=variant,
+                                   total_bytes=total_bytes)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_ms[:total_bytes].cpu().numpy().view(np.uint16), cm), (seed, "match_stats variant", variant)
+            assert np.array_equal(d_rng.cpu().numpy().view(np.uint64), cr) and np.array_equal(d_fb.cpu().numpy().view(np.uint64), cf), (seed, "variant tail", variant)
+        nodes = mutate.integers(0, ix.n, size=4000).astype(np.uint64)
+        singles = np.stack([nodes, nodes], axis=1)
+        so, sv = cpu.locate_batch(singles)
+        go, gv = gpu.locate_batch(singles)
+        assert np.array_equal(go, so) and np.array_equal(gv, sv), (seed, "locate one-node ranges")
+        ones = singles[np.diff(so) == 1]
+        if len(ones):
+            oo, ov = cpu.locate_batch(ones)
+            go, gv = gpu.locate_batch(ones)
+            assert np.array_equal(go, oo) and np.array_equal(gv, ov), (seed, "locate one-value ranges")
+        print(line + f"  breaks={len(want_brk)} packed={len(fixed)} one-value={len(ones)}  ok", flush=True)
         gpu.close()
     print(f"campaign of {args.seeds} graphs: no difference ({time.time() - t_start:.0f} s)")
 

@@ -141,14 +141,14 @@ def test_eight_ranks_share_the_gpu_with_an_asynchronous_transport():
     gather calls return before their bytes have moved (with a transport that completes inside the call nothing could overlap).
     Reference shape of the only data-parallel query path: src/algorithms.cpp:106-114 (a static split)."""
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-             "--master-port", str(free_port()), "bench.py", "--gpus", "8", "--degree", "24", "--queries", str(8 * 250_000 + 3), "--steps", "6",
+             "--master-port", str(free_port()), "bench.py", "--gpus", "8", "--degree", "20", "--queries", str(8 * 100_000 + 3), "--steps", "6",
              "--warmup", "2", "--no-cpu", "--no-secondary"], env={"GCSA2_BENCH_BACKEND": "gloo", "GCSA2_BENCH_WIRE": "40"}, timeout=1500)
     check_line(d, 8, 6)
-    assert "40-bit pairs" in d["config"]["parallelism"] and d["config"]["queries_total"] == 8 * 250_000 + 3
+    assert "40-bit pairs" in d["config"]["parallelism"] and d["config"]["queries_total"] == 8 * 100_000 + 3
     mg = d["multi_gpu"]
-    assert len(mg["per_rank"]) == 8 and sorted(x["queries"] for x in mg["per_rank"]) == [250_000] * 5 + [250_001] * 3
+    assert len(mg["per_rank"]) == 8 and sorted(x["queries"] for x in mg["per_rank"]) == [100_000] * 5 + [100_001] * 3
     assert "asynchronous" in mg["gather"] and mg["rccl_ranks"] == 0 and mg["wire_bytes_per_query"] == 10
-    assert mg["bytes_into_root_per_step"] == 10 * (8 * 250_000 + 3 - mg["per_rank"][0]["queries"])
+    assert mg["bytes_into_root_per_step"] == 10 * (8 * 100_000 + 3 - mg["per_rank"][0]["queries"])
     # the overlap: no gather call waits for its bytes -- on the root most calls return before the seven parts have arrived (a
     # transport that completes inside the call returns late every time, and then nothing of gather k can run under kernel
     # k + 1).  `gather_hidden_frac` is reported per rank; with eight processes time-slicing ONE GPU and a gather through host
