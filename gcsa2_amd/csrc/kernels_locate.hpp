@@ -955,6 +955,8 @@ __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __
 // crowded into a small part of the segment's span -- goes on the `skew` list, which the host hands to that radix sort as before.
 constexpr int SPLIT_THREADS = 1024;
 constexpr u32 SPLIT_BUCKETS = 4096;
+constexpr u32 SPLIT_SAMPLE = 8192;             // values whose minimum and maximum stand for the segment's
+constexpr u32 SPLIT_AHEAD = 4;                 // independent loads per lane in the streaming passes
 constexpr u32 SPLIT_TARGET = 24;               // values per bucket aimed at (segments beyond 4096 x 24 values get larger ones)
 
 // ascending bitonic sort of one value per lane across the wavefront (64 lanes; padding = ~0 sorts to the end)
@@ -983,7 +985,8 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   __shared__ u32 cursor[SPLIT_BUCKETS];        // histogram, then the buckets' write cursors (= their ends after the scatter)
   __shared__ u32 starts[SPLIT_BUCKETS];
   __shared__ u32 wave_sums[SPLIT_THREADS / 64];
-  __shared__ unsigned long long s_lo, s_hi;
+  __shared__ unsigned long long s_lo, s_hi, list_base, skew_base;
+  __shared__ u32 wg_listed, wg_skewed, wg_skew_values;
   constexpr u32 PER_THREAD = SPLIT_BUCKETS / SPLIT_THREADS;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 b = over_begin[blockIdx.x], len = over_end[blockIdx.x] - b;
@@ -991,7 +994,18 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   for(u32 k = tid; k < SPLIT_BUCKETS; k += SPLIT_THREADS) { cursor[k] = 0; }
   __syncthreads();
   unsigned long long lo = ~0ull, hi = 0;
-  for(u64 i = tid; i < len; i += SPLIT_THREADS) { const u64 v = values[b + i]; lo = (v < lo ? v : lo); hi = (v > hi ? v : hi); }
+  // (every streaming pass keeps SPLIT_AHEAD independent loads per lane in flight: with one, a workgroup moved ~8 GB/s per CU)
+  // (minimum and maximum of a SAMPLE -- the segment's first SPLIT_SAMPLE values, which arrive in path order, i.e. in no order of
+  // value -- instead of a pass over the segment: the bucket of a value only has to be a monotone function of it, so what lies
+  // outside the sample's span is clamped into the first or the last bucket, ~len / SPLIT_SAMPLE values each)
+  for(u64 i0 = tid; i0 < len && i0 < SPLIT_SAMPLE; i0 += SPLIT_AHEAD * SPLIT_THREADS)
+  {
+    u64 got[SPLIT_AHEAD];
+#pragma unroll
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? values[b + i] : values[b + tid % len]); }
+#pragma unroll
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { lo = (got[j] < lo ? got[j] : lo); hi = (got[j] > hi ? got[j] : hi); }
+  }
   for(int o = 32; o > 0; o >>= 1)
   {
     const unsigned long long a = __shfl_down(lo, o, 64), c = __shfl_down(hi, o, 64);
@@ -1006,7 +1020,19 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   const u64 span = hi - lo;                                   // largest (v - lo)
   u32 shift = 0;
   while(shift < 63 && (span >> shift) >= nb) { shift++; }
-  for(u64 i = tid; i < len; i += SPLIT_THREADS) { atomicAdd(&cursor[u32((values[b + i] - lo) >> shift)], 1u); }
+  auto bucket_of = [&](u64 v) -> u32
+  {
+    const u64 raw = (v > lo ? (v - lo) >> shift : 0);
+    return u32(raw < nb ? raw : nb - 1);
+  };
+  for(u64 i0 = tid; i0 < len; i0 += SPLIT_AHEAD * SPLIT_THREADS)
+  {
+    u64 got[SPLIT_AHEAD];
+#pragma unroll
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? values[b + i] : lo); }
+#pragma unroll
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { if(i0 + u64(j) * SPLIT_THREADS < len) { atomicAdd(&cursor[bucket_of(got[j])], 1u); } }
+  }
   __syncthreads();
   // exclusive prefix sums of the counts: PER_THREAD consecutive buckets per thread, then across the wavefront and the workgroup
   u32 mine[PER_THREAD], sum = 0;
@@ -1018,63 +1044,95 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   __syncthreads();
   u32 before = incl - sum;
   for(u32 w = 0; w < wave; w++) { before += wave_sums[w]; }
+  const u32 small = (skew_above < 64 ? skew_above : 64u);     // a run, and a bucket that needs no list, holds at most this many values
+  // the buckets that are too large for a run are listed here, by the threads that own them, in slots the WORKGROUP reserves with
+  // one atomic per list (one atomic per bucket on the global counters -- a million of them on one address -- was 5 of the
+  // kernel's 14 ms on the clustered segments of the 32-mer batch; profiles/r05_locate.md)
+  u32 my_listed = 0, my_skewed = 0, my_skew_values = 0;
 #pragma unroll
-  for(u32 k = 0; k < PER_THREAD; k++) { starts[tid * PER_THREAD + k] = before; cursor[tid * PER_THREAD + k] = before; before += mine[k]; }
-  __syncthreads();
-  for(u64 i = tid; i < len; i += SPLIT_THREADS)
+  for(u32 k = 0; k < PER_THREAD; k++)
   {
-    const u64 v = values[b + i];
-    scratch[b + atomicAdd(&cursor[u32((v - lo) >> shift)], 1u)] = v;
+    starts[tid * PER_THREAD + k] = before; cursor[tid * PER_THREAD + k] = before; before += mine[k];
+    if(mine[k] > small) { if(mine[k] <= skew_above) { my_listed++; } else { my_skewed++; my_skew_values += mine[k]; } }
+  }
+  if(tid == 0) { wg_listed = 0; wg_skewed = 0; wg_skew_values = 0; }
+  __syncthreads();
+  u32 listed_at = 0, skewed_at = 0;
+  if(my_listed > 0) { listed_at = atomicAdd(&wg_listed, my_listed); }
+  if(my_skewed > 0) { skewed_at = atomicAdd(&wg_skewed, my_skewed); atomicAdd(&wg_skew_values, my_skew_values); }
+  __syncthreads();
+  if(tid == 0)
+  {
+    list_base = (wg_listed > 0 ? atomicAdd(totals + T_BUCKETS, (unsigned long long)wg_listed) : 0ull);
+    skew_base = (wg_skewed > 0 ? atomicAdd(totals + T_SKEW, (unsigned long long)wg_skewed) : 0ull);
+    if(wg_skewed > 0) { atomicAdd(totals + T_SKEW_VALUES, (unsigned long long)wg_skew_values); }
+  }
+  __syncthreads();
+  {
+    u32 at = starts[tid * PER_THREAD];
+#pragma unroll
+    for(u32 k = 0; k < PER_THREAD; k++)
+    {
+      if(mine[k] > small)
+      {
+        if(mine[k] <= skew_above) { const u64 slot = list_base + listed_at++; bkt_begin[slot] = b + at; bkt_end[slot] = b + at + mine[k]; }
+        else { const u64 slot = skew_base + skewed_at++; skew_begin[slot] = b + at; skew_end[slot] = b + at + mine[k]; }
+      }
+      at += mine[k];
+    }
+  }
+  for(u64 i0 = tid; i0 < len; i0 += SPLIT_AHEAD * SPLIT_THREADS)
+  {
+    u64 got[SPLIT_AHEAD];
+#pragma unroll
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? values[b + i] : lo); }
+#pragma unroll
+    for(u32 j = 0; j < SPLIT_AHEAD; j++)
+    {
+      if(i0 + u64(j) * SPLIT_THREADS < len) { scratch[b + atomicAdd(&cursor[bucket_of(got[j])], 1u)] = got[j]; }
+    }
   }
   __syncthreads();                                             // (the workgroup's stores have completed: s_waitcnt vmcnt(0) + barrier)
   // Each wavefront takes a contiguous share of the buckets and sorts it in runs of WHOLE buckets that hold at most 64 values
   // together (the buckets are value-ordered, so a run sorted by value is final): one value per lane, 21 exchange steps.
   const u32 share = (nb + SPLIT_THREADS / 64 - 1) / (SPLIT_THREADS / 64);
   const u32 k_end = ((wave + 1) * share < nb ? (wave + 1) * share : nb);
-  const u32 small = (skew_above < 64 ? skew_above : 64u);
   u32 k = wave * share;
-  while(k < k_end)
+  bool have = false;                                           // a run whose values are in flight: sorted while the NEXT run's load is
+  u32 held_first = 0, held_count = 0;
+  u64 held = 0;
+  while(k < k_end || have)
   {
-    const u32 first = starts[k];
-    // ends of the next 64 buckets (lane j: bucket k + j); the run ends behind the last one that keeps it within `small` values
-    const u32 kk = k + lane;
-    const u32 end = (kk < k_end ? cursor[kk] : ~u32(0));
-    const u64 fits = __ballot(kk < k_end && end - first <= small);
-    // (the fitting buckets are a prefix: ends grow)
-    const u32 take = u32(__popcll(fits));
-    if(take == 0)
+    bool got = false;
+    u32 first = 0, count = 0;
+    while(k < k_end && !got)
     {
-      // bucket k alone has more than `small` values: the workgroup sorts of the next launches take it, or the radix sort
-      const u32 count = cursor[k] - first;
-      if(count <= skew_above)
+      first = starts[k];
+      // ends of the next 64 buckets (lane j: bucket k + j); the run ends behind the last one that keeps it within `small` values
+      const u32 kk = k + lane;
+      const u32 end = (kk < k_end ? cursor[kk] : ~u32(0));
+      const u64 fits = __ballot(kk < k_end && end - first <= small);        // (a prefix of the lanes: ends grow)
+      const u32 take = u32(__popcll(fits));
+      if(take == 0)
       {
-        if(lane == 0)
-        {
-          const u64 slot = atomicAdd(totals + T_BUCKETS, 1ull);
-          bkt_begin[slot] = b + first; bkt_end[slot] = b + first + count;
-        }
+        // bucket k alone has more than `small` values: listed above for the sorts of the next launches; one that is too large
+        // even for those (BIG_SEGMENT; lower in tests, GCSA2_SPLIT_SKEW) goes back to where the radix sort expects it
+        const u32 big = cursor[k] - first;
+        if(big > skew_above) { for(u32 i = first + lane; i < first + big; i += 64) { values[b + i] = scratch[b + i]; } }
+        k++;
+        continue;
       }
-      else                                                     // (BIG_SEGMENT; lower in tests, GCSA2_SPLIT_SKEW)
-      {
-        if(lane == 0)
-        {
-          const u64 slot = atomicAdd(totals + T_SKEW, 1ull);
-          skew_begin[slot] = b + first; skew_end[slot] = b + first + count;
-          atomicAdd(totals + T_SKEW_VALUES, (unsigned long long)count);
-        }
-        for(u32 i = first + lane; i < first + count; i += 64) { values[b + i] = scratch[b + i]; }     // back to where the radix sort expects them
-      }
-      k++;
-      continue;
+      count = cursor[k + take - 1] - first;                    // (uniform)
+      k += take;
+      got = (count > 0);
     }
-    const u32 count = cursor[k + take - 1] - first;            // (uniform)
-    if(count > 0)
+    const u64 next = (got && lane < count ? scratch[b + first + lane] : ~u64(0));    // requested now, looked at in the next turn
+    if(have)
     {
-      u64 v = (lane < count ? scratch[b + first + lane] : ~u64(0));
-      if(count > 1) { v = wave_sort(v, lane); }
-      if(lane < count) { values[b + first + lane] = v; }
+      const u64 v = (held_count > 1 ? wave_sort(held, lane) : held);
+      if(lane < held_count) { values[b + held_first + lane] = v; }
     }
-    k += take;
+    have = got; held_first = first; held_count = count; held = next;
   }
 }
 
