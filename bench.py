@@ -1083,7 +1083,50 @@ def config5(args, wl, dev):
     out["parent_queries_per_s"] = nq / (t_parent * 1e-3)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_match_stats(ix, d_pat, d_ms, d_rng, d_fb, m)
+    if "error" not in out.get("roofline", {}):
+        del d_ms, d_find, d_nodes
+        torch.cuda.empty_cache()
+        out["four_times_the_batch"] = config5_large_batch(wl, dev, nxt, out["roofline"], 4 * nq, m)
     return out
+
+
+def config5_large_batch(wl, dev, nxt, small_roofline, nq, m):
+    """The same workload with FOUR times the patterns (4 M x 256 bp, dense statistics only): the persistent lanes of the kernel hold
+    262 144 patterns at a time, so a batch of 1 M is four patterns per lane and its last patterns -- a pattern with mismatches
+    takes a fifth of the whole launch -- drain a machine that has nothing else to run; at 4 M the drain is a twentieth.  The
+    steady-state rate, with the requests per pattern of the 1 M batch's instrumented twin against the request ceiling."""
+    import torch
+    gpu = wl.gpu
+    stream = torch.cuda.current_stream()
+    pats, _, expected = wl.long_patterns(0, nq, m, CONFIG5_SEED + 1)
+    for col in range(37, m, 41):
+        pats[1::2, col] = nxt[pats[1::2, col].to(torch.int64)]
+    d_pat = padded_bytes(pats)
+    del pats
+    d_off = torch.arange(nq + 1, dtype=torch.int64, device=dev) * m
+    d_ms = torch.zeros(nq * m + 8, dtype=torch.int16, device=dev)
+    d_rng = torch.zeros((nq, 2), dtype=torch.int64, device=dev)
+    d_fb = torch.zeros(nq, dtype=torch.int64, device=dev)
+    run = lambda: gpu.match_stats_device(d_pat.data_ptr(), d_off.data_ptr(), nq, d_ms.data_ptr(), d_rng.data_ptr(), d_fb.data_ptr(), stream.cuda_stream, total_bytes=nq * m)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(3):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    exp = expected[0::2]
+    want_ms = (m - torch.arange(m, device=dev)).to(torch.int16).view(1, m)
+    ok = bool(torch.equal(d_rng[0::2, 0], exp)) and bool(torch.equal(d_rng[0::2, 1], exp)) and bool((d_fb[0::2] == 0).all()) and \
+        bool((d_ms[: nq * m].view(nq, m)[0:200_000:2] == want_ms).all())
+    per_pattern = small_roofline["requests_per_pattern"]
+    rate = per_pattern * nq / (ms * 1e-3) / 1e9
+    limit = small_roofline["request_rate"]["ceiling_G_per_s"]
+    return {"patterns": nq, "match_stats_ms": ms, "patterns_per_s": nq / (ms * 1e-3), "parent_calls_per_pattern": float(d_fb.to(torch.float64).mean().item()),
+            "unmodified_half_equals_closed_form": ok, "requests_per_pattern": per_pattern,
+            "request_rate": {"achieved_G_per_s": rate, "ceiling_G_per_s": limit, "frac_of_ceiling": rate / limit}}
 
 
 def match_stats_roofline(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, kernel_ms, dev, records=None, events=None):
@@ -1818,6 +1861,7 @@ def one_number(key, leg):
         out = pick(leg, "patterns_per_s", "find_patterns_per_s", "n_gpus")
         out["match_stats_frac_of_request_ceiling"] = leg.get("roofline", {}).get("frac_of_request_ceiling")
         out["match_breaks_patterns_per_s"] = leg.get("match_breaks", {}).get("patterns_per_s")
+        out["patterns_per_s_at_4x_the_batch"] = leg.get("four_times_the_batch", {}).get("patterns_per_s")
         out["locate_values_per_s"] = leg.get("locate", {}).get("values_per_s")
         out["locate_frac_of_request_ceiling"] = leg.get("locate", {}).get("roofline", {}).get("request_rate", {}).get("frac_of_ceiling")
         return out

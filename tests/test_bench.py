@@ -90,6 +90,9 @@ def test_single_gpu_line_with_secondaries():
     c5 = d["config5"]
     assert c5["unmodified_half_equals_closed_form"] and c5["find_unmodified_half_equals_closed_form"] and c5["locate"]["count_equals_located"]
     assert c5["locate_unmodified_half_equals_closed_form"] and c5["cpu_baseline"]["gpu_matches_cpu_on_sample"]
+    big = c5["four_times_the_batch"]
+    assert big["patterns"] == 4_000_000 and big["unmodified_half_equals_closed_form"] is True and big["patterns_per_s"] > 0
+    assert c5["roofline"]["requests_per_pattern"] > 100 and 0 < c5["roofline"]["request_rate"]["frac_of_ceiling"] < 1.5
     mb = c5["match_breaks"]
     assert mb["unmodified_half_has_one_record_in_closed_form"] and mb["expands_to_the_dense_statistics_on_the_first_patterns"]
     assert mb["final_ranges_and_parent_counts_equal_dense"] and mb["records"] > 1_000_000 and mb["clean_batch"]["breaks_patterns_per_s"] > 0
