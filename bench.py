@@ -1698,6 +1698,25 @@ def repeats_hbm_secondary(args, D, dev, local_rank, log2_bases=30):
         # a linear graph: every path node has one value, the start position of its suffix; locate() of a pattern = its occurrences
         first_vals = d_val[: int(d_loff[1].item())]
         loc["sorted_distinct_first_range"] = bool((first_vals[1:] > first_vals[:-1]).all().item()) if first_vals.numel() > 1 else True
+        # ... of EVERY range (the split + register sort of segments beyond 8192 values, round 5, at full size): values rise strictly
+        # inside a range; only across a range boundary may a value be followed by a smaller or equal one
+        total_vals = int(d_loff[-1].item())
+        if total_vals > 1:
+            rises = d_val[1:total_vals] > d_val[: total_vals - 1]
+            inner = d_loff[1:-1]
+            rises[inner[(inner > 0) & (inner < total_vals)] - 1] = True
+            loc["sorted_distinct_every_range"] = bool(rises.all().item())
+            del rises
+        # ... and the DEFINITION on the widest ranges of the first few thousand: on this linear graph locate() of a pattern's range
+        # is the sorted list of its occurrences in the text (as node values), found by comparing windows of the text
+        order = torch.argsort(sizes[:4000], descending=True)[:4].cpu().numpy()
+        same, checked = True, 0
+        for q in order:
+            a, e = int(d_loff[q].item()), int(d_loff[q + 1].item())
+            want_vals = repeats_torch.occurrence_values_device(seq, pats[int(q)])
+            same = same and bool(torch.equal(d_val[a:e], want_vals))
+            checked += e - a
+        loc["widest_ranges_equal_occurrences_in_text"] = {"ranges": len(order), "values": checked, "equal": same}
         o["locate"] = loc
         out[f"{m}-mers"] = o
         del pats, leg, d_out, d_loff, d_val, sizes
@@ -1964,7 +1983,7 @@ class Emitter:
 
     def __init__(self, args, rank):
         import threading
-        self.args, self.rank, self.result, self.done = args, rank, None, False
+        self.args, self.rank, self.result, self.done, self.current = args, rank, None, False, None
         self.lock = threading.Lock()
         if rank == 0:
             self._watch_sigterm()
@@ -1976,7 +1995,12 @@ class Emitter:
         try:
             rd, wr = socket.socketpair()
             wr.setblocking(False)
-            signal.signal(signal.SIGTERM, lambda *_: None)            # (the wake-up fd is written at C level, whatever the main thread is blocked in)
+            # (the wake-up fd is written at C level, whatever the main thread is blocked in.  SIGSEGV / SIGBUS / SIGFPE / SIGABRT too: a
+            # crash inside a library call -- which runs without the interpreter lock -- leaves the watcher thread free to print the
+            # line before the process dies; a crash that holds the lock still loses it)
+            fatal = [signal.SIGSEGV, signal.SIGBUS, signal.SIGFPE, signal.SIGABRT]
+            for sig in [signal.SIGTERM] + fatal:
+                signal.signal(sig, lambda *_: None)
             signal.set_wakeup_fd(wr.fileno(), warn_on_full_buffer=False)
         except (ValueError, OSError):
             return
@@ -1987,11 +2011,14 @@ class Emitter:
                 data = rd.recv(16)
                 if not data:
                     return
-                if signal.SIGTERM in data:
+                hit = [sig for sig in (signal.SIGTERM, signal.SIGSEGV, signal.SIGBUS, signal.SIGFPE, signal.SIGABRT) if int(sig) in data]
+                if hit:
                     if self.result is not None:
-                        self.result.setdefault("errors", []).append("SIGTERM before the last leg finished")
+                        self.result.setdefault("errors", []).append(f"{hit[0].name} in leg {self.current or '?'}: the legs after it did not run")
+                        if self.current and self.current not in self.result:
+                            self.result[self.current] = {"error": f"{hit[0].name} (the process was ended by the signal)"}
                     self.emit()
-                    os._exit(143)
+                    os._exit(128 + int(hit[0]))
         threading.Thread(target=watch, daemon=True).start()
 
     def headline(self, result):
@@ -2013,10 +2040,14 @@ class Emitter:
 
     def leg(self, key, fn, keep=True):
         t = time.time()
-        fail = os.environ.get("GCSA2_BENCH_FAIL_LEG", "")           # tests: a leg that raises must not cost the line
+        self.current = key
+        fail = os.environ.get("GCSA2_BENCH_FAIL_LEG", "")           # tests: a leg that raises -- or crashes -- must not cost the line
         try:
             if fail and fail == key:
                 raise RuntimeError(f"GCSA2_BENCH_FAIL_LEG={key}")
+            if fail == "crash:" + key:                              # a wild read inside a C call (ctypes releases the interpreter lock)
+                import ctypes
+                ctypes.CDLL(None).memcpy(ctypes.c_void_p(16), ctypes.c_void_p(8), 8)
             value = fn()
         except Exception as e:
             import traceback

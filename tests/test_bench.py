@@ -230,6 +230,7 @@ def test_wide_range_and_ladder_secondaries():
         leg = r[m]
         assert leg["range_width_equals_occurrences_in_text_on_sample"] is True and leg["cpu_baseline"]["gpu_matches_cpu_on_sample"] is True
         assert leg["locate"]["count_equals_located"] is True and leg["mean_range_width_path_nodes"] > 1.5
+        assert leg["locate"]["sorted_distinct_every_range"] is True and leg["locate"]["widest_ranges_equal_occurrences_in_text"]["equal"] is True
 
 
 def test_a_failing_secondary_does_not_cost_the_line():
@@ -244,3 +245,13 @@ def test_a_failing_secondary_does_not_cost_the_line():
              "--no-secondary"], env={"GCSA2_BENCH_FAIL_LEG": "cpu_baseline"})
     check_line(d, 1, 2)
     assert "error" in d["cpu_baseline"] and "error" in d["_line"]["cpu_baseline"]
+
+
+def test_a_crash_inside_a_library_call_still_prints_the_line():
+    """A secondary that dies of SIGSEGV inside a C call (the interpreter lock is released there): the watcher thread prints the
+    line -- headline, roofline, the legs before the crash, the crashed leg as an error -- and the process exits with 128 + 11."""
+    d = run([sys.executable, "bench.py", "--degree", "20", "--queries", "300000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1",
+             "--secondary", "config5"], env={"GCSA2_BENCH_FAIL_LEG": "crash:config5"}, rc=139)
+    check_line(d, 1, 2)
+    assert "SIGSEGV" in d["config5"]["error"] and "SIGSEGV in leg config5" in d["errors"][0]
+    assert d["cpu_baseline"]["gpu_matches_cpu_on_sample"] is True and "error" in d["_line"]["secondary"]["config5"]

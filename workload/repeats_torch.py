@@ -128,3 +128,28 @@ def count_occurrences_device(seq: torch.Tensor, patterns: torch.Tensor) -> torch
         for q in range(patterns.shape[0]):
             counts[q] += (code == want[q]).sum()
     return counts
+
+
+def occurrence_values_device(seq: torch.Tensor, pattern: torch.Tensor, node_len: int = 32, id_offset: int = 11) -> torch.Tensor:
+    """Definition-level check of locate() on the linear graph of workload/linear_torch.py: the sorted values of the path nodes
+    whose suffixes start with `pattern` (one row of ASCII bytes, length m <= 32) -- an occurrence at backbone index p has the value
+    ((p // node_len) + 1) << id_offset | (p % node_len) -- found by comparing the packed 2-bit code of every m-base window."""
+    n, m = int(seq.shape[0]), int(pattern.shape[0])
+    assert m <= 32
+    comp = torch.zeros(256, dtype=torch.int64, device=seq.device)
+    for ch, c in zip(b"ACGT", range(4)):
+        comp[ch] = c
+    want = 0
+    for j in range(m):
+        want = (want << 2) | int(comp[int(pattern[j])])
+    found = []
+    chunk = 1 << 27
+    for b in range(0, n - m + 1, chunk):
+        e = min(n - m + 1, b + chunk)
+        code = torch.zeros(e - b, dtype=torch.int64, device=seq.device)
+        for j in range(m):
+            code = (code << 2) | (seq[b + j: e + j].to(torch.int64) - 1)
+        found.append(torch.nonzero(code == want).reshape(-1) + b)
+    p = torch.cat(found) if found else torch.zeros(0, dtype=torch.int64, device=seq.device)
+    values = ((torch.div(p, node_len, rounding_mode="floor") + 1) << id_offset) | (p % node_len)
+    return torch.sort(values).values
