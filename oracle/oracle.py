@@ -105,6 +105,13 @@ class OracleIndex:
         self.sigma = int(ix.sigma)
         self.char2comp = np.asarray(ix.char2comp)
         self.last_seconds = 0.0
+        # what the view was made with: a query that needs a component the view left out is refused here (the C restatement
+        # indexes the arrays it is given; bench.py opens find()-only oracles for its larger legs)
+        self._parts = {"samples": kw.get("with_samples", True), "counters": kw.get("with_counters", True), "lcp": kw.get("with_lcp", True)}
+
+    def _need(self, part, what):
+        if not self._parts[part]:
+            raise RuntimeError(f"OracleIndex: {what} needs the {part}, and this oracle was opened without them")
 
     def close(self):
         if self._h:
@@ -161,6 +168,7 @@ class OracleIndex:
         return out
 
     def locate(self, rng, sort=True, max_positions=None):
+        self._need("samples", "locate()")
         cnt = C.c_uint64()
         if isinstance(rng, (int, np.integer)):
             rng = (int(rng), int(rng))
@@ -229,6 +237,7 @@ class OracleIndex:
         return out
 
     def count_batch(self, ranges, threads=1):
+        self._need("counters", "count_batch()")
         ranges = np.ascontiguousarray(ranges, dtype=np.uint64)
         out = np.zeros(ranges.shape[0], dtype=np.uint64)
         self.last_seconds = lib().oracle_count_batch(self._h, _p64(ranges), ranges.shape[0],
@@ -250,6 +259,7 @@ class OracleIndex:
         return out
 
     def locate_batch(self, ranges, threads=1):
+        self._need("samples", "locate_batch()")
         ranges = np.ascontiguousarray(ranges, dtype=np.uint64)
         nq = ranges.shape[0]
         offsets = np.zeros(nq + 1, dtype=np.uint64)
