@@ -945,8 +945,8 @@ __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __
 // the top bits of (value - the segment's smallest value) into up to 4096 buckets of a few dozen values -- minimum and
 // maximum, a histogram in LDS, its prefix sums, the scatter into `scratch` at the same offsets -- and then its sixteen
 // wavefronts sort the buckets, one bucket of up to 64 values per wavefront at a time, in REGISTERS (a bitonic network over the
-// lanes: 21 exchange steps, no LDS, no barrier) straight into `values`.  A segment is read three times and written twice by
-// the workgroup that owns it (it sits in L2), the values are contiguous per segment already, and nothing is sorted across
+// lanes: 21 exchange steps, no LDS, no barrier; 32-bit keys relative to the run's base where they fit, wave_sort32) straight into
+// `values`.  A segment is read three times and written twice by the workgroup that owns it, the values are contiguous per segment already, and nothing is sorted across
 // segments: round 4 packed (segment rank << 37 | value) keys and gave them to the library's device-wide radix sort, seven
 // passes over 51-bit keys of which 14 bits said what the layout already knew (19 of the 35 ms of the 16-mer batch on the
 // 2^30-base text, profiles/r04_locate.md; a first form of this kernel that left buckets of ~1500 values to the workgroup
@@ -957,23 +957,115 @@ constexpr int SPLIT_THREADS = 1024;
 constexpr u32 SPLIT_BUCKETS = 4096;
 constexpr u32 SPLIT_SAMPLE = 8192;             // values whose minimum and maximum stand for the segment's
 constexpr u32 SPLIT_AHEAD = 4;                 // independent loads per lane in the streaming passes
+constexpr u32 SPLIT_RUNS_AHEAD = 3;           // runs of buckets whose values a wavefront has requested ahead of the one it sorts
+constexpr u32 SPLIT_CHUNK = 32;                // buckets a wavefront draws at a time in the run phase
 constexpr u32 SPLIT_TARGET = 24;               // values per bucket aimed at (segments beyond 4096 x 24 values get larger ones)
+
+// The value of lane (l ^ STRIDE), for every lane l.  Strides below 16 stay inside a row of sixteen lanes and go through the
+// vector unit's own lane crossbar (DPP: quad permutations for 1 and 2, a pair of masked row shifts for 4, a row rotation for 8);
+// 16 and 32 cross rows: gfx950's permlane swaps.  (All 21 steps as ds_bpermute -- what __shfl_xor compiles to -- made the run
+// sort of k_over_split wait for the LDS unit 42 times per run: profiles/r05_locate.md.)
+template<u32 STRIDE>
+__device__ __forceinline__ u64 lane_xor(u64 v)
+{
+  if constexpr(STRIDE >= 16)
+  {
+    // gfx950's half exchanges: v_permlane32_swap trades lanes 32-63 of its first operand for lanes 0-31 of the second,
+    // v_permlane16_swap rows 1 and 3 of the first for rows 0 and 2 of the second; with both operands = v, every lane finds its
+    // partner's word in one of the two results
+    const u32 lo = u32(v), hi = u32(v >> 32);
+    const u32 lane = __lane_id();
+    u32 out_lo, out_hi;
+    if constexpr(STRIDE == 32)
+    {
+      const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      out_lo = (lane < 32 ? a[1] : a[0]); out_hi = (lane < 32 ? c[1] : c[0]);
+    }
+    else
+    {
+      const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      out_lo = ((lane & 16) ? a[0] : a[1]); out_hi = ((lane & 16) ? c[0] : c[1]);
+    }
+    return u64(out_lo) | (u64(out_hi) << 32);
+  }
+  else
+  {
+    int lo = int(u32(v)), hi = int(u32(v >> 32));
+    if constexpr(STRIDE == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); }       // quad_perm [1, 0, 3, 2]
+    if constexpr(STRIDE == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); }       // quad_perm [2, 3, 0, 1]
+    if constexpr(STRIDE == 4)
+    {
+      // banks 0 and 2 (lanes with bit 2 clear) read four lanes up (row_shl:4), banks 1 and 3 four lanes down (row_shr:4)
+      const int lo_up = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xF, 0x5, false), hi_up = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xF, 0x5, false);
+      lo = __builtin_amdgcn_update_dpp(lo_up, lo, 0x114, 0xF, 0xA, false); hi = __builtin_amdgcn_update_dpp(hi_up, hi, 0x114, 0xF, 0xA, false);
+    }
+    if constexpr(STRIDE == 8) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, false); }      // row_ror:8
+    return u64(u32(lo)) | (u64(u32(hi)) << 32);
+  }
+}
+
+template<u32 K, u32 J>
+__device__ __forceinline__ void bitonic_steps(u64& v, u32 lane)
+{
+  const u64 other = lane_xor<J>(v);
+  const bool up = ((lane & K) == 0), lower = ((lane & J) == 0);
+  const bool take_min = (up == lower);
+  v = (take_min ? (other < v ? other : v) : (other > v ? other : v));
+  if constexpr(J > 1) { bitonic_steps<K, J / 2>(v, lane); }
+}
+
+// The same network on 32-bit keys, for runs whose values lie within 2^32 of a common base (nearly all: a run spans a few
+// buckets of the split).  The run sort is bound by the vector ALU -- 8.4 M runs x 21 steps on the 16-mer batch of the 2^30-base
+// text -- and a 64-bit step is a 64-bit compare, four selects and the direction test per lane: ~10 instructions.  Here a step
+// is min and max of the lane's key and its partner's (the DPP modifier folds into them) and ONE select whose condition is a
+// compile-time lane mask in a scalar register pair: three instructions.
+constexpr u64 take_min_mask(u32 K, u32 J)
+{
+  u64 m = 0;
+  for(u32 l = 0; l < 64; l++) { if(((l & K) == 0) == ((l & J) == 0)) { m |= u64(1) << l; } }
+  return m;
+}
+__device__ __forceinline__ u32 select_by_mask(u32 if_clear, u32 if_set, u64 mask)
+{
+  u32 r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+  return r;
+}
+template<u32 STRIDE>
+__device__ __forceinline__ u32 lane_xor32(u32 v, u32 lane)
+{
+  if constexpr(STRIDE == 32) { const auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane < 32 ? a[1] : a[0]); }
+  else if constexpr(STRIDE == 16) { const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false); return ((lane & 16) ? a[0] : a[1]); }
+  else if constexpr(STRIDE == 8) { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0x128, 0xF, 0xF, true)); }
+  else if constexpr(STRIDE == 4)
+  {
+    const int up = __builtin_amdgcn_update_dpp(int(v), int(v), 0x104, 0xF, 0x5, false);
+    return u32(__builtin_amdgcn_update_dpp(up, int(v), 0x114, 0xF, 0xA, false));
+  }
+  else if constexpr(STRIDE == 2) { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0x4E, 0xF, 0xF, true)); }
+  else { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xF, 0xF, true)); }
+}
+template<u32 K, u32 J>
+__device__ __forceinline__ void bitonic_steps32(u32& v, u32 lane)
+{
+  const u32 other = lane_xor32<J>(v, lane);
+  const u32 lo = (other < v ? other : v), hi = (other < v ? v : other);
+  v = select_by_mask(hi, lo, take_min_mask(K, J));
+  if constexpr(J > 1) { bitonic_steps32<K, J / 2>(v, lane); }
+}
+// ascending; padding = ~0 (a real key is below that)
+__device__ __forceinline__ u32 wave_sort32(u32 v, u32 lane)
+{
+  bitonic_steps32<2, 1>(v, lane); bitonic_steps32<4, 2>(v, lane); bitonic_steps32<8, 4>(v, lane);
+  bitonic_steps32<16, 8>(v, lane); bitonic_steps32<32, 16>(v, lane); bitonic_steps32<64, 32>(v, lane);
+  return v;
+}
 
 // ascending bitonic sort of one value per lane across the wavefront (64 lanes; padding = ~0 sorts to the end)
 __device__ __forceinline__ u64 wave_sort(u64 v, u32 lane)
 {
-#pragma unroll
-  for(u32 k = 2; k <= 64; k <<= 1)
-  {
-#pragma unroll
-    for(u32 j = k >> 1; j > 0; j >>= 1)
-    {
-      const u64 other = __shfl_xor(v, int(j), 64);
-      const bool up = ((lane & k) == 0), lower = ((lane & j) == 0);
-      const bool take_min = (up == lower);
-      v = (take_min ? (other < v ? other : v) : (other > v ? other : v));
-    }
-  }
+  bitonic_steps<2, 1>(v, lane); bitonic_steps<4, 2>(v, lane); bitonic_steps<8, 4>(v, lane);
+  bitonic_steps<16, 8>(v, lane); bitonic_steps<32, 16>(v, lane); bitonic_steps<64, 32>(v, lane);
   return v;
 }
 
@@ -986,7 +1078,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   __shared__ u32 starts[SPLIT_BUCKETS];
   __shared__ u32 wave_sums[SPLIT_THREADS / 64];
   __shared__ unsigned long long s_lo, s_hi, list_base, skew_base;
-  __shared__ u32 wg_listed, wg_skewed, wg_skew_values;
+  __shared__ u32 wg_listed, wg_skewed, wg_skew_values, next_chunk;
   constexpr u32 PER_THREAD = SPLIT_BUCKETS / SPLIT_THREADS;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 b = over_begin[blockIdx.x], len = over_end[blockIdx.x] - b;
@@ -1055,7 +1147,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
     starts[tid * PER_THREAD + k] = before; cursor[tid * PER_THREAD + k] = before; before += mine[k];
     if(mine[k] > small) { if(mine[k] <= skew_above) { my_listed++; } else { my_skewed++; my_skew_values += mine[k]; } }
   }
-  if(tid == 0) { wg_listed = 0; wg_skewed = 0; wg_skew_values = 0; }
+  if(tid == 0) { wg_listed = 0; wg_skewed = 0; wg_skew_values = 0; next_chunk = 0; }
   __syncthreads();
   u32 listed_at = 0, skewed_at = 0;
   if(my_listed > 0) { listed_at = atomicAdd(&wg_listed, my_listed); }
@@ -1093,20 +1185,26 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
     }
   }
   __syncthreads();                                             // (the workgroup's stores have completed: s_waitcnt vmcnt(0) + barrier)
-  // Each wavefront takes a contiguous share of the buckets and sorts it in runs of WHOLE buckets that hold at most 64 values
-  // together (the buckets are value-ordered, so a run sorted by value is final): one value per lane, 21 exchange steps.
-  const u32 share = (nb + SPLIT_THREADS / 64 - 1) / (SPLIT_THREADS / 64);
-  const u32 k_end = ((wave + 1) * share < nb ? (wave + 1) * share : nb);
-  u32 k = wave * share;
-  bool have = false;                                           // a run whose values are in flight: sorted while the NEXT run's load is
-  u32 held_first = 0, held_count = 0;
-  u64 held = 0;
-  while(k < k_end || have)
+  // The wavefronts sort the buckets in runs of WHOLE buckets that hold at most 64 values together (the buckets are
+  // value-ordered, so a run sorted by value is final): one value per lane, 21 exchange steps.  A wavefront draws CHUNKS of
+  // SPLIT_CHUNK consecutive buckets from a counter of the workgroup.
+  u32 k = 0, k_end = 0;
+  // the next run of this wavefront: [first, first + count) of the segment; false when the segment's buckets are used up
+  // (`base`: every value of the run lies in [base, base + 2^32 - 1), or NO_BASE: the first and the last bucket take what lies
+  // outside the sample's span, and a wide segment's buckets may be wider than that)
+  constexpr u64 NO_BASE = ~u64(0);
+  auto next_run = [&](u32& first, u32& count, u64& base) -> bool
   {
-    bool got = false;
-    u32 first = 0, count = 0;
-    while(k < k_end && !got)
+    while(true)
     {
+      if(k >= k_end)
+      {
+        u32 got = 0;
+        if(lane == 0) { got = atomicAdd(&next_chunk, SPLIT_CHUNK); }
+        got = __builtin_amdgcn_readfirstlane(got);
+        if(got >= nb) { return false; }
+        k = got; k_end = (got + SPLIT_CHUNK < nb ? got + SPLIT_CHUNK : nb);
+      }
       first = starts[k];
       // ends of the next 64 buckets (lane j: bucket k + j); the run ends behind the last one that keeps it within `small` values
       const u32 kk = k + lane;
@@ -1123,16 +1221,44 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
         continue;
       }
       count = cursor[k + take - 1] - first;                    // (uniform)
+      base = (k > 0 && k + take < nb && shift < 32 && (u64(take) << shift) < 0xFFFFFFFFull ? lo + (u64(k) << shift) : NO_BASE);
       k += take;
-      got = (count > 0);
+      if(count > 0) { return true; }
     }
-    const u64 next = (got && lane < count ? scratch[b + first + lane] : ~u64(0));    // requested now, looked at in the next turn
-    if(have)
+  };
+  // SPLIT_RUNS_AHEAD runs are in flight: a run is sorted while the loads of the ones behind it travel
+  static_assert(SPLIT_RUNS_AHEAD >= 2, "the pipeline below shifts at least two stages");
+  bool live[SPLIT_RUNS_AHEAD];
+  u32 run_first[SPLIT_RUNS_AHEAD], run_count[SPLIT_RUNS_AHEAD];
+  u64 run_value[SPLIT_RUNS_AHEAD], run_base[SPLIT_RUNS_AHEAD];
+#pragma unroll
+  for(u32 d = 0; d < SPLIT_RUNS_AHEAD; d++)
+  {
+    run_first[d] = 0; run_count[d] = 0; run_base[d] = NO_BASE;
+    live[d] = next_run(run_first[d], run_count[d], run_base[d]);
+    run_value[d] = (live[d] && lane < run_count[d] ? scratch[b + run_first[d] + lane] : ~u64(0));
+  }
+  while(live[0])
+  {
+    u64 v = run_value[0];
+    if(run_count[0] > 1)
     {
-      const u64 v = (held_count > 1 ? wave_sort(held, lane) : held);
-      if(lane < held_count) { values[b + held_first + lane] = v; }
+      if(run_base[0] != NO_BASE)                               // (uniform)
+      {
+        const u32 key = wave_sort32(lane < run_count[0] ? u32(v - run_base[0]) : ~u32(0), lane);
+        v = run_base[0] + key;
+      }
+      else { v = wave_sort(v, lane); }
     }
-    have = got; held_first = first; held_count = count; held = next;
+    if(lane < run_count[0]) { values[b + run_first[0] + lane] = v; }
+#pragma unroll
+    for(u32 d = 0; d + 1 < SPLIT_RUNS_AHEAD; d++)
+    {
+      live[d] = live[d + 1]; run_first[d] = run_first[d + 1]; run_count[d] = run_count[d + 1]; run_value[d] = run_value[d + 1]; run_base[d] = run_base[d + 1];
+    }
+    constexpr u32 last = SPLIT_RUNS_AHEAD - 1;
+    live[last] = live[last - 1] && next_run(run_first[last], run_count[last], run_base[last]);
+    run_value[last] = (live[last] && lane < run_count[last] ? scratch[b + run_first[last] + lane] : ~u64(0));
   }
 }
 
