@@ -188,6 +188,37 @@ class Dist:
             self.comm = None
             log("warning: the library communicator is not available on every rank; using torch.distributed.gather")
 
+    def probe_comm(self):
+        """The library's gather has never run with RCCL peers on the box this was built on (one GPU): before anything is timed,
+        one small ragged gather of known bytes goes through it, and if any rank sees an error -- or the root wrong bytes --
+        every rank drops the communicator together and the data path falls back (torch.distributed.gather under RCCL, host
+        copies under gloo); the line's `config.parallelism` / `multi_gpu.gather` says which path ran."""
+        if self.comm is None:
+            return
+        import torch
+        counts = [(1 << 16) + 8 * r for r in range(self.world)]
+        ok = True
+        try:
+            send = torch.full((counts[self.rank],), self.rank + 1, dtype=torch.uint8, device=self.dev)
+            recv = torch.zeros(sum(counts), dtype=torch.uint8, device=self.dev) if self.rank == 0 else None
+            stream = torch.cuda.current_stream()
+            self.comm.gather(send.data_ptr(), counts, recv.data_ptr() if self.rank == 0 else 0, 0, stream.cuda_stream)
+            torch.cuda.synchronize()
+            if os.environ.get("GCSA2_BENCH_FAIL_PROBE") == str(self.rank):     # tests: the probe fails on one rank
+                raise RuntimeError("GCSA2_BENCH_FAIL_PROBE")
+            if self.rank == 0:
+                expect = torch.cat([torch.full((c,), r + 1, dtype=torch.uint8) for r, c in enumerate(counts)])
+                ok = bool(torch.equal(recv.cpu(), expect))
+                if not ok:
+                    log("warning: the probe gather through the library communicator delivered wrong bytes")
+        except Exception as e:
+            print(f"[bench] rank {self.rank}: probe gather failed ({e})", file=sys.stderr, flush=True)
+            ok = False
+        if not self.all_true(ok):
+            self.comm.close()
+            self.comm = None
+            log("warning: the library communicator failed its probe gather; using the fallback data path")
+
     def barrier(self):
         if self.active:
             self.dist.barrier()
@@ -722,6 +753,8 @@ def measure(args, D, dev, wl, steps, warmup):
             mine["transport_calls"] = transport.calls
             mine["transport_early_returns"] = getattr(transport, "early_returns", 0)
         mine["rccl_ranks"] = D.comm.rccl_ranks() if D.comm is not None else None
+        # (what this rank computed in the last step, for the root to hold against what arrived: sums of sp and ep, mod 2^63)
+        mine["shard_checksum"] = [int(d_out[:, 0].sum().item()), int(d_out[:, 1].sum().item())]
         everyone = [None] * D.world
         D.dist.all_gather_object(everyone, mine)
         per_rank = everyone
@@ -737,6 +770,11 @@ def measure(args, D, dev, wl, steps, warmup):
         result["gathered"] = gathered if packed else recv[last][: total * 16].view(torch.int64).view(total, 2)
         mine = result["gathered"][bounds[0][0]:bounds[0][1]]
         assert torch.equal(mine, d_out), "gathered shard differs from the computed ranges"
+        for r, (b0, e0) in enumerate(bounds):                 # every other shard: the checksums its rank computed on its own GPU
+            part = result["gathered"][b0:e0]
+            got = [int(part[:, 0].sum().item()), int(part[:, 1].sum().item())]
+            assert got == per_rank[r]["shard_checksum"], f"the shard gathered from rank {r} differs from what that rank computed"
+        result["gathered_shards_verified"] = len(bounds)
 
     # algorithmic traffic of one launch (instrumented kernel, outside the timed region)
     d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
@@ -1929,7 +1967,7 @@ def compact_line(full):
         out["cpu_baseline"] = cb
     if "multi_gpu" in full:
         mg = full["multi_gpu"]
-        out["multi_gpu"] = pick(mg, "backend", "wire_bytes_per_query", "bytes_into_root_per_step", "rccl_ranks", "slowest_kernel_ms",
+        out["multi_gpu"] = pick(mg, "backend", "wire_bytes_per_query", "bytes_into_root_per_step", "rccl_ranks", "gathered_shards_verified", "slowest_kernel_ms",
                                 "root_gather_ms", "root_gather_hidden_frac")
         out["multi_gpu"]["gather"] = short(mg.get("gather", ""), 100)
         out["multi_gpu"]["kernel_ms_per_rank"] = [round(x["kernel_ms"], 3) for x in mg.get("per_rank", [])]
@@ -2099,6 +2137,7 @@ def main():
         raise SystemExit(f"bench.py: world size {world} but --gpus {args.gpus}")
     from gcsa2_amd import binding
     D.make_comm(binding, local_rank)
+    D.probe_comm()
     global MEASURED_CEILING
     ceiling = measured_request_ceiling() if (rank == 0 and world == 1 and not args.no_extras) else None
     MEASURED_CEILING = ceiling
@@ -2160,6 +2199,7 @@ def run_legs(args, D, dev, local_rank, wl, ceiling, emitter):
                 "rccl_ranks": ranks[0]["rccl_ranks"],
                 "slowest_kernel_ms": max(x["kernel_ms"] for x in ranks), "root_gather_ms": ranks[0]["gather_ms"],
                 "root_gather_hidden_frac": ranks[0]["gather_hidden_frac"],
+                "gathered_shards_verified": r.get("gathered_shards_verified"),
                 "note": "per rank and step, HIP events on the rank's own streams: kernel = k_find2 over the shard; pack = wire format; "
                         "gather = the grouped send / recv (+ unpack on the root) on the second stream, overlapping the next kernel; "
                         "pace = kernel start to kernel start; gather_hidden_frac = 1 - (pace - kernel - pack) / gather",

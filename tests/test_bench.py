@@ -151,6 +151,7 @@ def test_eight_ranks_share_the_gpu_with_an_asynchronous_transport():
     mg = d["multi_gpu"]
     assert len(mg["per_rank"]) == 8 and sorted(x["queries"] for x in mg["per_rank"]) == [100_000] * 5 + [100_001] * 3
     assert "asynchronous" in mg["gather"] and mg["rccl_ranks"] == 0 and mg["wire_bytes_per_query"] == 10
+    assert mg["gathered_shards_verified"] == 8          # the root holds every shard against the checksums its rank computed
     assert mg["bytes_into_root_per_step"] == 10 * (8 * 100_000 + 3 - mg["per_rank"][0]["queries"])
     # the overlap: no gather call waits for its bytes -- on the root most calls return before the seven parts have arrived (a
     # transport that completes inside the call returns late every time, and then nothing of gather k can run under kernel
@@ -160,6 +161,18 @@ def test_eight_ranks_share_the_gpu_with_an_asynchronous_transport():
     assert root["transport_calls"] >= 8 and root["transport_early_returns"] >= root["transport_calls"] // 2, root
     assert all(x["gather_hidden_frac"] is not None and 0.0 <= x["gather_hidden_frac"] <= 1.0 for x in mg["per_rank"])
     assert len(d["_line"]["multi_gpu"]["kernel_ms_per_rank"]) == 8
+
+
+def test_a_communicator_that_fails_its_probe_is_dropped_by_every_rank():
+    """Before anything is timed one small ragged gather of known bytes goes through the library's communicator; a rank that
+    sees an error there (GCSA2_BENCH_FAIL_PROBE: rank 1) makes EVERY rank fall back to the other data path, and the line says
+    which one ran -- the RCCL transport has never run with peers on the box this is developed on."""
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--degree", "20", "--queries", "200001", "--steps", "2",
+             "--warmup", "1", "--no-cpu", "--no-secondary"], env={"GCSA2_BENCH_BACKEND": "gloo", "GCSA2_BENCH_FAIL_PROBE": "1"})
+    check_line(d, 2, 2)
+    mg = d["multi_gpu"]
+    assert mg["gather"].startswith("host copies") and mg["gathered_shards_verified"] == 2
 
 
 def test_plain_invocation_launches_its_own_ranks():
