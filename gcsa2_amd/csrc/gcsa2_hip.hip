@@ -1573,8 +1573,8 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   }
   if(large + huge > 0)
   {
-    hipLaunchKernelGGL((k_sort_big<4096, 0>), dim3(unsigned(large + huge)), dim3(BIG_THREADS), 0, stream, seg_begin, seg_end, sorted, d_totals + T_LARGE);
-    hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(large + huge)), dim3(BIG_THREADS), 0, stream, seg_begin, seg_end, sorted, d_totals + T_LARGE);
+    hipLaunchKernelGGL((k_sort_big<4096, 0>), dim3(unsigned(large + huge)), dim3(big_threads<4096>()), 0, stream, seg_begin, seg_end, sorted, d_totals + T_LARGE);
+    hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(large + huge)), dim3(big_threads<BIG_SEGMENT>()), 0, stream, seg_begin, seg_end, sorted, d_totals + T_LARGE);
     LAUNCH_CHECK("k_sort_big");
   }
   auto radix_over = [&](u64* over_begin, u64* over_end, u64 over, u64 over_values) -> int
@@ -1631,17 +1631,21 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     const u64 skew_cap = over_values / skew_above + over + 16;
     HIP_TRY(scratch.get(skew_begin, skew_cap)); HIP_TRY(scratch.get(skew_end, skew_cap));
     hipLaunchKernelGGL(k_over_split, dim3(unsigned(over)), dim3(SPLIT_THREADS), 0, stream, over_begin, over_end, sorted, split_tmp,
-                       bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target);
+                       bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target, bucket_cap - 1);
     LAUNCH_CHECK("k_over_split");
     rc = read_totals(ix, slot, totals, stream);
     if(rc != GCSA2_OK) { return rc; }
-    const u64 buckets = totals[T_BUCKETS], skew = totals[T_SKEW], skew_values = totals[T_SKEW_VALUES];
-    if(buckets > bucket_cap) { return fail(GCSA2_ERR_HIP, "locate: more buckets than the split reserved"); }
+    const u64 buckets = totals[T_BUCKETS], big_buckets = totals[T_BIG_BUCKETS], skew = totals[T_SKEW], skew_values = totals[T_SKEW_VALUES];
+    if(buckets + big_buckets > bucket_cap) { return fail(GCSA2_ERR_HIP, "locate: more buckets than the split reserved"); }
     if(buckets > 0)
     {
       hipLaunchKernelGGL(k_sort_bucket, dim3(unsigned(buckets)), dim3(64), 0, stream, bkt_begin, bkt_end, sorted, split_tmp, d_totals + T_BUCKETS);
-      hipLaunchKernelGGL((k_sort_big<4096, MEDIUM_SEGMENT>), dim3(unsigned(buckets)), dim3(BIG_THREADS), 0, stream, bkt_begin, bkt_end, sorted, d_totals + T_BUCKETS, split_tmp);
-      hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(buckets)), dim3(BIG_THREADS), 0, stream, bkt_begin, bkt_end, sorted, d_totals + T_BUCKETS, split_tmp);
+      LAUNCH_CHECK("k_sort_bucket");
+    }
+    if(big_buckets > 0)                                       // (listed from the back of the same arrays)
+    {
+      hipLaunchKernelGGL((k_sort_big<4096, MEDIUM_SEGMENT>), dim3(unsigned(big_buckets)), dim3(big_threads<4096>()), 0, stream, bkt_begin, bkt_end, sorted, d_totals + T_BIG_BUCKETS, split_tmp, bucket_cap - 1);
+      hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(big_buckets)), dim3(big_threads<BIG_SEGMENT>()), 0, stream, bkt_begin, bkt_end, sorted, d_totals + T_BIG_BUCKETS, split_tmp, bucket_cap - 1);
       LAUNCH_CHECK("k_sort_big (buckets)");
     }
     if(skew > 0) { rc = radix_over(skew_begin, skew_end, skew, skew_values); if(rc != GCSA2_OK) { return rc; } }

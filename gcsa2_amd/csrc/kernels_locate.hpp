@@ -450,7 +450,7 @@ constexpr u32 BIG_SEGMENT = 8192;
 constexpr u32 HUGE_SPLIT = BIG_SEGMENT / 2;
 // totals of one pass of the locate pipeline (a slot of TOTAL_WORDS u64 in device memory, mirrored to page-locked host memory)
 enum { T_NODES = 0, T_RAW = 1, T_LARGE = 2, T_UNIQUE = 3, T_MULTI = 4, T_MEDIUM = 5, T_HUGE_A = 6, T_OVER = 7, T_HUGE_B = 8, T_OVER_VALUES = 9,
-       T_BUCKETS = 10, T_SKEW = 11, T_SKEW_VALUES = 12,
+       T_BUCKETS = 10, T_SKEW = 11, T_SKEW_VALUES = 12, T_BIG_BUCKETS = 13,
        TOTAL_WORDS = 16 };
 
 __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
@@ -496,77 +496,273 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
   }
 }
 
-// one wavefront (= one workgroup) per query with SMALL_SEGMENT + 1 .. MEDIUM_SEGMENT values: bitonic sort in LDS,
-// in place.  Segment s of the list is the one at seg_begin / seg_end [last - s].
+// The value of lane (l ^ STRIDE), for every lane l.  Strides below 16 stay inside a row of sixteen lanes and go through the
+// vector unit's own lane crossbar (DPP: quad permutations for 1 and 2, a pair of masked row shifts for 4, a row rotation for 8);
+// 16 and 32 cross rows: gfx950's permlane swaps.  (All 21 steps as ds_bpermute -- what __shfl_xor compiles to -- made the run
+// sort of k_over_split wait for the LDS unit 42 times per run: profiles/r05_locate.md.)
+template<u32 STRIDE>
+__device__ __forceinline__ u64 lane_xor(u64 v)
+{
+  if constexpr(STRIDE >= 16)
+  {
+    // gfx950's half exchanges: v_permlane32_swap trades lanes 32-63 of its first operand for lanes 0-31 of the second,
+    // v_permlane16_swap rows 1 and 3 of the first for rows 0 and 2 of the second; with both operands = v, every lane finds its
+    // partner's word in one of the two results
+    const u32 lo = u32(v), hi = u32(v >> 32);
+    const u32 lane = __lane_id();
+    u32 out_lo, out_hi;
+    if constexpr(STRIDE == 32)
+    {
+      const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      out_lo = (lane < 32 ? a[1] : a[0]); out_hi = (lane < 32 ? c[1] : c[0]);
+    }
+    else
+    {
+      const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      out_lo = ((lane & 16) ? a[0] : a[1]); out_hi = ((lane & 16) ? c[0] : c[1]);
+    }
+    return u64(out_lo) | (u64(out_hi) << 32);
+  }
+  else
+  {
+    int lo = int(u32(v)), hi = int(u32(v >> 32));
+    // (every lane has a source lane in these three: with bound_ctrl the old value of the destination is not an operand)
+    if constexpr(STRIDE == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); }       // quad_perm [1, 0, 3, 2]
+    if constexpr(STRIDE == 2) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); }       // quad_perm [2, 3, 0, 1]
+    if constexpr(STRIDE == 4)
+    {
+      // banks 0 and 2 (lanes with bit 2 clear) read four lanes up (row_shl:4), banks 1 and 3 four lanes down (row_shr:4)
+      const int lo_up = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xF, 0x5, false), hi_up = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xF, 0x5, false);
+      lo = __builtin_amdgcn_update_dpp(lo_up, lo, 0x114, 0xF, 0xA, false); hi = __builtin_amdgcn_update_dpp(hi_up, hi, 0x114, 0xF, 0xA, false);
+    }
+    if constexpr(STRIDE == 8) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, true); }      // row_ror:8
+    return u64(u32(lo)) | (u64(u32(hi)) << 32);
+  }
+}
+
+template<u32 K, u32 J>
+__device__ __forceinline__ void bitonic_steps(u64& v, u32 lane)
+{
+  const u64 other = lane_xor<J>(v);
+  const bool up = ((lane & K) == 0), lower = ((lane & J) == 0);
+  const bool take_min = (up == lower);
+  v = (take_min ? (other < v ? other : v) : (other > v ? other : v));
+  if constexpr(J > 1) { bitonic_steps<K, J / 2>(v, lane); }
+}
+
+// The same network on 32-bit keys, for runs whose values lie within 2^32 of a common base (nearly all: a run spans a few
+// buckets of the split).  The run sort is bound by the vector ALU -- 8.4 M runs x 21 steps on the 16-mer batch of the 2^30-base
+// text -- and a 64-bit step is a 64-bit compare, four selects and the direction test per lane: ~10 instructions.  Here a step
+// is min and max of the lane's key and its partner's (the DPP modifier folds into them) and ONE select whose condition is a
+// compile-time lane mask in a scalar register pair: three instructions.
+constexpr u64 take_min_mask(u32 K, u32 J)
+{
+  u64 m = 0;
+  for(u32 l = 0; l < 64; l++) { if(((l & K) == 0) == ((l & J) == 0)) { m |= u64(1) << l; } }
+  return m;
+}
+__device__ __forceinline__ u32 select_by_mask(u32 if_clear, u32 if_set, u64 mask)
+{
+  u32 r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+  return r;
+}
+template<u32 STRIDE>
+__device__ __forceinline__ u32 lane_xor32(u32 v, u32 lane)
+{
+  if constexpr(STRIDE == 32) { const auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane < 32 ? a[1] : a[0]); }
+  else if constexpr(STRIDE == 16) { const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false); return ((lane & 16) ? a[0] : a[1]); }
+  else if constexpr(STRIDE == 8) { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0x128, 0xF, 0xF, true)); }
+  else if constexpr(STRIDE == 4)
+  {
+    const int up = __builtin_amdgcn_update_dpp(int(v), int(v), 0x104, 0xF, 0x5, false);
+    return u32(__builtin_amdgcn_update_dpp(up, int(v), 0x114, 0xF, 0xA, false));
+  }
+  else if constexpr(STRIDE == 2) { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0x4E, 0xF, 0xF, true)); }
+  else { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xF, 0xF, true)); }
+}
+template<u32 K, u32 J>
+__device__ __forceinline__ void bitonic_steps32(u32& v, u32 lane)
+{
+  const u32 other = lane_xor32<J>(v, lane);
+  const u32 lo = (other < v ? other : v), hi = (other < v ? v : other);
+  v = select_by_mask(hi, lo, take_min_mask(K, J));
+  if constexpr(J > 1) { bitonic_steps32<K, J / 2>(v, lane); }
+}
+// ascending; padding = ~0 (a real key is below that)
+__device__ __forceinline__ u32 wave_sort32(u32 v, u32 lane)
+{
+  bitonic_steps32<2, 1>(v, lane); bitonic_steps32<4, 2>(v, lane); bitonic_steps32<8, 4>(v, lane);
+  bitonic_steps32<16, 8>(v, lane); bitonic_steps32<32, 16>(v, lane); bitonic_steps32<64, 32>(v, lane);
+  return v;
+}
+
+// ascending bitonic sort of one value per lane across the wavefront (64 lanes; padding = ~0 sorts to the end)
+__device__ __forceinline__ u64 wave_sort(u64 v, u32 lane)
+{
+  bitonic_steps<2, 1>(v, lane); bitonic_steps<4, 2>(v, lane); bitonic_steps<8, 4>(v, lane);
+  bitonic_steps<16, 8>(v, lane); bitonic_steps<32, 16>(v, lane); bitonic_steps<64, 32>(v, lane);
+  return v;
+}
+
+// A bitonic sort of up to 1024 values held by ONE wavefront in registers: element e = 64 r + lane is register r of the lane.
+// Exchange steps with a stride below 64 cross lanes (lane_xor: DPP / permlane, no LDS), steps with a stride of 64 and more pair
+// two registers of the same lane; a step is one 64-bit compare whose result -- a lane mask in a scalar pair -- is combined
+// with the step's compile-time direction mask by a scalar instruction, and two selects.  (k_sort_medium and k_sort_bucket ran
+// the same network over an array in LDS: two reads, two writes and a barrier per step, whose latency a lone wavefront per
+// workgroup cannot hide.)
+constexpr u64 lanes_with_bit_clear(u32 bit)     // the lanes l of 0 .. 63 with (l & bit) == 0
+{
+  return bit == 1 ? 0x5555555555555555ull : bit == 2 ? 0x3333333333333333ull : bit == 4 ? 0x0F0F0F0F0F0F0F0Full
+       : bit == 8 ? 0x00FF00FF00FF00FFull : bit == 16 ? 0x0000FFFF0000FFFFull : bit == 32 ? 0x00000000FFFFFFFFull : ~0ull;
+}
+__device__ __forceinline__ u64 scalar64(u64 x)      // a wave-uniform value, said so to the compiler (the "s" operands below)
+{
+  return u64(u32(__builtin_amdgcn_readfirstlane(int(u32(x))))) | (u64(u32(__builtin_amdgcn_readfirstlane(int(u32(x >> 32))))) << 32);
+}
+__device__ __forceinline__ u64 select64_by_mask(u64 if_clear, u64 if_set, u64 mask)
+{
+  return u64(select_by_mask(u32(if_clear), u32(if_set), mask)) | (u64(select_by_mask(u32(if_clear >> 32), u32(if_set >> 32), mask)) << 32);
+}
+// (`flip`: 0, or all ones for the same network with every comparison inverted -- a descending sort, a descending merge)
+template<u32 R, u32 K, u32 J>
+__device__ __forceinline__ void regs_steps(u64 (&v)[R], u64 flip_in = 0)
+{
+  const u64 flip = scalar64(flip_in);
+  if constexpr(J >= 64)
+  {
+    constexpr u32 rj = J / 64;
+#pragma unroll
+    for(u32 r = 0; r < R; r++)
+    {
+      if((r & rj) == 0)
+      {
+        const bool up = (((r * 64) & K) == 0);
+        const u64 a = v[r], c = v[r | rj];
+        const u64 greater = __ballot(a > c);
+        const u64 swap = (up ? greater : ~greater) ^ flip;
+        v[r] = select64_by_mask(a, c, swap); v[r | rj] = select64_by_mask(c, a, swap);
+      }
+    }
+  }
+  else
+  {
+#pragma unroll
+    for(u32 r = 0; r < R; r++)
+    {
+      const u64 other = lane_xor<J>(v[r]);
+      const u64 smaller = __ballot(other < v[r]);
+      const u64 up = (K < 64 ? lanes_with_bit_clear(K) : ((((r * 64) & K) == 0) ? ~0ull : 0ull));
+      const u64 take_min = ~(up ^ lanes_with_bit_clear(J));
+      v[r] = select64_by_mask(v[r], other, ~(smaller ^ take_min) ^ flip);     // the partner's value where it is the one this lane keeps
+    }
+  }
+  if constexpr(J > 1) { regs_steps<R, K, J / 2>(v, flip); }
+}
+template<u32 R, u32 K = 2>
+__device__ __forceinline__ void wave_sort_regs(u64 (&v)[R], u64 flip = 0)
+{
+  regs_steps<R, K, K / 2>(v, flip);
+  if constexpr(K < 64 * R) { wave_sort_regs<R, 2 * K>(v, flip); }
+}
+// `len` values at src[0, len) sorted into dst[0, len) (dst may be src) by the wavefront, len <= 64 R
+template<u32 R>
+__device__ __forceinline__ void sort_segment_regs(const u64* src, u64* dst, u32 len, u32 lane)
+{
+  u64 v[R];
+#pragma unroll
+  for(u32 r = 0; r < R; r++) { v[r] = (r * 64 + lane < len ? src[r * 64 + lane] : ~u64(0)); }      // padding sorts to the end
+  wave_sort_regs<R>(v);
+#pragma unroll
+  for(u32 r = 0; r < R; r++) { if(r * 64 + lane < len) { dst[r * 64 + lane] = v[r]; } }
+}
+__device__ __forceinline__ void sort_segment_by_wave(const u64* src, u64* dst, u32 len, u32 lane)      // len <= MEDIUM_SEGMENT (uniform)
+{
+  if(len <= 64) { sort_segment_regs<1>(src, dst, len, lane); }
+  else if(len <= 128) { sort_segment_regs<2>(src, dst, len, lane); }
+  else if(len <= 256) { sort_segment_regs<4>(src, dst, len, lane); }
+  else if(len <= 512) { sort_segment_regs<8>(src, dst, len, lane); }
+  else { sort_segment_regs<16>(src, dst, len, lane); }
+}
+
+// one wavefront (= one workgroup) per query with SMALL_SEGMENT + 1 .. MEDIUM_SEGMENT values: bitonic sort in registers
+// (wave_sort_regs; in LDS until round 5), in place.  Segment s of the list is the one at seg_begin / seg_end [last - s].
 // (The grid is an upper bound -- the duplicate filter appends to the list while the host is not looking --; `count` on the
 // device says how many segments there are.)
 __global__ __launch_bounds__(64) void k_sort_medium(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end, u64 last,
                                                     u64* __restrict__ values, const unsigned long long* __restrict__ count)
 {
-  __shared__ u64 buf[MEDIUM_SEGMENT];
   const u32 lane = threadIdx.x;
   if(blockIdx.x >= *count) { return; }
   const u64 b = seg_begin[last - blockIdx.x];
   const u32 len = u32(seg_end[last - blockIdx.x] - b);
-  u32 n2 = 64;
-  while(n2 < len) { n2 <<= 1; }
-  for(u32 i = lane; i < n2; i += 64) { buf[i] = (i < len ? values[b + i] : ~u64(0)); }    // padding sorts to the end
-  __syncthreads();
-  for(u32 k = 2; k <= n2; k <<= 1)
-  {
-    for(u32 j = k >> 1; j > 0; j >>= 1)
-    {
-      for(u32 t = lane; t < (n2 >> 1); t += 64)
-      {
-        const u32 l = ((t & ~(j - 1)) << 1) | (t & (j - 1)), r = l | j;
-        const u64 x = buf[l], y = buf[r];
-        const bool up = ((l & k) == 0);
-        if((x > y) == up) { buf[l] = y; buf[r] = x; }
-      }
-      __syncthreads();
-    }
-  }
-  for(u32 i = lane; i < len; i += 64) { values[b + i] = buf[i]; }
+  sort_segment_by_wave(values + b, values + b, len, lane);
 }
 
-// one workgroup per LARGE segment (list from the start of the segment arrays) with at most BIG_SEGMENT values: bitonic sort in
-// 64 KB of LDS, in place (longer segments are on the list of the segmented radix sort).  Round 2 sent everything above 1024 values
+// one workgroup per LARGE segment (list from the start of the segment arrays) with at most BIG_SEGMENT values: bitonic sort
+// in registers and (for the widest strides) LDS, in place (longer segments are on the list of the segmented radix sort).  Round 2 sent everything above 1024 values
 // there: on a repeat-rich index that library call was 80 % of locate() (profiles/r03_locate.md).
 // Two instantiations share the list: CAPACITY 4096 takes the segments of up to 4096 values in 32 KB of LDS (five workgroups
 // per CU), CAPACITY 8192 the rest in 64 KB (two per CU); a workgroup whose segment belongs to the other one exits at once.
-constexpr int BIG_THREADS = 256;
+// Round 5: every wavefront of the workgroup holds 1024 values in registers (wave_sort_regs) and sorts them there, ascending or
+// descending by its parity; the stages above 1024 exchange whole registers between wavefronts through LDS for the strides of
+// 1024 and more -- one to three exchanges per stage, six for 8192 values -- and finish in registers again.  (All 78 / 91 steps
+// ran over the LDS array with a barrier each until then.)  CAPACITY / 16 threads.
+template<u32 CAPACITY> constexpr int big_threads() { return int(CAPACITY / 16); }
 // `source`: where the unsorted values are (the same offsets); nullptr = in place.  (The buckets of k_over_split are read from
 // its scratch array and land, sorted, in the values array.)
 template<u32 CAPACITY, u32 ABOVE>
-__global__ __launch_bounds__(BIG_THREADS) void k_sort_big(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end,
-                                                        u64* values, const unsigned long long* __restrict__ count, const u64* source = nullptr)
+__global__ __launch_bounds__(CAPACITY / 16) void k_sort_big(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end,
+                                                           u64* values, const unsigned long long* __restrict__ count, const u64* source = nullptr,
+                                                           u64 from_end = 0)      // from_end != 0: segment s of the list is at [from_end - s]
 {
   __shared__ u64 buf[CAPACITY];
-  const u32 tid = threadIdx.x;
+  const u32 tid = threadIdx.x, lane = tid & 63;
+  const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar for the compiler too: the direction masks below live in scalar pairs)
   if(blockIdx.x >= *count) { return; }                      // the grid is an upper bound (see k_sort_medium)
-  const u64 b = seg_begin[blockIdx.x];
-  const u32 len = u32(seg_end[blockIdx.x] - b);            // <= BIG_SEGMENT: k_collect_multi
+  const u64 at = (from_end != 0 ? from_end - blockIdx.x : u64(blockIdx.x));
+  const u64 b = seg_begin[at];
+  const u32 len = u32(seg_end[at] - b);                    // <= BIG_SEGMENT: k_collect_multi
   if(len > CAPACITY || len <= ABOVE) { return; }            // the other instantiation's segment (uniform per workgroup)
-  u32 n2 = 2048;
+  u32 n2 = 1024;
   while(n2 < len) { n2 <<= 1; }
   const u64* from = (source != nullptr ? source : values);
-  for(u32 i = tid; i < n2; i += BIG_THREADS) { buf[i] = (i < len ? from[b + i] : ~u64(0)); }    // padding sorts to the end
-  __syncthreads();
-  for(u32 k = 2; k <= n2; k <<= 1)
+  const u32 first = wave * 1024;                            // this wavefront's elements: first + 64 r + lane
+  const bool active = (first < n2);
+  u64 v[16];
+#pragma unroll
+  for(u32 r = 0; r < 16; r++) { const u32 e = first + r * 64 + lane; v[r] = (active && e < len ? from[b + e] : ~u64(0)); }    // padding sorts to the end
+  if(active) { wave_sort_regs<16>(v, (n2 > 1024 && (wave & 1)) ? ~u64(0) : u64(0)); }
+  for(u32 K = 2048; K <= n2; K <<= 1)
   {
-    for(u32 j = k >> 1; j > 0; j >>= 1)
+    const bool descending = (K < n2 && (first & K) != 0);   // (uniform per wavefront)
+    for(u32 J = K >> 1; J >= 1024; J >>= 1)
     {
-      for(u32 t = tid; t < (n2 >> 1); t += BIG_THREADS)
+      if(active)
       {
-        const u32 l = ((t & ~(j - 1)) << 1) | (t & (j - 1)), r = l | j;
-        const u64 x = buf[l], y = buf[r];
-        const bool up = ((l & k) == 0);
-        if((x > y) == up) { buf[l] = y; buf[r] = x; }
+#pragma unroll
+        for(u32 r = 0; r < 16; r++) { buf[first + r * 64 + lane] = v[r]; }
+      }
+      __syncthreads();
+      if(active)
+      {
+        const bool keep_min = (((first & J) == 0) != descending);
+#pragma unroll
+        for(u32 r = 0; r < 16; r++)
+        {
+          const u64 other = buf[(first ^ J) + r * 64 + lane];
+          v[r] = (keep_min ? (other < v[r] ? other : v[r]) : (other > v[r] ? other : v[r]));
+        }
       }
       __syncthreads();
     }
+    if(active) { regs_steps<16, 2048, 512>(v, descending ? ~u64(0) : u64(0)); }
   }
-  for(u32 i = tid; i < len; i += BIG_THREADS) { values[b + i] = buf[i]; }
+  if(active)
+  {
+#pragma unroll
+    for(u32 r = 0; r < 16; r++) { const u32 e = first + r * 64 + lane; if(e < len) { values[b + e] = v[r]; } }
+  }
 }
 
 // one workgroup per HUGE segment (more than BIG_SEGMENT values before deduplication): on a repeat-rich index such a segment
@@ -961,124 +1157,16 @@ constexpr u32 SPLIT_RUNS_AHEAD = 3;           // runs of buckets whose values a 
 constexpr u32 SPLIT_CHUNK = 32;                // buckets a wavefront draws at a time in the run phase
 constexpr u32 SPLIT_TARGET = 24;               // values per bucket aimed at (segments beyond 4096 x 24 values get larger ones)
 
-// The value of lane (l ^ STRIDE), for every lane l.  Strides below 16 stay inside a row of sixteen lanes and go through the
-// vector unit's own lane crossbar (DPP: quad permutations for 1 and 2, a pair of masked row shifts for 4, a row rotation for 8);
-// 16 and 32 cross rows: gfx950's permlane swaps.  (All 21 steps as ds_bpermute -- what __shfl_xor compiles to -- made the run
-// sort of k_over_split wait for the LDS unit 42 times per run: profiles/r05_locate.md.)
-template<u32 STRIDE>
-__device__ __forceinline__ u64 lane_xor(u64 v)
-{
-  if constexpr(STRIDE >= 16)
-  {
-    // gfx950's half exchanges: v_permlane32_swap trades lanes 32-63 of its first operand for lanes 0-31 of the second,
-    // v_permlane16_swap rows 1 and 3 of the first for rows 0 and 2 of the second; with both operands = v, every lane finds its
-    // partner's word in one of the two results
-    const u32 lo = u32(v), hi = u32(v >> 32);
-    const u32 lane = __lane_id();
-    u32 out_lo, out_hi;
-    if constexpr(STRIDE == 32)
-    {
-      const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-      out_lo = (lane < 32 ? a[1] : a[0]); out_hi = (lane < 32 ? c[1] : c[0]);
-    }
-    else
-    {
-      const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-      out_lo = ((lane & 16) ? a[0] : a[1]); out_hi = ((lane & 16) ? c[0] : c[1]);
-    }
-    return u64(out_lo) | (u64(out_hi) << 32);
-  }
-  else
-  {
-    int lo = int(u32(v)), hi = int(u32(v >> 32));
-    if constexpr(STRIDE == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); }       // quad_perm [1, 0, 3, 2]
-    if constexpr(STRIDE == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); }       // quad_perm [2, 3, 0, 1]
-    if constexpr(STRIDE == 4)
-    {
-      // banks 0 and 2 (lanes with bit 2 clear) read four lanes up (row_shl:4), banks 1 and 3 four lanes down (row_shr:4)
-      const int lo_up = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xF, 0x5, false), hi_up = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xF, 0x5, false);
-      lo = __builtin_amdgcn_update_dpp(lo_up, lo, 0x114, 0xF, 0xA, false); hi = __builtin_amdgcn_update_dpp(hi_up, hi, 0x114, 0xF, 0xA, false);
-    }
-    if constexpr(STRIDE == 8) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, false); }      // row_ror:8
-    return u64(u32(lo)) | (u64(u32(hi)) << 32);
-  }
-}
-
-template<u32 K, u32 J>
-__device__ __forceinline__ void bitonic_steps(u64& v, u32 lane)
-{
-  const u64 other = lane_xor<J>(v);
-  const bool up = ((lane & K) == 0), lower = ((lane & J) == 0);
-  const bool take_min = (up == lower);
-  v = (take_min ? (other < v ? other : v) : (other > v ? other : v));
-  if constexpr(J > 1) { bitonic_steps<K, J / 2>(v, lane); }
-}
-
-// The same network on 32-bit keys, for runs whose values lie within 2^32 of a common base (nearly all: a run spans a few
-// buckets of the split).  The run sort is bound by the vector ALU -- 8.4 M runs x 21 steps on the 16-mer batch of the 2^30-base
-// text -- and a 64-bit step is a 64-bit compare, four selects and the direction test per lane: ~10 instructions.  Here a step
-// is min and max of the lane's key and its partner's (the DPP modifier folds into them) and ONE select whose condition is a
-// compile-time lane mask in a scalar register pair: three instructions.
-constexpr u64 take_min_mask(u32 K, u32 J)
-{
-  u64 m = 0;
-  for(u32 l = 0; l < 64; l++) { if(((l & K) == 0) == ((l & J) == 0)) { m |= u64(1) << l; } }
-  return m;
-}
-__device__ __forceinline__ u32 select_by_mask(u32 if_clear, u32 if_set, u64 mask)
-{
-  u32 r;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
-  return r;
-}
-template<u32 STRIDE>
-__device__ __forceinline__ u32 lane_xor32(u32 v, u32 lane)
-{
-  if constexpr(STRIDE == 32) { const auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane < 32 ? a[1] : a[0]); }
-  else if constexpr(STRIDE == 16) { const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false); return ((lane & 16) ? a[0] : a[1]); }
-  else if constexpr(STRIDE == 8) { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0x128, 0xF, 0xF, true)); }
-  else if constexpr(STRIDE == 4)
-  {
-    const int up = __builtin_amdgcn_update_dpp(int(v), int(v), 0x104, 0xF, 0x5, false);
-    return u32(__builtin_amdgcn_update_dpp(up, int(v), 0x114, 0xF, 0xA, false));
-  }
-  else if constexpr(STRIDE == 2) { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0x4E, 0xF, 0xF, true)); }
-  else { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xF, 0xF, true)); }
-}
-template<u32 K, u32 J>
-__device__ __forceinline__ void bitonic_steps32(u32& v, u32 lane)
-{
-  const u32 other = lane_xor32<J>(v, lane);
-  const u32 lo = (other < v ? other : v), hi = (other < v ? v : other);
-  v = select_by_mask(hi, lo, take_min_mask(K, J));
-  if constexpr(J > 1) { bitonic_steps32<K, J / 2>(v, lane); }
-}
-// ascending; padding = ~0 (a real key is below that)
-__device__ __forceinline__ u32 wave_sort32(u32 v, u32 lane)
-{
-  bitonic_steps32<2, 1>(v, lane); bitonic_steps32<4, 2>(v, lane); bitonic_steps32<8, 4>(v, lane);
-  bitonic_steps32<16, 8>(v, lane); bitonic_steps32<32, 16>(v, lane); bitonic_steps32<64, 32>(v, lane);
-  return v;
-}
-
-// ascending bitonic sort of one value per lane across the wavefront (64 lanes; padding = ~0 sorts to the end)
-__device__ __forceinline__ u64 wave_sort(u64 v, u32 lane)
-{
-  bitonic_steps<2, 1>(v, lane); bitonic_steps<4, 2>(v, lane); bitonic_steps<8, 4>(v, lane);
-  bitonic_steps<16, 8>(v, lane); bitonic_steps<32, 16>(v, lane); bitonic_steps<64, 32>(v, lane);
-  return v;
-}
-
 __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restrict__ over_begin, const u64* __restrict__ over_end,
                                                              u64* values, u64* scratch, u64* __restrict__ bkt_begin, u64* __restrict__ bkt_end,
                                                              u64* __restrict__ skew_begin, u64* __restrict__ skew_end,
-                                                             unsigned long long* __restrict__ totals, u32 skew_above, u32 target)
+                                                             unsigned long long* __restrict__ totals, u32 skew_above, u32 target, u64 bucket_last)
 {
   __shared__ u32 cursor[SPLIT_BUCKETS];        // histogram, then the buckets' write cursors (= their ends after the scatter)
   __shared__ u32 starts[SPLIT_BUCKETS];
   __shared__ u32 wave_sums[SPLIT_THREADS / 64];
-  __shared__ unsigned long long s_lo, s_hi, list_base, skew_base;
-  __shared__ u32 wg_listed, wg_skewed, wg_skew_values, next_chunk;
+  __shared__ unsigned long long s_lo, s_hi, list_base, big_base, skew_base;
+  __shared__ u32 wg_listed, wg_big, wg_skewed, wg_skew_values, next_chunk;
   constexpr u32 PER_THREAD = SPLIT_BUCKETS / SPLIT_THREADS;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 b = over_begin[blockIdx.x], len = over_end[blockIdx.x] - b;
@@ -1140,22 +1228,31 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   // the buckets that are too large for a run are listed here, by the threads that own them, in slots the WORKGROUP reserves with
   // one atomic per list (one atomic per bucket on the global counters -- a million of them on one address -- was 5 of the
   // kernel's 14 ms on the clustered segments of the 32-mer batch; profiles/r05_locate.md)
-  u32 my_listed = 0, my_skewed = 0, my_skew_values = 0;
+  // (two lists in the same arrays: the buckets one wavefront sorts, k_sort_bucket, from the front; the few beyond MEDIUM_SEGMENT
+  // values, k_sort_big, from the back -- as one list, the workgroup sorts launched a million workgroups to find a few hundred)
+  u32 my_listed = 0, my_big = 0, my_skewed = 0, my_skew_values = 0;
 #pragma unroll
   for(u32 k = 0; k < PER_THREAD; k++)
   {
     starts[tid * PER_THREAD + k] = before; cursor[tid * PER_THREAD + k] = before; before += mine[k];
-    if(mine[k] > small) { if(mine[k] <= skew_above) { my_listed++; } else { my_skewed++; my_skew_values += mine[k]; } }
+    if(mine[k] > small)
+    {
+      if(mine[k] > skew_above) { my_skewed++; my_skew_values += mine[k]; }
+      else if(mine[k] > MEDIUM_SEGMENT) { my_big++; }
+      else { my_listed++; }
+    }
   }
-  if(tid == 0) { wg_listed = 0; wg_skewed = 0; wg_skew_values = 0; next_chunk = 0; }
+  if(tid == 0) { wg_listed = 0; wg_big = 0; wg_skewed = 0; wg_skew_values = 0; next_chunk = 0; }
   __syncthreads();
-  u32 listed_at = 0, skewed_at = 0;
+  u32 listed_at = 0, big_at = 0, skewed_at = 0;
   if(my_listed > 0) { listed_at = atomicAdd(&wg_listed, my_listed); }
+  if(my_big > 0) { big_at = atomicAdd(&wg_big, my_big); }
   if(my_skewed > 0) { skewed_at = atomicAdd(&wg_skewed, my_skewed); atomicAdd(&wg_skew_values, my_skew_values); }
   __syncthreads();
   if(tid == 0)
   {
     list_base = (wg_listed > 0 ? atomicAdd(totals + T_BUCKETS, (unsigned long long)wg_listed) : 0ull);
+    big_base = (wg_big > 0 ? atomicAdd(totals + T_BIG_BUCKETS, (unsigned long long)wg_big) : 0ull);
     skew_base = (wg_skewed > 0 ? atomicAdd(totals + T_SKEW, (unsigned long long)wg_skewed) : 0ull);
     if(wg_skewed > 0) { atomicAdd(totals + T_SKEW_VALUES, (unsigned long long)wg_skew_values); }
   }
@@ -1167,8 +1264,9 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
     {
       if(mine[k] > small)
       {
-        if(mine[k] <= skew_above) { const u64 slot = list_base + listed_at++; bkt_begin[slot] = b + at; bkt_end[slot] = b + at + mine[k]; }
-        else { const u64 slot = skew_base + skewed_at++; skew_begin[slot] = b + at; skew_end[slot] = b + at + mine[k]; }
+        if(mine[k] > skew_above) { const u64 slot = skew_base + skewed_at++; skew_begin[slot] = b + at; skew_end[slot] = b + at + mine[k]; }
+        else if(mine[k] > MEDIUM_SEGMENT) { const u64 slot = bucket_last - (big_base + big_at++); bkt_begin[slot] = b + at; bkt_end[slot] = b + at + mine[k]; }
+        else { const u64 slot = list_base + listed_at++; bkt_begin[slot] = b + at; bkt_end[slot] = b + at + mine[k]; }
       }
       at += mine[k];
     }
@@ -1262,37 +1360,18 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   }
 }
 
-// one wavefront (= one workgroup) per listed bucket of up to MEDIUM_SEGMENT values: bitonic sort in 8 KB of LDS, read from
+// one wavefront (= one workgroup) per listed bucket of up to MEDIUM_SEGMENT values: bitonic sort in registers, read from
 // `source`, written to `values` (k_sort_medium's network; the list is k_over_split's: buckets of 65 .. skew_above values, the
 // longer ones are left to k_sort_big)
 __global__ __launch_bounds__(64) void k_sort_bucket(const u64* __restrict__ bkt_begin, const u64* __restrict__ bkt_end, u64* values,
                                                     const u64* __restrict__ source, const unsigned long long* __restrict__ count)
 {
-  __shared__ u64 buf[MEDIUM_SEGMENT];
   if(blockIdx.x >= *count) { return; }
   const u32 lane = threadIdx.x;
   const u64 b = bkt_begin[blockIdx.x];
   const u32 len = u32(bkt_end[blockIdx.x] - b);
   if(len > MEDIUM_SEGMENT) { return; }                        // k_sort_big's
-  u32 n2 = 128;
-  while(n2 < len) { n2 <<= 1; }
-  for(u32 i = lane; i < n2; i += 64) { buf[i] = (i < len ? source[b + i] : ~u64(0)); }
-  __syncthreads();
-  for(u32 k = 2; k <= n2; k <<= 1)
-  {
-    for(u32 j = k >> 1; j > 0; j >>= 1)
-    {
-      for(u32 t = lane; t < (n2 >> 1); t += 64)
-      {
-        const u32 l = ((t & ~(j - 1)) << 1) | (t & (j - 1)), r = l | j;
-        const u64 x = buf[l], y = buf[r];
-        const bool up = ((l & k) == 0);
-        if((x > y) == up) { buf[l] = y; buf[r] = x; }
-      }
-      __syncthreads();
-    }
-  }
-  for(u32 i = lane; i < len; i += 64) { values[b + i] = buf[i]; }
+  sort_segment_by_wave(source + b, values + b, len, lane);
 }
 
 // Segments with more than BIG_SEGMENT distinct values whose split left a bucket too large (k_over_split's skew list), and every
