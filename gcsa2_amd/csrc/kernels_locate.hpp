@@ -665,13 +665,68 @@ __device__ __forceinline__ void wave_sort_regs(u64 (&v)[R], u64 flip = 0)
   regs_steps<R, K, K / 2>(v, flip);
   if constexpr(K < 64 * R) { wave_sort_regs<R, 2 * K>(v, flip); }
 }
-// `len` values at src[0, len) sorted into dst[0, len) (dst may be src) by the wavefront, len <= 64 R
+// The same network on 32-bit keys (ascending only): a cross-lane step is min and max with a DPP operand and one select on a
+// compile-time lane mask, a cross-register step min and max alone.
+template<u32 R, u32 K, u32 J>
+__device__ __forceinline__ void regs_steps32(u32 (&v)[R], u32 lane)
+{
+  if constexpr(J >= 64)
+  {
+    constexpr u32 rj = J / 64;
+#pragma unroll
+    for(u32 r = 0; r < R; r++)
+    {
+      if((r & rj) == 0)
+      {
+        const bool up = (((r * 64) & K) == 0);
+        const u32 a = v[r], c = v[r | rj];
+        const u32 lo = (a < c ? a : c), hi = (a < c ? c : a);
+        v[r] = (up ? lo : hi); v[r | rj] = (up ? hi : lo);
+      }
+    }
+  }
+  else
+  {
+#pragma unroll
+    for(u32 r = 0; r < R; r++)
+    {
+      const u32 other = lane_xor32<J>(v[r], lane);
+      const u32 lo = (other < v[r] ? other : v[r]), hi = (other < v[r] ? v[r] : other);
+      const u64 up = (K < 64 ? lanes_with_bit_clear(K) : ((((r * 64) & K) == 0) ? ~0ull : 0ull));
+      v[r] = select_by_mask(hi, lo, ~(up ^ lanes_with_bit_clear(J)));
+    }
+  }
+  if constexpr(J > 1) { regs_steps32<R, K, J / 2>(v, lane); }
+}
+template<u32 R, u32 K = 2>
+__device__ __forceinline__ void wave_sort_regs32(u32 (&v)[R], u32 lane)
+{
+  regs_steps32<R, K, K / 2>(v, lane);
+  if constexpr(K < 64 * R) { wave_sort_regs32<R, 2 * K>(v, lane); }
+}
+// `len` values at src[0, len) sorted into dst[0, len) (dst may be src) by the wavefront, len <= 64 R.  When all of them share
+// their upper 32 bits -- the values of a bucket of k_over_split nearly always do, a query's values when they lie in one 4 G
+// stretch of the node numbers -- the lower halves are sorted as 32-bit keys.
 template<u32 R>
 __device__ __forceinline__ void sort_segment_regs(const u64* src, u64* dst, u32 len, u32 lane)
 {
   u64 v[R];
 #pragma unroll
   for(u32 r = 0; r < R; r++) { v[r] = (r * 64 + lane < len ? src[r * 64 + lane] : ~u64(0)); }      // padding sorts to the end
+  const u32 top = u32(__builtin_amdgcn_readfirstlane(int(u32(v[0] >> 32))));      // (element 0 exists: len >= 1)
+  bool differs = false;
+#pragma unroll
+  for(u32 r = 0; r < R; r++) { differs = differs || (r * 64 + lane < len && u32(v[r] >> 32) != top); }
+  if(__ballot(differs) == 0)                                  // (uniform)
+  {
+    u32 key[R];
+#pragma unroll
+    for(u32 r = 0; r < R; r++) { key[r] = (r * 64 + lane < len ? u32(v[r]) : ~u32(0)); }           // (a key of all ones ties with the padding: the same value either way)
+    wave_sort_regs32<R>(key, lane);
+#pragma unroll
+    for(u32 r = 0; r < R; r++) { if(r * 64 + lane < len) { dst[r * 64 + lane] = (u64(top) << 32) | key[r]; } }
+    return;
+  }
   wave_sort_regs<R>(v);
 #pragma unroll
   for(u32 r = 0; r < R; r++) { if(r * 64 + lane < len) { dst[r * 64 + lane] = v[r]; } }
@@ -1155,7 +1210,12 @@ constexpr u32 SPLIT_SAMPLE = 8192;             // values whose minimum and maxim
 constexpr u32 SPLIT_AHEAD = 4;                 // independent loads per lane in the streaming passes
 constexpr u32 SPLIT_RUNS_AHEAD = 3;           // runs of buckets whose values a wavefront has requested ahead of the one it sorts
 constexpr u32 SPLIT_CHUNK = 32;                // buckets a wavefront draws at a time in the run phase
-constexpr u32 SPLIT_TARGET = 24;               // values per bucket aimed at (segments beyond 4096 x 24 values get larger ones)
+// Values per bucket aimed at.  24 until the sorts of the listed buckets moved into registers (k_sort_bucket, late in round 5):
+// buckets a wavefront's RUN could take, because a listed bucket cost an LDS sort.  With a few hundred values per bucket the
+// workgroup writes into ~150 streams per segment instead of 4096 -- the partly written lines of all workgroups stay in L2 --
+// and nearly every bucket is listed: k_over_split 8.2 -> 4.2 ms, k_sort_bucket 0.4 -> 2.7 ms on the 16-mer batch of the
+// 2^30-base text (flat from 192 to 512; profiles/r05_locate.md).
+constexpr u32 SPLIT_TARGET = 256;
 
 __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restrict__ over_begin, const u64* __restrict__ over_end,
                                                              u64* values, u64* scratch, u64* __restrict__ bkt_begin, u64* __restrict__ bkt_end,

@@ -1487,25 +1487,34 @@ def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
     assert np.array_equal(go, co) and np.array_equal(gv, cv) and int(np.diff(co).max()) > 1024
 
 
-@pytest.mark.parametrize("knobs", [{}, {"GCSA2_SPLIT_TARGET": "300"}, {"GCSA2_SPLIT_TARGET": "1500", "GCSA2_SPLIT_SKEW": "700"}, {"GCSA2_SPLIT_SKEW": "16"},
-                                   {"GCSA2_LOCATE_SPLIT_SORT": "0"}],
-                         ids=["split", "split-with-listed-buckets", "split-with-listed-and-skewed-buckets", "split-with-skewed-buckets", "radix-sort"])
+@pytest.mark.parametrize("knobs", [{}, {"GCSA2_SPLIT_TARGET": "24"}, {"GCSA2_SPLIT_TARGET": "1500", "GCSA2_SPLIT_SKEW": "700"}, {"GCSA2_SPLIT_SKEW": "16"},
+                                   {"GCSA2_LOCATE_SPLIT_SORT": "0"}, {"values": "across 2^32"}, {"values": "across 2^32", "GCSA2_SPLIT_TARGET": "24"},
+                                   {"values": "across 2^32", "GCSA2_SPLIT_TARGET": "1500", "GCSA2_SPLIT_SKEW": "3000"}],
+                         ids=["split-with-listed-buckets", "split-with-runs", "split-with-listed-and-skewed-buckets", "split-with-skewed-buckets", "radix-sort",
+                              "64-bit-keys", "64-bit-keys-runs", "64-bit-keys-large-buckets"])
 def test_locate_many_large_distinct_segments(engine, knobs, monkeypatch):
     """Ranges of thousands of path nodes whose values are all DISTINCT (a linear text: one value per path node), as found
     16-mers of interspersed repeats have on the 2^30-base text of bench.py: dozens of segments beyond the 8192 distinct values
     the LDS hash set and sorts hold.  Round 5: one workgroup per such segment splits it into buckets of a few dozen values and
     sorts them in registers, a wavefront per bucket (k_over_split); a bucket of more than 64 values is listed for the
     workgroup sort, one that is still too large for that goes to the device-wide radix sort over (segment, value) keys, which
-    sorted all of them in round 4 (GCSA2_LOCATE_SPLIT_SORT=0) -- the test knobs make buckets of ~300 / ~1500 values and call
-    more than 700 / 16 values too large, so that every branch runs; through the job interface
+    sorted all of them in round 4 (GCSA2_LOCATE_SPLIT_SORT=0) -- the test knobs make buckets of ~24 (sorted in runs inside the
+    split) / ~256 (the default: listed for the register sorts) / ~1500 values and call more than 700 / 16 values too large, so
+    that every branch runs, with node_type values below 2^32 and on both sides of it (32- and 64-bit sort keys); through the job interface
     (the value buffer is made once the total is known) and into caller-owned buffers (no wait for the total; a buffer that is
     too small is refused with the size needed and nothing is written behind its end)."""
     import torch
     from oracle.oracle import OracleIndex
     from workload import builder
+    knobs = dict(knobs)
+    across = knobs.pop("values", None)
     for key, value in knobs.items():
         monkeypatch.setenv(key, value)
     g = graphs.linear_graph(70000, 0x4E1, node_len=32)
+    if across:
+        # node_type values on both sides of 2^32: the register sorts take 32-bit keys only when a segment's values share their
+        # upper halves (sort_segment_regs), the run sort of k_over_split when a run lies within 2^32 of its base
+        g.value += np.uint64((1 << 32) - int(g.value.max()) // 2)
     ix = builder.build(g, 16, sample_period=32)
     gpu, lcp = engine.open_index(ix)
     cpu = OracleIndex(ix)
