@@ -962,7 +962,24 @@ def locate_roofline(gpu, d_ranges, nq, total, ms):
            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
            "algorithmic_bytes_per_call": algo, "call_ms": ms, "path_nodes": nodes, "one_node_ranges": singles,
            "request_rate": {"table_lines_per_call": lines, "achieved_G_per_s": rate, "ceiling_G_per_s": limit, "frac_of_ceiling": rate / limit}}
+    seen = locate_traffic(nq, nodes, total)
+    if seen:               # (reads by request size; writes as 64- and 32-byte requests, which the microarchitecture guide leaves uncalibrated)
+        out["traffic"] = seen["read_bytes_per_call"] + seen["write_bytes_per_call"]
+        out["traffic_read"], out["traffic_write"] = seen["read_bytes_per_call"], seen["write_bytes_per_call"]
+        out["traffic_over_algorithmic"] = out["traffic"] / algo
+        out["traffic_GBps"] = out["traffic"] / (ms * 1e-3) / 1e9
+        out["traffic_source"] = seen.get("source")
     return out
+
+
+def locate_traffic(nq, nodes, total):
+    """Memory-side bytes of one locate() call from the committed counter passes of this exact batch (profiles/traffic.json,
+    "locate": tools/pmc_locate.sh + tools/pmc_locate_summary.py); the batch is identified by its ranges, path nodes and values."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get("locate", {}).get(f"{nq}_{nodes}_{total}")
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic(args, key, gpu, nq, m):

@@ -90,3 +90,32 @@ def test_failed_legs_non_finite_numbers_and_eight_ranks_still_fit():
     huge["wide_ranges"] = {f"{k}-mers of a very long leg name number {k}": {"value": 1.0 * k, "served": "HBM"} for k in range(200)}
     line = bench.compact_line(bench.finite(huge))
     assert len(line) < bench.LINE_LIMIT and strict(line)["secondary_dropped_for_size"] is True
+
+
+def test_locate_counter_summary_adds_up(tmp_path):
+    """tools/pmc_locate_summary.py: bytes per locate() call from the two counter passes (reads by request size, writes as 64- and
+    32-byte requests), summed over the dispatches of the engine's locate kernels and divided by the calls of the bench leg."""
+    import csv
+    import subprocess
+    import sys
+    header = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"]
+    rows_rd = [[1, "(anonymous namespace)::k_over_split(unsigned long const*)", "TCC_EA0_RDREQ_128B_sum", 1000],
+               [1, "(anonymous namespace)::k_over_split(unsigned long const*)", "TCC_EA0_RDREQ_64B_sum", 10],
+               [1, "(anonymous namespace)::k_over_split(unsigned long const*)", "TCC_EA0_RDREQ_32B_sum", 4],
+               [1, "(anonymous namespace)::k_over_split(unsigned long const*)", "TCC_EA0_RDREQ_sum", 1014],
+               [2, "void (anonymous namespace)::k_sort_big<4096u, 0u>(unsigned long const*)", "TCC_EA0_RDREQ_128B_sum", 500],
+               [2, "void (anonymous namespace)::k_sort_big<4096u, 0u>(unsigned long const*)", "TCC_EA0_RDREQ_sum", 500]]
+    rows_wr = [[1, "(anonymous namespace)::k_over_split(unsigned long const*)", "TCC_EA0_WRREQ_sum", 300],
+               [1, "(anonymous namespace)::k_over_split(unsigned long const*)", "TCC_EA0_WRREQ_64B_sum", 200]]
+    for suffix, rows in (("_rdreq", rows_rd), ("_wrreq", rows_wr)):
+        d = tmp_path / ("x_locate" + suffix) / "host"
+        d.mkdir(parents=True)
+        with open(d / "x_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(header)
+            w.writerows(rows)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_locate_summary.py"), str(tmp_path / "x_locate"), "5"],
+                         capture_output=True, text=True, check=True)
+    d = json.loads(out.stdout)
+    assert d["read_bytes_per_call"] == (128 * 1500 + 64 * 10 + 32 * 4) / 5 and d["write_bytes_per_call"] == (64 * 200 + 32 * 100) / 5
+    assert d["read_requests_per_call"] == 1514 / 5 and d["write_requests_per_call"] == 60 and "k_over_split" in out.stderr
