@@ -125,6 +125,7 @@ struct gcsa2_index
     u32 split_target = SPLIT_TARGET;   // GCSA2_SPLIT_TARGET (tests): values per bucket k_over_split aims at
     u32 split_skew = BIG_SEGMENT;      // GCSA2_SPLIT_SKEW (tests): buckets of more values than this count as skewed and go to the radix sort
     bool locate_split_sort = true;     // GCSA2_LOCATE_SPLIT_SORT=0: segments beyond 8192 distinct values go to the library's device-wide radix sort (round 4; A/B)
+    bool locate_fused_compact = true;  // GCSA2_LOCATE_FUSED_COMPACT=0: caller-owned buffers also take the four-kernel compaction of the job interface (A/B)
     bool locate_single = true;         // GCSA2_LOCATE_SINGLE=0: batches of one-value ranges go through the general locate pipeline too (A/B)
     u32 ms_kernel = 2;                 // GCSA2_MS_KERNEL=3: variant 0 of the matching statistics runs k_match_stats3 (kernels_ms3.hpp; A/B: it loses, profiles/r05_match_stats.md)
     u32 ms_speculate = 1;              // GCSA2_MS_SPECULATE: bit 0 clear: k_match_stats3 requests an LCP window only after a step has failed; bit 1: one parent() per round; bit 2: no short parent() (A/B)
@@ -730,6 +731,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.kmer_piece = u64(knob("GCSA2_KMER_PIECE", long(1) << 27, 4, long(1) << 27));
     ix->tune.locate_trace = (knob("GCSA2_LOCATE_TRACE", 0, 0, 1) != 0);
     ix->tune.locate_single = (knob("GCSA2_LOCATE_SINGLE", 1, 0, 1) != 0);
+    ix->tune.locate_fused_compact = (knob("GCSA2_LOCATE_FUSED_COMPACT", 1, 0, 1) != 0);
     ix->tune.locate_split_sort = (knob("GCSA2_LOCATE_SPLIT_SORT", 1, 0, 1) != 0);
     ix->tune.split_skew = u32(knob("GCSA2_SPLIT_SKEW", BIG_SEGMENT, 16, BIG_SEGMENT));
     ix->tune.split_target = u32(knob("GCSA2_SPLIT_TARGET", SPLIT_TARGET, 1, 4096));
@@ -1651,6 +1653,31 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     if(skew > 0) { rc = radix_over(skew_begin, skew_end, skew, skew_values); if(rc != GCSA2_OK) { return rc; } }
   }
   else if(over > 0) { rc = radix_over(over_begin, over_end, over, over_values); if(rc != GCSA2_OK) { return rc; } }
+  if(known_out != nullptr && ix->tune.locate_fused_compact)
+  {
+    // the caller owns the values buffer: marks, counts, prefix sums and compaction in one sweep (k_mark_compact)
+    const u64 tiles = (nwords * 64 + COMPACT_TILE - 1) / COMPACT_TILE;
+    unsigned long long* tile_status = nullptr;
+    HIP_TRY(scratch.get(tile_status, tiles + 1));                         // (+ the ticket counter behind the last tile)
+    HIP_TRY(hipMemsetAsync(tile_status, 0, (tiles + 1) * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(words, 0, nwords * sizeof(u64), stream));
+    hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, words);
+    hipLaunchKernelGGL(k_mark_compact, dim3(unsigned(tiles)), dim3(COMPACT_THREADS), 0, stream, sorted, total_raw, nwords, words, word_before,
+                       known_out, known_capacity, tile_status, reinterpret_cast<unsigned int*>(tile_status + tiles), d_totals + T_UNIQUE);
+    LAUNCH_CHECK("k_mark_starts / k_mark_compact");
+    hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, words, word_before, nq, total_raw, nwords, d_offsets);
+    LAUNCH_CHECK("k_final_offsets");
+    stamp(4);
+    rc = read_totals(ix, slot, totals, stream);          // in stream order behind everything above: the pass is complete
+    if(rc != GCSA2_OK) { return rc; }
+    stamp(5);
+    scratch.settled = true;
+    *total_out = totals[T_UNIQUE];
+    if(totals[T_UNIQUE] > known_capacity) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small"); }
+    HIP_TRY(hipStreamSynchronize(stream));
+    stamp(6);
+    return GCSA2_OK;
+  }
   hipLaunchKernelGGL(k_mark_changes, dim3(grid_for(nwords * 64)), dim3(TPB), 0, stream, sorted, total_raw, words);
   hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, words);
   hipLaunchKernelGGL(k_word_counts, dim3(grid_for(nwords + 1)), dim3(TPB), 0, stream, words, nwords, word_counts);

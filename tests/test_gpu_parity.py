@@ -1488,9 +1488,10 @@ def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
 
 
 @pytest.mark.parametrize("knobs", [{}, {"GCSA2_SPLIT_TARGET": "24"}, {"GCSA2_SPLIT_TARGET": "1500", "GCSA2_SPLIT_SKEW": "700"}, {"GCSA2_SPLIT_SKEW": "16"},
-                                   {"GCSA2_LOCATE_SPLIT_SORT": "0"}, {"values": "across 2^32"}, {"values": "across 2^32", "GCSA2_SPLIT_TARGET": "24"},
+                                   {"GCSA2_LOCATE_SPLIT_SORT": "0"}, {"GCSA2_LOCATE_FUSED_COMPACT": "0"}, {"values": "across 2^32"}, {"values": "across 2^32", "GCSA2_SPLIT_TARGET": "24"},
                                    {"values": "across 2^32", "GCSA2_SPLIT_TARGET": "1500", "GCSA2_SPLIT_SKEW": "3000"}],
                          ids=["split-with-listed-buckets", "split-with-runs", "split-with-listed-and-skewed-buckets", "split-with-skewed-buckets", "radix-sort",
+                              "four-kernel-compaction",
                               "64-bit-keys", "64-bit-keys-runs", "64-bit-keys-large-buckets"])
 def test_locate_many_large_distinct_segments(engine, knobs, monkeypatch):
     """Ranges of thousands of path nodes whose values are all DISTINCT (a linear text: one value per path node), as found
