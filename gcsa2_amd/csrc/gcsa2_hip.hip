@@ -1522,8 +1522,8 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     HIP_TRY(scratch.get(later_words, spans));
     HIP_TRY(hipMemsetAsync(extra_slots, 0, nq * sizeof(u64), stream));
     hipLaunchKernelGGL(k_block_owners, dim3(grid_for(spans + 1)), dim3(TPB), 0, stream, node_off, nq, total_nodes, OWNER_SPAN, spans, owners);
-    hipLaunchKernelGGL(k_locate_tab_unordered, dim3(unsigned(blocks)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_off, raw_off,
-                       total_nodes, sorted, owners, later_words);
+    hipLaunchKernelGGL(k_locate_tab_unordered, dim3(unsigned((blocks + TAB_SPANS - 1) / TAB_SPANS)), dim3(TPB), 0, stream, ix->img, d_ranges, nq, node_off, raw_off,
+                       total_nodes, sorted, owners, later_words, spans);
     if(total_raw > total_nodes || ix->img.sample_width >= 63)
     {
       hipLaunchKernelGGL(k_locate_tab_rest, dim3(grid_for(spans)), dim3(TPB), 0, stream, ix->img, d_ranges, node_off, raw_off, total_nodes, sorted,

@@ -329,34 +329,54 @@ __global__ __launch_bounds__(TPB) void k_locate_tab(DevImage img, const u64* __r
 // stores the single values and only MARKS the other nodes, one 64-bit word per wavefront (a list with one atomic per
 // wavefront was tried first: 1.2 M atomics on one counter took 8 ms); the second pass gives every word to one lane, which
 // works through its one or two marked nodes.  Everything that is uniform over a wavefront is read through the scalar cache.
+// (Round 5: TAB_SPANS spans of 64 nodes per wavefront.  With one, a wavefront lived through three dependent memory latencies --
+// the owners, the owner's range / offsets, the table entry -- for 64 nodes, and the CU's 32 wavefronts made that 175 G nodes/s:
+// 3.1 ms of the 14 ms of the 16-mer batch on the 2^30-base text.  The owner's range and offsets are now read for every span's
+// FIRST owner without asking whether the span has one owner -- no branch in front of the loads, the spans' chains overlap --
+// and a span with several owners repairs its lanes afterwards.)
+constexpr u32 TAB_SPANS = 4;                  // (2: 1.95 ms, 4: 1.69 ms, 8: 1.82 ms for the 16-mer batch's table pass; 1: 3.17 ms)
 __global__ __launch_bounds__(TPB) void k_locate_tab_unordered(DevImage img, const u64* __restrict__ ranges, u64 nq,
                                                               const u64* __restrict__ node_off, const u64* __restrict__ raw_off,
                                                               u64 total_nodes, u64* __restrict__ values, const u64* __restrict__ owners,
-                                                              u64* __restrict__ later_words)
+                                                              u64* __restrict__ later_words, u64 spans)
 {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
-  const u64 j = u64(blockIdx.x) * (TPB / OWNER_SPAN) + wave;           // this wave's span of OWNER_SPAN = 64 nodes
-  const u64 g_first = j * OWNER_SPAN;
-  if(g_first >= total_nodes) { return; }                               // uniform
-  const u64 g = g_first + lane;
-  const bool live = g < total_nodes;
-  const u64 qa = owners[j], qb = owners[j + 1];                        // uniform addresses: scalar loads
-  u64 q, sp, first, b;
-  if(qa == qb)                                                         // uniform branch: the whole wave inside one query
+  const u64 j0 = (u64(blockIdx.x) * (TPB / OWNER_SPAN) + wave) * TAB_SPANS;   // this wave's spans of OWNER_SPAN = 64 nodes
+  if(j0 >= spans) { return; }                                          // uniform
+  u64 qo[TAB_SPANS + 1];
+#pragma unroll
+  for(u32 s = 0; s <= TAB_SPANS; s++) { qo[s] = owners[j0 + s <= spans ? j0 + s : spans]; }      // uniform addresses: scalar loads
+  u64 sp[TAB_SPANS], first[TAB_SPANS], b[TAB_SPANS];
+#pragma unroll
+  for(u32 s = 0; s < TAB_SPANS; s++)
   {
-    q = qa; sp = ranges[2 * qa]; first = node_off[qa]; b = raw_off[qa];
+    const u64 q = (qo[s] < nq ? qo[s] : nq - 1);                    // (the entry behind the last span names no query)
+    sp[s] = ranges[2 * q]; first[s] = node_off[q]; b[s] = raw_off[q];
   }
-  else
+  u64 entry[TAB_SPANS];
+#pragma unroll
+  for(u32 s = 0; s < TAB_SPANS; s++)
   {
-    const u64 g_end = (g_first + OWNER_SPAN <= total_nodes ? g_first + OWNER_SPAN : total_nodes);
-    q = owner_between(node_off, qa, qb, g_first, g_end, live ? g : g_first);
-    sp = ranges[2 * q]; first = node_off[q]; b = raw_off[q];
+    const u64 g_first = (j0 + s) * OWNER_SPAN, g = g_first + lane;
+    const bool live = (j0 + s < spans && g < total_nodes);
+    if(j0 + s < spans && qo[s] != qo[s + 1])                           // uniform branch: several queries meet in this span
+    {
+      const u64 g_end = (g_first + OWNER_SPAN <= total_nodes ? g_first + OWNER_SPAN : total_nodes);
+      const u64 q = owner_between(node_off, qo[s], qo[s + 1], g_first, g_end, live ? g : g_first);
+      sp[s] = ranges[2 * q]; first[s] = node_off[q]; b[s] = raw_off[q];
+    }
+    entry[s] = (live ? img.locate_tab[sp[s] + (g - first[s])] : LOCATE_DIRECT);
   }
-  const u64 entry = live ? img.locate_tab[sp + (g - first)] : LOCATE_DIRECT;
-  if(live && (entry & LOCATE_DIRECT)) { values[b + (g - first)] = entry & ~LOCATE_DIRECT; }
-  const u64 later = __ballot(live && !(entry & LOCATE_DIRECT));
-  if(lane == 0) { later_words[j] = later; }
+#pragma unroll
+  for(u32 s = 0; s < TAB_SPANS; s++)
+  {
+    const u64 g = (j0 + s) * OWNER_SPAN + lane;
+    const bool live = (j0 + s < spans && g < total_nodes);
+    if(live && (entry[s] & LOCATE_DIRECT)) { values[b[s] + (g - first[s])] = entry[s] & ~LOCATE_DIRECT; }
+    const u64 later = __ballot(live && !(entry[s] & LOCATE_DIRECT));
+    if(lane == 0 && j0 + s < spans) { later_words[j0 + s] = later; }
+  }
 }
 
 // second pass: one lane per word of marks; its path nodes have several values each.  A node with more than COOP_RUN values
