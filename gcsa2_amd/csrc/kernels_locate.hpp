@@ -581,6 +581,8 @@ constexpr u64 take_min_mask(u32 K, u32 J)
   for(u32 l = 0; l < 64; l++) { if(((l & K) == 0) == ((l & J) == 0)) { m |= u64(1) << l; } }
   return m;
 }
+// (`mask` has to be uniform in the compiler's eyes -- a constant, a ballot, scalar64() of something -- or the "s" operand
+// arrives as a vector register pair and the assembler refuses the instruction)
 __device__ __forceinline__ u32 select_by_mask(u32 if_clear, u32 if_set, u64 mask)
 {
   u32 r;
