@@ -1025,7 +1025,9 @@ def roofline(args, r, wl, key, ceiling=None):
     # bytes -- is served partly on-die, and `achieved` / `frac` are ALGORITHMIC rates, not memory-side ones.
     reuse = requests / max(1.0, ws / 128.0)          # (information: requests per distinct line; a 60 GB working set touched twice by
     #                                                    # different queries at random times is still served by HBM)
-    on_die = ws < 8 * CACHE_BYTES or req_rate > limit or achieved > HBM_PEAK_GBS or (traffic is not None and traffic < 0.9 * r["algo_bytes"])
+    # (the ceiling is this box's probe of a few seconds before the index was loaded: 47.1 - 48.6 G/s over the round's boxes and
+    # +-2 % from probe to probe, so a rate within 3 % above it is the ceiling, not evidence of on-die service)
+    on_die = ws < 8 * CACHE_BYTES or req_rate > 1.03 * limit or achieved > HBM_PEAK_GBS or (traffic is not None and traffic < 0.9 * r["algo_bytes"])
     out = {"bound": "hbm", "kernel": "k_find2<pair>" if gpu.pair_block_bytes() else "k_find2",
            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
            "algorithmic_bytes_per_launch": r["algo_bytes"], "kernel_ms": r["kernel_ms"], "working_set_bytes": ws,
@@ -1036,9 +1038,8 @@ def roofline(args, r, wl, key, ceiling=None):
                                    else "far beyond the 256 MiB Infinity Cache, one request per line: served by HBM"))}
     # what bounds a random-gather kernel beyond L2 is requests per second (profiles/r01_gather_bench.md:
     # ~50 G dependent random 128-byte fetches/s at HBM footprints); reported beside the byte roofline
-    out["request_rate"] = {"achieved_G_per_s": req_rate, "ceiling_G_per_s": limit, "requests_per_query": requests / nq}
-    if not on_die:
-        out["request_rate"]["frac_of_ceiling"] = req_rate / limit
+    # (on a partly cached launch the fraction may exceed 1: it is then part of the evidence for the label, not an HBM figure)
+    out["request_rate"] = {"achieved_G_per_s": req_rate, "ceiling_G_per_s": limit, "requests_per_query": requests / nq, "frac_of_ceiling": req_rate / limit}
     if traffic is not None:
         out["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_*_sum pass of this workload; "
                                  "128 B x RDREQ_128B + 64 B x RDREQ_64B + 32 B x RDREQ_32B)")
@@ -1565,8 +1566,7 @@ def find_leg(args, D, dev, leg, steps, expect=None, key="unprofiled"):
            "image_bytes_hbm": leg.gpu.device_bytes()}
     if rf["served"] != "HBM":
         out["frac_is"] = "algorithmic bytes / kernel time / 8 TB/s: the launch is partly served on-die, this is NOT an HBM fraction"
-    else:
-        out["frac_of_request_ceiling"] = rf["request_rate"].get("frac_of_ceiling")
+    out["frac_of_request_ceiling"] = rf["request_rate"].get("frac_of_ceiling")
     for name in ("traffic", "traffic_over_algorithmic", "traffic_GBps", "traffic_frac_of_measured_hbm_rate"):
         if rf.get(name) is not None:
             out[name] = rf[name]
@@ -1673,7 +1673,7 @@ def memory_ladder(args, D, dev, wl, headline):
     last = rungs[-1]
     headline["value_at_reference_footprint"] = {
         "value": last["value"], "unit": "queries/s", "image_GB": round(last["image_bytes_hbm"] / 1e9, 1), "frac": last["frac"],
-        "frac_of_request_ceiling": last.get("frac_of_request_ceiling"), "requests_per_query": last["requests_per_query"],
+        "frac_of_request_ceiling": last.get("frac_of_request_ceiling"), "served": last.get("served"), "requests_per_query": last["requests_per_query"],
         "tables": last["workload"], "note": "the headline batch on the smallest image of the memory ladder (north_star: ~30 GB)"}
     return out
 
