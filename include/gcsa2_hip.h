@@ -279,9 +279,10 @@ int gcsa2_locate_device(const gcsa2_index* index, const uint64_t* d_ranges, uint
                         const uint64_t** d_values, uint64_t* total_values, void* stream);
 /* The same query into caller-owned device buffers (no allocation of results, for pipelines that
  * reuse their buffers): d_offsets has n_queries + 1 entries, d_values room for `capacity` values.
- * *total_values = number of values; if that exceeds capacity nothing is written to d_values and the
- * call fails with GCSA2_ERR_BUFFER_TOO_SMALL (*total_values tells how much is needed).  Complete
- * on return. */
+ * *total_values = number of values; if that exceeds capacity the call fails with
+ * GCSA2_ERR_BUFFER_TOO_SMALL (*total_values tells how much is needed) and nothing has been written
+ * behind d_values + capacity -- the buffer itself may hold a prefix of the result by then: the values
+ * are compacted into it before the host has seen their number.  Complete on return. */
 int gcsa2_locate_into(const gcsa2_index* index, const uint64_t* d_ranges, uint64_t n_queries, int sort,
                       uint64_t* d_offsets, uint64_t* d_values, uint64_t capacity,
                       uint64_t* total_values, void* stream);
