@@ -471,24 +471,34 @@ constexpr u32 HUGE_SPLIT = BIG_SEGMENT / 2;
 // totals of one pass of the locate pipeline (a slot of TOTAL_WORDS u64 in device memory, mirrored to page-locked host memory)
 enum { T_NODES = 0, T_RAW = 1, T_LARGE = 2, T_UNIQUE = 3, T_MULTI = 4, T_MEDIUM = 5, T_HUGE_A = 6, T_OVER = 7, T_HUGE_B = 8, T_OVER_VALUES = 9,
        T_BUCKETS = 10, T_SKEW = 11, T_SKEW_VALUES = 12, T_BIG_BUCKETS = 13,
-       TOTAL_WORDS = 16 };
+       T_DUPS = 14,         // a flag: some sort met a value equal to its left neighbour (round 6: none -> the sorted values are final where they lie)
+       T_CAND = 15,         // ranges listed for the look at their table entries (k_classify_fused)
+       T_MID_BUCKETS = 16,  // buckets of k_over_split with BUCKET_BY_WAVE + 1 .. MEDIUM_SEGMENT values (k_sort_bucket<MEDIUM_SEGMENT>)
+       TOTAL_WORDS = 24 };
 
 __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
                                                        unsigned long long* __restrict__ totals,
                                                        u64* __restrict__ seg_begin, u64* __restrict__ seg_end,
                                                        u64* __restrict__ huge_begin, u64* __restrict__ huge_end, u32 medium_limit,
-                                                       u32 big_limit)
+                                                       u32 big_limit, const u64* __restrict__ ranges, const u64* __restrict__ locate_tab,
+                                                       u64* __restrict__ over_begin, u64* __restrict__ over_end, const u64** __restrict__ over_src)
 {
   __shared__ WgSlots slots;
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
   const u32 lane = threadIdx.x & 63;
   if(q == 0) { totals[T_NODES] = node_off[nq]; totals[T_RAW] = raw_off[nq]; }
   u64 b = 0, e = 0;
-  if(q < nq) { b = raw_off[q]; e = raw_off[q + 1]; }
-  const u64 multi = __ballot(e - b >= 2), large = __ballot(e - b > medium_limit && e - b <= big_limit);
-  const u64 medium = __ballot(e - b > SMALL_SEGMENT && e - b <= medium_limit);
-  const bool is_huge = e - b > medium_limit && e - b > big_limit;
+  bool fused = false;
+  if(q < nq)
+  {
+    b = raw_off[q]; e = raw_off[q + 1];
+    fused = (e > b && node_off[q + 1] == node_off[q]);        // values and no path node to walk: k_classify_fused took the nodes out
+  }
+  const u64 multi = __ballot(e - b >= 2), large = __ballot(!fused && e - b > medium_limit && e - b <= big_limit);
+  const u64 medium = __ballot(!fused && e - b > SMALL_SEGMENT && e - b <= medium_limit);
+  const bool is_huge = !fused && e - b > medium_limit && e - b > big_limit;
   const u64 huge_a = __ballot(is_huge && e - b <= HUGE_SPLIT), huge_b = __ballot(is_huge && e - b > HUGE_SPLIT);
+  const u64 fused_mask = __ballot(fused);
   wg_reserve(slots, totals + T_MULTI, u32(__popcll(multi)));           // (every wave of the workgroup: wg_reserve synchronises it)
   u64 slot = wg_reserve(slots, totals + T_LARGE, u32(__popcll(large)));
   if((large >> lane) & 1)
@@ -514,6 +524,16 @@ __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ n
     slot += __popcll(huge_b & ((u64(1) << lane) - 1));
     huge_begin[nq - 1 - slot] = b; huge_end[nq - 1 - slot] = e;
   }
+  if(__syncthreads_or(fused_mask != 0) == 0) { return; }       // (uniform over the workgroup)
+  slot = wg_reserve(slots, totals + T_OVER, u32(__popcll(fused_mask)));
+  u64 mine = (fused ? e - b : 0);
+  if((fused_mask >> lane) & 1)
+  {
+    slot += __popcll(fused_mask & ((u64(1) << lane) - 1));
+    over_begin[slot] = b; over_end[slot] = e; over_src[slot] = locate_tab + ranges[2 * q];
+  }
+  for(int o = 32; o > 0; o >>= 1) { mine += __shfl_down(mine, o, 64); }
+  if(lane == 0 && mine != 0) { atomicAdd(totals + T_OVER_VALUES, (unsigned long long)mine); }
 }
 
 // The value of lane (l ^ STRIDE), for every lane l.  Strides below 16 stay inside a row of sixteen lanes and go through the
@@ -729,12 +749,35 @@ __device__ __forceinline__ void wave_sort_regs32(u32 (&v)[R], u32 lane)
 // `len` values at src[0, len) sorted into dst[0, len) (dst may be src) by the wavefront, len <= 64 R.  When all of them share
 // their upper 32 bits -- the values of a bucket of k_over_split nearly always do, a query's values when they lie in one 4 G
 // stretch of the node numbers -- the lower halves are sorted as 32-bit keys.
+// Values of a wavefront's sorted registers (element e = 64 r + lane, ascending, the first `len` real) that equal their left
+// neighbour, summed over the wavefront: what removeDuplicates (utils.h:350-357) will drop.  Round 6: the sorts report them, and
+// a batch without any needs no compaction -- its values are sorted in the caller's buffer, at the offsets the size scan gave.
+template<u32 R, class T>
+__device__ __forceinline__ u32 dups_in_regs(const T (&v)[R], u32 len, u32 lane)
+{
+  u32 mine = 0;
+#pragma unroll
+  for(u32 r = 0; r < R; r++)
+  {
+    T left = __shfl_up(v[r], 1, 64);
+    if(r > 0) { const T wrap = __shfl(v[r - 1], 63, 64); left = (lane == 0 ? wrap : left); }
+    const u32 e = r * 64 + lane;
+    mine += u32(e > 0 && e < len && v[r] == left);
+  }
+  for(int o = 32; o > 0; o >>= 1) { mine += __shfl_down(mine, o, 64); }
+  return u32(__builtin_amdgcn_readfirstlane(int(mine)));
+}
+
+// `len` values at src[0, len) sorted into dst[0, len) (dst may be src) by the wavefront, len <= 64 R.  When all of them share
+// their upper 32 bits -- the values of a bucket of k_over_split nearly always do, a query's values when they lie in one 4 G
+// stretch of the node numbers -- the lower halves are sorted as 32-bit keys.  MASK: bits cleared from what is read (the
+// locate table's direct flag, when src is the table itself).  Returns the number of duplicates (dups_in_regs).
 template<u32 R>
-__device__ __forceinline__ void sort_segment_regs(const u64* src, u64* dst, u32 len, u32 lane)
+__device__ __forceinline__ u32 sort_segment_regs(const u64* src, u64* dst, u32 len, u32 lane, u64 keep = ~u64(0))
 {
   u64 v[R];
 #pragma unroll
-  for(u32 r = 0; r < R; r++) { v[r] = (r * 64 + lane < len ? src[r * 64 + lane] : ~u64(0)); }      // padding sorts to the end
+  for(u32 r = 0; r < R; r++) { v[r] = (r * 64 + lane < len ? (src[r * 64 + lane] & keep) : ~u64(0)); }      // padding sorts to the end
   const u32 top = u32(__builtin_amdgcn_readfirstlane(int(u32(v[0] >> 32))));      // (element 0 exists: len >= 1)
   bool differs = false;
 #pragma unroll
@@ -747,19 +790,33 @@ __device__ __forceinline__ void sort_segment_regs(const u64* src, u64* dst, u32 
     wave_sort_regs32<R>(key, lane);
 #pragma unroll
     for(u32 r = 0; r < R; r++) { if(r * 64 + lane < len) { dst[r * 64 + lane] = (u64(top) << 32) | key[r]; } }
-    return;
+    return dups_in_regs<R>(key, len, lane);
   }
   wave_sort_regs<R>(v);
 #pragma unroll
   for(u32 r = 0; r < R; r++) { if(r * 64 + lane < len) { dst[r * 64 + lane] = v[r]; } }
+  return dups_in_regs<R>(v, len, lane);
 }
-__device__ __forceinline__ void sort_segment_by_wave(const u64* src, u64* dst, u32 len, u32 lane)      // len <= MEDIUM_SEGMENT (uniform)
+// (MOST: the longest segment the caller passes, 64 R_max -- the register budget of the kernel follows from it)
+template<u32 MOST = MEDIUM_SEGMENT>
+__device__ __forceinline__ u32 sort_segment_by_wave(const u64* src, u64* dst, u32 len, u32 lane, u64 keep = ~u64(0))      // len <= MOST (uniform)
 {
-  if(len <= 64) { sort_segment_regs<1>(src, dst, len, lane); }
-  else if(len <= 128) { sort_segment_regs<2>(src, dst, len, lane); }
-  else if(len <= 256) { sort_segment_regs<4>(src, dst, len, lane); }
-  else if(len <= 512) { sort_segment_regs<8>(src, dst, len, lane); }
-  else { sort_segment_regs<16>(src, dst, len, lane); }
+  if(len <= 64) { return sort_segment_regs<1>(src, dst, len, lane, keep); }
+  else if(len <= 128) { return sort_segment_regs<2>(src, dst, len, lane, keep); }
+  else if(len <= 256 || MOST <= 256) { return sort_segment_regs<4>(src, dst, len, lane, keep); }
+  else if(len <= 512 || MOST <= 512) { return sort_segment_regs<8>(src, dst, len, lane, keep); }
+  else { return sort_segment_regs<16>(src, dst, len, lane, keep); }
+}
+// totals[T_DUPS] is a FLAG with a count's type: non-zero iff some sort met a duplicate.  A wavefront that has some adds them
+// only while the word still reads zero -- on a variation graph most queries have duplicates, and a hundred thousand
+// wavefronts adding to one address would cost more than the sorts.
+__device__ __forceinline__ void flag_dups(unsigned long long* flag, u32 dups)
+{
+  if(dups != 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { atomicAdd(flag, (unsigned long long)dups); }
+}
+__device__ __forceinline__ void report_dups(unsigned long long* totals, u32 dups, u32 lane)
+{
+  if(lane == 0) { flag_dups(totals + T_DUPS, dups); }
 }
 
 // one wavefront (= one workgroup) per query with SMALL_SEGMENT + 1 .. MEDIUM_SEGMENT values: bitonic sort in registers
@@ -767,13 +824,13 @@ __device__ __forceinline__ void sort_segment_by_wave(const u64* src, u64* dst, u
 // (The grid is an upper bound -- the duplicate filter appends to the list while the host is not looking --; `count` on the
 // device says how many segments there are.)
 __global__ __launch_bounds__(64) void k_sort_medium(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end, u64 last,
-                                                    u64* __restrict__ values, const unsigned long long* __restrict__ count)
+                                                    u64* __restrict__ values, unsigned long long* __restrict__ totals)
 {
   const u32 lane = threadIdx.x;
-  if(blockIdx.x >= *count) { return; }
+  if(blockIdx.x >= totals[T_MEDIUM]) { return; }
   const u64 b = seg_begin[last - blockIdx.x];
   const u32 len = u32(seg_end[last - blockIdx.x] - b);
-  sort_segment_by_wave(values + b, values + b, len, lane);
+  report_dups(totals, sort_segment_by_wave(values + b, values + b, len, lane), lane);
 }
 
 // one workgroup per LARGE segment (list from the start of the segment arrays) with at most BIG_SEGMENT values: bitonic sort
@@ -790,10 +847,12 @@ template<u32 CAPACITY> constexpr int big_threads() { return int(CAPACITY / 16); 
 // its scratch array and land, sorted, in the values array.)
 template<u32 CAPACITY, u32 ABOVE>
 __global__ __launch_bounds__(CAPACITY / 16) void k_sort_big(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end,
-                                                           u64* values, const unsigned long long* __restrict__ count, const u64* source = nullptr,
+                                                           u64* values, const unsigned long long* __restrict__ count, unsigned long long* __restrict__ dup_counter,
+                                                           const u64* source = nullptr,
                                                            u64 from_end = 0)      // from_end != 0: segment s of the list is at [from_end - s]
 {
   __shared__ u64 buf[CAPACITY];
+  __shared__ u64 tails[CAPACITY / 1024];                    // the last value of every wavefront's sorted stretch
   const u32 tid = threadIdx.x, lane = tid & 63;
   const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar for the compiler too: the direction masks below live in scalar pairs)
   if(blockIdx.x >= *count) { return; }                      // the grid is an upper bound (see k_sort_medium)
@@ -839,6 +898,14 @@ __global__ __launch_bounds__(CAPACITY / 16) void k_sort_big(const u64* __restric
   {
 #pragma unroll
     for(u32 r = 0; r < 16; r++) { const u32 e = first + r * 64 + lane; if(e < len) { values[b + e] = v[r]; } }
+    if(lane == 63) { tails[wave] = v[15]; }
+  }
+  __syncthreads();
+  if(active)                                                  // duplicates: inside the wavefront's stretch, and against the stretch before it
+  {
+    u32 dups = dups_in_regs<16>(v, (len > first ? len - first : 0u), lane);
+    if(lane == 0 && wave > 0 && first < len && v[0] == tails[wave - 1]) { dups++; }
+    if(lane == 0) { flag_dups(dup_counter, dups); }
   }
 }
 
@@ -863,7 +930,7 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
                                                             u64* __restrict__ values, u64 nq, u32 medium_limit,
                                                             unsigned long long* __restrict__ totals,
                                                             u64* __restrict__ seg_begin, u64* __restrict__ seg_end,
-                                                            u64* __restrict__ over_begin, u64* __restrict__ over_end)
+                                                            u64* __restrict__ over_begin, u64* __restrict__ over_end, const u64** __restrict__ over_src)
 {
   __shared__ unsigned long long table[HUGE_SLOTS];
   __shared__ u32 distinct, has_ones, placed;
@@ -910,7 +977,7 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
       if(tid == 0)
       {
         const u64 slot = atomicAdd(totals + T_OVER, 1ull);
-        over_begin[slot] = b; over_end[slot] = e;
+        over_begin[slot] = b; over_end[slot] = e; over_src[slot] = nullptr;
         atomicAdd(totals + T_OVER_VALUES, (unsigned long long)len);
       }
       return;
@@ -960,7 +1027,7 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
     if(tid == 0)
     {
       const u64 slot = atomicAdd(totals + T_OVER, 1ull);
-      over_begin[slot] = b; over_end[slot] = e;
+      over_begin[slot] = b; over_end[slot] = e; over_src[slot] = nullptr;
       atomicAdd(totals + T_OVER_VALUES, (unsigned long long)len);
     }
     return;
@@ -981,6 +1048,7 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   unsigned long long top = largest;
   if(has_ones) { if(tid == 0) { values[b + count] = HUGE_EMPTY; } count++; top = HUGE_EMPTY; }
   for(u64 i = count + tid; i < len; i += HUGE_THREADS) { values[b + i] = top; }
+  if(tid == 0 && len > count) { flag_dups(totals + T_DUPS, 1u); }      // (the filled tail repeats `top`)
   if(tid == 0 && count >= 2)
   {
     if(count <= medium_limit && medium_limit > SMALL_SEGMENT)
@@ -997,37 +1065,42 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
 }
 
 // one lane per query with 2..SMALL_SEGMENT values: bitonic network over registers, in place
-__global__ __launch_bounds__(TPB) void k_sort_small(const u64* __restrict__ raw_off, u64 nq, u64* __restrict__ values)
+__global__ __launch_bounds__(TPB) void k_sort_small(const u64* __restrict__ raw_off, u64 nq, u64* __restrict__ values,
+                                                    unsigned long long* __restrict__ totals)
 {
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  const u64 b = raw_off[q], len = raw_off[q + 1] - b;
-  if(len < 2 || len > SMALL_SEGMENT) { return; }
-  u64 v[SMALL_SEGMENT];
-#pragma unroll
-  for(u32 i = 0; i < SMALL_SEGMENT; i++) { v[i] = (i < len ? values[b + i] : ~u64(0)); }
-#pragma unroll
-  for(u32 k = 2; k <= SMALL_SEGMENT; k <<= 1)
+  u64 b = 0, len = 0;
+  if(q < nq) { b = raw_off[q]; len = raw_off[q + 1] - b; }
+  u32 dups = 0;
+  if(len >= 2 && len <= SMALL_SEGMENT)
   {
+    u64 v[SMALL_SEGMENT];
 #pragma unroll
-    for(u32 j = k >> 1; j > 0; j >>= 1)
+    for(u32 i = 0; i < SMALL_SEGMENT; i++) { v[i] = (i < len ? values[b + i] : ~u64(0)); }
+#pragma unroll
+    for(u32 k = 2; k <= SMALL_SEGMENT; k <<= 1)
     {
 #pragma unroll
-      for(u32 i = 0; i < SMALL_SEGMENT; i++)
+      for(u32 j = k >> 1; j > 0; j >>= 1)
       {
-        const u32 l = i ^ j;
-        if(l > i)
+#pragma unroll
+        for(u32 i = 0; i < SMALL_SEGMENT; i++)
         {
-          const bool up = ((i & k) == 0);
-          const u64 lo = (v[i] < v[l] ? v[i] : v[l]), hi = (v[i] < v[l] ? v[l] : v[i]);
-          v[i] = (up ? lo : hi); v[l] = (up ? hi : lo);
+          const u32 l = i ^ j;
+          if(l > i)
+          {
+            const bool up = ((i & k) == 0);
+            const u64 lo = (v[i] < v[l] ? v[i] : v[l]), hi = (v[i] < v[l] ? v[l] : v[i]);
+            v[i] = (up ? lo : hi); v[l] = (up ? hi : lo);
+          }
         }
       }
     }
-  }
-  // padding (all ones) sorts to the end; a real value of all ones is then still within the first len slots
+    // padding (all ones) sorts to the end; a real value of all ones is then still within the first len slots
 #pragma unroll
-  for(u32 i = 0; i < SMALL_SEGMENT; i++) { if(i < len) { values[b + i] = v[i]; } }
+    for(u32 i = 0; i < SMALL_SEGMENT; i++) { if(i < len) { values[b + i] = v[i]; dups += u32(i > 0 && v[i] == v[i - 1]); } }
+  }
+  if(__ballot(dups != 0) != 0) { report_dups(totals, 1u, threadIdx.x & 63); }      // (uniform)
 }
 
 // ---- countKMers frontier expansion (src/algorithms.cpp:364-421) -------------------------------
@@ -1176,22 +1249,72 @@ __global__ __launch_bounds__(TPB) void k_kmer_compare(const DevImage* __restrict
 // ---- locate ------------------------------------------------------------------------------
 
 // per query: number of path nodes to walk and number of values before deduplication
-// (also clears entry nq of both arrays -- the scans turn it into the totals -- and the segment counter)
+// (also clears entry nq of both arrays -- the scans turn it into the totals; the totals slot is cleared by the host)
+// fuse_above != 0 (sorted mode with the locate table): a range of more than fuse_above path nodes, each with ONE value, is listed
+// as a candidate for the split sort that reads the table itself (k_classify_fused decides).
 __global__ __launch_bounds__(TPB) void k_locate_sizes(DevImage img, const u64* __restrict__ ranges, u64 nq,
                                                       u64* __restrict__ node_counts, u64* __restrict__ raw_counts,
-                                                      unsigned long long* __restrict__ totals)
+                                                      unsigned long long* __restrict__ totals, u64 fuse_above, u64* __restrict__ candidates)
 {
+  __shared__ WgSlots slots;
   u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
-  if(q >= nq) { return; }
-  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; for(u32 i = 0; i < TOTAL_WORDS; i++) { totals[i] = 0; } }
-  ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
+  const u32 lane = threadIdx.x & 63;
+  if(q == 0) { node_counts[nq] = 0; raw_counts[nq] = 0; }
   u64 nodes = 0, raw = 0;
-  if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831
+  if(q < nq)
   {
-    nodes = r.y + 1 - r.x;
-    raw = nodes + sada_sparse_count(img, r.x, r.y);         // sum of |values(i)| = sum of (A[i] + 1)
+    ulonglong2 r = reinterpret_cast<const ulonglong2*>(ranges)[q];
+    if(!(range_empty(r.x, r.y) || r.y >= img.n))              // gcsa.cpp:831
+    {
+      nodes = r.y + 1 - r.x;
+      raw = nodes + sada_sparse_count(img, r.x, r.y);         // sum of |values(i)| = sum of (A[i] + 1)
+    }
+    node_counts[q] = nodes; raw_counts[q] = raw;
   }
-  node_counts[q] = nodes; raw_counts[q] = raw;
+  if(fuse_above == 0) { return; }                             // (uniform)
+  const u64 listed = __ballot(nodes > fuse_above && raw == nodes);
+  if(__syncthreads_or(listed != 0) == 0) { return; }          // (no candidate in the workgroup: the common case)
+  u64 slot = wg_reserve(slots, totals + T_CAND, u32(__popcll(listed)));
+  if((listed >> lane) & 1) { candidates[slot + __popcll(listed & ((u64(1) << lane) - 1))] = q; }
+}
+
+// One wavefront per candidate (a stride loop over the list): CLASSIFY_SAMPLE table entries of the range at equal distances,
+// sorted in registers.  All of them direct values and no two equal -> the range almost certainly has more than BIG_SEGMENT
+// distinct values (the argument of k_dedup_huge's sample) and is FUSED: its path nodes are taken out of the table pass
+// (node_counts[q] = 0; its slots in the raw order stay), k_collect_multi lists it for k_over_split with the table as the source,
+// and its values are read once, by the workgroup that splits them -- not written by the table pass and read back (round 5: the
+// 4.4 GB written and 4.5 GB read again on the 16-mer batch of the 2^30-base text).  A wrong guess costs time, never a result:
+// the split sort takes any segment.
+constexpr u32 CLASSIFY_SAMPLE = 256;      // (512: 0.15 ms for the 13 899 candidates of the 16-mer batch on the 2^30-base text -- the sort of the sample)
+__global__ __launch_bounds__(64) void k_classify_fused(DevImage img, const u64* __restrict__ ranges, const u64* __restrict__ candidates,
+                                                       const unsigned long long* __restrict__ totals, u64* __restrict__ node_counts)
+{
+  const u32 lane = threadIdx.x;
+  const u64 count = totals[T_CAND];
+  for(u64 i = blockIdx.x; i < count; i += gridDim.x)          // (uniform)
+  {
+    const u64 q = candidates[i];
+    const u64 sp = ranges[2 * q], nodes = ranges[2 * q + 1] + 1 - sp;
+    const u32 sample = u32(nodes < CLASSIFY_SAMPLE ? nodes : CLASSIFY_SAMPLE);
+    constexpr u32 R = CLASSIFY_SAMPLE / 64;
+    u64 v[R];
+    bool direct = true;
+#pragma unroll
+    for(u32 r = 0; r < R; r++)
+    {
+      const u32 k = r * 64 + lane;
+      v[r] = ~u64(0);
+      if(k < sample)
+      {
+        const u64 entry = img.locate_tab[sp + (u64(k) * nodes) / sample];
+        direct = direct && (entry & LOCATE_DIRECT) != 0;
+        v[r] = entry & ~LOCATE_DIRECT;
+      }
+    }
+    wave_sort_regs<R>(v);
+    const u32 dups = dups_in_regs<R>(v, sample, lane);
+    if(__ballot(!direct) == 0 && dups == 0 && lane == 0) { node_counts[q] = 0; }
+  }
 }
 
 // The whole of locate() for a batch in which EVERY range is one path node with one value that the locate table holds directly
@@ -1265,7 +1388,21 @@ __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __
 // listed for the workgroup sort (k_sort_big reads `scratch`, writes `values`), one of more than `skew_above` values -- values
 // crowded into a small part of the segment's span -- goes on the `skew` list, which the host hands to that radix sort as before.
 constexpr int SPLIT_THREADS = 1024;
-constexpr u32 SPLIT_BUCKETS = 4096;
+constexpr u32 SPLIT_BUCKETS_UNTILED = 4096;
+// Round 6, TILED: the scatter goes through LDS a tile of SPLIT_TILE values at a time.  Untiled, the 64 lanes of a store
+// instruction hit ~50 different buckets: 64 eight-byte write requests where a copy sends a few lines.  The L2 merges them, but
+// it takes REQUESTS at a fixed rate: with the stores switched off the kernel took 1.7 of its 4.4 ms on the 16-mer batch of the
+// 2^30-base text (GCSA2_SPLIT_DEBUG=1; profiles/r06_locate.md).  Tiled, the workgroup counts the tile's values per bucket (the
+// LDS atomics that also rank a value inside its bucket), every wavefront scans the counts for itself (four per lane, one
+// 16-byte read; all write the same offsets, so no barrier), the values are placed bucket by bucket in an LDS buffer and written
+// out in that order: neighbouring lanes hold neighbouring values of one bucket, SPLIT_TILE / buckets of them in a row.  Three
+// barriers per tile; the next tile's values are requested before the current one is worked on.  For segments of at most
+// SPLIT_TILED_BUCKETS buckets (65 536 values at 256 per bucket): the scan is then one 16-byte read per lane.  A longer segment
+// keeps the value-by-value scatter -- tried: 1024 buckets through the tiles with sixteen counts per lane (2.8 -> 3.9 ms on the
+// 16-mer batch: every wavefront reads and writes 8 KB of counts per tile); all segments with at most 256 buckets (the longer
+// buckets of the long segments then cost the workgroup sorts 3.4 ms on the 32-mer batch).
+constexpr u32 SPLIT_TILED_BUCKETS = 256;
+constexpr u32 SPLIT_TILE_PER = 4, SPLIT_TILE = 1024 * SPLIT_TILE_PER;
 constexpr u32 SPLIT_SAMPLE = 8192;             // values whose minimum and maximum stand for the segment's
 constexpr u32 SPLIT_AHEAD = 4;                 // independent loads per lane in the streaming passes
 constexpr u32 SPLIT_RUNS_AHEAD = 3;           // runs of buckets whose values a wavefront has requested ahead of the one it sorts
@@ -1276,20 +1413,39 @@ constexpr u32 SPLIT_CHUNK = 32;                // buckets a wavefront draws at a
 // and nearly every bucket is listed: k_over_split 8.2 -> 4.2 ms, k_sort_bucket 0.4 -> 2.7 ms on the 16-mer batch of the
 // 2^30-base text (flat from 192 to 512; profiles/r05_locate.md).
 constexpr u32 SPLIT_TARGET = 256;
+// The longest bucket one wavefront sorts (k_sort_bucket); a longer one goes to the workgroup sort.  1024 (16 registers of values
+// per lane, 102 VGPRs: four wavefronts per SIMD) until round 6; with 512 the kernel needs half the registers and twice the
+// wavefronts hide its loads.
+constexpr u32 BUCKET_BY_WAVE = 512;
 
-__global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restrict__ over_begin, const u64* __restrict__ over_end,
+// (waves_per_eu: two workgroups per CU, said to the register allocator -- 4.55 -> 4.43 ms and 3.30 -> 3.03 ms on the two batches
+// of the 2^30-base text)
+template<bool TILED>
+__global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_over_split(const u64* __restrict__ over_begin, const u64* __restrict__ over_end,
                                                              u64* values, u64* scratch, u64* __restrict__ bkt_begin, u64* __restrict__ bkt_end,
                                                              u64* __restrict__ skew_begin, u64* __restrict__ skew_end,
-                                                             unsigned long long* __restrict__ totals, u32 skew_above, u32 target, u64 bucket_last)
+                                                             unsigned long long* __restrict__ totals, u32 skew_above, u32 target, u64 bucket_last,
+                                                             const u64* const* __restrict__ over_src, u32 debug,
+                                                             u64* __restrict__ mid_begin, u64* __restrict__ mid_end)
 {
-  __shared__ u32 cursor[SPLIT_BUCKETS];        // histogram, then the buckets' write cursors (= their ends after the scatter)
+  constexpr u32 SPLIT_BUCKETS = SPLIT_BUCKETS_UNTILED;
+  __shared__ __attribute__((aligned(16))) u32 cursor[SPLIT_BUCKETS];        // histogram, then the buckets' write cursors (= their ends after the scatter)
   __shared__ u32 starts[SPLIT_BUCKETS];
   __shared__ u32 wave_sums[SPLIT_THREADS / 64];
-  __shared__ unsigned long long s_lo, s_hi, list_base, big_base, skew_base;
-  __shared__ u32 wg_listed, wg_big, wg_skewed, wg_skew_values, next_chunk;
+  __shared__ unsigned long long s_lo, s_hi, list_base, big_base, skew_base, mid_base;
+  __shared__ u32 wg_listed, wg_big, wg_skewed, wg_skew_values, next_chunk, wg_mid;
+  __shared__ __attribute__((aligned(16))) u32 tile_count[2][TILED ? SPLIT_TILED_BUCKETS : 4];      // values of the tile per bucket (two tiles alternate)
+  __shared__ __attribute__((aligned(16))) u32 tile_off[TILED ? SPLIT_TILED_BUCKETS : 4];           // their exclusive prefix sums
+  __shared__ __attribute__((aligned(16))) u32 tile_delta[TILED ? SPLIT_TILED_BUCKETS : 4];         // where in the segment the bucket's values of this tile go, minus tile_off
+  __shared__ u64 tile_value[TILED ? SPLIT_TILE : 1];                  // the tile, bucket by bucket
+  __shared__ unsigned char tile_bucket[TILED ? SPLIT_TILE : 1];
   constexpr u32 PER_THREAD = SPLIT_BUCKETS / SPLIT_THREADS;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 b = over_begin[blockIdx.x], len = over_end[blockIdx.x] - b;
+  // where the segment's unsorted values are: the raw values the table pass wrote, or -- a FUSED range (k_classify_fused) -- the
+  // entries of the locate table for its path nodes, which lie side by side there (their flag bit is cleared as they are read)
+  const u64* __restrict__ src = (over_src[blockIdx.x] != nullptr ? over_src[blockIdx.x] : values + b);
+  constexpr u64 KEEP = ~LOCATE_DIRECT;                        // (a raw value has the bit clear: k_build_locate_table)
   if(tid == 0) { s_lo = ~0ull; s_hi = 0; }
   for(u32 k = tid; k < SPLIT_BUCKETS; k += SPLIT_THREADS) { cursor[k] = 0; }
   __syncthreads();
@@ -1302,7 +1458,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   {
     u64 got[SPLIT_AHEAD];
 #pragma unroll
-    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? values[b + i] : values[b + tid % len]); }
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? src[i] : src[tid % len]) & KEEP; }
 #pragma unroll
     for(u32 j = 0; j < SPLIT_AHEAD; j++) { lo = (got[j] < lo ? got[j] : lo); hi = (got[j] > hi ? got[j] : hi); }
   }
@@ -1329,9 +1485,9 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   {
     u64 got[SPLIT_AHEAD];
 #pragma unroll
-    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? values[b + i] : lo); }
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? (src[i] & KEEP) : lo); }
 #pragma unroll
-    for(u32 j = 0; j < SPLIT_AHEAD; j++) { if(i0 + u64(j) * SPLIT_THREADS < len) { atomicAdd(&cursor[bucket_of(got[j])], 1u); } }
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { if(i0 + u64(j) * SPLIT_THREADS < len && !(debug & 8)) { atomicAdd(&cursor[bucket_of(got[j])], 1u); } }
   }
   __syncthreads();
   // exclusive prefix sums of the counts: PER_THREAD consecutive buckets per thread, then across the wavefront and the workgroup
@@ -1350,7 +1506,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   // kernel's 14 ms on the clustered segments of the 32-mer batch; profiles/r05_locate.md)
   // (two lists in the same arrays: the buckets one wavefront sorts, k_sort_bucket, from the front; the few beyond MEDIUM_SEGMENT
   // values, k_sort_big, from the back -- as one list, the workgroup sorts launched a million workgroups to find a few hundred)
-  u32 my_listed = 0, my_big = 0, my_skewed = 0, my_skew_values = 0;
+  u32 my_listed = 0, my_big = 0, my_skewed = 0, my_skew_values = 0, my_mid = 0;
 #pragma unroll
   for(u32 k = 0; k < PER_THREAD; k++)
   {
@@ -1359,20 +1515,23 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
     {
       if(mine[k] > skew_above) { my_skewed++; my_skew_values += mine[k]; }
       else if(mine[k] > MEDIUM_SEGMENT) { my_big++; }
+      else if(mine[k] > BUCKET_BY_WAVE) { my_mid++; }
       else { my_listed++; }
     }
   }
-  if(tid == 0) { wg_listed = 0; wg_big = 0; wg_skewed = 0; wg_skew_values = 0; next_chunk = 0; }
+  if(tid == 0) { wg_listed = 0; wg_big = 0; wg_skewed = 0; wg_skew_values = 0; next_chunk = 0; wg_mid = 0; }
   __syncthreads();
-  u32 listed_at = 0, big_at = 0, skewed_at = 0;
+  u32 listed_at = 0, big_at = 0, skewed_at = 0, mid_at = 0;
   if(my_listed > 0) { listed_at = atomicAdd(&wg_listed, my_listed); }
   if(my_big > 0) { big_at = atomicAdd(&wg_big, my_big); }
+  if(my_mid > 0) { mid_at = atomicAdd(&wg_mid, my_mid); }
   if(my_skewed > 0) { skewed_at = atomicAdd(&wg_skewed, my_skewed); atomicAdd(&wg_skew_values, my_skew_values); }
   __syncthreads();
   if(tid == 0)
   {
     list_base = (wg_listed > 0 ? atomicAdd(totals + T_BUCKETS, (unsigned long long)wg_listed) : 0ull);
     big_base = (wg_big > 0 ? atomicAdd(totals + T_BIG_BUCKETS, (unsigned long long)wg_big) : 0ull);
+    mid_base = (wg_mid > 0 ? atomicAdd(totals + T_MID_BUCKETS, (unsigned long long)wg_mid) : 0ull);
     skew_base = (wg_skewed > 0 ? atomicAdd(totals + T_SKEW, (unsigned long long)wg_skewed) : 0ull);
     if(wg_skewed > 0) { atomicAdd(totals + T_SKEW_VALUES, (unsigned long long)wg_skew_values); }
   }
@@ -1386,20 +1545,94 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
       {
         if(mine[k] > skew_above) { const u64 slot = skew_base + skewed_at++; skew_begin[slot] = b + at; skew_end[slot] = b + at + mine[k]; }
         else if(mine[k] > MEDIUM_SEGMENT) { const u64 slot = bucket_last - (big_base + big_at++); bkt_begin[slot] = b + at; bkt_end[slot] = b + at + mine[k]; }
+        else if(mine[k] > BUCKET_BY_WAVE) { const u64 slot = mid_base + mid_at++; mid_begin[slot] = b + at; mid_end[slot] = b + at + mine[k]; }
         else { const u64 slot = list_base + listed_at++; bkt_begin[slot] = b + at; bkt_end[slot] = b + at + mine[k]; }
       }
       at += mine[k];
     }
   }
-  for(u64 i0 = tid; i0 < len; i0 += SPLIT_AHEAD * SPLIT_THREADS)
+  if(TILED && nb <= SPLIT_TILED_BUCKETS)                      // (uniform)
+  {
+    static_assert(SPLIT_TILED_BUCKETS == 256 && SPLIT_THREADS == 1024, "four counts per lane; bucket numbers in a byte");
+    if(tid < SPLIT_TILED_BUCKETS) { tile_count[0][tid] = 0; tile_count[1][tid] = 0; }
+    __syncthreads();
+    u64 next[SPLIT_TILE_PER];
+#pragma unroll
+    for(u32 j = 0; j < SPLIT_TILE_PER; j++) { const u64 i = u64(j) * SPLIT_THREADS + tid; next[j] = (i < len ? src[i] : 0); }
+    u32 which = 0;
+    for(u64 t0 = 0; t0 < len && !(debug & 4); t0 += SPLIT_TILE, which ^= 1u)
+    {
+      u32* __restrict__ count = tile_count[which];
+      u64 got[SPLIT_TILE_PER];
+      u32 bkt[SPLIT_TILE_PER], rank[SPLIT_TILE_PER];
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_TILE_PER; j++) { got[j] = next[j] & KEEP; }
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_TILE_PER; j++)                  // the next tile's values travel while this one is worked on
+      {
+        const u64 i = t0 + SPLIT_TILE + u64(j) * SPLIT_THREADS + tid;
+        next[j] = (i < len ? src[i] : 0);
+      }
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_TILE_PER; j++)
+      {
+        bkt[j] = bucket_of(got[j]); rank[j] = 0;
+        if(t0 + u64(j) * SPLIT_THREADS + tid < len) { rank[j] = atomicAdd(&count[bkt[j]], 1u); }
+      }
+      __syncthreads();
+      {
+        // every wavefront scans the 256 counts for itself: lane l has buckets 4 l .. 4 l + 3; wavefront 0 also says where the
+        // buckets' values of this tile go (tile_delta)
+        const uint4 c = *reinterpret_cast<const uint4*>(&count[lane * 4]);
+        const u32 sum = c.x + c.y + c.z + c.w;
+        u32 incl = sum;
+        for(int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(incl, o, 64); if(lane >= u32(o)) { incl += up; } }
+        const u32 at = incl - sum;
+        const uint4 off = make_uint4(at, at + c.x, at + c.x + c.y, at + c.x + c.y + c.z);
+        *reinterpret_cast<uint4*>(&tile_off[lane * 4]) = off;
+        if(wave == 0)
+        {
+          const uint4 cur = *reinterpret_cast<const uint4*>(&cursor[lane * 4]);
+          *reinterpret_cast<uint4*>(&tile_delta[lane * 4]) = make_uint4(cur.x - off.x, cur.y - off.y, cur.z - off.z, cur.w - off.w);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_TILE_PER; j++)
+      {
+        if(t0 + u64(j) * SPLIT_THREADS + tid < len)
+        {
+          const u32 at = tile_off[bkt[j]] + rank[j];
+          tile_value[at] = got[j]; tile_bucket[at] = (unsigned char)bkt[j];
+        }
+      }
+      __syncthreads();
+      const u32 here = u32(len - t0 < SPLIT_TILE ? len - t0 : SPLIT_TILE);
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_TILE_PER; j++)
+      {
+        const u32 at = j * SPLIT_THREADS + tid;
+        if(at < here && !(debug & 1)) { scratch[b + u32(tile_delta[tile_bucket[at]] + at)] = tile_value[at]; }
+      }
+      __syncthreads();
+      // the owners move the buckets' cursors on and clear this tile's counts (the next tile counts in the other array)
+      if(tid < SPLIT_TILED_BUCKETS) { cursor[tid] += count[tid]; count[tid] = 0; }
+    }
+  }
+  else
+  for(u64 i0 = tid; i0 < len && !(debug & 4); i0 += SPLIT_AHEAD * SPLIT_THREADS)
   {
     u64 got[SPLIT_AHEAD];
 #pragma unroll
-    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? values[b + i] : lo); }
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? (src[i] & KEEP) : lo); }
 #pragma unroll
     for(u32 j = 0; j < SPLIT_AHEAD; j++)
     {
-      if(i0 + u64(j) * SPLIT_THREADS < len) { scratch[b + atomicAdd(&cursor[bucket_of(got[j])], 1u)] = got[j]; }
+      if(i0 + u64(j) * SPLIT_THREADS < len)
+      {
+        const u32 at = atomicAdd(&cursor[bucket_of(got[j])], 1u);
+        if(!(debug & 1)) { scratch[b + at] = got[j]; }
+      }
     }
   }
   __syncthreads();                                             // (the workgroup's stores have completed: s_waitcnt vmcnt(0) + barrier)
@@ -1453,9 +1686,10 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
   for(u32 d = 0; d < SPLIT_RUNS_AHEAD; d++)
   {
     run_first[d] = 0; run_count[d] = 0; run_base[d] = NO_BASE;
-    live[d] = next_run(run_first[d], run_count[d], run_base[d]);
+    live[d] = !(debug & 2) && next_run(run_first[d], run_count[d], run_base[d]);
     run_value[d] = (live[d] && lane < run_count[d] ? scratch[b + run_first[d] + lane] : ~u64(0));
   }
+  u32 run_dups = 0;
   while(live[0])
   {
     u64 v = run_value[0];
@@ -1467,6 +1701,8 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
         v = run_base[0] + key;
       }
       else { v = wave_sort(v, lane); }
+      const u64 left = __shfl_up(v, 1, 64);
+      run_dups += u32(__popcll(__ballot(lane > 0 && lane < run_count[0] && v == left)));      // (runs are whole buckets: no value spans two)
     }
     if(lane < run_count[0]) { values[b + run_first[0] + lane] = v; }
 #pragma unroll
@@ -1478,20 +1714,25 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_over_split(const u64* __restr
     live[last] = live[last - 1] && next_run(run_first[last], run_count[last], run_base[last]);
     run_value[last] = (live[last] && lane < run_count[last] ? scratch[b + run_first[last] + lane] : ~u64(0));
   }
+  report_dups(totals, run_dups, lane);
 }
 
 // one wavefront (= one workgroup) per listed bucket of up to MEDIUM_SEGMENT values: bitonic sort in registers, read from
 // `source`, written to `values` (k_sort_medium's network; the list is k_over_split's: buckets of 65 .. skew_above values, the
 // longer ones are left to k_sort_big)
+// (MOST = BUCKET_BY_WAVE: the list of the buckets up to 512 values, 57 VGPRs; MOST = MEDIUM_SEGMENT: the list of the ones from 513
+// to 1024 values -- sixteen registers of values per lane, 102 VGPRs -- which went to the workgroup sort for a while in round 6:
+// 0.6 ms against 0.2 on the 16-mer batch of the 2^30-base text)
+template<u32 MOST>
 __global__ __launch_bounds__(64) void k_sort_bucket(const u64* __restrict__ bkt_begin, const u64* __restrict__ bkt_end, u64* values,
-                                                    const u64* __restrict__ source, const unsigned long long* __restrict__ count)
+                                                    const u64* __restrict__ source, unsigned long long* __restrict__ totals)
 {
-  if(blockIdx.x >= *count) { return; }
+  if(blockIdx.x >= totals[MOST == BUCKET_BY_WAVE ? T_BUCKETS : T_MID_BUCKETS]) { return; }
   const u32 lane = threadIdx.x;
   const u64 b = bkt_begin[blockIdx.x];
   const u32 len = u32(bkt_end[blockIdx.x] - b);
-  if(len > MEDIUM_SEGMENT) { return; }                        // k_sort_big's
-  sort_segment_by_wave(source + b, values + b, len, lane);
+  if(len > MOST) { return; }                                  // (cannot be: k_over_split fills the lists by length)
+  report_dups(totals, sort_segment_by_wave<MOST>(source + b, values + b, len, lane), lane);
 }
 
 // Segments with more than BIG_SEGMENT distinct values whose split left a bucket too large (k_over_split's skew list), and every
@@ -1621,6 +1862,8 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_mark_compact(const u64* __r
                                                                   unsigned long long* __restrict__ status, unsigned int* __restrict__ ticket,
                                                                   unsigned long long* __restrict__ unique_out)
 {
+  // IN PLACE (out == sorted, round 6) is safe: a tile writes in front of its own first value, and only once every tile before
+  // it has published a count -- which a tile does after ALL its loads have arrived in registers, as this one's have by then.
   constexpr u32 WAVES = COMPACT_THREADS / 64, WORDS = COMPACT_ROWS * WAVES;       // words of the bitmap per tile
   static_assert(WORDS % 64 == 0 && WORDS <= 128, "the scan of the word counts below takes one or two entries per lane");
   __shared__ u32 counts[WORDS];

@@ -282,7 +282,11 @@ int gcsa2_locate_device(const gcsa2_index* index, const uint64_t* d_ranges, uint
  * *total_values = number of values; if that exceeds capacity the call fails with
  * GCSA2_ERR_BUFFER_TOO_SMALL (*total_values tells how much is needed) and nothing has been written
  * behind d_values + capacity -- the buffer itself may hold a prefix of the result by then: the values
- * are compacted into it before the host has seen their number.  Complete on return. */
+ * are compacted into it before the host has seen their number.  On success d_values[0, *total_values)
+ * is the result; what lies between *total_values and capacity is unspecified: a buffer with room for
+ * the values BEFORE deduplication (sum of the ranges' value counts, >= *total_values) is used as the
+ * sorts' work space and compacted in place, and when no range repeats a value -- a text index -- nothing
+ * is compacted at all.  Complete on return. */
 int gcsa2_locate_into(const gcsa2_index* index, const uint64_t* d_ranges, uint64_t n_queries, int sort,
                       uint64_t* d_offsets, uint64_t* d_values, uint64_t capacity,
                       uint64_t* total_values, void* stream);

@@ -67,9 +67,8 @@ def derive_suffix_tree(keys, lcp, ranges):
             "parent": parents, "depth": depth, "rmq": rmq}
 
 
-def main():
-    with open(PATH) as f:
-        gold = json.load(f)
+def suffix_tree_of(gold):
+    """The "suffix_tree" section for the example object `gold` (its keys and find() ranges); make_paper_example.py calls this."""
     keys = [node["key"] for node in gold["nodes"]]
     n = len(keys)
     order = gold["comp_order"]
@@ -78,8 +77,16 @@ def main():
     ranges = [(i, i) for i in range(n)] + [tuple(q["range"]) for q in gold["find"] if q["range"][0] <= q["range"][1]]
     ranges += [(2, 4), (2, 3), (9, 12), (10, 11), (13, 15), (14, 15), (1, 4), (5, 6), (7, 8), (0, n - 1), (0, 4), (9, 15)]
     st = derive_suffix_tree(keys, lcp, ranges)
-    gold["suffix_tree"] = {"_source": "derived from the keys above by tests/golden/make_paper_lcp.py (definitions only; see its docstring)"}
-    gold["suffix_tree"].update(st)
+    section = {"_source": "derived from the keys above by tests/golden/make_paper_lcp.py (definitions only; see its docstring)"}
+    section.update(st)
+    return section
+
+
+def main():
+    with open(PATH) as f:
+        gold = json.load(f)
+    gold["suffix_tree"] = suffix_tree_of(gold)
+    st, lcp = gold["suffix_tree"], gold["suffix_tree"]["lcp"]
     text = json.dumps(gold, indent=2)
     with open(PATH, "w") as f:
         f.write(text + "\n")

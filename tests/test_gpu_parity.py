@@ -795,16 +795,23 @@ def test_locate_into_caller_buffers(engine):
             parts = [cpu.locate((int(a), int(b)), sort=False) for a, b in ranges]
             co = np.concatenate([[0], np.cumsum([len(x) for x in parts])]).astype(np.uint64)
             cv = np.concatenate(parts)
-        d_o = torch.full((len(ranges) + 1,), -1, dtype=torch.int64, device=dev)
-        d_v = torch.full((len(cv) + 5,), -1, dtype=torch.int64, device=dev)
-        total = gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), d_v.shape[0], sort=sort)
-        assert total == len(cv)
-        assert np.array_equal(d_o.cpu().numpy().view(np.uint64), co)
-        assert np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], cv)
-        assert (d_v[total:] == -1).all()
+        raw = sum(len(cpu.locate((int(a), int(b)), sort=False)) for a, b in ranges)       # values before removeDuplicates
+        assert raw > len(cv) + 5 or not sort, "the case has duplicates to remove"
+        # capacities: the distinct values and a few more (the pipeline sorts in scratch and compacts into the buffer), and room
+        # for the values BEFORE deduplication (round 6: the buffer is then the sorts' target and is compacted in place); what
+        # lies between the total and the capacity is unspecified, nothing is written behind the capacity
+        for capacity in (len(cv) + 5, raw + 3):
+            d_o = torch.full((len(ranges) + 1,), -1, dtype=torch.int64, device=dev)
+            d_v = torch.full((capacity + 64,), -1, dtype=torch.int64, device=dev)
+            total = gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), capacity, sort=sort)
+            assert total == len(cv)
+            assert np.array_equal(d_o.cpu().numpy().view(np.uint64), co)
+            assert np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], cv)
+            assert (d_v[capacity:] == -1).all()
+        d_v.fill_(-1)
         with pytest.raises(engine.Gcsa2Error) as e:
             gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), len(cv) - 1, sort=sort)
-        assert e.value.code == -6 and e.value.needed == len(cv)
+        assert e.value.code == -6 and e.value.needed == len(cv) and (d_v[len(cv) - 1:] == -1).all()
     assert gpu.locate_into(d_r.data_ptr(), 0, d_o.data_ptr(), 0, 0) == 0 and int(d_o[0]) == 0
 
 
@@ -847,10 +854,10 @@ def test_locate_batches_of_one_value_ranges(engine, single, monkeypatch):
             else:
                 wo, wv = co, cv
             d_o = torch.full((len(ranges) + 1,), -1, dtype=torch.int64, device=dev)
-            d_v = torch.full((len(wv) + 5,), -1, dtype=torch.int64, device=dev)
-            total = gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), d_v.shape[0], sort=sort)
+            d_v = torch.full((len(wv) + 5 + 64,), -1, dtype=torch.int64, device=dev)
+            total = gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), len(wv) + 5, sort=sort)
             assert total == len(wv) and np.array_equal(d_o.cpu().numpy().view(np.uint64), wo), (tag, sort)
-            assert np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], wv) and (d_v[total:] == -1).all(), (tag, sort)
+            assert np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], wv) and (d_v[len(wv) + 5:] == -1).all(), (tag, sort)
             with pytest.raises(engine.Gcsa2Error) as e:
                 gpu.locate_into(d_r.data_ptr(), len(ranges), d_o.data_ptr(), d_v.data_ptr(), len(wv) - 1, sort=sort)
             assert e.value.code == -6 and e.value.needed == len(wv), (tag, sort)
@@ -1489,10 +1496,13 @@ def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
 
 @pytest.mark.parametrize("knobs", [{}, {"GCSA2_SPLIT_TARGET": "24"}, {"GCSA2_SPLIT_TARGET": "1500", "GCSA2_SPLIT_SKEW": "700"}, {"GCSA2_SPLIT_SKEW": "16"},
                                    {"GCSA2_LOCATE_SPLIT_SORT": "0"}, {"GCSA2_LOCATE_FUSED_COMPACT": "0"}, {"values": "across 2^32"}, {"values": "across 2^32", "GCSA2_SPLIT_TARGET": "24"},
-                                   {"values": "across 2^32", "GCSA2_SPLIT_TARGET": "1500", "GCSA2_SPLIT_SKEW": "3000"}],
+                                   {"values": "across 2^32", "GCSA2_SPLIT_TARGET": "1500", "GCSA2_SPLIT_SKEW": "3000"},
+                                   {"GCSA2_LOCATE_FUSE": "0"}, {"GCSA2_LOCATE_IN_PLACE": "0"}, {"GCSA2_LOCATE_FUSE_ABOVE": "600"},
+                                   {"GCSA2_LOCATE_FUSE_ABOVE": "2", "GCSA2_SPLIT_TARGET": "24"}, {"values": "across 2^32", "GCSA2_LOCATE_FUSE_ABOVE": "600", "GCSA2_SPLIT_SKEW": "16"}],
                          ids=["split-with-listed-buckets", "split-with-runs", "split-with-listed-and-skewed-buckets", "split-with-skewed-buckets", "radix-sort",
                               "four-kernel-compaction",
-                              "64-bit-keys", "64-bit-keys-runs", "64-bit-keys-large-buckets"])
+                              "64-bit-keys", "64-bit-keys-runs", "64-bit-keys-large-buckets",
+                              "table-pass-for-every-range", "sorts-in-scratch", "fused-from-600-nodes", "fused-from-3-nodes-runs", "fused-64-bit-keys-skewed"])
 def test_locate_many_large_distinct_segments(engine, knobs, monkeypatch):
     """Ranges of thousands of path nodes whose values are all DISTINCT (a linear text: one value per path node), as found
     16-mers of interspersed repeats have on the 2^30-base text of bench.py: dozens of segments beyond the 8192 distinct values
@@ -1503,7 +1513,10 @@ def test_locate_many_large_distinct_segments(engine, knobs, monkeypatch):
     split) / ~256 (the default: listed for the register sorts) / ~1500 values and call more than 700 / 16 values too large, so
     that every branch runs, with node_type values below 2^32 and on both sides of it (32- and 64-bit sort keys); through the job interface
     (the value buffer is made once the total is known) and into caller-owned buffers (no wait for the total; a buffer that is
-    too small is refused with the size needed and nothing is written behind its end)."""
+    too small is refused with the size needed and nothing is written behind its end).  Round 6: these ranges are FUSED -- their
+    values never pass through the table pass, the split reads the locate table (GCSA2_LOCATE_FUSE=0: as before; the threshold of
+    8192 path nodes lowered so that ranges of 700 / 3 nodes take that path too) -- and the caller's buffer is the sorts' target
+    (GCSA2_LOCATE_IN_PLACE=0: scratch + compaction)."""
     import torch
     from oracle.oracle import OracleIndex
     from workload import builder
@@ -1542,7 +1555,7 @@ def test_locate_many_large_distinct_segments(engine, knobs, monkeypatch):
     for _ in range(3):                                         # the scratch pool and the result slots are reused
         total = gpu.locate_into(d_r.data_ptr(), len(arr), d_o.data_ptr(), d_v.data_ptr(), d_v.shape[0])
         assert total == len(cv) and np.array_equal(d_o.cpu().numpy().view(np.uint64), co)
-        assert np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], cv) and (d_v[total:] == -1).all()
+        assert np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], cv) and (d_v[total:] == -1).all()       # (no duplicates: raw == distinct)
     d_v.fill_(-1)
     with pytest.raises(engine.Gcsa2Error) as e:
         gpu.locate_into(d_r.data_ptr(), len(arr), d_o.data_ptr(), d_v.data_ptr(), len(cv) // 2)
