@@ -9,7 +9,7 @@ shift
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 CMD="python $ROOT/bench.py $* --locate --steps 2 --warmup 1 --no-cpu --no-secondary --no-extras --full-json /tmp/pmc_locate_full.json"
-ONLY="--kernel-include-regex k_locate_|k_over_|k_sort_|k_compact|k_mark_|k_dedup_huge|k_collect_multi|k_block_owners|k_word_counts|k_final_offsets|k_huge_to_over"
+ONLY="--kernel-include-regex k_locate_|k_over_|k_sort_|k_compact|k_mark_|k_dedup_huge|k_collect_multi|k_block_owners|k_word_counts|k_final_offsets|k_huge_to_over|k_classify_fused"
 timeout ${PASS_TIMEOUT:-600} rocprofv3 $ONLY --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum \
     --output-format csv -d $ROOT/gpurun_out/${TAG}_locate_rdreq -o x -- $CMD > $ROOT/gpurun_out/${TAG}_locate_rdreq.log 2>&1
 timeout ${PASS_TIMEOUT:-600} rocprofv3 $ONLY --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum \
