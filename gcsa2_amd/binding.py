@@ -38,7 +38,7 @@ EXPORTS = [
     "gcsa2_group_find_batch", "gcsa2_group_find_device", "gcsa2_group_uses_rccl",
     "gcsa2_group_match_stats_device", "gcsa2_group_locate_device", "gcsa2_comm_match_stats", "gcsa2_comm_locate",
     "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_create_custom", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_rccl_ranks", "gcsa2_comm_gather",
-    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_pack_ranges40_device", "gcsa2_unpack_ranges40_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device", "gcsa2_match_breaks_device", "gcsa2_match_breaks_batch",
+    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_pack_ranges40_device", "gcsa2_unpack_ranges40_device", "gcsa2_wire48_bytes", "gcsa2_pack_ranges48_device", "gcsa2_unpack_ranges48_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device", "gcsa2_match_breaks_device", "gcsa2_match_breaks_batch",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
     "gcsa2_host_view_parse_gcsa", "gcsa2_host_view_parse_lcp", "gcsa2_host_view_serialize_gcsa", "gcsa2_host_view_serialize_lcp",
@@ -172,6 +172,10 @@ def load_library():
     L.gcsa2_unpack_ranges32_device.argtypes = [vp, u64, vp, vp]
     L.gcsa2_pack_ranges40_device.argtypes = [vp, u64, vp, vp]
     L.gcsa2_unpack_ranges40_device.argtypes = [vp, u64, vp, vp]
+    L.gcsa2_wire48_bytes.argtypes = [u64, u64]
+    L.gcsa2_wire48_bytes.restype = u64
+    L.gcsa2_pack_ranges48_device.argtypes = [vp, u64, vp, u64, vp]
+    L.gcsa2_unpack_ranges48_device.argtypes = [vp, u64, u64, vp, vp, vp]
     _lib = L
     return L
 
@@ -868,6 +872,19 @@ def pack_ranges40_device(d_ranges, nq, d_packed, stream=0):
 
 def unpack_ranges40_device(d_packed, nq, d_ranges, stream=0):
     _check(load_library().gcsa2_unpack_ranges40_device(d_packed, nq, d_ranges, stream))
+
+
+def wire48_bytes(nq, capacity):
+    """Size of a shard's block in the six-byte wire format: nq ranges and an overflow list of `capacity` entries."""
+    return int(load_library().gcsa2_wire48_bytes(nq, capacity))
+
+
+def pack_ranges48_device(d_ranges, nq, d_packed, capacity, stream=0):
+    _check(load_library().gcsa2_pack_ranges48_device(d_ranges, nq, d_packed, capacity, stream))
+
+
+def unpack_ranges48_device(d_packed, nq, capacity, d_ranges, d_overflow_count=0, stream=0):
+    _check(load_library().gcsa2_unpack_ranges48_device(d_packed, nq, capacity, d_ranges, d_overflow_count, stream))
 
 
 class GCSAGroup:

@@ -114,6 +114,68 @@ __global__ __launch_bounds__(TPB) void k_unpack_ranges40(const unsigned short* _
   reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, sp + len - 1);
 }
 
+// Six bytes per range for the common case (round 6): sp in 40 bits and the length ep + 1 - sp in ONE byte -- 0 .. 254 as it is,
+// 255 = "in the overflow list" -- followed, behind the shard's ranges, by a count and a list of (query, length) pairs for the
+// ranges of 255 and more path nodes.  The list has a fixed capacity, so a shard's block has a size every rank knows before
+// anything is searched (gcsa2_wire48_bytes): the gather stays one grouped send / recv of fixed sizes.  A 32-mer batch on a
+// whole-genome index is nearly all lengths 0 and 1: 75 MB per peer and step at N = 8 instead of the 125 MB of the 40-bit pairs.
+// A batch with more long ranges than the list holds is REPORTED (the count behind the ranges exceeds the capacity), never
+// truncated silently: the caller falls back to the 40-bit pairs.
+// block: [6 n bytes, padded to 16] [u64 count, u64 0] [capacity x (u64 query, u64 length)]
+__host__ __device__ inline u64 wire48_list_offset(u64 nq) { return (6 * nq + 15) & ~u64(15); }
+
+__global__ __launch_bounds__(TPB) void k_pack_ranges48(const u64* __restrict__ in, u64 nq, unsigned char* __restrict__ out, u64 capacity)
+{
+  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  const u32 lane = threadIdx.x & 63;
+  bool longer = false;
+  u64 len = 0;
+  if(q < nq)
+  {
+    const ulonglong2 r = reinterpret_cast<const ulonglong2*>(in)[q];
+    const u64 sp = r.x;
+    len = r.y + 1 - r.x;
+    longer = (len >= 255);
+    unsigned short* o = reinterpret_cast<unsigned short*>(out + 6 * q);
+    o[0] = (unsigned short)sp; o[1] = (unsigned short)(sp >> 16);
+    o[2] = (unsigned short)(((sp >> 32) & 0xFF) | ((longer ? u64(255) : len) << 8));
+  }
+  const u64 mask = __ballot(longer);
+  if(mask == 0) { return; }                                   // (uniform)
+  unsigned long long* list = reinterpret_cast<unsigned long long*>(out + wire48_list_offset(nq));
+  unsigned long long base = 0;
+  const u32 leader = u32(__ffsll((long long)mask)) - 1;
+  if(lane == leader) { base = atomicAdd(list, (unsigned long long)__popcll(mask)); }
+  base = __shfl(base, leader, 64);
+  if(longer)
+  {
+    const u64 slot = base + __popcll(mask & ((u64(1) << lane) - 1));
+    if(slot < capacity) { list[2 + 2 * slot] = q; list[3 + 2 * slot] = len; }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_unpack_ranges48(const unsigned char* __restrict__ in, u64 nq, u64* __restrict__ out)
+{
+  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  const unsigned short* o = reinterpret_cast<const unsigned short*>(in + 6 * q);
+  const u64 sp = u64(o[0]) | (u64(o[1]) << 16) | (u64(o[2] & 0xFF) << 32);
+  const u64 len = u64(o[2] >> 8);                              // (255: the overflow pass writes the upper end)
+  reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, sp + len - 1);
+}
+
+// the ranges of the overflow list: the length is there, the lower end is what k_unpack_ranges48 wrote (stream order)
+__global__ __launch_bounds__(TPB) void k_unpack_overflow48(const unsigned char* __restrict__ in, u64 nq, u64 capacity, u64* __restrict__ out,
+                                                           u64* __restrict__ count_out)
+{
+  const unsigned long long* list = reinterpret_cast<const unsigned long long*>(in + wire48_list_offset(nq));
+  const u64 count = list[0], i = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(i == 0 && count_out != nullptr) { *count_out = count; }
+  if(i >= count || i >= capacity) { return; }
+  const u64 q = list[2 + 2 * i], len = list[3 + 2 * i];
+  if(q < nq) { out[2 * q + 1] = out[2 * q] + len - 1; }
+}
+
 }  // namespace
 
 // One rank of the query path's communicator: an RCCL communicator (gcsa2_comm_create), or the application's own transport
@@ -274,6 +336,33 @@ int gcsa2_unpack_ranges40_device(const void* d_packed, uint64_t nq, uint64_t* d_
   if(nq == 0) { return GCSA2_OK; }
   hipLaunchKernelGGL(k_unpack_ranges40, dim3(grid_for(nq)), dim3(TPB), 0, static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(d_packed), nq, d_ranges);
   LAUNCH_CHECK("k_unpack_ranges40");
+  return GCSA2_OK;
+}
+
+uint64_t gcsa2_wire48_bytes(uint64_t nq, uint64_t capacity) { return wire48_list_offset(nq) + 16 + 16 * capacity; }
+
+int gcsa2_pack_ranges48_device(const uint64_t* d_ranges, uint64_t nq, void* d_packed, uint64_t capacity, void* stream)
+{
+  if(d_packed == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(d_packed) + wire48_list_offset(nq), 0, 16, st));     // the list's count
+  if(nq == 0) { return GCSA2_OK; }
+  hipLaunchKernelGGL(k_pack_ranges48, dim3(grid_for(nq)), dim3(TPB), 0, st, d_ranges, nq, static_cast<unsigned char*>(d_packed), capacity);
+  LAUNCH_CHECK("k_pack_ranges48");
+  return GCSA2_OK;
+}
+
+int gcsa2_unpack_ranges48_device(const void* d_packed, uint64_t nq, uint64_t capacity, uint64_t* d_ranges, uint64_t* d_overflow_count, void* stream)
+{
+  if(d_packed == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null buffer"); }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if(nq > 0)
+  {
+    hipLaunchKernelGGL(k_unpack_ranges48, dim3(grid_for(nq)), dim3(TPB), 0, st, static_cast<const unsigned char*>(d_packed), nq, d_ranges);
+    LAUNCH_CHECK("k_unpack_ranges48");
+  }
+  hipLaunchKernelGGL(k_unpack_overflow48, dim3(grid_for(capacity > 0 ? capacity : 1)), dim3(TPB), 0, st, static_cast<const unsigned char*>(d_packed), nq, capacity, d_ranges, d_overflow_count);
+  LAUNCH_CHECK("k_unpack_overflow48");
   return GCSA2_OK;
 }
 

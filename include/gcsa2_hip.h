@@ -556,6 +556,16 @@ int gcsa2_unpack_ranges32_device(const uint32_t* d_packed, uint64_t n_queries, u
  * range (sp and length, 40 bits each) instead of 16; d_packed holds 10 * n_queries bytes, 2-byte aligned. */
 int gcsa2_pack_ranges40_device(const uint64_t* d_ranges, uint64_t n_queries, void* d_packed, void* stream);
 int gcsa2_unpack_ranges40_device(const void* d_packed, uint64_t n_queries, uint64_t* d_ranges, void* stream);
+/* Six bytes per range for the common case (same indexes): sp in 40 bits, the length in one byte, and behind the shard's ranges
+ * a list of (query, length) pairs, `capacity` of them at most, for the ranges of 255 and more path nodes.  A shard's block has
+ * gcsa2_wire48_bytes(n_queries, capacity) bytes whatever the ranges are -- the gather (src/algorithms.cpp:106-114 is the static
+ * split it serves) keeps fixed sizes --, 16-byte aligned.  *d_overflow_count (optional, device memory) receives the number of
+ * long ranges the shard had: a value beyond `capacity` means the block does not hold the batch (the ranges that did not fit
+ * come out 255 path nodes long) and the caller must use the 40-bit pairs; nothing is truncated silently. */
+uint64_t gcsa2_wire48_bytes(uint64_t n_queries, uint64_t capacity);
+int gcsa2_pack_ranges48_device(const uint64_t* d_ranges, uint64_t n_queries, void* d_packed, uint64_t capacity, void* stream);
+int gcsa2_unpack_ranges48_device(const void* d_packed, uint64_t n_queries, uint64_t capacity, uint64_t* d_ranges,
+                                 uint64_t* d_overflow_count, void* stream);
 
 #ifdef __cplusplus
 }

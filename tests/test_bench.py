@@ -111,21 +111,28 @@ def test_distributed_path_world_size_1(no_comm):
              "--warmup", "1", "--no-cpu", "--secondary", "config5"], env={"GCSA2_BENCH_NO_COMM": no_comm})
     check_line(d, 1, 3)
     assert ("gcsa2_comm_gather" in d["config"]["parallelism"]) == (no_comm == "")
-    assert "u32 pairs" in d["config"]["parallelism"]
+    assert "6 bytes" in d["config"]["parallelism"]
 
 
-@pytest.mark.parametrize("wire", ["", "40", "64"], ids=["u32-pairs", "40-bit-pairs", "u64-pairs"])
+@pytest.mark.parametrize("wire", ["", "32", "40", "64"], ids=["six-bytes", "u32-pairs", "40-bit-pairs", "u64-pairs"])
 def test_two_ranks_share_the_gpu_through_the_host(wire):
-    """(the wire format of the gathered ranges follows the index size: u32 pairs below 2^32, 40-bit pairs below 2^40 -- the
-    headline index --, u64 pairs beyond; GCSA2_BENCH_WIRE forces the wider ones on this small index)"""
+    """(the wire format of the gathered ranges: six bytes per range -- 40-bit sp, a length byte, a list for the long ranges -- below
+    2^40 path nodes, u64 pairs beyond; GCSA2_BENCH_WIRE forces the u32 pairs, the 40-bit pairs (the fallback when a batch has more
+    long ranges than the list holds) and the u64 pairs on this small index)"""
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
              "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--degree", "24", "--queries", "1000001", "--steps", "2",
              "--warmup", "1", "--no-cpu"] + (["--secondary", "config5"] if wire == "" else ["--no-secondary"]),
             env={"GCSA2_BENCH_BACKEND": "gloo", "GCSA2_BENCH_WIRE": wire})
     check_line(d, 2, 2)
-    assert ("40-bit pairs" in d["config"]["parallelism"]) == (wire == "40") and ("u32 pairs" in d["config"]["parallelism"]) == (wire == "")
+    assert ("40-bit pairs" in d["config"]["parallelism"]) == (wire == "40") and ("u32 pairs" in d["config"]["parallelism"]) == (wire == "32")
+    assert ("6 bytes" in d["config"]["parallelism"]) == (wire == "")
+    mg = d["multi_gpu"]
+    assert mg["asserted"] is True and mg["gathered_shards_verified"] == 2 and "problems" not in mg
+    assert mg["gather_only"]["reps"] >= 2 and mg["root_ingest_GBps"] > 0           # the gather alone, after the timed steps
     if wire != "":
         return
+    # one peer: its 500 000 ranges in six bytes each, the count of its list and 500 000 // 64 + 64 entries of 16 bytes
+    assert mg["wire_bytes_per_query"] == 6 and mg["bytes_into_root_per_step"] == 6 * 500_000 + 16 + 16 * (500_000 // 64 + 64)
     assert d["scaling"] == "strong" and d["config"]["queries_per_gpu"] == 500001 and d["config"]["queries_total"] == 1000001
     # config 5 sharded over the two ranks: matching statistics and the CSR of located values gathered on the root
     c5 = d["config5"]
@@ -138,21 +145,23 @@ def test_two_ranks_share_the_gpu_through_the_host(wire):
 
 
 def test_eight_ranks_share_the_gpu_with_an_asynchronous_transport():
-    """The target world size as far as one GPU allows: eight ranks, the 40-bit wire format of the headline
-    index (10 bytes per range), ragged shards (8 k + 3 queries), the library's gcsa2_comm_gather over a transport that only
+    """The target world size as far as one GPU allows: eight ranks, the six-byte wire format of the headline
+    index (round 6; 40-bit pairs until then), ragged shards (8 k + 3 queries), the library's gcsa2_comm_gather over a transport that only
     ENQUEUES on the gather stream -- so the gather of step k really runs under the kernel of step k + 1 and the root's
     gather calls return before their bytes have moved (with a transport that completes inside the call nothing could overlap).
     Reference shape of the only data-parallel query path: src/algorithms.cpp:106-114 (a static split)."""
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
              "--master-port", str(free_port()), "bench.py", "--gpus", "8", "--degree", "20", "--queries", str(8 * 100_000 + 3), "--steps", "6",
-             "--warmup", "2", "--no-cpu", "--no-secondary"], env={"GCSA2_BENCH_BACKEND": "gloo", "GCSA2_BENCH_WIRE": "40"}, timeout=1500)
+             "--warmup", "2", "--no-cpu", "--no-secondary"], env={"GCSA2_BENCH_BACKEND": "gloo"}, timeout=1500)
     check_line(d, 8, 6)
-    assert "40-bit pairs" in d["config"]["parallelism"] and d["config"]["queries_total"] == 8 * 100_000 + 3
+    assert "6 bytes" in d["config"]["parallelism"] and d["config"]["queries_total"] == 8 * 100_000 + 3
     mg = d["multi_gpu"]
     assert len(mg["per_rank"]) == 8 and sorted(x["queries"] for x in mg["per_rank"]) == [100_000] * 5 + [100_001] * 3
-    assert "asynchronous" in mg["gather"] and mg["rccl_ranks"] == 0 and mg["wire_bytes_per_query"] == 10
-    assert mg["gathered_shards_verified"] == 8          # the root holds every shard against the checksums its rank computed
-    assert mg["bytes_into_root_per_step"] == 10 * (8 * 100_000 + 3 - mg["per_rank"][0]["queries"])
+    assert "asynchronous" in mg["gather"] and mg["rccl_ranks"] == 0 and mg["wire_bytes_per_query"] == 6
+    assert mg["gathered_shards_verified"] == 8 and mg["asserted"] is True          # the root holds every shard against the checksums its rank computed
+    peers = [x["queries"] for x in mg["per_rank"][1:]]
+    assert mg["bytes_into_root_per_step"] == sum((6 * c + 15) // 16 * 16 + 16 + 16 * (c // 64 + 64) for c in peers)
+    assert mg["gather_only"]["bytes_into_root_per_gather"] == mg["bytes_into_root_per_step"]
     # the overlap: no gather call waits for its bytes -- on the root most calls return before the seven parts have arrived (a
     # transport that completes inside the call returns late every time, and then nothing of gather k can run under kernel
     # k + 1).  `gather_hidden_frac` is reported per rank; with eight processes time-slicing ONE GPU and a gather through host

@@ -1307,6 +1307,38 @@ def test_group_find_device_and_comm(engine):
     engine.unpack_ranges40_device(d_packed.data_ptr(), both.shape[0], d_back.data_ptr(), st)
     torch.cuda.synchronize()
     assert torch.equal(d_in, d_back)
+    # the six-byte form (round 6): sp in 40 bits, the length in one byte, the ranges of 255 and more path nodes in a list of
+    # fixed capacity behind the shard's ranges.  Exact for every range -- wrapped empties, lengths 254 / 255 / 256 on either
+    # side of the byte, lengths beyond 2^32 -- as long as the list holds the long ones; a list that is too short is REPORTED
+    # (the count the unpack returns exceeds the capacity), and every range that did fit is still exact.
+    edge = np.array([[9, 9 + 253], [9, 9 + 254], [9, 9 + 255], [2**40 - 300, 2**40 - 2], [1, 0], [0, 2**64 - 1]], dtype=np.uint64)
+    both = np.concatenate([both, edge, both[::-1]])
+    n = both.shape[0]
+    lengths = both[:, 1] + np.uint64(1) - both[:, 0]
+    long_ones = int((lengths >= 255).sum())
+    assert long_ones >= 6 and int((lengths == 0).sum()) >= 4
+    d_in = torch.from_numpy(both.view(np.int64).copy()).to(dev)
+    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    for capacity in (long_ones, long_ones + 7, 2):
+        size = engine.wire48_bytes(n, capacity)
+        assert size == ((6 * n + 15) // 16) * 16 + 16 + 16 * capacity
+        d_packed = torch.full((size + 16,), 0x5A, dtype=torch.uint8, device=dev)
+        d_back = torch.full_like(d_in, -7)
+        engine.pack_ranges48_device(d_in.data_ptr(), n, d_packed.data_ptr(), capacity, st)
+        engine.unpack_ranges48_device(d_packed.data_ptr(), n, capacity, d_back.data_ptr(), d_count.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert int(d_count.item()) == long_ones and (d_packed[size:] == 0x5A).all()
+        got = d_back.cpu().numpy().view(np.uint64)
+        if capacity >= long_ones:
+            assert np.array_equal(got, both)
+        else:                                  # reported, and what fits is exact: the short ranges, and `capacity` of the long ones
+            short = lengths < 255
+            assert np.array_equal(got[short], both[short]) and capacity <= int((got[~short] == both[~short]).all(axis=1).sum()) < long_ones
+            assert np.array_equal(got[~short][:, 0], both[~short][:, 0])
+    engine.pack_ranges48_device(d_in.data_ptr(), 0, d_packed.data_ptr(), 0, st)              # an empty shard: a count of zero, nothing else
+    engine.unpack_ranges48_device(d_packed.data_ptr(), 0, 0, d_back.data_ptr(), d_count.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert int(d_count.item()) == 0
 
 
 def test_sharded_match_stats_and_locate(engine):
