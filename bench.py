@@ -1326,13 +1326,10 @@ def match_stats_roofline(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, kernel_ms,
         torch.cuda.synchronize()
         assert torch.equal(keep[0], d_ms) and torch.equal(keep[1], d_rng) and torch.equal(keep[2], d_fb), "instrumented and timed kernels disagree"
         prof = [int(x) for x in d_prof.cpu()]
-        if os.environ.get("GCSA2_MS_KERNEL", "2") == "3":
-            names = ["rounds", "second_fetches", "lane_steps", "pair_attempts", "failed_pair_attempts", "parent_calls", "lcp_windows", "retries_from_staged_block"]
-            events = dict(zip(names, prof[8:16]))
-        else:                             # k_match_stats2's twin: one window per parent() call, every retry a block request (a lane step)
-            names = ["rounds", "rounds_with_second_fetch", "lane_steps", "pair_attempts", "failed_pair_attempts", "parent_calls", "tree_walks", "second_fetches"]
-            events = dict(zip(names, prof[8:16]))
-            events["lcp_windows"] = events["parent_calls"]
+        # k_match_stats2's twin: one window per parent() call, every retry a block request (a lane step)
+        names = ["rounds", "rounds_with_second_fetch", "lane_steps", "pair_attempts", "failed_pair_attempts", "parent_calls", "tree_walks", "second_fetches"]
+        events = dict(zip(names, prof[8:16]))
+        events["lcp_windows"] = events["parent_calls"]
         del keep
     lines = events["lane_steps"] + events["second_fetches"] + events["lcp_windows"]
     records_in = nq * ((m + 31) // 32 + 2)
@@ -1343,7 +1340,7 @@ def match_stats_roofline(gpu, d_pat, d_off, nq, m, d_ms, d_rng, d_fb, kernel_ms,
     limit = MEASURED_CEILING or REQUEST_CEILING_GPS
     rate = requests / (kernel_ms * 1e-3) / 1e9
     achieved = algo / (kernel_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": ("k_match_stats3" if os.environ.get("GCSA2_MS_KERNEL", "2") == "3" else "k_match_stats2") + ("<breaks>" if records is not None else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": "k_match_stats2" + ("<breaks>" if records is not None else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo, "kernel_ms": kernel_ms,
             "events": events, "requests_per_pattern": requests / nq, "line_requests_per_pattern": lines / nq,
             "request_rate": {"achieved_G_per_s": rate, "ceiling_G_per_s": limit, "frac_of_ceiling": rate / limit},

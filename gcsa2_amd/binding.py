@@ -38,7 +38,7 @@ EXPORTS = [
     "gcsa2_group_find_batch", "gcsa2_group_find_device", "gcsa2_group_uses_rccl",
     "gcsa2_group_match_stats_device", "gcsa2_group_locate_device", "gcsa2_comm_match_stats", "gcsa2_comm_locate",
     "gcsa2_comm_unique_id", "gcsa2_comm_create", "gcsa2_comm_create_custom", "gcsa2_comm_destroy", "gcsa2_comm_rank", "gcsa2_comm_world", "gcsa2_comm_rccl_ranks", "gcsa2_comm_gather",
-    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_pack_ranges40_device", "gcsa2_unpack_ranges40_device", "gcsa2_wire48_bytes", "gcsa2_pack_ranges48_device", "gcsa2_unpack_ranges48_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device", "gcsa2_match_breaks_device", "gcsa2_match_breaks_batch",
+    "gcsa2_pack_ranges32_device", "gcsa2_unpack_ranges32_device", "gcsa2_pack_ranges40_device", "gcsa2_unpack_ranges40_device", "gcsa2_wire48_bytes", "gcsa2_mailbox_stats", "gcsa2_pack_ranges48_device", "gcsa2_unpack_ranges48_device", "gcsa2_count_kmers", "gcsa2_compare_kmers", "gcsa2_compare_kmers_records", "gcsa2_match_stats_batch", "gcsa2_match_stats_device", "gcsa2_match_stats_device_variant", "gcsa2_match_stats_device_sized", "gcsa2_match_stats_profile_device", "gcsa2_match_breaks_device", "gcsa2_match_breaks_batch",
     "gcsa2_host_view_save", "gcsa2_host_view_load", "gcsa2_host_view_get", "gcsa2_host_view_free",
     "gcsa2_index_create_from_file", "gcsa2_host_view_load_gcsa", "gcsa2_index_create_from_gcsa",
     "gcsa2_host_view_parse_gcsa", "gcsa2_host_view_parse_lcp", "gcsa2_host_view_serialize_gcsa", "gcsa2_host_view_serialize_lcp",
@@ -172,6 +172,7 @@ def load_library():
     L.gcsa2_unpack_ranges32_device.argtypes = [vp, u64, vp, vp]
     L.gcsa2_pack_ranges40_device.argtypes = [vp, u64, vp, vp]
     L.gcsa2_unpack_ranges40_device.argtypes = [vp, u64, vp, vp]
+    L.gcsa2_mailbox_stats.argtypes = [vp, u64p, u64p]
     L.gcsa2_wire48_bytes.argtypes = [u64, u64]
     L.gcsa2_wire48_bytes.restype = u64
     L.gcsa2_pack_ranges48_device.argtypes = [vp, u64, vp, u64, vp]
@@ -407,6 +408,12 @@ class GCSA:
 
     def pair_block_bytes(self):
         return int(self._L.gcsa2_pair_block_bytes(self._h))
+
+    def mailbox_stats(self):
+        """(scalar calls answered by the resident wavefront, launches of it): gcsa2_mailbox_stats."""
+        calls, launches = C.c_uint64(0), C.c_uint64(0)
+        _check(self._L.gcsa2_mailbox_stats(self._h, C.byref(calls), C.byref(launches)))
+        return int(calls.value), int(launches.value)
 
     def locate_table_bytes(self):
         return int(self._L.gcsa2_locate_table_bytes(self._h))

@@ -44,7 +44,7 @@ using namespace g2;
 #include "kernels_find.hpp"
 #include "kernels_locate.hpp"
 #include "kernels_lcp.hpp"
-#include "kernels_ms3.hpp"
+#include "kernels_mailbox.hpp"
 #include "kernels_build.hpp"
 
 // ==========================================================================================
@@ -83,6 +83,9 @@ struct gcsa2_index
   mutable std::atomic<unsigned> next_slot{0};
   mutable std::atomic<unsigned long long> next_ticket{1};
   mutable std::atomic<int> single_backoff{0};     // locate(): calls that skip the one-kernel attempt after it met a misfit (locate_chunk)
+  // the resident wavefront that answers scalar calls (kernels_mailbox.hpp): its slot in page-locked memory, its stream
+  struct Mailbox { MailSlot* slot = nullptr; hipStream_t stream = nullptr; std::mutex lock; unsigned long long ticket = 0, launches = 0, calls = 0; bool failed = false; };
+  mutable Mailbox mail;
   mutable std::mutex staging_lock;
   mutable std::vector<Staging*> staging_pool;
   int compute_units = 256;
@@ -132,9 +135,10 @@ struct gcsa2_index
     u64 fuse_above = BIG_SEGMENT;      // GCSA2_LOCATE_FUSE_ABOVE (tests): path nodes from which such a range is a candidate for the fused split
     bool split_tiled = true;           // GCSA2_SPLIT_TILED=0: k_over_split scatters value by value, as in round 5 (A/B; round 6)
     u32 split_debug = 0;               // GCSA2_SPLIT_DEBUG (timing only, WRONG results): bit 0 no scatter stores, bit 1 no run phase, bit 2 no scatter pass, bit 3 no histogram atomics
+    bool mailbox = true;               // GCSA2_MAILBOX=0: one-query calls of LF / count / parent / LF(node) take the launch path like any batch (A/B; round 6)
+    u64 mailbox_park_us = 200;         // GCSA2_MAILBOX_PARK_US: the resident wavefront leaves after this long without a request
+    u64 mailbox_life_ms = 20;          // GCSA2_MAILBOX_LIFE_MS: ... and after this long whatever happens (the next call launches it again)
     bool locate_in_place = true;       // GCSA2_LOCATE_IN_PLACE=0: caller-owned buffers that hold the raw values are not used as the sort's target (A/B; round 6)
-    u32 ms_kernel = 2;                 // GCSA2_MS_KERNEL=3: variant 0 of the matching statistics runs k_match_stats3 (kernels_ms3.hpp; A/B: it loses, profiles/r05_match_stats.md)
-    u32 ms_speculate = 1;              // GCSA2_MS_SPECULATE: bit 0 clear: k_match_stats3 requests an LCP window only after a step has failed; bit 1: one parent() per round; bit 2: no short parent() (A/B)
     size_t arena_cap = size_t(24) << 30;  // GCSA2_ARENA_CAP_MB: most scratch a handle keeps between calls per arena (struct Scratch)
     u64 budget_bytes = 0;              // GCSA2_MEMORY_BUDGET_MB: most device memory the image may take (0: what the device has free)
   } tune;
@@ -605,6 +609,95 @@ struct Scratch
 }  // namespace
 
 namespace {
+
+// ---- the mailbox: scalar calls answered by a resident wavefront (kernels_mailbox.hpp) ---------------------------------------
+constexpr int MAIL_UNAVAILABLE = 1;          // internal, not a gcsa2_status: take the launch path
+constexpr unsigned long long MAIL_TICKS_PER_US = 100;      // wall_clock64(): the constant 100 MHz counter
+
+inline void mailbox_launch(const gcsa2_index* ix, unsigned long long answered)
+{
+  gcsa2_index::Mailbox& m = ix->mail;
+  volatile MailSlot* s = m.slot;
+  s->alive = 1;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  hipLaunchKernelGGL(k_mailbox, dim3(1), dim3(64), 0, m.stream, ix->img, m.slot, answered, ix->tune.mailbox_park_us * MAIL_TICKS_PER_US,
+                     ix->tune.mailbox_life_ms * 1000 * MAIL_TICKS_PER_US);
+  m.launches++;
+}
+
+// One request through the slot.  GCSA2_OK with the results, MAIL_UNAVAILABLE when the mailbox is switched off, held by another
+// host thread (that thread's loop keeps the wavefront; this call takes the launch path instead of queueing behind it) or could
+// not be set up; an error when the device does not answer.
+int mailbox_call(const gcsa2_index* ix, unsigned long long op, unsigned long long a0, unsigned long long a1, unsigned long long a2, u64* results, int n_results)
+{
+  gcsa2_index::Mailbox& m = ix->mail;
+  if(!ix->tune.mailbox || m.failed) { return MAIL_UNAVAILABLE; }
+  std::unique_lock<std::mutex> hold(m.lock, std::try_to_lock);
+  if(!hold.owns_lock()) { return MAIL_UNAVAILABLE; }
+  if(m.slot == nullptr)
+  {
+    void* raw = nullptr;
+    if(hipHostMalloc(&raw, sizeof(MailSlot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); m.failed = true; return MAIL_UNAVAILABLE; }
+    std::memset(raw, 0, sizeof(MailSlot));
+    if(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(raw); m.failed = true; return MAIL_UNAVAILABLE; }
+    m.slot = static_cast<MailSlot*>(raw);
+  }
+  volatile MailSlot* s = m.slot;
+  const unsigned long long ticket = ++m.ticket;
+  m.calls++;
+  s->op = op; s->arg[0] = a0; s->arg[1] = a1; s->arg[2] = a2;
+  std::atomic_thread_fence(std::memory_order_release);
+  if(s->alive == 0) { mailbox_launch(ix, ticket - 1); if(hipGetLastError() != hipSuccess) { m.failed = true; return MAIL_UNAVAILABLE; } }
+  s->request = ticket;
+  const auto t0 = std::chrono::steady_clock::now();
+  for(u64 spins = 1; s->done != ticket || s->front != ticket; spins++)       // (both ends of the answer's line: kernels_mailbox.hpp)
+  {
+    __builtin_ia32_pause();
+    if(s->alive == 0)
+    {
+      // the wavefront has left -- perhaps after answering in its last look at the slot; if not, the next instance answers
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if(s->done == ticket && s->front == ticket) { break; }
+      mailbox_launch(ix, ticket - 1);
+      if(hipGetLastError() != hipSuccess) { m.failed = true; return fail(GCSA2_ERR_HIP, "mailbox: the resident kernel could not be launched"); }
+    }
+    if((spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+    {
+      m.failed = true;
+      return fail(GCSA2_ERR_HIP, "mailbox: the device did not answer a scalar call within 10 s");
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for(int k = 0; k < n_results; k++) { results[k] = s->result[k]; }
+  return GCSA2_OK;
+}
+
+// ends the resident wavefront (before the image changes or goes away) and, with `release`, gives the slot and the stream back
+void mailbox_stop(const gcsa2_index* ix, bool release)
+{
+  gcsa2_index::Mailbox& m = ix->mail;
+  std::lock_guard<std::mutex> hold(m.lock);
+  if(m.slot == nullptr) { return; }
+  volatile MailSlot* s = m.slot;
+  if(s->alive != 0 && !m.failed)
+  {
+    const unsigned long long ticket = ++m.ticket;
+    s->op = MAIL_QUIT;
+    std::atomic_thread_fence(std::memory_order_release);
+    s->request = ticket;
+  }
+  (void)hipStreamSynchronize(m.stream);                       // (an instance that had left already: nothing to wait for)
+  s->alive = 0; s->done = m.ticket; s->front = m.ticket;
+  if(release)
+  {
+    (void)hipStreamDestroy(m.stream); (void)hipHostFree(m.slot);
+    m.slot = nullptr; m.stream = nullptr;
+  }
+}
+
+}  // namespace
+
+namespace {
 // owners: scratch of total_nodes / OWNER_SPAN + 3 entries (k_block_owners).  Values in path order (the table walk has an
 // unordered two-pass form for the sorted mode: locate_chunk).
 inline void launch_walk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, const u64* node_off, const u64* raw_off,
@@ -741,13 +834,14 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.locate_fuse = (knob("GCSA2_LOCATE_FUSE", 1, 0, 1) != 0);
     ix->tune.fuse_above = u64(knob("GCSA2_LOCATE_FUSE_ABOVE", BIG_SEGMENT, 1, long(1) << 40));
     ix->tune.locate_in_place = (knob("GCSA2_LOCATE_IN_PLACE", 1, 0, 1) != 0);
+    ix->tune.mailbox = (knob("GCSA2_MAILBOX", 1, 0, 1) != 0);
+    ix->tune.mailbox_park_us = u64(knob("GCSA2_MAILBOX_PARK_US", 200, 1, 1000000));
+    ix->tune.mailbox_life_ms = u64(knob("GCSA2_MAILBOX_LIFE_MS", 20, 1, 10000));
     ix->tune.split_debug = u32(knob("GCSA2_SPLIT_DEBUG", 0, 0, 15));
     ix->tune.split_tiled = (knob("GCSA2_SPLIT_TILED", 1, 0, 1) != 0);
     ix->tune.locate_split_sort = (knob("GCSA2_LOCATE_SPLIT_SORT", 1, 0, 1) != 0);
     ix->tune.split_skew = u32(knob("GCSA2_SPLIT_SKEW", BIG_SEGMENT, 16, BIG_SEGMENT));
     ix->tune.split_target = u32(knob("GCSA2_SPLIT_TARGET", SPLIT_TARGET, 1, 4096));
-    ix->tune.ms_kernel = u32(knob("GCSA2_MS_KERNEL", 2, 2, 3));
-    ix->tune.ms_speculate = u32(knob("GCSA2_MS_SPECULATE", 3, 0, 7));
     ix->tune.arena_cap = size_t(knob("GCSA2_ARENA_CAP_MB", 24576, 0, long(1) << 20)) << 20;    // 24 GB: 1/12 of an MI355X's HBM per arena
     ix->tune.seed_wide = u32(knob("GCSA2_SEED_WIDE", long(SEED_WIDE), 2, long(SEED_WIDE)));     // tests: meet the marked seed entries
     {
@@ -1068,6 +1162,7 @@ int gcsa2_index_set_tables(gcsa2_index* ix, int pair_blocks, int kmer_k, int loc
   }
   DeviceGuard guard(ix->device);
   if(!guard.ok) { return fail(GCSA2_ERR_HIP, "hipSetDevice failed"); }
+  mailbox_stop(ix, false);                   // (so does the resident wavefront of the scalar calls)
   HIP_TRY(hipDeviceSynchronize());           // launches in flight hold the old pointers
   // drops first, so that what is built next finds the memory
   if(pair_blocks == 0) { drop_pair_blocks(ix); }
@@ -1132,6 +1227,7 @@ int gcsa2_index_trim(gcsa2_index* ix)
   if(ix == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null index"); }
   DeviceGuard guard(ix->device);
   if(!guard.ok) { return fail(GCSA2_ERR_HIP, "hipSetDevice failed"); }
+  mailbox_stop(ix, true);                                      // (the resident wavefront holds a copy of the image's pointers)
   HIP_TRY(hipDeviceSynchronize());
   release_host_staging(ix);
   if(ix->pool != nullptr) { HIP_TRY(hipMemPoolTrimTo(ix->pool, 0)); }
@@ -1158,6 +1254,7 @@ void gcsa2_index_destroy(gcsa2_index* ix)
 {
   if(ix == nullptr) { return; }
   DeviceGuard guard(ix->device);
+  mailbox_stop(ix, true);
   if(ix->d_base) { (void)hipFree(ix->d_base); }
   if(ix->d_kmer) { (void)hipFree(ix->d_kmer); }
   if(ix->d_pred4) { (void)hipFree(ix->d_pred4); }
@@ -1169,6 +1266,15 @@ void gcsa2_index_destroy(gcsa2_index* ix)
   if(ix->pool) { (void)hipDeviceSynchronize(); (void)hipMemPoolDestroy(ix->pool); }
   release_host_staging(ix);
   delete ix;
+}
+
+// scalar calls answered by the resident wavefront so far, and how often it had to be launched (diagnostics, tests)
+int gcsa2_mailbox_stats(const gcsa2_index* ix, uint64_t* calls, uint64_t* launches)
+{
+  if(ix == nullptr || calls == nullptr || launches == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null argument"); }
+  std::lock_guard<std::mutex> hold(ix->mail.lock);
+  *calls = ix->mail.calls; *launches = ix->mail.launches;
+  return GCSA2_OK;
 }
 
 uint64_t gcsa2_size(const gcsa2_index* ix) { return ix->img.n; }
@@ -2358,6 +2464,13 @@ int gcsa2_lf_batch(const gcsa2_index* ix, const uint64_t* in, const uint8_t* com
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
+  if(nq == 1)                                // the per-character caller (gcsa.h:155-162 in a loop): through the resident wavefront
+  {
+    u64 r[2];
+    const int rc = mailbox_call(ix, MAIL_LF, in[0], in[1], comps[0], r, 2);
+    if(rc == GCSA2_OK) { out[0] = r[0]; out[1] = r[1]; return GCSA2_OK; }
+    if(rc != MAIL_UNAVAILABLE) { return rc; }
+  }
   Lease lease(ix);
   HIP_TRY(lease.begin(2 * Lease::need(2 * nq * 8) + Lease::need(nq), true));
   u64* d_in = lease.dev<u64>(2 * nq); u64* d_out = lease.dev<u64>(2 * nq); u8* d_c = lease.dev<u8>(nq);
@@ -2375,6 +2488,11 @@ int gcsa2_lf_node_batch(const gcsa2_index* ix, const uint64_t* in, uint64_t nq, 
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
+  if(nq == 1)
+  {
+    const int rc = mailbox_call(ix, MAIL_LF_NODE, in[0], 0, 0, out, 1);
+    if(rc != MAIL_UNAVAILABLE) { return rc; }
+  }
   Lease lease(ix);
   HIP_TRY(lease.begin(2 * Lease::need(nq * 8), true));
   u64* d_in = lease.dev<u64>(nq); u64* d_out = lease.dev<u64>(nq);
@@ -2424,6 +2542,11 @@ int gcsa2_count_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t nq
   CHECK_INDEX(ix);
   if(nq == 0) { return GCSA2_OK; }
   DeviceGuard guard(ix->device);
+  if(nq == 1 && ix->img.has_counters)
+  {
+    const int rc1 = mailbox_call(ix, MAIL_COUNT, ranges[0], ranges[1], 0, counts, 1);
+    if(rc1 != MAIL_UNAVAILABLE) { return rc1; }
+  }
   Lease lease(ix);
   HIP_TRY(lease.begin(Lease::need(2 * nq * 8) + Lease::need(nq * 8), true));
   u64* d_in = lease.dev<u64>(2 * nq); u64* d_out = lease.dev<u64>(nq);
@@ -2475,6 +2598,12 @@ int gcsa2_parent_batch(const gcsa2_index* ix, const uint64_t* ranges, uint64_t n
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
   if(nq == 0) { return GCSA2_OK; }
   static_assert(sizeof(gcsa2_stnode) == 5 * sizeof(u64), "gcsa2_stnode is five packed u64");
+  if(nq == 1)
+  {
+    DeviceGuard guard(ix->device);
+    const int rc = mailbox_call(ix, MAIL_PARENT, ranges[0], ranges[1], 0, reinterpret_cast<uint64_t*>(nodes), 5);
+    if(rc != MAIL_UNAVAILABLE) { return rc; }
+  }
   return simple_batch(ix, ranges, 2, reinterpret_cast<uint64_t*>(nodes), 5, nq, "k_parent", [&](u64* d_in, u64* d_out, hipStream_t st)
   { hipLaunchKernelGGL(k_parent, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_in, nq, reinterpret_cast<gcsa2_stnode*>(d_out)); });
 }
@@ -3312,72 +3441,21 @@ extern "C" int gcsa2_count_kmers(const gcsa2_index* ix, uint64_t k, int include_
 // patterns from a counter, 0 = the library chooses by batch size.  total_bytes = offsets[nq] when the caller knows it (GCSA2_UNKNOWN: read back from the
 // device, which waits for the stream once).
 namespace {
-// k_match_stats3 (kernels_ms3.hpp): the pre-pass writes 16-byte pattern records; persistent lanes or a lane per pattern
-template<bool PAIR, bool REFILL, bool BREAKS>
-void launch_ms3(const gcsa2_index* ix, unsigned grid, hipStream_t st, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq,
-                unsigned short* out, uint64_t* d_ranges, uint64_t* d_fallbacks, unsigned long long* queue, const ulonglong2* recs, const BreakSink* sink)
-{
-  unsigned long long* none = nullptr;
-  hipLaunchKernelGGL((k_match_stats3<PAIR, REFILL, false, BREAKS>), dim3(grid), dim3(TPB2), 0, st,
-                     ix->img, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, ix->tune.cool_down, queue, REFILL ? ix->tune.ms_refill_at : 64u,
-                     recs, ix->tune.ms_speculate, none, BREAKS ? *sink : BreakSink{nullptr, 0, nullptr, nullptr, 0});
-}
-
-int match_stats_launch3(const gcsa2_index* ix, bool persistent, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, u64 total_bytes,
-                        uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st, const BreakSink* sink)
-{
-  const u64 records = (total_bytes >> 5) + nq + 6;
-  ulonglong2* recs = nullptr;
-  unsigned long long* queue = nullptr;
-  HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&recs), records * sizeof(ulonglong2), st));
-  hipLaunchKernelGGL(k_pack_records, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, recs);
-  const u64 lanes_grid = (nq + TPB2 - 1) / TPB2;
-  const u64 resident = ix->tune.ms_grid != 0 ? ix->tune.ms_grid : u64(ix->compute_units) * 8;
-  unsigned grid = unsigned(lanes_grid);
-  if(persistent)
-  {
-    hipError_t qe = pool_alloc(ix, reinterpret_cast<void**>(&queue), sizeof(unsigned long long), st);
-    if(qe == hipSuccess) { qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st); }
-    if(qe != hipSuccess) { (void)hipFreeAsync(recs, st); return fail(GCSA2_ERR_HIP, std::string("matching statistics queue: ") + hipGetErrorString(qe)); }
-    grid = unsigned(lanes_grid < resident ? lanes_grid : resident);
-  }
-  unsigned short* out = reinterpret_cast<unsigned short*>(d_ms);
-  const bool pair = ix->img.flp != nullptr, breaks = sink != nullptr;
-#define GCSA2_MS3(P, R, B) launch_ms3<P, R, B>(ix, grid, st, d_patterns, d_offsets, nq, out, d_ranges, d_fallbacks, queue, recs, sink)
-  if(pair) { if(persistent) { if(breaks) { GCSA2_MS3(true, true, true); } else { GCSA2_MS3(true, true, false); } }
-             else { if(breaks) { GCSA2_MS3(true, false, true); } else { GCSA2_MS3(true, false, false); } } }
-  else { if(persistent) { if(breaks) { GCSA2_MS3(false, true, true); } else { GCSA2_MS3(false, true, false); } }
-         else { if(breaks) { GCSA2_MS3(false, false, true); } else { GCSA2_MS3(false, false, false); } } }
-#undef GCSA2_MS3
-  hipError_t le = hipGetLastError();
-  if(queue != nullptr) { (void)hipFreeAsync(queue, st); }
-  (void)hipFreeAsync(recs, st);                                        // stream-ordered: released after the kernel
-  if(le != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats3: ") + hipGetErrorString(le)); }
-  return GCSA2_OK;
-}
-
 int match_stats_launch(const gcsa2_index* ix, int variant, const uint8_t* d_patterns, const uint64_t* d_offsets, uint64_t nq, u64 total_bytes,
                        uint16_t* d_ms, uint64_t* d_ranges, uint64_t* d_fallbacks, hipStream_t st, const BreakSink* sink)
 {
   CHECK_INDEX(ix);
   DeviceGuard guard(ix->device);
   if(!ix->img.has_lcp) { return fail(GCSA2_ERR_MISSING_COMPONENT, "index was created without an LCP array"); }
-  if(variant != 0 && variant != 2 && variant != 5 && variant != 6 && variant != 7)
+  if(variant != 0 && variant != 2 && variant != 5)
   {
-    return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown matching statistics variant (0: the library chooses; 2 / 5: k_match_stats2 with a lane per pattern / persistent lanes; 6 / 7: k_match_stats3)");
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "unknown matching statistics variant (0: the library chooses; 2 / 5: a lane per pattern / persistent lanes)");
   }
   if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
   if(total_bytes == GCSA2_UNKNOWN)
   {
     HIP_TRY(hipMemcpyAsync(&total_bytes, d_offsets + nq, sizeof(u64), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-  }
-  {
-    // variant 0 chooses the launch shape (below) and the kernel (tune.ms_kernel)
-    const u64 lanes_grid0 = (nq + TPB2 - 1) / TPB2;
-    const u64 resident0 = ix->tune.ms_grid != 0 ? ix->tune.ms_grid : u64(ix->compute_units) * 8;
-    if(variant == 0 && ix->tune.ms_kernel == 3) { variant = (lanes_grid0 > 2 * resident0 ? 7 : 6); }
-    if(variant == 6 || variant == 7) { return match_stats_launch3(ix, variant == 7, d_patterns, d_offsets, nq, total_bytes, d_ms, d_ranges, d_fallbacks, st, sink); }
   }
   // pre-pass: the patterns as 16-byte records, last character first (k_pack_records); stream-ordered scratch
   ulonglong2* recs = nullptr;
@@ -3492,7 +3570,7 @@ int gcsa2_match_breaks_device(const gcsa2_index* ix, const uint8_t* d_patterns, 
   // records than one per pattern position and one per pattern, whatever the caller's capacity is: ADVICE r04)
   const u64 lane_waves = (nq + 63) / 64, lanes_grid = (nq + TPB2 - 1) / TPB2;
   const u64 resident = ix->tune.ms_grid != 0 ? ix->tune.ms_grid : u64(ix->compute_units) * 8;
-  const bool persistent = (variant == 5 || variant == 7 || (variant == 0 && lanes_grid > 2 * resident));
+  const bool persistent = (variant == 5 || (variant == 0 && lanes_grid > 2 * resident));
   const u64 waves = (persistent && resident * (TPB2 / 64) < lane_waves ? resident * (TPB2 / 64) : lane_waves);
   const u64 most = (total_bytes != GCSA2_UNKNOWN && total_bytes + nq < capacity ? total_bytes + nq : capacity);
   const u64 tmp_slots = most + (waves + 1) * BREAK_BLOCK;
@@ -3526,10 +3604,16 @@ int gcsa2_match_breaks_device(const gcsa2_index* ix, const uint8_t* d_patterns, 
   const u64 reserved = totals[0], found = totals[1];          // slots the wavefronts reserved (with holes), records in all
   *total_breaks = found;
   if(found > capacity) { return fail(GCSA2_ERR_BUFFER_TOO_SMALL, "break buffer too small"); }
+  //  the record scratch is sized from the caller's `total_bytes`: if that figure was too small the wavefronts
+  // reserved slots beyond the scratch and dropped those records -- refused, not returned as a CSR with holes
+  if(reserved > tmp_slots)
+  {
+    return fail(GCSA2_ERR_INVALID_ARGUMENT, "match_breaks: total_bytes is smaller than the patterns' total length (more break records than the scratch sized from it holds)");
+  }
   if(found > 0)
   {
     scratch.settled = false;
-    const u64 stored = (reserved < tmp_slots ? reserved : tmp_slots);
+    const u64 stored = reserved;
     hipLaunchKernelGGL(k_breaks_scatter, dim3(grid_for(stored)), dim3(TPB), 0, st, sink.tmp, stored, d_break_offsets, reinterpret_cast<u64*>(d_breaks), capacity);
     LAUNCH_CHECK("k_breaks_scatter");
   }
@@ -3602,19 +3686,6 @@ extern "C" int gcsa2_match_stats_profile_device(const gcsa2_index* ix, const uin
   if(d_prof == nullptr) { return fail(GCSA2_ERR_INVALID_ARGUMENT, "null profile buffer"); }
   if(nq == 0 || ix->img.n == 0) { return GCSA2_OK; }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if(ix->tune.ms_kernel == 3)
-  {
-    ulonglong2* recs = nullptr;
-    HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&recs), ((total_bytes >> 5) + nq + 6) * sizeof(ulonglong2), st));
-    hipLaunchKernelGGL(k_pack_records, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, recs);
-    hipLaunchKernelGGL((k_match_stats3<true, false, true>), dim3(unsigned((nq + TPB2 - 1) / TPB2)), dim3(TPB2), 0, st,
-                       ix->img, d_patterns, d_offsets, nq, reinterpret_cast<unsigned short*>(d_ms), d_ranges, d_fallbacks, ix->tune.cool_down,
-                       (unsigned long long*)nullptr, 64u, recs, ix->tune.ms_speculate, reinterpret_cast<unsigned long long*>(d_prof));
-    hipError_t le3 = hipGetLastError();
-    (void)hipFreeAsync(recs, st);
-    if(le3 != hipSuccess) { return fail(GCSA2_ERR_HIP, std::string("k_match_stats3<prof>: ") + hipGetErrorString(le3)); }
-    return GCSA2_OK;
-  }
   ulonglong2* recs = nullptr;
   HIP_TRY(pool_alloc(ix, reinterpret_cast<void**>(&recs), ((total_bytes >> 5) + nq + 6) * sizeof(ulonglong2), st));
   hipLaunchKernelGGL(k_pack_records, dim3(grid_for(nq)), dim3(TPB), 0, st, ix->img, d_patterns, d_offsets, nq, recs);

@@ -750,25 +750,18 @@ __global__ __launch_bounds__(TPB) void k_pattern_lengths(const u64* __restrict__
   idx[q] = u32(q);
 }
 
-// LF(range, comp) (gcsa.h:155-162) for a batch, one step: same fused-block machinery as k_find2.
-// This is the primitive vg's MEM loop calls once per character.
-__global__ __launch_bounds__(TPB2) void k_lf2(DevImage img, const u64* __restrict__ in, const u8* __restrict__ comps,
-                                             u64 nq, u64* __restrict__ out)
+// LF(range, comp) (gcsa.h:155-162), one step for the lanes of a wavefront (`live`: this lane has a range): the fused-block
+// machinery of k_find2.  Every lane of the wavefront must call it.  This is the primitive vg's MEM loop calls once per character.
+__device__ __forceinline__ void lf_step_wave(const DevImage& img, u64 in_sp, u64 in_ep, u32 comp, bool live, ulonglong2* wave_stage, u32 lane,
+                                             u64& out_sp, u64& out_ep)
 {
-  __shared__ ulonglong2 stage[TPB2 * 8];
-  const u32 lane = threadIdx.x & 63;
-  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
-  const u64 q = u64(blockIdx.x) * TPB2 + threadIdx.x;
-  bool live = q < nq;
   u64 sp = 0, ep = 0;
   u32 idx_sp = 0, idx_ep = 0, r_sp = 0, r_ep = 0;
   if(live)
   {
-    ulonglong2 r = reinterpret_cast<const ulonglong2*>(in)[q];
-    u32 comp = comps[q];
     if(comp >= img.sigma) { comp = u32(img.sigma - 1); }     // memory safety only
-    sp = clampu(r.x, img.n);
-    u64 e1 = clampu(r.y + 1, img.n);
+    sp = clampu(in_sp, img.n);
+    u64 e1 = clampu(in_ep + 1, img.n);
     u32 b_sp, b_ep;
     flb_block_of(sp, b_sp, r_sp); flb_block_of(e1, b_ep, r_ep);
     idx_sp = comp * u32(img.flb_nblocks) + b_sp; idx_ep = comp * u32(img.flb_nblocks) + b_ep;
@@ -797,8 +790,24 @@ __global__ __launch_bounds__(TPB2) void k_lf2(DevImage img, const u64* __restric
   {
     u64 a = e_sp, b = e_ep - 1;
     if(range_empty(a, b)) { sp = a; ep = b; } else { sp = n_sp; ep = n_ep; }     // gcsa.h:160-161
-    reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep);
   }
+  out_sp = sp; out_ep = ep;
+}
+
+__global__ __launch_bounds__(TPB2) void k_lf2(DevImage img, const u64* __restrict__ in, const u8* __restrict__ comps,
+                                             u64 nq, u64* __restrict__ out)
+{
+  __shared__ ulonglong2 stage[TPB2 * 8];
+  const u32 lane = threadIdx.x & 63;
+  ulonglong2* wave_stage = stage + (threadIdx.x & ~63u) * 8;
+  const u64 q = u64(blockIdx.x) * TPB2 + threadIdx.x;
+  const bool live = q < nq;
+  ulonglong2 r = make_ulonglong2(0, 0);
+  u32 comp = 0;
+  if(live) { r = reinterpret_cast<const ulonglong2*>(in)[q]; comp = comps[q]; }
+  u64 sp = 0, ep = 0;
+  lf_step_wave(img, r.x, r.y, comp, live, wave_stage, lane, sp, ep);
+  if(live) { reinterpret_cast<ulonglong2*>(out)[q] = make_ulonglong2(sp, ep); }
 }
 
 // LF(path_node): first incoming edge, comps 1..fast_chars, then fast_chars+1..sigma-1, else 0

@@ -356,8 +356,49 @@ __global__ __launch_bounds__(TPB) void k_lcp_access(DevImage img, const u64* __r
 // skipped.  ms[offset + i] = length of the longest match starting at i (capped at 65535), the final
 // range is the one of position 0.  Paper: paper.tex:344 (after Ohlebusch et al. 2010).
 
-// (the pre-pass that packs the patterns -- 2-bit codes and flags, last character first, 16-byte records -- is k_pack_records,
-// kernels_ms3.hpp; round 4's k_pack_patterns wrote the codes and the flags as two arrays)
+// (round 4's k_pack_patterns wrote the codes and the flags as two arrays; round 5's k_match_stats3 -- 32 LCP-window slots per
+// wavefront, parent() and the retry in the round of the failure: half the rounds, twice the instructions per round, 8-17 %
+// slower -- was retired in round 6 with variants 6 / 7: profiles/r05_match_stats.md has its A/B series, profiles/r06_match_stats.md
+// why the kernel's next step is another one)
+// Pre-pass: every pattern as 16-byte records, LAST character first.  Record j of pattern q lives at index
+// (offsets[q] >> 5) + q + j (consecutive patterns never overlap, see k_pack_patterns) and holds the characters at distance
+// t = 32 j .. 32 j + 31 from the pattern's end: x = comp - 1 of a fast character in bits [2 (t & 31), 2 (t & 31) + 2),
+// y = bit (t & 31) set for any other character and for the positions past the pattern's first character.
+__global__ __launch_bounds__(TPB) void k_pack_records(DevImage img, const u8* __restrict__ patterns, const u64* __restrict__ offsets,
+                                                     u64 nq, ulonglong2* __restrict__ recs)
+{
+  __shared__ u8 c2c[256];
+  c2c[threadIdx.x] = img.char2comp[threadIdx.x];
+  __syncthreads();
+  const u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  if(q >= nq) { return; }
+  const u64 begin = offsets[q], len = offsets[q + 1] - begin;
+  const u64 first_word = (begin >> 5) + q, words = (len + 31) >> 5;
+  for(u64 j = 0; j < words; j++)
+  {
+    const u64 high = len - 32 * j;                              // one past the pattern position of t = 32 j
+    const u64 count = (high < 32 ? high : 32), low = reinterpret_cast<u64>(patterns) + begin + high - count;
+    const u64 base = low & ~u64(7), last = (low + count - 1) & ~u64(7);
+    u64 w[5];
+#pragma unroll
+    for(u32 k = 0; k < 5; k++) { const u64 a = base + 8 * k; w[k] = *reinterpret_cast<const u64*>(a < last ? a : last); }
+    u64 code = 0; u32 flags = (count < 32 ? ~u32(0) << count : 0u);
+    for(u32 r = 0; r < count; r++)
+    {
+      const u64 at = (low - base) + (count - 1 - r);           // byte offset of the character at distance 32 j + r from the end
+      u64 word = w[0];
+#pragma unroll
+      for(u32 k = 1; k < 5; k++) { if((at >> 3) == k) { word = w[k]; } }
+      const u32 c = u32(c2c[u32(word >> ((at & 7) * 8)) & 0xFF]) - 1;
+      code |= u64(c & 3) << (2 * r);
+      flags |= u32(c < 4 ? 0 : 1) << r;
+    }
+    recs[first_word + j] = make_ulonglong2(code, u64(flags));
+  }
+  // (the two records behind a pattern's last one are read ahead by the kernel: flags only)
+  if(q + 1 == nq) { for(u64 j = words; j < words + 3; j++) { recs[first_word + j] = make_ulonglong2(0, ~u64(0)); } }
+}
+
 
 // parent() of (sp, ep) from a 128-byte window of the LCP array staged in the lane's LDS slot (fetch_blocks with LCP_FLAG): the
 // window starts at byte `wstart` (a multiple of 16), 48..63 positions before sp.  node_lcp = max(LCP[sp], LCP[ep + 1]); the
@@ -552,7 +593,7 @@ __global__ __launch_bounds__(TPB2, 4) void k_match_stats2(DevImage img, const u8
   u32 depth = 0, calls = 0;
   bool need_parent = false;
   u32 force_single = 0;
-  // Round 5: the pattern as 16-byte RECORDS (k_pack_records, kernels_ms3.hpp: 2-bit codes + "not a fast character" flags of 32
+  // Round 5: the pattern as 16-byte RECORDS (k_pack_records above: 2-bit codes + "not a fast character" flags of 32
   // characters).  The lane holds the record of position i - 1 (slot (total - i) & 31), the one behind it (a pair step at
   // slot 31 reads its first character there) and the one behind that, REQUESTED when a record is entered and not looked at
   // before the next entry.  Round 4 re-read two code words and two flag words from two arrays every 24 characters and used

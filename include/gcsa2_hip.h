@@ -257,6 +257,18 @@ int gcsa2_count_batch(const gcsa2_index* index, const uint64_t* ranges, uint64_t
 int gcsa2_count_device(const gcsa2_index* index, const uint64_t* d_ranges, uint64_t n_queries,
                        uint64_t* d_counts, void* stream);
 
+/* ---- scalar calls: the per-character caller (include/gcsa/gcsa.h:155-162 in a loop; vg's MEM finder) ---------------------
+ * A one-query call of gcsa2_lf_batch / gcsa2_lf_node_batch / gcsa2_count_batch / gcsa2_parent_batch -- what the facade's
+ * scalar LF() / count() / parent() make -- does not launch a kernel: the request goes through a page-locked slot to ONE
+ * resident wavefront of the index's device, which answers in the same slot (4 us per call instead of 12-17 through a launch;
+ * a CPU LF step takes 0.35 us, paper.tex:408: batches remain the way to throughput).  The wavefront is launched by the first
+ * such call, leaves by itself after GCSA2_MAILBOX_PARK_US (default 200) microseconds without a request -- that is how long a
+ * device-wide synchronisation elsewhere in the process may wait for it -- and after GCSA2_MAILBOX_LIFE_MS (20) in any case; the
+ * next call launches it again.  It occupies one wavefront slot of one CU while it lives.  One host thread at a time uses it;
+ * a second thread's call takes the launch path meanwhile.  GCSA2_MAILBOX=0 (read at create time) switches it off.  Results
+ * are those of the batch kernels bit for bit (the same device functions).  gcsa2_mailbox_stats: calls answered, launches. */
+int gcsa2_mailbox_stats(const gcsa2_index* index, uint64_t* calls, uint64_t* launches);
+
 /* ---- locate: GCSA::locate(range, results, append=false, sort) (src/gcsa.cpp:827-842) -------
  * Two calls, CSR output.  locate_run runs the whole query and keeps the result on the device
  * inside `*job`; locate_fetch copies the values (offsets[n_queries] of them) and frees the job.

@@ -113,7 +113,7 @@ def main():
         d_pat = torch.zeros(total_bytes + 16, dtype=torch.uint8, device=dev)
         d_pat[:total_bytes] = torch.from_numpy(np.ascontiguousarray(data[:total_bytes]).copy()).to(dev)
         d_off = torch.from_numpy(off.view(np.int64).copy()).to(dev)
-        for variant in (2, 5, 6, 7):
+        for variant in (2, 5):
             d_ms = torch.full((total_bytes + 8,), -3, dtype=torch.int16, device=dev)
             d_rng = torch.zeros((len(rows), 2), dtype=torch.int64, device=dev)
             d_fb = torch.zeros(len(rows), dtype=torch.int64, device=dev)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""A/B of the matching-statistics kernels on config 5's batch (1 M x 256 bp, every second pattern with a substitution every
-41 bp; pangenome-sized index): k_match_stats2 (round 4) against k_match_stats3 (round 5: pattern records, LCP-window slots,
-parent() + retry in one round), with and without the speculative window request; dense statistics, break points, and the
-unmodified patterns alone.  Every configuration must return the first one's bytes.  One JSON line per configuration.
-  python tests/perf/ms_ab.py [--degree 34] [--configs 'GCSA2_MS_KERNEL=2;GCSA2_MS_KERNEL=3;GCSA2_MS_KERNEL=3,GCSA2_MS_SPECULATE=0']"""
+"""A/B of the matching-statistics kernel's knobs on config 5's batch (1 M x 256 bp, every second pattern with a substitution
+every 41 bp; pangenome-sized index): dense statistics, break points, and the unmodified patterns alone.  Every configuration
+must return the first one's bytes.  One JSON line per configuration.  (Round 5 compared k_match_stats2 with k_match_stats3
+through GCSA2_MS_KERNEL here: profiles/r05_ms/; that kernel was retired in round 6.)
+  python tests/perf/ms_ab.py [--degree 34] [--configs ';GCSA2_COOL_DOWN=6;GCSA2_MS_GRID=1024']"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -13,7 +13,7 @@ from gcsa2_amd.binding import GCSA
 ap = argparse.ArgumentParser()
 ap.add_argument("--degree", type=int, default=34)
 ap.add_argument("--patterns", type=int, default=1_000_000)
-ap.add_argument("--configs", default="GCSA2_MS_KERNEL=2;GCSA2_MS_KERNEL=3;GCSA2_MS_KERNEL=3,GCSA2_MS_SPECULATE=0")
+ap.add_argument("--configs", default=";GCSA2_COOL_DOWN=6;GCSA2_MS_GRID=1024")
 ap.add_argument("--reps", type=int, default=5)
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -45,7 +45,7 @@ def timed(fn):
 
 
 ref = None
-knobs = ("GCSA2_MS_KERNEL", "GCSA2_MS_SPECULATE", "GCSA2_COOL_DOWN", "GCSA2_MS_REFILL_AT", "GCSA2_MS_GRID")
+knobs = ("GCSA2_COOL_DOWN", "GCSA2_MS_REFILL_AT", "GCSA2_MS_GRID")
 for config in args.configs.split(";"):
     for k in knobs: os.environ.pop(k, None)
     for kv in filter(None, config.split(",")):

@@ -19,13 +19,6 @@ EVENTS = ["rounds (per wave)", "rounds with a second fetch", "lane steps", "pair
           "tree walks", "lane second fetches"]
 
 
-if os.environ.get("GCSA2_MS_KERNEL", "2") == "3":       # k_match_stats3 (kernels_ms3.hpp) numbers its phases and events like this
-    PHASES = ["stores + records + finished / new patterns (under the requests in flight)", "record advance + plan + issue of the next requests", "wait for the requests",
-              "first evaluation", "second fetch + evaluation", "outcome", "recovery: parent() from the LCP window", "recovery: retry from the staged block"]
-    EVENTS = ["rounds (per wave)", "lane second fetches", "lane steps", "pair attempts", "failed pair attempts", "parent() calls",
-              "LCP windows requested", "retries answered from the staged block"]
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--degree", type=int, default=34)
