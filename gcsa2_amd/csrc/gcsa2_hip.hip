@@ -134,7 +134,7 @@ struct gcsa2_index
     bool locate_fuse = true;           // GCSA2_LOCATE_FUSE=0: wide ranges of one-value path nodes go through the table pass like the others (A/B; round 6)
     u64 fuse_above = BIG_SEGMENT;      // GCSA2_LOCATE_FUSE_ABOVE (tests): path nodes from which such a range is a candidate for the fused split
     bool split_tiled = true;           // GCSA2_SPLIT_TILED=0: k_over_split scatters value by value, as in round 5 (A/B; round 6)
-    u32 split_debug = 0;               // GCSA2_SPLIT_DEBUG (timing only, WRONG results): bit 0 no scatter stores, bit 1 no run phase, bit 2 no scatter pass, bit 3 no histogram atomics
+    u32 split_debug = 0;               // GCSA2_SPLIT_DEBUG (timing only, WRONG results): timing only, WRONG results: bit 0 no scatter stores, bit 1 no run phase, bit 2 no scatter pass, bit 3 no histogram atomics
     bool mailbox = true;               // GCSA2_MAILBOX=0: one-query calls of LF / count / parent / LF(node) take the launch path like any batch (A/B; round 6)
     u64 mailbox_park_us = 200;         // GCSA2_MAILBOX_PARK_US: the resident wavefront leaves after this long without a request
     u64 mailbox_life_ms = 20;          // GCSA2_MAILBOX_LIFE_MS: ... and after this long whatever happens (the next call launches it again)

@@ -1396,11 +1396,12 @@ constexpr u32 SPLIT_BUCKETS_UNTILED = 4096;
 // LDS atomics that also rank a value inside its bucket), every wavefront scans the counts for itself (four per lane, one
 // 16-byte read; all write the same offsets, so no barrier), the values are placed bucket by bucket in an LDS buffer and written
 // out in that order: neighbouring lanes hold neighbouring values of one bucket, SPLIT_TILE / buckets of them in a row.  Three
-// barriers per tile; the next tile's values are requested before the current one is worked on.  For segments of at most
-// SPLIT_TILED_BUCKETS buckets (65 536 values at 256 per bucket): the scan is then one 16-byte read per lane.  A longer segment
-// keeps the value-by-value scatter -- tried: 1024 buckets through the tiles with sixteen counts per lane (2.8 -> 3.9 ms on the
-// 16-mer batch: every wavefront reads and writes 8 KB of counts per tile); all segments with at most 256 buckets (the longer
-// buckets of the long segments then cost the workgroup sorts 3.4 ms on the 32-mer batch).
+// barriers per tile; the next tile's values are requested before the current one is worked on.  At most SPLIT_TILED_BUCKETS = 256
+// buckets, whatever the segment's length: the scan is then one 16-byte read per lane, and a segment beyond 65 536 values gets
+// longer buckets -- up to 512 values a wavefront sorts in eight registers per lane, up to 1024 in sixteen (lists of their own),
+// beyond that the workgroup sort.  (Tried: 1024 buckets through the tiles with sixteen counts per lane: 2.8 -> 3.9 ms on the
+// 16-mer batch, every wavefront reads and writes 8 KB of counts per tile; tiles for the segments of up to 256 buckets and the
+// value-by-value scatter beyond: 7.43 / 6.58 ms for the two batches against 7.00 / 6.22 with every segment through the tiles.)
 constexpr u32 SPLIT_TILED_BUCKETS = 256;
 constexpr u32 SPLIT_TILE_PER = 4, SPLIT_TILE = 1024 * SPLIT_TILE_PER;
 constexpr u32 SPLIT_SAMPLE = 8192;             // values whose minimum and maximum stand for the segment's
@@ -1472,7 +1473,8 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   lo = s_lo; hi = s_hi;
   // buckets: the smallest power of two with len / buckets <= SPLIT_TARGET, at most SPLIT_BUCKETS; bucket = (v - lo) >> shift
   u32 nb = 2;
-  while(nb < SPLIT_BUCKETS && u64(nb) * target < len) { nb <<= 1; }          // (target: SPLIT_TARGET; GCSA2_SPLIT_TARGET in tests)
+  const u32 most_buckets = (TILED ? SPLIT_TILED_BUCKETS : SPLIT_BUCKETS);
+  while(nb < most_buckets && u64(nb) * target < len) { nb <<= 1; }          // (target: SPLIT_TARGET; GCSA2_SPLIT_TARGET in tests)
   const u64 span = hi - lo;                                   // largest (v - lo)
   u32 shift = 0;
   while(shift < 63 && (span >> shift) >= nb) { shift++; }
@@ -1551,7 +1553,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
       at += mine[k];
     }
   }
-  if(TILED && nb <= SPLIT_TILED_BUCKETS)                      // (uniform)
+  if constexpr(TILED)
   {
     static_assert(SPLIT_TILED_BUCKETS == 256 && SPLIT_THREADS == 1024, "four counts per lane; bucket numbers in a byte");
     if(tid < SPLIT_TILED_BUCKETS) { tile_count[0][tid] = 0; tile_count[1][tid] = 0; }
