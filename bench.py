@@ -732,6 +732,9 @@ def measure(args, D, dev, wl, steps, warmup):
             comm_stream.synchronize()
         if unpack_stream is not None:
             unpack_stream.synchronize()
+        transport = getattr(D, "transport", None)
+        if transport is not None and hasattr(transport, "check"):
+            transport.check()                # (a host-memory transport whose helper thread failed says so here, not at the next call)
 
     for k in range(warmup):
         step(k)

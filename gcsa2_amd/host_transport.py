@@ -189,7 +189,24 @@ class AsyncHostGather(HostGather):
                 self.early_returns += 1
         return 0
 
+    def check(self):
+        """Raises what the helper thread met, if anything.  A failure there releases every waiting stream -- the
+        copies enqueued behind the wait then move whatever the page-locked buffers hold -- and the gather call that enqueued
+        them has long returned 0, so the caller asks HERE, after synchronising the stream it gave the transport, before it
+        trusts what arrived.  (A test-grade transport: RCCL is the product's; a peer whose send fails leaves the root's receive
+        to the process group's timeout.)"""
+        if self.failed is not None:
+            raise RuntimeError(f"the host-memory gather failed in its helper thread: {self.failed!r}")
+
     def close(self):
-        """(after the streams have drained) ends the helper thread"""
+        """(after the streams have drained) ends the helper thread, gives back the buffers and events of the calls that were
+        still listed, and raises what the thread met"""
         self.jobs.put(None)
         self.worker.join(timeout=10)
+        try:
+            self._reap()
+            for key in list(self.pending):
+                self._release(self.pending.pop(key))
+        except Exception:                       # (closing must not hide the failure below)
+            pass
+        self.check()
