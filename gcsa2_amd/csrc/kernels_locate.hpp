@@ -749,6 +749,97 @@ __device__ __forceinline__ void wave_sort_regs32(u32 (&v)[R], u32 lane)
 // `len` values at src[0, len) sorted into dst[0, len) (dst may be src) by the wavefront, len <= 64 R.  When all of them share
 // their upper 32 bits -- the values of a bucket of k_over_split nearly always do, a query's values when they lie in one 4 G
 // stretch of the node numbers -- the lower halves are sorted as 32-bit keys.
+// Round 6: the 32-bit network in BLOCKED layout -- element e = R lane + r, a lane holds R neighbours -- and in the form whose
+// comparators all point the same way (a stage first compares e with e ^ (K - 1), the mirror image inside its block of K, then
+// with e ^ J for J = K / 4 ... 1; the smaller value always goes to the smaller index).  The most frequent strides are the
+// smallest ones -- stride 1 occurs in every stage --, and in this layout the strides below R stay inside a lane: a compare-
+// exchange is v_min_u32 + v_max_u32 on two registers, no lane exchange, no select, no direction mask (with e = 64 r + lane
+// every stride below 64 crossed lanes: 33 of the 36 steps of a 256-value sort).  Strides of R and more cross lanes as before
+// (DPP / permlane operand, min, max, a select on a compile-time lane mask).  Counted for 256 values, R = 4: 324 vector
+// instructions instead of 408; 512 values, R = 8: 720 instead of 984.  Input order is free (the values arrive unsorted), so
+// the loads stay coalesced; the sorted registers go through LDS once to return to e = 64 r + lane for the stores.
+template<u32 M>
+__device__ __forceinline__ u32 lane_mirror32(u32 v, u32 lane)      // the value of lane (l ^ M), M = 2^t - 1
+{
+  static_assert(M == 1 || M == 3 || M == 7 || M == 15 || M == 31 || M == 63, "a mask of low bits");
+  if constexpr(M == 1) { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xF, 0xF, true)); }          // quad_perm [1, 0, 3, 2]
+  else if constexpr(M == 3) { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0x1B, 0xF, 0xF, true)); }     // quad_perm [3, 2, 1, 0]
+  else if constexpr(M == 7) { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0x141, 0xF, 0xF, true)); }    // row_half_mirror
+  else if constexpr(M == 15) { return u32(__builtin_amdgcn_update_dpp(0, int(v), 0x140, 0xF, 0xF, true)); }   // row_mirror
+  else if constexpr(M == 31) { return lane_xor32<16>(lane_mirror32<15>(v, lane), lane); }
+  else { return lane_xor32<32>(lane_xor32<16>(lane_mirror32<15>(v, lane), lane), lane); }
+}
+template<u32 R, u32 J>
+__device__ __forceinline__ void blocked_steps32(u32 (&v)[R], u32 lane)      // compare e with e ^ J, then J / 2, ..., 1
+{
+  if constexpr(J >= R)
+  {
+    constexpr u32 L = J / R;                                  // partner lane = lane ^ L; the lane with the bit clear keeps the smaller value
+#pragma unroll
+    for(u32 r = 0; r < R; r++)
+    {
+      const u32 other = lane_xor32<L>(v[r], lane);
+      const u32 lo = (other < v[r] ? other : v[r]), hi = (other < v[r] ? v[r] : other);
+      v[r] = select_by_mask(hi, lo, lanes_with_bit_clear(L));
+    }
+  }
+  else
+  {
+#pragma unroll
+    for(u32 r = 0; r < R; r++)
+    {
+      if((r & J) == 0)
+      {
+        const u32 a = v[r], c = v[r | J];
+        v[r] = (a < c ? a : c); v[r | J] = (a < c ? c : a);
+      }
+    }
+  }
+  if constexpr(J > 1) { blocked_steps32<R, J / 2>(v, lane); }
+}
+template<u32 R, u32 K = 2>
+__device__ __forceinline__ void wave_sort_blocked32(u32 (&v)[R], u32 lane)
+{
+  // the mirror step of stage K: e with e ^ (K - 1)
+  if constexpr(K <= R)
+  {
+#pragma unroll
+    for(u32 r = 0; r < R; r++)
+    {
+      const u32 p = r ^ (K - 1);
+      if(r < p) { const u32 a = v[r], c = v[p]; v[r] = (a < c ? a : c); v[p] = (a < c ? c : a); }
+    }
+  }
+  else
+  {
+    constexpr u32 M = K / R - 1;                              // partner: lane ^ M, register R - 1 - r; the lane whose top bit of M + 1 is clear is the lower one
+    u32 other[R];
+#pragma unroll
+    for(u32 r = 0; r < R; r++) { other[r] = lane_mirror32<M>(v[R - 1 - r], lane); }
+#pragma unroll
+    for(u32 r = 0; r < R; r++)
+    {
+      const u32 lo = (other[r] < v[r] ? other[r] : v[r]), hi = (other[r] < v[r] ? v[r] : other[r]);
+      v[r] = select_by_mask(hi, lo, lanes_with_bit_clear((M + 1) / 2));
+    }
+  }
+  if constexpr(K >= 4) { blocked_steps32<R, K / 4>(v, lane); }
+  if constexpr(K < 64 * R) { wave_sort_blocked32<R, 2 * K>(v, lane); }
+}
+// sorted registers in blocked layout (element R lane + r) -> the layout of the loads and stores (element 64 r + lane), through
+// `stage` (64 R words of LDS that belong to this wavefront)
+template<u32 R>
+__device__ __forceinline__ void blocked_to_striped32(u32 (&v)[R], u32* stage, u32 lane)
+{
+  if constexpr(R == 1) { return; }
+#pragma unroll
+  for(u32 r = 0; r < R; r++) { stage[R * lane + r] = v[r]; }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for(u32 r = 0; r < R; r++) { v[r] = stage[64 * r + lane]; }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // Values of a wavefront's sorted registers (element e = 64 r + lane, ascending, the first `len` real) that equal their left
 // neighbour, summed over the wavefront: what removeDuplicates (utils.h:350-357) will drop.  Round 6: the sorts report them, and
 // a batch without any needs no compaction -- its values are sorted in the caller's buffer, at the offsets the size scan gave.
@@ -773,7 +864,7 @@ __device__ __forceinline__ u32 dups_in_regs(const T (&v)[R], u32 len, u32 lane)
 // stretch of the node numbers -- the lower halves are sorted as 32-bit keys.  MASK: bits cleared from what is read (the
 // locate table's direct flag, when src is the table itself).  Returns the number of duplicates (dups_in_regs).
 template<u32 R>
-__device__ __forceinline__ u32 sort_segment_regs(const u64* src, u64* dst, u32 len, u32 lane, u64 keep = ~u64(0))
+__device__ __forceinline__ u32 sort_segment_regs(const u64* src, u64* dst, u32 len, u32 lane, u64 keep = ~u64(0), u32* stage = nullptr)
 {
   u64 v[R];
 #pragma unroll
@@ -787,7 +878,8 @@ __device__ __forceinline__ u32 sort_segment_regs(const u64* src, u64* dst, u32 l
     u32 key[R];
 #pragma unroll
     for(u32 r = 0; r < R; r++) { key[r] = (r * 64 + lane < len ? u32(v[r]) : ~u32(0)); }           // (a key of all ones ties with the padding: the same value either way)
-    wave_sort_regs32<R>(key, lane);
+    if(stage != nullptr) { wave_sort_blocked32<R>(key, lane); blocked_to_striped32<R>(key, stage, lane); }      // (uniform: the kernel has a transposition buffer)
+    else { wave_sort_regs32<R>(key, lane); }
 #pragma unroll
     for(u32 r = 0; r < R; r++) { if(r * 64 + lane < len) { dst[r * 64 + lane] = (u64(top) << 32) | key[r]; } }
     return dups_in_regs<R>(key, len, lane);
@@ -799,13 +891,13 @@ __device__ __forceinline__ u32 sort_segment_regs(const u64* src, u64* dst, u32 l
 }
 // (MOST: the longest segment the caller passes, 64 R_max -- the register budget of the kernel follows from it)
 template<u32 MOST = MEDIUM_SEGMENT>
-__device__ __forceinline__ u32 sort_segment_by_wave(const u64* src, u64* dst, u32 len, u32 lane, u64 keep = ~u64(0))      // len <= MOST (uniform)
+__device__ __forceinline__ u32 sort_segment_by_wave(const u64* src, u64* dst, u32 len, u32 lane, u64 keep = ~u64(0), u32* stage = nullptr)      // len <= MOST (uniform)
 {
-  if(len <= 64) { return sort_segment_regs<1>(src, dst, len, lane, keep); }
-  else if(len <= 128) { return sort_segment_regs<2>(src, dst, len, lane, keep); }
-  else if(len <= 256 || MOST <= 256) { return sort_segment_regs<4>(src, dst, len, lane, keep); }
-  else if(len <= 512 || MOST <= 512) { return sort_segment_regs<8>(src, dst, len, lane, keep); }
-  else { return sort_segment_regs<16>(src, dst, len, lane, keep); }
+  if(len <= 64) { return sort_segment_regs<1>(src, dst, len, lane, keep, stage); }
+  else if(len <= 128) { return sort_segment_regs<2>(src, dst, len, lane, keep, stage); }
+  else if(len <= 256 || MOST <= 256) { return sort_segment_regs<4>(src, dst, len, lane, keep, stage); }
+  else if(len <= 512 || MOST <= 512) { return sort_segment_regs<8>(src, dst, len, lane, keep, stage); }
+  else { return sort_segment_regs<16>(src, dst, len, lane, keep, stage); }
 }
 // totals[T_DUPS] is a FLAG with a count's type: non-zero iff some sort met a duplicate.  A wavefront that has some adds them
 // only while the word still reads zero -- on a variation graph most queries have duplicates, and a hundred thousand
@@ -826,11 +918,12 @@ __device__ __forceinline__ void report_dups(unsigned long long* totals, u32 dups
 __global__ __launch_bounds__(64) void k_sort_medium(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end, u64 last,
                                                     u64* __restrict__ values, unsigned long long* __restrict__ totals)
 {
+  __shared__ u32 stage[MEDIUM_SEGMENT];                     // (the transposition of the blocked 32-bit network)
   const u32 lane = threadIdx.x;
   if(blockIdx.x >= totals[T_MEDIUM]) { return; }
   const u64 b = seg_begin[last - blockIdx.x];
   const u32 len = u32(seg_end[last - blockIdx.x] - b);
-  report_dups(totals, sort_segment_by_wave(values + b, values + b, len, lane), lane);
+  report_dups(totals, sort_segment_by_wave(values + b, values + b, len, lane, ~u64(0), stage), lane);
 }
 
 // one workgroup per LARGE segment (list from the start of the segment arrays) with at most BIG_SEGMENT values: bitonic sort
@@ -1402,7 +1495,10 @@ constexpr u32 SPLIT_BUCKETS_UNTILED = 4096;
 // beyond that the workgroup sort.  (Tried: 1024 buckets through the tiles with sixteen counts per lane: 2.8 -> 3.9 ms on the
 // 16-mer batch, every wavefront reads and writes 8 KB of counts per tile; tiles for the segments of up to 256 buckets and the
 // value-by-value scatter beyond: 7.43 / 6.58 ms for the two batches against 7.00 / 6.22 with every segment through the tiles.)
-constexpr u32 SPLIT_TILED_BUCKETS = 256;
+#ifndef GCSA2_TILED_BUCKETS
+#define GCSA2_TILED_BUCKETS 512
+#endif
+constexpr u32 SPLIT_TILED_BUCKETS = GCSA2_TILED_BUCKETS;
 constexpr u32 SPLIT_TILE_PER = 4, SPLIT_TILE = 1024 * SPLIT_TILE_PER;
 constexpr u32 SPLIT_SAMPLE = 8192;             // values whose minimum and maximum stand for the segment's
 constexpr u32 SPLIT_AHEAD = 4;                 // independent loads per lane in the streaming passes
@@ -1429,7 +1525,8 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
                                                              const u64* const* __restrict__ over_src, u32 debug,
                                                              u64* __restrict__ mid_begin, u64* __restrict__ mid_end)
 {
-  constexpr u32 SPLIT_BUCKETS = SPLIT_BUCKETS_UNTILED;
+  // (the tiled form never has more than SPLIT_TILED_BUCKETS buckets: its cursor / start arrays are as long as the workgroup)
+  constexpr u32 SPLIT_BUCKETS = (TILED ? u32(SPLIT_THREADS) : SPLIT_BUCKETS_UNTILED);
   __shared__ __attribute__((aligned(16))) u32 cursor[SPLIT_BUCKETS];        // histogram, then the buckets' write cursors (= their ends after the scatter)
   __shared__ u32 starts[SPLIT_BUCKETS];
   __shared__ u32 wave_sums[SPLIT_THREADS / 64];
@@ -1439,7 +1536,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   __shared__ __attribute__((aligned(16))) u32 tile_off[TILED ? SPLIT_TILED_BUCKETS : 4];           // their exclusive prefix sums
   __shared__ __attribute__((aligned(16))) u32 tile_delta[TILED ? SPLIT_TILED_BUCKETS : 4];         // where in the segment the bucket's values of this tile go, minus tile_off
   __shared__ u64 tile_value[TILED ? SPLIT_TILE : 1];                  // the tile, bucket by bucket
-  __shared__ unsigned char tile_bucket[TILED ? SPLIT_TILE : 1];
+  __shared__ unsigned short tile_bucket[TILED ? SPLIT_TILE : 1];
   constexpr u32 PER_THREAD = SPLIT_BUCKETS / SPLIT_THREADS;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 b = over_begin[blockIdx.x], len = over_end[blockIdx.x] - b;
@@ -1555,7 +1652,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   }
   if constexpr(TILED)
   {
-    static_assert(SPLIT_TILED_BUCKETS == 256 && SPLIT_THREADS == 1024, "four counts per lane; bucket numbers in a byte");
+    static_assert(SPLIT_TILED_BUCKETS % 256 == 0 && SPLIT_TILED_BUCKETS <= SPLIT_THREADS && SPLIT_THREADS == 1024, "counts per lane in groups of four; a thread owns a bucket");
     if(tid < SPLIT_TILED_BUCKETS) { tile_count[0][tid] = 0; tile_count[1][tid] = 0; }
     __syncthreads();
     u64 next[SPLIT_TILE_PER];
@@ -1583,19 +1680,34 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
       }
       __syncthreads();
       {
-        // every wavefront scans the 256 counts for itself: lane l has buckets 4 l .. 4 l + 3; wavefront 0 also says where the
-        // buckets' values of this tile go (tile_delta)
-        const uint4 c = *reinterpret_cast<const uint4*>(&count[lane * 4]);
-        const u32 sum = c.x + c.y + c.z + c.w;
+        // every wavefront scans the counts for itself: lane l has buckets PER l .. PER l + PER - 1 (16-byte reads); wavefront 0
+        // also says where the buckets' values of this tile go (tile_delta)
+        constexpr u32 PER = SPLIT_TILED_BUCKETS / 64;
+        // (two passes over the lane's counts -- its total first, then, after the scan over the lanes, the counts again for the
+        // offsets: holding them across the scan cost the kernel its second workgroup per CU once PER was 8)
+        u32 sum = 0;
+#pragma unroll
+        for(u32 k = 0; k < PER; k += 4)
+        {
+          const uint4 part = *reinterpret_cast<const uint4*>(&count[lane * PER + k]);
+          sum += part.x + part.y + part.z + part.w;
+        }
         u32 incl = sum;
         for(int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(incl, o, 64); if(lane >= u32(o)) { incl += up; } }
-        const u32 at = incl - sum;
-        const uint4 off = make_uint4(at, at + c.x, at + c.x + c.y, at + c.x + c.y + c.z);
-        *reinterpret_cast<uint4*>(&tile_off[lane * 4]) = off;
-        if(wave == 0)
+        u32 at = incl - sum;
+        asm volatile("" ::: "memory");                          // (the counts are read again, not kept)
+#pragma unroll
+        for(u32 k = 0; k < PER; k += 4)
         {
-          const uint4 cur = *reinterpret_cast<const uint4*>(&cursor[lane * 4]);
-          *reinterpret_cast<uint4*>(&tile_delta[lane * 4]) = make_uint4(cur.x - off.x, cur.y - off.y, cur.z - off.z, cur.w - off.w);
+          const uint4 part = *reinterpret_cast<const uint4*>(&count[lane * PER + k]);
+          const uint4 off = make_uint4(at, at + part.x, at + part.x + part.y, at + part.x + part.y + part.z);
+          *reinterpret_cast<uint4*>(&tile_off[lane * PER + k]) = off;
+          if(wave == 0)
+          {
+            const uint4 cur = *reinterpret_cast<const uint4*>(&cursor[lane * PER + k]);
+            *reinterpret_cast<uint4*>(&tile_delta[lane * PER + k]) = make_uint4(cur.x - off.x, cur.y - off.y, cur.z - off.z, cur.w - off.w);
+          }
+          at += part.x + part.y + part.z + part.w;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -1605,7 +1717,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
         if(t0 + u64(j) * SPLIT_THREADS + tid < len)
         {
           const u32 at = tile_off[bkt[j]] + rank[j];
-          tile_value[at] = got[j]; tile_bucket[at] = (unsigned char)bkt[j];
+          tile_value[at] = got[j]; tile_bucket[at] = (unsigned short)bkt[j];
         }
       }
       __syncthreads();
@@ -1734,7 +1846,8 @@ __global__ __launch_bounds__(64) void k_sort_bucket(const u64* __restrict__ bkt_
   const u64 b = bkt_begin[blockIdx.x];
   const u32 len = u32(bkt_end[blockIdx.x] - b);
   if(len > MOST) { return; }                                  // (cannot be: k_over_split fills the lists by length)
-  report_dups(totals, sort_segment_by_wave<MOST>(source + b, values + b, len, lane), lane);
+  __shared__ u32 stage[MOST];                                 // (the transposition of the blocked 32-bit network)
+  report_dups(totals, sort_segment_by_wave<MOST>(source + b, values + b, len, lane, ~u64(0), stage), lane);
 }
 
 // Segments with more than BIG_SEGMENT distinct values whose split left a bucket too large (k_over_split's skew list), and every

@@ -63,6 +63,15 @@ def main():
         if args.cpu_only:
             print(line, flush=True)
             continue
+        # round 6: on every second graph the fused split of locate() takes ranges of a few dozen path nodes (its threshold is 8192)
+        # and the split aims at small buckets, so that the table-reading split, its LDS tiles and the run phase meet these graphs
+        for key in ("GCSA2_LOCATE_FUSE_ABOVE", "GCSA2_SPLIT_TARGET", "GCSA2_SPLIT_SKEW"):
+            os.environ.pop(key, None)
+        if seed % 2 == 1:
+            os.environ["GCSA2_LOCATE_FUSE_ABOVE"] = str((8, 64, 300)[seed % 3])
+            os.environ["GCSA2_SPLIT_TARGET"] = str((24, 256, 6)[(seed // 3) % 3])
+            if seed % 5 == 0:
+                os.environ["GCSA2_SPLIT_SKEW"] = "40"
         gpu, lcp = open_index(ix)
         assert np.array_equal(gpu.find_batch(data, off), c_find), (seed, "find")
         wide = np.array([[a, min(a + w, ix.n - 1)] for a, w in zip(mutate.integers(0, ix.n, size=3000), mutate.integers(0, 3000, size=3000))],
@@ -89,6 +98,7 @@ def main():
         fixed = [r for r in rows if len(r) == m and all(c in b"ACGT" for c in r)]
         fixed_arr = np.frombuffer(b"".join(fixed), dtype=np.uint8).reshape(len(fixed), m) if fixed else None
         dev = torch.device("cuda", 0)
+        raw_wide = sum(len(cpu.locate((int(a), int(b)), sort=False)) for a, b in wide)       # values before removeDuplicates
         for shape in (None, (int(mutate.integers(0, 2)), int(mutate.integers(0, 9)), int(mutate.integers(0, 2)))):
             if shape is not None:
                 gpu.set_tables(pair_blocks=shape[0], kmer_k=shape[1], locate_table=shape[2])
@@ -107,6 +117,12 @@ def main():
             d_v = torch.zeros(len(cv) + 1, dtype=torch.int64, device=dev)
             total = gpu.locate_into(d_r.data_ptr(), len(wide), d_o.data_ptr(), d_v.data_ptr(), d_v.shape[0])
             assert total == len(cv) and np.array_equal(d_o.cpu().numpy().view(np.uint64), co) and np.array_equal(d_v.cpu().numpy().view(np.uint64)[:total], cv), (seed, "locate_into", shape)
+            # round 6: a buffer with room for the values BEFORE deduplication is the sorts' work space and is compacted in place
+            raw = raw_wide
+            d_w = torch.full((raw + 3 + 32,), -1, dtype=torch.int64, device=dev)
+            total = gpu.locate_into(d_r.data_ptr(), len(wide), d_o.data_ptr(), d_w.data_ptr(), raw + 3)
+            assert total == len(cv) and np.array_equal(d_o.cpu().numpy().view(np.uint64), co) and np.array_equal(d_w.cpu().numpy().view(np.uint64)[:total], cv), (seed, "locate_into in place", shape)
+            assert bool((d_w[raw + 3:] == -1).all()), (seed, "locate_into wrote behind the capacity", shape)
         # round 5: every launch shape of both matching-statistics kernels (2 / 5: k_match_stats2, 6 / 7: k_match_stats3) on the device
         # buffers, and locate() of batches of one-node ranges (the one-kernel path when every node has one value, the pipeline otherwise)
         total_bytes = int(off[-1])
@@ -122,6 +138,11 @@ def main():
             torch.cuda.synchronize()
             assert np.array_equal(d_ms[:total_bytes].cpu().numpy().view(np.uint16), cm), (seed, "match_stats variant", variant)
             assert np.array_equal(d_rng.cpu().numpy().view(np.uint64), cr) and np.array_equal(d_fb.cpu().numpy().view(np.uint64), cf), (seed, "variant tail", variant)
+        # round 6: one-query calls (the resident wavefront of kernels_mailbox.hpp answers them)
+        for (a, b), c in zip(wide[:60], comps[:60]):
+            r = (int(a), int(b))
+            assert gpu.LF(r, int(c)) == cpu.LF(r, int(c)), (seed, "scalar LF", r, int(c))
+            assert gpu.count(r) == cpu.count(r) and lcp.parent(r) == cpu.parent(r), (seed, "scalar count / parent", r)
         nodes = mutate.integers(0, ix.n, size=4000).astype(np.uint64)
         singles = np.stack([nodes, nodes], axis=1)
         so, sv = cpu.locate_batch(singles)
