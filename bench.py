@@ -2088,8 +2088,7 @@ def one_number(key, leg):
         if isinstance(v, dict) and "value" in v:
             out[short(k, 40)] = {"queries_per_s": v["value"], "served": v.get("served", v.get("roofline", {}).get("served"))}
             if isinstance(v.get("locate"), dict) and "ms_per_step" in v["locate"]:       # locate() of the leg's ranges: call time, algorithmic fraction of 8 TB/s
-                out[short(k, 40)].update(locate_ms=v["locate"]["ms_per_step"], locate_frac=v["locate"].get("roofline", {}).get("frac"),
-                                         locate_traffic_over_algorithmic=v["locate"].get("roofline", {}).get("traffic_over_algorithmic"))
+                out[short(k, 40)].update(locate_ms=v["locate"]["ms_per_step"], locate_frac=v["locate"].get("roofline", {}).get("frac"))
     return out
 
 
@@ -2104,7 +2103,7 @@ def compact_line(full):
     cfg["parallelism"] = short(cfg.get("parallelism", ""), 160)
     out["config"] = cfg
     rf = dict(full["roofline"])
-    for k in ("working_set_note", "traffic_source_note", "traffic_GBps", "traffic_frac_of_measured_hbm_rate"):
+    for k in ("working_set_note", "traffic_source_note", "traffic_GBps", "traffic_frac_of_measured_hbm_rate", "traffic_lookup", "requests_per_distinct_line"):
         rf.pop(k, None)
     if "request_rate" in rf:
         rf["request_rate"] = {k: v for k, v in rf["request_rate"].items() if k != "ceiling_source"}
