@@ -134,7 +134,6 @@ struct gcsa2_index
     bool locate_fuse = true;           // GCSA2_LOCATE_FUSE=0: wide ranges of one-value path nodes go through the table pass like the others (A/B; round 6)
     u64 fuse_above = BIG_SEGMENT;      // GCSA2_LOCATE_FUSE_ABOVE (tests): path nodes from which such a range is a candidate for the fused split
     bool split_tiled = true;           // GCSA2_SPLIT_TILED=0: k_over_split scatters value by value, as in round 5 (A/B; round 6)
-    u32 split_debug = 0;               // GCSA2_SPLIT_DEBUG (timing only, WRONG results): timing only, WRONG results: bit 0 no scatter stores, bit 1 no run phase, bit 2 no scatter pass, bit 3 no histogram atomics
     bool mailbox = true;               // GCSA2_MAILBOX=0: one-query calls of LF / count / parent / LF(node) take the launch path like any batch (A/B; round 6)
     u64 mailbox_park_us = 200;         // GCSA2_MAILBOX_PARK_US: the resident wavefront leaves after this long without a request
     u64 mailbox_life_ms = 20;          // GCSA2_MAILBOX_LIFE_MS: ... and after this long whatever happens (the next call launches it again)
@@ -837,7 +836,6 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.mailbox = (knob("GCSA2_MAILBOX", 1, 0, 1) != 0);
     ix->tune.mailbox_park_us = u64(knob("GCSA2_MAILBOX_PARK_US", 200, 1, 1000000));
     ix->tune.mailbox_life_ms = u64(knob("GCSA2_MAILBOX_LIFE_MS", 20, 1, 10000));
-    ix->tune.split_debug = u32(knob("GCSA2_SPLIT_DEBUG", 0, 0, 15));
     ix->tune.split_tiled = (knob("GCSA2_SPLIT_TILED", 1, 0, 1) != 0);
     ix->tune.locate_split_sort = (knob("GCSA2_LOCATE_SPLIT_SORT", 1, 0, 1) != 0);
     ix->tune.split_skew = u32(knob("GCSA2_SPLIT_SKEW", BIG_SEGMENT, 16, BIG_SEGMENT));
@@ -1783,12 +1781,12 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     if(ix->tune.split_tiled)
     {
       hipLaunchKernelGGL(k_over_split<true>, dim3(unsigned(over)), dim3(SPLIT_THREADS), 0, stream, over_begin, over_end, sorted, split_tmp,
-                         bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target, bucket_cap - 1, over_src, ix->tune.split_debug, mid_begin, mid_end);
+                         bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target, bucket_cap - 1, over_src, mid_begin, mid_end);
     }
     else
     {
       hipLaunchKernelGGL(k_over_split<false>, dim3(unsigned(over)), dim3(SPLIT_THREADS), 0, stream, over_begin, over_end, sorted, split_tmp,
-                         bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target, bucket_cap - 1, over_src, ix->tune.split_debug, mid_begin, mid_end);
+                         bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target, bucket_cap - 1, over_src, mid_begin, mid_end);
     }
     LAUNCH_CHECK("k_over_split");
     rc = read_totals(ix, slot, totals, stream);

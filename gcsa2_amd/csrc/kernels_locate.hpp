@@ -1480,12 +1480,15 @@ __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __
 // bitonic sort took 22 ms for them: 66 barriers per bucket, profiles/r05_locate.md).  A bucket of more than 64 values is
 // listed for the workgroup sort (k_sort_big reads `scratch`, writes `values`), one of more than `skew_above` values -- values
 // crowded into a small part of the segment's span -- goes on the `skew` list, which the host hands to that radix sort as before.
-constexpr int SPLIT_THREADS = 1024;
+#ifndef GCSA2_SPLIT_THREADS
+#define GCSA2_SPLIT_THREADS 1024
+#endif
+constexpr int SPLIT_THREADS = GCSA2_SPLIT_THREADS;
 constexpr u32 SPLIT_BUCKETS_UNTILED = 4096;
 // Round 6, TILED: the scatter goes through LDS a tile of SPLIT_TILE values at a time.  Untiled, the 64 lanes of a store
 // instruction hit ~50 different buckets: 64 eight-byte write requests where a copy sends a few lines.  The L2 merges them, but
 // it takes REQUESTS at a fixed rate: with the stores switched off the kernel took 1.7 of its 4.4 ms on the 16-mer batch of the
-// 2^30-base text (GCSA2_SPLIT_DEBUG=1; profiles/r06_locate.md).  Tiled, the workgroup counts the tile's values per bucket (the
+// 2^30-base text (profiles/r06_locate.md; the knock-out knob is profiles/r06_locate/split_debug.patch).  Tiled, the workgroup counts the tile's values per bucket (the
 // LDS atomics that also rank a value inside its bucket), every wavefront scans the counts for itself (four per lane, one
 // 16-byte read; all write the same offsets, so no barrier), the values are placed bucket by bucket in an LDS buffer and written
 // out in that order: neighbouring lanes hold neighbouring values of one bucket, SPLIT_TILE / buckets of them in a row.  Three
@@ -1499,7 +1502,7 @@ constexpr u32 SPLIT_BUCKETS_UNTILED = 4096;
 #define GCSA2_TILED_BUCKETS 512
 #endif
 constexpr u32 SPLIT_TILED_BUCKETS = GCSA2_TILED_BUCKETS;
-constexpr u32 SPLIT_TILE_PER = 4, SPLIT_TILE = 1024 * SPLIT_TILE_PER;
+constexpr u32 SPLIT_TILE_PER = 4, SPLIT_TILE = u32(SPLIT_THREADS) * SPLIT_TILE_PER;
 constexpr u32 SPLIT_SAMPLE = 8192;             // values whose minimum and maximum stand for the segment's
 constexpr u32 SPLIT_AHEAD = 4;                 // independent loads per lane in the streaming passes
 constexpr u32 SPLIT_RUNS_AHEAD = 3;           // runs of buckets whose values a wavefront has requested ahead of the one it sorts
@@ -1522,7 +1525,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
                                                              u64* values, u64* scratch, u64* __restrict__ bkt_begin, u64* __restrict__ bkt_end,
                                                              u64* __restrict__ skew_begin, u64* __restrict__ skew_end,
                                                              unsigned long long* __restrict__ totals, u32 skew_above, u32 target, u64 bucket_last,
-                                                             const u64* const* __restrict__ over_src, u32 debug,
+                                                             const u64* const* __restrict__ over_src,
                                                              u64* __restrict__ mid_begin, u64* __restrict__ mid_end)
 {
   // (the tiled form never has more than SPLIT_TILED_BUCKETS buckets: its cursor / start arrays are as long as the workgroup)
@@ -1586,7 +1589,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
 #pragma unroll
     for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? (src[i] & KEEP) : lo); }
 #pragma unroll
-    for(u32 j = 0; j < SPLIT_AHEAD; j++) { if(i0 + u64(j) * SPLIT_THREADS < len && !(debug & 8)) { atomicAdd(&cursor[bucket_of(got[j])], 1u); } }
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { if(i0 + u64(j) * SPLIT_THREADS < len) { atomicAdd(&cursor[bucket_of(got[j])], 1u); } }
   }
   __syncthreads();
   // exclusive prefix sums of the counts: PER_THREAD consecutive buckets per thread, then across the wavefront and the workgroup
@@ -1652,14 +1655,14 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   }
   if constexpr(TILED)
   {
-    static_assert(SPLIT_TILED_BUCKETS % 256 == 0 && SPLIT_TILED_BUCKETS <= SPLIT_THREADS && SPLIT_THREADS == 1024, "counts per lane in groups of four; a thread owns a bucket");
+    static_assert(SPLIT_TILED_BUCKETS % 256 == 0 && SPLIT_TILED_BUCKETS <= SPLIT_THREADS, "counts per lane in groups of four; a thread owns a bucket");
     if(tid < SPLIT_TILED_BUCKETS) { tile_count[0][tid] = 0; tile_count[1][tid] = 0; }
     __syncthreads();
     u64 next[SPLIT_TILE_PER];
 #pragma unroll
     for(u32 j = 0; j < SPLIT_TILE_PER; j++) { const u64 i = u64(j) * SPLIT_THREADS + tid; next[j] = (i < len ? src[i] : 0); }
     u32 which = 0;
-    for(u64 t0 = 0; t0 < len && !(debug & 4); t0 += SPLIT_TILE, which ^= 1u)
+    for(u64 t0 = 0; t0 < len; t0 += SPLIT_TILE, which ^= 1u)
     {
       u32* __restrict__ count = tile_count[which];
       u64 got[SPLIT_TILE_PER];
@@ -1726,7 +1729,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
       for(u32 j = 0; j < SPLIT_TILE_PER; j++)
       {
         const u32 at = j * SPLIT_THREADS + tid;
-        if(at < here && !(debug & 1)) { scratch[b + u32(tile_delta[tile_bucket[at]] + at)] = tile_value[at]; }
+        if(at < here) { scratch[b + u32(tile_delta[tile_bucket[at]] + at)] = tile_value[at]; }
       }
       __syncthreads();
       // the owners move the buckets' cursors on and clear this tile's counts (the next tile counts in the other array)
@@ -1734,7 +1737,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
     }
   }
   else
-  for(u64 i0 = tid; i0 < len && !(debug & 4); i0 += SPLIT_AHEAD * SPLIT_THREADS)
+  for(u64 i0 = tid; i0 < len; i0 += SPLIT_AHEAD * SPLIT_THREADS)
   {
     u64 got[SPLIT_AHEAD];
 #pragma unroll
@@ -1744,8 +1747,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
     {
       if(i0 + u64(j) * SPLIT_THREADS < len)
       {
-        const u32 at = atomicAdd(&cursor[bucket_of(got[j])], 1u);
-        if(!(debug & 1)) { scratch[b + at] = got[j]; }
+        scratch[b + atomicAdd(&cursor[bucket_of(got[j])], 1u)] = got[j];
       }
     }
   }
@@ -1800,7 +1802,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   for(u32 d = 0; d < SPLIT_RUNS_AHEAD; d++)
   {
     run_first[d] = 0; run_count[d] = 0; run_base[d] = NO_BASE;
-    live[d] = !(debug & 2) && next_run(run_first[d], run_count[d], run_base[d]);
+    live[d] = next_run(run_first[d], run_count[d], run_base[d]);
     run_value[d] = (live[d] && lane < run_count[d] ? scratch[b + run_first[d] + lane] : ~u64(0));
   }
   u32 run_dups = 0;
