@@ -1645,8 +1645,17 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   const u64 nwords = total_raw / 64 + 1;
   // Round 6: a caller's buffer that holds the values BEFORE deduplication is the target of the table pass and of every sort;
   // when no sort meets a duplicate (the flag totals[T_DUPS]) the values are final where they lie, at the offsets of the size
-  // scan, and nothing is compacted; otherwise k_mark_compact compacts in place.  (A buffer sized for the distinct values only,
-  // and the job interface, keep the scratch array and the out-of-place compaction.)
+  // scan, and nothing is compacted; otherwise k_mark_compact compacts in place.  (A buffer sized for the distinct values only
+  // keeps the scratch array and the out-of-place compaction.)
+  // The job interface (the library makes the value buffer) takes the same path when the values before deduplication are at most
+  // 2^30 (8 GB): the buffer is then made for THEM, before the sorts instead of behind them -- a job's buffer may be longer than
+  // its `total`.
+  if(known_out == nullptr && ix->tune.locate_fused_compact && ix->tune.locate_in_place && total_raw <= (u64(1) << 30))
+  {
+    u64* made = values_for(total_raw);
+    if(made == nullptr) { return g_error.empty() ? fail(GCSA2_ERR_BUFFER_TOO_SMALL, "values buffer too small") : GCSA2_ERR_BUFFER_TOO_SMALL; }
+    known_out = made; known_capacity = total_raw;
+  }
   const bool in_place = (known_out != nullptr && ix->tune.locate_fused_compact && ix->tune.locate_in_place && total_raw <= known_capacity);
   if(in_place) { sorted = known_out; } else { HIP_TRY(scratch.get(sorted, total_raw)); }
   bool force_compact = !in_place;

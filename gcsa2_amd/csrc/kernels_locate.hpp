@@ -1489,15 +1489,16 @@ constexpr u32 SPLIT_BUCKETS_UNTILED = 4096;
 // instruction hit ~50 different buckets: 64 eight-byte write requests where a copy sends a few lines.  The L2 merges them, but
 // it takes REQUESTS at a fixed rate: with the stores switched off the kernel took 1.7 of its 4.4 ms on the 16-mer batch of the
 // 2^30-base text (profiles/r06_locate.md; the knock-out knob is profiles/r06_locate/split_debug.patch).  Tiled, the workgroup counts the tile's values per bucket (the
-// LDS atomics that also rank a value inside its bucket), every wavefront scans the counts for itself (four per lane, one
-// 16-byte read; all write the same offsets, so no barrier), the values are placed bucket by bucket in an LDS buffer and written
-// out in that order: neighbouring lanes hold neighbouring values of one bucket, SPLIT_TILE / buckets of them in a row.  Three
-// barriers per tile; the next tile's values are requested before the current one is worked on.  At most SPLIT_TILED_BUCKETS = 256
-// buckets, whatever the segment's length: the scan is then one 16-byte read per lane, and a segment beyond 65 536 values gets
-// longer buckets -- up to 512 values a wavefront sorts in eight registers per lane, up to 1024 in sixteen (lists of their own),
-// beyond that the workgroup sort.  (Tried: 1024 buckets through the tiles with sixteen counts per lane: 2.8 -> 3.9 ms on the
-// 16-mer batch, every wavefront reads and writes 8 KB of counts per tile; tiles for the segments of up to 256 buckets and the
-// value-by-value scatter beyond: 7.43 / 6.58 ms for the two batches against 7.00 / 6.22 with every segment through the tiles.)
+// LDS atomics that also rank a value inside its bucket), every wavefront scans the counts for itself (eight per lane, two
+// 16-byte reads, twice: the lane's total, then -- after the scan over the lanes -- the offsets; all wavefronts write the same
+// offsets, so no barrier), the values are placed bucket by bucket in an LDS buffer and written out in that order: neighbouring
+// lanes hold neighbouring values of one bucket, SPLIT_TILE / buckets of them in a row.  Three barriers per tile; the next
+// tile's values are requested before the current one is worked on.  At most SPLIT_TILED_BUCKETS = 512 buckets, whatever the
+// segment's length: a segment beyond 131 072 values gets longer buckets -- up to 512 values a wavefront sorts in eight
+// registers per lane, up to 1024 in sixteen (lists of their own), beyond that the workgroup sort.  (The series, 16-mer /
+// 32-mer batch, profiles/r06_locate.md: 256 buckets 6.84 / 6.34 ms, 512 buckets 6.82 / 6.04, 1024 buckets 7.72 / 6.79 -- every
+// wavefront reads and writes 8 KB of counts per tile --; counts held in registers across the scan cost the second workgroup
+// per CU; workgroups of 512 threads 6.99 / 5.25; tiles only for segments of up to 256 buckets 7.43 / 6.58.)
 #ifndef GCSA2_TILED_BUCKETS
 #define GCSA2_TILED_BUCKETS 512
 #endif
