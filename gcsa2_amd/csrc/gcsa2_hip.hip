@@ -121,6 +121,7 @@ struct gcsa2_index
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
     bool pipe_wide = false;            // GCSA2_PIPE_WIRE=16: the packed-pattern pipeline brings the ranges home as u64 pairs (A/B)
     bool ms_pieces = true;             // GCSA2_MS_PIECES=0: large host batches of matching statistics go through one copy in, one launch, one copy out
+    bool dedup_narrow = true;          // GCSA2_DEDUP_NARROW=0: the duplicate filter's hash table holds 64-bit words even when the index's values fit 32 bits
     bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the device-wide radix sort, duplicates and all
     bool zero_copy = true;             // GCSA2_ZERO_COPY=0: small host-pointer calls copy through the arenas like large ones
     bool poll_small = true;            // GCSA2_POLL_SMALL=0: zero-copy calls end with hipStreamSynchronize instead of a polled ticket
@@ -818,6 +819,7 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.zero_copy = (knob("GCSA2_ZERO_COPY", 1, 0, 1) != 0);
     ix->tune.poll_small = (knob("GCSA2_POLL_SMALL", 1, 0, 1) != 0);
     ix->tune.dedup_huge = (knob("GCSA2_DEDUP_HUGE", 1, 0, 1) != 0);
+    ix->tune.dedup_narrow = (knob("GCSA2_DEDUP_NARROW", 1, 0, 1) != 0);
     ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 6, 1, 16));
     ix->tune.pipe_chunk = u64(1) << knob("GCSA2_PIPE_CHUNK", 18, 15, 20);
     ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);
@@ -1690,6 +1692,16 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   // over (segment, value) keys.  Then flag + scan + compact.
   u64 over = totals[T_OVER], over_values = totals[T_OVER_VALUES];      // (the fused ranges: k_collect_multi listed them)
   const u64 huge = huge_a + huge_b;
+  // the slots behind the distinct values of a filtered segment are marked in a bitmap instead of being filled and read again
+  // (k_dedup_huge, k_mark_compact) -- when the one-sweep compaction is the one that will run
+  // (an index whose values lie below 2^32 -- samples of at most 31 bits + fewer than 2^23 steps -- gets the 32-bit hash table)
+  const bool narrow_values = (ix->img.sample_width <= 31 && ix->tune.dedup_narrow);
+  unsigned long long* dead = nullptr;
+  if(huge > 0 && ix->tune.dedup_huge && known_out != nullptr && ix->tune.locate_fused_compact)
+  {
+    HIP_TRY(scratch.get(dead, nwords));
+    HIP_TRY(hipMemsetAsync(dead, 0, nwords * sizeof(unsigned long long), stream));
+  }
   if(huge > 0 && !ix->tune.dedup_huge)
   {
     // (A/B knob: no duplicate filter; every segment of more than BIG_SEGMENT values -- all on the second list -- goes to the radix sort)
@@ -1702,14 +1714,24 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   }
   else if(huge_a > 0)
   {
-    hipLaunchKernelGGL((k_dedup_huge<BIG_SEGMENT, false, 512>), dim3(unsigned(huge_a)), dim3(512), 0, stream, huge_begin, huge_end, nq - 1, sorted, nq,
-                       medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end, over_src);
+    // (64-bit words for the short segments whatever the index: with 32-bit words -- 32 KB, five workgroups on a CU instead of two --
+    // this kernel was SLOWER on the 2^23 repeat graph, 0.81 against 0.62 ms for the 32-mer batch; the long segments' kernel gains, 3.6 -> 2.9 ms)
+    hipLaunchKernelGGL((k_dedup_huge<BIG_SEGMENT, false, 512, unsigned long long>), dim3(unsigned(huge_a)), dim3(512), 0, stream, huge_begin, huge_end, nq - 1, sorted, nq,
+                       medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end, over_src, dead);
     LAUNCH_CHECK("k_dedup_huge");
   }
   if(huge_b > 0 && ix->tune.dedup_huge)
   {
-    hipLaunchKernelGGL((k_dedup_huge<2 * BIG_SEGMENT, true, 1024>), dim3(unsigned(huge_b)), dim3(1024), 0, stream, huge_begin, huge_end, nq - 1, sorted, nq,
-                       medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end, over_src);
+    if(narrow_values)
+    {
+      hipLaunchKernelGGL((k_dedup_huge<2 * BIG_SEGMENT, true, 1024, u32>), dim3(unsigned(huge_b)), dim3(1024), 0, stream, huge_begin, huge_end, nq - 1, sorted, nq,
+                         medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end, over_src, dead);
+    }
+    else
+    {
+      hipLaunchKernelGGL((k_dedup_huge<2 * BIG_SEGMENT, true, 1024, unsigned long long>), dim3(unsigned(huge_b)), dim3(1024), 0, stream, huge_begin, huge_end, nq - 1, sorted, nq,
+                         medium_limit, d_totals, seg_begin, seg_end, over_begin, over_end, over_src, dead);
+    }
     LAUNCH_CHECK("k_dedup_huge");
     stamp(2);
     rc = read_totals(ix, slot, totals, stream);          // only these segments can overflow
@@ -1850,7 +1872,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
     HIP_TRY(hipMemsetAsync(words, 0, nwords * sizeof(u64), stream));
     hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nq)), dim3(TPB), 0, stream, raw_off, nq, words);
     hipLaunchKernelGGL(k_mark_compact, dim3(unsigned(tiles)), dim3(COMPACT_THREADS), 0, stream, sorted, total_raw, nwords, words, word_before,
-                       known_out, known_capacity, tile_status, reinterpret_cast<unsigned int*>(tile_status + tiles), d_totals + T_UNIQUE);
+                       known_out, known_capacity, tile_status, reinterpret_cast<unsigned int*>(tile_status + tiles), d_totals + T_UNIQUE, reinterpret_cast<const u64*>(dead));
     LAUNCH_CHECK("k_mark_starts / k_mark_compact");
     hipLaunchKernelGGL(k_final_offsets, dim3(grid_for(nq + 1)), dim3(TPB), 0, stream, words, word_before, nq, total_raw, nwords, d_offsets);
     LAUNCH_CHECK("k_final_offsets");

@@ -1018,15 +1018,22 @@ constexpr u64 HUGE_EMPTY = ~u64(0);
 // (Reading the locate table from this kernel instead of the walk's output -- the raw values of these queries never written --
 // was measured: 8.7 against 5.9 ms for the repeat-rich batch.  One or two workgroups per CU do not hide the latency of the
 // table gathers; the walk kernel with a lane per path node does.)
-template<u32 HUGE_SLOTS, bool FROM_END, int HUGE_THREADS>
+// WORD (round 6): the table's slot type.  unsigned long long: any value.  u32: an index whose values lie below 2^32 - 1 (the host
+// knows: sample_width <= 31) -- the compare-and-swap chains are what this kernel waits for, a 32-bit one is issued at twice the
+// rate, and the table of the long segments is 64 KB instead of 128, so that two workgroups share a CU; a value that does not fit
+// makes the segment overflow to the split sort (a detour, never a wrong result).
+template<u32 HUGE_SLOTS, bool FROM_END, int HUGE_THREADS, class WORD>
 __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restrict__ huge_begin, const u64* __restrict__ huge_end, u64 last,
                                                             u64* __restrict__ values, u64 nq, u32 medium_limit,
                                                             unsigned long long* __restrict__ totals,
                                                             u64* __restrict__ seg_begin, u64* __restrict__ seg_end,
-                                                            u64* __restrict__ over_begin, u64* __restrict__ over_end, const u64** __restrict__ over_src)
+                                                            u64* __restrict__ over_begin, u64* __restrict__ over_end, const u64** __restrict__ over_src,
+                                                            unsigned long long* __restrict__ dead)
 {
-  __shared__ unsigned long long table[HUGE_SLOTS];
-  __shared__ u32 distinct, has_ones, placed;
+  __shared__ WORD table[HUGE_SLOTS];
+  constexpr WORD EMPTY = WORD(~WORD(0));
+  constexpr bool NARROW = (sizeof(WORD) == 4);
+  __shared__ u32 distinct, has_ones, too_wide;
   __shared__ unsigned long long largest;
   const u32 tid = threadIdx.x;
   const u64 at = (FROM_END ? last - blockIdx.x : u64(blockIdx.x));
@@ -1037,7 +1044,8 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   // ends.  Round 3 filled the table to HUGE_SLOTS - HUGE_THREADS first: linear probing at a load of 0.94 under 1024 lanes of
   // LDS atomics made every all-distinct segment cost a millisecond, 93 ms of a 134 ms batch; profiles/r04_locate.md.)
   constexpr u32 STOP = MOST + 1;
-  static_assert(MOST + 1 + HUGE_THREADS < HUGE_SLOTS, "the table must keep free slots");
+  constexpr u32 AHEAD = 4;                                    // values a lane has loaded before it inserts the first of them
+  static_assert(MOST + 1 + AHEAD * HUGE_THREADS < HUGE_SLOTS, "the table must keep free slots");
   // A look at a SAMPLE first (round 5): 512 values at equal distances.  When no two of them are equal the segment almost
   // certainly has more than MOST distinct values -- with D <= 8192 distinct values among 512 random positions ~16 equal pairs
   // are expected, none with probability e^-16 -- and is listed for the split sort at once: a wrong guess costs time there, never
@@ -1045,20 +1053,31 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   // had cleared 128 KB of LDS and inserted ~10 000 values: 0.9 of the batch's 12.8 ms, 1.2 GB read for nothing.)
   constexpr u32 SAMPLE = 512, SAMPLE_SLOTS = 2048;
   static_assert(SAMPLE <= HUGE_THREADS && SAMPLE_SLOTS <= HUGE_SLOTS, "the sample uses the front of the table");
+  // (the first values of every lane are requested BEFORE the sample is looked at: their round trip passes behind it; a segment
+  // the sample sends away has read 32 KB for nothing)
+  const u64 items = len;
+  u64 got[AHEAD];
+#pragma unroll
+  for(u32 j = 0; j < AHEAD; j++)
+  {
+    const u64 i = u64(tid) + u64(j) * HUGE_THREADS;
+    got[j] = 0;
+    if(i < items) { got[j] = values[b + i]; }
+  }
   if(len > MOST)                                              // (uniform; otherwise the segment cannot overflow)
   {
-    for(u32 i = tid; i < SAMPLE_SLOTS; i += HUGE_THREADS) { table[i] = HUGE_EMPTY; }
+    for(u32 i = tid; i < SAMPLE_SLOTS; i += HUGE_THREADS) { table[i] = EMPTY; }
     if(tid == 0) { distinct = 0; }
     __syncthreads();
     if(tid < SAMPLE)
     {
       const u64 v = values[b + (u64(tid) * len) / SAMPLE];
       u32 slot = u32((v * 0x9E3779B97F4A7C15ull) >> 32) & (SAMPLE_SLOTS - 1);
-      while(v != HUGE_EMPTY)
+      while(v != HUGE_EMPTY && !(NARROW && v >= u64(EMPTY)))
       {
-        const unsigned long long prev = atomicCAS(&table[slot], HUGE_EMPTY, (unsigned long long)v);
-        if(prev == HUGE_EMPTY) { break; }
-        if(prev == v) { atomicAdd(&distinct, 1u); break; }    // (here: equal pairs seen)
+        const WORD prev = atomicCAS(&table[slot], EMPTY, WORD(v));
+        if(prev == EMPTY) { break; }
+        if(prev == WORD(v)) { atomicAdd(&distinct, 1u); break; }    // (here: equal pairs seen)
         slot = (slot + 1) & (SAMPLE_SLOTS - 1);
       }
     }
@@ -1076,36 +1095,44 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
       return;
     }
   }
-  for(u32 i = tid; i < HUGE_SLOTS; i += HUGE_THREADS) { table[i] = HUGE_EMPTY; }
-  if(tid == 0) { distinct = 0; has_ones = 0; placed = 0; largest = 0; }
+  for(u32 i = tid; i < HUGE_SLOTS; i += HUGE_THREADS) { table[i] = EMPTY; }
+  if(tid == 0) { distinct = 0; has_ones = 0; largest = 0; too_wide = 0; }
   __syncthreads();
   auto insert = [&](u64 v)
   {
     if(v == HUGE_EMPTY) { has_ones = 1; return; }
+    if(NARROW && v >= u64(EMPTY)) { too_wide = 1; return; }                    // (not an index this instantiation was chosen for: overflow)
     if(*reinterpret_cast<volatile u32*>(&distinct) >= STOP) { return; }        // the segment has overflowed
     u32 slot = u32((v * 0x9E3779B97F4A7C15ull) >> 32) & (HUGE_SLOTS - 1);
     while(true)
     {
-      const unsigned long long prev = atomicCAS(&table[slot], HUGE_EMPTY, (unsigned long long)v);
-      if(prev == HUGE_EMPTY) { atomicAdd(&distinct, 1u); break; }
-      if(prev == v) { break; }
+      const WORD prev = atomicCAS(&table[slot], EMPTY, WORD(v));
+      if(prev == EMPTY) { atomicAdd(&distinct, 1u); break; }
+      if(prev == WORD(v)) { break; }
       slot = (slot + 1) & (HUGE_SLOTS - 1);
     }
   };
-  const u64 items = len;
   // no barrier inside the loop: insert() stops by itself before the table fills, and whether the segment overflowed is
-  // only asked at the end; four independent loads per lane are in flight before the first insertion
-  constexpr u32 AHEAD = 4;
+  // only asked at the end; AHEAD independent loads per lane are in flight before the first insertion.
+  // Round 6 timed the phases of this kernel on the 16-mer batch of the 2^23 repeat graph (45 900 segments of ~12 000 values, two
+  // workgroups per CU; profiles/r06_locate.md section 6): launch + the list entry 0.53 ms, + the loads 0.9, + the insertions 2.1-2.4,
+  // + the sample 0.3, + sweep, tail and listing 0.9-1.7.  What did NOT move the insertions: a 32-bit table (half the LDS, a
+  // compare-and-swap of half the width), a plain read of the slot before the compare-and-swap, neither counter operation removed
+  // (2.47 -> 2.28 without both), the count of distinct values kept per wavefront (2.09 -> 2.53), the next group requested before
+  // this one is inserted (2.09 -> 2.37).  Every phase of a workgroup waits for the one before it and only two workgroups share a
+  // CU: the kernel is a chain of latencies, not a rate.
   for(u64 base = tid; base < items; base += AHEAD * HUGE_THREADS)
   {
     if(*reinterpret_cast<volatile u32*>(&distinct) >= STOP) { break; }           // overflowed: nothing more to learn
-    u64 got[AHEAD];
-#pragma unroll
-    for(u32 j = 0; j < AHEAD; j++)
+    if(base != tid)
     {
-      const u64 i = base + u64(j) * HUGE_THREADS;
-      got[j] = 0;
-      if(i < items) { got[j] = values[b + i]; }
+#pragma unroll
+      for(u32 j = 0; j < AHEAD; j++)
+      {
+        const u64 i = base + u64(j) * HUGE_THREADS;
+        got[j] = 0;
+        if(i < items) { got[j] = values[b + i]; }
+      }
     }
 #pragma unroll
     for(u32 j = 0; j < AHEAD; j++)
@@ -1114,7 +1141,7 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
     }
   }
   __syncthreads();
-  const bool overflow = (distinct + has_ones > MOST);          // uniform: read after the barrier
+  const bool overflow = (distinct + has_ones > MOST || too_wide != 0);          // uniform: read after the barrier
   if(overflow)
   {
     if(tid == 0)
@@ -1125,36 +1152,82 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
     }
     return;
   }
-  unsigned long long mine = 0;
-  for(u32 i = tid; i < HUGE_SLOTS; i += HUGE_THREADS)
+  // (the count is final: the segment is listed for its sort NOW, so that the device-wide atomics' round trips pass while the
+  // table is swept -- with one or two workgroups on a CU nobody else would hide them)
+  if(tid == 0)
   {
-    const unsigned long long v = table[i];
-    if(v != HUGE_EMPTY)
+    const u32 final_count = distinct + (has_ones ? 1u : 0u);
+    if(len > final_count) { flag_dups(totals + T_DUPS, 1u); }      // (the tail: duplicates, or dead slots -- either way the values are not final where they lie)
+    if(final_count >= 2)
     {
-      values[b + atomicAdd(&placed, 1u)] = v;
+      if(final_count <= medium_limit && medium_limit > SMALL_SEGMENT)
+      {
+        const u64 slot = atomicAdd(totals + T_MEDIUM, 1ull);
+        seg_begin[nq - 1 - slot] = b; seg_end[nq - 1 - slot] = b + final_count;
+      }
+      else
+      {
+        const u64 slot = atomicAdd(totals + T_LARGE, 1ull);
+        seg_begin[slot] = b; seg_end[slot] = b + final_count;
+      }
+    }
+  }
+  // The table is swept ONCE into registers; a scan over the workgroup's counts places every lane's values (round 6: sixteen
+  // rounds of an LDS atomic on the one cursor, each waited for, were a quarter of this kernel).
+  unsigned long long mine = 0;
+  static_assert(HUGE_SLOTS % HUGE_THREADS == 0, "the sweep over the table has a uniform trip count");
+  constexpr u32 PER_LANE = HUGE_SLOTS / HUGE_THREADS, HUGE_WAVES = HUGE_THREADS / 64;
+  __shared__ u32 wave_total[HUGE_WAVES];
+  WORD held[PER_LANE];
+  u32 occupied = 0;
+#pragma unroll
+  for(u32 k = 0; k < PER_LANE; k++) { held[k] = table[tid + k * HUGE_THREADS]; occupied += u32(held[k] != EMPTY); }
+  u32 upto = occupied;                                        // inclusive scan over the wavefront
+#pragma unroll
+  for(u32 d = 1; d < 64; d <<= 1) { const u32 other = __shfl_up(upto, d); if((tid & 63) >= d) { upto += other; } }
+  if((tid & 63) == 63) { wave_total[tid >> 6] = upto; }
+  __syncthreads();
+  u32 put = upto - occupied;
+  for(u32 w = 0; w < (tid >> 6); w++) { put += wave_total[w]; }
+#pragma unroll
+  for(u32 k = 0; k < PER_LANE; k++)
+  {
+    if(held[k] != EMPTY)
+    {
+      const unsigned long long v = (unsigned long long)held[k];
+      values[b + put++] = v;
       mine = (v > mine ? v : mine);
     }
   }
-  atomicMax(&largest, mine);
+  if(dead == nullptr)                                         // (the largest value fills the tail below; with the bitmap nobody asks)
+  {
+#pragma unroll
+    for(u32 d = 32; d > 0; d >>= 1) { const unsigned long long other = __shfl_xor(mine, int(d)); mine = (other > mine ? other : mine); }
+    if((tid & 63) == 0) { atomicMax(&largest, mine); }
+  }
   __syncthreads();
   u32 count = distinct;
   unsigned long long top = largest;
   if(has_ones) { if(tid == 0) { values[b + count] = HUGE_EMPTY; } count++; top = HUGE_EMPTY; }
-  for(u64 i = count + tid; i < len; i += HUGE_THREADS) { values[b + i] = top; }
-  if(tid == 0 && len > count) { flag_dups(totals + T_DUPS, 1u); }      // (the filled tail repeats `top`)
-  if(tid == 0 && count >= 2)
+  // The rest of the segment holds nothing: with the bitmap `dead` (round 6; the one-sweep compaction reads it) its slots are
+  // marked, a word of 64 slots at a time, and neither written here nor read there -- four raw values in five on a repeat-rich
+  // graph; without it (the four-kernel compaction) they are filled with the largest value, duplicates the marks then drop.
+  if(dead != nullptr)
   {
-    if(count <= medium_limit && medium_limit > SMALL_SEGMENT)
+    const u64 first = b + count, end = b + len;                 // dead slots: [first, end)
+    if(first < end)
     {
-      const u64 slot = atomicAdd(totals + T_MEDIUM, 1ull);
-      seg_begin[nq - 1 - slot] = b; seg_end[nq - 1 - slot] = b + count;
-    }
-    else
-    {
-      const u64 slot = atomicAdd(totals + T_LARGE, 1ull);
-      seg_begin[slot] = b; seg_end[slot] = b + count;
+      const u64 w0 = first >> 6, w1 = (end - 1) >> 6;
+      for(u64 w = w0 + tid; w <= w1; w += HUGE_THREADS)
+      {
+        unsigned long long bits = ~0ull;
+        if(w == w0) { bits &= ~0ull << (first & 63); }
+        if(w == w1 && (end & 63) != 0) { bits &= ~(~0ull << (end & 63)); }
+        if(w == w0 || w == w1) { atomicOr(dead + w, bits); } else { dead[w] = bits; }      // (the edge words are shared with the neighbours)
+      }
     }
   }
+  else { for(u64 i = count + tid; i < len; i += HUGE_THREADS) { values[b + i] = top; } }
 }
 
 // one lane per query with 2..SMALL_SEGMENT values: bitonic network over registers, in place
@@ -1978,7 +2051,7 @@ constexpr u64 TILE_COUNT = u64(1) << 62, TILE_PREFIX = u64(2) << 62, TILE_VALUE 
 __global__ __launch_bounds__(COMPACT_THREADS) void k_mark_compact(const u64* __restrict__ sorted, u64 total, u64 nwords, u64* __restrict__ words,
                                                                   u32* __restrict__ word_before, u64* __restrict__ out, u64 capacity,
                                                                   unsigned long long* __restrict__ status, unsigned int* __restrict__ ticket,
-                                                                  unsigned long long* __restrict__ unique_out)
+                                                                  unsigned long long* __restrict__ unique_out, const u64* __restrict__ dead)
 {
   // IN PLACE (out == sorted, round 6) is safe: a tile writes in front of its own first value, and only once every tile before
   // it has published a count -- which a tile does after ALL its loads have arrived in registers, as this one's have by then.
@@ -1995,12 +2068,16 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_mark_compact(const u64* __r
   // wavefront `wave` takes COMPACT_ROWS consecutive words of the tile: row j = the 64 values of word (base / 64 + wave ROWS + j)
   const u64 mine0 = base + u64(wave) * COMPACT_ROWS * 64 + lane;
   u64 value[COMPACT_ROWS], mask[COMPACT_ROWS];
+  // (`dead`: slots that hold nothing -- the tails behind the distinct values k_dedup_huge left at the front of its segments;
+  // they are neither loaded nor marked.  The slot behind a dead stretch starts a segment, so no live value is compared with one.)
+  u64 live[COMPACT_ROWS];
 #pragma unroll
   for(u32 j = 0; j < COMPACT_ROWS; j++)                       // (all loads of the tile leave before the first is looked at)
   {
     const u64 g = mine0 + j * 64;
-    value[j] = (g < total ? sorted[g] : 0);
     const u64 w = (base >> 6) + wave * COMPACT_ROWS + j;      // (uniform)
+    live[j] = (dead != nullptr && w < nwords ? ~dead[w] : ~u64(0));
+    value[j] = (g < total && ((live[j] >> lane) & 1) ? sorted[g] : 0);
     mask[j] = (w < nwords ? words[w] : 0);                    // segment starts
   }
   u64 carry = (lane == 0 && mine0 > 0 && mine0 < total ? sorted[mine0 - 1] : 0);       // the value in front of the wavefront's first
@@ -2011,7 +2088,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_mark_compact(const u64* __r
     const u64 left = __shfl_up(value[j], 1, 64);
     const bool first = (g < total && (g == 0 || value[j] != (lane == 0 ? carry : left)));
     carry = __shfl(value[j], 63, 64);                          // (lane 0's predecessor in the next row)
-    mask[j] = __ballot(first) | mask[j];
+    mask[j] = (__ballot(first) | mask[j]) & live[j];
     if(lane == 0) { counts[wave * COMPACT_ROWS + j] = u32(__popcll(mask[j])); }
   }
   __syncthreads();

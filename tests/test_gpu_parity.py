@@ -1530,7 +1530,7 @@ def test_locate_splits_large_batches(case, engine, monkeypatch):
         tiny.close()
 
 
-@pytest.mark.parametrize("dedup_huge", [1, 0])
+@pytest.mark.parametrize("dedup_huge", [1, 0, "wide"])
 def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
     """removeDuplicates at every segment size class: 1 value, 2..16 (registers, one lane), 17..1024 (one wavefront in
     LDS), 1025..8192 (one workgroup in LDS), more (duplicates removed through an LDS hash set, then the LDS sorts; the
@@ -1541,7 +1541,9 @@ def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
     from workload import builder
     g = graphs.snp_graph(30000, 0x4D1, 0x4D2, snp_period=5, node_len=16)
     ix = builder.build(g, 16, sample_period=16)
-    monkeypatch.setenv("GCSA2_DEDUP_HUGE", str(dedup_huge))
+    # ("wide": the filter's hash table with 64-bit words; an index whose values fit 32 bits gets 32-bit words otherwise)
+    monkeypatch.setenv("GCSA2_DEDUP_HUGE", "1" if dedup_huge == "wide" else str(dedup_huge))
+    monkeypatch.setenv("GCSA2_DEDUP_NARROW", "0" if dedup_huge == "wide" else "1")
     gpu, lcp = engine.open_index(ix)
     cpu = OracleIndex(ix)
     rng = SplitMix64(0x4D3)
