@@ -961,6 +961,72 @@ __global__ __launch_bounds__(CAPACITY / 16) void k_sort_big(const u64* __restric
   u64 v[16];
 #pragma unroll
   for(u32 r = 0; r < 16; r++) { const u32 e = first + r * 64 + lane; v[r] = (active && e < len ? from[b + e] : ~u64(0)); }    // padding sorts to the end
+  // Round 6: a segment whose values share their upper 32 bits -- the distinct values the duplicate filter leaves on an index of
+  // fewer than 2^32 positions, the long buckets of a split -- is sorted as 32-bit keys by the network of wave_sort_blocked32
+  // (element 16 lane + r of a wavefront's 1024, every comparator pointing the same way): the stage that joins blocks of K / 2
+  // compares e with its mirror image e ^ (K - 1) -- the partner wavefront's registers in reverse, through LDS --, then e ^ J for
+  // J = K / 4 ... 1024 through LDS and J = 512 ... 1 in registers.  Half the registers, half the LDS traffic, and a compare-
+  // exchange is two instructions instead of the six of a 64-bit one.
+  __shared__ u32 wide;
+  if(tid == 0) { wide = 0; }
+  __syncthreads();
+  const u32 top = u32(from[b] >> 32);                         // (uniform: len >= 1)
+  {
+    bool differs = false;
+#pragma unroll
+    for(u32 r = 0; r < 16; r++) { const u32 e = first + r * 64 + lane; differs = differs || (active && e < len && u32(v[r] >> 32) != top); }
+    if(__ballot(differs) != 0 && lane == 0) { wide = 1; }
+  }
+  __syncthreads();
+  if(wide == 0)                                               // (uniform)
+  {
+    u32* buf32 = reinterpret_cast<u32*>(buf);
+    u32 key[16];
+#pragma unroll
+    for(u32 r = 0; r < 16; r++) { const u32 e = first + r * 64 + lane; key[r] = (active && e < len ? u32(v[r]) : ~u32(0)); }      // (a key of all ones ties with the padding: the same value either way)
+    if(active) { wave_sort_blocked32<16>(key, lane); }
+    for(u32 K = 2048; K <= n2; K <<= 1)
+    {
+      for(u32 J = K >> 1; J >= 1024; J >>= 1)
+      {
+        const bool mirror = (J == (K >> 1));                    // the first step of the stage
+        if(active)
+        {
+#pragma unroll
+          for(u32 r = 0; r < 16; r++) { buf32[first + 64 * r + lane] = key[r]; }      // (element 16 lane + r lies at word 64 r + lane: no bank is asked twice, forwards or mirrored)
+        }
+        __syncthreads();
+        if(active)
+        {
+          const bool keep_min = ((first & J) == 0);
+          const u32 partner = (mirror ? (first ^ (K - 1024)) + 63 - lane : (first ^ J) + lane);      // (the mirror image of element 16 lane + r: 16 (63 - lane) + 15 - r)
+#pragma unroll
+          for(u32 r = 0; r < 16; r++)
+          {
+            const u32 other = (mirror ? buf32[partner + 64 * (15 - r)] : buf32[partner + 64 * r]);
+            key[r] = (keep_min ? (other < key[r] ? other : key[r]) : (other > key[r] ? other : key[r]));
+          }
+        }
+        __syncthreads();
+      }
+      if(active) { blocked_steps32<16, 512>(key, lane); }
+    }
+    if(active)
+    {
+      blocked_to_striped32<16>(key, buf32 + first, lane);       // (this wavefront's own 4 KB; every exchange above ended behind a barrier)
+#pragma unroll
+      for(u32 r = 0; r < 16; r++) { const u32 e = first + r * 64 + lane; if(e < len) { values[b + e] = (u64(top) << 32) | key[r]; } }
+      if(lane == 63) { tails[wave] = (u64(top) << 32) | key[15]; }
+    }
+    __syncthreads();
+    if(active)
+    {
+      u32 dups = dups_in_regs<16>(key, (len > first ? len - first : 0u), lane);
+      if(lane == 0 && wave > 0 && first < len && ((u64(top) << 32) | key[0]) == tails[wave - 1]) { dups++; }
+      if(lane == 0) { flag_dups(dup_counter, dups); }
+    }
+    return;
+  }
   if(active) { wave_sort_regs<16>(v, (n2 > 1024 && (wave & 1)) ? ~u64(0) : u64(0)); }
   for(u32 K = 2048; K <= n2; K <<= 1)
   {
@@ -2048,6 +2114,12 @@ __global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted,
 constexpr u32 COMPACT_THREADS = 256, COMPACT_ROWS = 32, COMPACT_TILE = COMPACT_THREADS * COMPACT_ROWS;
 constexpr u64 TILE_COUNT = u64(1) << 62, TILE_PREFIX = u64(2) << 62, TILE_VALUE = TILE_COUNT - 1;
 
+// the 64-bit value of one lane (a compile-time lane: v_readlane, a scalar result -- __shfl goes through ds_bpermute whatever the lane)
+__device__ __forceinline__ u64 lane_value(u64 v, int from)
+{
+  return (u64(u32(__builtin_amdgcn_readlane(int(u32(v >> 32)), from))) << 32) | u64(u32(__builtin_amdgcn_readlane(int(u32(v)), from)));
+}
+
 __global__ __launch_bounds__(COMPACT_THREADS) void k_mark_compact(const u64* __restrict__ sorted, u64 total, u64 nwords, u64* __restrict__ words,
                                                                   u32* __restrict__ word_before, u64* __restrict__ out, u64 capacity,
                                                                   unsigned long long* __restrict__ status, unsigned int* __restrict__ ticket,
@@ -2067,29 +2139,45 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_mark_compact(const u64* __r
   const u64 tile = __builtin_amdgcn_readfirstlane(s_tile), base = tile * COMPACT_TILE;
   // wavefront `wave` takes COMPACT_ROWS consecutive words of the tile: row j = the 64 values of word (base / 64 + wave ROWS + j)
   const u64 mine0 = base + u64(wave) * COMPACT_ROWS * 64 + lane;
-  u64 value[COMPACT_ROWS], mask[COMPACT_ROWS];
+  u64 value[COMPACT_ROWS];
   // (`dead`: slots that hold nothing -- the tails behind the distinct values k_dedup_huge left at the front of its segments;
   // they are neither loaded nor marked.  The slot behind a dead stretch starts a segment, so no live value is compared with one.)
-  u64 live[COMPACT_ROWS];
+  // What a lane knows about its own 32 slots is kept as BITS of three registers (round 6): the rows' words of the bitmaps are
+  // uniform, and 32 live words + 32 mark words held across the look-back were 128 scalar registers -- more than a wavefront has;
+  // the spills made this kernel 154 vector registers wide, three workgroups on a CU.  The marks of a row are one ballot away.
+  static_assert(COMPACT_ROWS <= 32, "a bit per row");
+  u32 my_live = 0, my_start = 0, my_keep = 0;
+  const u64* __restrict__ wave_values = sorted + (base + u64(wave) * COMPACT_ROWS * 64);      // (uniform: one base, 32-bit lane offsets)
+  // (the wavefront's 32 words of either bitmap: ONE coalesced load each, lane j holds the words of row j)
+  const u64 w_mine = (base >> 6) + u64(wave) * COMPACT_ROWS + lane;
+  const bool w_exists = (lane < COMPACT_ROWS && w_mine < nwords);
+  const u64 dead_words = (dead != nullptr && w_exists ? dead[w_mine] : 0);
+  const u64 start_words = (w_exists ? words[w_mine] : 0);
 #pragma unroll
   for(u32 j = 0; j < COMPACT_ROWS; j++)                       // (all loads of the tile leave before the first is looked at)
   {
     const u64 g = mine0 + j * 64;
-    const u64 w = (base >> 6) + wave * COMPACT_ROWS + j;      // (uniform)
-    live[j] = (dead != nullptr && w < nwords ? ~dead[w] : ~u64(0));
-    value[j] = (g < total && ((live[j] >> lane) & 1) ? sorted[g] : 0);
-    mask[j] = (w < nwords ? words[w] : 0);                    // segment starts
+    const u64 live = ~lane_value(dead_words, int(j));
+    const u64 starts = lane_value(start_words, int(j));        // segment starts
+    const bool alive = (g < total && ((live >> lane) & 1) != 0);
+    value[j] = (alive ? wave_values[lane + j * 64] : 0);
+    my_live |= u32(alive) << j;
+    my_start |= u32((starts >> lane) & 1) << j;
   }
   u64 carry = (lane == 0 && mine0 > 0 && mine0 < total ? sorted[mine0 - 1] : 0);       // the value in front of the wavefront's first
 #pragma unroll
   for(u32 j = 0; j < COMPACT_ROWS; j++)
   {
     const u64 g = mine0 + j * 64;
-    const u64 left = __shfl_up(value[j], 1, 64);
-    const bool first = (g < total && (g == 0 || value[j] != (lane == 0 ? carry : left)));
-    carry = __shfl(value[j], 63, 64);                          // (lane 0's predecessor in the next row)
-    mask[j] = (__ballot(first) | mask[j]) & live[j];
-    if(lane == 0) { counts[wave * COMPACT_ROWS + j] = u32(__popcll(mask[j])); }
+    // (the left neighbour: wave_shr:1, a DPP move per half -- no trip through the LDS crossbar; lane 0 keeps its own value and takes the carry)
+    const u64 left = (u64(u32(__builtin_amdgcn_update_dpp(int(u32(value[j] >> 32)), int(u32(value[j] >> 32)), 0x138, 0xF, 0xF, false))) << 32)
+                     | u64(u32(__builtin_amdgcn_update_dpp(int(u32(value[j])), int(u32(value[j])), 0x138, 0xF, 0xF, false)));
+    const bool first = (g == 0 || value[j] != (lane == 0 ? carry : left));
+    carry = lane_value(value[j], 63);                          // (lane 0's predecessor in the next row)
+    const bool keep = (((my_live >> j) & 1) != 0 && (first || ((my_start >> j) & 1) != 0));
+    my_keep |= u32(keep) << j;
+    const u64 marks = __ballot(keep);
+    if(lane == 0) { counts[wave * COMPACT_ROWS + j] = u32(__popcll(marks)); }
   }
   __syncthreads();
   // exclusive prefix sums of the word counts of the tile (one wavefront, 64 words at a time), the tile's count, and the look-back
@@ -2149,11 +2237,13 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_mark_compact(const u64* __r
   {
     const u64 g = mine0 + j * 64;
     const u64 w = g >> 6;
+    const bool keep = (((my_keep >> j) & 1) != 0);
+    const u64 marks = __ballot(keep);
     const u64 word_first = before + counts[wave * COMPACT_ROWS + j];
-    if(lane == 0 && w < nwords) { words[w] = mask[j]; word_before[w] = u32(word_first); }
-    if(g < total && ((mask[j] >> lane) & 1))
+    if(lane == 0 && w < nwords) { words[w] = marks; word_before[w] = u32(word_first); }
+    if(keep)
     {
-      const u64 dest = word_first + u64(__popcll(mask[j] & ((u64(1) << lane) - 1)));
+      const u64 dest = word_first + u64(__popcll(marks & ((u64(1) << lane) - 1)));
       if(dest < capacity) { out[dest] = value[j]; }
     }
   }
