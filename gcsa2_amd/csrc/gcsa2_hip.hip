@@ -121,7 +121,6 @@ struct gcsa2_index
     bool pipe_split = false;           // GCSA2_PIPE_SPLIT=1: downloads on a second stream per lane
     bool pipe_wide = false;            // GCSA2_PIPE_WIRE=16: the packed-pattern pipeline brings the ranges home as u64 pairs (A/B)
     bool ms_pieces = true;             // GCSA2_MS_PIECES=0: large host batches of matching statistics go through one copy in, one launch, one copy out
-    bool split_one_pass = false;       // GCSA2_SPLIT_ONE_PASS=1 (A/B): the split of a wide range scatters at once into buckets with reserves, no histogram pass (measured: no gain, kernels_locate.hpp)
     bool dedup_narrow = true;          // GCSA2_DEDUP_NARROW=0: the duplicate filter's hash table holds 64-bit words even when the index's values fit 32 bits
     bool dedup_huge = true;            // GCSA2_DEDUP_HUGE=0 sends every locate segment of more than 8192 values to the device-wide radix sort, duplicates and all
     bool zero_copy = true;             // GCSA2_ZERO_COPY=0: small host-pointer calls copy through the arenas like large ones
@@ -821,7 +820,6 @@ int gcsa2_index_create(const gcsa2_host_view* v, int device, gcsa2_index** out)
     ix->tune.poll_small = (knob("GCSA2_POLL_SMALL", 1, 0, 1) != 0);
     ix->tune.dedup_huge = (knob("GCSA2_DEDUP_HUGE", 1, 0, 1) != 0);
     ix->tune.dedup_narrow = (knob("GCSA2_DEDUP_NARROW", 1, 0, 1) != 0);
-    ix->tune.split_one_pass = (knob("GCSA2_SPLIT_ONE_PASS", 0, 0, 1) != 0);
     ix->tune.pipe_lanes = u32(knob("GCSA2_PIPE_LANES", 6, 1, 16));
     ix->tune.pipe_chunk = u64(1) << knob("GCSA2_PIPE_CHUNK", 18, 15, 20);
     ix->tune.pipe_split = (knob("GCSA2_PIPE_SPLIT", 0, 0, 1) != 0);
@@ -1801,52 +1799,46 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   {
     // segments of more than BIG_SEGMENT distinct values: one workgroup each splits its segment into buckets that the
     // workgroup sort holds (k_over_split); what a skewed segment leaves over goes to the device-wide radix sort as before
-    // (one pass -- the tiled split without its histogram pass, an A/B knob: kernels_locate.hpp -- lists every bucket that holds a
-    // value, at most 2 len / target + 2 of a segment, and scatters into stretches with reserves: scratch of twice the raw values)
-    const bool one_pass = (ix->tune.split_tiled && ix->tune.split_one_pass);
-    const u64 bucket_cap = (one_pass ? 2 * (over_values / ix->tune.split_target) + 2 * over : over_values / 64 + over) + 16;      // (two passes: listed buckets have more than 64 values)
-    u64 *split_tmp = nullptr, *bkt_begin = nullptr, *bkt_end = nullptr, *bkt_src = nullptr, *skew_begin = nullptr, *skew_end = nullptr;
-    HIP_TRY(scratch.get(split_tmp, one_pass ? 2 * total_raw : total_raw));
-    HIP_TRY(scratch.get(bkt_begin, bucket_cap)); HIP_TRY(scratch.get(bkt_end, bucket_cap)); HIP_TRY(scratch.get(bkt_src, bucket_cap));
+    const u64 bucket_cap = over_values / 64 + over + 16;                  // listed buckets have more than 64 values
+    u64 *split_tmp = nullptr, *bkt_begin = nullptr, *bkt_end = nullptr, *skew_begin = nullptr, *skew_end = nullptr;
+    HIP_TRY(scratch.get(split_tmp, total_raw));
+    HIP_TRY(scratch.get(bkt_begin, bucket_cap)); HIP_TRY(scratch.get(bkt_end, bucket_cap));
     const u32 skew_above = ix->tune.split_skew;                            // BIG_SEGMENT (lower in tests): what the workgroup sort takes
     const u64 skew_cap = over_values / skew_above + over + 16;
     HIP_TRY(scratch.get(skew_begin, skew_cap)); HIP_TRY(scratch.get(skew_end, skew_cap));
     const u64 mid_cap = over_values / BUCKET_BY_WAVE + over + 16;         // buckets of 513 .. 1024 values
-    u64 *mid_begin = nullptr, *mid_end = nullptr, *mid_src = nullptr;
-    HIP_TRY(scratch.get(mid_begin, mid_cap)); HIP_TRY(scratch.get(mid_end, mid_cap)); HIP_TRY(scratch.get(mid_src, mid_cap));
+    u64 *mid_begin = nullptr, *mid_end = nullptr;
+    HIP_TRY(scratch.get(mid_begin, mid_cap)); HIP_TRY(scratch.get(mid_end, mid_cap));
     if(ix->tune.split_tiled)
     {
       hipLaunchKernelGGL(k_over_split<true>, dim3(unsigned(over)), dim3(SPLIT_THREADS), 0, stream, over_begin, over_end, sorted, split_tmp,
-                         bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target, bucket_cap - 1, over_src, mid_begin, mid_end,
-                         bkt_src, mid_src, u32(one_pass ? 1 : 0));
+                         bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target, bucket_cap - 1, over_src, mid_begin, mid_end);
     }
     else
     {
       hipLaunchKernelGGL(k_over_split<false>, dim3(unsigned(over)), dim3(SPLIT_THREADS), 0, stream, over_begin, over_end, sorted, split_tmp,
-                         bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target, bucket_cap - 1, over_src, mid_begin, mid_end,
-                         bkt_src, mid_src, 0u);
+                         bkt_begin, bkt_end, skew_begin, skew_end, d_totals, skew_above, ix->tune.split_target, bucket_cap - 1, over_src, mid_begin, mid_end);
     }
     LAUNCH_CHECK("k_over_split");
     rc = read_totals(ix, slot, totals, stream);
     if(rc != GCSA2_OK) { return rc; }
     const u64 buckets = totals[T_BUCKETS], big_buckets = totals[T_BIG_BUCKETS], skew = totals[T_SKEW], skew_values = totals[T_SKEW_VALUES];
     const u64 mid_buckets = totals[T_MID_BUCKETS];
-    if(ix->tune.locate_trace) { std::fprintf(stderr, "[locate] split: %llu segments, %llu of them split again with a histogram\n", (unsigned long long)over, (unsigned long long)totals[T_SPLIT_REDONE]); }
     if(buckets + big_buckets > bucket_cap || mid_buckets > mid_cap) { return fail(GCSA2_ERR_HIP, "locate: more buckets than the split reserved"); }
     if(buckets > 0)
     {
-      hipLaunchKernelGGL(k_sort_bucket<BUCKET_BY_WAVE>, dim3(unsigned(buckets)), dim3(64), 0, stream, bkt_begin, bkt_end, sorted, split_tmp, d_totals, bkt_src);
+      hipLaunchKernelGGL(k_sort_bucket<BUCKET_BY_WAVE>, dim3(unsigned(buckets)), dim3(64), 0, stream, bkt_begin, bkt_end, sorted, split_tmp, d_totals);
       LAUNCH_CHECK("k_sort_bucket");
     }
     if(mid_buckets > 0)
     {
-      hipLaunchKernelGGL(k_sort_bucket<MEDIUM_SEGMENT>, dim3(unsigned(mid_buckets)), dim3(64), 0, stream, mid_begin, mid_end, sorted, split_tmp, d_totals, mid_src);
+      hipLaunchKernelGGL(k_sort_bucket<MEDIUM_SEGMENT>, dim3(unsigned(mid_buckets)), dim3(64), 0, stream, mid_begin, mid_end, sorted, split_tmp, d_totals);
       LAUNCH_CHECK("k_sort_bucket (513 .. 1024 values)");
     }
     if(big_buckets > 0)                                       // (listed from the back of the same arrays)
     {
-      hipLaunchKernelGGL((k_sort_big<4096, MEDIUM_SEGMENT>), dim3(unsigned(big_buckets)), dim3(big_threads<4096>()), 0, stream, bkt_begin, bkt_end, sorted, d_totals + T_BIG_BUCKETS, d_totals + T_DUPS, split_tmp, bucket_cap - 1, bkt_src);
-      hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(big_buckets)), dim3(big_threads<BIG_SEGMENT>()), 0, stream, bkt_begin, bkt_end, sorted, d_totals + T_BIG_BUCKETS, d_totals + T_DUPS, split_tmp, bucket_cap - 1, bkt_src);
+      hipLaunchKernelGGL((k_sort_big<4096, MEDIUM_SEGMENT>), dim3(unsigned(big_buckets)), dim3(big_threads<4096>()), 0, stream, bkt_begin, bkt_end, sorted, d_totals + T_BIG_BUCKETS, d_totals + T_DUPS, split_tmp, bucket_cap - 1);
+      hipLaunchKernelGGL((k_sort_big<BIG_SEGMENT, 4096>), dim3(unsigned(big_buckets)), dim3(big_threads<BIG_SEGMENT>()), 0, stream, bkt_begin, bkt_end, sorted, d_totals + T_BIG_BUCKETS, d_totals + T_DUPS, split_tmp, bucket_cap - 1);
       LAUNCH_CHECK("k_sort_big (buckets)");
     }
     if(skew > 0) { rc = radix_over(skew_begin, skew_end, skew, skew_values); if(rc != GCSA2_OK) { return rc; } }

@@ -474,7 +474,6 @@ enum { T_NODES = 0, T_RAW = 1, T_LARGE = 2, T_UNIQUE = 3, T_MULTI = 4, T_MEDIUM 
        T_DUPS = 14,         // a flag: some sort met a value equal to its left neighbour (round 6: none -> the sorted values are final where they lie)
        T_CAND = 15,         // ranges listed for the look at their table entries (k_classify_fused)
        T_MID_BUCKETS = 16,  // buckets of k_over_split with BUCKET_BY_WAVE + 1 .. MEDIUM_SEGMENT values (k_sort_bucket<MEDIUM_SEGMENT>)
-       T_SPLIT_REDONE = 17, // segments whose one-pass split met a bucket beyond its reserve and were split again with a histogram
        TOTAL_WORDS = 24 };
 
 __global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
@@ -943,8 +942,7 @@ template<u32 CAPACITY, u32 ABOVE>
 __global__ __launch_bounds__(CAPACITY / 16) void k_sort_big(const u64* __restrict__ seg_begin, const u64* __restrict__ seg_end,
                                                            u64* values, const unsigned long long* __restrict__ count, unsigned long long* __restrict__ dup_counter,
                                                            const u64* source = nullptr,
-                                                           u64 from_end = 0,      // from_end != 0: segment s of the list is at [from_end - s]
-                                                           const u64* __restrict__ seg_src = nullptr)      // with `source`: where in it the segment lies
+                                                           u64 from_end = 0)      // from_end != 0: segment s of the list is at [from_end - s]
 {
   __shared__ u64 buf[CAPACITY];
   __shared__ u64 tails[CAPACITY / 1024];                    // the last value of every wavefront's sorted stretch
@@ -957,12 +955,12 @@ __global__ __launch_bounds__(CAPACITY / 16) void k_sort_big(const u64* __restric
   if(len > CAPACITY || len <= ABOVE) { return; }            // the other instantiation's segment (uniform per workgroup)
   u32 n2 = 1024;
   while(n2 < len) { n2 <<= 1; }
-  const u64* from = (source != nullptr ? source + seg_src[at] : values + b);      // (the segment's first value)
+  const u64* from = (source != nullptr ? source : values);
   const u32 first = wave * 1024;                            // this wavefront's elements: first + 64 r + lane
   const bool active = (first < n2);
   u64 v[16];
 #pragma unroll
-  for(u32 r = 0; r < 16; r++) { const u32 e = first + r * 64 + lane; v[r] = (active && e < len ? from[e] : ~u64(0)); }    // padding sorts to the end
+  for(u32 r = 0; r < 16; r++) { const u32 e = first + r * 64 + lane; v[r] = (active && e < len ? from[b + e] : ~u64(0)); }    // padding sorts to the end
   // Round 6: a segment whose values share their upper 32 bits -- the distinct values the duplicate filter leaves on an index of
   // fewer than 2^32 positions, the long buckets of a split -- is sorted as 32-bit keys by the network of wave_sort_blocked32
   // (element 16 lane + r of a wavefront's 1024, every comparator pointing the same way): the stage that joins blocks of K / 2
@@ -972,7 +970,7 @@ __global__ __launch_bounds__(CAPACITY / 16) void k_sort_big(const u64* __restric
   __shared__ u32 wide;
   if(tid == 0) { wide = 0; }
   __syncthreads();
-  const u32 top = u32(from[0] >> 32);                         // (uniform: len >= 1)
+  const u32 top = u32(from[b] >> 32);                         // (uniform: len >= 1)
   {
     bool differs = false;
 #pragma unroll
@@ -1609,6 +1607,19 @@ __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __
   while(!bv_get(img.samples, s - 1));                        // lastSample, gcsa.h:208
 }
 
+// inclusive prefix sums over the wavefront by DPP: row_shr 1, 2, 4, 8 inside the rows of 16 lanes (a lane without a source adds
+// 0), then the last lane of row 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into the upper half (row_bcast:31)
+__device__ __forceinline__ u32 wave_scan_dpp(u32 x)
+{
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, true));
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, true));
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, true));
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, true));
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false));
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false));
+  return x;
+}
+
 // Segments with more than BIG_SEGMENT distinct values, round 5: ONE WORKGROUP PER SEGMENT sorts it.  It splits the segment on
 // the top bits of (value - the segment's smallest value) into up to 4096 buckets of a few dozen values -- minimum and
 // maximum, a histogram in LDS, its prefix sums, the scatter into `scratch` at the same offsets -- and then its sixteen
@@ -1668,8 +1679,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
                                                              u64* __restrict__ skew_begin, u64* __restrict__ skew_end,
                                                              unsigned long long* __restrict__ totals, u32 skew_above, u32 target, u64 bucket_last,
                                                              const u64* const* __restrict__ over_src,
-                                                             u64* __restrict__ mid_begin, u64* __restrict__ mid_end,
-                                                             u64* __restrict__ bkt_src, u64* __restrict__ mid_src, u32 one_pass)
+                                                             u64* __restrict__ mid_begin, u64* __restrict__ mid_end)
 {
   // (the tiled form never has more than SPLIT_TILED_BUCKETS buckets: its cursor / start arrays are as long as the workgroup)
   constexpr u32 SPLIT_BUCKETS = (TILED ? u32(SPLIT_THREADS) : SPLIT_BUCKETS_UNTILED);
@@ -1677,7 +1687,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   __shared__ u32 starts[SPLIT_BUCKETS];
   __shared__ u32 wave_sums[SPLIT_THREADS / 64];
   __shared__ unsigned long long s_lo, s_hi, list_base, big_base, skew_base, mid_base;
-  __shared__ u32 wg_listed, wg_big, wg_skewed, wg_skew_values, next_chunk, wg_mid, spilled;
+  __shared__ u32 wg_listed, wg_big, wg_skewed, wg_skew_values, next_chunk, wg_mid;
   __shared__ __attribute__((aligned(16))) u32 tile_count[2][TILED ? SPLIT_TILED_BUCKETS : 4];      // values of the tile per bucket (two tiles alternate)
   __shared__ __attribute__((aligned(16))) u32 tile_off[TILED ? SPLIT_TILED_BUCKETS : 4];           // their exclusive prefix sums
   __shared__ __attribute__((aligned(16))) u32 tile_delta[TILED ? SPLIT_TILED_BUCKETS : 4];         // where in the segment the bucket's values of this tile go, minus tile_off
@@ -1688,23 +1698,12 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   const u64 b = over_begin[blockIdx.x], len = over_end[blockIdx.x] - b;
   // where the segment's unsorted values are: the raw values the table pass wrote, or -- a FUSED range (k_classify_fused) -- the
   // entries of the locate table for its path nodes, which lie side by side there (their flag bit is cleared as they are read)
-  const u64* __restrict__ src = (over_src[blockIdx.x] != nullptr ? over_src[blockIdx.x] : values + b);
+  // (a pointer that was LOADED -- over_src[] -- is a generic one to the compiler: its loads were flat_load, which count as LDS
+  // operations too, so every wait for the LDS behind a prefetch waited for the prefetch.  Said to be global memory here.)
+  typedef const __attribute__((address_space(1))) u64* global_values;
+  const global_values src = (global_values)(over_src[blockIdx.x] != nullptr ? over_src[blockIdx.x] : values + b);
   constexpr u64 KEEP = ~LOCATE_DIRECT;                        // (a raw value has the bit clear: k_build_locate_table)
-  // ONE PASS (round 6, `one_pass`, GCSA2_SPLIT_ONE_PASS=1; the tiled form; an A/B that did not pay and is off): the histogram
-  // pass -- a third of this kernel, the segment read once more -- only says how many values every bucket will hold.  Instead
-  // every bucket gets room for one and a half times its share (+ 32, or a third of the share when that is less) in a scratch
-  // array of twice the segment's length (the segment at raw offset b owns scratch[2 b, 2 b + 2 len)) and the values are
-  // scattered at once; the counts are what the cursors say afterwards, their prefix sums the buckets' places in `values`, and
-  // the sorts read a bucket where it lies (bkt_src / mid_src: the lists carry the source offset next to the destination).  A
-  // segment whose values do not fill the buckets evenly -- the workgroup sees a tile that would pass a bucket's reserve BEFORE it
-  // stores the tile -- is split again with the histogram first (totals[T_SPLIT_REDONE] counts them).
-  // Measured on the 2^30-base text, same box, k_over_split per call: 16-mer batch 3.00 ms with the histogram pass, 3.30 without
-  // (1541 of 13 899 segments split again); 32-mer batch 2.38 / 2.83 ms (2354 of 16 893).  The histogram pass is the segment's
-  // FIRST read, at HBM speed with four loads per lane in flight; what it leaves in the Infinity Cache makes the scatter's read
-  // nearly free.  Without it the scatter -- three barriers per tile, one tile requested ahead -- waits for HBM itself, and
-  // every eighth segment pays twice.  (profiles/r06_locate.md section 7)
-  const u64 sb = (one_pass != 0 ? 2 * b : b);                 // the segment's stretch of `scratch`
-  if(tid == 0) { s_lo = ~0ull; s_hi = 0; spilled = 0; }
+  if(tid == 0) { s_lo = ~0ull; s_hi = 0; }
   for(u32 k = tid; k < SPLIT_BUCKETS; k += SPLIT_THREADS) { cursor[k] = 0; }
   __syncthreads();
   unsigned long long lo = ~0ull, hi = 0;
@@ -1736,149 +1735,27 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   u32 shift = 0;
   while(shift < 63 && (span >> shift) >= nb) { shift++; }
   // (the buckets are a power of two wide, so the sample's span ends somewhere in the upper half of them: the ones behind it stay
-  // empty and are dropped -- a value above the sample's largest goes into the last bucket the span reaches)
+  // empty and are dropped -- a value above the sample's largest goes into the last bucket the span reaches.  k_over_split 3.2 -> 3.0 ms
+  // on the 16-mer batch of the 2^30-base text: the prefix sums, the lists and the runs walk over fewer buckets.)
   nb = u32(span >> shift) + 1;
   auto bucket_of = [&](u64 v) -> u32
   {
     const u64 raw = (v > lo ? (v - lo) >> shift : 0);
     return u32(raw < nb ? raw : nb - 1);
   };
-  // the scatter through LDS tiles; `reserve` != 0: the one-pass form (bucket k may grow to (k + 1) reserve; the loop ends at the
-  // first tile that would pass a reserve, `spilled` set)
-  auto scatter_tiled = [&](u32 reserve)
+  for(u64 i0 = tid; i0 < len; i0 += SPLIT_AHEAD * SPLIT_THREADS)
   {
-    static_assert(SPLIT_TILED_BUCKETS % 256 == 0 && SPLIT_TILED_BUCKETS <= SPLIT_THREADS, "counts per lane in groups of four; a thread owns a bucket");
-    if(tid < SPLIT_TILED_BUCKETS) { tile_count[0][tid] = 0; tile_count[1][tid] = 0; }
-    __syncthreads();
-    u64 next[SPLIT_TILE_PER];
+    u64 got[SPLIT_AHEAD];
 #pragma unroll
-    for(u32 j = 0; j < SPLIT_TILE_PER; j++) { const u64 i = u64(j) * SPLIT_THREADS + tid; next[j] = (i < len ? src[i] : 0); }
-    u32 which = 0;
-    for(u64 t0 = 0; t0 < len; t0 += SPLIT_TILE, which ^= 1u)
-    {
-      u32* __restrict__ count = tile_count[which];
-      u64 got[SPLIT_TILE_PER];
-      u32 bkt[SPLIT_TILE_PER], rank[SPLIT_TILE_PER];
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? (src[i] & KEEP) : lo); }
 #pragma unroll
-      for(u32 j = 0; j < SPLIT_TILE_PER; j++) { got[j] = next[j] & KEEP; }
-#pragma unroll
-      for(u32 j = 0; j < SPLIT_TILE_PER; j++)                  // the next tile's values travel while this one is worked on
-      {
-        const u64 i = t0 + SPLIT_TILE + u64(j) * SPLIT_THREADS + tid;
-        next[j] = (i < len ? src[i] : 0);
-      }
-#pragma unroll
-      for(u32 j = 0; j < SPLIT_TILE_PER; j++)
-      {
-        bkt[j] = bucket_of(got[j]); rank[j] = 0;
-        if(t0 + u64(j) * SPLIT_THREADS + tid < len) { rank[j] = atomicAdd(&count[bkt[j]], 1u); }
-      }
-      __syncthreads();
-      {
-        // every wavefront scans the counts for itself: lane l has buckets PER l .. PER l + PER - 1 (16-byte reads); wavefront 0
-        // also says where the buckets' values of this tile go (tile_delta)
-        constexpr u32 PER = SPLIT_TILED_BUCKETS / 64;
-        // (two passes over the lane's counts -- its total first, then, after the scan over the lanes, the counts again for the
-        // offsets: holding them across the scan cost the kernel its second workgroup per CU once PER was 8)
-        u32 sum = 0;
-#pragma unroll
-        for(u32 k = 0; k < PER; k += 4)
-        {
-          const uint4 part = *reinterpret_cast<const uint4*>(&count[lane * PER + k]);
-          sum += part.x + part.y + part.z + part.w;
-        }
-        u32 incl = sum;
-        for(int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(incl, o, 64); if(lane >= u32(o)) { incl += up; } }
-        u32 at = incl - sum;
-        asm volatile("" ::: "memory");                          // (the counts are read again, not kept)
-#pragma unroll
-        for(u32 k = 0; k < PER; k += 4)
-        {
-          const uint4 part = *reinterpret_cast<const uint4*>(&count[lane * PER + k]);
-          const uint4 off = make_uint4(at, at + part.x, at + part.x + part.y, at + part.x + part.y + part.z);
-          *reinterpret_cast<uint4*>(&tile_off[lane * PER + k]) = off;
-          if(wave == 0)
-          {
-            const uint4 cur = *reinterpret_cast<const uint4*>(&cursor[lane * PER + k]);
-            *reinterpret_cast<uint4*>(&tile_delta[lane * PER + k]) = make_uint4(cur.x - off.x, cur.y - off.y, cur.z - off.z, cur.w - off.w);
-            if(reserve != 0)                                      // (one pass: does this tile fit the buckets' reserves?)
-            {
-              const u32 first_limit = (lane * PER + k + 1) * reserve;
-              if(cur.x + part.x > first_limit || cur.y + part.y > first_limit + reserve || cur.z + part.z > first_limit + 2 * reserve
-                 || cur.w + part.w > first_limit + 3 * reserve) { spilled = 1; }
-            }
-          }
-          at += part.x + part.y + part.z + part.w;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for(u32 j = 0; j < SPLIT_TILE_PER; j++)
-      {
-        if(t0 + u64(j) * SPLIT_THREADS + tid < len)
-        {
-          const u32 at = tile_off[bkt[j]] + rank[j];
-          tile_value[at] = got[j]; tile_bucket[at] = (unsigned short)bkt[j];
-        }
-      }
-      __syncthreads();
-      if(reserve != 0 && spilled != 0) { break; }               // (uniform: written before the barrier; nothing of this tile has been stored)
-      const u32 here = u32(len - t0 < SPLIT_TILE ? len - t0 : SPLIT_TILE);
-#pragma unroll
-      for(u32 j = 0; j < SPLIT_TILE_PER; j++)
-      {
-        const u32 at = j * SPLIT_THREADS + tid;
-        if(at < here) { scratch[sb + u32(tile_delta[tile_bucket[at]] + at)] = tile_value[at]; }
-      }
-      __syncthreads();
-      // the owners move the buckets' cursors on and clear this tile's counts (the next tile counts in the other array)
-      if(tid < SPLIT_TILED_BUCKETS) { cursor[tid] += count[tid]; count[tid] = 0; }
-    }
-  };
-  bool sparse = false;                                        // (uniform) the one-pass form holds
-  u32 reserve = 0;
-  if constexpr(TILED)
-  {
-    // (a bucket's reserve stays within what the workgroup sort takes, so that no bucket of a one-pass split is a skewed one)
-    // (one and a half times the bucket's share + 32, + at most a third of the share for short buckets: nb reserves fit 2 len)
-    const u64 room = (3 * len) / (2 * nb) + (len / (2 * nb) < 32 ? len / (2 * nb) : 32);
-    if(one_pass != 0 && room <= u64(skew_above))
-    {
-      reserve = u32(room);
-      for(u32 k = tid; k < SPLIT_BUCKETS; k += SPLIT_THREADS) { cursor[k] = k * reserve; }
-      __syncthreads();
-      scatter_tiled(reserve);
-      __syncthreads();
-      sparse = (spilled == 0);
-      if(!sparse)
-      {
-        if(tid == 0) { atomicAdd(totals + T_SPLIT_REDONE, 1ull); }
-        for(u32 k = tid; k < SPLIT_BUCKETS; k += SPLIT_THREADS) { cursor[k] = 0; }
-        __syncthreads();
-      }
-    }
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { if(i0 + u64(j) * SPLIT_THREADS < len) { atomicAdd(&cursor[bucket_of(got[j])], 1u); } }
   }
-  if(!sparse)
-  {
-    for(u64 i0 = tid; i0 < len; i0 += SPLIT_AHEAD * SPLIT_THREADS)
-    {
-      u64 got[SPLIT_AHEAD];
-  #pragma unroll
-      for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? (src[i] & KEEP) : lo); }
-  #pragma unroll
-      for(u32 j = 0; j < SPLIT_AHEAD; j++) { if(i0 + u64(j) * SPLIT_THREADS < len) { atomicAdd(&cursor[bucket_of(got[j])], 1u); } }
-    }
-    __syncthreads();
-  }
+  __syncthreads();
   // exclusive prefix sums of the counts: PER_THREAD consecutive buckets per thread, then across the wavefront and the workgroup
   u32 mine[PER_THREAD], sum = 0;
 #pragma unroll
-  for(u32 k = 0; k < PER_THREAD; k++)
-  {
-    const u32 bucket = tid * PER_THREAD + k;
-    mine[k] = cursor[bucket] - (sparse ? bucket * reserve : 0u);      // (one pass: the cursor stands behind the bucket's last value, its stretch starts at bucket * reserve)
-    sum += mine[k];
-  }
+  for(u32 k = 0; k < PER_THREAD; k++) { mine[k] = cursor[tid * PER_THREAD + k]; sum += mine[k]; }
   u32 incl = sum;
   for(int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(incl, o, 64); if(lane >= u32(o)) { incl += up; } }
   if(lane == 63) { wave_sums[wave] = incl; }
@@ -1886,7 +1763,6 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   u32 before = incl - sum;
   for(u32 w = 0; w < wave; w++) { before += wave_sums[w]; }
   const u32 small = (skew_above < 64 ? skew_above : 64u);     // a run, and a bucket that needs no list, holds at most this many values
-  const u32 list_above = (sparse ? 0u : small);               // (one pass: there is no run phase -- every bucket with a value is listed)
   // the buckets that are too large for a run are listed here, by the threads that own them, in slots the WORKGROUP reserves with
   // one atomic per list (one atomic per bucket on the global counters -- a million of them on one address -- was 5 of the
   // kernel's 14 ms on the clustered segments of the 32-mer batch; profiles/r05_locate.md)
@@ -1897,7 +1773,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   for(u32 k = 0; k < PER_THREAD; k++)
   {
     starts[tid * PER_THREAD + k] = before; cursor[tid * PER_THREAD + k] = before; before += mine[k];
-    if(mine[k] > list_above)
+    if(mine[k] > small)
     {
       if(mine[k] > skew_above) { my_skewed++; my_skew_values += mine[k]; }
       else if(mine[k] > MEDIUM_SEGMENT) { my_big++; }
@@ -1927,20 +1803,114 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
 #pragma unroll
     for(u32 k = 0; k < PER_THREAD; k++)
     {
-      if(mine[k] > list_above)
+      if(mine[k] > small)
       {
-        // (where the sorts read the bucket: at its place in the dense scatter below, or -- one pass -- at the head of its stretch)
-        const u64 from = sb + (sparse ? u64(tid * PER_THREAD + k) * reserve : u64(at));
         if(mine[k] > skew_above) { const u64 slot = skew_base + skewed_at++; skew_begin[slot] = b + at; skew_end[slot] = b + at + mine[k]; }
-        else if(mine[k] > MEDIUM_SEGMENT) { const u64 slot = bucket_last - (big_base + big_at++); bkt_begin[slot] = b + at; bkt_end[slot] = b + at + mine[k]; bkt_src[slot] = from; }
-        else if(mine[k] > BUCKET_BY_WAVE) { const u64 slot = mid_base + mid_at++; mid_begin[slot] = b + at; mid_end[slot] = b + at + mine[k]; mid_src[slot] = from; }
-        else { const u64 slot = list_base + listed_at++; bkt_begin[slot] = b + at; bkt_end[slot] = b + at + mine[k]; bkt_src[slot] = from; }
+        else if(mine[k] > MEDIUM_SEGMENT) { const u64 slot = bucket_last - (big_base + big_at++); bkt_begin[slot] = b + at; bkt_end[slot] = b + at + mine[k]; }
+        else if(mine[k] > BUCKET_BY_WAVE) { const u64 slot = mid_base + mid_at++; mid_begin[slot] = b + at; mid_end[slot] = b + at + mine[k]; }
+        else { const u64 slot = list_base + listed_at++; bkt_begin[slot] = b + at; bkt_end[slot] = b + at + mine[k]; }
       }
       at += mine[k];
     }
   }
-  if(sparse) { return; }                                      // (one pass: the values lie in their buckets already, every bucket is listed)
-  if constexpr(TILED) { scatter_tiled(0); }
+  if constexpr(TILED)
+  {
+    static_assert(SPLIT_TILED_BUCKETS % 256 == 0 && SPLIT_TILED_BUCKETS <= SPLIT_THREADS, "counts per lane in groups of four; a thread owns a bucket");
+    if(tid < SPLIT_TILED_BUCKETS) { tile_count[0][tid] = 0; tile_count[1][tid] = 0; }
+    __syncthreads();
+    u64 next[SPLIT_TILE_PER];
+#pragma unroll
+    for(u32 j = 0; j < SPLIT_TILE_PER; j++) { const u64 i = u64(j) * SPLIT_THREADS + tid; next[j] = src[i < len ? i : len - 1]; }      // (no branch around a load: see below)
+    u32 which = 0;
+    for(u64 t0 = 0; t0 < len; t0 += SPLIT_TILE, which ^= 1u)
+    {
+      u32* __restrict__ count = tile_count[which];
+      u64 got[SPLIT_TILE_PER];
+      u32 where[SPLIT_TILE_PER];                              // bucket | rank inside the bucket's values of this tile << 16 (one register: the kernel has 64)
+      static_assert(SPLIT_TILED_BUCKETS <= 65536 && SPLIT_TILE <= 65536, "two 16-bit halves");
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_TILE_PER; j++) { got[j] = next[j] & KEEP; asm volatile("" : "+v"(got[j])); }
+      // The next tile's values travel while this one is worked on.  They did not until late in round 6: (i) the loads were
+      // flat_load (above); (ii) they sat behind `if(i < len)` branches, and the compiler cannot count memory operations across a
+      // branch, so its wait for the PREVIOUS tile's values -- placed at their first use, behind these loads -- was
+      // s_waitcnt vmcnt(0): the workgroup waited for the loads it had just issued.  Now the index is clamped instead (every lane
+      // loads), and the previous values are pinned in their registers (the empty asm) BEFORE the new loads leave, so that the wait
+      // lands there: on loads and stores a tile old.  One uniform base per tile and 32-bit lane offsets keep the addresses in
+      // one scalar pair and one register (the kernel lives on 64 registers).
+      const u64 next_base = (t0 + SPLIT_TILE < len ? t0 + SPLIT_TILE : len - 1);
+      const global_values next_src = src + next_base;
+      const u64 left = len - 1 - next_base;
+      const u32 last = u32(left < SPLIT_TILE ? left : SPLIT_TILE);      // the last index of that tile that exists
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_TILE_PER; j++)
+      {
+        const u32 i = j * SPLIT_THREADS + tid;
+        next[j] = next_src[i < last ? i : last];
+      }
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_TILE_PER; j++)
+      {
+        where[j] = bucket_of(got[j]);
+        if(t0 + u64(j) * SPLIT_THREADS + tid < len) { where[j] |= atomicAdd(&count[where[j]], 1u) << 16; }
+      }
+      __syncthreads();
+      {
+        // every wavefront scans the counts for itself: lane l has buckets PER l .. PER l + PER - 1 (16-byte reads); wavefront 0
+        // also says where the buckets' values of this tile go (tile_delta)
+        constexpr u32 PER = SPLIT_TILED_BUCKETS / 64;
+        // (two passes over the lane's counts -- its total first, then, after the scan over the lanes, the counts again for the
+        // offsets: holding them across the scan cost the kernel its second workgroup per CU once PER was 8)
+        u32 sum = 0;
+#pragma unroll
+        for(u32 k = 0; k < PER; k += 4)
+        {
+          const uint4 part = *reinterpret_cast<const uint4*>(&count[lane * PER + k]);
+          sum += part.x + part.y + part.z + part.w;
+        }
+        const u32 incl = wave_scan_dpp(sum);                    // (no trip through the LDS crossbar: six __shfl_up were six waits of every wavefront, once per tile)
+        u32 at = incl - sum;
+        asm volatile("" ::: "memory");                          // (the counts are read again, not kept)
+#pragma unroll
+        for(u32 k = 0; k < PER; k += 4)
+        {
+          const uint4 part = *reinterpret_cast<const uint4*>(&count[lane * PER + k]);
+          const uint4 off = make_uint4(at, at + part.x, at + part.x + part.y, at + part.x + part.y + part.z);
+          *reinterpret_cast<uint4*>(&tile_off[lane * PER + k]) = off;
+          if(wave == 0)
+          {
+            const uint4 cur = *reinterpret_cast<const uint4*>(&cursor[lane * PER + k]);
+            *reinterpret_cast<uint4*>(&tile_delta[lane * PER + k]) = make_uint4(cur.x - off.x, cur.y - off.y, cur.z - off.z, cur.w - off.w);
+          }
+          at += part.x + part.y + part.z + part.w;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_TILE_PER; j++)
+      {
+        if(t0 + u64(j) * SPLIT_THREADS + tid < len)
+        {
+          const u32 at = tile_off[where[j] & 0xFFFFu] + (where[j] >> 16);
+          tile_value[at] = got[j]; tile_bucket[at] = (unsigned short)(where[j] & 0xFFFFu);
+        }
+      }
+      __syncthreads();
+      const u32 here = u32(len - t0 < SPLIT_TILE ? len - t0 : SPLIT_TILE);
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_TILE_PER; j++)
+      {
+        const u32 at = j * SPLIT_THREADS + tid;
+        if(at < here) { scratch[b + u32(tile_delta[tile_bucket[at]] + at)] = tile_value[at]; }
+      }
+      __syncthreads();
+      // the owners move the buckets' cursors on and clear this tile's counts (the next tile counts in the other array)
+      // (The barrier above is not needed for correctness -- whatever the next tile overwrites, it overwrites behind ITS first
+      // barrier, which no wavefront passes before all have stored this tile -- and was taken out once: 2.79 -> 2.93 ms on the 16-mer
+      // batch of the 2^30-base text, same box, three runs each.  Wavefronts that run ahead into the next tile's atomics take the
+      // LDS from the ones still reading this tile.)
+      if(tid < SPLIT_TILED_BUCKETS) { cursor[tid] += count[tid]; count[tid] = 0; }
+    }
+  }
   else
   for(u64 i0 = tid; i0 < len; i0 += SPLIT_AHEAD * SPLIT_THREADS)
   {
@@ -1952,7 +1922,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
     {
       if(i0 + u64(j) * SPLIT_THREADS < len)
       {
-        scratch[sb + atomicAdd(&cursor[bucket_of(got[j])], 1u)] = got[j];
+        scratch[b + atomicAdd(&cursor[bucket_of(got[j])], 1u)] = got[j];
       }
     }
   }
@@ -1988,7 +1958,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
         // bucket k alone has more than `small` values: listed above for the sorts of the next launches; one that is too large
         // even for those (BIG_SEGMENT; lower in tests, GCSA2_SPLIT_SKEW) goes back to where the radix sort expects it
         const u32 big = cursor[k] - first;
-        if(big > skew_above) { for(u32 i = first + lane; i < first + big; i += 64) { values[b + i] = scratch[sb + i]; } }
+        if(big > skew_above) { for(u32 i = first + lane; i < first + big; i += 64) { values[b + i] = scratch[b + i]; } }
         k++;
         continue;
       }
@@ -2008,7 +1978,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   {
     run_first[d] = 0; run_count[d] = 0; run_base[d] = NO_BASE;
     live[d] = next_run(run_first[d], run_count[d], run_base[d]);
-    run_value[d] = (live[d] && lane < run_count[d] ? scratch[sb + run_first[d] + lane] : ~u64(0));
+    run_value[d] = (live[d] && lane < run_count[d] ? scratch[b + run_first[d] + lane] : ~u64(0));
   }
   u32 run_dups = 0;
   while(live[0])
@@ -2033,7 +2003,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
     }
     constexpr u32 last = SPLIT_RUNS_AHEAD - 1;
     live[last] = live[last - 1] && next_run(run_first[last], run_count[last], run_base[last]);
-    run_value[last] = (live[last] && lane < run_count[last] ? scratch[sb + run_first[last] + lane] : ~u64(0));
+    run_value[last] = (live[last] && lane < run_count[last] ? scratch[b + run_first[last] + lane] : ~u64(0));
   }
   report_dups(totals, run_dups, lane);
 }
@@ -2046,8 +2016,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
 // 0.6 ms against 0.2 on the 16-mer batch of the 2^30-base text)
 template<u32 MOST>
 __global__ __launch_bounds__(64) void k_sort_bucket(const u64* __restrict__ bkt_begin, const u64* __restrict__ bkt_end, u64* values,
-                                                    const u64* __restrict__ source, unsigned long long* __restrict__ totals,
-                                                    const u64* __restrict__ bkt_src)      // where in `source` the bucket lies (k_over_split)
+                                                    const u64* __restrict__ source, unsigned long long* __restrict__ totals)
 {
   if(blockIdx.x >= totals[MOST == BUCKET_BY_WAVE ? T_BUCKETS : T_MID_BUCKETS]) { return; }
   const u32 lane = threadIdx.x;
@@ -2055,7 +2024,7 @@ __global__ __launch_bounds__(64) void k_sort_bucket(const u64* __restrict__ bkt_
   const u32 len = u32(bkt_end[blockIdx.x] - b);
   if(len > MOST) { return; }                                  // (cannot be: k_over_split fills the lists by length)
   __shared__ u32 stage[MOST];                                 // (the transposition of the blocked 32-bit network)
-  report_dups(totals, sort_segment_by_wave<MOST>(source + bkt_src[blockIdx.x], values + b, len, lane, ~u64(0), stage), lane);
+  report_dups(totals, sort_segment_by_wave<MOST>(source + b, values + b, len, lane, ~u64(0), stage), lane);
 }
 
 // Segments with more than BIG_SEGMENT distinct values whose split left a bucket too large (k_over_split's skew list), and every

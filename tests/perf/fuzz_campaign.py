@@ -65,10 +65,8 @@ def main():
             continue
         # round 6: on every second graph the fused split of locate() takes ranges of a few dozen path nodes (its threshold is 8192)
         # and the split aims at small buckets, so that the table-reading split, its LDS tiles and the run phase meet these graphs
-        for key in ("GCSA2_LOCATE_FUSE_ABOVE", "GCSA2_SPLIT_TARGET", "GCSA2_SPLIT_SKEW", "GCSA2_SPLIT_ONE_PASS"):
+        for key in ("GCSA2_LOCATE_FUSE_ABOVE", "GCSA2_SPLIT_TARGET", "GCSA2_SPLIT_SKEW"):
             os.environ.pop(key, None)
-        if seed % 4 >= 2:
-            os.environ["GCSA2_SPLIT_ONE_PASS"] = "1"          # the split without its histogram pass (an A/B knob of the library)
         if seed % 2 == 1:
             os.environ["GCSA2_LOCATE_FUSE_ABOVE"] = str((8, 64, 300)[seed % 3])
             os.environ["GCSA2_SPLIT_TARGET"] = str((24, 256, 6)[(seed // 3) % 3])

@@ -1579,14 +1579,11 @@ def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
                                    {"GCSA2_LOCATE_SPLIT_SORT": "0"}, {"GCSA2_LOCATE_FUSED_COMPACT": "0"}, {"values": "across 2^32"}, {"values": "across 2^32", "GCSA2_SPLIT_TARGET": "24"},
                                    {"values": "across 2^32", "GCSA2_SPLIT_TARGET": "1500", "GCSA2_SPLIT_SKEW": "3000"},
                                    {"GCSA2_LOCATE_FUSE": "0"}, {"GCSA2_LOCATE_IN_PLACE": "0"}, {"GCSA2_LOCATE_FUSE_ABOVE": "600"},
-                                   {"GCSA2_SPLIT_ONE_PASS": "1"}, {"GCSA2_SPLIT_ONE_PASS": "1", "GCSA2_SPLIT_TARGET": "24", "GCSA2_LOCATE_FUSE_ABOVE": "2"},
-                                   {"values": "across 2^32", "GCSA2_SPLIT_ONE_PASS": "1"},
                                    {"GCSA2_LOCATE_FUSE_ABOVE": "2", "GCSA2_SPLIT_TARGET": "24"}, {"values": "across 2^32", "GCSA2_LOCATE_FUSE_ABOVE": "600", "GCSA2_SPLIT_SKEW": "16"}],
                          ids=["split-with-listed-buckets", "split-with-runs", "split-with-listed-and-skewed-buckets", "split-with-skewed-buckets", "radix-sort",
                               "four-kernel-compaction",
                               "64-bit-keys", "64-bit-keys-runs", "64-bit-keys-large-buckets",
                               "table-pass-for-every-range", "sorts-in-scratch", "fused-from-600-nodes",
-                              "one-pass-split", "one-pass-split-runs-from-3-nodes", "one-pass-split-64-bit-keys",
                               "fused-from-3-nodes-runs", "fused-64-bit-keys-skewed"])
 def test_locate_many_large_distinct_segments(engine, knobs, monkeypatch):
     """Ranges of thousands of path nodes whose values are all DISTINCT (a linear text: one value per path node), as found
@@ -1599,9 +1596,7 @@ def test_locate_many_large_distinct_segments(engine, knobs, monkeypatch):
     that every branch runs, with node_type values below 2^32 and on both sides of it (32- and 64-bit sort keys); through the job interface
     (the value buffer is made once the total is known) and into caller-owned buffers (no wait for the total; a buffer that is
     too small is refused with the size needed and nothing is written behind its end).  Round 6: these ranges are FUSED -- their
-    values never pass through the table pass, the split reads the locate table (GCSA2_LOCATE_FUSE=0: as before; GCSA2_SPLIT_ONE_PASS=1:
-    the split without its histogram pass, buckets with reserves, and -- values on both sides of 2^32 crowd into two buckets -- its
-    way back to the histogram; the threshold of
+    values never pass through the table pass, the split reads the locate table (GCSA2_LOCATE_FUSE=0: as before; the threshold of
     8192 path nodes lowered so that ranges of 700 / 3 nodes take that path too) -- and the caller's buffer is the sorts' target
     (GCSA2_LOCATE_IN_PLACE=0: scratch + compaction)."""
     import torch
