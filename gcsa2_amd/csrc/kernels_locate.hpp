@@ -843,22 +843,27 @@ __device__ __forceinline__ void blocked_to_striped32(u32 (&v)[R], u32* stage, u3
 // Values of a wavefront's sorted registers (element e = 64 r + lane, ascending, the first `len` real) that equal their left
 // neighbour, summed over the wavefront: what removeDuplicates (utils.h:350-357) will drop.  Round 6: the sorts report them, and
 // a batch without any needs no compaction -- its values are sorted in the caller's buffer, at the offsets the size scan gave.
+// (the left neighbour by DPP wave_shr:1 -- lane 0 keeps its own value and is overruled --, the last lane of the register before by
+// v_readlane, the count by ballots: no ds_bpermute, which is what __shfl_up / __shfl / __shfl_down compile to -- 21 trips through the
+// LDS crossbar per 512 sorted values until late in round 6)
+__device__ __forceinline__ u32 wave_shr1(u32 v) { return u32(__builtin_amdgcn_update_dpp(int(v), int(v), 0x138, 0xF, 0xF, false)); }
+__device__ __forceinline__ u64 wave_shr1(u64 v) { return (u64(wave_shr1(u32(v >> 32))) << 32) | u64(wave_shr1(u32(v))); }
+__device__ __forceinline__ u32 last_lane_value(u32 v) { return u32(__builtin_amdgcn_readlane(int(v), 63)); }
+__device__ __forceinline__ u64 last_lane_value(u64 v) { return (u64(last_lane_value(u32(v >> 32))) << 32) | u64(last_lane_value(u32(v))); }
 template<u32 R, class T>
 __device__ __forceinline__ u32 dups_in_regs(const T (&v)[R], u32 len, u32 lane)
 {
-  u32 mine = 0;
+  u32 total = 0;                                              // (uniform)
 #pragma unroll
   for(u32 r = 0; r < R; r++)
   {
-    T left = __shfl_up(v[r], 1, 64);
-    if(r > 0) { const T wrap = __shfl(v[r - 1], 63, 64); left = (lane == 0 ? wrap : left); }
+    T left = wave_shr1(v[r]);
+    if(r > 0) { const T wrap = last_lane_value(v[r - 1]); left = (lane == 0 ? wrap : left); }
     const u32 e = r * 64 + lane;
-    mine += u32(e > 0 && e < len && v[r] == left);
+    total += u32(__popcll(__ballot(e > 0 && e < len && v[r] == left)));
   }
-  for(int o = 32; o > 0; o >>= 1) { mine += __shfl_down(mine, o, 64); }
-  return u32(__builtin_amdgcn_readfirstlane(int(mine)));
+  return total;
 }
-
 // `len` values at src[0, len) sorted into dst[0, len) (dst may be src) by the wavefront, len <= 64 R.  When all of them share
 // their upper 32 bits -- the values of a bucket of k_over_split nearly always do, a query's values when they lie in one 4 G
 // stretch of the node numbers -- the lower halves are sorted as 32-bit keys.  MASK: bits cleared from what is read (the
