@@ -1190,7 +1190,9 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
   // + the sample 0.3, + sweep, tail and listing 0.9-1.7.  What did NOT move the insertions: a 32-bit table (half the LDS, a
   // compare-and-swap of half the width), a plain read of the slot before the compare-and-swap, neither counter operation removed
   // (2.47 -> 2.28 without both), the count of distinct values kept per wavefront (2.09 -> 2.53), the next group requested before
-  // this one is inserted (2.09 -> 2.37).  Every phase of a workgroup waits for the one before it and only two workgroups share a
+  // this one is inserted (2.09 -> 2.37; again with clamped indices instead of branches around the loads and this group's values
+  // pinned, so that the compiler's wait is not for the loads just issued -- what repaired k_over_split's prefetch --: 2.90 -> 3.33 ms
+  // for the whole kernel, same box, two runs each).  Every phase of a workgroup waits for the one before it and only two workgroups share a
   // CU: the kernel is a chain of latencies, not a rate.
   for(u64 base = tid; base < items; base += AHEAD * HUGE_THREADS)
   {
