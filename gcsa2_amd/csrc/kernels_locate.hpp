@@ -843,6 +843,19 @@ __device__ __forceinline__ void blocked_to_striped32(u32 (&v)[R], u32* stage, u3
 // Values of a wavefront's sorted registers (element e = 64 r + lane, ascending, the first `len` real) that equal their left
 // neighbour, summed over the wavefront: what removeDuplicates (utils.h:350-357) will drop.  Round 6: the sorts report them, and
 // a batch without any needs no compaction -- its values are sorted in the caller's buffer, at the offsets the size scan gave.
+// inclusive prefix sums over the wavefront by DPP: row_shr 1, 2, 4, 8 inside the rows of 16 lanes (a lane without a source adds
+// 0), then the last lane of row 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into the upper half (row_bcast:31)
+__device__ __forceinline__ u32 wave_scan_dpp(u32 x)
+{
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, true));
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, true));
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, true));
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, true));
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false));
+  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false));
+  return x;
+}
+
 // (the left neighbour by DPP wave_shr:1 -- lane 0 keeps its own value and is overruled --, the last lane of the register before by
 // v_readlane, the count by ballots: no ds_bpermute, which is what __shfl_up / __shfl / __shfl_down compile to -- 21 trips through the
 // LDS crossbar per 512 sorted values until late in round 6)
@@ -1256,8 +1269,7 @@ __global__ __launch_bounds__(HUGE_THREADS) void k_dedup_huge(const u64* __restri
 #pragma unroll
   for(u32 k = 0; k < PER_LANE; k++) { held[k] = table[tid + k * HUGE_THREADS]; occupied += u32(held[k] != EMPTY); }
   u32 upto = occupied;                                        // inclusive scan over the wavefront
-#pragma unroll
-  for(u32 d = 1; d < 64; d <<= 1) { const u32 other = __shfl_up(upto, d); if((tid & 63) >= d) { upto += other; } }
+  upto = wave_scan_dpp(upto);
   if((tid & 63) == 63) { wave_total[tid >> 6] = upto; }
   __syncthreads();
   u32 put = upto - occupied;
@@ -1614,19 +1626,6 @@ __global__ __launch_bounds__(TPB) void k_locate_walk(DevImage img, const u64* __
   while(!bv_get(img.samples, s - 1));                        // lastSample, gcsa.h:208
 }
 
-// inclusive prefix sums over the wavefront by DPP: row_shr 1, 2, 4, 8 inside the rows of 16 lanes (a lane without a source adds
-// 0), then the last lane of row 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into the upper half (row_bcast:31)
-__device__ __forceinline__ u32 wave_scan_dpp(u32 x)
-{
-  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, true));
-  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, true));
-  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, true));
-  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, true));
-  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false));
-  x += u32(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false));
-  return x;
-}
-
 // Segments with more than BIG_SEGMENT distinct values, round 5: ONE WORKGROUP PER SEGMENT sorts it.  It splits the segment on
 // the top bits of (value - the segment's smallest value) into up to 4096 buckets of a few dozen values -- minimum and
 // maximum, a histogram in LDS, its prefix sums, the scatter into `scratch` at the same offsets -- and then its sixteen
@@ -1763,8 +1762,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   u32 mine[PER_THREAD], sum = 0;
 #pragma unroll
   for(u32 k = 0; k < PER_THREAD; k++) { mine[k] = cursor[tid * PER_THREAD + k]; sum += mine[k]; }
-  u32 incl = sum;
-  for(int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(incl, o, 64); if(lane >= u32(o)) { incl += up; } }
+  const u32 incl = wave_scan_dpp(sum);
   if(lane == 63) { wave_sums[wave] = incl; }
   __syncthreads();
   u32 before = incl - sum;
@@ -1999,7 +1997,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
         v = run_base[0] + key;
       }
       else { v = wave_sort(v, lane); }
-      const u64 left = __shfl_up(v, 1, 64);
+      const u64 left = wave_shr1(v);
       run_dups += u32(__popcll(__ballot(lane > 0 && lane < run_count[0] && v == left)));      // (runs are whole buckets: no value spans two)
     }
     if(lane < run_count[0]) { values[b + run_first[0] + lane] = v; }
@@ -2230,10 +2228,9 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_mark_compact(const u64* __r
     for(u32 half = 0; half < WORDS; half += 64)
     {
       const u32 mine = counts[half + lane];
-      u32 incl = mine;
-      for(int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(incl, o, 64); if(lane >= u32(o)) { incl += up; } }
+      const u32 incl = wave_scan_dpp(mine);
       counts[half + lane] = tile_count + incl - mine;
-      tile_count += __shfl(incl, 63, 64);
+      tile_count += last_lane_value(incl);
     }
     // the look-back, 64 tiles at a time: lane l reads the status of tile (tile - 1 - l) of the window; the nearest tile that
     // knows its prefix ends the walk, the counts of the tiles in front of it are added up.  (One lane walking back tile by tile
@@ -2254,9 +2251,16 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_mark_compact(const u64* __r
         while(__ballot((seen >> 62) == 0) != 0);               // (every tile of the window holds a smaller ticket: running or done)
         const u64 knows = __ballot((seen >> 62) == 2);          // lanes whose tile knows its prefix (a lane in front of tile 0 counts as one, with 0)
         const u32 stop = (knows != 0 ? u32(__ffsll((long long)knows)) - 1 : 64u);
-        u64 part = (lane <= stop ? (seen & TILE_VALUE) : 0);
-        for(int o = 32; o > 0; o >>= 1) { part += __shfl_down(part, o, 64); }
-        before += __shfl(part, 0, 64);
+        // (the tiles in front of the nearest one that knows its prefix hold COUNTS, at most COMPACT_TILE each: their sum by DPP in 32
+        // bits; the prefix itself -- one lane's 64-bit value -- by v_readlane at a scalar lane index: no ds_bpermute in the look-back)
+        const u32 small = last_lane_value(wave_scan_dpp(lane < stop ? u32(seen & TILE_VALUE) : 0u));
+        u64 known = 0;
+        if(stop < 64)
+        {
+          const u64 value = seen & TILE_VALUE;
+          known = (u64(u32(__builtin_amdgcn_readlane(int(u32(value >> 32)), int(stop)))) << 32) | u64(u32(__builtin_amdgcn_readlane(int(u32(value)), int(stop))));
+        }
+        before += known + small;
         if(knows != 0) { break; }
         top -= 64;
       }
