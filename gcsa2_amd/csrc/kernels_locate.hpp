@@ -2150,7 +2150,10 @@ __global__ __launch_bounds__(TPB) void k_compact(const u64* __restrict__ sorted,
 // single-pass scans), and writes its first occurrences in place.  The 4.3 GB of the 16-mer batch on the 2^30-base text are read
 // once instead of twice.  status[tile]: bits 62-63 = 1 count of the tile / 2 count of everything up to and including it.
 // (a tile of 8192 values: with 2048 the look-back and the ticket of four times as many tiles cost more than the second read
-// they save -- 3.6 ms against 3.3 for the four kernels on the 16-mer batch; 4096: 2.45 ms; 8192: 2.19 ms)
+// they save -- 3.6 ms against 3.3 for the four kernels on the 16-mer batch; 4096: 2.45 ms; 8192: 2.19 ms.  Again at the end of
+// round 6, on the 16-mer batch of the 2^23 repeat graph, where two slots in three are dead: 8192 on 124 registers 1.38 ms, 4096
+// on 68 registers 1.87 ms; the look-back over 256 tiles per round trip instead of 64: 1.62 ms.  A tile costs its chain of round
+// trips -- ticket, bitmap words, values, look-back -- whatever it holds, and the kernel runs as many chains as fit a CU.)
 constexpr u32 COMPACT_THREADS = 256, COMPACT_ROWS = 32, COMPACT_TILE = COMPACT_THREADS * COMPACT_ROWS;
 constexpr u64 TILE_COUNT = u64(1) << 62, TILE_PREFIX = u64(2) << 62, TILE_VALUE = TILE_COUNT - 1;
 
