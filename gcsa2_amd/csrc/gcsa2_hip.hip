@@ -1598,7 +1598,7 @@ int locate_chunk(const gcsa2_index* ix, const u64* d_ranges, u64 nq, int sort, u
   // with the duplicate filter every segment beyond the medium class goes through it first (listed as huge), without it only
   // the ones the workgroup sort cannot hold
   const u32 big_limit = (ix->tune.dedup_huge && sort ? (medium_limit > SMALL_SEGMENT ? medium_limit : SMALL_SEGMENT) : BIG_SEGMENT);
-  hipLaunchKernelGGL(k_collect_multi, dim3(grid_for(nq)), dim3(TPB), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, huge_begin, huge_end, medium_limit, big_limit,
+  hipLaunchKernelGGL(k_collect_multi, dim3(unsigned((nq + COLLECT_THREADS - 1) / COLLECT_THREADS)), dim3(COLLECT_THREADS), 0, stream, node_off, raw_off, nq, d_totals, seg_begin, seg_end, huge_begin, huge_end, medium_limit, big_limit,
                      d_ranges, ix->img.locate_tab, over_begin, over_end, over_src);
   LAUNCH_CHECK("k_collect_multi");
   unsigned long long totals[TOTAL_WORDS];

@@ -435,9 +435,11 @@ __global__ __launch_bounds__(TPB) void k_locate_tab_rest(DevImage img, const u64
 // Output slots for a whole workgroup with ONE atomic: every wave passes the number of slots it wants and
 // gets the index of its first one.  (One atomic per wave and comp on a single counter was what bounded
 // these kernels: ~400 K same-address atomics per level.)  All threads of the workgroup must call it.
-struct WgSlots { u32 count[TPB / 64]; unsigned long long base; };
+template<int THREADS> struct WgSlotsOf { u32 count[THREADS / 64]; unsigned long long base; };
+typedef WgSlotsOf<TPB> WgSlots;
 
-__device__ __forceinline__ u64 wg_reserve(WgSlots& sh, unsigned long long* counter, u32 wave_count)
+template<int THREADS>
+__device__ __forceinline__ u64 wg_reserve(WgSlotsOf<THREADS>& sh, unsigned long long* counter, u32 wave_count)
 {
   const u32 wave = threadIdx.x >> 6;
   if((threadIdx.x & 63) == 0) { sh.count[wave] = wave_count; }
@@ -445,7 +447,7 @@ __device__ __forceinline__ u64 wg_reserve(WgSlots& sh, unsigned long long* count
   if(threadIdx.x == 0)
   {
     u32 total = 0;
-    for(u32 w = 0; w < TPB / 64; w++) { total += sh.count[w]; }
+    for(u32 w = 0; w < THREADS / 64; w++) { total += sh.count[w]; }
     sh.base = (total > 0 ? atomicAdd(counter, (unsigned long long)total) : 0ull);
   }
   __syncthreads();
@@ -476,15 +478,18 @@ enum { T_NODES = 0, T_RAW = 1, T_LARGE = 2, T_UNIQUE = 3, T_MULTI = 4, T_MEDIUM 
        T_MID_BUCKETS = 16,  // buckets of k_over_split with BUCKET_BY_WAVE + 1 .. MEDIUM_SEGMENT values (k_sort_bucket<MEDIUM_SEGMENT>)
        TOTAL_WORDS = 24 };
 
-__global__ __launch_bounds__(TPB) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
+// (Workgroups of 1024 lanes since late in round 6: the lists' counters share a cache line, and the L2 takes the atomics on one line
+// one after the other -- with 256 lanes per workgroup, 1563 workgroups x 4-6 reservations were the 139 us this kernel took for 400 k ranges.)
+constexpr int COLLECT_THREADS = 1024;
+__global__ __launch_bounds__(COLLECT_THREADS) void k_collect_multi(const u64* __restrict__ node_off, const u64* __restrict__ raw_off, u64 nq,
                                                        unsigned long long* __restrict__ totals,
                                                        u64* __restrict__ seg_begin, u64* __restrict__ seg_end,
                                                        u64* __restrict__ huge_begin, u64* __restrict__ huge_end, u32 medium_limit,
                                                        u32 big_limit, const u64* __restrict__ ranges, const u64* __restrict__ locate_tab,
                                                        u64* __restrict__ over_begin, u64* __restrict__ over_end, const u64** __restrict__ over_src)
 {
-  __shared__ WgSlots slots;
-  u64 q = u64(blockIdx.x) * TPB + threadIdx.x;
+  __shared__ WgSlotsOf<COLLECT_THREADS> slots;
+  u64 q = u64(blockIdx.x) * COLLECT_THREADS + threadIdx.x;
   const u32 lane = threadIdx.x & 63;
   if(q == 0) { totals[T_NODES] = node_off[nq]; totals[T_RAW] = raw_off[nq]; }
   u64 b = 0, e = 0;
