@@ -2024,6 +2024,8 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
 // (MOST = BUCKET_BY_WAVE: the list of the buckets up to 512 values, 57 VGPRs; MOST = MEDIUM_SEGMENT: the list of the ones from 513
 // to 1024 values -- sixteen registers of values per lane, 102 VGPRs -- which went to the workgroup sort for a while in round 6:
 // 0.6 ms against 0.2 on the 16-mer batch of the 2^30-base text)
+// (one wavefront = one workgroup per bucket, 2.7 M workgroups per call of the 16-mer batch of the 2^30-base text: four or eight
+// buckets per workgroup, a wavefront each, were measured at the end of round 6 -- 1.94 ms against 1.85 on one box; the dispatcher is not it)
 template<u32 MOST>
 __global__ __launch_bounds__(64) void k_sort_bucket(const u64* __restrict__ bkt_begin, const u64* __restrict__ bkt_end, u64* values,
                                                     const u64* __restrict__ source, unsigned long long* __restrict__ totals)
