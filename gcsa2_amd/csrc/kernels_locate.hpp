@@ -488,9 +488,15 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect_multi(const u64* __
                                                        u32 big_limit, const u64* __restrict__ ranges, const u64* __restrict__ locate_tab,
                                                        u64* __restrict__ over_begin, u64* __restrict__ over_end, const u64** __restrict__ over_src)
 {
-  __shared__ WgSlotsOf<COLLECT_THREADS> slots;
+  // the six lists' slots are reserved TOGETHER: every wavefront leaves its six counts in LDS, lanes 0..5 of the workgroup add up a
+  // list each and ask its counter once, all in one round trip (six reservations one behind the other, each with its barriers and
+  // its wait for the atomic, were most of this kernel)
+  constexpr u32 LISTS = 6, WAVES = COLLECT_THREADS / 64;
+  enum { L_MULTI = 0, L_LARGE = 1, L_MEDIUM = 2, L_HUGE_A = 3, L_HUGE_B = 4, L_OVER = 5 };
+  __shared__ u32 wave_count[LISTS][WAVES];
+  __shared__ unsigned long long list_base[LISTS], wave_values[WAVES];
   u64 q = u64(blockIdx.x) * COLLECT_THREADS + threadIdx.x;
-  const u32 lane = threadIdx.x & 63;
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if(q == 0) { totals[T_NODES] = node_off[nq]; totals[T_RAW] = raw_off[nq]; }
   u64 b = 0, e = 0;
   bool fused = false;
@@ -499,46 +505,48 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect_multi(const u64* __
     b = raw_off[q]; e = raw_off[q + 1];
     fused = (e > b && node_off[q + 1] == node_off[q]);        // values and no path node to walk: k_classify_fused took the nodes out
   }
-  const u64 multi = __ballot(e - b >= 2), large = __ballot(!fused && e - b > medium_limit && e - b <= big_limit);
-  const u64 medium = __ballot(!fused && e - b > SMALL_SEGMENT && e - b <= medium_limit);
   const bool is_huge = !fused && e - b > medium_limit && e - b > big_limit;
-  const u64 huge_a = __ballot(is_huge && e - b <= HUGE_SPLIT), huge_b = __ballot(is_huge && e - b > HUGE_SPLIT);
-  const u64 fused_mask = __ballot(fused);
-  wg_reserve(slots, totals + T_MULTI, u32(__popcll(multi)));           // (every wave of the workgroup: wg_reserve synchronises it)
-  u64 slot = wg_reserve(slots, totals + T_LARGE, u32(__popcll(large)));
-  if((large >> lane) & 1)
+  u64 mask[LISTS];
+  mask[L_MULTI] = __ballot(e - b >= 2);
+  mask[L_LARGE] = __ballot(!fused && e - b > medium_limit && e - b <= big_limit);
+  mask[L_MEDIUM] = __ballot(!fused && e - b > SMALL_SEGMENT && e - b <= medium_limit);
+  mask[L_HUGE_A] = __ballot(is_huge && e - b <= HUGE_SPLIT);
+  mask[L_HUGE_B] = __ballot(is_huge && e - b > HUGE_SPLIT);
+  mask[L_OVER] = __ballot(fused);
+  u64 fused_values = (fused ? e - b : 0);
+  for(int o = 32; o > 0; o >>= 1) { fused_values += __shfl_down(fused_values, o, 64); }
+  if(lane == 0)
   {
-    slot += __popcll(large & ((u64(1) << lane) - 1));
-    seg_begin[slot] = b; seg_end[slot] = e;
+#pragma unroll
+    for(u32 t = 0; t < LISTS; t++) { wave_count[t][wave] = u32(__popcll(mask[t])); }
+    wave_values[wave] = fused_values;
   }
-  slot = wg_reserve(slots, totals + T_MEDIUM, u32(__popcll(medium)));
-  if((medium >> lane) & 1)
+  __syncthreads();
+  if(threadIdx.x < LISTS)
   {
-    slot += __popcll(medium & ((u64(1) << lane) - 1));
-    seg_begin[nq - 1 - slot] = b; seg_end[nq - 1 - slot] = e;        // a query is in at most one of the two lists
+    constexpr u32 counter_of[LISTS] = { T_MULTI, T_LARGE, T_MEDIUM, T_HUGE_A, T_HUGE_B, T_OVER };
+    u32 total = 0;
+    for(u32 w = 0; w < WAVES; w++) { total += wave_count[threadIdx.x][w]; }
+    list_base[threadIdx.x] = (total > 0 ? atomicAdd(totals + counter_of[threadIdx.x], (unsigned long long)total) : 0ull);
   }
-  slot = wg_reserve(slots, totals + T_HUGE_A, u32(__popcll(huge_a)));
-  if((huge_a >> lane) & 1)
+  else if(threadIdx.x == 64)                                  // (another wavefront: the sum of the fused ranges' values)
   {
-    slot += __popcll(huge_a & ((u64(1) << lane) - 1));
-    huge_begin[slot] = b; huge_end[slot] = e;
+    unsigned long long values = 0;
+    for(u32 w = 0; w < WAVES; w++) { values += wave_values[w]; }
+    if(values != 0) { atomicAdd(totals + T_OVER_VALUES, values); }
   }
-  slot = wg_reserve(slots, totals + T_HUGE_B, u32(__popcll(huge_b)));
-  if((huge_b >> lane) & 1)
+  __syncthreads();
+  auto my_slot = [&](u32 t) -> u64
   {
-    slot += __popcll(huge_b & ((u64(1) << lane) - 1));
-    huge_begin[nq - 1 - slot] = b; huge_end[nq - 1 - slot] = e;
-  }
-  if(__syncthreads_or(fused_mask != 0) == 0) { return; }       // (uniform over the workgroup)
-  slot = wg_reserve(slots, totals + T_OVER, u32(__popcll(fused_mask)));
-  u64 mine = (fused ? e - b : 0);
-  if((fused_mask >> lane) & 1)
-  {
-    slot += __popcll(fused_mask & ((u64(1) << lane) - 1));
-    over_begin[slot] = b; over_end[slot] = e; over_src[slot] = locate_tab + ranges[2 * q];
-  }
-  for(int o = 32; o > 0; o >>= 1) { mine += __shfl_down(mine, o, 64); }
-  if(lane == 0 && mine != 0) { atomicAdd(totals + T_OVER_VALUES, (unsigned long long)mine); }
+    u64 slot = list_base[t];
+    for(u32 w = 0; w < wave; w++) { slot += wave_count[t][w]; }
+    return slot + u64(__popcll(mask[t] & ((u64(1) << lane) - 1)));
+  };
+  if((mask[L_LARGE] >> lane) & 1) { const u64 slot = my_slot(L_LARGE); seg_begin[slot] = b; seg_end[slot] = e; }
+  if((mask[L_MEDIUM] >> lane) & 1) { const u64 slot = my_slot(L_MEDIUM); seg_begin[nq - 1 - slot] = b; seg_end[nq - 1 - slot] = e; }      // a query is in at most one of the two lists
+  if((mask[L_HUGE_A] >> lane) & 1) { const u64 slot = my_slot(L_HUGE_A); huge_begin[slot] = b; huge_end[slot] = e; }
+  if((mask[L_HUGE_B] >> lane) & 1) { const u64 slot = my_slot(L_HUGE_B); huge_begin[nq - 1 - slot] = b; huge_end[nq - 1 - slot] = e; }
+  if((mask[L_OVER] >> lane) & 1) { const u64 slot = my_slot(L_OVER); over_begin[slot] = b; over_end[slot] = e; over_src[slot] = locate_tab + ranges[2 * q]; }
 }
 
 // The value of lane (l ^ STRIDE), for every lane l.  Strides below 16 stay inside a row of sixteen lanes and go through the
