@@ -839,6 +839,71 @@ __device__ __forceinline__ void wave_sort_blocked32(u32 (&v)[R], u32 lane)
   if constexpr(K >= 4) { blocked_steps32<R, K / 4>(v, lane); }
   if constexpr(K < 64 * R) { wave_sort_blocked32<R, 2 * K>(v, lane); }
 }
+// The same network for THREE and SIX values per lane (the end of round 6): 192 and 384 values.  On the 32-mer batch of the 2^30-base
+// text two buckets in three hold 257..384 values (profiles/r06_locate.md section 11) and were sorted in eight registers per lane
+// that they filled to 60 %.  Nothing in the merge needs a power of two: a lane's values are sorted by a sorting network (3 or 12
+// comparators), a stage compares element e with its mirror image in the block of twice the size -- lane ^ M, register R - 1 - r --,
+// then lane with lane ^ L for L = (M + 1) / 4 ... 1 (every half-cleaner works on an even number of elements), and what a lane holds
+// then is a bitonic sequence of R values: for six, compare r with r + 3 and sort the triples.  (tests/test_sort_network_model.py is
+// the model this was transcribed from: 2 .. 64 lanes, random inputs and 0-1 inputs.)
+__device__ __forceinline__ void compare_exchange32(u32& a, u32& c) { const u32 lo = (a < c ? a : c), hi = (a < c ? c : a); a = lo; c = hi; }
+template<u32 R>
+__device__ __forceinline__ void lane_sort_odd32(u32 (&v)[R])            // any order -> ascending
+{
+  static_assert(R == 3 || R == 6, "three or six values per lane");
+  if constexpr(R == 3) { compare_exchange32(v[0], v[1]); compare_exchange32(v[1], v[2]); compare_exchange32(v[0], v[1]); }
+  else
+  {
+    compare_exchange32(v[0], v[5]); compare_exchange32(v[1], v[3]); compare_exchange32(v[2], v[4]);
+    compare_exchange32(v[1], v[2]); compare_exchange32(v[3], v[4]);
+    compare_exchange32(v[0], v[3]); compare_exchange32(v[2], v[5]);
+    compare_exchange32(v[0], v[1]); compare_exchange32(v[2], v[3]); compare_exchange32(v[4], v[5]);
+    compare_exchange32(v[1], v[2]); compare_exchange32(v[3], v[4]);
+  }
+}
+template<u32 R>
+__device__ __forceinline__ void lane_bitonic_odd32(u32 (&v)[R])            // a bitonic sequence of R values -> ascending
+{
+  if constexpr(R == 3) { lane_sort_odd32<3>(v); }
+  else
+  {
+    compare_exchange32(v[0], v[3]); compare_exchange32(v[1], v[4]); compare_exchange32(v[2], v[5]);
+    compare_exchange32(v[0], v[1]); compare_exchange32(v[1], v[2]); compare_exchange32(v[0], v[1]);
+    compare_exchange32(v[3], v[4]); compare_exchange32(v[4], v[5]); compare_exchange32(v[3], v[4]);
+  }
+}
+template<u32 R, u32 L>
+__device__ __forceinline__ void lane_halves_odd32(u32 (&v)[R], u32 lane)   // lane with lane ^ L, then L / 2, ..., 1: the lane with the bit clear keeps the smaller value
+{
+  if constexpr(L >= 1)
+  {
+#pragma unroll
+    for(u32 r = 0; r < R; r++)
+    {
+      const u32 other = lane_xor32<L>(v[r], lane);
+      const u32 lo = (other < v[r] ? other : v[r]), hi = (other < v[r] ? v[r] : other);
+      v[r] = select_by_mask(hi, lo, lanes_with_bit_clear(L));
+    }
+    if constexpr(L > 1) { lane_halves_odd32<R, L / 2>(v, lane); }
+  }
+}
+template<u32 R, u32 M = 1>
+__device__ __forceinline__ void wave_sort_blocked32_odd(u32 (&v)[R], u32 lane)      // element R lane + r; M + 1 = lanes per block of this stage
+{
+  if constexpr(M == 1) { lane_sort_odd32<R>(v); }
+  u32 other[R];
+#pragma unroll
+  for(u32 r = 0; r < R; r++) { other[r] = lane_mirror32<M>(v[R - 1 - r], lane); }
+#pragma unroll
+  for(u32 r = 0; r < R; r++)
+  {
+    const u32 lo = (other[r] < v[r] ? other[r] : v[r]), hi = (other[r] < v[r] ? v[r] : other[r]);
+    v[r] = select_by_mask(hi, lo, lanes_with_bit_clear((M + 1) / 2));
+  }
+  if constexpr(M >= 3) { lane_halves_odd32<R, (M + 1) / 4>(v, lane); }
+  lane_bitonic_odd32<R>(v);
+  if constexpr(M < 63) { wave_sort_blocked32_odd<R, 2 * M + 1>(v, lane); }
+}
 // sorted registers in blocked layout (element R lane + r) -> the layout of the loads and stores (element 64 r + lane), through
 // `stage` (64 R words of LDS that belong to this wavefront)
 template<u32 R>
@@ -909,13 +974,25 @@ __device__ __forceinline__ u32 sort_segment_regs(const u64* src, u64* dst, u32 l
     u32 key[R];
 #pragma unroll
     for(u32 r = 0; r < R; r++) { key[r] = (r * 64 + lane < len ? u32(v[r]) : ~u32(0)); }           // (a key of all ones ties with the padding: the same value either way)
-    if(stage != nullptr) { wave_sort_blocked32<R>(key, lane); blocked_to_striped32<R>(key, stage, lane); }      // (uniform: the kernel has a transposition buffer)
+    if constexpr(R == 3 || R == 6) { wave_sort_blocked32_odd<R>(key, lane); blocked_to_striped32<R>(key, stage, lane); }      // (only called with a transposition buffer)
+    else if(stage != nullptr) { wave_sort_blocked32<R>(key, lane); blocked_to_striped32<R>(key, stage, lane); }      // (uniform: the kernel has a transposition buffer)
     else { wave_sort_regs32<R>(key, lane); }
 #pragma unroll
     for(u32 r = 0; r < R; r++) { if(r * 64 + lane < len) { dst[r * 64 + lane] = (u64(top) << 32) | key[r]; } }
     return dups_in_regs<R>(key, len, lane);
   }
-  wave_sort_regs<R>(v);
+  if constexpr(R == 3 || R == 6)
+  {
+    // (values on both sides of a multiple of 2^32: the 64-bit network wants a power of two -- padded; the padding sorts to the end)
+    constexpr u32 P = (R == 3 ? 4 : 8);
+    u64 w[P];
+#pragma unroll
+    for(u32 r = 0; r < P; r++) { w[r] = (r < R ? v[r] : ~u64(0)); }
+    wave_sort_regs<P>(w);
+#pragma unroll
+    for(u32 r = 0; r < R; r++) { v[r] = w[r]; }
+  }
+  else { wave_sort_regs<R>(v); }
 #pragma unroll
   for(u32 r = 0; r < R; r++) { if(r * 64 + lane < len) { dst[r * 64 + lane] = v[r]; } }
   return dups_in_regs<R>(v, len, lane);
@@ -926,7 +1003,9 @@ __device__ __forceinline__ u32 sort_segment_by_wave(const u64* src, u64* dst, u3
 {
   if(len <= 64) { return sort_segment_regs<1>(src, dst, len, lane, keep, stage); }
   else if(len <= 128) { return sort_segment_regs<2>(src, dst, len, lane, keep, stage); }
+  else if(len <= 192 && stage != nullptr) { return sort_segment_regs<3>(src, dst, len, lane, keep, stage); }
   else if(len <= 256 || MOST <= 256) { return sort_segment_regs<4>(src, dst, len, lane, keep, stage); }
+  else if(len <= 384 && stage != nullptr) { return sort_segment_regs<6>(src, dst, len, lane, keep, stage); }
   else if(len <= 512 || MOST <= 512) { return sort_segment_regs<8>(src, dst, len, lane, keep, stage); }
   else { return sort_segment_regs<16>(src, dst, len, lane, keep, stage); }
 }

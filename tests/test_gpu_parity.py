@@ -1533,7 +1533,7 @@ def test_locate_splits_large_batches(case, engine, monkeypatch):
 @pytest.mark.parametrize("dedup_huge", [1, 0, "wide"])
 def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
     """removeDuplicates at every segment size class: 1 value, 2..16 (registers, one lane), 17..1024 (one wavefront in
-    LDS), 1025..8192 (one workgroup in LDS), more (duplicates removed through an LDS hash set, then the LDS sorts; the
+    LDS; round 6: in registers, incl. the three- and six-register networks for up to 192 and 384 values), 1025..8192 (one workgroup in LDS), more (duplicates removed through an LDS hash set, then the LDS sorts; the
     device-wide radix sort over (segment, value) keys when more than 8192 values are distinct -- the whole-index range here --
     or, with GCSA2_DEDUP_HUGE=0, always), mixed in one batch and in both sort modes; ranges of consecutive path nodes of a repetitive SNP graph (many
     duplicates per segment).  A second batch has no segment beyond 8192 values: the library sort is then not called at all."""
@@ -1548,7 +1548,7 @@ def test_locate_segment_sizes(engine, monkeypatch, dedup_huge):
     cpu = OracleIndex(ix)
     rng = SplitMix64(0x4D3)
     ranges = []
-    for width in (1, 2, 3, 8, 15, 16, 17, 31, 33, 63, 64, 65, 127, 200, 511, 512, 513, 900, 1023, 1024, 1025, 1500, 2047, 2048, 2049, 3000,
+    for width in (1, 2, 3, 8, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 150, 191, 192, 193, 200, 257, 300, 383, 384, 385, 511, 512, 513, 900, 1023, 1024, 1025, 1500, 2047, 2048, 2049, 3000,
                   4096, 4097, 7000, 8191, 8192, 8193, 9000, 20000):
         for _ in range(6):
             a = rng.below(ix.n - width)
