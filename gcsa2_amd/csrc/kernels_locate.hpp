@@ -1841,13 +1841,22 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
     const u64 raw = (v > lo ? (v - lo) >> shift : 0);
     return u32(raw < nb ? raw : nb - 1);
   };
-  for(u64 i0 = tid; i0 < len; i0 += SPLIT_AHEAD * SPLIT_THREADS)
+  // (the histogram pass: the group of SPLIT_AHEAD values behind the one being counted is on its way -- clamped indices instead of
+  // branches around the loads and the current values pinned, as in the tile loop below: the compiler's waits stay exact)
   {
-    u64 got[SPLIT_AHEAD];
+    u64 ahead[SPLIT_AHEAD];
 #pragma unroll
-    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(j) * SPLIT_THREADS; got[j] = (i < len ? (src[i] & KEEP) : lo); }
+    for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = u64(tid) + u64(j) * SPLIT_THREADS; ahead[j] = src[i < len ? i : len - 1]; }
+    for(u64 i0 = tid; i0 < len; i0 += SPLIT_AHEAD * SPLIT_THREADS)
+    {
+      u64 got[SPLIT_AHEAD];
 #pragma unroll
-    for(u32 j = 0; j < SPLIT_AHEAD; j++) { if(i0 + u64(j) * SPLIT_THREADS < len) { atomicAdd(&cursor[bucket_of(got[j])], 1u); } }
+      for(u32 j = 0; j < SPLIT_AHEAD; j++) { got[j] = ahead[j] & KEEP; asm volatile("" : "+v"(got[j])); }
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_AHEAD; j++) { const u64 i = i0 + u64(SPLIT_AHEAD + j) * SPLIT_THREADS; ahead[j] = src[i < len ? i : len - 1]; }
+#pragma unroll
+      for(u32 j = 0; j < SPLIT_AHEAD; j++) { if(i0 + u64(j) * SPLIT_THREADS < len) { atomicAdd(&cursor[bucket_of(got[j])], 1u); } }
+    }
   }
   __syncthreads();
   // exclusive prefix sums of the counts: PER_THREAD consecutive buckets per thread, then across the wavefront and the workgroup
