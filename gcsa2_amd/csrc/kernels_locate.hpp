@@ -1790,7 +1790,6 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
   __shared__ __attribute__((aligned(16))) u32 tile_off[TILED ? SPLIT_TILED_BUCKETS : 4];           // their exclusive prefix sums
   __shared__ __attribute__((aligned(16))) u32 tile_delta[TILED ? SPLIT_TILED_BUCKETS : 4];         // where in the segment the bucket's values of this tile go, minus tile_off
   __shared__ u64 tile_value[TILED ? SPLIT_TILE : 1];                  // the tile, bucket by bucket
-  __shared__ unsigned short tile_bucket[TILED ? SPLIT_TILE : 1];
   constexpr u32 PER_THREAD = SPLIT_BUCKETS / SPLIT_THREADS;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 b = over_begin[blockIdx.x], len = over_end[blockIdx.x] - b;
@@ -1997,7 +1996,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
         if(t0 + u64(j) * SPLIT_THREADS + tid < len)
         {
           const u32 at = tile_off[where[j] & 0xFFFFu] + (where[j] >> 16);
-          tile_value[at] = got[j]; tile_bucket[at] = (unsigned short)(where[j] & 0xFFFFu);
+          tile_value[at] = got[j];
         }
       }
       __syncthreads();
@@ -2006,7 +2005,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(8
       for(u32 j = 0; j < SPLIT_TILE_PER; j++)
       {
         const u32 at = j * SPLIT_THREADS + tid;
-        if(at < here) { scratch[b + u32(tile_delta[tile_bucket[at]] + at)] = tile_value[at]; }
+        if(at < here) { const u64 v = tile_value[at]; scratch[b + u32(tile_delta[bucket_of(v)] + at)] = v; }      // (the bucket again from the value: three instructions instead of a 16-bit LDS array written and read)
       }
       __syncthreads();
       // the owners move the buckets' cursors on and clear this tile's counts (the next tile counts in the other array)
