@@ -771,6 +771,14 @@ __device__ __forceinline__ void wave_sort_regs32(u32 (&v)[R], u32 lane)
 // (DPP / permlane operand, min, max, a select on a compile-time lane mask).  Counted for 256 values, R = 4: 324 vector
 // instructions instead of 408; 512 values, R = 8: 720 instead of 984.  Input order is free (the values arrive unsorted), so
 // the loads stay coalesced; the sorted registers go through LDS once to return to e = 64 r + lane for the stores.
+// A compare-exchange across lanes in ONE instruction behind the exchange (the end of round 6): the lane with bit BIT of its number
+// clear keeps the smaller of its value and its partner's, the other lane the larger -- min(a, b) = med3(a, b, 0), max(a, b) =
+// med3(a, b, ~0), so both are v_med3_u32 with a third operand that depends on the lane alone (six such masks in a wavefront, each
+// computed once).  v_min + v_max + v_cndmask until then: the register sorts are bound by their vector instructions (97 % VALU busy
+// in `tools/pmc_split.sh`'s passes), and two in three of them were these.
+__device__ __forceinline__ u32 med3_u32(u32 a, u32 b, u32 c) { u32 r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+template<u32 BIT>
+__device__ __forceinline__ u32 keeps_larger32(u32 lane) { return 0u - ((lane / BIT) & 1u); }      // all ones in the lanes with the bit set
 template<u32 M>
 __device__ __forceinline__ u32 lane_mirror32(u32 v, u32 lane)      // the value of lane (l ^ M), M = 2^t - 1
 {
@@ -792,8 +800,7 @@ __device__ __forceinline__ void blocked_steps32(u32 (&v)[R], u32 lane)      // c
     for(u32 r = 0; r < R; r++)
     {
       const u32 other = lane_xor32<L>(v[r], lane);
-      const u32 lo = (other < v[r] ? other : v[r]), hi = (other < v[r] ? v[r] : other);
-      v[r] = select_by_mask(hi, lo, lanes_with_bit_clear(L));
+      v[r] = med3_u32(v[r], other, keeps_larger32<L>(lane));
     }
   }
   else
@@ -830,11 +837,7 @@ __device__ __forceinline__ void wave_sort_blocked32(u32 (&v)[R], u32 lane)
 #pragma unroll
     for(u32 r = 0; r < R; r++) { other[r] = lane_mirror32<M>(v[R - 1 - r], lane); }
 #pragma unroll
-    for(u32 r = 0; r < R; r++)
-    {
-      const u32 lo = (other[r] < v[r] ? other[r] : v[r]), hi = (other[r] < v[r] ? v[r] : other[r]);
-      v[r] = select_by_mask(hi, lo, lanes_with_bit_clear((M + 1) / 2));
-    }
+    for(u32 r = 0; r < R; r++) { v[r] = med3_u32(v[r], other[r], keeps_larger32<(M + 1) / 2>(lane)); }
   }
   if constexpr(K >= 4) { blocked_steps32<R, K / 4>(v, lane); }
   if constexpr(K < 64 * R) { wave_sort_blocked32<R, 2 * K>(v, lane); }
@@ -881,8 +884,7 @@ __device__ __forceinline__ void lane_halves_odd32(u32 (&v)[R], u32 lane)   // la
     for(u32 r = 0; r < R; r++)
     {
       const u32 other = lane_xor32<L>(v[r], lane);
-      const u32 lo = (other < v[r] ? other : v[r]), hi = (other < v[r] ? v[r] : other);
-      v[r] = select_by_mask(hi, lo, lanes_with_bit_clear(L));
+      v[r] = med3_u32(v[r], other, keeps_larger32<L>(lane));
     }
     if constexpr(L > 1) { lane_halves_odd32<R, L / 2>(v, lane); }
   }
@@ -895,11 +897,7 @@ __device__ __forceinline__ void wave_sort_blocked32_odd(u32 (&v)[R], u32 lane)  
 #pragma unroll
   for(u32 r = 0; r < R; r++) { other[r] = lane_mirror32<M>(v[R - 1 - r], lane); }
 #pragma unroll
-  for(u32 r = 0; r < R; r++)
-  {
-    const u32 lo = (other[r] < v[r] ? other[r] : v[r]), hi = (other[r] < v[r] ? v[r] : other[r]);
-    v[r] = select_by_mask(hi, lo, lanes_with_bit_clear((M + 1) / 2));
-  }
+  for(u32 r = 0; r < R; r++) { v[r] = med3_u32(v[r], other[r], keeps_larger32<(M + 1) / 2>(lane)); }
   if constexpr(M >= 3) { lane_halves_odd32<R, (M + 1) / 4>(v, lane); }
   lane_bitonic_odd32<R>(v);
   if constexpr(M < 63) { wave_sort_blocked32_odd<R, 2 * M + 1>(v, lane); }
